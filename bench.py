@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X backend (BASELINE.json metric).
+
+Workload (config.workload): BASELINE.json configs[1] — dgRMatrix 1M x 100k, 32 nnz/row (nnz = 32M),
+f64, %*% dense 100k x 128 — one "step" = one SpMM over the whole matrix, inputs resident in HBM.
+N GPUs (launched by torch.distributed.run, one rank per GPU): every rank owns a row block of that size
+(weak scaling: global A has N x 1M rows, B replicated), computes its block of C and all-gathers the
+blocks over RCCL/xGMI so every rank holds the full C (north_star's exchange step).  value = total
+GFLOP/s over all ranks, 2*nnz*n flops per rank-step, max-over-ranks time, all-gather included.
+
+Prints ONE JSON line on rank 0; see DESIGN.md §Measurement for how roofline / cpu_baseline are defined.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--cols", type=int, default=100_000)
+    ap.add_argument("--nnz-row", type=int, default=32)
+    ap.add_argument("--n", type=int, default=128, help="dense columns")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--layout", default="colmajor", choices=["colmajor", "rowmajor"],
+                    help="C layout at N=1 (colmajor = what tcrossprod_csr_dense returns to R)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--extras", action="store_true", help="also time SpMV / gather / merge (configs 3, 4 scaled)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, p, j, x, B_host):
+    """Reference algorithm restated (oracle/mx_oracle.c), timed on this box's host cores; bounded sample."""
+    from oracle import oracle as O
+    threads = O.max_threads()
+    m, n = p.size - 1, B_host.shape[1]
+    # bounded sample: the first `rows_s` rows of the same matrix, sized from a probe so the leg stays ~cpu-seconds
+    probe_rows = min(m, 20_000)
+    dt = np.float64 if args.dtype == "f64" else np.float32
+    Bflat = np.ascontiguousarray(B_host, dtype=dt).reshape(-1)
+
+    def run(rows):
+        pp = p[: rows + 1]
+        C_out = np.zeros(rows * n, dtype=dt)
+        t0 = time.perf_counter()
+        O.gemm_csr_drm_as_dcm(rows, n, pp, j, x, Bflat, n, C_out, rows, threads, False)
+        return time.perf_counter() - t0
+    run(probe_rows)
+    t_probe = run(probe_rows)
+    rate = probe_rows / max(t_probe, 1e-9)
+    rows_s = int(min(m, max(probe_rows, rate * args.cpu_seconds / 3)))
+    best = min(run(rows_s) for _ in range(3))
+    nnz_s = int(p[rows_s] - p[0])
+    return {"value": round(2.0 * nnz_s * n / best / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"first {rows_s} of {m} rows of the same CSR x the same dense {B_host.shape[0]}x{n} "
+                      f"({args.dtype}), gemm_csr_drm_as_dcm restated with OpenMP schedule(dynamic), best of 3"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from matrixextra_amd import _lib, device as D, synth
+    _lib.load()                      # fails loudly if libmxgpu.so is missing
+
+    m, K, n = args.rows, args.cols, args.n
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    ndt = np.float64 if args.dtype == "f64" else np.float32
+    s_dense = 8 if args.dtype == "f64" else 4
+
+    # synthetic inputs: seeds A=1 (+rank for the other row blocks), B=2
+    p, j, x = synth.csr_fixed(m, K, args.nnz_row, seed=synth.SEED_A + 1000 * rank)
+    B_host = synth.dense_normal(K, n, dtype=ndt)
+    A = D.DeviceCSR.from_host(p, j, x, K)
+    B = torch.from_numpy(B_host).cuda()
+    nnz = A.nnz
+    colmajor = (args.layout == "colmajor") and world == 1
+    if world > 1:
+        C_full = torch.empty((world * m, n), dtype=tdt, device="cuda")     # gathered row-major blocks
+        C_loc = C_full[rank * m:(rank + 1) * m]                              # compute straight into my slot
+    else:
+        C_full = None
+        C_loc = torch.empty((n, m) if colmajor else (m, n), dtype=tdt, device="cuda")
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(k=None):
+        if k is not None:
+            ev[k][0].record()
+        D.spmm(A, B, out=C_loc, colmajor=colmajor)
+        if k is not None:
+            ev[k][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(C_full, C_loc)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = np.array([a.elapsed_time(b) for a, b in ev])          # HIP events on the launch stream
+    kern_avg_s = float(kern_ms.mean()) / 1e3
+    flops_rank_step = 2.0 * nnz * n
+    alg_bytes = synth.spmm_algorithmic_bytes(m, K, n, nnz, s_dense)
+    achieved = alg_bytes / kern_avg_s / 1e9
+
+    # parity spot check of the timed output against the CPU restatement (checker only; not timed)
+    parity = None
+    if rank == 0:
+        from oracle import oracle as O
+        rows_chk = 2048
+        ref = np.zeros(rows_chk * n, dtype=ndt)
+        O.gemm_csr_drm_as_drm(rows_chk, n, p[: rows_chk + 1], j, x, B_host.reshape(-1), n, ref, n, O.max_threads(), True)
+        got = (C_loc[:, :rows_chk].t() if colmajor else C_loc[:rows_chk]).cpu().numpy()
+        parity = float(np.max(np.abs(got - ref.reshape(rows_chk, n)) / (np.abs(ref.reshape(rows_chk, n)) + 1e-30)))
+        if world > 1:
+            blk = C_full[(world - 1) * m:(world - 1) * m + 4].cpu().numpy()
+            assert np.isfinite(blk).all()
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "CSR x dense SpMM GFLOP/s (fp64, 1M x 100k, 32 nnz/row, k=128) + achieved HBM BW% vs CPU ref",
+            "value": round(world * flops_rank_step * args.steps / elapsed / 1e9, 2),
+            "unit": "GFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"dgRMatrix {m}x{K} nnz/row={args.nnz_row} {args.dtype} %*% dense {K}x{n} "
+                                   f"(BASELINE configs[1]); C {'col' if colmajor else 'row'}-major"
+                                   + (f"; row-block per GPU + RCCL all-gather of C ({world}x{m} rows)" if world > 1 else ""),
+                       "rows_per_gpu": m, "cols": K, "nnz_per_row": args.nnz_row, "dense_cols": n,
+                       "parallelism": f"rowshard{world}" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "spmm_rowwave_kernel", "kernel_avg_ms": round(kern_avg_s * 1e3, 4),
+                         "kernel_min_ms": round(float(kern_ms.min()), 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "kernel_gflops": round(flops_rank_step / kern_avg_s / 1e9, 1),
+            "parity_max_rel_err_vs_oracle": parity,
+            "device": _lib.device_name(),
+        }
+        if world > 1:
+            gather_s = max(elapsed / args.steps - kern_avg_s, 1e-9)
+            out["allgather"] = {"bytes_received_per_gpu": int((world - 1) * m * n * s_dense),
+                                "approx_ms": round(gather_s * 1e3, 3),
+                                "approx_GBps_in_per_gpu": round((world - 1) * m * n * s_dense / gather_s / 1e9, 1)}
+        if args.extras:
+            out["extras"] = extras(args, A, B, torch, D, synth, p, j, x)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, p, j, x, B_host)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def extras(args, A, B, torch, D, synth, p, j, x):
+    """configs[2]: SpMV + 200k-row gather on the same CSR; configs[3] scaled to fit beside it: CSR+CSR / CSR*CSR."""
+    from matrixextra_amd import _lib
+
+    def timeit(fn, reps=10):
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps / 1e3
+    res = {}
+    m, K, nnz = A.m, A.K, A.nnz
+    v = torch.from_numpy(synth.dense_normal(K, 1).reshape(-1)).cuda()
+    t = timeit(lambda: D.spmv(A, v))
+    byts = 4 * (m + 1) + 12 * nnz + 8 * K + 8 * m
+    res["spmv"] = {"ms": round(t * 1e3, 4), "GFLOP/s": round(2 * nnz / t / 1e9, 1), "GB/s": round(byts / t / 1e9, 1)}
+    rows = torch.from_numpy(synth.rows_with_replacement(200_000, m)).cuda()
+    g = D.csr_gather_rows(A, rows)
+    t = timeit(lambda: D.csr_gather_rows(A, rows))
+    byts = 4 * 200_000 * 4 + 2 * 12 * g.nnz
+    res["gather_200k_rows"] = {"ms": round(t * 1e3, 4), "nnz_out": g.nnz, "GB/s": round(byts / t / 1e9, 1)}
+    p2, j2, x2 = synth.csr_overlapping(p, j, K, args.nnz_row)
+    A2 = D.DeviceCSR.from_host(p2, j2, x2, K)
+    for name, op in (("add", _lib.MX_OP_ADD), ("mul", _lib.MX_OP_MUL)):
+        o = D.csr_elemwise(op, A, A2)
+        t = timeit(lambda: D.csr_elemwise(op, A, A2), reps=5)
+        byts = 12 * (A.nnz + A2.nnz) + 8 * (m + 1) + 12 * o.nnz + 4 * (m + 1)
+        res[f"csr_{name}_csr"] = {"ms": round(t * 1e3, 4), "nnz_out": o.nnz, "GB/s": round(byts / t / 1e9, 1),
+                                  "Mnnz_in/s": round((A.nnz + A2.nnz) / t / 1e6, 1)}
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,258 @@
+/* mxgpu.h — C-ABI of libmxgpu.so, the MI355X (gfx950) backend for MatrixExtra's
+ * CSR hot path.
+ *
+ * Two layers, both plain C (pointers + sizes, no torch / Rcpp / R types):
+ *
+ *  (1) mx_*   "export level": one entry point per Rcpp-exported routine of the
+ *             reference's hot path (src/RcppExports.cpp CallEntries[] :2233-2242,
+ *             :2290-2291, :2297-2298, :2333-2334, :2341-2343).  Arguments are
+ *             HOST pointers with exactly the meaning of the reference's
+ *             IntegerVector / NumericVector / NumericMatrix views; outputs are
+ *             caller-allocated (fixed-size results) or obtained through a
+ *             begin/finish pair (variable-size results, so that the caller —
+ *             the R .Call shim — can allocate R vectors of the right length
+ *             and have the D2H copy land directly in them).  Synchronous at
+ *             return, as the reference is (SURVEY §8b "Threading").
+ *
+ *  (2) mxd_*  "device level": the same operations on DEVICE pointers, enqueued
+ *             on a caller-supplied hipStream_t (passed as void*), no
+ *             allocation, no synchronisation (graph-capture safe) except where
+ *             a size must come back to the host.  This is what bench.py, the
+ *             multi-GPU path and layer (1) drive.
+ *
+ * Every function returns 0 on success, non-zero on failure; the message for the
+ * calling thread is read with mx_last_error() (the .Call shim turns it into
+ * Rf_error, mirroring BEGIN_RCPP/END_RCPP at src/RcppExports.cpp:16,24).
+ *
+ * Index type is int32 (R INTSXP) throughout, as in the reference.
+ * R's NA_INTEGER / NA_LOGICAL = INT_MIN; NA_REAL = NaN with low word 1954.
+ */
+#ifndef MXGPU_H
+#define MXGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MXGPU_ABI_VERSION 1
+
+/* ---- status / device management ------------------------------------------ */
+const char *mx_last_error(void);
+int  mx_abi_version(void);
+int  mx_device_count(int *count);
+int  mx_set_device(int device);
+int  mx_device_name(char *buf, size_t buflen);
+/* raw device memory for callers that do not bring their own allocator */
+int  mx_dev_malloc(void **dptr, size_t bytes);
+int  mx_dev_free(void *dptr);
+int  mx_dev_memset(void *dptr, int value, size_t bytes, void *stream);
+int  mx_memcpy_h2d(void *dptr, const void *hptr, size_t bytes, void *stream);
+int  mx_memcpy_d2h(void *hptr, const void *dptr, size_t bytes, void *stream);
+int  mx_stream_sync(void *stream);
+int  mx_host_register(void *hptr, size_t bytes);   /* pin caller memory for async H2D/D2H */
+int  mx_host_unregister(void *hptr);
+
+/* ---- element types --------------------------------------------------------- */
+typedef enum {
+    MX_F64 = 0,      /* double (R numeric)                                   */
+    MX_F32 = 1,      /* float  (float32@Data INTSXP reinterpreted)           */
+    MX_I32 = 2,      /* R integer, NA_INTEGER = INT_MIN                      */
+    MX_LGL = 3,      /* R logical, {0,1,NA_LOGICAL}                          */
+    MX_NONE = 4      /* no values (ngRMatrix)                                */
+} mx_dtype;
+
+typedef enum {
+    MX_OP_ADD = 0,   /* add_csr_elemwise(substract=false)   operators.cpp:539 */
+    MX_OP_SUB = 1,   /* add_csr_elemwise(substract=true)                      */
+    MX_OP_MUL = 2,   /* multiply_csr_elemwise               operators.cpp:209 */
+    MX_OP_OR  = 3,   /* logicalor_csr_elemwise(xor=false)   operators.cpp:556 */
+    MX_OP_XOR = 4,   /* logicalor_csr_elemwise(xor=true)                      */
+    MX_OP_AND = 5    /* logicaland_csr_elemwise             operators.cpp:224 */
+} mx_merge_op;
+
+/* ========================================================================== */
+/* (2) device level                                                           */
+/* ========================================================================== */
+
+/* SpMM  C = A * B,  A CSR m x K (int32 indptr[m+1], indices[nnz], f64 values),
+ * B row-major K x n with leading dimension ldb (elements), C m x n.
+ *   colmajor_out = 0 : C row-major, leading dim ldc  (gemm_csr_drm_as_drm,
+ *                      src/matmul.cpp:118-142; exports start from zeroed C so
+ *                      "C += A*B" == "C = A*B")
+ *   colmajor_out = 1 : C column-major, leading dim ldc (gemm_csr_drm_as_dcm,
+ *                      src/matmul.cpp:150-185)
+ * dense_dtype MX_F64 or MX_F32; CSR values are f64 in both (narrowed per
+ * nonzero for MX_F32 as at src/matmul.cpp:53-57).  Column indices need not be
+ * sorted; duplicates accumulate.  Rows with no entries give zeros. */
+int mxd_spmm_csr_dense(int m, int n,
+                       const int32_t *indptr, const int32_t *indices, const double *values,
+                       const void *B, size_t ldb,
+                       void *C, size_t ldc,
+                       int dense_dtype, int colmajor_out, void *stream);
+
+/* SpMV  y = A * v  (matmul_csr_dvec<>, src/matmul.cpp:381-419).
+ * v_dtype MX_F64 / MX_I32 / MX_LGL -> y f64[m];  MX_F32 -> y f32[m]
+ * (float accumulate).  NA_INTEGER / NA_LOGICAL entries contribute NA_REAL. */
+int mxd_spmv_csr_dvec(int m, int64_t nnz /* lanes-per-row hint, -1 = unknown */,
+                      const int32_t *indptr, const int32_t *indices, const double *values,
+                      const void *v, int v_dtype, void *y, void *stream);
+
+/* CSR (+) CSR, pass 1: per-row output lengths (union for ADD/SUB/OR/XOR,
+ * intersection for MUL/AND) then exclusive scan into out_indptr[m+1].
+ * Rows must be sorted ascending with unique column ids (precondition the R
+ * callers establish, R/operators.R:58,64,748,754).  workspace: mxd_merge_workspace_bytes(m).
+ * *nnz_out_host (pinned or pageable host int64) is written after an internal
+ * stream sync — the one host round trip of the operation.  nnz1 / nnz2 only
+ * steer the lanes-per-row choice (pass -1 when unknown). */
+size_t mxd_merge_workspace_bytes(int m);
+int mxd_csr_merge_count(int op, int m,
+                        const int32_t *indptr1, const int32_t *indices1, int64_t nnz1,
+                        const int32_t *indptr2, const int32_t *indices2, int64_t nnz2,
+                        int32_t *out_indptr, void *workspace,
+                        int64_t *nnz_out_host, void *stream);
+/* pass 2: fill out_indices / out_values (f64 for ADD/SUB/MUL, int32 R logical
+ * for OR/XOR/AND) at the offsets in out_indptr. */
+int mxd_csr_merge_fill(int op, int m,
+                       const int32_t *indptr1, const int32_t *indices1, const void *values1, int64_t nnz1,
+                       const int32_t *indptr2, const int32_t *indices2, const void *values2, int64_t nnz2,
+                       const int32_t *out_indptr, int32_t *out_indices, void *out_values,
+                       void *stream);
+/* identical-pattern fast path (operators.cpp:104-132, :343-395): values only */
+int mxd_values_elemwise(int op, int64_t nnz, const void *values1, const void *values2,
+                        void *out_values, void *stream);
+
+/* Row gather  out = A[rows_take, :]  (copy_csr_rows_template, src/slice.cpp:225-274)
+ * pass 1: new_indptr[r+1] + total;  pass 2: copy.  value_dtype MX_F64 / MX_LGL / MX_NONE. */
+size_t mxd_gather_workspace_bytes(int r);
+int mxd_csr_gather_count(int r, const int32_t *indptr, const int32_t *rows_take,
+                         int32_t *new_indptr, void *workspace,
+                         int64_t *nnz_out_host, void *stream);
+int mxd_csr_gather_fill(int r, const int32_t *indptr, const int32_t *indices, const void *values,
+                        const int32_t *rows_take, const int32_t *new_indptr,
+                        int32_t *new_indices, void *new_values, int value_dtype,
+                        int64_t nnz_out /* lanes-per-row hint, -1 = unknown */, void *stream);
+
+/* check_is_seq / check_is_rev_seq (src/slice.cpp:25-47) on a device vector.
+ * *flag_host receives 0/1 after an internal stream sync. */
+int mxd_check_is_seq(const int32_t *idx, int64_t n, int reversed, int32_t *workspace4,
+                     int *flag_host, void *stream);
+
+/* exclusive scan of int32 counts[n] -> out[n+1] (out[n] = total); total also
+ * returned as int64 in *total_dev (device int64).  workspace: mxd_scan_workspace_bytes(n). */
+size_t mxd_scan_workspace_bytes(int64_t n);
+int mxd_exclusive_scan_i32(const int32_t *counts, int64_t n, int32_t *out,
+                           int64_t *total_dev, void *workspace, void *stream);
+
+/* Next-row components: per-row sortedness check and
+ * per-row index sort (check_is_sorted / sort_sparse_indices_known_ncol,
+ * src/misc.cpp:118-128, :261-298). */
+int mxd_csr_rows_sorted(int m, const int32_t *indptr, const int32_t *indices,
+                        int32_t *workspace4, int *flag_host, void *stream);
+/* sorts every row by column id (stable), in place; tmp_indices / tmp_values are
+ * caller scratch of nnz entries each (tmp_values unused for MX_NONE). */
+int mxd_csr_sort_rows(int m, int64_t nnz, const int32_t *indptr, int32_t *indices, void *values,
+                      int value_dtype, int32_t *tmp_indices, void *tmp_values, void *stream);
+
+/* ========================================================================== */
+/* (1) export level — host pointers, names follow the Rcpp exports            */
+/* ========================================================================== */
+
+/* tcrossprod_csr_dense_numeric  src/matmul.cpp:345-359  (RcppExports.cpp:547)
+ * X CSR with nrows_X rows; Y_colmajor is nrow_Y x ncol_Y column-major (so it
+ * is ncol_Y x nrow_Y row-major == B of the SpMM); out is nrows_X x nrow_Y
+ * column-major, fully written.  nthreads is accepted and ignored. */
+int mx_tcrossprod_csr_dense_numeric(const int32_t *X_indptr, const int32_t *X_indices,
+                                    const double *X_values, int nrows_X,
+                                    const double *Y_colmajor, int nrow_Y, int ncol_Y,
+                                    int nthreads, double *out_colmajor);
+/* tcrossprod_csr_dense_float32  src/matmul.cpp:361-375  (RcppExports.cpp:561) */
+int mx_tcrossprod_csr_dense_float32(const int32_t *X_indptr, const int32_t *X_indices,
+                                    const double *X_values, int nrows_X,
+                                    const float *Y_colmajor, int nrow_Y, int ncol_Y,
+                                    int nthreads, float *out_colmajor);
+/* matmul_dense_csc_numeric  src/matmul.cpp:221-235  (RcppExports.cpp:489)
+ * X_colmajor nrows_X x ncols_X; Y CSC with ncols_Y columns; out nrows_X x ncols_Y col-major. */
+int mx_matmul_dense_csc_numeric(const double *X_colmajor, int nrows_X, int ncols_X,
+                                const int32_t *Y_indptr, const int32_t *Y_indices,
+                                const double *Y_values, int ncols_Y,
+                                int nthreads, double *out_colmajor);
+int mx_matmul_dense_csc_float32(const float *X_colmajor, int nrows_X, int ncols_X,
+                                const int32_t *Y_indptr, const int32_t *Y_indices,
+                                const double *Y_values, int ncols_Y,
+                                int nthreads, float *out_colmajor);
+/* tcrossprod_dense_csr_numeric  src/matmul.cpp:283-297  (RcppExports.cpp:517)
+ * out is nrows_X x nrows_Y col-major; ncols_Y is unused by the reference too. */
+int mx_tcrossprod_dense_csr_numeric(const double *X_colmajor, int nrows_X, int ncols_X,
+                                    const int32_t *Y_indptr, const int32_t *Y_indices,
+                                    const double *Y_values, int nrows_Y,
+                                    int nthreads, int ncols_Y, double *out_colmajor);
+int mx_tcrossprod_dense_csr_float32(const float *X_colmajor, int nrows_X, int ncols_X,
+                                    const int32_t *Y_indptr, const int32_t *Y_indices,
+                                    const double *Y_values, int nrows_Y,
+                                    int nthreads, int ncols_Y, float *out_colmajor);
+
+/* matmul_csr_dvec_{numeric,integer,logical,float32}  src/matmul.cpp:421-483
+ * (RcppExports.cpp:575,589,603,617).  len_y = ncol(X). */
+int mx_matmul_csr_dvec_numeric(const int32_t *X_indptr, const int32_t *X_indices,
+                               const double *X_values, int nrows_X,
+                               const double *y_dense, int len_y, int nthreads, double *out);
+int mx_matmul_csr_dvec_integer(const int32_t *X_indptr, const int32_t *X_indices,
+                               const double *X_values, int nrows_X,
+                               const int32_t *y_dense, int len_y, int nthreads, double *out);
+int mx_matmul_csr_dvec_logical(const int32_t *X_indptr, const int32_t *X_indices,
+                               const double *X_values, int nrows_X,
+                               const int32_t *y_dense, int len_y, int nthreads, double *out);
+int mx_matmul_csr_dvec_float32(const int32_t *X_indptr, const int32_t *X_indices,
+                               const double *X_values, int nrows_X,
+                               const float *y_dense, int len_y, int nthreads, float *out);
+
+/* Variable-size results: begin computes on the device and reports the sizes,
+ * finish copies into caller-allocated vectors and releases the handle
+ * (mx_result_discard releases without copying). */
+typedef struct mx_result mx_result;
+typedef struct {
+    int64_t indptr_len;    /* length of the indptr vector to allocate           */
+    int64_t nnz;           /* length of indices (and of values if it has any)   */
+    int     values_dtype;  /* MX_F64 / MX_LGL / MX_NONE                         */
+    int     alias_structure; /* 1: reference returns the INPUT indptr1/indices1
+                                objects themselves (operators.cpp:127-131,:390-394);
+                                finish then fills only values                   */
+} mx_result_info;
+
+/* add_csr_elemwise / logicalor_csr_elemwise / multiply_csr_elemwise /
+ * logicaland_csr_elemwise  (RcppExports.cpp:1287,1303,1192,1207).
+ * op selects the export and its flag (substract / xor_op). nrows = len(indptr)-1. */
+int mx_csr_elemwise_begin(int op, int nrows,
+                          const int32_t *indptr1, const int32_t *indptr2,
+                          const int32_t *indices1, const int32_t *indices2,
+                          const void *values1, const void *values2,
+                          int64_t nnz1, int64_t nnz2,
+                          mx_result **res, mx_result_info *info);
+/* copy_csr_rows_{numeric,logical,binary}  src/slice.cpp:276-324 (RcppExports.cpp:1886,1899,1912)
+ * value_dtype MX_F64 / MX_LGL / MX_NONE; n_values = length of the values vector
+ * (0 => no values copied, slice.cpp:246,257). */
+int mx_copy_csr_rows_begin(const int32_t *indptr, int nrows,
+                           const int32_t *indices, const void *values, int value_dtype,
+                           int64_t n_values,
+                           const int32_t *rows_take, int64_t n_take,
+                           mx_result **res, mx_result_info *info);
+int mx_result_finish(mx_result *res, int32_t *out_indptr, int32_t *out_indices, void *out_values);
+int mx_result_discard(mx_result *res);
+
+/* check_is_seq / check_is_rev_seq  src/slice.cpp:25-47 (RcppExports.cpp:1795,1805) */
+int mx_check_is_seq(const int32_t *indices, int64_t n, int *result);
+int mx_check_is_rev_seq(const int32_t *indices, int64_t n, int *result);
+
+/* §8(f)-1: sort_sparse_indices (R/utils.R:22-161 -> src/misc.cpp:261-298,333-347) and
+ * check_is_sorted (src/misc.cpp:118-128) for a CSR held in host memory; sorts in place. */
+int mx_check_indices_are_sorted(const int32_t *indptr, const int32_t *indices, int nrows, int *result);
+int mx_sort_sparse_indices(const int32_t *indptr, int32_t *indices, void *values,
+                           int value_dtype, int nrows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MXGPU_H */

@@ -1,0 +1,435 @@
+// api.hip — export-level C-ABI (host pointers) of libmxgpu: one entry point per
+// Rcpp export of the reference's hot path, marshalling host vectors to the
+// device, running the HIP kernels and bringing the result back.  There is no
+// CPU fallback: without a usable GPU every call fails with an error.
+#include "mx_common.h"
+
+#include <cstring>
+#include <new>
+
+namespace mx {
+
+static thread_local char g_err[512] = "";
+
+int set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+int spmv_launch(int m, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
+                const void *v, int v_dtype, void *y, hipStream_t st);
+
+// owning device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n)
+    {
+        bytes = n;
+        if (n == 0) n = 16;                  // keep pointers non-null and 16-B aligned
+        MX_HIP(hipMalloc(&p, n));
+        return 0;
+    }
+    int upload(const void *h, size_t n)
+    {
+        if (alloc(n)) return 1;
+        if (n) MX_HIP(hipMemcpy(p, h, n, hipMemcpyHostToDevice));
+        return 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+static inline size_t dtype_bytes(int dt)
+{
+    switch (dt) { case MX_F64: return 8; case MX_F32: case MX_I32: case MX_LGL: return 4; default: return 0; }
+}
+
+struct Csr {
+    DevBuf p, j, x;
+    int64_t nnz = 0;
+    // uploads indptr[0..m], indices/values[0..indptr[m]); value_bytes 0 => no values
+    int upload(const int32_t *indptr, const int32_t *indices, const void *values, int m, size_t value_bytes)
+    {
+        MX_REQUIRE(m >= 0 && indptr, "CSR upload: bad arguments");
+        nnz = indptr[m];
+        MX_REQUIRE(nnz >= 0 && indptr[0] >= 0, "CSR upload: negative index pointer");
+        if (p.upload(indptr, sizeof(int32_t) * ((size_t)m + 1))) return 1;
+        if (j.upload(indices, sizeof(int32_t) * (size_t)nnz)) return 1;
+        if (value_bytes && x.upload(values, value_bytes * (size_t)nnz)) return 1;
+        return 0;
+    }
+};
+
+// C(m x n) = A(CSR, m rows) * B(row-major rows of length ldb); host in, host out
+template <typename real_t>
+static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int32_t *indices, const double *values,
+                     const real_t *B_host, size_t ldb, real_t *C_host, size_t ldc, size_t c_elems, bool colmajor)
+{
+    MX_REQUIRE(m >= 0 && n >= 0 && K_rows >= 0, "negative dimension");
+    if (c_elems == 0) return 0;
+    // reference early-out (matmul.cpp:128-129,160-161): result stays the zero-initialised matrix
+    if (m == 0 || n == 0 || indptr[0] == indptr[m]) { memset(C_host, 0, c_elems * sizeof(real_t)); return 0; }
+    Csr A;
+    if (A.upload(indptr, indices, values, m, sizeof(double))) return 1;
+    DevBuf B, C;
+    if (B.upload(B_host, sizeof(real_t) * (size_t)K_rows * ldb)) return 1;
+    if (C.alloc(sizeof(real_t) * c_elems)) return 1;
+    const int dt = sizeof(real_t) == 8 ? MX_F64 : MX_F32;
+    if (mxd_spmm_csr_dense(m, n, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), B.p, ldb, C.p, ldc, dt,
+                           colmajor ? 1 : 0, nullptr)) return 1;
+    MX_HIP(hipMemcpy(C_host, C.p, sizeof(real_t) * c_elems, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+template <typename vec_t, typename out_t>
+static int spmv_host(int m, const int32_t *indptr, const int32_t *indices, const double *values, const vec_t *y,
+                     int len_y, int v_dtype, out_t *out)
+{
+    MX_REQUIRE(m >= 0 && len_y >= 0, "negative dimension");
+    if (m == 0) return 0;
+    Csr A;
+    if (A.upload(indptr, indices, values, m, sizeof(double))) return 1;
+    DevBuf v, o;
+    if (v.upload(y, sizeof(vec_t) * (size_t)len_y)) return 1;
+    if (o.alloc(sizeof(out_t) * (size_t)m)) return 1;
+    if (spmv_launch(m, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), v.p, v_dtype, o.p, nullptr))
+        return 1;
+    MX_HIP(hipMemcpy(out, o.p, sizeof(out_t) * (size_t)m, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // namespace mx
+
+// variable-size result waiting on the device for the caller's vectors
+struct mx_result {
+    mx::DevBuf indptr, indices, values;
+    mx_result_info info;
+};
+
+using namespace mx;
+
+extern "C" {
+
+const char *mx_last_error(void) { return mx::g_err; }
+int mx_abi_version(void) { return MXGPU_ABI_VERSION; }
+
+int mx_device_count(int *count)
+{
+    MX_REQUIRE(count, "mx_device_count: null pointer");
+    *count = 0;
+    MX_HIP(hipGetDeviceCount(count));
+    return 0;
+}
+int mx_set_device(int device) { MX_HIP(hipSetDevice(device)); return 0; }
+int mx_device_name(char *buf, size_t buflen)
+{
+    int dev = 0;
+    MX_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    MX_HIP(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+int mx_dev_malloc(void **dptr, size_t bytes) { MX_HIP(hipMalloc(dptr, bytes ? bytes : 16)); return 0; }
+int mx_dev_free(void *dptr) { MX_HIP(hipFree(dptr)); return 0; }
+int mx_dev_memset(void *dptr, int value, size_t bytes, void *stream)
+{
+    MX_HIP(hipMemsetAsync(dptr, value, bytes, as_stream(stream)));
+    return 0;
+}
+int mx_memcpy_h2d(void *dptr, const void *hptr, size_t bytes, void *stream)
+{
+    MX_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return 0;
+}
+int mx_memcpy_d2h(void *hptr, const void *dptr, size_t bytes, void *stream)
+{
+    MX_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return 0;
+}
+int mx_stream_sync(void *stream) { MX_HIP(hipStreamSynchronize(as_stream(stream))); return 0; }
+int mx_host_register(void *hptr, size_t bytes) { MX_HIP(hipHostRegister(hptr, bytes, hipHostRegisterDefault)); return 0; }
+int mx_host_unregister(void *hptr) { MX_HIP(hipHostUnregister(hptr)); return 0; }
+
+// ---- SpMM exports ------------------------------------------------------------------------------
+int mx_tcrossprod_csr_dense_numeric(const int32_t *X_indptr, const int32_t *X_indices, const double *X_values,
+                                    int nrows_X, const double *Y_colmajor, int nrow_Y, int ncol_Y, int nthreads,
+                                    double *out_colmajor)
+{
+    (void)nthreads;
+    // gemm_csr_drm_as_dcm(m = nrow X, n = nrow Y, B = Y, ldb = nrow Y, C, ldc = m)   matmul.cpp:326-332
+    return spmm_host<double>(nrows_X, nrow_Y, ncol_Y, X_indptr, X_indices, X_values, Y_colmajor, (size_t)nrow_Y,
+                             out_colmajor, (size_t)nrows_X, (size_t)nrows_X * (size_t)nrow_Y, true);
+}
+int mx_tcrossprod_csr_dense_float32(const int32_t *X_indptr, const int32_t *X_indices, const double *X_values,
+                                    int nrows_X, const float *Y_colmajor, int nrow_Y, int ncol_Y, int nthreads,
+                                    float *out_colmajor)
+{
+    (void)nthreads;
+    return spmm_host<float>(nrows_X, nrow_Y, ncol_Y, X_indptr, X_indices, X_values, Y_colmajor, (size_t)nrow_Y,
+                            out_colmajor, (size_t)nrows_X, (size_t)nrows_X * (size_t)nrow_Y, true);
+}
+int mx_matmul_dense_csc_numeric(const double *X_colmajor, int nrows_X, int ncols_X, const int32_t *Y_indptr,
+                                const int32_t *Y_indices, const double *Y_values, int ncols_Y, int nthreads,
+                                double *out_colmajor)
+{
+    (void)nthreads;
+    // gemm_csr_drm_as_drm(m = ncol Y, n = nrow X, CSC-as-CSR, B = X, ldb = nrow X, C, ldc = nrow X)  matmul.cpp:201-208
+    return spmm_host<double>(ncols_Y, nrows_X, ncols_X, Y_indptr, Y_indices, Y_values, X_colmajor, (size_t)nrows_X,
+                             out_colmajor, (size_t)nrows_X, (size_t)nrows_X * (size_t)ncols_Y, false);
+}
+int mx_matmul_dense_csc_float32(const float *X_colmajor, int nrows_X, int ncols_X, const int32_t *Y_indptr,
+                                const int32_t *Y_indices, const double *Y_values, int ncols_Y, int nthreads,
+                                float *out_colmajor)
+{
+    (void)nthreads;
+    return spmm_host<float>(ncols_Y, nrows_X, ncols_X, Y_indptr, Y_indices, Y_values, X_colmajor, (size_t)nrows_X,
+                            out_colmajor, (size_t)nrows_X, (size_t)nrows_X * (size_t)ncols_Y, false);
+}
+int mx_tcrossprod_dense_csr_numeric(const double *X_colmajor, int nrows_X, int ncols_X, const int32_t *Y_indptr,
+                                    const int32_t *Y_indices, const double *Y_values, int nrows_Y, int nthreads,
+                                    int ncols_Y, double *out_colmajor)
+{
+    (void)nthreads; (void)ncols_Y;
+    // gemm_csr_drm_as_drm(m = nrow Y, n = nrow X, Y, B = X, ldb = nrow X, C, ldc = nrow X)  matmul.cpp:263-270
+    return spmm_host<double>(nrows_Y, nrows_X, ncols_X, Y_indptr, Y_indices, Y_values, X_colmajor, (size_t)nrows_X,
+                             out_colmajor, (size_t)nrows_X, (size_t)nrows_X * (size_t)nrows_Y, false);
+}
+int mx_tcrossprod_dense_csr_float32(const float *X_colmajor, int nrows_X, int ncols_X, const int32_t *Y_indptr,
+                                    const int32_t *Y_indices, const double *Y_values, int nrows_Y, int nthreads,
+                                    int ncols_Y, float *out_colmajor)
+{
+    (void)nthreads; (void)ncols_Y;
+    return spmm_host<float>(nrows_Y, nrows_X, ncols_X, Y_indptr, Y_indices, Y_values, X_colmajor, (size_t)nrows_X,
+                            out_colmajor, (size_t)nrows_X, (size_t)nrows_X * (size_t)nrows_Y, false);
+}
+
+// ---- SpMV exports ------------------------------------------------------------------------------
+int mx_matmul_csr_dvec_numeric(const int32_t *p, const int32_t *j, const double *x, int nrows_X, const double *y,
+                               int len_y, int nthreads, double *out)
+{
+    (void)nthreads;
+    return spmv_host<double, double>(nrows_X, p, j, x, y, len_y, MX_F64, out);
+}
+int mx_matmul_csr_dvec_integer(const int32_t *p, const int32_t *j, const double *x, int nrows_X, const int32_t *y,
+                               int len_y, int nthreads, double *out)
+{
+    (void)nthreads;
+    return spmv_host<int32_t, double>(nrows_X, p, j, x, y, len_y, MX_I32, out);
+}
+int mx_matmul_csr_dvec_logical(const int32_t *p, const int32_t *j, const double *x, int nrows_X, const int32_t *y,
+                               int len_y, int nthreads, double *out)
+{
+    (void)nthreads;
+    return spmv_host<int32_t, double>(nrows_X, p, j, x, y, len_y, MX_LGL, out);
+}
+int mx_matmul_csr_dvec_float32(const int32_t *p, const int32_t *j, const double *x, int nrows_X, const float *y,
+                               int len_y, int nthreads, float *out)
+{
+    (void)nthreads;
+    return spmv_host<float, float>(nrows_X, p, j, x, y, len_y, MX_F32, out);
+}
+
+// ---- CSR (+) CSR -------------------------------------------------------------------------------
+int mx_csr_elemwise_begin(int op, int nrows, const int32_t *indptr1, const int32_t *indptr2,
+                          const int32_t *indices1, const int32_t *indices2, const void *values1,
+                          const void *values2, int64_t nnz1, int64_t nnz2, mx_result **res_out,
+                          mx_result_info *info)
+{
+    MX_REQUIRE(res_out && info, "mx_csr_elemwise_begin: null output pointer");
+    MX_REQUIRE(op >= MX_OP_ADD && op <= MX_OP_AND, "mx_csr_elemwise_begin: unknown op %d", op);
+    MX_REQUIRE(nrows >= 0 && nnz1 >= 0 && nnz2 >= 0, "mx_csr_elemwise_begin: negative size");
+    *res_out = nullptr;
+    const bool lgl = op == MX_OP_OR || op == MX_OP_XOR || op == MX_OP_AND;
+    const size_t vb = lgl ? 4 : 8;
+    mx_result *res = new (std::nothrow) mx_result();
+    MX_REQUIRE(res, "out of host memory");
+    res->info.values_dtype = lgl ? MX_LGL : MX_F64;
+    res->info.alias_structure = 0;
+    int rc = 0;
+    do {
+        // identical-structure fast paths: pointer identity, as operators.cpp:104-108 / :343-346 test it
+        if (nnz1 == nnz2 && indptr1 == indptr2 && indices1 == indices2) {
+            if (op == MX_OP_SUB && values1 == values2) {
+                // operators.cpp:348-355: IntegerVector(indptr.size()) zeros, empty indices / values
+                res->info.indptr_len = (int64_t)nrows + 1;
+                res->info.nnz = 0;
+                if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
+                if (hipMemset(res->indptr.p, 0, sizeof(int32_t) * ((size_t)nrows + 1)) != hipSuccess) {
+                    rc = set_error("hipMemset failed"); break;
+                }
+                break;
+            }
+            res->info.alias_structure = 1;
+            res->info.indptr_len = (int64_t)nrows + 1;
+            res->info.nnz = nnz1;
+            DevBuf a, b;
+            if ((rc = a.upload(values1, vb * (size_t)nnz1))) break;
+            if ((rc = b.upload(values2, vb * (size_t)nnz2))) break;
+            if ((rc = res->values.alloc(vb * (size_t)nnz1))) break;
+            if ((rc = mxd_values_elemwise(op, nnz1, a.p, b.p, res->values.p, nullptr))) break;
+            if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
+            break;
+        }
+        Csr A, B;
+        if ((rc = A.upload(indptr1, indices1, values1, nrows, vb))) break;
+        if ((rc = B.upload(indptr2, indices2, values2, nrows, vb))) break;
+        DevBuf ws;
+        if ((rc = ws.alloc(mxd_merge_workspace_bytes(nrows)))) break;
+        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
+        int64_t nnz_out = 0;
+        if ((rc = mxd_csr_merge_count(op, nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.nnz, B.p.as<int32_t>(),
+                                      B.j.as<int32_t>(), B.nnz, res->indptr.as<int32_t>(), ws.p, &nnz_out, nullptr)))
+            break;
+        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
+        if ((rc = res->values.alloc(vb * (size_t)nnz_out))) break;
+        if ((rc = mxd_csr_merge_fill(op, nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, A.nnz, B.p.as<int32_t>(),
+                                     B.j.as<int32_t>(), B.x.p, B.nnz, res->indptr.as<int32_t>(),
+                                     res->indices.as<int32_t>(), res->values.p, nullptr)))
+            break;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
+        res->info.indptr_len = (int64_t)nrows + 1;
+        res->info.nnz = nnz_out;
+    } while (0);
+    if (rc) { delete res; return rc; }
+    *info = res->info;
+    *res_out = res;
+    return 0;
+}
+
+// ---- row gather --------------------------------------------------------------------------------
+int mx_copy_csr_rows_begin(const int32_t *indptr, int nrows, const int32_t *indices, const void *values,
+                           int value_dtype, int64_t n_values, const int32_t *rows_take, int64_t n_take,
+                           mx_result **res_out, mx_result_info *info)
+{
+    MX_REQUIRE(res_out && info, "mx_copy_csr_rows_begin: null output pointer");
+    MX_REQUIRE(nrows >= 0 && n_take >= 0 && n_take <= INT_MAX, "mx_copy_csr_rows_begin: bad size");
+    MX_REQUIRE(value_dtype == MX_F64 || value_dtype == MX_LGL || value_dtype == MX_NONE,
+               "mx_copy_csr_rows_begin: unsupported value dtype %d", value_dtype);
+    *res_out = nullptr;
+    const bool has_values = value_dtype != MX_NONE && n_values > 0;   // slice.cpp:246,257
+    const size_t vb = has_values ? dtype_bytes(value_dtype) : 0;
+    mx_result *res = new (std::nothrow) mx_result();
+    MX_REQUIRE(res, "out of host memory");
+    res->info.values_dtype = value_dtype;
+    res->info.alias_structure = 0;
+    int rc = 0;
+    do {
+        Csr A;
+        if ((rc = A.upload(indptr, indices, values, nrows, vb))) break;
+        DevBuf rows, ws;
+        if ((rc = rows.upload(rows_take, sizeof(int32_t) * (size_t)n_take))) break;
+        if ((rc = ws.alloc(mxd_gather_workspace_bytes((int)n_take)))) break;
+        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)n_take + 1)))) break;
+        int64_t nnz_out = 0;
+        if ((rc = mxd_csr_gather_count((int)n_take, A.p.as<int32_t>(), rows.as<int32_t>(), res->indptr.as<int32_t>(),
+                                       ws.p, &nnz_out, nullptr)))
+            break;
+        if (nnz_out == 0) {          // slice.cpp:236-240: three EMPTY vectors (even the indptr)
+            res->info.indptr_len = 0;
+            res->info.nnz = 0;
+            break;
+        }
+        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
+        if (has_values && (rc = res->values.alloc(vb * (size_t)nnz_out))) break;
+        if ((rc = mxd_csr_gather_fill((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, rows.as<int32_t>(),
+                                      res->indptr.as<int32_t>(), res->indices.as<int32_t>(), res->values.p,
+                                      has_values ? value_dtype : MX_NONE, nnz_out, nullptr)))
+            break;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
+        res->info.indptr_len = n_take + 1;
+        res->info.nnz = nnz_out;
+        if (!has_values) res->info.values_dtype = MX_NONE;
+    } while (0);
+    if (rc) { delete res; return rc; }
+    *info = res->info;
+    *res_out = res;
+    return 0;
+}
+
+int mx_result_finish(mx_result *res, int32_t *out_indptr, int32_t *out_indices, void *out_values)
+{
+    MX_REQUIRE(res, "mx_result_finish: null handle");
+    int rc = 0;
+    do {
+        const mx_result_info &inf = res->info;
+        if (!inf.alias_structure) {
+            if (inf.indptr_len > 0 && out_indptr &&
+                hipMemcpy(out_indptr, res->indptr.p, sizeof(int32_t) * (size_t)inf.indptr_len, hipMemcpyDeviceToHost) != hipSuccess) {
+                rc = set_error("D2H copy of indptr failed"); break;
+            }
+            if (inf.nnz > 0 && out_indices &&
+                hipMemcpy(out_indices, res->indices.p, sizeof(int32_t) * (size_t)inf.nnz, hipMemcpyDeviceToHost) != hipSuccess) {
+                rc = set_error("D2H copy of indices failed"); break;
+            }
+        }
+        const size_t vb = dtype_bytes(inf.values_dtype);
+        if (vb && inf.nnz > 0 && out_values && res->values.p &&
+            hipMemcpy(out_values, res->values.p, vb * (size_t)inf.nnz, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = set_error("D2H copy of values failed"); break;
+        }
+    } while (0);
+    delete res;
+    return rc;
+}
+
+int mx_result_discard(mx_result *res) { delete res; return 0; }
+
+// ---- index-vector classification -------------------------------------------------------------------
+static int check_seq_host(const int32_t *indices, int64_t n, int reversed, int *result)
+{
+    MX_REQUIRE(result, "check_is_seq: null result pointer");
+    if (n < 2) { *result = 1; return 0; }
+    // slice.cpp:28,40: end-point test first — avoids the transfer for the common negative
+    const int64_t span = reversed ? (int64_t)indices[0] - indices[n - 1] : (int64_t)indices[n - 1] - indices[0];
+    if (span != n - 1) { *result = 0; return 0; }
+    DevBuf d, flag;
+    if (d.upload(indices, sizeof(int32_t) * (size_t)n)) return 1;
+    if (flag.alloc(16)) return 1;
+    return mxd_check_is_seq(d.as<int32_t>(), n, reversed, flag.as<int32_t>(), result, nullptr);
+}
+int mx_check_is_seq(const int32_t *indices, int64_t n, int *result) { return check_seq_host(indices, n, 0, result); }
+int mx_check_is_rev_seq(const int32_t *indices, int64_t n, int *result) { return check_seq_host(indices, n, 1, result); }
+
+// ---- sort precondition (§8f rank 1) ------------------------------------------------------------------
+int mx_check_indices_are_sorted(const int32_t *indptr, const int32_t *indices, int nrows, int *result)
+{
+    MX_REQUIRE(result, "mx_check_indices_are_sorted: null result pointer");
+    if (nrows <= 0) { *result = 1; return 0; }
+    Csr A;
+    if (A.upload(indptr, indices, nullptr, nrows, 0)) return 1;
+    DevBuf flag;
+    if (flag.alloc(16)) return 1;
+    return mxd_csr_rows_sorted(nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), flag.as<int32_t>(), result, nullptr);
+}
+
+int mx_sort_sparse_indices(const int32_t *indptr, int32_t *indices, void *values, int value_dtype, int nrows)
+{
+    if (nrows <= 0) return 0;
+    const size_t vb = values ? dtype_bytes(value_dtype) : 0;
+    Csr A;
+    if (A.upload(indptr, indices, values, nrows, vb)) return 1;
+    if (A.nnz < 2) return 0;
+    DevBuf flag, tj, tx;
+    if (flag.alloc(16)) return 1;
+    int sorted = 0;
+    if (mxd_csr_rows_sorted(nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), flag.as<int32_t>(), &sorted, nullptr)) return 1;
+    if (sorted) return 0;                      // nothing to do, inputs untouched
+    if (tj.alloc(sizeof(int32_t) * (size_t)A.nnz)) return 1;
+    if (vb && tx.alloc(vb * (size_t)A.nnz)) return 1;
+    if (mxd_csr_sort_rows(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), vb ? A.x.p : nullptr,
+                          vb ? value_dtype : MX_NONE, tj.as<int32_t>(), tx.p, nullptr)) return 1;
+    MX_HIP(hipMemcpy(indices, A.j.p, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
+    if (vb) MX_HIP(hipMemcpy(values, A.x.p, vb * (size_t)A.nnz, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// mx_common.h — shared host/device helpers of libmxgpu (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <climits>
+#include "../../include/mxgpu.h"
+
+#define MX_WAVE 64
+#define MX_NA_INT INT_MIN                       // R NA_INTEGER / NA_LOGICAL
+#define MX_NA_REAL_BITS 0x7FF00000000007A2ULL   // R NA_real_ (NaN, low word 1954)
+
+namespace mx {
+
+// thread-local error text behind mx_last_error()
+int set_error(const char *fmt, ...);
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define MX_HIP(expr)                                                                   \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return mx::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                 __FILE__, __LINE__);                                  \
+    } while (0)
+
+#define MX_LAUNCH_CHECK()                                                              \
+    do {                                                                               \
+        hipError_t _e = hipGetLastError();                                             \
+        if (_e != hipSuccess)                                                          \
+            return mx::set_error("kernel launch failed: %s (%s:%d)",                   \
+                                 hipGetErrorString(_e), __FILE__, __LINE__);           \
+    } while (0)
+
+#define MX_REQUIRE(cond, ...)                                                          \
+    do { if (!(cond)) return mx::set_error(__VA_ARGS__); } while (0)
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// lanes-per-row for the sub-wave ("group") kernels: smallest power of two
+// >= avg row length, clamped to [lo, 64]
+inline int pick_group(double avg_len, int lo = 4)
+{
+    int g = lo;
+    while (g < 64 && (double)g < avg_len) g <<= 1;
+    return g;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (MX_WAVE - 1); }
+
+// wave-uniform broadcast of a value known to be uniform (moves it to an SGPR)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+
+__device__ __forceinline__ double na_real()
+{
+    return __longlong_as_double((long long)MX_NA_REAL_BITS);
+}
+
+// R's three-valued logic, src/operators.cpp:17-25
+__device__ __forceinline__ int r_logical_or(int x, int y)
+{
+    if (x == MX_NA_INT) return (y == MX_NA_INT) ? MX_NA_INT : (y ? 1 : MX_NA_INT);
+    if (y == MX_NA_INT) return x ? 1 : MX_NA_INT;
+    return (x != 0) || (y != 0);
+}
+__device__ __forceinline__ int r_logical_and(int x, int y)
+{
+    if (x == MX_NA_INT) return (y == MX_NA_INT) ? MX_NA_INT : (y ? MX_NA_INT : 0);
+    if (y == MX_NA_INT) return x ? MX_NA_INT : 0;
+    return (x != 0) && (y != 0);
+}
+__device__ __forceinline__ int r_logical_xor(int x, int y)
+{
+    if (x == MX_NA_INT || y == MX_NA_INT) return MX_NA_INT;
+    return (x != 0) != (y != 0);
+}
+
+// first position in [first, first+count) whose value is >= key
+__device__ __forceinline__ int lower_bound_dev(const int32_t *__restrict__ first, int count, int key)
+{
+    int lo = 0;
+    while (count > 0) {
+        const int step = count >> 1;
+        if (first[lo + step] < key) { lo += step + 1; count -= step + 1; }
+        else count = step;
+    }
+    return lo;
+}
+#endif  // __HIPCC__
+
+}  // namespace mx

@@ -1,0 +1,138 @@
+// scan.hip — exclusive prefix sum of int32 row lengths into an int32 indptr,
+// carried in int64 so that an overflow of R's int32 nnz limit is detected
+// instead of wrapping (the reference keeps `size_t curr` and stores it into an
+// int indptr, operators.cpp:414,521).
+//
+// Three launches (reduce tiles -> scan tile sums in one workgroup -> scan tiles
+// with carried offset).  Row-count vectors are <= 32 MB here; the scan is a
+// bandwidth-trivial step between the count and fill passes of merge / gather.
+#include "mx_common.h"
+
+namespace mx {
+
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__device__ __forceinline__ long long wave_incl_scan(long long v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < MX_WAVE; off <<= 1) {
+        const long long o = __shfl_up(v, off, MX_WAVE);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// inclusive scan of one value per thread across the workgroup; returns the
+// thread's inclusive value, *block_total = sum over the workgroup
+__device__ __forceinline__ long long block_incl_scan(long long v, long long *block_total)
+{
+    __shared__ long long wave_sums[SCAN_BLOCK / MX_WAVE];
+    const int lane = lane_id(), wave = threadIdx.x / MX_WAVE;
+    long long incl = wave_incl_scan(v);
+    if (lane == MX_WAVE - 1) wave_sums[wave] = incl;
+    __syncthreads();
+    long long base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_BLOCK / MX_WAVE; w++) {
+        const long long ws = wave_sums[w];
+        if (w < wave) base += ws;
+        total += ws;
+    }
+    __syncthreads();
+    *block_total = total;
+    return incl + base;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK)
+void scan_reduce_kernel(const int32_t *__restrict__ counts, int64_t n, long long *__restrict__ tile_sums)
+{
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    long long sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+        if (base + i < n) sum += counts[base + i];
+    long long total;
+    block_incl_scan(sum, &total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// one workgroup: exclusive scan of the tile sums in place; grand total out
+__global__ __launch_bounds__(SCAN_BLOCK)
+void scan_sums_kernel(long long *__restrict__ tile_sums, int64_t ntiles, long long *__restrict__ total_out)
+{
+    long long carry = 0;
+    for (int64_t b0 = 0; b0 < ntiles; b0 += SCAN_BLOCK) {
+        const int64_t i = b0 + threadIdx.x;
+        const long long v = i < ntiles ? tile_sums[i] : 0;
+        long long total;
+        const long long incl = block_incl_scan(v, &total);
+        if (i < ntiles) tile_sums[i] = carry + incl - v;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK)
+void scan_tiles_kernel(const int32_t *__restrict__ counts, int64_t n, const long long *__restrict__ tile_offsets,
+                       const long long *__restrict__ total, int32_t *__restrict__ out)
+{
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int32_t c[SCAN_ITEMS];
+    long long sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        c[i] = base + i < n ? counts[base + i] : 0;
+        sum += c[i];
+    }
+    long long block_total;
+    const long long incl = block_incl_scan(sum, &block_total);
+    long long run = tile_offsets[blockIdx.x] + incl - sum;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) out[base + i] = (int32_t)run;
+        run += c[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (int32_t)*total;
+}
+
+// workspace layout: [int64 total][int64 tile_sums[ntiles]]
+size_t scan_workspace_bytes(int64_t n)
+{
+    return sizeof(long long) * (size_t)(1 + ceil_div(n > 0 ? n : 1, SCAN_TILE));
+}
+
+int exclusive_scan_i32(const int32_t *counts, int64_t n, int32_t *out, int64_t *total_dev, void *workspace,
+                       hipStream_t st)
+{
+    long long *ws = (long long *)workspace;
+    long long *total = total_dev ? (long long *)total_dev : ws;
+    long long *tile_sums = ws + 1;
+    if (n <= 0) {
+        MX_HIP(hipMemsetAsync(out, 0, sizeof(int32_t), st));
+        MX_HIP(hipMemsetAsync(total, 0, sizeof(long long), st));
+        return 0;
+    }
+    const int64_t ntiles = ceil_div(n, SCAN_TILE);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0, st, counts, n, tile_sums);
+    MX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, tile_sums, ntiles, total);
+    MX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0, st, counts, n, tile_sums,
+                       total, out);
+    MX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mx
+
+extern "C" size_t mxd_scan_workspace_bytes(int64_t n) { return mx::scan_workspace_bytes(n); }
+
+extern "C" int mxd_exclusive_scan_i32(const int32_t *counts, int64_t n, int32_t *out, int64_t *total_dev,
+                                      void *workspace, void *stream)
+{
+    MX_REQUIRE(out && workspace, "mxd_exclusive_scan_i32: null pointer");
+    return mx::exclusive_scan_i32(counts, n, out, total_dev, workspace, mx::as_stream(stream));
+}

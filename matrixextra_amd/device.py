@@ -1,0 +1,126 @@
+"""Device-resident operands and mxd_* launches on torch tensors.
+
+torch is plumbing here: it owns the HBM allocations, the stream and (in
+distributed.py) the RCCL communicator; every kernel that runs is one of
+libmxgpu.so's hand-written HIP kernels, launched on torch's current stream
+through the device-level C-ABI (include/mxgpu.h, mxd_*).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MX_F32, MX_F64, MX_LGL, MX_NONE, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dp(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+@dataclass
+class DeviceCSR:
+    """CSR arrays resident in HBM: int32 indptr[m+1], int32 indices[nnz], values (f64 / int32 logical / None)."""
+    indptr: torch.Tensor
+    indices: torch.Tensor
+    values: torch.Tensor | None
+    m: int
+    K: int
+    nnz: int
+
+    @classmethod
+    def from_host(cls, indptr, indices, values, K, device="cuda"):
+        p = torch.from_numpy(np.ascontiguousarray(indptr, dtype=np.int32)).to(device)
+        j = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int32)).to(device)
+        x = None if values is None else torch.from_numpy(np.ascontiguousarray(values)).to(device)
+        return cls(p, j, x, int(p.numel() - 1), int(K), int(j.numel()))
+
+    def to_host(self):
+        return (self.indptr.cpu().numpy(), self.indices.cpu().numpy(),
+                None if self.values is None else self.values.cpu().numpy())
+
+
+def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajor: bool = False):
+    """C = A @ B with B (K x n) row-major in HBM.  colmajor=False: C row-major (m x n) —
+    gemm_csr_drm_as_drm layout; colmajor=True: C column-major (what tcrossprod_csr_dense returns to R),
+    stored as a row-major (n x m) tensor and returned as its transposed view."""
+    lib = _lib.load()
+    assert B.is_cuda and B.dim() == 2 and B.stride(1) == 1 and B.shape[0] == A.K
+    n = int(B.shape[1])
+    dt = MX_F64 if B.dtype == torch.float64 else MX_F32
+    assert B.dtype in (torch.float64, torch.float32)
+    if colmajor:
+        if out is None:
+            out = torch.empty((n, A.m), dtype=B.dtype, device=B.device)
+        assert out.shape == (n, A.m) and out.is_contiguous()
+        ldc = A.m
+    else:
+        if out is None:
+            out = torch.empty((A.m, n), dtype=B.dtype, device=B.device)
+        assert out.shape == (A.m, n) and out.is_contiguous()
+        ldc = n
+    check(lib.mxd_spmm_csr_dense(C.c_int(A.m), C.c_int(n), _dp(A.indptr), _dp(A.indices), _dp(A.values),
+                                 _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),
+                                 C.c_int(dt), C.c_int(1 if colmajor else 0), _stream()))
+    return out.t() if colmajor else out
+
+
+def spmv(A: DeviceCSR, v: torch.Tensor, v_dtype=None, out=None):
+    """y = A @ v (matmul_csr_dvec).  v float64 / float32 / int32 (v_dtype MX_I32 or MX_LGL for int32)."""
+    lib = _lib.load()
+    if v_dtype is None:
+        v_dtype = {torch.float64: MX_F64, torch.float32: MX_F32}[v.dtype]
+    odt = torch.float32 if v_dtype == MX_F32 else torch.float64
+    if out is None:
+        out = torch.empty(A.m, dtype=odt, device=v.device)
+    check(lib.mxd_spmv_csr_dvec(C.c_int(A.m), C.c_int64(A.nnz), _dp(A.indptr), _dp(A.indices), _dp(A.values),
+                                _dp(v), C.c_int(v_dtype), _dp(out), _stream()))
+    return out
+
+
+def csr_elemwise(op, A: DeviceCSR, B: DeviceCSR):
+    """CSR (+) CSR on device-resident operands: count -> scan -> (one host round trip for nnz) -> fill."""
+    lib = _lib.load()
+    assert A.m == B.m
+    dev = A.indptr.device
+    ws = torch.empty(lib.mxd_merge_workspace_bytes(A.m), dtype=torch.uint8, device=dev)
+    out_p = torch.empty(A.m + 1, dtype=torch.int32, device=dev)
+    nnz_out = C.c_int64(0)
+    check(lib.mxd_csr_merge_count(C.c_int(op), C.c_int(A.m), _dp(A.indptr), _dp(A.indices), C.c_int64(A.nnz),
+                                  _dp(B.indptr), _dp(B.indices), C.c_int64(B.nnz), _dp(out_p), _dp(ws),
+                                  C.byref(nnz_out), _stream()))
+    logical = op in (_lib.MX_OP_OR, _lib.MX_OP_XOR, _lib.MX_OP_AND)
+    out_j = torch.empty(nnz_out.value, dtype=torch.int32, device=dev)
+    out_x = torch.empty(nnz_out.value, dtype=torch.int32 if logical else torch.float64, device=dev)
+    check(lib.mxd_csr_merge_fill(C.c_int(op), C.c_int(A.m), _dp(A.indptr), _dp(A.indices), _dp(A.values),
+                                 C.c_int64(A.nnz), _dp(B.indptr), _dp(B.indices), _dp(B.values), C.c_int64(B.nnz),
+                                 _dp(out_p), _dp(out_j), _dp(out_x), _stream()))
+    return DeviceCSR(out_p, out_j, out_x, A.m, A.K, int(nnz_out.value))
+
+
+def csr_gather_rows(A: DeviceCSR, rows: torch.Tensor):
+    """A[rows, :] on device (copy_csr_rows).  rows int32, 0-based."""
+    lib = _lib.load()
+    dev = A.indptr.device
+    r = int(rows.numel())
+    ws = torch.empty(lib.mxd_gather_workspace_bytes(r), dtype=torch.uint8, device=dev)
+    new_p = torch.empty(r + 1, dtype=torch.int32, device=dev)
+    nnz_out = C.c_int64(0)
+    check(lib.mxd_csr_gather_count(C.c_int(r), _dp(A.indptr), _dp(rows), _dp(new_p), _dp(ws),
+                                   C.byref(nnz_out), _stream()))
+    new_j = torch.empty(nnz_out.value, dtype=torch.int32, device=dev)
+    if A.values is None:
+        vd, new_x = MX_NONE, None
+    else:
+        vd = MX_F64 if A.values.dtype == torch.float64 else MX_LGL
+        new_x = torch.empty(nnz_out.value, dtype=A.values.dtype, device=dev)
+    check(lib.mxd_csr_gather_fill(C.c_int(r), _dp(A.indptr), _dp(A.indices), _dp(A.values), _dp(rows), _dp(new_p),
+                                  _dp(new_j), _dp(new_x), C.c_int(vd), C.c_int64(nnz_out.value), _stream()))
+    return DeviceCSR(new_p, new_j, new_x, r, A.K, int(nnz_out.value))

@@ -1,0 +1,265 @@
+"""Python twins of the reference's R/RcppExports.R wrappers for the hot path.
+
+Same names, argument order and return shapes as the R side sees them
+(R/RcppExports.R:148-150, 360, 388, 564 …): dense results are numpy arrays in
+column-major (Fortran) order, list results are dicts with `indptr`, `indices`,
+`values`.  Every function goes through the C-ABI of libmxgpu.so
+(include/mxgpu.h) — i.e. through the HIP kernels; nothing here computes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (MX_F64, MX_LGL, MX_NONE, MX_OP_ADD, MX_OP_AND, MX_OP_MUL, MX_OP_OR,
+                   MX_OP_SUB, MX_OP_XOR, ResultInfo, check, ptr)
+
+
+def _i32(a):
+    a = np.asarray(a)
+    if a.dtype != np.int32 or not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a, dtype=np.int32)
+    return a
+
+
+def _f64(a):
+    a = np.asarray(a)
+    if a.dtype != np.float64 or not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a, dtype=np.float64)
+    return a
+
+
+def _dense(M, dtype):
+    M = np.asarray(M)
+    if M.ndim != 2:
+        raise ValueError("dense operand must be a 2-d matrix")
+    if M.dtype != dtype or not M.flags.f_contiguous:
+        M = np.asfortranarray(M, dtype=dtype)
+    return M
+
+
+# ----------------------------------------------------------------------------- SpMM
+def _tcrossprod_csr_dense(X_csr_indptr, X_csr_indices, X_csr_values, Y_colmajor, nthreads, dtype, fn):
+    p, j, x = _i32(X_csr_indptr), _i32(X_csr_indices), _f64(X_csr_values)
+    Y = _dense(Y_colmajor, dtype)
+    m, n, K = p.size - 1, Y.shape[0], Y.shape[1]
+    out = np.empty((m, n), dtype=dtype, order="F")
+    check(fn(ptr(p), ptr(j), ptr(x), C.c_int(m), ptr(Y), C.c_int(n), C.c_int(K), C.c_int(int(nthreads)), ptr(out)))
+    return out
+
+
+def tcrossprod_csr_dense_numeric(X_csr_indptr, X_csr_indices, X_csr_values, Y_colmajor, nthreads=1):
+    """R/RcppExports.R:148-150 -> src/matmul.cpp:345-359."""
+    return _tcrossprod_csr_dense(X_csr_indptr, X_csr_indices, X_csr_values, Y_colmajor, nthreads, np.float64,
+                                 _lib.load().mx_tcrossprod_csr_dense_numeric)
+
+
+def tcrossprod_csr_dense_float32(X_csr_indptr, X_csr_indices, X_csr_values, Y_colmajor, nthreads=1):
+    """src/matmul.cpp:361-375 (Y / result are the float32@Data bits; here numpy float32)."""
+    return _tcrossprod_csr_dense(X_csr_indptr, X_csr_indices, X_csr_values, Y_colmajor, nthreads, np.float32,
+                                 _lib.load().mx_tcrossprod_csr_dense_float32)
+
+
+def _dense_times_sparse(X_colmajor, indptr, indices, values, nthreads, dtype, fn, extra=None):
+    X = _dense(X_colmajor, dtype)
+    p, i, x = _i32(indptr), _i32(indices), _f64(values)
+    nrows_X, ncols_X, nout = X.shape[0], X.shape[1], p.size - 1
+    out = np.empty((nrows_X, nout), dtype=dtype, order="F")
+    args = [ptr(X), C.c_int(nrows_X), C.c_int(ncols_X), ptr(p), ptr(i), ptr(x), C.c_int(nout),
+            C.c_int(int(nthreads))]
+    if extra is not None:
+        args.append(C.c_int(int(extra)))
+    args.append(ptr(out))
+    check(fn(*args))
+    return out
+
+
+def matmul_dense_csc_numeric(X_colmajor, Y_csc_indptr, Y_csc_indices, Y_csc_values, nthreads=1):
+    """src/matmul.cpp:221-235."""
+    return _dense_times_sparse(X_colmajor, Y_csc_indptr, Y_csc_indices, Y_csc_values, nthreads, np.float64,
+                               _lib.load().mx_matmul_dense_csc_numeric)
+
+
+def matmul_dense_csc_float32(X_colmajor, Y_csc_indptr, Y_csc_indices, Y_csc_values, nthreads=1):
+    """src/matmul.cpp:237-251."""
+    return _dense_times_sparse(X_colmajor, Y_csc_indptr, Y_csc_indices, Y_csc_values, nthreads, np.float32,
+                               _lib.load().mx_matmul_dense_csc_float32)
+
+
+def tcrossprod_dense_csr_numeric(X_colmajor, Y_csr_indptr, Y_csr_indices, Y_csr_values, nthreads=1, ncols_Y=0):
+    """src/matmul.cpp:283-297."""
+    return _dense_times_sparse(X_colmajor, Y_csr_indptr, Y_csr_indices, Y_csr_values, nthreads, np.float64,
+                               _lib.load().mx_tcrossprod_dense_csr_numeric, extra=ncols_Y)
+
+
+def tcrossprod_dense_csr_float32(X_colmajor, Y_csr_indptr, Y_csr_indices, Y_csr_values, nthreads=1, ncols_Y=0):
+    """src/matmul.cpp:299-313."""
+    return _dense_times_sparse(X_colmajor, Y_csr_indptr, Y_csr_indices, Y_csr_values, nthreads, np.float32,
+                               _lib.load().mx_tcrossprod_dense_csr_float32, extra=ncols_Y)
+
+
+# ----------------------------------------------------------------------------- SpMV
+def _dvec(X_csr_indptr, X_csr_indices, X_csr_values, y_dense, nthreads, ydt, odt, fn):
+    p, j, x = _i32(X_csr_indptr), _i32(X_csr_indices), _f64(X_csr_values)
+    y = np.ascontiguousarray(y_dense, dtype=ydt)
+    m = p.size - 1
+    out = np.empty(m, dtype=odt)
+    check(fn(ptr(p), ptr(j), ptr(x), C.c_int(m), ptr(y), C.c_int(y.size), C.c_int(int(nthreads)), ptr(out)))
+    return out
+
+
+def matmul_csr_dvec_numeric(X_csr_indptr, X_csr_indices, X_csr_values, y_dense, nthreads=1):
+    """src/matmul.cpp:421-435."""
+    return _dvec(X_csr_indptr, X_csr_indices, X_csr_values, y_dense, nthreads, np.float64, np.float64,
+                 _lib.load().mx_matmul_csr_dvec_numeric)
+
+
+def matmul_csr_dvec_integer(X_csr_indptr, X_csr_indices, X_csr_values, y_dense, nthreads=1):
+    """src/matmul.cpp:437-451."""
+    return _dvec(X_csr_indptr, X_csr_indices, X_csr_values, y_dense, nthreads, np.int32, np.float64,
+                 _lib.load().mx_matmul_csr_dvec_integer)
+
+
+def matmul_csr_dvec_logical(X_csr_indptr, X_csr_indices, X_csr_values, y_dense, nthreads=1):
+    """src/matmul.cpp:453-467."""
+    return _dvec(X_csr_indptr, X_csr_indices, X_csr_values, y_dense, nthreads, np.int32, np.float64,
+                 _lib.load().mx_matmul_csr_dvec_logical)
+
+
+def matmul_csr_dvec_float32(X_csr_indptr, X_csr_indices, X_csr_values, y_dense, nthreads=1):
+    """src/matmul.cpp:469-483."""
+    return _dvec(X_csr_indptr, X_csr_indices, X_csr_values, y_dense, nthreads, np.float32, np.float32,
+                 _lib.load().mx_matmul_csr_dvec_float32)
+
+
+# ----------------------------------------------------------------------------- list results
+_VDT = {MX_F64: np.float64, MX_LGL: np.int32}
+
+
+def _finish(res, info, alias_from=None, empty_values_dtype=np.float64):
+    lib = _lib.load()
+    vdt = _VDT.get(info.values_dtype)
+    if info.alias_structure:
+        indptr, indices = alias_from          # the INPUT objects themselves, as the reference returns them
+        values = np.empty(info.nnz, dtype=vdt)
+        check(lib.mx_result_finish(res, None, None, ptr(values)))
+        return dict(indptr=indptr, indices=indices, values=values)
+    indptr = np.empty(info.indptr_len, dtype=np.int32)
+    indices = np.empty(info.nnz, dtype=np.int32)
+    values = np.empty(info.nnz if vdt is not None else 0, dtype=vdt if vdt is not None else empty_values_dtype)
+    check(lib.mx_result_finish(res, ptr(indptr), ptr(indices), ptr(values) if values.size else None))
+    return dict(indptr=indptr, indices=indices, values=values)
+
+
+def _same(a, b):
+    return a is b
+
+
+def _elemwise(op, indptr1, indptr2, indices1, indices2, values1, values2, vdt):
+    lib = _lib.load()
+    # keep object identity visible to the C-ABI as pointer identity (operators.cpp:104-108, :343-346)
+    p1 = _i32(indptr1)
+    p2 = p1 if _same(indptr1, indptr2) else _i32(indptr2)
+    j1 = _i32(indices1)
+    j2 = j1 if _same(indices1, indices2) else _i32(indices2)
+    v1 = np.ascontiguousarray(values1, dtype=vdt)
+    v2 = v1 if _same(values1, values2) else np.ascontiguousarray(values2, dtype=vdt)
+    res = C.c_void_p()
+    info = ResultInfo()
+    check(lib.mx_csr_elemwise_begin(C.c_int(op), C.c_int(p1.size - 1), ptr(p1), ptr(p2), ptr(j1), ptr(j2),
+                                    ptr(v1), ptr(v2), C.c_int64(j1.size), C.c_int64(j2.size),
+                                    C.byref(res), C.byref(info)))
+    return _finish(res, info, alias_from=(indptr1, indices1))
+
+
+def multiply_csr_elemwise(indptr1, indptr2, indices1, indices2, values1, values2):
+    """R/RcppExports.R:360 -> src/operators.cpp:209-222."""
+    return _elemwise(MX_OP_MUL, indptr1, indptr2, indices1, indices2, values1, values2, np.float64)
+
+
+def logicaland_csr_elemwise(indptr1, indptr2, indices1, indices2, values1, values2):
+    """src/operators.cpp:224-237."""
+    return _elemwise(MX_OP_AND, indptr1, indptr2, indices1, indices2, values1, values2, np.int32)
+
+
+def add_csr_elemwise(indptr1, indptr2, indices1, indices2, values1, values2, substract):
+    """R/RcppExports.R:388 -> src/operators.cpp:539-554."""
+    return _elemwise(MX_OP_SUB if substract else MX_OP_ADD, indptr1, indptr2, indices1, indices2,
+                     values1, values2, np.float64)
+
+
+def logicalor_csr_elemwise(indptr1, indptr2, indices1, indices2, values1, values2, xor_op):
+    """src/operators.cpp:556-571."""
+    return _elemwise(MX_OP_XOR if xor_op else MX_OP_OR, indptr1, indptr2, indices1, indices2,
+                     values1, values2, np.int32)
+
+
+def _copy_rows(indptr, indices, values, rows_take, value_dtype, vdt):
+    lib = _lib.load()
+    p, j, rows = _i32(indptr), _i32(indices), _i32(rows_take)
+    v = None if values is None else np.ascontiguousarray(values, dtype=vdt)
+    res = C.c_void_p()
+    info = ResultInfo()
+    check(lib.mx_copy_csr_rows_begin(ptr(p), C.c_int(p.size - 1), ptr(j), ptr(v), C.c_int(value_dtype),
+                                     C.c_int64(0 if v is None else v.size), ptr(rows), C.c_int64(rows.size),
+                                     C.byref(res), C.byref(info)))
+    return _finish(res, info, empty_values_dtype=vdt if vdt is not None else np.float64)
+
+
+def copy_csr_rows_numeric(indptr, indices, values, rows_take):
+    """R/RcppExports.R:564 -> src/slice.cpp:276-291."""
+    return _copy_rows(indptr, indices, values, rows_take, MX_F64, np.float64)
+
+
+def copy_csr_rows_logical(indptr, indices, values, rows_take):
+    """src/slice.cpp:293-308."""
+    return _copy_rows(indptr, indices, values, rows_take, MX_LGL, np.int32)
+
+
+def copy_csr_rows_binary(indptr, indices, rows_take):
+    """src/slice.cpp:310-324."""
+    return _copy_rows(indptr, indices, None, rows_take, MX_NONE, None)
+
+
+def check_is_seq(indices) -> bool:
+    """src/slice.cpp:25-35."""
+    a = _i32(indices)
+    r = C.c_int(0)
+    check(_lib.load().mx_check_is_seq(ptr(a), C.c_int64(a.size), C.byref(r)))
+    return bool(r.value)
+
+
+def check_is_rev_seq(indices) -> bool:
+    """src/slice.cpp:37-47."""
+    a = _i32(indices)
+    r = C.c_int(0)
+    check(_lib.load().mx_check_is_rev_seq(ptr(a), C.c_int64(a.size), C.byref(r)))
+    return bool(r.value)
+
+
+# ----------------------------------------------------------------------------- sort precondition (§8f-1)
+def check_indices_are_sorted(indptr, indices) -> bool:
+    """Per-row check_is_sorted, src/misc.cpp:118-128."""
+    p, j = _i32(indptr), _i32(indices)
+    r = C.c_int(0)
+    check(_lib.load().mx_check_indices_are_sorted(ptr(p), ptr(j), C.c_int(p.size - 1), C.byref(r)))
+    return bool(r.value)
+
+
+def sort_sparse_indices_inplace(indptr, indices, values=None):
+    """sort_sparse_indices_{numeric,logical}_known_ncol / _binary (src/misc.cpp:333-378): sorts the given
+    int32 `indices` (and `values`) arrays IN PLACE, like the R-side call does."""
+    p = _i32(indptr)
+    if not (isinstance(indices, np.ndarray) and indices.dtype == np.int32 and indices.flags.c_contiguous):
+        raise TypeError("indices must be a contiguous int32 numpy array (sorted in place)")
+    if values is None:
+        vd = MX_NONE
+    elif values.dtype == np.float64:
+        vd = MX_F64
+    elif values.dtype == np.int32:
+        vd = MX_LGL
+    else:
+        raise TypeError("values must be float64 or int32 (R logical)")
+    check(_lib.load().mx_sort_sparse_indices(ptr(p), ptr(indices), ptr(values), C.c_int(vd), C.c_int(p.size - 1)))

@@ -1,0 +1,92 @@
+"""Deterministic synthetic workloads of BASELINE.json / SURVEY.md §8(d).
+
+numpy Generator(PCG64(seed)); fixed nnz per row, distinct column ids per row,
+sorted ascending, approximately uniform over [0, K); values ~ U(-1, 1) f64;
+dense operands ~ N(0, 1).  Seeds: A=1, B=2, rows=3, second merge operand=4.
+Used by bench.py and the tests; generates inputs only (no arithmetic of the path).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED_A, SEED_B, SEED_ROWS, SEED_A2 = 1, 2, 3, 4
+
+
+def _distinct_sorted_columns(rng, m, K, k, chunk=1 << 18):
+    """(m, k) int32, each row strictly increasing in [0, K): sorted draws from [0, K-k] plus 0..k-1."""
+    if k > K:
+        raise ValueError("nnz per row exceeds the number of columns")
+    out = np.empty((m, k), dtype=np.int32)
+    off = np.arange(k, dtype=np.int32)
+    for s in range(0, m, chunk):
+        e = min(m, s + chunk)
+        c = rng.integers(0, K - k + 1, size=(e - s, k), dtype=np.int32)
+        c.sort(axis=1)
+        out[s:e] = c + off
+    return out
+
+
+def csr_fixed(m, K, nnz_row, seed=SEED_A):
+    """CSR with exactly nnz_row entries per row. Returns (indptr int32[m+1], indices int32, values f64)."""
+    rng = np.random.default_rng(np.random.PCG64(seed))
+    cols = _distinct_sorted_columns(rng, m, K, nnz_row)
+    indptr = (np.arange(m + 1, dtype=np.int64) * nnz_row).astype(np.int32)
+    values = rng.uniform(-1.0, 1.0, size=m * nnz_row)
+    return indptr, cols.reshape(-1), values
+
+
+def csr_skewed(m, K, mean_nnz, seed=SEED_A, sigma=1.0, max_nnz=None):
+    """Log-normal row lengths with the given mean (the 'skewed' variant of §8d); some rows empty."""
+    rng = np.random.default_rng(np.random.PCG64(seed))
+    mu = np.log(mean_nnz) - 0.5 * sigma * sigma
+    lens = np.floor(rng.lognormal(mu, sigma, size=m)).astype(np.int64)
+    lens = np.minimum(lens, K if max_nnz is None else min(K, max_nnz))
+    indptr = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(lens, out=indptr[1:])
+    indices = np.empty(indptr[-1], dtype=np.int32)
+    for r in range(m):
+        n = lens[r]
+        if n:
+            indices[indptr[r]:indptr[r + 1]] = np.sort(rng.choice(K, size=n, replace=False))
+    values = rng.uniform(-1.0, 1.0, size=indptr[-1])
+    return indptr.astype(np.int32), indices, values
+
+
+def dense_normal(rows, cols, seed=SEED_B, dtype=np.float64, order="C"):
+    rng = np.random.default_rng(np.random.PCG64(seed))
+    a = rng.standard_normal(size=(rows, cols))
+    return np.asarray(a, dtype=dtype, order=order)
+
+
+def rows_with_replacement(r, m, seed=SEED_ROWS):
+    """cfg3: r draws with replacement from [0, m), unsorted (0-based, as copy_csr_rows receives them)."""
+    rng = np.random.default_rng(np.random.PCG64(seed))
+    return rng.integers(0, m, size=r, dtype=np.int32)
+
+
+def csr_overlapping(indptr, indices, K, nnz_row, share=0.5, seed=SEED_A2):
+    """cfg4 second operand: per row keep ~share of A's columns and draw the rest fresh, so that both
+    the coincident and the one-sided branches of the merge run.  A must have nnz_row entries per row."""
+    rng = np.random.default_rng(np.random.PCG64(seed))
+    m = indptr.size - 1
+    a_cols = indices.reshape(m, nnz_row)
+    keep = int(round(nnz_row * share))
+    fresh = _distinct_sorted_columns(rng, m, K, nnz_row)
+    # first `keep` columns from a random subset of A's columns, the rest fresh; then sort + dedupe per row
+    pick = np.argsort(rng.random((m, nnz_row), dtype=np.float32), axis=1)[:, :keep]
+    shared = np.take_along_axis(a_cols, pick.astype(np.int64), axis=1)
+    cols = np.concatenate([shared, fresh[:, : nnz_row - keep]], axis=1)
+    cols.sort(axis=1)
+    dup = np.zeros_like(cols, dtype=bool)
+    dup[:, 1:] = cols[:, 1:] == cols[:, :-1]
+    lens = (~dup).sum(axis=1)
+    indptr2 = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(lens, out=indptr2[1:])
+    indices2 = cols[~dup]
+    values2 = rng.uniform(-1.0, 1.0, size=indices2.size)
+    return indptr2.astype(np.int32), indices2.astype(np.int32), values2
+
+
+def spmm_algorithmic_bytes(m, K, n, nnz, s_dense):
+    """4(m+1) + 4 nnz + 8 nnz + s*K*n + s*m*n."""
+    return 4 * (m + 1) + 12 * nnz + s_dense * K * n + s_dense * m * n

@@ -1,0 +1,310 @@
+"""ctypes front end of the CPU restatement (oracle/mx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py — never by matrixextra_amd/.
+
+Functions carry the names and argument order of the reference's Rcpp exports
+(src/RcppExports.cpp) and return what the R side receives: a numpy array for
+the dense results, a dict(indptr=, indices=, values=) for the list results.
+Dense matrices are numpy arrays in Fortran (column-major) order, as R holds them.
+
+Parity status: see the header of mx_oracle.c ("parity unpinned by
+reference-run outputs"; pinned by the reference's literal KATs + dense numpy).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmxoracle.so")
+
+NA_INTEGER = np.int32(-2147483648)
+NA_LOGICAL = NA_INTEGER
+NA_REAL = np.frombuffer(np.uint64(0x7FF00000000007A2).tobytes(), dtype=np.float64)[0]
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
+            os.path.join(_HERE, "mx_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.mxo_multiply_csr_elemwise.restype = C.c_size_t
+        _lib.mxo_add_csr_elemwise.restype = C.c_size_t
+        _lib.mxo_copy_csr_rows_size.restype = C.c_size_t
+    return _lib
+
+
+def max_threads() -> int:
+    return int(lib().mxo_max_threads())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _same_buffer(a, b) -> bool:
+    """Pointer identity, the test the reference applies with INTEGER(a) == INTEGER(b)."""
+    return (a is b) or (a.size == b.size and a.size > 0 and
+                        a.__array_interface__["data"][0] == b.__array_interface__["data"][0])
+
+
+# ----------------------------------------------------------------------------- SpMM kernels
+def gemm_csr_drm_as_drm(m, n, indptr, indices, values, B, ldb, C_out, ldc, nthreads=1, use_fma=False):
+    """src/matmul.cpp:118-142. B, C_out flat arrays (float64 or float32)."""
+    f = lib().mxo_gemm_csr_drm_as_drm_f64 if B.dtype == np.float64 else lib().mxo_gemm_csr_drm_as_drm_f32
+    f(C.c_int(m), C.c_int(n), _p(indptr), _p(indices), _p(values), _p(B), C.c_size_t(ldb),
+      _p(C_out), C.c_size_t(ldc), C.c_int(nthreads), C.c_int(int(use_fma)))
+
+
+def gemm_csr_drm_as_dcm(m, n, indptr, indices, values, B, ldb, C_out, ldc, nthreads=1, use_fma=False):
+    """src/matmul.cpp:150-185."""
+    f = lib().mxo_gemm_csr_drm_as_dcm_f64 if B.dtype == np.float64 else lib().mxo_gemm_csr_drm_as_dcm_f32
+    f(C.c_int(m), C.c_int(n), _p(indptr), _p(indices), _p(values), _p(B), C.c_size_t(ldb),
+      _p(C_out), C.c_int(ldc), C.c_int(nthreads), C.c_int(int(use_fma)))
+
+
+def _dense_in(M, dtype):
+    M = np.asarray(M)
+    assert M.ndim == 2
+    return np.asfortranarray(M, dtype=dtype)
+
+
+def tcrossprod_csr_dense(X_indptr, X_indices, X_values, Y_colmajor, nthreads=1, use_fma=False):
+    """tcrossprod_csr_dense<> src/matmul.cpp:316-343: out(nrow X, nrow Y) col-major."""
+    dt = np.float32 if np.asarray(Y_colmajor).dtype == np.float32 else np.float64
+    Y = _dense_in(Y_colmajor, dt)
+    p, j, x = _i32(X_indptr), _i32(X_indices), _f64(X_values)
+    m, n = p.size - 1, Y.shape[0]
+    out = np.zeros((m, n), dtype=dt, order="F")
+    gemm_csr_drm_as_dcm(m, n, p, j, x, Y.reshape(-1, order="F"), Y.shape[0],
+                        out.reshape(-1, order="F"), m, nthreads, use_fma)
+    return out
+
+
+tcrossprod_csr_dense_numeric = tcrossprod_csr_dense
+tcrossprod_csr_dense_float32 = tcrossprod_csr_dense
+
+
+def matmul_dense_csc(X_colmajor, Y_indptr, Y_indices, Y_values, nthreads=1, use_fma=False):
+    """matmul_dense_csc<> src/matmul.cpp:188-219: out(nrow X, ncol Y) col-major."""
+    dt = np.float32 if np.asarray(X_colmajor).dtype == np.float32 else np.float64
+    X = _dense_in(X_colmajor, dt)
+    p, i, x = _i32(Y_indptr), _i32(Y_indices), _f64(Y_values)
+    nrows_X, ncols_Y = X.shape[0], p.size - 1
+    out = np.zeros((nrows_X, ncols_Y), dtype=dt, order="F")
+    gemm_csr_drm_as_drm(ncols_Y, nrows_X, p, i, x, X.reshape(-1, order="F"), nrows_X,
+                        out.reshape(-1, order="F"), nrows_X, nthreads, use_fma)
+    return out
+
+
+matmul_dense_csc_numeric = matmul_dense_csc
+matmul_dense_csc_float32 = matmul_dense_csc
+
+
+def tcrossprod_dense_csr(X_colmajor, Y_indptr, Y_indices, Y_values, nthreads=1, ncols_Y=0, use_fma=False):
+    """tcrossprod_dense_csr<> src/matmul.cpp:254-281: out(nrow X, nrow Y) col-major."""
+    dt = np.float32 if np.asarray(X_colmajor).dtype == np.float32 else np.float64
+    X = _dense_in(X_colmajor, dt)
+    p, j, x = _i32(Y_indptr), _i32(Y_indices), _f64(Y_values)
+    nrows_X, nrows_Y = X.shape[0], p.size - 1
+    out = np.zeros((nrows_X, nrows_Y), dtype=dt, order="F")
+    gemm_csr_drm_as_drm(nrows_Y, nrows_X, p, j, x, X.reshape(-1, order="F"), nrows_X,
+                        out.reshape(-1, order="F"), nrows_X, nthreads, use_fma)
+    return out
+
+
+tcrossprod_dense_csr_numeric = tcrossprod_dense_csr
+tcrossprod_dense_csr_float32 = tcrossprod_dense_csr
+
+
+# ----------------------------------------------------------------------------- SpMV
+def _dvec(kind, X_indptr, X_indices, X_values, y_dense, nthreads):
+    p, j, x = _i32(X_indptr), _i32(X_indices), _f64(X_values)
+    m = p.size - 1
+    if kind == 3:
+        y = np.ascontiguousarray(y_dense, dtype=np.float32)
+        out = np.zeros(m, dtype=np.float32)
+    elif kind == 0:
+        y = _f64(y_dense)
+        out = np.zeros(m, dtype=np.float64)
+    else:
+        y = _i32(y_dense)
+        out = np.zeros(m, dtype=np.float64)
+    lib().mxo_matmul_csr_dvec(C.c_int(m), _p(p), _p(j), _p(x), _p(y), C.c_int(kind), _p(out), C.c_int(nthreads))
+    return out
+
+
+def matmul_csr_dvec_numeric(p, j, x, y, nthreads=1):
+    """src/matmul.cpp:421-435"""
+    return _dvec(0, p, j, x, y, nthreads)
+
+
+def matmul_csr_dvec_integer(p, j, x, y, nthreads=1):
+    """src/matmul.cpp:437-451"""
+    return _dvec(1, p, j, x, y, nthreads)
+
+
+def matmul_csr_dvec_logical(p, j, x, y, nthreads=1):
+    """src/matmul.cpp:453-467"""
+    return _dvec(2, p, j, x, y, nthreads)
+
+
+def matmul_csr_dvec_float32(p, j, x, y, nthreads=1):
+    """src/matmul.cpp:469-483"""
+    return _dvec(3, p, j, x, y, nthreads)
+
+
+# ----------------------------------------------------------------------------- merges
+def _r_logical_vec(which, a, b):
+    f = lib().mxo_r_logical
+    return np.array([f(which, int(u), int(v)) for u, v in zip(a, b)], dtype=np.int32)
+
+
+def _multiply(indptr1, indptr2, indices1, indices2, values1, values2, logical):
+    vdt = np.int32 if logical else np.float64
+    # identical-pattern fast path: operators.cpp:104-132 (indptr/indices returned aliased)
+    if (indptr1.size == indptr2.size and indices1.size == indices2.size and
+            _same_buffer(indptr1, indptr2) and _same_buffer(indices1, indices2)):
+        v1, v2 = np.asarray(values1, dtype=vdt), np.asarray(values2, dtype=vdt)
+        vals = _r_logical_vec(1, v1, v2) if logical else v1 * v2
+        return dict(indptr=indptr1, indices=indices1, values=vals)
+    p1, p2, j1, j2 = _i32(indptr1), _i32(indptr2), _i32(indices1), _i32(indices2)
+    v1, v2 = np.ascontiguousarray(values1, dtype=vdt), np.ascontiguousarray(values2, dtype=vdt)
+    nrows = p1.size - 1
+    cap = max(min(j1.size, j2.size), 1)
+    op = np.zeros(nrows + 1, dtype=np.int32)
+    oj = np.empty(cap, dtype=np.int32)
+    ov = np.empty(cap, dtype=vdt)
+    nnz = lib().mxo_multiply_csr_elemwise(C.c_int(nrows), _p(p1), _p(p2), _p(j1), _p(j2), _p(v1), _p(v2),
+                                          C.c_int(int(logical)), _p(op), _p(oj), _p(ov))
+    return dict(indptr=op, indices=oj[:nnz].copy(), values=ov[:nnz].copy())
+
+
+def multiply_csr_elemwise(indptr1, indptr2, indices1, indices2, values1, values2):
+    """src/operators.cpp:209-222"""
+    return _multiply(indptr1, indptr2, indices1, indices2, values1, values2, False)
+
+
+def logicaland_csr_elemwise(indptr1, indptr2, indices1, indices2, values1, values2):
+    """src/operators.cpp:224-237"""
+    return _multiply(indptr1, indptr2, indices1, indices2, values1, values2, True)
+
+
+def _add(indptr1, indptr2, indices1, indices2, values1, values2, mode, substract):
+    lgl = mode != 0
+    vdt = np.int32 if lgl else np.float64
+    # same-structure fast paths: operators.cpp:343-395
+    if (indices1.size == indices2.size and _same_buffer(indptr1, indptr2) and
+            _same_buffer(indices1, indices2)):
+        if substract and _same_buffer(np.asarray(values1), np.asarray(values2)):
+            # operators.cpp:348-355: zeroed indptr of the same length, EMPTY indices/values
+            return dict(indptr=np.zeros(indptr1.size, dtype=np.int32),
+                        indices=np.zeros(0, dtype=np.int32), values=np.zeros(0, dtype=np.float64))
+        v1, v2 = np.asarray(values1, dtype=vdt), np.asarray(values2, dtype=vdt)
+        if not lgl:
+            vals = v1 - v2 if substract else v1 + v2
+        else:
+            vals = _r_logical_vec(2 if mode == 2 else 0, v1, v2)
+        return dict(indptr=indptr1, indices=indices1, values=vals)
+    p1, p2, j1, j2 = _i32(indptr1), _i32(indptr2), _i32(indices1), _i32(indices2)
+    v1, v2 = np.ascontiguousarray(values1, dtype=vdt), np.ascontiguousarray(values2, dtype=vdt)
+    nrows = p1.size - 1
+    cap = max(j1.size + j2.size, 1)
+    op = np.zeros(nrows + 1, dtype=np.int32)
+    oj = np.empty(cap, dtype=np.int32)
+    ov = np.empty(cap, dtype=vdt)
+    nnz = lib().mxo_add_csr_elemwise(C.c_int(nrows), _p(p1), _p(p2), _p(j1), _p(j2), _p(v1), _p(v2),
+                                     C.c_int(mode), C.c_int(int(substract)), _p(op), _p(oj), _p(ov))
+    return dict(indptr=op, indices=oj[:nnz].copy(), values=ov[:nnz].copy())
+
+
+def add_csr_elemwise(indptr1, indptr2, indices1, indices2, values1, values2, substract):
+    """src/operators.cpp:539-554"""
+    return _add(indptr1, indptr2, indices1, indices2, values1, values2, 0, bool(substract))
+
+
+def logicalor_csr_elemwise(indptr1, indptr2, indices1, indices2, values1, values2, xor_op):
+    """src/operators.cpp:556-571"""
+    return _add(indptr1, indptr2, indices1, indices2, values1, values2, 2 if xor_op else 1, False)
+
+
+# ----------------------------------------------------------------------------- gather
+def _copy_rows(indptr, indices, values, rows_take, vdt):
+    p, j, rows = _i32(indptr), _i32(indices), _i32(rows_take)
+    total = lib().mxo_copy_csr_rows_size(_p(p), _p(rows), C.c_size_t(rows.size))
+    empty_v = np.zeros(0, dtype=vdt if vdt is not None else np.float64)
+    if total == 0:  # slice.cpp:236-240: three empty vectors
+        return dict(indptr=np.zeros(0, dtype=np.int32), indices=np.zeros(0, dtype=np.int32), values=empty_v)
+    has_values = values is not None and np.asarray(values).size > 0
+    v = np.ascontiguousarray(values, dtype=vdt) if has_values else None
+    npz = np.zeros(rows.size + 1, dtype=np.int32)
+    nj = np.empty(total, dtype=np.int32)
+    nv = np.empty(total, dtype=vdt) if has_values else empty_v
+    lib().mxo_copy_csr_rows(_p(p), _p(j), _p(v), C.c_int(v.dtype.itemsize if has_values else 0),
+                            _p(rows), C.c_size_t(rows.size), _p(npz), _p(nj), _p(nv) if has_values else None)
+    return dict(indptr=npz, indices=nj, values=nv)
+
+
+def copy_csr_rows_numeric(indptr, indices, values, rows_take):
+    """src/slice.cpp:276-291"""
+    return _copy_rows(indptr, indices, values, rows_take, np.float64)
+
+
+def copy_csr_rows_logical(indptr, indices, values, rows_take):
+    """src/slice.cpp:293-308"""
+    return _copy_rows(indptr, indices, values, rows_take, np.int32)
+
+
+def copy_csr_rows_binary(indptr, indices, rows_take):
+    """src/slice.cpp:310-324"""
+    return _copy_rows(indptr, indices, None, rows_take, None)
+
+
+def check_is_seq(indices) -> bool:
+    """src/slice.cpp:25-35"""
+    a = _i32(indices)
+    return bool(lib().mxo_check_is_seq(_p(a), C.c_size_t(a.size)))
+
+
+def check_is_rev_seq(indices) -> bool:
+    """src/slice.cpp:37-47"""
+    a = _i32(indices)
+    return bool(lib().mxo_check_is_rev_seq(_p(a), C.c_size_t(a.size)))
+
+
+# ----------------------------------------------------------------------------- sort precondition
+def check_indices_are_sorted(indptr, indices) -> bool:
+    """check_is_sorted per row, src/misc.cpp:118-128 / :283"""
+    p, j = _i32(indptr), _i32(indices)
+    return bool(lib().mxo_check_indices_are_sorted(_p(p), _p(j), C.c_int(p.size - 1)))
+
+
+def sort_sparse_indices(indptr, indices, values=None):
+    """sort_sparse_indices_known_ncol, src/misc.cpp:261-298; returns sorted COPIES."""
+    p = _i32(indptr)
+    j = _i32(indices).copy()
+    v = None if values is None else np.array(values, copy=True)
+    vb = 0 if v is None else v.dtype.itemsize
+    lib().mxo_sort_sparse_indices(_p(p), _p(j), _p(v), C.c_int(vb), C.c_int(p.size - 1))
+    return j, v

@@ -1,0 +1,258 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU restatement on the same seeded inputs.
+
+Bars (BASELINE.json north_star): bit-exact for every integer / index output and for merge / gather
+values; <= 1e-6 relative for f64 SpMM / SpMV (we assert 1e-12, the kernels keep the reference's
+summation order), 1e-5 for f32.  NaN payloads are compared as NaN-ness only.
+"""
+import numpy as np
+import pytest
+
+from conftest import rand_csr
+from matrixextra_amd import exports as G
+from matrixextra_amd import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+NA = int(O.NA_INTEGER)
+F64_RTOL = 1e-12      # well inside the 1e-6 bar
+F32_RTOL = 1e-5
+
+
+def assert_list_equal(g, o, values_exact=True):
+    assert g["indptr"].dtype == np.int32 and g["indices"].dtype == np.int32
+    np.testing.assert_array_equal(g["indptr"], o["indptr"])
+    np.testing.assert_array_equal(g["indices"], o["indices"])
+    assert g["values"].dtype == o["values"].dtype and g["values"].shape == o["values"].shape
+    if g["values"].dtype.kind == "f":
+        nan_g, nan_o = np.isnan(g["values"]), np.isnan(o["values"])
+        np.testing.assert_array_equal(nan_g, nan_o)
+        # bit-exact incl. the sign of zero for everything that is not NaN
+        np.testing.assert_array_equal(g["values"][~nan_g].view(np.int64), o["values"][~nan_o].view(np.int64))
+    else:
+        np.testing.assert_array_equal(g["values"], o["values"])
+
+
+# ----------------------------------------------------------------------------- SpMM
+SPMM_SHAPES = [
+    (100, 50, 20, 0.4),     # test-matmul.R:108-114 "matmult CSR-dense" shape
+    (1, 50, 7, 0.5), (50, 1, 3, 1.0), (33, 70, 1, 0.3),   # 1-row / 1-col edge shapes (test-matmul.R:24-26)
+    (257, 300, 128, 0.05),  # n = 128 (headline slab width), partial row tile
+    (64, 90, 130, 0.1),     # n just past one 128-column slab
+    (31, 40, 256, 0.2), (40, 64, 65, 0.2), (10, 12, 300, 0.5),
+    (5, 3, 9, 0.7),         # n > m  (the reference's scratch overflow case, not copied)
+]
+
+
+@pytest.mark.parametrize("m,K,n,dens", SPMM_SHAPES)
+def test_tcrossprod_csr_dense_numeric(gpu, m, K, n, dens):
+    p, j, x = rand_csr(m, K, dens, seed=m + 7 * n, sorted_cols=False, empty_rows=(0,) if m > 3 else ())
+    Y = np.asfortranarray(np.random.default_rng(n).normal(size=(n, K)))
+    got = G.tcrossprod_csr_dense_numeric(p, j, x, Y, 4)
+    ref = O.tcrossprod_csr_dense_numeric(p, j, x, Y, 2, use_fma=False)
+    assert got.shape == (m, n) and got.flags.f_contiguous and got.dtype == np.float64
+    np.testing.assert_allclose(got, ref, rtol=F64_RTOL, atol=1e-13)
+    # same summation order + FMA on both sides -> bitwise
+    np.testing.assert_array_equal(got, O.tcrossprod_csr_dense_numeric(p, j, x, Y, 1, use_fma=True))
+
+
+@pytest.mark.parametrize("m,K,n,dens", SPMM_SHAPES)
+def test_tcrossprod_csr_dense_float32(gpu, m, K, n, dens):
+    p, j, x = rand_csr(m, K, dens, seed=m + 3 * n, sorted_cols=False)
+    Y = np.asfortranarray(np.random.default_rng(n).normal(size=(n, K)).astype(np.float32))
+    got = G.tcrossprod_csr_dense_float32(p, j, x, Y, 1)
+    ref = O.tcrossprod_csr_dense_float32(p, j, x, Y, 1, use_fma=False)
+    assert got.dtype == np.float32 and got.flags.f_contiguous
+    np.testing.assert_allclose(got, ref, rtol=F32_RTOL, atol=1e-5)
+    np.testing.assert_array_equal(got, O.tcrossprod_csr_dense_float32(p, j, x, Y, 1, use_fma=True))
+
+
+@pytest.mark.parametrize("m,K,n,dens", SPMM_SHAPES[:7])
+def test_dense_csc_and_dense_csr(gpu, m, K, n, dens):
+    # (p, j, x) read as CSC of Y (K x m) for matmul_dense_csc and as CSR of Y (m x K) for tcrossprod_dense_csr
+    p, j, x = rand_csr(m, K, dens, seed=2 * m + n, sorted_cols=False)
+    rng = np.random.default_rng(m)
+    X = np.asfortranarray(rng.normal(size=(n, K)))
+    for gf, of in [(G.matmul_dense_csc_numeric, O.matmul_dense_csc_numeric),
+                   (lambda *a: G.tcrossprod_dense_csr_numeric(*a, K), lambda *a: O.tcrossprod_dense_csr_numeric(*a, K))]:
+        got, ref = gf(X, p, j, x, 1), of(X, p, j, x, 1)
+        assert got.shape == (n, m) and got.flags.f_contiguous
+        np.testing.assert_allclose(got, ref, rtol=F64_RTOL, atol=1e-13)
+    X32 = np.asfortranarray(X.astype(np.float32))
+    np.testing.assert_allclose(G.matmul_dense_csc_float32(X32, p, j, x, 1), O.matmul_dense_csc_float32(X32, p, j, x, 1),
+                               rtol=F32_RTOL, atol=1e-5)
+    np.testing.assert_allclose(G.tcrossprod_dense_csr_float32(X32, p, j, x, 1, K),
+                               O.tcrossprod_dense_csr_float32(X32, p, j, x, 1, K), rtol=F32_RTOL, atol=1e-5)
+
+
+def test_spmm_special_cases(gpu):
+    # duplicates accumulate; unsorted columns; all-empty matrix; NaN / Inf propagate
+    p = np.array([0, 3, 3, 5], dtype=np.int32)
+    j = np.array([1, 1, 0, 1, 0], dtype=np.int32)
+    x = np.array([2.0, 3.0, 1.0, np.inf, np.nan])
+    Y = np.asfortranarray(np.array([[1.0, 10.0], [2.0, 20.0], [0.0, 0.5]]))       # n=3, K=2
+    got, ref = G.tcrossprod_csr_dense_numeric(p, j, x, Y), O.tcrossprod_csr_dense_numeric(p, j, x, Y)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
+    z = G.tcrossprod_csr_dense_numeric(np.zeros(5, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0), Y)
+    assert z.shape == (4, 3) and not z.any()
+    # long rows (> one wavefront of entries) and many rows
+    pl, jl, xl = rand_csr(70, 400, 0.6, seed=99)
+    Yl = np.asfortranarray(np.random.default_rng(1).normal(size=(128, 400)))
+    np.testing.assert_allclose(G.tcrossprod_csr_dense_numeric(pl, jl, xl, Yl), O.tcrossprod_csr_dense_numeric(pl, jl, xl, Yl),
+                               rtol=F64_RTOL, atol=1e-12)
+
+
+def test_spmm_cfg1_shape(gpu):
+    # BASELINE.json configs[0]: 10k x 10k, 16/row, dense 10k x 64 f64
+    p, j, x = synth.csr_fixed(10_000, 10_000, 16)
+    B = synth.dense_normal(10_000, 64)
+    Y = np.asfortranarray(B.T)
+    got = G.tcrossprod_csr_dense_numeric(p, j, x, Y, 8)
+    ref = O.tcrossprod_csr_dense_numeric(p, j, x, Y, O.max_threads())
+    np.testing.assert_allclose(got, ref, rtol=F64_RTOL, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------- SpMV
+@pytest.mark.parametrize("m,K,dens", [(60, 25, 0.3), (1, 10, 0.9), (500, 700, 0.02), (300, 40, 1.0), (64, 2000, 0.2)])
+def test_spmv_all_kinds(gpu, m, K, dens):
+    p, j, x = rand_csr(m, K, dens, seed=m + K, sorted_cols=False, empty_rows=(0,) if m > 2 else ())
+    rng = np.random.default_rng(K)
+    y = rng.normal(size=K)
+    np.testing.assert_allclose(G.matmul_csr_dvec_numeric(p, j, x, y), O.matmul_csr_dvec_numeric(p, j, x, y),
+                               rtol=1e-11, atol=1e-12)
+    yi = rng.integers(-9, 9, size=K).astype(np.int32)
+    yl = rng.integers(0, 2, size=K).astype(np.int32)
+    for k in rng.integers(0, K, size=max(1, K // 10)):
+        yi[k] = NA
+        yl[k] = NA
+    for gf, of, v in [(G.matmul_csr_dvec_integer, O.matmul_csr_dvec_integer, yi),
+                      (G.matmul_csr_dvec_logical, O.matmul_csr_dvec_logical, yl)]:
+        got, ref = gf(p, j, x, v), of(p, j, x, v)
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))      # NA_REAL where an NA entry is touched
+        np.testing.assert_allclose(got[~np.isnan(got)], ref[~np.isnan(ref)], rtol=1e-11, atol=1e-12)
+        na_rows = np.isnan(got)
+        if na_rows.any():                                                  # the NA payload (low word 1954) is kept
+            assert (got[na_rows].view(np.uint64) & 0xFFFFFFFF == 1954).all()
+    yf = y.astype(np.float32)
+    got, ref = G.matmul_csr_dvec_float32(p, j, x, yf), O.matmul_csr_dvec_float32(p, j, x, yf)
+    assert got.dtype == np.float32
+    np.testing.assert_allclose(got, ref, rtol=F32_RTOL, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- merges
+MERGE_CASES = [(100, 35, 0.4, 0.6), (100, 35, 0.05, 0.9), (50, 20, 0.0, 0.5), (50, 20, 0.5, 0.0),
+               (3, 300, 0.9, 0.9), (1000, 64, 0.1, 0.1), (17, 1, 0.5, 0.5), (40, 200, 0.7, 0.02)]
+
+
+@pytest.mark.parametrize("m,K,d1,d2", MERGE_CASES)
+def test_add_sub_mul(gpu, m, K, d1, d2):
+    p1, j1, x1 = rand_csr(m, K, d1, seed=11 + m, empty_rows=(1,) if m > 2 else ())
+    p2, j2, x2 = rand_csr(m, K, d2, seed=12 + K, empty_rows=(1, 2) if m > 3 else ())
+    keep1, keep2 = (x1.copy(), j1.copy(), p1.copy()), (x2.copy(), j2.copy(), p2.copy())
+    for sub in (False, True):
+        assert_list_equal(G.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub), O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub))
+    assert_list_equal(G.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2), O.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2))
+    # inputs are never modified (test-operators.R:21-27 expect_unmodified)
+    for a, b in zip(keep1 + keep2, (x1, j1, p1, x2, j2, p2)):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_merge_special_values_and_fast_paths(gpu):
+    p = np.array([0, 2, 2, 4], dtype=np.int32)
+    j = np.array([1, 3, 0, 2], dtype=np.int32)
+    x = np.array([1.5, -2.0, np.inf, 0.0])
+    x2 = np.array([-1.5, np.nan, -np.inf, 0.0])
+    # general path (different buffers): cancellation keeps an explicit 0; Inf-Inf = NaN; -0 handling
+    for sub in (False, True):
+        assert_list_equal(G.add_csr_elemwise(p, p.copy(), j, j.copy(), x, x2, sub),
+                          O.add_csr_elemwise(p, p.copy(), j, j.copy(), x, x2, sub))
+    assert_list_equal(G.multiply_csr_elemwise(p, p.copy(), j, j.copy(), x, x2),
+                      O.multiply_csr_elemwise(p, p.copy(), j, j.copy(), x, x2))
+    # B-only entries under subtraction are negated, -(0.0) = -0.0
+    pb = np.array([0, 1, 3, 3], dtype=np.int32); jb = np.array([0, 1, 2], dtype=np.int32); xb = np.array([0.0, 5.0, -7.0])
+    assert_list_equal(G.add_csr_elemwise(p, pb, j, jb, x, xb, True), O.add_csr_elemwise(p, pb, j, jb, x, xb, True))
+    # identical-structure fast paths (pointer identity): aliased structure / all-empty result
+    r = G.add_csr_elemwise(p, p, j, j, x, x2, False)
+    assert r["indptr"] is p and r["indices"] is j
+    assert_list_equal(r, O.add_csr_elemwise(p, p, j, j, x, x2, False))
+    r = G.multiply_csr_elemwise(p, p, j, j, x, x2)
+    assert r["indptr"] is p and r["indices"] is j
+    assert_list_equal(r, O.multiply_csr_elemwise(p, p, j, j, x, x2))
+    assert_list_equal(G.add_csr_elemwise(p, p, j, j, x, x, True), O.add_csr_elemwise(p, p, j, j, x, x, True))
+
+
+@pytest.mark.parametrize("m,K,d1,d2", MERGE_CASES[:6])
+def test_logical_or_xor_and(gpu, m, K, d1, d2):
+    p1, j1, x1 = rand_csr(m, K, d1, seed=21 + m, dtype="l")
+    p2, j2, x2 = rand_csr(m, K, d2, seed=22 + K, dtype="l")
+    for xor in (False, True):
+        assert_list_equal(G.logicalor_csr_elemwise(p1, p2, j1, j2, x1, x2, xor),
+                          O.logicalor_csr_elemwise(p1, p2, j1, j2, x1, x2, xor))
+    assert_list_equal(G.logicaland_csr_elemwise(p1, p2, j1, j2, x1, x2), O.logicaland_csr_elemwise(p1, p2, j1, j2, x1, x2))
+    # fast path for logicals
+    assert_list_equal(G.logicalor_csr_elemwise(p1, p1, j1, j1, x1, x1[::-1].copy(), False),
+                      O.logicalor_csr_elemwise(p1, p1, j1, j1, x1, x1[::-1].copy(), False))
+
+
+def test_merge_mid_size_overlap(gpu):
+    # cfg4-shaped, scaled down: fixed 50/row, ~50% shared pattern
+    m, K = 20_000, 20_000
+    p1, j1, x1 = synth.csr_fixed(m, K, 50)
+    p2, j2, x2 = synth.csr_overlapping(p1, j1, K, 50)
+    for sub in (False, True):
+        assert_list_equal(G.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub), O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub))
+    assert_list_equal(G.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2), O.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2))
+
+
+# ----------------------------------------------------------------------------- gather
+def test_copy_csr_rows(gpu):
+    p, j, x = rand_csr(1000, 500, 0.1, seed=7, empty_rows=(10, 11))     # test-slice.R:6-16 fixture shape
+    rng = np.random.default_rng(9)
+    cases = [rng.integers(0, 1000, size=300).astype(np.int32),
+             np.array([999, 999, 10, 0, 999], dtype=np.int32),          # repeats, first/last row (test-slice.R:282-292)
+             np.arange(999, -1, -1, dtype=np.int32),                    # reversed sequence (test-slice.R:243-280)
+             np.array([5], dtype=np.int32),
+             np.array([10, 11, 10], dtype=np.int32),                    # selects no entries: three EMPTY vectors
+             np.zeros(0, dtype=np.int32)]
+    xl = rng.choice(np.array([0, 1, NA], dtype=np.int32), size=x.size)
+    for rows in cases:
+        assert_list_equal(G.copy_csr_rows_numeric(p, j, x, rows), O.copy_csr_rows_numeric(p, j, x, rows))
+        assert_list_equal(G.copy_csr_rows_logical(p, j, xl, rows), O.copy_csr_rows_logical(p, j, xl, rows))
+        assert_list_equal(G.copy_csr_rows_binary(p, j, rows), O.copy_csr_rows_binary(p, j, rows))
+
+
+def test_copy_csr_rows_skewed_lengths(gpu):
+    p, j, x = synth.csr_skewed(5000, 3000, 20, seed=5)
+    rows = synth.rows_with_replacement(4000, 5000)
+    assert_list_equal(G.copy_csr_rows_numeric(p, j, x, rows), O.copy_csr_rows_numeric(p, j, x, rows))
+
+
+def test_check_is_seq(gpu):
+    rng = np.random.default_rng(0)
+    big = np.arange(7, 7 + 100_000, dtype=np.int32)
+    cases = [[], [5], [3, 4, 5], [3, 5, 5], [3, 5, 4, 6], [5, 4, 3], big, big[::-1].copy()]
+    broken = big.copy(); broken[[500, 501]] = broken[[501, 500]]         # same end points, not a sequence
+    cases += [broken, broken[::-1].copy(), rng.integers(0, 100, size=1000).astype(np.int32)]
+    for c in cases:
+        assert G.check_is_seq(c) == O.check_is_seq(c)
+        assert G.check_is_rev_seq(c) == O.check_is_rev_seq(c)
+
+
+# ----------------------------------------------------------------------------- sort precondition (§8f rank 1)
+def test_sort_indices_kat_and_random(gpu):
+    p = np.array([0, 1, 4, 5, 6], dtype=np.int32)                      # tests/testthat/test-utilities.R:32-49
+    j = np.array([4, 2, 1, 4, 1, 0], dtype=np.int32)
+    x = np.array([-0.91, 0.14, -0.12, -0.12, 1.1, 0.66])
+    assert not G.check_indices_are_sorted(p, j)
+    G.sort_sparse_indices_inplace(p, j, x)
+    assert j.tolist() == [4, 1, 2, 4, 1, 0] and x.tolist() == [-0.91, -0.12, 0.14, -0.12, 1.1, 0.66]
+    assert G.check_indices_are_sorted(p, j)
+    for dtype in ("d", "l", "n"):
+        pp, jj, xx = rand_csr(300, 200, 0.2, seed=4, sorted_cols=False, dtype=dtype, empty_rows=(0, 7))
+        js, xs = O.sort_sparse_indices(pp, jj, xx)
+        assert G.check_indices_are_sorted(pp, jj) == O.check_indices_are_sorted(pp, jj)
+        G.sort_sparse_indices_inplace(pp, jj, xx)
+        np.testing.assert_array_equal(jj, js)
+        if xx is not None:
+            np.testing.assert_array_equal(xx, xs)
+        assert G.check_indices_are_sorted(pp, jj)

@@ -1,0 +1,76 @@
+"""Host-side mirror of the R glue: argument checks, messages, index canonicalisation — no GPU needed
+(every case here stops before any compute call, as the reference's R code does)."""
+import numpy as np
+import pytest
+
+import matrixextra_amd as mx
+from matrixextra_amd import matmul, operators, slice as mslice
+from matrixextra_amd.matrices import MatrixExtraError, check_valid_matrix
+
+
+def _csr(m=4, K=5):
+    return mx.dgRMatrix([0, 1, 4, 5, 6][: m + 1], [4, 1, 2, 4, 1, 0], [-0.91, 0.14, -0.12, -0.12, 1.1, 0.66], (m, K))
+
+
+def test_dimension_mismatch_messages():
+    X = _csr()
+    with pytest.raises(MatrixExtraError, match="Matrix dimensions do not match."):       # R/matmul.R:145
+        X @ np.ones((4, 3))
+    with pytest.raises(MatrixExtraError, match="Matrix dimensions do not match."):
+        mx.tcrossprod(X, np.ones((3, 4)))
+    with pytest.raises(MatrixExtraError, match="Matrix-vector dimensions do not match."):  # R/matmul.R:547
+        X @ np.ones(4)
+    Y = mx.dgRMatrix([0, 0, 0, 0, 0], [], [], (4, 6))
+    with pytest.raises(MatrixExtraError, match="in order to add/substract them"):         # R/operators.R:716
+        X + Y
+    with pytest.raises(MatrixExtraError, match="in order to multiply them"):              # R/operators.R:45
+        X * Y
+
+
+def test_check_valid_matrix_negatives():
+    # tests/testthat/test-utilities.R:63-70 style structural negatives that R/utils.R:383-392 catches
+    X = _csr()
+    check_valid_matrix(X)
+    bad = _csr(); bad.p = np.array([0, 1, 4, 5, 100], dtype=np.int32)
+    with pytest.raises(MatrixExtraError, match="bad start/end"):
+        check_valid_matrix(bad)
+    bad = _csr(); bad.p = np.array([0, 1, 4, 5], dtype=np.int32)
+    with pytest.raises(MatrixExtraError, match="doesn't match with dimension"):
+        check_valid_matrix(bad)
+    bad = _csr(); bad.x = bad.x[:-1]
+    with pytest.raises(MatrixExtraError, match="lengths of indices and values differ"):
+        check_valid_matrix(bad)
+
+
+def test_get_indices_integer():
+    g = mslice.get_indices_integer
+    assert g([1, 3, 3], 5, None).tolist() == [1, 3, 3]
+    assert g([-1, -5], 5, None).tolist() == [2, 3, 4]                 # negative = exclusion (R/slice.R:48-49)
+    assert g(np.array([True, False, True, False, True]), 5, None).tolist() == [1, 3, 5]
+    assert g(np.array([True, False]), 5, None).tolist() == [1, 3, 5]  # recycled mask
+    assert g(["b", "a"], 3, ["a", "b", "c"]).tolist() == [2, 1]
+    with pytest.raises(MatrixExtraError, match="not present in matrix"):   # R/slice.R:50-51
+        g([1, 6], 5, None)
+
+
+def test_slice_paths_that_never_reach_native_code():
+    X = _csr()
+    X.Dimnames = [list("abcd"), None]
+    assert mx.subset_csr(X, None) is X
+    e = mx.subset_csr(X, np.zeros(0, dtype=np.int32))
+    assert e.Dim == (0, 5) and e.p.tolist() == [0] and isinstance(e, mx.dgRMatrix)
+    Z = mx.dgRMatrix([0, 0, 0], [], [], (2, 3))
+    e = mx.subset_csr(Z, [2, 1, 2])                                    # no entries at all: R/slice.R:404-421
+    assert e.Dim == (3, 3) and e.p.tolist() == [0, 0, 0, 0]
+
+
+def test_ngRMatrix_identity_shortcuts():
+    # R/operators.R:47-50, :720-740 — decided on the host from pointer identity, no kernel involved
+    p = np.array([0, 1, 2], dtype=np.int32); j = np.array([0, 1], dtype=np.int32)
+    A = mx.ngRMatrix(p, j, None, (2, 2)); B = mx.ngRMatrix(p, j, None, (2, 2))
+    assert operators.multiply_csr_by_csr(A, B) is A
+    assert operators.add_csr_matrices(A, B) is A
+    x = operators.xor_csr_matrices(A, B)
+    assert isinstance(x, mx.lgRMatrix) and x.p.tolist() == [0, 0, 0] and x.j.size == 0
+    s = operators.add_csr_matrices(A, B, True)
+    assert isinstance(s, mx.dgRMatrix) and s.x.tolist() == [2.0, 2.0]

@@ -1,0 +1,255 @@
+"""The CPU restatement (oracle/) against (1) the literal known answers the reference tree holds and
+(2) an independent dense numpy / scipy evaluation on seeded inputs.  CPU-only.
+
+The reference publishes no golden vectors for these routines (its tests draw inputs from R's RNG,
+SURVEY.md §4); the KATs below are the ones that do exist in the tree:
+  * vignettes/Introducing_MatrixExtra.Rmd:164-166 3x3 matrix, with X+X (:186), Xr[1:2,] (:306), Xr*Xr (:316,
+    printed in inst/doc/Introducing_MatrixExtra.html:648)
+  * tests/testthat/test-utilities.R:32-49 index-sort KAT
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import csr_to_dense, rand_csr
+from oracle import oracle as O
+
+NA = int(O.NA_INTEGER)
+
+# vignette 3x3: i=(1,1,2,3), j=(1,3,3,2), x=(1,2,3,4)  ->  CSR
+VIG_P = np.array([0, 2, 3, 4], dtype=np.int32)
+VIG_J = np.array([0, 2, 2, 1], dtype=np.int32)
+VIG_X = np.array([1.0, 2.0, 3.0, 4.0])
+
+
+def test_kat_vignette_add():
+    # X + X  = [[2,.,4],[.,.,6],[.,8,.]]
+    r = O.add_csr_elemwise(VIG_P, VIG_P.copy(), VIG_J, VIG_J.copy(), VIG_X, VIG_X.copy(), False)
+    assert r["indptr"].tolist() == [0, 2, 3, 4]
+    assert r["indices"].tolist() == [0, 2, 2, 1]
+    assert r["values"].tolist() == [2.0, 4.0, 6.0, 8.0]
+
+
+def test_kat_vignette_multiply():
+    # Xr * Xr = [[1,.,4],[.,.,9],[.,16,.]]
+    r = O.multiply_csr_elemwise(VIG_P, VIG_P.copy(), VIG_J, VIG_J.copy(), VIG_X, VIG_X.copy())
+    assert r["indptr"].tolist() == [0, 2, 3, 4]
+    assert r["indices"].tolist() == [0, 2, 2, 1]
+    assert r["values"].tolist() == [1.0, 4.0, 9.0, 16.0]
+
+
+def test_kat_vignette_rows():
+    # Xr[1:2,] is a contiguous run in R (pure-R branch); the gather of rows (0,1) must agree with it,
+    # and a non-sequential pick exercises copy_csr_rows proper
+    r = O.copy_csr_rows_numeric(VIG_P, VIG_J, VIG_X, np.array([0, 1], dtype=np.int32))
+    assert r["indptr"].tolist() == [0, 2, 3] and r["indices"].tolist() == [0, 2, 2]
+    assert r["values"].tolist() == [1.0, 2.0, 3.0]
+    r = O.copy_csr_rows_numeric(VIG_P, VIG_J, VIG_X, np.array([2, 0, 2], dtype=np.int32))
+    assert r["indptr"].tolist() == [0, 1, 3, 4] and r["indices"].tolist() == [1, 0, 2, 1]
+    assert r["values"].tolist() == [4.0, 1.0, 2.0, 4.0]
+
+
+def test_kat_sort_indices():
+    # tests/testthat/test-utilities.R:32-49
+    p = np.array([0, 1, 4, 5, 6], dtype=np.int32)
+    j = np.array([4, 2, 1, 4, 1, 0], dtype=np.int32)
+    x = np.array([-0.91, 0.14, -0.12, -0.12, 1.1, 0.66])
+    assert not O.check_indices_are_sorted(p, j)
+    js, xs = O.sort_sparse_indices(p, j, x)
+    assert js.tolist() == [4, 1, 2, 4, 1, 0]
+    assert xs.tolist() == [-0.91, -0.12, 0.14, -0.12, 1.1, 0.66]
+    assert j.tolist() == [4, 2, 1, 4, 1, 0]          # copy=TRUE leaves the input alone
+    assert O.check_indices_are_sorted(p, js)
+
+
+def test_kat_readme_matrix_spmm():
+    # README.md:17-27 3x4 example matrix [[1,0,0,2... layout used only as a fixed small case vs dense
+    X = np.array([[1.0, 0, 0, 2], [0, 0, 3, 0], [0, 4, 0, 0]])
+    A = sp.csr_matrix(X)
+    B = np.arange(12, dtype=np.float64).reshape(4, 3) - 5
+    out = O.tcrossprod_csr_dense_numeric(A.indptr, A.indices, A.data, B.T.copy())
+    np.testing.assert_array_equal(out, X @ B)
+
+
+@pytest.mark.parametrize("use_fma", [False, True])
+@pytest.mark.parametrize("shape", [(100, 50, 20), (7, 5, 1), (1, 9, 4), (30, 40, 130)])
+def test_spmm_vs_dense(shape, use_fma):
+    m, K, n = shape
+    p, j, x = rand_csr(m, K, 0.4, seed=m * 31 + n, sorted_cols=False, empty_rows=(0,) if m > 2 else ())
+    Ad = csr_to_dense(p, j, x, K)
+    rng = np.random.default_rng(5)
+    B = rng.normal(size=(K, n))
+    expect = Ad @ B
+    got = O.tcrossprod_csr_dense_numeric(p, j, x, np.asfortranarray(B.T), nthreads=2, use_fma=use_fma)
+    np.testing.assert_allclose(got, expect, rtol=1e-12, atol=1e-12)
+    assert got.flags.f_contiguous and got.shape == (m, n)
+    # float32 dense, f64 CSR values
+    got32 = O.tcrossprod_csr_dense_float32(p, j, x, np.asfortranarray(B.T.astype(np.float32)), use_fma=use_fma)
+    assert got32.dtype == np.float32
+    np.testing.assert_allclose(got32, expect, rtol=2e-4, atol=2e-4)
+    # dense %*% CSC  (CSC of Y == CSR of t(Y)): X(n x m) %*% t(A)(m... use A as CSR of t(Y), Y = t(A): K x m
+    Xd = rng.normal(size=(n, K))
+    # tcrossprod(X, A) = X %*% t(A) -> (n x m)
+    got_t = O.tcrossprod_dense_csr_numeric(np.asfortranarray(Xd), p, j, x, nthreads=1, ncols_Y=K, use_fma=use_fma)
+    np.testing.assert_allclose(got_t, Xd @ Ad.T, rtol=1e-12, atol=1e-12)
+    # matmul_dense_csc: Y is (K' x ncolY) CSC; reuse (p,j,x) as CSC of Y with ncol(Y)=m, nrow(Y)=K -> Y = t(A)
+    got_c = O.matmul_dense_csc_numeric(np.asfortranarray(Xd), p, j, x, use_fma=use_fma)
+    np.testing.assert_allclose(got_c, Xd @ Ad.T, rtol=1e-12, atol=1e-12)
+
+
+def test_spmm_duplicates_accumulate_and_empty():
+    p = np.array([0, 3, 3], dtype=np.int32)
+    j = np.array([1, 1, 0], dtype=np.int32)
+    x = np.array([2.0, 3.0, 1.0])
+    B = np.array([[1.0, 2.0], [10.0, 20.0]])
+    out = O.tcrossprod_csr_dense_numeric(p, j, x, np.asfortranarray(B.T))
+    np.testing.assert_array_equal(out, np.array([[51.0, 102.0], [0.0, 0.0]]))
+    # all-empty matrix: early return keeps zeros (matmul.cpp:160-161)
+    out = O.tcrossprod_csr_dense_numeric(np.zeros(4, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0),
+                                         np.asfortranarray(B.T))
+    assert out.shape == (3, 2) and not out.any()
+
+
+def test_spmv_kinds():
+    p, j, x = rand_csr(60, 25, 0.3, seed=3, empty_rows=(5,))
+    Ad = csr_to_dense(p, j, x, 25)
+    rng = np.random.default_rng(1)
+    y = rng.normal(size=25)
+    np.testing.assert_allclose(O.matmul_csr_dvec_numeric(p, j, x, y, 2), Ad @ y, rtol=1e-12, atol=1e-12)
+    yi = rng.integers(-5, 5, size=25).astype(np.int32)
+    np.testing.assert_allclose(O.matmul_csr_dvec_integer(p, j, x, yi), Ad @ yi, rtol=1e-12, atol=1e-12)
+    yl = rng.integers(0, 2, size=25).astype(np.int32)
+    np.testing.assert_allclose(O.matmul_csr_dvec_logical(p, j, x, yl * 7), Ad @ yl, rtol=1e-12, atol=1e-12)
+    yf = y.astype(np.float32)
+    r = O.matmul_csr_dvec_float32(p, j, x, yf)
+    assert r.dtype == np.float32
+    np.testing.assert_allclose(r, Ad @ yf.astype(np.float64), rtol=1e-5, atol=1e-5)
+    # NA_INTEGER / NA_LOGICAL -> NA_REAL in every row that touches the entry
+    yi2 = yi.copy(); yi2[3] = NA
+    r = O.matmul_csr_dvec_integer(p, j, x, yi2)
+    touched = Ad[:, 3] != 0
+    assert np.isnan(r[touched]).all() and not np.isnan(r[~touched]).any()
+    r = O.matmul_csr_dvec_logical(p, j, x, yi2)
+    assert np.isnan(r[touched]).all() and not np.isnan(r[~touched]).any()
+
+
+def test_r_logical_tables():
+    # R: NA&TRUE=NA NA&FALSE=FALSE NA&NA=NA NA|TRUE=TRUE NA|FALSE=NA NA|NA=NA (operators.cpp:8-15)
+    f = O.lib().mxo_r_logical
+    OR, AND, XOR = 0, 1, 2
+    assert f(AND, NA, 1) == NA and f(AND, NA, 0) == 0 and f(AND, NA, NA) == NA
+    assert f(AND, 1, NA) == NA and f(AND, 0, NA) == 0
+    assert f(OR, NA, 1) == 1 and f(OR, NA, 0) == NA and f(OR, NA, NA) == NA
+    assert f(OR, 1, NA) == 1 and f(OR, 0, NA) == NA
+    assert f(XOR, NA, 1) == NA and f(XOR, 1, 0) == 1 and f(XOR, 1, 1) == 0 and f(XOR, 0, 0) == 0
+    assert f(OR, 2, 0) == 1 and f(AND, 2, 3) == 1
+
+
+def _dense_union(p1, j1, x1, p2, j2, x2, K, op):
+    A, B = csr_to_dense(p1, j1, x1, K), csr_to_dense(p2, j2, x2, K)
+    return op(A, B)
+
+
+@pytest.mark.parametrize("dens", [(0.4, 0.6), (0.05, 0.9), (0.0, 0.5), (0.5, 0.0)])
+def test_add_sub_mul_vs_dense_and_structure(dens):
+    m, K = 100, 35
+    p1, j1, x1 = rand_csr(m, K, dens[0], seed=11, empty_rows=(3,))
+    p2, j2, x2 = rand_csr(m, K, dens[1], seed=12, empty_rows=(3, 4))
+    for sub in (False, True):
+        r = O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub)
+        D = csr_to_dense(r["indptr"], r["indices"], r["values"], K)
+        np.testing.assert_array_equal(D, _dense_union(p1, j1, x1, p2, j2, x2, K, np.subtract if sub else np.add))
+        # structure = union of patterns, sorted, unique
+        pat = (csr_to_dense(p1, j1, None, K) + csr_to_dense(p2, j2, None, K)) > 0
+        assert r["indptr"].tolist() == [0] + np.cumsum(pat.sum(axis=1)).tolist()
+        assert r["indices"].tolist() == np.nonzero(pat)[1].tolist()
+    r = O.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2)
+    pat = (csr_to_dense(p1, j1, None, K) * csr_to_dense(p2, j2, None, K)) > 0
+    assert r["indptr"].tolist() == [0] + np.cumsum(pat.sum(axis=1)).tolist()
+    assert r["indices"].tolist() == np.nonzero(pat)[1].tolist()
+    np.testing.assert_array_equal(csr_to_dense(r["indptr"], r["indices"], r["values"], K),
+                                  _dense_union(p1, j1, x1, p2, j2, x2, K, np.multiply))
+
+
+def test_add_keeps_explicit_zero_on_cancellation():
+    p = np.array([0, 2], dtype=np.int32)
+    j = np.array([1, 3], dtype=np.int32)
+    x = np.array([1.5, -2.0])
+    r = O.add_csr_elemwise(p, p.copy(), j, j.copy(), x, x.copy(), True)     # different buffers: general path
+    assert r["indptr"].tolist() == [0, 2] and r["indices"].tolist() == [1, 3] and r["values"].tolist() == [0.0, 0.0]
+    r = O.add_csr_elemwise(p, p, j, j, x, x, True)                          # same buffers: all-empty fast path
+    assert r["indptr"].tolist() == [0, 0] and r["indices"].size == 0 and r["values"].size == 0
+    r = O.add_csr_elemwise(p, p, j, j, x, x.copy(), False)                  # same structure: aliased
+    assert r["indptr"] is p and r["indices"] is j and r["values"].tolist() == [3.0, -4.0]
+    r = O.multiply_csr_elemwise(p, p, j, j, x, x)
+    assert r["indptr"] is p and r["values"].tolist() == [2.25, 4.0]
+
+
+def test_sub_negates_b_only_entries_including_zero_sign():
+    p1 = np.array([0, 1], dtype=np.int32); j1 = np.array([0], dtype=np.int32); x1 = np.array([1.0])
+    p2 = np.array([0, 2], dtype=np.int32); j2 = np.array([1, 2], dtype=np.int32); x2 = np.array([0.0, 5.0])
+    r = O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, True)
+    assert r["indices"].tolist() == [0, 1, 2]
+    assert r["values"][2] == -5.0 and np.signbit(r["values"][1])          # -(0.0) = -0.0 (operators.cpp:434)
+
+
+def test_logical_or_xor_and():
+    m, K = 40, 17
+    p1, j1, x1 = rand_csr(m, K, 0.5, seed=21, dtype="l")
+    p2, j2, x2 = rand_csr(m, K, 0.5, seed=22, dtype="l")
+    f = O.lib().mxo_r_logical
+
+    def dense_l(p, j, x):
+        D = np.full((m, K), -1, dtype=np.int64)          # -1 = structurally absent
+        for r in range(m):
+            D[r, j[p[r]:p[r + 1]]] = x[p[r]:p[r + 1]]
+        return D
+    D1, D2 = dense_l(p1, j1, x1), dense_l(p2, j2, x2)
+    for xor in (False, True):
+        r = O.logicalor_csr_elemwise(p1, p2, j1, j2, x1, x2, xor)
+        Dr = dense_l(r["indptr"], r["indices"], r["values"])
+        for a in range(m):
+            for b in range(K):
+                u, v = D1[a, b], D2[a, b]
+                if u == -1 and v == -1:
+                    assert Dr[a, b] == -1
+                elif u == -1:
+                    assert Dr[a, b] == v                  # one-sided entries are copied verbatim
+                elif v == -1:
+                    assert Dr[a, b] == u
+                else:
+                    assert Dr[a, b] == f(2 if xor else 0, int(u), int(v))
+    r = O.logicaland_csr_elemwise(p1, p2, j1, j2, x1, x2)
+    Dr = dense_l(r["indptr"], r["indices"], r["values"])
+    both = (D1 != -1) & (D2 != -1)
+    assert ((Dr != -1) == both).all()
+    for a, b in zip(*np.nonzero(both)):
+        assert Dr[a, b] == f(1, int(D1[a, b]), int(D2[a, b]))
+
+
+def test_gather_rows():
+    p, j, x = rand_csr(1000, 500, 0.1, seed=7, empty_rows=(10, 11))
+    rng = np.random.default_rng(9)
+    rows = rng.integers(0, 1000, size=300).astype(np.int32)
+    rows[:4] = [999, 999, 10, 0]
+    r = O.copy_csr_rows_numeric(p, j, x, rows)
+    A = sp.csr_matrix((x, j, p), shape=(1000, 500))
+    E = A[rows]
+    assert r["indptr"].tolist() == E.indptr.tolist()
+    assert r["indices"].tolist() == E.indices.tolist()
+    assert r["values"].tolist() == E.data.tolist()
+    rb = O.copy_csr_rows_binary(p, j, rows)
+    assert rb["indices"].tolist() == E.indices.tolist() and rb["values"].size == 0
+    xl = (x > 0).astype(np.int32)
+    rl = O.copy_csr_rows_logical(p, j, xl, rows)
+    assert rl["values"].dtype == np.int32 and rl["values"].tolist() == sp.csr_matrix((xl, j, p), shape=(1000, 500))[rows].data.tolist()
+    # selection with no entries at all: three EMPTY vectors (slice.cpp:236-240)
+    e = O.copy_csr_rows_numeric(p, j, x, np.array([10, 11, 10], dtype=np.int32))
+    assert e["indptr"].size == 0 and e["indices"].size == 0 and e["values"].size == 0
+
+
+def test_check_is_seq():
+    assert O.check_is_seq([]) and O.check_is_seq([5]) and O.check_is_seq([3, 4, 5])
+    assert not O.check_is_seq([3, 5, 5]) and not O.check_is_seq([3, 5, 4, 6]) and not O.check_is_seq([5, 4, 3])
+    assert O.check_is_rev_seq([5, 4, 3]) and O.check_is_rev_seq([1]) and not O.check_is_rev_seq([3, 4, 5])
+    assert not O.check_is_rev_seq([6, 4, 5, 3])

@@ -93,6 +93,21 @@ int mxd_spmm_csr_dense(int m, int n,
                        void *C, size_t ldc,
                        int dense_dtype, int colmajor_out, void *stream);
 
+/* Same product with an explicit kernel choice.  K = number of rows of B (= ncol A).
+ *   algo MX_SPMM_ROWWAVE : one wavefront per row x 1-KiB column chunk (any operands)
+ *   algo MX_SPMM_SLAB    : 128-byte column slabs dealt to the XCDs + column panels sized to one XCD's L2,
+ *                          accumulators in registers (needs 16-B aligned rows of B; npanels > 1 needs
+ *                          rows sorted by column — pass rows_sorted = 1 only when that is known, e.g. from
+ *                          mxd_csr_rows_sorted)
+ *   algo MX_SPMM_AUTO    : SLAB when B is larger than an XCD's L2 and the operands qualify, else ROWWAVE
+ * npanels <= 0 / wg_per_cu <= 0 pick defaults. */
+typedef enum { MX_SPMM_AUTO = 0, MX_SPMM_ROWWAVE = 1, MX_SPMM_SLAB = 2 } mx_spmm_algo;
+int mxd_spmm_csr_dense_ex(int m, int n, int K,
+                          const int32_t *indptr, const int32_t *indices, const double *values,
+                          const void *B, size_t ldb, void *C, size_t ldc,
+                          int dense_dtype, int colmajor_out, int algo, int rows_sorted,
+                          int npanels, int wg_per_cu, void *stream);
+
 /* SpMV  y = A * v  (matmul_csr_dvec<>, src/matmul.cpp:381-419).
  * v_dtype MX_F64 / MX_I32 / MX_LGL -> y f64[m];  MX_F32 -> y f32[m]
  * (float accumulate).  NA_INTEGER / NA_LOGICAL entries contribute NA_REAL. */

@@ -4,6 +4,7 @@
 // CPU fallback: without a usable GPU every call fails with an error.
 #include "mx_common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -83,8 +84,19 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     if (B.upload(B_host, sizeof(real_t) * (size_t)K_rows * ldb)) return 1;
     if (C.alloc(sizeof(real_t) * c_elems)) return 1;
     const int dt = sizeof(real_t) == 8 ? MX_F64 : MX_F32;
-    if (mxd_spmm_csr_dense(m, n, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), B.p, ldb, C.p, ldc, dt,
-                           colmajor ? 1 : 0, nullptr)) return 1;
+    // kernel choice: AUTO unless the MXGPU_SPMM_ALGO / MXGPU_SPMM_PANELS tuning knobs say otherwise
+    int algo = MX_SPMM_AUTO, npanels = 0;
+    if (const char *e = getenv("MXGPU_SPMM_ALGO")) algo = atoi(e);
+    if (const char *e = getenv("MXGPU_SPMM_PANELS")) npanels = atoi(e);
+    int sorted = 0;
+    if (algo == MX_SPMM_SLAB) {
+        // column panels need rows sorted by column id: one pass over the indices on the device
+        DevBuf flag;
+        if (flag.alloc(16)) return 1;
+        if (mxd_csr_rows_sorted(m, A.p.as<int32_t>(), A.j.as<int32_t>(), flag.as<int32_t>(), &sorted, nullptr)) return 1;
+    }
+    if (mxd_spmm_csr_dense_ex(m, n, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), B.p, ldb, C.p, ldc,
+                              dt, colmajor ? 1 : 0, algo, sorted, npanels, 0, nullptr)) return 1;
     MX_HIP(hipMemcpy(C_host, C.p, sizeof(real_t) * c_elems, hipMemcpyDeviceToHost));
     return 0;
 }

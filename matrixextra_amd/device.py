@@ -34,6 +34,18 @@ class DeviceCSR:
     m: int
     K: int
     nnz: int
+    _sorted: bool | None = None
+
+    def rows_sorted(self) -> bool:
+        """check_is_sorted per row on the device (src/misc.cpp:118-128); cached."""
+        if self._sorted is None:
+            lib = _lib.load()
+            ws = torch.empty(4, dtype=torch.int32, device=self.indptr.device)
+            flag = C.c_int(0)
+            check(lib.mxd_csr_rows_sorted(C.c_int(self.m), _dp(self.indptr), _dp(self.indices), _dp(ws),
+                                          C.byref(flag), _stream()))
+            self._sorted = bool(flag.value)
+        return self._sorted
 
     @classmethod
     def from_host(cls, indptr, indices, values, K, device="cuda"):
@@ -47,10 +59,12 @@ class DeviceCSR:
                 None if self.values is None else self.values.cpu().numpy())
 
 
-def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajor: bool = False):
+def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajor: bool = False,
+         algo: int = 0, npanels: int = 0, wg_per_cu: int = 0):
     """C = A @ B with B (K x n) row-major in HBM.  colmajor=False: C row-major (m x n) —
     gemm_csr_drm_as_drm layout; colmajor=True: C column-major (what tcrossprod_csr_dense returns to R),
-    stored as a row-major (n x m) tensor and returned as its transposed view."""
+    stored as a row-major (n x m) tensor and returned as its transposed view.
+    algo: 0 auto, 1 row-wave kernel, 2 slab/panel kernel (include/mxgpu.h mx_spmm_algo)."""
     lib = _lib.load()
     assert B.is_cuda and B.dim() == 2 and B.stride(1) == 1 and B.shape[0] == A.K
     n = int(B.shape[1])
@@ -66,9 +80,11 @@ def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajo
             out = torch.empty((A.m, n), dtype=B.dtype, device=B.device)
         assert out.shape == (A.m, n) and out.is_contiguous()
         ldc = n
-    check(lib.mxd_spmm_csr_dense(C.c_int(A.m), C.c_int(n), _dp(A.indptr), _dp(A.indices), _dp(A.values),
-                                 _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),
-                                 C.c_int(dt), C.c_int(1 if colmajor else 0), _stream()))
+    sorted_rows = A.rows_sorted() if algo != 1 else False
+    check(lib.mxd_spmm_csr_dense_ex(C.c_int(A.m), C.c_int(n), C.c_int(A.K), _dp(A.indptr), _dp(A.indices),
+                                    _dp(A.values), _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),
+                                    C.c_int(dt), C.c_int(1 if colmajor else 0), C.c_int(algo),
+                                    C.c_int(int(sorted_rows)), C.c_int(npanels), C.c_int(wg_per_cu), _stream()))
     return out.t() if colmajor else out
 
 

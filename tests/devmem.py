@@ -1,0 +1,52 @@
+"""Test helper: drive the device-level C-ABI (mxd_*) directly with library-managed device memory
+(mx_dev_malloc / mx_memcpy_*), no torch involved."""
+import ctypes as C
+
+import numpy as np
+
+from matrixextra_amd import _lib
+from matrixextra_amd._lib import check
+
+
+class Dev:
+    """A numpy array mirrored into device memory for the lifetime of the object."""
+
+    def __init__(self, arr=None, nbytes=None):
+        lib = _lib.load()
+        self.host = None if arr is None else np.ascontiguousarray(arr)
+        self.nbytes = int(nbytes if arr is None else self.host.nbytes)
+        self.ptr = C.c_void_p()
+        check(lib.mx_dev_malloc(C.byref(self.ptr), C.c_size_t(max(self.nbytes, 16))))
+        if self.host is not None and self.nbytes:
+            check(lib.mx_memcpy_h2d(self.ptr, C.c_void_p(self.host.ctypes.data), C.c_size_t(self.nbytes), None))
+            check(lib.mx_stream_sync(None))
+
+    def download(self, dtype, shape):
+        lib = _lib.load()
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes:
+            check(lib.mx_memcpy_d2h(C.c_void_p(out.ctypes.data), self.ptr, C.c_size_t(out.nbytes), None))
+            check(lib.mx_stream_sync(None))
+        return out
+
+    def __del__(self):
+        try:
+            _lib.load().mx_dev_free(self.ptr)
+        except Exception:
+            pass
+
+
+def spmm_device(p, j, x, B_rowmajor, colmajor, algo, rows_sorted, npanels=0, wg_per_cu=0):
+    """C = A @ B through mxd_spmm_csr_dense_ex; returns C as an (m, n) numpy array."""
+    lib = _lib.load()
+    m, (K, n) = p.size - 1, B_rowmajor.shape
+    dt = _lib.MX_F64 if B_rowmajor.dtype == np.float64 else _lib.MX_F32
+    dp, dj, dx, dB = Dev(p.astype(np.int32)), Dev(j.astype(np.int32)), Dev(x.astype(np.float64)), Dev(B_rowmajor)
+    dC = Dev(nbytes=m * n * B_rowmajor.dtype.itemsize)
+    check(lib.mx_dev_memset(dC.ptr, 0xFF, C.c_size_t(dC.nbytes), None))      # poison: every element must be written
+    check(lib.mxd_spmm_csr_dense_ex(C.c_int(m), C.c_int(n), C.c_int(K), dp.ptr, dj.ptr, dx.ptr, dB.ptr, C.c_size_t(n),
+                                    dC.ptr, C.c_size_t(m if colmajor else n), C.c_int(dt), C.c_int(int(colmajor)),
+                                    C.c_int(algo), C.c_int(int(rows_sorted)), C.c_int(npanels), C.c_int(wg_per_cu), None))
+    check(lib.mx_stream_sync(None))
+    out = dC.download(B_rowmajor.dtype, (n, m) if colmajor else (m, n))
+    return out.T if colmajor else out

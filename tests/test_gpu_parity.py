@@ -256,3 +256,36 @@ def test_sort_indices_kat_and_random(gpu):
         if xx is not None:
             np.testing.assert_array_equal(xx, xs)
         assert G.check_indices_are_sorted(pp, jj)
+
+
+# ----------------------------------------------------------------------------- SpMM kernel variants (device level)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("colmajor", [False, True])
+@pytest.mark.parametrize("m,K,n,per_row,npanels", [
+    (3000, 5000, 128, 32, 4), (3000, 5000, 128, 32, 1), (1000, 700, 64, 9, 3), (777, 900, 16, 20, 7),
+    (515, 300, 132, 40, 5), (2050, 64, 256, 12, 2), (300, 4000, 8, 70, 16)])
+def test_spmm_slab_kernel_vs_oracle(gpu, dtype, colmajor, m, K, n, per_row, npanels):
+    from devmem import spmm_device
+    p, j, x = synth.csr_fixed(m, K, per_row, seed=m + n)
+    p = p.copy(); p[m // 2 + 1:] -= 0            # keep; empty rows come from the skewed case below
+    B = synth.dense_normal(K, n, dtype=dtype)
+    ref = O.tcrossprod_csr_dense(p, j, x, np.asfortranarray(B.T), 1, use_fma=True)
+    for algo in (1, 2):
+        got = spmm_device(p, j, x, B, colmajor, algo, rows_sorted=True, npanels=npanels)
+        np.testing.assert_array_equal(got, ref)                     # same order + FMA => bitwise
+    # panels forced off for rows of unknown order
+    np.testing.assert_array_equal(spmm_device(p, j, x, B, colmajor, 2, rows_sorted=False, npanels=npanels), ref)
+
+
+def test_spmm_slab_kernel_skewed_rows_and_unsorted(gpu):
+    from devmem import spmm_device
+    p, j, x = synth.csr_skewed(4000, 2500, 24, seed=3)               # empty rows, rows longer than a chunk
+    B = synth.dense_normal(2500, 128)
+    ref = O.tcrossprod_csr_dense(p, j, x, np.asfortranarray(B.T), 1, use_fma=True)
+    for npanels in (1, 2, 5, 33):
+        np.testing.assert_array_equal(spmm_device(p, j, x, B, True, 2, True, npanels), ref)
+    pu, ju, xu = rand_csr(500, 300, 0.2, seed=8, sorted_cols=False)
+    Bu = synth.dense_normal(300, 32)
+    refu = O.tcrossprod_csr_dense(pu, ju, xu, np.asfortranarray(Bu.T), 1, use_fma=True)
+    np.testing.assert_array_equal(spmm_device(pu, ju, xu, Bu, True, 2, rows_sorted=False), refu)
+    np.testing.assert_array_equal(spmm_device(pu, ju, xu, Bu, False, 0, rows_sorted=False), refu)

@@ -113,14 +113,30 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    sharded = None
+    if world > 1:
+        # matrixextra_amd.distributed: equal row blocks -> compute into my slot of C_full, one RCCL all-gather in place
+        from matrixextra_amd import distributed as MD
+
+        def timed_local(local_A, Bt, out, _k=[None]):
+            if _k[0] is not None:
+                ev[_k[0]][0].record()
+            D.spmm(local_A, Bt, out=out, colmajor=False, algo=args.algo, npanels=args.panels, wg_per_cu=args.wg_per_cu)
+            if _k[0] is not None:
+                ev[_k[0]][1].record()
+        timed_local.k = timed_local.__defaults__[0]
+        sharded = MD.RowShardedSpMM(A, [(r * m, (r + 1) * m) for r in range(world)], timed_local)
+
     def step(k=None):
+        if world > 1:
+            timed_local.k[0] = k
+            sharded(B, out=C_full)
+            return
         if k is not None:
             ev[k][0].record()
         D.spmm(A, B, out=C_loc, colmajor=colmajor, algo=args.algo, npanels=args.panels, wg_per_cu=args.wg_per_cu)
         if k is not None:
             ev[k][1].record()
-        if world > 1:
-            dist.all_gather_into_tensor(C_full, C_loc)
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,112 @@
+"""Row-sharded SpMM across the GPUs of one node (new design — the reference is single-process).
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  A is cut into contiguous row
+blocks balanced by nonzeros, B is replicated, every rank computes its block of C with the HIP SpMM kernel and
+the blocks are exchanged with ONE all-gather so that every rank holds the full C.  Row blocks of a
+row-major C are contiguous, so the gathered buffer *is* C (row-major, gemm_csr_drm_as_drm layout); the
+column-major matrix R needs is produced by the strided D2H copy at the boundary.
+
+xGMI is point-to-point (7 links per GPU): an all-gather of s bytes per rank moves (N-1)*s bytes INTO every
+GPU; it is the dominant cost of the sharded product (C is ~10x larger than A+B for the headline shapes).
+
+The compute step is injected (`spmm_local`) so that the partition / exchange logic can be exercised with
+world_size-2 gloo process groups on CPU (tests/test_distributed.py) — the product path passes
+matrixextra_amd.device.spmm, there is no CPU implementation in this package.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def nnz_balanced_row_blocks(indptr: np.ndarray, world: int) -> List[Tuple[int, int]]:
+    """Contiguous row ranges [r0, r1) per rank with (almost) equal numbers of nonzeros.
+    Every rank gets a (possibly empty) range; ranges tile [0, m) in rank order."""
+    indptr = np.asarray(indptr)
+    m = indptr.size - 1
+    nnz = int(indptr[m])
+    cuts = [0]
+    for r in range(1, world):
+        target = nnz * r // world
+        c = int(np.searchsorted(indptr, target, side="left"))
+        cuts.append(min(max(c, cuts[-1]), m))
+    cuts.append(m)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def shard_csr(indptr, indices, values, r0: int, r1: int):
+    """Rows [r0, r1) as a self-contained CSR (indptr rebased to 0). Views where possible."""
+    indptr = np.asarray(indptr)
+    s, e = int(indptr[r0]), int(indptr[r1])
+    p = (indptr[r0:r1 + 1] - indptr[r0]).astype(np.int32)
+    return p, np.asarray(indices)[s:e], None if values is None else np.asarray(values)[s:e]
+
+
+@dataclass
+class RowShardedSpMM:
+    """Per-rank handle: my row block of A (any object `spmm_local` understands) + the global row layout."""
+    local_A: object
+    row_blocks: Sequence[Tuple[int, int]]
+    spmm_local: Callable          # (local_A, B, out) -> None, writes the (rows_local x n) row-major block into `out`
+    group: object = None
+
+    def __post_init__(self):
+        self.world = dist.get_world_size(self.group)
+        self.rank = dist.get_rank(self.group)
+        assert len(self.row_blocks) == self.world
+        self.rows = [b - a for a, b in self.row_blocks]
+        self.max_rows = max(self.rows) if self.rows else 0
+        self.equal = all(r == self.max_rows for r in self.rows)
+
+    def __call__(self, B: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Returns the full C (sum(rows) x n, row-major) on every rank."""
+        n = int(B.shape[1])
+        m_total = sum(self.rows)
+        if out is None:
+            out = torch.empty((m_total, n), dtype=B.dtype, device=B.device)
+        r0, r1 = self.row_blocks[self.rank]
+        if self.equal:
+            # equal blocks: compute straight into my slot of the gathered buffer, one all-gather in place
+            mine = out[r0:r1]
+            self.spmm_local(self.local_A, B, mine)
+            if self.world > 1:
+                dist.all_gather_into_tensor(out, mine, group=self.group) if _has_into_tensor(B) else \
+                    _all_gather_list(out, mine, self.rows, self.group)
+            return out
+        # ragged blocks: gather padded blocks, then compact
+        pad = torch.zeros((self.max_rows, n), dtype=B.dtype, device=B.device)
+        self.spmm_local(self.local_A, B, pad[: r1 - r0])
+        bufs = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(bufs, pad, group=self.group)
+        for rk, (a, b) in enumerate(self.row_blocks):
+            out[a:b] = bufs[rk][: b - a]
+        return out
+
+
+def _has_into_tensor(t: torch.Tensor) -> bool:
+    return t.is_cuda          # gloo has no all_gather_into_tensor on CPU tensors in every build: use the list form there
+
+
+def _all_gather_list(out, mine, rows, group):
+    chunks = list(torch.split(out, rows, dim=0))
+    dist.all_gather(chunks, mine.contiguous(), group=group)
+    # torch.split gives views of `out`, but gloo may write into temporaries: copy back if needed
+    off = 0
+    for c, r in zip(chunks, rows):
+        if c.data_ptr() != out[off:off + r].data_ptr():
+            out[off:off + r] = c
+        off += r
+
+
+def gpu_spmm_local(algo: int = 0):
+    """The product compute step: HIP SpMM on a DeviceCSR, row-major block written in place."""
+    from . import device as D
+
+    def run(local_A, B, out):
+        if local_A.m:
+            D.spmm(local_A, B, out=out, colmajor=False, algo=algo)
+    return run

@@ -1,0 +1,70 @@
+### mxgpu_overlay.R — route MatrixExtra's CSR hot path to the MI355X backend without rebuilding MatrixExtra.
+###
+### The S4 method registrations of the reference (R/matmul.R, R/operators.R, R/slice.R) and its R glue stay
+### exactly as they are: `%*%`, `tcrossprod`, `+`, `-`, `*`, `&`, `|`, `[` on dgRMatrix objects dispatch
+### unchanged.  The glue reaches native code only through the one-line wrappers of R/RcppExports.R
+### (e.g. :148-150 `tcrossprod_csr_dense_numeric <- function(...) .Call(`_MatrixExtra_tcrossprod_csr_dense_numeric`, ...)`).
+### This overlay rebinds those 19 wrappers inside the MatrixExtra namespace so that they `.Call` the routines of
+### the same names registered by mxgpu_r.so (matrixextra_amd/csrc/r_shim.cpp), which forward to libmxgpu.so.
+### Every other native routine (~140 of them) keeps pointing at MatrixExtra's own CPU code.
+###
+### Usage:
+###   library(MatrixExtra)
+###   source("mxgpu_overlay.R")
+###   mxgpu_enable("/path/to/mxgpu_r.so")     # needs libmxgpu.so on the loader path and a visible MI355X
+###   ... X %*% Y, X + Z, X[rows, ] ...       # now run on the GPU
+###   mxgpu_disable()                         # restore the CPU wrappers
+###
+### NOT TESTED in the development image (no R there); see INTEGRATION.md.
+
+.mxgpu_state <- new.env()
+
+.mxgpu_hot_routines <- c(
+    "matmul_dense_csc_numeric", "matmul_dense_csc_float32",
+    "tcrossprod_dense_csr_numeric", "tcrossprod_dense_csr_float32",
+    "tcrossprod_csr_dense_numeric", "tcrossprod_csr_dense_float32",
+    "matmul_csr_dvec_numeric", "matmul_csr_dvec_integer", "matmul_csr_dvec_logical", "matmul_csr_dvec_float32",
+    "multiply_csr_elemwise", "logicaland_csr_elemwise", "add_csr_elemwise", "logicalor_csr_elemwise",
+    "copy_csr_rows_numeric", "copy_csr_rows_logical", "copy_csr_rows_binary",
+    "check_is_seq", "check_is_rev_seq"
+)
+
+mxgpu_enable <- function(shim_path, min_nnz = 0L) {
+    dll <- dyn.load(shim_path)
+    ns <- asNamespace("MatrixExtra")
+    .mxgpu_state$saved <- list()
+    for (fn in .mxgpu_hot_routines) {
+        cpu_fun <- get(fn, envir = ns)
+        .mxgpu_state$saved[[fn]] <- cpu_fun
+        native <- getNativeSymbolInfo(paste0("_MatrixExtra_", fn), dll)
+        gpu_fun <- local({
+            native <- native; cpu_fun <- cpu_fun; min_nnz <- min_nnz
+            function(...) {
+                ## tiny operands are cheaper on the host than a PCIe round trip: optional size gate on the
+                ## length of the first index vector passed (0 = always use the GPU)
+                args <- list(...)
+                if (min_nnz > 0L) {
+                    lens <- vapply(args, length, integer(1L))
+                    if (max(lens) < min_nnz) return(do.call(cpu_fun, args))
+                }
+                do.call(.Call, c(list(native), args))
+            }
+        })
+        formals_cpu <- formals(cpu_fun)
+        unlockBinding(fn, ns)
+        assign(fn, gpu_fun, envir = ns)
+        lockBinding(fn, ns)
+    }
+    invisible(TRUE)
+}
+
+mxgpu_disable <- function() {
+    ns <- asNamespace("MatrixExtra")
+    for (fn in names(.mxgpu_state$saved)) {
+        unlockBinding(fn, ns)
+        assign(fn, .mxgpu_state$saved[[fn]], envir = ns)
+        lockBinding(fn, ns)
+    }
+    .mxgpu_state$saved <- list()
+    invisible(TRUE)
+}

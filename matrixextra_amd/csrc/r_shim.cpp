@@ -1,0 +1,301 @@
+// r_shim.cpp — thin `.Call` translation unit between R and libmxgpu's C-ABI.
+//
+// Exports, for the 19 hot-path routines, exactly the native-routine names and arities that the
+// reference registers in CallEntries[] (src/RcppExports.cpp:2233-2242, 2290-2291, 2297-2298, 2333-2334,
+// 2341-2343), so R code written as `.Call("_MatrixExtra_<fn>", ...)` (R/RcppExports.R) dispatches
+// unchanged, plus mxgpu_register() to add them to a DllInfo.  Written against the plain R C API
+// (no Rcpp): INTEGER()/REAL(), Rf_allocMatrix, Rf_error.
+//
+// This file is NOT part of libmxgpu.so and cannot be compiled in the development image (no R headers):
+// it is built on a machine that has R with
+//     R CMD SHLIB -o mxgpu_r.so r_shim.cpp -L<repo>/matrixextra_amd -lmxgpu -I<repo>/include
+// See INTEGRATION.md.  Everything numerically meaningful lives behind the C-ABI and is tested through it;
+// what is left here is mechanical marshalling:
+//   * inputs are borrowed (no copies unless the SEXP type differs, as Rcpp's input_parameter<> does);
+//   * outputs are fresh R objects; variable-size results use the begin/finish pair so that the D2H copy
+//     lands directly in R-allocated vectors (SURVEY §8b "Ownership");
+//   * identical-structure merges return the INPUT indptr/indices SEXPs (operators.cpp:127-131, :390-394);
+//   * a non-zero status becomes Rf_error(mx_last_error()) after the device handle is released.
+#if defined(__has_include)
+#  if __has_include(<Rinternals.h>)
+#    define MXGPU_HAVE_R 1
+#  endif
+#endif
+
+#ifdef MXGPU_HAVE_R
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+#include "mxgpu.h"
+
+namespace {
+
+struct Protect {          // PROTECT counter that unwinds on scope exit (normal returns only; Rf_error long-jumps
+    int n = 0;            // and R unprotects everything above the .Call frame itself)
+    SEXP operator()(SEXP s) { PROTECT(s); ++n; return s; }
+    ~Protect() { if (n) UNPROTECT(n); }
+};
+
+inline SEXP as_type(SEXP x, SEXPTYPE t, Protect &p) { return TYPEOF(x) == t ? x : p(Rf_coerceVector(x, t)); }
+inline void fail() { Rf_error("%s", mx_last_error()); }
+
+// float32@Data is an INTSXP matrix carrying binary32 bit patterns (R/matmul.R:260,276; matmul.cpp:213)
+inline const float *f32(SEXP x) { return reinterpret_cast<const float *>(INTEGER(x)); }
+inline float *f32w(SEXP x) { return reinterpret_cast<float *>(INTEGER(x)); }
+
+SEXP named_list3(SEXP indptr, SEXP indices, SEXP values, Protect &p)
+{
+    SEXP out = p(Rf_allocVector(VECSXP, 3));
+    SET_VECTOR_ELT(out, 0, indptr);
+    SET_VECTOR_ELT(out, 1, indices);
+    SET_VECTOR_ELT(out, 2, values);
+    SEXP nm = p(Rf_allocVector(STRSXP, 3));
+    SET_STRING_ELT(nm, 0, Rf_mkChar("indptr"));
+    SET_STRING_ELT(nm, 1, Rf_mkChar("indices"));
+    SET_STRING_ELT(nm, 2, Rf_mkChar("values"));
+    Rf_setAttrib(out, R_NamesSymbol, nm);
+    return out;
+}
+
+SEXP finish_list(mx_result *res, const mx_result_info &info, SEXP alias_p, SEXP alias_j, Protect &p)
+{
+    const SEXPTYPE vt = info.values_dtype == MX_F64 ? REALSXP : (info.values_dtype == MX_LGL ? LGLSXP : REALSXP);
+    const R_xlen_t nv = info.values_dtype == MX_NONE ? 0 : (R_xlen_t)info.nnz;
+    SEXP values = p(Rf_allocVector(vt, nv));           // may long-jump on allocation failure:
+    void *vptr = vt == REALSXP ? (void *)REAL(values) : (void *)LOGICAL(values);
+    SEXP indptr = alias_p, indices = alias_j;
+    if (!info.alias_structure) {
+        indptr = p(Rf_allocVector(INTSXP, (R_xlen_t)info.indptr_len));
+        indices = p(Rf_allocVector(INTSXP, (R_xlen_t)info.nnz));
+    }
+    if (mx_result_finish(res, info.alias_structure ? nullptr : INTEGER(indptr),
+                         info.alias_structure ? nullptr : INTEGER(indices), nv ? vptr : nullptr))
+        fail();
+    return named_list3(indptr, indices, values, p);
+}
+
+// R allocation can long-jump; run it with the device handle guarded so it is never leaked
+struct FinishArgs { mx_result *res; mx_result_info info; SEXP alias_p, alias_j; SEXP out; };
+void finish_body(void *d)
+{
+    FinishArgs *a = static_cast<FinishArgs *>(d);
+    Protect p;
+    a->out = finish_list(a->res, a->info, a->alias_p, a->alias_j, p);
+    a->res = nullptr;                      // consumed by mx_result_finish
+    R_PreserveObject(a->out);              // survives p's UNPROTECT; released by the caller
+}
+void finish_cleanup(void *d)
+{
+    FinishArgs *a = static_cast<FinishArgs *>(d);
+    if (a->res) mx_result_discard(a->res);
+}
+SEXP finish_guarded(mx_result *res, const mx_result_info &info, SEXP alias_p, SEXP alias_j)
+{
+    FinishArgs a{res, info, alias_p, alias_j, R_NilValue};
+    R_ExecWithCleanup([](void *d) -> SEXP { finish_body(d); return R_NilValue; }, &a, finish_cleanup, &a);
+    SEXP out = a.out;
+    PROTECT(out);
+    R_ReleaseObject(out);
+    UNPROTECT(1);
+    return out;
+}
+
+SEXP elemwise(int op, SEXP p1, SEXP p2, SEXP j1, SEXP j2, SEXP x1, SEXP x2, SEXPTYPE vt)
+{
+    Protect p;
+    p1 = as_type(p1, INTSXP, p); p2 = as_type(p2, INTSXP, p);
+    j1 = as_type(j1, INTSXP, p); j2 = as_type(j2, INTSXP, p);
+    x1 = as_type(x1, vt, p);     x2 = as_type(x2, vt, p);
+    const void *v1 = vt == REALSXP ? (const void *)REAL(x1) : (const void *)LOGICAL(x1);
+    const void *v2 = vt == REALSXP ? (const void *)REAL(x2) : (const void *)LOGICAL(x2);
+    mx_result *res = nullptr;
+    mx_result_info info;
+    if (mx_csr_elemwise_begin(op, (int)XLENGTH(p1) - 1, INTEGER(p1), INTEGER(p2), INTEGER(j1), INTEGER(j2), v1, v2,
+                              (int64_t)XLENGTH(j1), (int64_t)XLENGTH(j2), &res, &info))
+        fail();
+    return finish_guarded(res, info, p1, j1);
+}
+
+SEXP copy_rows(SEXP indptr, SEXP indices, SEXP values, SEXP rows_take, int dtype)
+{
+    Protect p;
+    indptr = as_type(indptr, INTSXP, p); indices = as_type(indices, INTSXP, p);
+    rows_take = as_type(rows_take, INTSXP, p);
+    const void *v = nullptr;
+    int64_t nv = 0;
+    if (dtype == MX_F64) { values = as_type(values, REALSXP, p); v = REAL(values); nv = XLENGTH(values); }
+    else if (dtype == MX_LGL) { values = as_type(values, LGLSXP, p); v = LOGICAL(values); nv = XLENGTH(values); }
+    mx_result *res = nullptr;
+    mx_result_info info;
+    if (mx_copy_csr_rows_begin(INTEGER(indptr), (int)XLENGTH(indptr) - 1, INTEGER(indices), v, dtype, nv,
+                               INTEGER(rows_take), (int64_t)XLENGTH(rows_take), &res, &info))
+        fail();
+    if (dtype != MX_NONE) info.values_dtype = dtype;     // empty values keep their R type (slice.cpp:246)
+    return finish_guarded(res, info, R_NilValue, R_NilValue);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- CSR x dense --------------------------------------------------------------------------------
+SEXP _MatrixExtra_tcrossprod_csr_dense_numeric(SEXP p_, SEXP j_, SEXP x_, SEXP Y, SEXP nthreads)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); x_ = as_type(x_, REALSXP, p); Y = as_type(Y, REALSXP, p);
+    const int m = (int)XLENGTH(p_) - 1, n = Rf_nrows(Y), K = Rf_ncols(Y);
+    SEXP out = p(Rf_allocMatrix(REALSXP, m, n));
+    if (mx_tcrossprod_csr_dense_numeric(INTEGER(p_), INTEGER(j_), REAL(x_), m, REAL(Y), n, K, Rf_asInteger(nthreads), REAL(out)))
+        fail();
+    return out;
+}
+SEXP _MatrixExtra_tcrossprod_csr_dense_float32(SEXP p_, SEXP j_, SEXP x_, SEXP Y, SEXP nthreads)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); x_ = as_type(x_, REALSXP, p); Y = as_type(Y, INTSXP, p);
+    const int m = (int)XLENGTH(p_) - 1, n = Rf_nrows(Y), K = Rf_ncols(Y);
+    SEXP out = p(Rf_allocMatrix(INTSXP, m, n));
+    if (mx_tcrossprod_csr_dense_float32(INTEGER(p_), INTEGER(j_), REAL(x_), m, f32(Y), n, K, Rf_asInteger(nthreads), f32w(out)))
+        fail();
+    return out;
+}
+SEXP _MatrixExtra_matmul_dense_csc_numeric(SEXP X, SEXP p_, SEXP i_, SEXP x_, SEXP nthreads)
+{
+    Protect p;
+    X = as_type(X, REALSXP, p); p_ = as_type(p_, INTSXP, p); i_ = as_type(i_, INTSXP, p); x_ = as_type(x_, REALSXP, p);
+    const int nr = Rf_nrows(X), nc = Rf_ncols(X), ncY = (int)XLENGTH(p_) - 1;
+    SEXP out = p(Rf_allocMatrix(REALSXP, nr, ncY));
+    if (mx_matmul_dense_csc_numeric(REAL(X), nr, nc, INTEGER(p_), INTEGER(i_), REAL(x_), ncY, Rf_asInteger(nthreads), REAL(out)))
+        fail();
+    return out;
+}
+SEXP _MatrixExtra_matmul_dense_csc_float32(SEXP X, SEXP p_, SEXP i_, SEXP x_, SEXP nthreads)
+{
+    Protect p;
+    X = as_type(X, INTSXP, p); p_ = as_type(p_, INTSXP, p); i_ = as_type(i_, INTSXP, p); x_ = as_type(x_, REALSXP, p);
+    const int nr = Rf_nrows(X), nc = Rf_ncols(X), ncY = (int)XLENGTH(p_) - 1;
+    SEXP out = p(Rf_allocMatrix(INTSXP, nr, ncY));
+    if (mx_matmul_dense_csc_float32(f32(X), nr, nc, INTEGER(p_), INTEGER(i_), REAL(x_), ncY, Rf_asInteger(nthreads), f32w(out)))
+        fail();
+    return out;
+}
+SEXP _MatrixExtra_tcrossprod_dense_csr_numeric(SEXP X, SEXP p_, SEXP j_, SEXP x_, SEXP nthreads, SEXP ncols_Y)
+{
+    Protect p;
+    X = as_type(X, REALSXP, p); p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); x_ = as_type(x_, REALSXP, p);
+    const int nr = Rf_nrows(X), nc = Rf_ncols(X), nrY = (int)XLENGTH(p_) - 1;
+    SEXP out = p(Rf_allocMatrix(REALSXP, nr, nrY));
+    if (mx_tcrossprod_dense_csr_numeric(REAL(X), nr, nc, INTEGER(p_), INTEGER(j_), REAL(x_), nrY, Rf_asInteger(nthreads),
+                                        Rf_asInteger(ncols_Y), REAL(out)))
+        fail();
+    return out;
+}
+SEXP _MatrixExtra_tcrossprod_dense_csr_float32(SEXP X, SEXP p_, SEXP j_, SEXP x_, SEXP nthreads, SEXP ncols_Y)
+{
+    Protect p;
+    X = as_type(X, INTSXP, p); p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); x_ = as_type(x_, REALSXP, p);
+    const int nr = Rf_nrows(X), nc = Rf_ncols(X), nrY = (int)XLENGTH(p_) - 1;
+    SEXP out = p(Rf_allocMatrix(INTSXP, nr, nrY));
+    if (mx_tcrossprod_dense_csr_float32(f32(X), nr, nc, INTEGER(p_), INTEGER(j_), REAL(x_), nrY, Rf_asInteger(nthreads),
+                                        Rf_asInteger(ncols_Y), f32w(out)))
+        fail();
+    return out;
+}
+
+// ---- CSR x dense vector ---------------------------------------------------------------------------
+SEXP _MatrixExtra_matmul_csr_dvec_numeric(SEXP p_, SEXP j_, SEXP x_, SEXP y, SEXP nthreads)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); x_ = as_type(x_, REALSXP, p); y = as_type(y, REALSXP, p);
+    const int m = (int)XLENGTH(p_) - 1;
+    SEXP out = p(Rf_allocVector(REALSXP, m));
+    if (mx_matmul_csr_dvec_numeric(INTEGER(p_), INTEGER(j_), REAL(x_), m, REAL(y), (int)XLENGTH(y), Rf_asInteger(nthreads), REAL(out)))
+        fail();
+    return out;
+}
+SEXP _MatrixExtra_matmul_csr_dvec_integer(SEXP p_, SEXP j_, SEXP x_, SEXP y, SEXP nthreads)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); x_ = as_type(x_, REALSXP, p); y = as_type(y, INTSXP, p);
+    const int m = (int)XLENGTH(p_) - 1;
+    SEXP out = p(Rf_allocVector(REALSXP, m));
+    if (mx_matmul_csr_dvec_integer(INTEGER(p_), INTEGER(j_), REAL(x_), m, INTEGER(y), (int)XLENGTH(y), Rf_asInteger(nthreads), REAL(out)))
+        fail();
+    return out;
+}
+SEXP _MatrixExtra_matmul_csr_dvec_logical(SEXP p_, SEXP j_, SEXP x_, SEXP y, SEXP nthreads)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); x_ = as_type(x_, REALSXP, p); y = as_type(y, LGLSXP, p);
+    const int m = (int)XLENGTH(p_) - 1;
+    SEXP out = p(Rf_allocVector(REALSXP, m));
+    if (mx_matmul_csr_dvec_logical(INTEGER(p_), INTEGER(j_), REAL(x_), m, LOGICAL(y), (int)XLENGTH(y), Rf_asInteger(nthreads), REAL(out)))
+        fail();
+    return out;
+}
+SEXP _MatrixExtra_matmul_csr_dvec_float32(SEXP p_, SEXP j_, SEXP x_, SEXP y, SEXP nthreads)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); x_ = as_type(x_, REALSXP, p); y = as_type(y, INTSXP, p);
+    const int m = (int)XLENGTH(p_) - 1;
+    SEXP out = p(Rf_allocVector(INTSXP, m));
+    if (mx_matmul_csr_dvec_float32(INTEGER(p_), INTEGER(j_), REAL(x_), m, f32(y), (int)XLENGTH(y), Rf_asInteger(nthreads), f32w(out)))
+        fail();
+    return out;
+}
+
+// ---- CSR (+) CSR --------------------------------------------------------------------------------------
+SEXP _MatrixExtra_multiply_csr_elemwise(SEXP p1, SEXP p2, SEXP j1, SEXP j2, SEXP x1, SEXP x2)
+{ return elemwise(MX_OP_MUL, p1, p2, j1, j2, x1, x2, REALSXP); }
+SEXP _MatrixExtra_logicaland_csr_elemwise(SEXP p1, SEXP p2, SEXP j1, SEXP j2, SEXP x1, SEXP x2)
+{ return elemwise(MX_OP_AND, p1, p2, j1, j2, x1, x2, LGLSXP); }
+SEXP _MatrixExtra_add_csr_elemwise(SEXP p1, SEXP p2, SEXP j1, SEXP j2, SEXP x1, SEXP x2, SEXP substract)
+{ return elemwise(Rf_asLogical(substract) ? MX_OP_SUB : MX_OP_ADD, p1, p2, j1, j2, x1, x2, REALSXP); }
+SEXP _MatrixExtra_logicalor_csr_elemwise(SEXP p1, SEXP p2, SEXP j1, SEXP j2, SEXP x1, SEXP x2, SEXP xor_op)
+{ return elemwise(Rf_asLogical(xor_op) ? MX_OP_XOR : MX_OP_OR, p1, p2, j1, j2, x1, x2, LGLSXP); }
+
+// ---- X[rows, ] -------------------------------------------------------------------------------------------
+SEXP _MatrixExtra_copy_csr_rows_numeric(SEXP p_, SEXP j_, SEXP x_, SEXP rows) { return copy_rows(p_, j_, x_, rows, MX_F64); }
+SEXP _MatrixExtra_copy_csr_rows_logical(SEXP p_, SEXP j_, SEXP x_, SEXP rows) { return copy_rows(p_, j_, x_, rows, MX_LGL); }
+SEXP _MatrixExtra_copy_csr_rows_binary(SEXP p_, SEXP j_, SEXP rows) { return copy_rows(p_, j_, R_NilValue, rows, MX_NONE); }
+
+SEXP _MatrixExtra_check_is_seq(SEXP idx)
+{
+    Protect p;
+    idx = as_type(idx, INTSXP, p);
+    int r = 0;
+    if (mx_check_is_seq(INTEGER(idx), (int64_t)XLENGTH(idx), &r)) fail();
+    return Rf_ScalarLogical(r);
+}
+SEXP _MatrixExtra_check_is_rev_seq(SEXP idx)
+{
+    Protect p;
+    idx = as_type(idx, INTSXP, p);
+    int r = 0;
+    if (mx_check_is_rev_seq(INTEGER(idx), (int64_t)XLENGTH(idx), &r)) fail();
+    return Rf_ScalarLogical(r);
+}
+
+#define MX_ENTRY(name, n) {"_MatrixExtra_" #name, (DL_FUNC)&_MatrixExtra_##name, n}
+static const R_CallMethodDef mxgpu_call_entries[] = {
+    MX_ENTRY(matmul_dense_csc_numeric, 5), MX_ENTRY(matmul_dense_csc_float32, 5),
+    MX_ENTRY(tcrossprod_dense_csr_numeric, 6), MX_ENTRY(tcrossprod_dense_csr_float32, 6),
+    MX_ENTRY(tcrossprod_csr_dense_numeric, 5), MX_ENTRY(tcrossprod_csr_dense_float32, 5),
+    MX_ENTRY(matmul_csr_dvec_numeric, 5), MX_ENTRY(matmul_csr_dvec_integer, 5),
+    MX_ENTRY(matmul_csr_dvec_logical, 5), MX_ENTRY(matmul_csr_dvec_float32, 5),
+    MX_ENTRY(multiply_csr_elemwise, 6), MX_ENTRY(logicaland_csr_elemwise, 6),
+    MX_ENTRY(add_csr_elemwise, 7), MX_ENTRY(logicalor_csr_elemwise, 7),
+    MX_ENTRY(copy_csr_rows_numeric, 4), MX_ENTRY(copy_csr_rows_logical, 4), MX_ENTRY(copy_csr_rows_binary, 3),
+    MX_ENTRY(check_is_seq, 1), MX_ENTRY(check_is_rev_seq, 1),
+    {NULL, NULL, 0}
+};
+
+// standalone use: dyn.load("mxgpu_r.so") registers the 19 routines under their reference names
+void R_init_mxgpu_r(DllInfo *dll)
+{
+    R_registerRoutines(dll, NULL, mxgpu_call_entries, NULL, NULL);
+    R_useDynamicSymbols(dll, FALSE);
+}
+
+}  // extern "C"
+#endif  // MXGPU_HAVE_R

@@ -2,7 +2,7 @@
 """Condense a rocprofv3 run (kernel-trace --stats CSVs + separate --pmc passes) into the small summary
 files committed under profiles/.
 
-usage: tools/prof_summary.py <gpurun_out/prof dir> <profiles/prefix> [kernel-substring]
+usage: tools/prof_summary.py <gpurun_out/prof dir> <profiles/prefix> [kernel-substring] [workload-tag]
 
 HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB,
 collected in separate --pmc passes (TCC slot limits); on gfx950 FETCH_SIZE counts the 128-B requests of a
@@ -38,7 +38,8 @@ def main():
             w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                         r["MinNs"], r["MaxNs"]])
     counters, counts = pmc(src, ksub)
-    out = {"kernel_substring": ksub, "counters_avg_per_launch": counters, "launches_sampled": counts}
+    out = {"kernel_substring": ksub, "workload": sys.argv[4] if len(sys.argv) > 4 else "cfg2-default",
+           "counters_avg_per_launch": counters, "launches_sampled": counts}
     k = [r for r in rows if ksub in r["Name"]]
     if k:
         out["kernel"] = k[0]["Name"][:200]

@@ -25,6 +25,7 @@
 //   4(m+1) + 12 nnz + s*K*n + s*m*n   (SURVEY §8d).  The gather of B rows is
 // served by L2 / Infinity Cache (B = 102 MB for the headline config).
 #include "mx_common.h"
+#include <cstdlib>
 
 namespace mx {
 
@@ -321,6 +322,22 @@ __device__ __forceinline__ void slab_chunk(int cnt, int jv, double av, const rea
     slab_fma<real_t, VEC, 7>(cnt, av, b7, acc);
 }
 
+// Timing-only barrier among the workgroups that share blockIdx % 8 (the XCD group): it keeps them on the same
+// column panel so that the panel stays L2-resident.  No data is handed over, so no release/acquire is needed
+// and a timeout is harmless: the spin is bounded and falling through only costs locality, never correctness
+// (all co-resident by grid sizing; a block that is not resident simply makes the others time out).
+__device__ __forceinline__ void xcd_timing_barrier(unsigned *ctr, unsigned target)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < 4096)
+            __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+}
+
 template <typename real_t, int RPG, bool COLMAJOR>
 __global__ __launch_bounds__(SLAB_BLOCK)
 void spmm_slab_kernel(int m, int n,
@@ -328,7 +345,8 @@ void spmm_slab_kernel(int m, int n,
                       const double *__restrict__ values,
                       const real_t *__restrict__ B, size_t ldb,
                       real_t *__restrict__ C, size_t ldc,
-                      int npanels, int panel_cols, int nslabs, int nrowblocks, int c_vec_ok)
+                      int npanels, int panel_cols, int nslabs, int nrowblocks, int c_vec_ok,
+                      unsigned *__restrict__ sync_ctr, int sync_mode)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
     constexpr int W = SLAB_GROUP * VEC;             // columns per slab
@@ -340,7 +358,14 @@ void spmm_slab_kernel(int m, int n,
     const long long total = (long long)nslabs * nrowblocks;
     const long long lo = total * xcd / 8, hi = total * (xcd + 1) / 8;
 
-    for (long long item = lo + wg; item < hi; item += nwg) {
+    // every workgroup of the group runs the same number of steps (idle ones only keep the barrier count right)
+    const int niter = (int)((hi - lo + nwg - 1) / nwg);
+    unsigned *const my_ctr = sync_ctr + xcd * 64;    // one counter per group, 256 B apart
+    unsigned step = 0;
+    for (int it = 0; it < niter; it++) {
+        const long long item_raw = lo + wg + (long long)it * nwg;
+        const bool have = item_raw < hi;
+        const long long item = have ? item_raw : lo;
         const int slab = (int)(item / nrowblocks);
         const int rb = (int)(item % nrowblocks);
         const int row0 = rb * RB + grp * RPG;
@@ -354,13 +379,17 @@ void spmm_slab_kernel(int m, int n,
         for (int r = 0; r < RPG; r++) {
             const int row = row0 + r;
             cur[r] = 0; end[r] = 0;
-            if (row < m) { cur[r] = indptr[row]; end[r] = indptr[row + 1]; }
+            if (have && row < m) { cur[r] = indptr[row]; end[r] = indptr[row + 1]; }
 #pragma unroll
             for (int v = 0; v < VEC; v++) acc[r][v] = 0;
         }
 
         for (int p = 0; p < npanels; p++) {
             const int pend = (p == npanels - 1) ? INT_MAX : (p + 1) * panel_cols;
+            if (sync_mode == 2 || (sync_mode == 1 && p == 0)) {
+                step++;
+                xcd_timing_barrier(my_ctr, step * (unsigned)nwg);
+            }
             unsigned pending = (1u << RPG) - 1u;          // rows that may still have entries in this panel
             while (__ballot(pending != 0) != 0ULL) {
                 int jv[RPG];
@@ -378,7 +407,10 @@ void spmm_slab_kernel(int m, int n,
                 }
 #pragma unroll
                 for (int r = 0; r < RPG; r++) {
-                    const int cnt = __popc(group8_ballot(jv[r] < pend));   // sorted row: in-panel entries are a prefix
+                    const unsigned long long inpanel = __ballot(jv[r] < pend);
+                    if (inpanel == 0ULL) { pending &= ~(1u << r); continue; }   // no group of this wave has entries here
+                    // sorted row: in-panel entries are a prefix of the chunk
+                    const int cnt = __popc((unsigned)(inpanel >> (lane_id() & ~(SLAB_GROUP - 1))) & 0xFFu);
                     // entry 0 of an empty chunk may be INT_MAX: slab_load only dereferences entries < cnt (else row 0)
                     slab_chunk<real_t, VEC>(cnt, jv[r], av[r], B, ldb, lcol, acc[r]);
                     cur[r] += cnt;
@@ -388,7 +420,7 @@ void spmm_slab_kernel(int m, int n,
         }
 
         // epilogue: lane holds columns col..col+VEC-1 of rows row0..row0+RPG-1
-        if (active) {
+        if (active && have) {
             if constexpr (!COLMAJOR) {
 #pragma unroll
                 for (int r = 0; r < RPG; r++)
@@ -427,12 +459,21 @@ static int pick_panels(int K, size_t l2_budget)
     return p;
 }
 
-template <typename real_t>
-static int launch_spmm_slab(int m, int n, int K, const int32_t *indptr, const int32_t *indices,
-                            const double *values, const real_t *B, size_t ldb, real_t *C, size_t ldc,
-                            int colmajor, int npanels, int wg_per_cu, hipStream_t stream)
+// per-device counters for the timing barrier (8 groups x 256 B), allocated once
+static unsigned *slab_sync_workspace()
 {
-    constexpr int RPG = 8;
+    static thread_local unsigned *ws[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!ws[dev] && hipMalloc((void **)&ws[dev], 8 * 64 * sizeof(unsigned)) != hipSuccess) ws[dev] = nullptr;
+    return ws[dev];
+}
+
+template <typename real_t, int RPG>
+static int launch_spmm_slab_rpg(int m, int n, int K, const int32_t *indptr, const int32_t *indices,
+                                const double *values, const real_t *B, size_t ldb, real_t *C, size_t ldc,
+                                int colmajor, int npanels, int wg_per_cu, int sync_mode, hipStream_t stream)
+{
     constexpr int VEC = 16 / (int)sizeof(real_t);
     constexpr int W = SLAB_GROUP * VEC;
     constexpr int RB = SLAB_GROUPS * RPG;
@@ -451,14 +492,36 @@ static int launch_spmm_slab(int m, int n, int K, const int32_t *indptr, const in
     grid = (grid / 8) * 8;
     if (grid < 8) grid = 8;
     const int c_vec_ok = colmajor && (ldc % VEC == 0) && ((uintptr_t)C % 16 == 0);
+    unsigned *sync = slab_sync_workspace();
+    if (!sync) sync_mode = 0;
+    if (sync_mode) MX_HIP(hipMemsetAsync(sync, 0, 8 * 64 * sizeof(unsigned), stream));
     if (colmajor)
         hipLaunchKernelGGL((spmm_slab_kernel<real_t, RPG, true>), dim3((unsigned)grid), dim3(SLAB_BLOCK), 0, stream,
-                           m, n, indptr, indices, values, B, ldb, C, ldc, npanels, panel_cols, nslabs, nrowblocks, c_vec_ok);
+                           m, n, indptr, indices, values, B, ldb, C, ldc, npanels, panel_cols, nslabs, nrowblocks,
+                           c_vec_ok, sync, sync_mode);
     else
         hipLaunchKernelGGL((spmm_slab_kernel<real_t, RPG, false>), dim3((unsigned)grid), dim3(SLAB_BLOCK), 0, stream,
-                           m, n, indptr, indices, values, B, ldb, C, ldc, npanels, panel_cols, nslabs, nrowblocks, c_vec_ok);
+                           m, n, indptr, indices, values, B, ldb, C, ldc, npanels, panel_cols, nslabs, nrowblocks,
+                           c_vec_ok, sync, sync_mode);
     MX_LAUNCH_CHECK();
     return 0;
+}
+
+template <typename real_t>
+static int launch_spmm_slab(int m, int n, int K, const int32_t *indptr, const int32_t *indices,
+                            const double *values, const real_t *B, size_t ldb, real_t *C, size_t ldc,
+                            int colmajor, int npanels, int wg_per_cu, hipStream_t stream)
+{
+    // experiment knobs (tuning only): MXGPU_SLAB_SYNC 0 none / 1 per row-block / 2 per panel; MXGPU_SLAB_RPG 8 / 16
+    int sync_mode = 2, rpg = 8;
+    if (const char *e = getenv("MXGPU_SLAB_SYNC")) sync_mode = atoi(e);
+    if (const char *e = getenv("MXGPU_SLAB_RPG")) rpg = atoi(e);
+    if (npanels <= 1) sync_mode = 0;
+    if (rpg == 16)
+        return launch_spmm_slab_rpg<real_t, 16>(m, n, K, indptr, indices, values, B, ldb, C, ldc, colmajor, npanels,
+                                                wg_per_cu, sync_mode, stream);
+    return launch_spmm_slab_rpg<real_t, 8>(m, n, K, indptr, indices, values, B, ldb, C, ldc, colmajor, npanels,
+                                           wg_per_cu, sync_mode, stream);
 }
 
 // can the slab kernel take these operands?  (16-B aligned rows of B, whole vectors per row;

@@ -48,6 +48,28 @@ __device__ __forceinline__ unsigned long long group_ballot(bool pred)
     }
 }
 
+// lower_bound(key) in a sorted row held one entry per lane (lane u of the group holds tbl = entry u, lanes past
+// the row's end hold INT_MAX): binary search whose probes are cross-lane reads (ds_bpermute), not memory loads.
+// Returns the count of entries < key (0..G) and whether entry[count] == key.
+template <int G>
+__device__ __forceinline__ int group_lower_bound(int tbl, int key, bool &hit)
+{
+    int lo = 0, len = G;
+#pragma unroll
+    for (int it = 0; it < 7; it++) {                  // ceil(log2(64)) + 1 probes at most
+        if ((1 << it) > G) break;
+        const int half = len >> 1;
+        const int probe = __shfl(tbl, lo + half, G);  // all lanes take part; finished lanes ignore the value
+        if (len > 0) {
+            if (probe < key) { lo += half + 1; len -= half + 1; }
+            else len = half;
+        }
+    }
+    const int at = __shfl(tbl, lo < G ? lo : G - 1, G);
+    hit = at == key;                                   // tbl[G-1] < key when lo == G, so no false hit
+    return lo;
+}
+
 template <int G, bool INTERSECT>
 __global__ __launch_bounds__(MERGE_BLOCK)
 void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__restrict__ j1,
@@ -61,6 +83,16 @@ void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
     int s1 = 0, e1 = 0, s2 = 0, e2 = 0;
     if (valid) { s1 = p1[row]; e1 = p1[row + 1]; s2 = p2[row]; e2 = p2[row + 1]; }
     const int n1 = e1 - s1, n2 = e2 - s2;
+    if (__ballot(n1 > G || n2 > G) == 0ULL) {
+        // every row of this wavefront fits its lane group: both rows live in registers
+        const int a = lg < n1 ? j1[s1 + lg] : INT_MAX;
+        const int b = lg < n2 ? j2[s2 + lg] : INT_MAX;
+        bool hit;
+        group_lower_bound<G>(b, a, hit);
+        const int hits = __popcll(group_ballot<G>(hit && lg < n1));
+        if (valid && lg == 0) counts[row] = INTERSECT ? hits : n1 + n2 - hits;
+        return;
+    }
     // search the shorter row's entries in the longer row
     const bool a_short = n1 <= n2;
     const int32_t *__restrict__ q = a_short ? j1 + s1 : j2 + s2;   // queries
@@ -111,6 +143,43 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
     const int32_t *__restrict__ a_idx = j1 + s1;
     const int32_t *__restrict__ b_idx = j2 + s2;
     const unsigned long long below = (1ULL << lg) - 1ULL;   // lg < 64 always
+
+    if (__ballot(n1 > G || n2 > G) == 0ULL) {
+        // register-resident rows: one entry of A and one of B per lane, searches by cross-lane probes
+        const bool va = lg < n1, vb = lg < n2;
+        const int a = va ? a_idx[lg] : INT_MAX;
+        const int b = vb ? b_idx[lg] : INT_MAX;
+        VT xa = VT(0), xb = VT(0);
+        if (va) xa = x1[s1 + lg];
+        if (vb) xb = x2[s2 + lg];
+        bool hit_a, hit_b;
+        const int lb_a = group_lower_bound<G>(b, a, hit_a);     // entries of B below a
+        hit_a = hit_a && va;
+        const VT partner = __shfl(xb, lb_a < G ? lb_a : G - 1, G);
+        const int before_a = __popcll(group_ballot<G>(hit_a) & below);
+        if constexpr (INTERSECT) {
+            if (hit_a) {
+                const int pos = o + before_a;
+                jo[pos] = a;
+                xo[pos] = combine<OP, VT>(xa, partner);
+            }
+        } else {
+            if (va) {
+                const int pos = o + lg + lb_a - before_a;
+                jo[pos] = a;
+                xo[pos] = hit_a ? combine<OP, VT>(xa, partner) : xa;
+            }
+            const int lb_b = group_lower_bound<G>(a, b, hit_b);  // entries of A below b
+            hit_b = hit_b && vb;
+            const int before_b = __popcll(group_ballot<G>(hit_b) & below);
+            if (vb && !hit_b) {
+                const int pos = o + lb_b + lg - before_b;
+                jo[pos] = b;
+                if constexpr (OP == MX_OP_SUB) xo[pos] = -xb; else xo[pos] = xb;
+            }
+        }
+        return;
+    }
 
     // entries of A
     int hits_before = 0;

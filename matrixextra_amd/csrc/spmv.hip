@@ -6,7 +6,7 @@
 // NA_INTEGER / NA_LOGICAL entries contribute NA_REAL (:406-411); a logical
 // entry counts as (bool)y (:411).
 //
-// Design: G lanes of a wavefront own one row (G = power of two picked from the
+// Design: G lanes of a wavefront own SPMV_ROWS consecutive rows (G = power of two picked from the
 // mean row length, 64 = one wavefront per row); lanes stride the row's entries
 // (coalesced (j, a) reads, gathered v[j] reads served by L2 — v is 0.8 MB for
 // the headline config), then a butterfly __shfl_xor reduction inside the group.
@@ -17,48 +17,104 @@ namespace mx {
 
 constexpr int SPMV_BLOCK = 256;
 
+constexpr int SPMV_ROWS = 1;     // rows per lane group (measured on MI355X: 1 -> 0.197 ms, 4 -> 0.221 ms for cfg3:
+                                 // the kernel is bound by the L2->L1 line traffic of the v[j] gather, not by latency)
+
+template <int KIND>
+__device__ __forceinline__ void spmv_term(double a, const void *__restrict__ v_, int j, double &acc, float &accf, int &na)
+{
+    if constexpr (KIND == MX_F64) {
+        acc = __builtin_fma(a, ((const double *)v_)[j], acc);
+    } else if constexpr (KIND == MX_I32) {
+        const int yv = ((const int32_t *)v_)[j];
+        if (yv == MX_NA_INT) na = 1; else acc = __builtin_fma(a, (double)yv, acc);
+    } else if constexpr (KIND == MX_LGL) {
+        const int yv = ((const int32_t *)v_)[j];
+        if (yv == MX_NA_INT) na = 1; else acc += a * (double)(yv != 0);
+    } else {
+        // float accumulator, double product: val += x * y with float val (matmul.cpp:403,413)
+        accf = (float)((double)accf + a * (double)((const float *)v_)[j]);
+    }
+}
+
+// G lanes own SPMV_ROWS consecutive rows; every stage (indptr, (j, a), v[j]) issues its loads unconditionally
+// (clamped addresses, select afterwards) so that they are in flight together.
 template <int G, int KIND>
 __global__ __launch_bounds__(SPMV_BLOCK)
 void spmv_group_kernel(int m, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                        const double *__restrict__ values, const void *__restrict__ v_, void *__restrict__ y_)
 {
+    constexpr int R = SPMV_ROWS;
     const int lg = threadIdx.x % G;
-    const long long row_ll = (long long)blockIdx.x * (SPMV_BLOCK / G) + threadIdx.x / G;
-    const bool valid = row_ll < m;
-    const int row = valid ? (int)row_ll : 0;
-    int s = 0, e = 0;
-    if (valid) { s = indptr[row]; e = indptr[row + 1]; }
-
-    double acc = 0.0;
-    float accf = 0.0f;
-    int na = 0;
-    for (int k = s + lg; k < e; k += G) {
-        const int j = indices[k];
-        const double a = values[k];
-        if constexpr (KIND == MX_F64) {
-            acc = __builtin_fma(a, ((const double *)v_)[j], acc);
-        } else if constexpr (KIND == MX_I32) {
-            const int yv = ((const int32_t *)v_)[j];
-            if (yv == MX_NA_INT) na = 1; else acc = __builtin_fma(a, (double)yv, acc);
-        } else if constexpr (KIND == MX_LGL) {
-            const int yv = ((const int32_t *)v_)[j];
-            if (yv == MX_NA_INT) na = 1; else acc += a * (double)(yv != 0);
-        } else {
-            // float accumulator, double product: val += x * y with float val (matmul.cpp:403,413)
-            accf = (float)((double)accf + a * (double)((const float *)v_)[j]);
+    const long long row0 = ((long long)blockIdx.x * (SPMV_BLOCK / G) + threadIdx.x / G) * R;
+    int s[R], e[R];
+    const int nnz = indptr[m];                    // uniform; entry 0 is a safe address for masked lanes iff nnz > 0
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const long long row = row0 + r;
+        const long long rs = row < m ? row : 0;   // clamped, unconditional loads: all 2R indptr reads in flight at once
+        const int ps = indptr[rs], pe = indptr[rs + 1];
+        s[r] = row < m ? ps : 0;
+        e[r] = row < m ? pe : 0;
+    }
+    if (nnz == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (lg == r % G && row0 + r < m) {
+                if constexpr (KIND == MX_F32) ((float *)y_)[row0 + r] = 0.0f; else ((double *)y_)[row0 + r] = 0.0;
+            }
+        return;
+    }
+    double acc[R];
+    float accf[R];
+    int na[R];
+    int j0[R];
+    double a0[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {                 // stage 1: first chunk of every row
+        acc[r] = 0.0; accf[r] = 0.0f; na[r] = 0;
+        const int k = s[r] + lg;
+        const bool ok = k < e[r];
+        const int ks = ok ? k : 0;                // unconditional (clamped) loads, selected afterwards
+        const int jl = indices[ks];
+        const double al = values[ks];
+        j0[r] = ok ? jl : -1;
+        a0[r] = al;
+    }
+    {                                             // stage 2: gathers of v, again unconditional + select
+        double accn[R];
+        float accfn[R];
+        int nan_[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            accn[r] = 0.0; accfn[r] = 0.0f; nan_[r] = 0;
+            spmv_term<KIND>(a0[r], v_, j0[r] >= 0 ? j0[r] : 0, accn[r], accfn[r], nan_[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (j0[r] >= 0) { acc[r] = accn[r]; accf[r] = accfn[r]; na[r] = nan_[r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)                   // rows longer than one group width
+        for (int k = s[r] + G + lg; k < e[r]; k += G)
+            spmv_term<KIND>(values[k], v_, indices[k], acc[r], accf[r], na[r]);
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if constexpr (KIND == MX_F32) accf[r] += __shfl_xor(accf[r], off, G);
+            else {
+                acc[r] += __shfl_xor(acc[r], off, G);
+                if constexpr (KIND == MX_I32 || KIND == MX_LGL) na[r] |= __shfl_xor(na[r], off, G);
+            }
         }
     }
 #pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) {
-        if constexpr (KIND == MX_F32) accf += __shfl_xor(accf, off, G);
-        else {
-            acc += __shfl_xor(acc, off, G);
-            if constexpr (KIND == MX_I32 || KIND == MX_LGL) na |= __shfl_xor(na, off, G);
+    for (int r = 0; r < R; r++) {
+        if (lg == r % G && row0 + r < m) {
+            if constexpr (KIND == MX_F32) ((float *)y_)[row0 + r] = accf[r];
+            else ((double *)y_)[row0 + r] = na[r] ? na_real() : acc[r];
         }
-    }
-    if (valid && lg == 0) {
-        if constexpr (KIND == MX_F32) ((float *)y_)[row] = accf;
-        else ((double *)y_)[row] = na ? na_real() : acc;
     }
 }
 
@@ -68,7 +124,7 @@ static int launch_spmv(int G, int m, const int32_t *indptr, const int32_t *indic
 {
 #define MX_SPMV_CASE(GG)                                                                        \
     case GG: {                                                                                  \
-        const unsigned grid = (unsigned)ceil_div(m, SPMV_BLOCK / GG);                           \
+        const unsigned grid = (unsigned)ceil_div(m, (SPMV_BLOCK / GG) * SPMV_ROWS);             \
         hipLaunchKernelGGL((spmv_group_kernel<GG, KIND>), dim3(grid), dim3(SPMV_BLOCK), 0, st,  \
                            m, indptr, indices, values, v, y);                                   \
         break;                                                                                  \

@@ -80,6 +80,9 @@ def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajo
             out = torch.empty((A.m, n), dtype=B.dtype, device=B.device)
         assert out.shape == (A.m, n) and out.is_contiguous()
         ldc = n
+    if A.nnz == 0:                       # reference early-out (matmul.cpp:128-129,160-161): all zeros
+        out.zero_()
+        return out.t() if colmajor else out
     sorted_rows = A.rows_sorted() if algo != 1 else False
     check(lib.mxd_spmm_csr_dense_ex(C.c_int(A.m), C.c_int(n), C.c_int(A.K), _dp(A.indptr), _dp(A.indices),
                                     _dp(A.values), _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),

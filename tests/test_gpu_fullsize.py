@@ -1,0 +1,132 @@
+"""Full-size runs of BASELINE.json's configs on the GPU, checked through size-independent properties
+(the CPU oracle would need minutes per case at these sizes):
+
+  cfg2  SpMM 1M x 100k, 32/row, f64 x dense 100k x 128:
+        column checksum  1^T (A B) == (A^T 1)^T B   (O(nnz + K n) on the host)
+        linearity        A (B1 + 2 B2) == A B1 + 2 A B2
+        exact rows       the first and last 512 rows against the oracle
+  cfg3  SpMV + gather of 200k random rows (with replacement):
+        y == (A B)[:, 0] of a one-column SpMM; sum(y) checksum;  gathered row sums == row sums[rows];
+        indptr of the result == cumsum of the picked row lengths (bit-exact)
+  cfg4  CSR + CSR, CSR - CSR, CSR * CSR on 2M x 2M, 50/row (nnz 1e8 each, ~50 % shared pattern):
+        rows sorted & unique; nnz(A+B) + nnz(A*B) == nnz(A) + nnz(B) (inclusion-exclusion);
+        sum(values(A+B)) == sum(A) + sum(B); (A-B) has the same structure as (A+B); A + A == 2 A exactly
+        (general path); sampled rows bit-exact against the oracle
+"""
+import numpy as np
+import pytest
+import torch
+
+from matrixextra_amd import _lib, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg2(gpu):
+    from matrixextra_amd import device as D
+    m, K, n = 1_000_000, 100_000, 128
+    p, j, x = synth.csr_fixed(m, K, 32)
+    A = D.DeviceCSR.from_host(p, j, x, K)
+    return dict(D=D, m=m, K=K, n=n, p=p, j=j, x=x, A=A)
+
+
+def test_cfg2_spmm_properties(cfg2):
+    D, m, K, n, p, j, x, A = (cfg2[k] for k in ("D", "m", "K", "n", "p", "j", "x", "A"))
+    B1 = synth.dense_normal(K, n, seed=2)
+    B2 = synth.dense_normal(K, n, seed=22)
+    tB1, tB2 = torch.from_numpy(B1).cuda(), torch.from_numpy(B2).cuda()
+    for colmajor in (True, False):
+        C1 = D.spmm(A, tB1, colmajor=colmajor)
+        # column checksum: w = A^T 1 (length K), 1^T C = w^T B
+        w = np.bincount(j, weights=x, minlength=K)
+        expect = w @ B1
+        got = C1.sum(dim=0).cpu().numpy()
+        scale = np.abs(x).sum() * np.abs(B1).max()
+        assert np.max(np.abs(got - expect)) <= 1e-12 * scale
+        # exact rows at both ends (same summation order + FMA as the oracle => bitwise)
+        for r0 in (0, m - 512):
+            rows = slice(r0, r0 + 512)
+            ref = np.zeros(512 * n)
+            pp = (p[r0:r0 + 513] - p[r0]).astype(np.int32)
+            O.gemm_csr_drm_as_drm(512, n, pp, j[p[r0]:p[r0 + 512]].copy(), x[p[r0]:p[r0 + 512]].copy(),
+                                  B1.reshape(-1), n, ref, n, 4, True)
+            np.testing.assert_array_equal(C1[rows].cpu().numpy(), ref.reshape(512, n))
+    # linearity
+    C1 = D.spmm(A, tB1)
+    C2 = D.spmm(A, tB2)
+    C12 = D.spmm(A, tB1 + 2.0 * tB2)
+    err = (C12 - (C1 + 2.0 * C2)).abs().max().item()
+    assert err <= 1e-11 * (C1.abs().max().item() + 2 * C2.abs().max().item())
+
+
+def test_cfg3_spmv_and_gather(cfg2):
+    D, m, K, p, j, x, A = (cfg2[k] for k in ("D", "m", "K", "p", "j", "x", "A"))
+    v = synth.dense_normal(K, 1, seed=5).reshape(-1)
+    tv = torch.from_numpy(v).cuda()
+    y = D.spmv(A, tv)
+    y_mm = D.spmm(A, tv.reshape(K, 1).contiguous())          # independent kernel (row-wave, VEC=1 path)
+    assert (y - y_mm[:, 0]).abs().max().item() <= 1e-12 * np.abs(x).max() * np.abs(v).max() * 32
+    w = np.bincount(j, weights=x, minlength=K)
+    assert abs(y.sum().item() - w @ v) <= 1e-9 * np.abs(x).sum() * np.abs(v).max()
+    # float32 / integer kinds on the full matrix against the f64 result
+    yf = D.spmv(A, tv.float())
+    assert yf.dtype == torch.float32 and (yf.double() - y).abs().max().item() <= 1e-4 * y.abs().max().item()
+    vi = torch.randint(-5, 6, (K,), dtype=torch.int32, device="cuda")
+    yi = D.spmv(A, vi, v_dtype=_lib.MX_I32)
+    yi_ref = D.spmv(A, vi.double())
+    assert torch.equal(yi, yi_ref)
+    # gather of 200k random rows
+    rows = synth.rows_with_replacement(200_000, m)
+    G = D.csr_gather_rows(A, torch.from_numpy(rows).cuda())
+    gp, gj, gx = G.to_host()
+    lens = (p[1:] - p[:-1])[rows]
+    np.testing.assert_array_equal(gp, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32))
+    assert G.nnz == int(lens.sum()) == 6_400_000
+    take = np.random.default_rng(0).integers(0, rows.size, size=2000)
+    for t in take:
+        r = rows[t]
+        np.testing.assert_array_equal(gj[gp[t]:gp[t + 1]], j[p[r]:p[r + 1]])
+        np.testing.assert_array_equal(gx[gp[t]:gp[t + 1]], x[p[r]:p[r + 1]])
+    rowsum = np.add.reduceat(x, p[:-1])
+    np.testing.assert_allclose(np.add.reduceat(gx, gp[:-1]), rowsum[rows], rtol=0, atol=0)
+
+
+def test_cfg4_merge_properties(gpu):
+    from matrixextra_amd import device as D
+    m = K = 2_000_000
+    p1, j1, x1 = synth.csr_fixed(m, K, 50)
+    p2, j2, x2 = synth.csr_overlapping(p1, j1, K, 50)
+    A, B = D.DeviceCSR.from_host(p1, j1, x1, K), D.DeviceCSR.from_host(p2, j2, x2, K)
+    S = D.csr_elemwise(_lib.MX_OP_ADD, A, B)
+    Dm = D.csr_elemwise(_lib.MX_OP_SUB, A, B)
+    M = D.csr_elemwise(_lib.MX_OP_MUL, A, B)
+    assert S.nnz + M.nnz == A.nnz + B.nnz                       # inclusion-exclusion on the patterns
+    assert torch.equal(S.indptr, Dm.indptr) and torch.equal(S.indices, Dm.indices)
+    assert abs(S.values.sum().item() - (x1.sum() + x2.sum())) <= 1e-9 * (np.abs(x1).sum() + np.abs(x2).sum())
+    assert abs(Dm.values.sum().item() - (x1.sum() - x2.sum())) <= 1e-9 * (np.abs(x1).sum() + np.abs(x2).sum())
+    for R in (S, M):                                            # rows sorted, unique
+        assert D.DeviceCSR(R.indptr, R.indices, None, m, K, R.nnz).rows_sorted()
+        d = R.indices[1:] - R.indices[:-1]
+        starts = torch.zeros(R.nnz, dtype=torch.bool, device="cuda")
+        starts[R.indptr[1:-1].long().clamp(max=R.nnz - 1)] = True
+        assert bool(((d > 0) | starts[1:]).all())
+    # A + A' (same pattern, different buffers => general path) == 2 A exactly
+    A2 = D.DeviceCSR(A.indptr.clone(), A.indices.clone(), A.values.clone(), m, K, A.nnz)
+    T = D.csr_elemwise(_lib.MX_OP_ADD, A, A2)
+    assert torch.equal(T.indptr, A.indptr) and torch.equal(T.indices, A.indices) and torch.equal(T.values, 2 * A.values)
+    # sampled row blocks bit-exact against the oracle
+    sp, sj, sx = S.to_host()
+    mp_, mj, mx_ = M.to_host()
+    for r0 in (0, 777_777, m - 1000):
+        r1 = r0 + 1000
+        a = (p1[r0:r1 + 1] - p1[r0]).astype(np.int32), j1[p1[r0]:p1[r1]].copy(), x1[p1[r0]:p1[r1]].copy()
+        b = (p2[r0:r1 + 1] - p2[r0]).astype(np.int32), j2[p2[r0]:p2[r1]].copy(), x2[p2[r0]:p2[r1]].copy()
+        o = O.add_csr_elemwise(a[0], b[0], a[1], b[1], a[2], b[2], False)
+        np.testing.assert_array_equal(sp[r0:r1 + 1] - sp[r0], o["indptr"])
+        np.testing.assert_array_equal(sj[sp[r0]:sp[r1]], o["indices"])
+        np.testing.assert_array_equal(sx[sp[r0]:sp[r1]], o["values"])
+        o = O.multiply_csr_elemwise(a[0], b[0], a[1], b[1], a[2], b[2])
+        np.testing.assert_array_equal(mj[mp_[r0]:mp_[r1]], o["indices"])
+        np.testing.assert_array_equal(mx_[mp_[r0]:mp_[r1]], o["values"])

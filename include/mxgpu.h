@@ -150,6 +150,36 @@ int mxd_csr_gather_fill(int r, const int32_t *indptr, const int32_t *indices, co
                         int32_t *new_indices, void *new_values, int value_dtype,
                         int64_t nnz_out /* lanes-per-row hint, -1 = unknown */, void *stream);
 
+/* Column-filtering slices.  Same count -> scan -> fill shape as the row gather; workspace of
+ * mxd_gather_workspace_bytes(r).  avg_row_len (mean entries per source row) only steers the lanes-per-row choice.
+ *   colrange: keep min_col <= col <= max_col, re-based to min_col, input order kept; values come out as f64
+ *             whatever the input kind (copy_csr_rows_col_seq_template, src/slice.cpp:326-383)
+ *   colmap:   arbitrary selector through a dense map built by mxd_colmap_build: start[ncol_map+1], pos[n] with
+ *             pos[start[c] .. start[c+1]) = ascending positions of column c in cols_take
+ *             (copy_csr_arbitrary_template, src/slice.cpp:449-578; re-order rows afterwards with mxd_csr_sort_rows
+ *             unless cols_take is non-decreasing) */
+int mxd_csr_colrange_count(int r, const int32_t *indptr, const int32_t *indices, const int32_t *rows_take,
+                           int min_col, int max_col, double avg_row_len, int32_t *new_indptr,
+                           void *workspace, int64_t *nnz_out_host, void *stream);
+int mxd_csr_colrange_fill(int r, const int32_t *indptr, const int32_t *indices, const void *values,
+                          int value_dtype, const int32_t *rows_take, int min_col, int max_col,
+                          double avg_row_len, const int32_t *new_indptr, int32_t *new_indices,
+                          double *new_values, void *stream);
+size_t mxd_colmap_workspace_bytes(int ncol_map);
+int mxd_colmap_build(const int32_t *cols_take, int64_t n, int ncol_map, int32_t *start, int32_t *pos,
+                     void *workspace, void *stream);
+int mxd_csr_colmap_count(int r, const int32_t *indptr, const int32_t *indices, const int32_t *rows_take,
+                         int ncol_map, const int32_t *start, double avg_row_len, int32_t *new_indptr,
+                         void *workspace, int64_t *nnz_out_host, void *stream);
+int mxd_csr_colmap_fill(int r, const int32_t *indptr, const int32_t *indices, const void *values,
+                        int value_dtype, const int32_t *rows_take, int ncol_map, const int32_t *start,
+                        const int32_t *pos, double avg_row_len, const int32_t *new_indptr,
+                        int32_t *new_indices, void *new_values, void *stream);
+/* col -> ncol-1-col and each row reversed, in place (reverse_columns_inplace, src/slice.cpp:142-170) */
+int mxd_csr_reverse_columns(int m, int64_t nnz, const int32_t *indptr, int32_t *indices, void *values,
+                            int value_dtype, int ncol, void *stream);
+int mxd_reversed_iota(int n, int32_t *out, void *stream);   /* out[i] = n-1-i: row list of reverse_rows */
+
 /* check_is_seq / check_is_rev_seq (src/slice.cpp:25-47) on a device vector.
  * *flag_host receives 0/1 after an internal stream sync. */
 int mxd_check_is_seq(const int32_t *idx, int64_t n, int reversed, int32_t *workspace4,
@@ -230,7 +260,8 @@ int mx_matmul_csr_dvec_float32(const int32_t *X_indptr, const int32_t *X_indices
 typedef struct mx_result mx_result;
 typedef struct {
     int64_t indptr_len;    /* length of the indptr vector to allocate           */
-    int64_t nnz;           /* length of indices (and of values if it has any)   */
+    int64_t nnz;           /* length of indices                                 */
+    int64_t values_len;    /* length of values (nnz, or 0 when there are none)  */
     int     values_dtype;  /* MX_F64 / MX_LGL / MX_NONE                         */
     int     alias_structure; /* 1: reference returns the INPUT indptr1/indices1
                                 objects themselves (operators.cpp:127-131,:390-394);
@@ -254,6 +285,25 @@ int mx_copy_csr_rows_begin(const int32_t *indptr, int nrows,
                            int64_t n_values,
                            const int32_t *rows_take, int64_t n_take,
                            mx_result **res, mx_result_info *info);
+/* copy_csr_rows_col_seq_{numeric,logical,binary}  src/slice.cpp:385-447 (RcppExports.cpp:1924,1939,1954):
+ * cols_take is only used for its min / max (minus index1), as in the reference.  Result values are f64. */
+int mx_copy_csr_rows_col_seq_begin(const int32_t *indptr, int nrows,
+                                   const int32_t *indices, const void *values, int value_dtype, int64_t n_values,
+                                   const int32_t *rows_take, int64_t n_take,
+                                   const int32_t *cols_take, int64_t n_cols_take, int index1,
+                                   mx_result **res, mx_result_info *info);
+/* copy_csr_arbitrary_{numeric,logical,binary}  src/slice.cpp:580-634: rows_take, cols_take 0-based */
+int mx_copy_csr_arbitrary_begin(const int32_t *indptr, int nrows,
+                                const int32_t *indices, const void *values, int value_dtype, int64_t n_values,
+                                const int32_t *rows_take, int64_t n_take,
+                                const int32_t *cols_take, int64_t n_cols_take,
+                                mx_result **res, mx_result_info *info);
+/* reverse_rows_{numeric,logical,binary}  src/slice.cpp:98-140 */
+int mx_reverse_rows_begin(const int32_t *indptr, int nrows, const int32_t *indices, const void *values,
+                          int value_dtype, int64_t n_values, mx_result **res, mx_result_info *info);
+/* reverse_columns_inplace_{numeric,logical,binary}  src/slice.cpp:172-221: modifies indices / values */
+int mx_reverse_columns_inplace(const int32_t *indptr, int nrows, int32_t *indices, void *values,
+                               int value_dtype, int64_t n_values, int ncol);
 int mx_result_finish(mx_result *res, int32_t *out_indptr, int32_t *out_indices, void *out_values);
 int mx_result_discard(mx_result *res);
 

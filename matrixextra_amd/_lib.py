@@ -26,7 +26,7 @@ class MxError(RuntimeError):
 
 
 class ResultInfo(C.Structure):
-    _fields_ = [("indptr_len", C.c_int64), ("nnz", C.c_int64),
+    _fields_ = [("indptr_len", C.c_int64), ("nnz", C.c_int64), ("values_len", C.c_int64),
                 ("values_dtype", C.c_int), ("alias_structure", C.c_int)]
 
 
@@ -61,6 +61,8 @@ def load() -> C.CDLL:
     lib.mxd_merge_workspace_bytes.argtypes = [C.c_int]
     lib.mxd_gather_workspace_bytes.argtypes = [C.c_int]
     lib.mxd_scan_workspace_bytes.argtypes = [C.c_int64]
+    lib.mxd_colmap_workspace_bytes.restype = C.c_size_t
+    lib.mxd_colmap_workspace_bytes.argtypes = [C.c_int]
     if lib.mx_abi_version() != 1:
         raise MxError("libmxgpu.so ABI version mismatch")
     _lib = lib

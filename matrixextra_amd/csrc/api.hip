@@ -274,6 +274,7 @@ int mx_csr_elemwise_begin(int op, int nrows, const int32_t *indptr1, const int32
                 // operators.cpp:348-355: IntegerVector(indptr.size()) zeros, empty indices / values
                 res->info.indptr_len = (int64_t)nrows + 1;
                 res->info.nnz = 0;
+                res->info.values_len = 0;
                 if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
                 if (hipMemset(res->indptr.p, 0, sizeof(int32_t) * ((size_t)nrows + 1)) != hipSuccess) {
                     rc = set_error("hipMemset failed"); break;
@@ -283,6 +284,7 @@ int mx_csr_elemwise_begin(int op, int nrows, const int32_t *indptr1, const int32
             res->info.alias_structure = 1;
             res->info.indptr_len = (int64_t)nrows + 1;
             res->info.nnz = nnz1;
+            res->info.values_len = nnz1;
             DevBuf a, b;
             if ((rc = a.upload(values1, vb * (size_t)nnz1))) break;
             if ((rc = b.upload(values2, vb * (size_t)nnz2))) break;
@@ -310,6 +312,7 @@ int mx_csr_elemwise_begin(int op, int nrows, const int32_t *indptr1, const int32
         if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
         res->info.indptr_len = (int64_t)nrows + 1;
         res->info.nnz = nnz_out;
+        res->info.values_len = nnz_out;
     } while (0);
     if (rc) { delete res; return rc; }
     *info = res->info;
@@ -348,6 +351,7 @@ int mx_copy_csr_rows_begin(const int32_t *indptr, int nrows, const int32_t *indi
         if (nnz_out == 0) {          // slice.cpp:236-240: three EMPTY vectors (even the indptr)
             res->info.indptr_len = 0;
             res->info.nnz = 0;
+            res->info.values_len = 0;
             break;
         }
         if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
@@ -359,11 +363,187 @@ int mx_copy_csr_rows_begin(const int32_t *indptr, int nrows, const int32_t *indi
         if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
         res->info.indptr_len = n_take + 1;
         res->info.nnz = nnz_out;
+        res->info.values_len = has_values ? nnz_out : 0;
         if (!has_values) res->info.values_dtype = MX_NONE;
     } while (0);
     if (rc) { delete res; return rc; }
     *info = res->info;
     *res_out = res;
+    return 0;
+}
+
+// ---- column-filtering slices (§8f rank 2) ----------------------------------------------------------------
+int mx_copy_csr_rows_col_seq_begin(const int32_t *indptr, int nrows, const int32_t *indices, const void *values,
+                                   int value_dtype, int64_t n_values, const int32_t *rows_take, int64_t n_take,
+                                   const int32_t *cols_take, int64_t n_cols_take, int index1,
+                                   mx_result **res_out, mx_result_info *info)
+{
+    MX_REQUIRE(res_out && info, "mx_copy_csr_rows_col_seq_begin: null output pointer");
+    MX_REQUIRE(nrows >= 0 && n_take >= 0 && n_take <= INT_MAX && n_cols_take > 0, "mx_copy_csr_rows_col_seq_begin: bad size");
+    MX_REQUIRE(value_dtype == MX_F64 || value_dtype == MX_LGL || value_dtype == MX_NONE,
+               "mx_copy_csr_rows_col_seq_begin: unsupported value dtype %d", value_dtype);
+    *res_out = nullptr;
+    int min_col = cols_take[0], max_col = cols_take[0];                      // slice.cpp:337-338
+    for (int64_t c = 1; c < n_cols_take; c++) { if (cols_take[c] < min_col) min_col = cols_take[c]; if (cols_take[c] > max_col) max_col = cols_take[c]; }
+    min_col -= index1 ? 1 : 0; max_col -= index1 ? 1 : 0;
+    const bool has_values = value_dtype != MX_NONE && n_values > 0;
+    mx_result *res = new (std::nothrow) mx_result();
+    MX_REQUIRE(res, "out of host memory");
+    res->info.values_dtype = MX_F64;                                         // always a NumericVector (slice.cpp:363)
+    res->info.alias_structure = 0;
+    int rc = 0;
+    do {
+        Csr A;
+        if ((rc = A.upload(indptr, indices, values, nrows, has_values ? dtype_bytes(value_dtype) : 0))) break;
+        DevBuf rows, ws;
+        if ((rc = rows.upload(rows_take, sizeof(int32_t) * (size_t)n_take))) break;
+        if ((rc = ws.alloc(mxd_gather_workspace_bytes((int)n_take)))) break;
+        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)n_take + 1)))) break;
+        const double avg = nrows > 0 ? (double)A.nnz / nrows : 0.0;
+        int64_t nnz_out = 0;
+        if ((rc = mxd_csr_colrange_count((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), rows.as<int32_t>(), min_col,
+                                         max_col, avg, res->indptr.as<int32_t>(), ws.p, &nnz_out, nullptr))) break;
+        res->info.indptr_len = n_take + 1;
+        res->info.nnz = nnz_out;
+        res->info.values_len = has_values ? nnz_out : 0;
+        if (nnz_out == 0) { res->info.values_len = 0; break; }                 // slice.cpp:355-359
+        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
+        if (has_values && (rc = res->values.alloc(sizeof(double) * (size_t)nnz_out))) break;
+        if ((rc = mxd_csr_colrange_fill((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p,
+                                        has_values ? value_dtype : MX_NONE, rows.as<int32_t>(), min_col, max_col, avg,
+                                        res->indptr.as<int32_t>(), res->indices.as<int32_t>(), res->values.as<double>(),
+                                        nullptr))) break;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
+    } while (0);
+    if (rc) { delete res; return rc; }
+    *info = res->info;
+    *res_out = res;
+    return 0;
+}
+
+int mx_copy_csr_arbitrary_begin(const int32_t *indptr, int nrows, const int32_t *indices, const void *values,
+                                int value_dtype, int64_t n_values, const int32_t *rows_take, int64_t n_take,
+                                const int32_t *cols_take, int64_t n_cols_take, mx_result **res_out,
+                                mx_result_info *info)
+{
+    MX_REQUIRE(res_out && info, "mx_copy_csr_arbitrary_begin: null output pointer");
+    MX_REQUIRE(nrows >= 0 && n_take >= 0 && n_take <= INT_MAX && n_cols_take >= 0 && n_cols_take <= INT_MAX,
+               "mx_copy_csr_arbitrary_begin: bad size");
+    MX_REQUIRE(value_dtype == MX_F64 || value_dtype == MX_LGL || value_dtype == MX_NONE,
+               "mx_copy_csr_arbitrary_begin: unsupported value dtype %d", value_dtype);
+    *res_out = nullptr;
+    const bool has_values = value_dtype != MX_NONE && n_values > 0;           // `if (values.size())`, slice.cpp:565
+    const size_t vb = has_values ? dtype_bytes(value_dtype) : 0;
+    int max_j = -1;
+    bool cols_sorted = true;                                                  // slice.cpp:487-493
+    for (int64_t c = 0; c < n_cols_take; c++) {
+        MX_REQUIRE(cols_take[c] >= 0, "mx_copy_csr_arbitrary_begin: negative column index");
+        if (cols_take[c] > max_j) max_j = cols_take[c];
+        if (c && cols_take[c] < cols_take[c - 1]) cols_sorted = false;
+    }
+    const int ncol_map = max_j + 1;
+    mx_result *res = new (std::nothrow) mx_result();
+    MX_REQUIRE(res, "out of host memory");
+    res->info.values_dtype = has_values ? value_dtype : MX_NONE;
+    res->info.alias_structure = 0;
+    int rc = 0;
+    do {
+        Csr A;
+        if ((rc = A.upload(indptr, indices, values, nrows, vb))) break;
+        DevBuf rows, cols, start, pos, ws, mws;
+        if ((rc = rows.upload(rows_take, sizeof(int32_t) * (size_t)n_take))) break;
+        if ((rc = cols.upload(cols_take, sizeof(int32_t) * (size_t)n_cols_take))) break;
+        if ((rc = start.alloc(sizeof(int32_t) * ((size_t)ncol_map + 1)))) break;
+        if ((rc = pos.alloc(sizeof(int32_t) * (size_t)n_cols_take))) break;
+        if ((rc = mws.alloc(mxd_colmap_workspace_bytes(ncol_map)))) break;
+        if ((rc = ws.alloc(mxd_gather_workspace_bytes((int)n_take)))) break;
+        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)n_take + 1)))) break;
+        if ((rc = mxd_colmap_build(cols.as<int32_t>(), n_cols_take, ncol_map, start.as<int32_t>(), pos.as<int32_t>(),
+                                   mws.p, nullptr))) break;
+        const double avg = nrows > 0 ? (double)A.nnz / nrows : 0.0;
+        int64_t nnz_out = 0;
+        if ((rc = mxd_csr_colmap_count((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), rows.as<int32_t>(), ncol_map,
+                                       start.as<int32_t>(), avg, res->indptr.as<int32_t>(), ws.p, &nnz_out, nullptr))) break;
+        res->info.indptr_len = n_take + 1;
+        res->info.nnz = nnz_out;
+        res->info.values_len = has_values ? nnz_out : 0;
+        if (nnz_out == 0) break;
+        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
+        if (has_values && (rc = res->values.alloc(vb * (size_t)nnz_out))) break;
+        if ((rc = mxd_csr_colmap_fill((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p,
+                                      has_values ? value_dtype : MX_NONE, rows.as<int32_t>(), ncol_map,
+                                      start.as<int32_t>(), pos.as<int32_t>(), avg, res->indptr.as<int32_t>(),
+                                      res->indices.as<int32_t>(), res->values.p, nullptr))) break;
+        if (!cols_sorted) {                                                   // slice.cpp:540-560
+            DevBuf tj, tx;
+            if ((rc = tj.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
+            if (has_values && (rc = tx.alloc(vb * (size_t)nnz_out))) break;
+            if ((rc = mxd_csr_sort_rows((int)n_take, nnz_out, res->indptr.as<int32_t>(), res->indices.as<int32_t>(),
+                                        res->values.p, has_values ? value_dtype : MX_NONE, tj.as<int32_t>(), tx.p, nullptr))) break;
+            if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
+        }
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
+    } while (0);
+    if (rc) { delete res; return rc; }
+    *info = res->info;
+    *res_out = res;
+    return 0;
+}
+
+int mx_reverse_rows_begin(const int32_t *indptr, int nrows, const int32_t *indices, const void *values,
+                          int value_dtype, int64_t n_values, mx_result **res_out, mx_result_info *info)
+{
+    MX_REQUIRE(res_out && info, "mx_reverse_rows_begin: null output pointer");
+    MX_REQUIRE(nrows >= 0, "mx_reverse_rows_begin: negative size");
+    *res_out = nullptr;
+    const bool has_values = value_dtype != MX_NONE && n_values > 0;           // slice.cpp:66
+    const size_t vb = has_values ? dtype_bytes(value_dtype) : 0;
+    mx_result *res = new (std::nothrow) mx_result();
+    MX_REQUIRE(res, "out of host memory");
+    res->info.values_dtype = has_values ? value_dtype : MX_NONE;
+    res->info.alias_structure = 0;
+    int rc = 0;
+    do {
+        Csr A;
+        if ((rc = A.upload(indptr, indices, values, nrows, vb))) break;
+        DevBuf rows, ws;
+        if ((rc = rows.alloc(sizeof(int32_t) * (size_t)nrows))) break;
+        if ((rc = ws.alloc(mxd_gather_workspace_bytes(nrows)))) break;
+        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
+        if ((rc = mxd_reversed_iota(nrows, rows.as<int32_t>(), nullptr))) break;
+        int64_t nnz_out = 0;
+        if ((rc = mxd_csr_gather_count(nrows, A.p.as<int32_t>(), rows.as<int32_t>(), res->indptr.as<int32_t>(), ws.p,
+                                       &nnz_out, nullptr))) break;
+        res->info.indptr_len = (int64_t)nrows + 1;                            // always full length (slice.cpp:57)
+        res->info.nnz = nnz_out;
+        res->info.values_len = has_values ? nnz_out : 0;
+        if (nnz_out == 0) break;
+        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
+        if (has_values && (rc = res->values.alloc(vb * (size_t)nnz_out))) break;
+        if ((rc = mxd_csr_gather_fill(nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, rows.as<int32_t>(),
+                                      res->indptr.as<int32_t>(), res->indices.as<int32_t>(), res->values.p,
+                                      has_values ? value_dtype : MX_NONE, nnz_out, nullptr))) break;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
+    } while (0);
+    if (rc) { delete res; return rc; }
+    *info = res->info;
+    *res_out = res;
+    return 0;
+}
+
+int mx_reverse_columns_inplace(const int32_t *indptr, int nrows, int32_t *indices, void *values, int value_dtype,
+                               int64_t n_values, int ncol)
+{
+    if (nrows <= 0) return 0;
+    const bool has_values = value_dtype != MX_NONE && n_values > 0 && values;
+    const size_t vb = has_values ? dtype_bytes(value_dtype) : 0;
+    Csr A;
+    if (A.upload(indptr, indices, values, nrows, vb)) return 1;
+    if (A.nnz == 0) return 0;
+    if (mxd_csr_reverse_columns(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p,
+                                has_values ? value_dtype : MX_NONE, ncol, nullptr)) return 1;
+    MX_HIP(hipMemcpy(indices, A.j.p, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
+    if (vb) MX_HIP(hipMemcpy(values, A.x.p, vb * (size_t)A.nnz, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -384,8 +564,8 @@ int mx_result_finish(mx_result *res, int32_t *out_indptr, int32_t *out_indices, 
             }
         }
         const size_t vb = dtype_bytes(inf.values_dtype);
-        if (vb && inf.nnz > 0 && out_values && res->values.p &&
-            hipMemcpy(out_values, res->values.p, vb * (size_t)inf.nnz, hipMemcpyDeviceToHost) != hipSuccess) {
+        if (vb && inf.values_len > 0 && out_values && res->values.p &&
+            hipMemcpy(out_values, res->values.p, vb * (size_t)inf.values_len, hipMemcpyDeviceToHost) != hipSuccess) {
             rc = set_error("D2H copy of values failed"); break;
         }
     } while (0);

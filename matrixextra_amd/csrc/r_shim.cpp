@@ -60,7 +60,7 @@ SEXP named_list3(SEXP indptr, SEXP indices, SEXP values, Protect &p)
 SEXP finish_list(mx_result *res, const mx_result_info &info, SEXP alias_p, SEXP alias_j, Protect &p)
 {
     const SEXPTYPE vt = info.values_dtype == MX_F64 ? REALSXP : (info.values_dtype == MX_LGL ? LGLSXP : REALSXP);
-    const R_xlen_t nv = info.values_dtype == MX_NONE ? 0 : (R_xlen_t)info.nnz;
+    const R_xlen_t nv = info.values_dtype == MX_NONE ? 0 : (R_xlen_t)info.values_len;
     SEXP values = p(Rf_allocVector(vt, nv));           // may long-jump on allocation failure:
     void *vptr = vt == REALSXP ? (void *)REAL(values) : (void *)LOGICAL(values);
     SEXP indptr = alias_p, indices = alias_j;

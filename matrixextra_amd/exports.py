@@ -143,12 +143,12 @@ def _finish(res, info, alias_from=None, empty_values_dtype=np.float64):
     vdt = _VDT.get(info.values_dtype)
     if info.alias_structure:
         indptr, indices = alias_from          # the INPUT objects themselves, as the reference returns them
-        values = np.empty(info.nnz, dtype=vdt)
+        values = np.empty(info.values_len, dtype=vdt)
         check(lib.mx_result_finish(res, None, None, ptr(values)))
         return dict(indptr=indptr, indices=indices, values=values)
     indptr = np.empty(info.indptr_len, dtype=np.int32)
     indices = np.empty(info.nnz, dtype=np.int32)
-    values = np.empty(info.nnz if vdt is not None else 0, dtype=vdt if vdt is not None else empty_values_dtype)
+    values = np.empty(info.values_len if vdt is not None else 0, dtype=vdt if vdt is not None else empty_values_dtype)
     check(lib.mx_result_finish(res, ptr(indptr), ptr(indices), ptr(values) if values.size else None))
     return dict(indptr=indptr, indices=indices, values=values)
 
@@ -221,6 +221,115 @@ def copy_csr_rows_logical(indptr, indices, values, rows_take):
 def copy_csr_rows_binary(indptr, indices, rows_take):
     """src/slice.cpp:310-324."""
     return _copy_rows(indptr, indices, None, rows_take, MX_NONE, None)
+
+
+# ----------------------------------------------------------------------------- column-filtering slices (§8f-2)
+def _col_seq(indptr, indices, values, rows_take, cols_take, index1, value_dtype, vdt):
+    lib = _lib.load()
+    p, j, rows, cols = _i32(indptr), _i32(indices), _i32(rows_take), _i32(cols_take)
+    v = None if values is None else np.ascontiguousarray(values, dtype=vdt)
+    res = C.c_void_p()
+    info = ResultInfo()
+    check(lib.mx_copy_csr_rows_col_seq_begin(ptr(p), C.c_int(p.size - 1), ptr(j), ptr(v), C.c_int(value_dtype),
+                                             C.c_int64(0 if v is None else v.size), ptr(rows), C.c_int64(rows.size),
+                                             ptr(cols), C.c_int64(cols.size), C.c_int(int(bool(index1))),
+                                             C.byref(res), C.byref(info)))
+    return _finish(res, info)          # values are always a numeric (float64) vector, slice.cpp:363
+
+
+def copy_csr_rows_col_seq_numeric(indptr, indices, values, rows_take, cols_take, index1):
+    """R/RcppExports.R:576 -> src/slice.cpp:385-403."""
+    return _col_seq(indptr, indices, values, rows_take, cols_take, index1, MX_F64, np.float64)
+
+
+def copy_csr_rows_col_seq_logical(indptr, indices, values, rows_take, cols_take, index1):
+    """src/slice.cpp:405-423 (values come back as numeric, like the reference's NumericVector)."""
+    return _col_seq(indptr, indices, values, rows_take, cols_take, index1, MX_LGL, np.int32)
+
+
+def copy_csr_rows_col_seq_binary(indptr, indices, rows_take, cols_take, index1):
+    """src/slice.cpp:425-443."""
+    return _col_seq(indptr, indices, None, rows_take, cols_take, index1, MX_NONE, None)
+
+
+def _arbitrary(indptr, indices, values, rows_take, cols_take, value_dtype, vdt):
+    lib = _lib.load()
+    p, j, rows, cols = _i32(indptr), _i32(indices), _i32(rows_take), _i32(cols_take)
+    v = None if values is None else np.ascontiguousarray(values, dtype=vdt)
+    res = C.c_void_p()
+    info = ResultInfo()
+    check(lib.mx_copy_csr_arbitrary_begin(ptr(p), C.c_int(p.size - 1), ptr(j), ptr(v), C.c_int(value_dtype),
+                                          C.c_int64(0 if v is None else v.size), ptr(rows), C.c_int64(rows.size),
+                                          ptr(cols), C.c_int64(cols.size), C.byref(res), C.byref(info)))
+    out = _finish(res, info, empty_values_dtype=vdt if vdt is not None else np.float64)
+    if info.values_dtype == MX_NONE:
+        del out["values"]              # the reference's list has no `values` element then (slice.cpp:565)
+    return out
+
+
+def copy_csr_arbitrary_numeric(indptr, indices, values, rows_take, cols_take):
+    """src/slice.cpp:580-596."""
+    return _arbitrary(indptr, indices, values, rows_take, cols_take, MX_F64, np.float64)
+
+
+def copy_csr_arbitrary_logical(indptr, indices, values, rows_take, cols_take):
+    """src/slice.cpp:598-614."""
+    return _arbitrary(indptr, indices, values, rows_take, cols_take, MX_LGL, np.int32)
+
+
+def copy_csr_arbitrary_binary(indptr, indices, rows_take, cols_take):
+    """src/slice.cpp:616-632."""
+    return _arbitrary(indptr, indices, None, rows_take, cols_take, MX_NONE, None)
+
+
+def _reverse_rows(indptr, indices, values, value_dtype, vdt):
+    lib = _lib.load()
+    p, j = _i32(indptr), _i32(indices)
+    v = None if values is None else np.ascontiguousarray(values, dtype=vdt)
+    res = C.c_void_p()
+    info = ResultInfo()
+    check(lib.mx_reverse_rows_begin(ptr(p), C.c_int(p.size - 1), ptr(j), ptr(v), C.c_int(value_dtype),
+                                    C.c_int64(0 if v is None else v.size), C.byref(res), C.byref(info)))
+    return _finish(res, info, empty_values_dtype=vdt if vdt is not None else np.float64)
+
+
+def reverse_rows_numeric(indptr, indices, values):
+    """src/slice.cpp:98-110."""
+    return _reverse_rows(indptr, indices, values, MX_F64, np.float64)
+
+
+def reverse_rows_logical(indptr, indices, values):
+    """src/slice.cpp:112-124."""
+    return _reverse_rows(indptr, indices, values, MX_LGL, np.int32)
+
+
+def reverse_rows_binary(indptr, indices):
+    """src/slice.cpp:126-138."""
+    return _reverse_rows(indptr, indices, None, MX_NONE, None)
+
+
+def _reverse_columns_inplace(indptr, indices, values, ncol, value_dtype):
+    p = _i32(indptr)
+    if not (isinstance(indices, np.ndarray) and indices.dtype == np.int32 and indices.flags.c_contiguous):
+        raise TypeError("indices must be a contiguous int32 numpy array (modified in place)")
+    check(_lib.load().mx_reverse_columns_inplace(ptr(p), C.c_int(p.size - 1), ptr(indices), ptr(values),
+                                                 C.c_int(value_dtype), C.c_int64(0 if values is None else values.size),
+                                                 C.c_int(int(ncol))))
+
+
+def reverse_columns_inplace_numeric(indptr, indices, values, ncol):
+    """src/slice.cpp:172-187: modifies `indices` / `values`."""
+    _reverse_columns_inplace(indptr, indices, values, ncol, MX_F64)
+
+
+def reverse_columns_inplace_logical(indptr, indices, values, ncol):
+    """src/slice.cpp:189-204."""
+    _reverse_columns_inplace(indptr, indices, values, ncol, MX_LGL)
+
+
+def reverse_columns_inplace_binary(indptr, indices, ncol):
+    """src/slice.cpp:206-221."""
+    _reverse_columns_inplace(indptr, indices, None, ncol, MX_NONE)
 
 
 def check_is_seq(indices) -> bool:

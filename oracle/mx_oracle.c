@@ -356,3 +356,128 @@ void mxo_sort_sparse_indices(const int *indptr, int *indices, void *values, int 
         }
     }
 }
+
+/* ==== §8(f) rank 2: column-filtering slices =================================================== */
+
+/* ---- copy_csr_rows_col_seq_template (slice.cpp:326-383) ------------------ */
+/* rows_take 0-based; keeps entries with min_col <= col <= max_col, re-based to min_col, input order kept.
+ * value_kind: 0 none, 1 f64, 2 int32 (R logical) — output values are ALWAYS double (the reference builds an
+ * Rcpp::NumericVector, slice.cpp:363).  Pass NULL outputs to only size the result.  Returns total entries;
+ * new_indptr[n_take+1] is always written. */
+size_t mxo_copy_csr_rows_col_seq(const int *indptr, const int *indices, const void *values, int value_kind,
+                                 const int *rows_take, size_t n_take, int min_col, int max_col,
+                                 int *new_indptr, int *new_indices, double *new_values)
+{
+    size_t total = 0;
+    new_indptr[0] = 0;
+    for (size_t row = 0; row < n_take; row++) {
+        for (int ix = indptr[rows_take[row]]; ix < indptr[rows_take[row] + 1]; ix++) {
+            if (indices[ix] >= min_col && indices[ix] <= max_col) {
+                if (new_indices) {
+                    new_indices[total] = indices[ix] - min_col;
+                    if (value_kind == 1) new_values[total] = ((const double *)values)[ix];
+                    else if (value_kind == 2) new_values[total] = (double)((const int *)values)[ix];
+                }
+                total++;
+            }
+        }
+        new_indptr[row + 1] = (int)total;
+    }
+    return total;
+}
+
+/* ---- copy_csr_arbitrary_template (slice.cpp:449-578) --------------------- */
+/* rows_take, cols_take 0-based.  A kept entry of column c goes to every position of c in cols_take
+ * (ascending position; a non-repeated column: its only position).  Rows are then ordered by new column id
+ * unless cols_take is non-decreasing (slice.cpp:487-493, 540-560).  value_bytes 0/4/8.
+ * Pass NULL outputs to only size the result.  ncol = number of columns of the matrix (dense map instead of
+ * the reference's hash map).  Returns total entries, or (size_t)-1 on allocation failure. */
+static int cmp_pair_key(const void *a, const void *b)
+{
+    const int ka = ((const int *)a)[0], kb = ((const int *)b)[0];
+    return (ka > kb) - (ka < kb);
+}
+size_t mxo_copy_csr_arbitrary(const int *indptr, const int *indices, const void *values, int value_bytes,
+                              const int *rows_take, size_t n_take, const int *cols_take, size_t n_cols_take,
+                              int ncol, int *new_indptr, int *new_indices, void *new_values)
+{
+    int *start = (int *)calloc((size_t)ncol + 2, sizeof(int));
+    int *pos = (int *)malloc((n_cols_take ? n_cols_take : 1) * sizeof(int));
+    if (!start || !pos) { free(start); free(pos); return (size_t)-1; }
+    for (size_t c = 0; c < n_cols_take; c++) start[cols_take[c] + 2]++;
+    for (int c = 0; c < ncol; c++) start[c + 2] += start[c + 1];           /* start[c+1] = first slot of column c */
+    for (size_t c = 0; c < n_cols_take; c++) pos[start[cols_take[c] + 1]++] = (int)c;   /* ascending positions */
+    /* now start[c] .. start[c+1] delimit column c's positions */
+    int cols_sorted = 1;
+    for (size_t c = 1; c < n_cols_take; c++) if (cols_take[c] < cols_take[c - 1]) { cols_sorted = 0; break; }
+    size_t total = 0;
+    new_indptr[0] = 0;
+    for (size_t r = 0; r < n_take; r++) {
+        const int row = rows_take[r];
+        const size_t row_begin = total;
+        for (int ix = indptr[row]; ix < indptr[row + 1]; ix++) {
+            const int c = indices[ix];
+            if (c < 0 || c >= ncol) continue;
+            for (int q = start[c]; q < start[c + 1]; q++) {
+                if (new_indices) {
+                    new_indices[total] = pos[q];
+                    if (value_bytes == 8) ((double *)new_values)[total] = ((const double *)values)[ix];
+                    else if (value_bytes == 4) ((int *)new_values)[total] = ((const int *)values)[ix];
+                }
+                total++;
+            }
+        }
+        new_indptr[r + 1] = (int)total;
+        if (new_indices && !cols_sorted && total > row_begin + 1) {
+            /* order the row by new column id (keys are unique inside a row of a valid matrix) */
+            const size_t len = total - row_begin;
+            int *tmp = (int *)malloc(len * 2 * sizeof(int));
+            if (!tmp) { free(start); free(pos); return (size_t)-1; }
+            for (size_t k = 0; k < len; k++) { tmp[2 * k] = new_indices[row_begin + k]; tmp[2 * k + 1] = (int)k; }
+            qsort(tmp, len, 2 * sizeof(int), cmp_pair_key);
+            if (value_bytes) {
+                char *vt = (char *)malloc(len * (size_t)value_bytes);
+                if (!vt) { free(tmp); free(start); free(pos); return (size_t)-1; }
+                memcpy(vt, (char *)new_values + row_begin * (size_t)value_bytes, len * (size_t)value_bytes);
+                for (size_t k = 0; k < len; k++)
+                    memcpy((char *)new_values + (row_begin + k) * (size_t)value_bytes,
+                           vt + (size_t)tmp[2 * k + 1] * (size_t)value_bytes, (size_t)value_bytes);
+                free(vt);
+            }
+            for (size_t k = 0; k < len; k++) new_indices[row_begin + k] = tmp[2 * k];
+            free(tmp);
+        }
+    }
+    free(start); free(pos);
+    return total;
+}
+
+/* ---- reverse_rows_template (slice.cpp:49-95) ------------------------------ */
+void mxo_reverse_rows(const int *indptr, const int *indices, const void *values, int value_bytes, int nrows,
+                      int *indptr_new, int *indices_new, void *values_new)
+{
+    indptr_new[0] = 0;
+    for (int row = 0; row < nrows; row++) {
+        const int rev = nrows - row - 1;
+        const int n_this = indptr[rev + 1] - indptr[rev];
+        indptr_new[row + 1] = indptr_new[row] + n_this;
+        memcpy(indices_new + indptr_new[row], indices + indptr[rev], (size_t)n_this * sizeof(int));
+        if (value_bytes)
+            memcpy((char *)values_new + (size_t)indptr_new[row] * (size_t)value_bytes,
+                   (const char *)values + (size_t)indptr[rev] * (size_t)value_bytes, (size_t)n_this * (size_t)value_bytes);
+    }
+}
+
+/* ---- reverse_columns_inplace (slice.cpp:142-170) -------------------------- */
+void mxo_reverse_columns_inplace(const int *indptr, int *indices, void *values, int value_bytes, int nrows, int ncol)
+{
+    for (int row = 0; row < nrows; row++) {
+        const int s = indptr[row], e = indptr[row + 1];
+        for (int ix = s; ix < e; ix++) indices[ix] = ncol - indices[ix] - 1;
+        for (int a = s, b = e - 1; a < b; a++, b--) {
+            const int t = indices[a]; indices[a] = indices[b]; indices[b] = t;
+            if (value_bytes == 8) { double *v = (double *)values; const double tv = v[a]; v[a] = v[b]; v[b] = tv; }
+            else if (value_bytes == 4) { int *v = (int *)values; const int tv = v[a]; v[a] = v[b]; v[b] = tv; }
+        }
+    }
+}

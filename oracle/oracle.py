@@ -44,6 +44,8 @@ def lib():
         _lib.mxo_multiply_csr_elemwise.restype = C.c_size_t
         _lib.mxo_add_csr_elemwise.restype = C.c_size_t
         _lib.mxo_copy_csr_rows_size.restype = C.c_size_t
+        _lib.mxo_copy_csr_rows_col_seq.restype = C.c_size_t
+        _lib.mxo_copy_csr_arbitrary.restype = C.c_size_t
     return _lib
 
 
@@ -308,3 +310,108 @@ def sort_sparse_indices(indptr, indices, values=None):
     vb = 0 if v is None else v.dtype.itemsize
     lib().mxo_sort_sparse_indices(_p(p), _p(j), _p(v), C.c_int(vb), C.c_int(p.size - 1))
     return j, v
+
+
+# ----------------------------------------------------------------------------- column-filtering slices (§8f-2)
+def _col_seq(indptr, indices, values, rows_take, cols_take, index1, kind):
+    p, j, rows, cols = _i32(indptr), _i32(indices), _i32(rows_take), _i32(cols_take)
+    lo, hi = int(cols.min()) - int(bool(index1)), int(cols.max()) - int(bool(index1))
+    has_values = values is not None and np.asarray(values).size > 0
+    v = None
+    if has_values:
+        v = np.ascontiguousarray(values, dtype=np.float64 if kind == 1 else np.int32)
+    npz = np.zeros(rows.size + 1, dtype=np.int32)
+    total = lib().mxo_copy_csr_rows_col_seq(_p(p), _p(j), _p(v), C.c_int(kind if has_values else 0), _p(rows),
+                                            C.c_size_t(rows.size), C.c_int(lo), C.c_int(hi), _p(npz), None, None)
+    if total == 0:  # slice.cpp:355-359
+        return dict(indptr=npz, indices=np.zeros(0, dtype=np.int32), values=np.zeros(0, dtype=np.float64))
+    nj = np.empty(total, dtype=np.int32)
+    nv = np.empty(total if has_values else 0, dtype=np.float64)
+    lib().mxo_copy_csr_rows_col_seq(_p(p), _p(j), _p(v), C.c_int(kind if has_values else 0), _p(rows),
+                                    C.c_size_t(rows.size), C.c_int(lo), C.c_int(hi), _p(npz), _p(nj),
+                                    _p(nv) if has_values else None)
+    return dict(indptr=npz, indices=nj, values=nv)
+
+
+def copy_csr_rows_col_seq_numeric(indptr, indices, values, rows_take, cols_take, index1):
+    """src/slice.cpp:385-403"""
+    return _col_seq(indptr, indices, values, rows_take, cols_take, index1, 1)
+
+
+def copy_csr_rows_col_seq_logical(indptr, indices, values, rows_take, cols_take, index1):
+    """src/slice.cpp:405-423"""
+    return _col_seq(indptr, indices, values, rows_take, cols_take, index1, 2)
+
+
+def copy_csr_rows_col_seq_binary(indptr, indices, rows_take, cols_take, index1):
+    """src/slice.cpp:425-443"""
+    return _col_seq(indptr, indices, None, rows_take, cols_take, index1, 0)
+
+
+def _arbitrary(indptr, indices, values, rows_take, cols_take, vdt):
+    p, j, rows, cols = _i32(indptr), _i32(indices), _i32(rows_take), _i32(cols_take)
+    has_values = values is not None and np.asarray(values).size > 0
+    v = np.ascontiguousarray(values, dtype=vdt) if has_values else None
+    vb = v.dtype.itemsize if has_values else 0
+    ncol = int(cols.max()) + 1 if cols.size else 0
+    npz = np.zeros(rows.size + 1, dtype=np.int32)
+    total = lib().mxo_copy_csr_arbitrary(_p(p), _p(j), _p(v), C.c_int(vb), _p(rows), C.c_size_t(rows.size), _p(cols),
+                                         C.c_size_t(cols.size), C.c_int(ncol), _p(npz), None, None)
+    nj = np.empty(total, dtype=np.int32)
+    nv = np.empty(total, dtype=vdt) if has_values else None
+    if total:
+        lib().mxo_copy_csr_arbitrary(_p(p), _p(j), _p(v), C.c_int(vb), _p(rows), C.c_size_t(rows.size), _p(cols),
+                                     C.c_size_t(cols.size), C.c_int(ncol), _p(npz), _p(nj), _p(nv))
+    out = dict(indptr=npz, indices=nj)
+    if has_values:
+        out["values"] = nv
+    return out
+
+
+def copy_csr_arbitrary_numeric(indptr, indices, values, rows_take, cols_take):
+    """src/slice.cpp:580-596"""
+    return _arbitrary(indptr, indices, values, rows_take, cols_take, np.float64)
+
+
+def copy_csr_arbitrary_logical(indptr, indices, values, rows_take, cols_take):
+    """src/slice.cpp:598-614"""
+    return _arbitrary(indptr, indices, values, rows_take, cols_take, np.int32)
+
+
+def copy_csr_arbitrary_binary(indptr, indices, rows_take, cols_take):
+    """src/slice.cpp:616-632"""
+    return _arbitrary(indptr, indices, None, rows_take, cols_take, None)
+
+
+def _reverse_rows(indptr, indices, values, vdt):
+    p, j = _i32(indptr), _i32(indices)
+    has_values = values is not None and np.asarray(values).size > 0
+    v = np.ascontiguousarray(values, dtype=vdt) if has_values else None
+    npz = np.zeros(p.size, dtype=np.int32)
+    nj = np.empty(j.size, dtype=np.int32)
+    nv = np.empty(j.size, dtype=vdt) if has_values else np.zeros(0, dtype=vdt if vdt is not None else np.float64)
+    lib().mxo_reverse_rows(_p(p), _p(j), _p(v), C.c_int(v.dtype.itemsize if has_values else 0), C.c_int(p.size - 1),
+                           _p(npz), _p(nj), _p(nv) if has_values else None)
+    return dict(indptr=npz, indices=nj, values=nv)
+
+
+def reverse_rows_numeric(indptr, indices, values):
+    """src/slice.cpp:98-110"""
+    return _reverse_rows(indptr, indices, values, np.float64)
+
+
+def reverse_rows_logical(indptr, indices, values):
+    """src/slice.cpp:112-124"""
+    return _reverse_rows(indptr, indices, values, np.int32)
+
+
+def reverse_rows_binary(indptr, indices):
+    """src/slice.cpp:126-138"""
+    return _reverse_rows(indptr, indices, None, None)
+
+
+def reverse_columns_inplace(indptr, indices, values, ncol):
+    """src/slice.cpp:142-170: modifies indices / values (int32 / float64-or-int32 numpy arrays) in place."""
+    p = _i32(indptr)
+    vb = 0 if values is None else values.dtype.itemsize
+    lib().mxo_reverse_columns_inplace(_p(p), _p(indices), _p(values), C.c_int(vb), C.c_int(p.size - 1), C.c_int(int(ncol)))

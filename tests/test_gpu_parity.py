@@ -289,3 +289,76 @@ def test_spmm_slab_kernel_skewed_rows_and_unsorted(gpu):
     refu = O.tcrossprod_csr_dense(pu, ju, xu, np.asfortranarray(Bu.T), 1, use_fma=True)
     np.testing.assert_array_equal(spmm_device(pu, ju, xu, Bu, True, 2, rows_sorted=False), refu)
     np.testing.assert_array_equal(spmm_device(pu, ju, xu, Bu, False, 0, rows_sorted=False), refu)
+
+
+# ----------------------------------------------------------------------------- §8(f) rank 2: column-filtering slices
+def _eq_lists(g, o):
+    assert set(g.keys()) == set(o.keys())
+    for k in g:
+        assert g[k].dtype == o[k].dtype and g[k].shape == o[k].shape, (k, g[k].dtype, o[k].dtype, g[k].shape, o[k].shape)
+        np.testing.assert_array_equal(g[k], o[k])
+
+
+def test_copy_csr_rows_col_seq(gpu):
+    p, j, x = rand_csr(1000, 500, 0.1, seed=7, empty_rows=(10, 11))
+    rng = np.random.default_rng(2)
+    xl = rng.choice(np.array([0, 1, NA], dtype=np.int32), size=x.size)
+    row_sets = [rng.integers(0, 1000, size=300).astype(np.int32), np.array([10, 11], dtype=np.int32),
+                np.arange(999, -1, -1, dtype=np.int32), np.zeros(0, dtype=np.int32)]
+    col_sets = [(np.arange(100, 201, dtype=np.int32), True), (np.arange(0, 500, dtype=np.int32), False),
+                (np.array([499], dtype=np.int32), False), (np.arange(250, 120, -1, dtype=np.int32), True)]
+    for rows in row_sets:
+        for cols, index1 in col_sets:
+            _eq_lists(G.copy_csr_rows_col_seq_numeric(p, j, x, rows, cols, index1),
+                      O.copy_csr_rows_col_seq_numeric(p, j, x, rows, cols, index1))
+            _eq_lists(G.copy_csr_rows_col_seq_logical(p, j, xl, rows, cols, index1),
+                      O.copy_csr_rows_col_seq_logical(p, j, xl, rows, cols, index1))
+            _eq_lists(G.copy_csr_rows_col_seq_binary(p, j, rows, cols, index1),
+                      O.copy_csr_rows_col_seq_binary(p, j, rows, cols, index1))
+
+
+def test_copy_csr_arbitrary(gpu):
+    p, j, x = rand_csr(1000, 500, 0.1, seed=7, empty_rows=(10, 11))
+    rng = np.random.default_rng(4)
+    xl = rng.choice(np.array([0, 1, NA], dtype=np.int32), size=x.size)
+    rows = rng.integers(0, 1000, size=400).astype(np.int32)
+    col_sets = [rng.permutation(500)[:60].astype(np.int32),                        # unsorted, unique
+                np.sort(rng.permutation(500)[:200]).astype(np.int32),              # sorted, unique
+                np.array([70, 3, 3, 41, 0, 499, 12, 3, 70], dtype=np.int32),       # repeats, unsorted
+                np.array([5, 5, 5, 9, 9, 300], dtype=np.int32),                    # repeats, sorted
+                np.array([17], dtype=np.int32)]
+    for cols in col_sets:
+        for rr in (rows, np.array([10, 11, 10], dtype=np.int32)):
+            _eq_lists(G.copy_csr_arbitrary_numeric(p, j, x, rr, cols), O.copy_csr_arbitrary_numeric(p, j, x, rr, cols))
+            _eq_lists(G.copy_csr_arbitrary_logical(p, j, xl, rr, cols), O.copy_csr_arbitrary_logical(p, j, xl, rr, cols))
+            _eq_lists(G.copy_csr_arbitrary_binary(p, j, rr, cols), O.copy_csr_arbitrary_binary(p, j, rr, cols))
+    ps, js, xs = synth.csr_skewed(3000, 2000, 15, seed=9)
+    cols = rng.permutation(2000)[:700].astype(np.int32)
+    rows = synth.rows_with_replacement(2500, 3000)
+    _eq_lists(G.copy_csr_arbitrary_numeric(ps, js, xs, rows, cols), O.copy_csr_arbitrary_numeric(ps, js, xs, rows, cols))
+
+
+def test_reverse_rows_and_columns(gpu):
+    for dtype in ("d", "l", "n"):
+        p, j, x = rand_csr(300, 170, 0.15, seed=23, dtype=dtype, empty_rows=(0, 299, 100))
+        if dtype == "d":
+            _eq_lists(G.reverse_rows_numeric(p, j, x), O.reverse_rows_numeric(p, j, x))
+        elif dtype == "l":
+            _eq_lists(G.reverse_rows_logical(p, j, x), O.reverse_rows_logical(p, j, x))
+        else:
+            _eq_lists(G.reverse_rows_binary(p, j), O.reverse_rows_binary(p, j))
+        jg, jo = j.copy(), j.copy()
+        xg = None if x is None else x.copy()
+        xo = None if x is None else x.copy()
+        O.reverse_columns_inplace(p, jo, xo, 170)
+        if dtype == "d":
+            G.reverse_columns_inplace_numeric(p, jg, xg, 170)
+        elif dtype == "l":
+            G.reverse_columns_inplace_logical(p, jg, xg, 170)
+        else:
+            G.reverse_columns_inplace_binary(p, jg, 170)
+        np.testing.assert_array_equal(jg, jo)
+        if x is not None:
+            np.testing.assert_array_equal(xg, xo)
+    e = G.reverse_rows_numeric(np.zeros(4, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0))
+    assert e["indptr"].tolist() == [0, 0, 0, 0] and e["indices"].size == 0

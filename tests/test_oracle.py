@@ -253,3 +253,50 @@ def test_check_is_seq():
     assert not O.check_is_seq([3, 5, 5]) and not O.check_is_seq([3, 5, 4, 6]) and not O.check_is_seq([5, 4, 3])
     assert O.check_is_rev_seq([5, 4, 3]) and O.check_is_rev_seq([1]) and not O.check_is_rev_seq([3, 4, 5])
     assert not O.check_is_rev_seq([6, 4, 5, 3])
+
+
+# ----------------------------------------------------------------------------- §8(f) rank 2: column-filtering slices
+def test_col_seq_and_arbitrary_vs_scipy():
+    p, j, x = rand_csr(200, 80, 0.15, seed=17, empty_rows=(5, 6))
+    A = sp.csr_matrix((x, j, p), shape=(200, 80))
+    rng = np.random.default_rng(3)
+    rows = rng.integers(0, 200, size=60).astype(np.int32)
+    cols_seq = np.arange(10, 41, dtype=np.int32)                     # R passes 1-based j with index1=TRUE
+    r = O.copy_csr_rows_col_seq_numeric(p, j, x, rows, cols_seq + 1, True)
+    E = A[rows][:, 10:41]
+    E.sort_indices()
+    assert r["indptr"].tolist() == E.indptr.tolist() and r["indices"].tolist() == E.indices.tolist()
+    assert r["values"].tolist() == E.data.tolist()
+    rb = O.copy_csr_rows_col_seq_binary(p, j, rows, cols_seq, False)
+    assert rb["indices"].tolist() == E.indices.tolist() and rb["values"].size == 0
+    rl = O.copy_csr_rows_col_seq_logical(p, j, (x > 0).astype(np.int32), rows, cols_seq, False)
+    assert rl["values"].dtype == np.float64                          # NumericVector in the reference
+    e = O.copy_csr_rows_col_seq_numeric(p, j, x, np.array([5, 6], dtype=np.int32), cols_seq, False)
+    assert e["indptr"].tolist() == [0, 0, 0] and e["indices"].size == 0
+    # arbitrary columns: unsorted, with a repeated column
+    cols = np.array([70, 3, 3, 41, 0, 79, 12], dtype=np.int32)
+    r = O.copy_csr_arbitrary_numeric(p, j, x, rows, cols)
+    E = A[rows][:, cols]
+    E.sort_indices()
+    assert r["indptr"].tolist() == E.indptr.tolist() and r["indices"].tolist() == E.indices.tolist()
+    assert r["values"].tolist() == E.data.tolist()
+    cs = np.sort(cols)
+    r = O.copy_csr_arbitrary_numeric(p, j, x, rows, cs)
+    E = A[rows][:, cs]
+    E.sort_indices()
+    assert r["indices"].tolist() == E.indices.tolist() and r["values"].tolist() == E.data.tolist()
+    assert "values" not in O.copy_csr_arbitrary_binary(p, j, rows, cols)
+
+
+def test_reverse_rows_and_columns():
+    p, j, x = rand_csr(30, 17, 0.3, seed=23, empty_rows=(0, 29))
+    A = sp.csr_matrix((x, j, p), shape=(30, 17))
+    r = O.reverse_rows_numeric(p, j, x)
+    E = A[::-1]
+    assert r["indptr"].tolist() == E.indptr.tolist() and r["indices"].tolist() == E.indices.tolist()
+    assert r["values"].tolist() == E.data.tolist()
+    jj, xx = j.copy(), x.copy()
+    O.reverse_columns_inplace(p, jj, xx, 17)
+    E = sp.csr_matrix(A[:, ::-1])
+    E.sort_indices()
+    assert jj.tolist() == E.indices.tolist() and xx.tolist() == E.data.tolist()

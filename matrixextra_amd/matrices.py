@@ -41,6 +41,7 @@ class RsparseMatrix:
     """Compressed sparse row. Subclasses fix the value type."""
     value_dtype = None
     r_class = "RsparseMatrix"
+    __array_ufunc__ = None            # numpy arrays on the left defer to __rmatmul__ etc.
 
     def __init__(self, p, j, x=None, Dim=None, Dimnames=None):
         self.p = np.ascontiguousarray(p, dtype=np.int32)
@@ -152,6 +153,7 @@ class ngRMatrix(RsparseMatrix):
 class dgCMatrix:
     """Compressed sparse column, numeric (only what `matrix %*% CsparseMatrix` needs)."""
     r_class = "dgCMatrix"
+    __array_ufunc__ = None
 
     def __init__(self, p, i, x, Dim, Dimnames=None):
         self.p = np.ascontiguousarray(p, dtype=np.int32)
@@ -180,6 +182,7 @@ class dgCMatrix:
 class float32:
     """The `float` package's float32: @Data holds binary32 values, column-major (R/matmul.R:260,276)."""
     r_class = "float32"
+    __array_ufunc__ = None
 
     def __init__(self, Data, Dimnames=None):
         Data = np.asarray(Data, dtype=np.float32)

@@ -180,6 +180,20 @@ int mxd_csr_reverse_columns(int m, int64_t nnz, const int32_t *indptr, int32_t *
                             int value_dtype, int ncol, void *stream);
 int mxd_reversed_iota(int n, int32_t *out, void *stream);   /* out[i] = n-1-i: row list of reverse_rows */
 
+/* cbind / rbind.
+ * cbind: out row r = X row r followed by Y row r (Y's column ids already shifted by ncol X), rows past the end of
+ * the shorter operand come from the longer one only (cbind_csr<>, src/cbind.cpp:4-99).  Outputs hold
+ * max(nX, nY)+1 / nnzX+nnzY entries; no scan needed (offsets are Xp[r] + Yp[r]). */
+int mxd_csr_cbind(int nX, int nY, const int32_t *Xp, const int32_t *Xj, const void *Xx, const int32_t *Yp,
+                  const int32_t *Yj_plus_ncol, const void *Yx, int value_dtype, int64_t nnz_total,
+                  int32_t *indptr, int32_t *indices, void *values, void *stream);
+/* rbind: append one operand at (row_offset, entry_offset) with the value conversions of concat_csr_batch
+ * (src/rbind.cpp:24-173).  in_kind 0 dgR, 1 lgR, 2 ngR, 3/4/5/6 d/i/l/n sparseVector (1-based indices, one row);
+ * out_kind 0 dgR, 1 lgR, 2 ngR. */
+int mxd_csr_rbind_append(int in_kind, const int32_t *indptr_in, const int32_t *indices_in, const void *values_in,
+                         int nrows_in, int64_t nnz_in, int out_kind, int row_offset, int64_t entry_offset,
+                         int32_t *out_indptr, int32_t *out_indices, void *out_values, void *stream);
+
 /* check_is_seq / check_is_rev_seq (src/slice.cpp:25-47) on a device vector.
  * *flag_host receives 0/1 after an internal stream sync. */
 int mxd_check_is_seq(const int32_t *idx, int64_t n, int reversed, int32_t *workspace4,
@@ -304,6 +318,22 @@ int mx_reverse_rows_begin(const int32_t *indptr, int nrows, const int32_t *indic
 /* reverse_columns_inplace_{numeric,logical,binary}  src/slice.cpp:172-221: modifies indices / values */
 int mx_reverse_columns_inplace(const int32_t *indptr, int nrows, int32_t *indices, void *values,
                                int value_dtype, int64_t n_values, int ncol);
+/* cbind_csr_{numeric,logical,binary}  src/cbind.cpp:101-157 (value_dtype MX_F64 / MX_LGL / MX_NONE) */
+int mx_cbind_csr_begin(const int32_t *X_indptr, int nrows_X, const int32_t *X_indices, const void *X_values,
+                       int64_t n_values_X, const int32_t *Y_indptr, int nrows_Y,
+                       const int32_t *Y_indices_plus_ncol, const void *Y_values, int64_t n_values_Y,
+                       int value_dtype, mx_result **res, mx_result_info *info);
+/* concat_csr_batch  src/rbind.cpp:24-173 over plain arrays instead of S4 objects */
+typedef struct {
+    int kind;                  /* 0 dgR, 1 lgR, 2 ngR, 3 dsparseVector, 4 isparseVector, 5 lsparseVector, 6 nsparseVector */
+    const int32_t *indptr;     /* matrices only */
+    const int32_t *indices;    /* @j (0-based) or @i of a sparse vector (1-based) */
+    const void *values;        /* f64 / int32 / NULL */
+    int nrows;                 /* matrices: Dim[1]; vectors: ignored (one row) */
+    int64_t nnz;
+} mx_rbind_input;
+int mx_concat_csr_batch_begin(const mx_rbind_input *objects, int n_inputs, int out_kind,
+                              mx_result **res, mx_result_info *info);
 int mx_result_finish(mx_result *res, int32_t *out_indptr, int32_t *out_indices, void *out_values);
 int mx_result_discard(mx_result *res);
 

@@ -26,7 +26,12 @@
     "matmul_csr_dvec_numeric", "matmul_csr_dvec_integer", "matmul_csr_dvec_logical", "matmul_csr_dvec_float32",
     "multiply_csr_elemwise", "logicaland_csr_elemwise", "add_csr_elemwise", "logicalor_csr_elemwise",
     "copy_csr_rows_numeric", "copy_csr_rows_logical", "copy_csr_rows_binary",
-    "check_is_seq", "check_is_rev_seq"
+    "check_is_seq", "check_is_rev_seq",
+    ## SURVEY section 8(f) rank 2: column-filtering slices and reversals
+    "copy_csr_rows_col_seq_numeric", "copy_csr_rows_col_seq_logical", "copy_csr_rows_col_seq_binary",
+    "copy_csr_arbitrary_numeric", "copy_csr_arbitrary_logical", "copy_csr_arbitrary_binary",
+    "reverse_rows_numeric", "reverse_rows_logical", "reverse_rows_binary",
+    "reverse_columns_inplace_numeric", "reverse_columns_inplace_logical", "reverse_columns_inplace_binary"
 )
 
 mxgpu_enable <- function(shim_path, min_nnz = 0L) {

@@ -547,6 +547,98 @@ int mx_reverse_columns_inplace(const int32_t *indptr, int nrows, int32_t *indice
     return 0;
 }
 
+// ---- cbind / rbind (§8f rank 3) ----------------------------------------------------------------------------
+int mx_cbind_csr_begin(const int32_t *Xp, int nX, const int32_t *Xj, const void *Xx, int64_t nvX, const int32_t *Yp,
+                       int nY, const int32_t *Yj, const void *Yx, int64_t nvY, int value_dtype, mx_result **res_out,
+                       mx_result_info *info)
+{
+    MX_REQUIRE(res_out && info && nX >= 0 && nY >= 0, "mx_cbind_csr_begin: bad arguments");
+    *res_out = nullptr;
+    const bool has_values = value_dtype != MX_NONE && (nvX > 0 || nvY > 0);           // cbind.cpp:19-20
+    const size_t vb = has_values ? dtype_bytes(value_dtype) : 0;
+    mx_result *res = new (std::nothrow) mx_result();
+    MX_REQUIRE(res, "out of host memory");
+    res->info.values_dtype = value_dtype == MX_NONE ? MX_F64 : value_dtype;           // binary: empty NumericVector
+    res->info.alias_structure = 0;
+    int rc = 0;
+    do {
+        Csr X, Y;
+        if ((rc = X.upload(Xp, Xj, Xx, nX, vb))) break;
+        if ((rc = Y.upload(Yp, Yj, Yx, nY, vb))) break;
+        const int nrows = nX > nY ? nX : nY;
+        const int64_t nnz = X.nnz + Y.nnz;
+        if (nnz > INT_MAX) { rc = set_error("cbind result exceeds R's int32 index range"); break; }
+        res->info.indptr_len = (int64_t)nrows + 1;
+        res->info.nnz = nnz;
+        res->info.values_len = has_values ? nnz : 0;
+        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
+        if (nnz == 0) {                                                               // cbind.cpp:22-29: zeros
+            if (hipMemset(res->indptr.p, 0, sizeof(int32_t) * ((size_t)nrows + 1)) != hipSuccess) rc = set_error("hipMemset failed");
+            break;
+        }
+        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz))) break;
+        if (has_values && (rc = res->values.alloc(vb * (size_t)nnz))) break;
+        if ((rc = mxd_csr_cbind(nX, nY, X.p.as<int32_t>(), X.j.as<int32_t>(), X.x.p, Y.p.as<int32_t>(), Y.j.as<int32_t>(),
+                                Y.x.p, has_values ? value_dtype : MX_NONE, nnz, res->indptr.as<int32_t>(),
+                                res->indices.as<int32_t>(), res->values.p, nullptr))) break;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
+    } while (0);
+    if (rc) { delete res; return rc; }
+    *info = res->info;
+    *res_out = res;
+    return 0;
+}
+
+int mx_concat_csr_batch_begin(const mx_rbind_input *objs, int n_inputs, int out_kind, mx_result **res_out,
+                              mx_result_info *info)
+{
+    MX_REQUIRE(res_out && info && n_inputs >= 0 && out_kind >= 0 && out_kind <= 2, "mx_concat_csr_batch_begin: bad arguments");
+    *res_out = nullptr;
+    int64_t nrows = 0, nnz = 0;
+    for (int k = 0; k < n_inputs; k++) {
+        MX_REQUIRE(objs[k].kind >= 0 && objs[k].kind <= 6, "Invalid vector type in argument %d.", k);   // rbind.cpp:131-135
+        nrows += objs[k].kind <= 2 ? objs[k].nrows : 1;
+        nnz += objs[k].nnz;
+    }
+    MX_REQUIRE(nrows <= INT_MAX - 1 && nnz <= INT_MAX, "rbind result exceeds R's int32 index range");
+    const size_t vb = out_kind == 0 ? 8 : out_kind == 1 ? 4 : 0;
+    mx_result *res = new (std::nothrow) mx_result();
+    MX_REQUIRE(res, "out of host memory");
+    res->info.values_dtype = out_kind == 0 ? MX_F64 : out_kind == 1 ? MX_LGL : MX_NONE;
+    res->info.alias_structure = 0;
+    res->info.indptr_len = nrows + 1;
+    res->info.nnz = nnz;
+    res->info.values_len = vb ? nnz : 0;
+    int rc = 0;
+    do {
+        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
+        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz))) break;
+        if (vb && (rc = res->values.alloc(vb * (size_t)nnz))) break;
+        if (hipMemset(res->indptr.p, 0, sizeof(int32_t)) != hipSuccess) { rc = set_error("hipMemset failed"); break; }
+        int row = 0;
+        int64_t pos = 0;
+        for (int k = 0; k < n_inputs && !rc; k++) {
+            const mx_rbind_input &o = objs[k];
+            const bool vec = o.kind >= 3;
+            const size_t ivb = (o.kind == 0 || o.kind == 3) ? 8 : (o.kind == 2 || o.kind == 6) ? 0 : 4;
+            DevBuf p, j, x;
+            if (!vec && (rc = p.upload(o.indptr, sizeof(int32_t) * ((size_t)o.nrows + 1)))) break;
+            if ((rc = j.upload(o.indices, sizeof(int32_t) * (size_t)o.nnz))) break;
+            if (ivb && (rc = x.upload(o.values, ivb * (size_t)o.nnz))) break;
+            if ((rc = mxd_csr_rbind_append(o.kind, p.as<int32_t>(), j.as<int32_t>(), ivb ? x.p : nullptr, vec ? 1 : o.nrows,
+                                           o.nnz, out_kind, row, pos, res->indptr.as<int32_t>(), res->indices.as<int32_t>(),
+                                           res->values.p, nullptr))) break;
+            if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
+            row += vec ? 1 : o.nrows;
+            pos += o.nnz;
+        }
+    } while (0);
+    if (rc) { delete res; return rc; }
+    *info = res->info;
+    *res_out = res;
+    return 0;
+}
+
 int mx_result_finish(mx_result *res, int32_t *out_indptr, int32_t *out_indices, void *out_values)
 {
     MX_REQUIRE(res, "mx_result_finish: null handle");

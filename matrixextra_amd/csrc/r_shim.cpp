@@ -1,6 +1,6 @@
 // r_shim.cpp — thin `.Call` translation unit between R and libmxgpu's C-ABI.
 //
-// Exports, for the 19 hot-path routines, exactly the native-routine names and arities that the
+// Exports, for the 19 hot-path routines (+ 12 column-slice / reversal routines of SURVEY §8f rank 2), exactly the native-routine names and arities that the
 // reference registers in CallEntries[] (src/RcppExports.cpp:2233-2242, 2290-2291, 2297-2298, 2333-2334,
 // 2341-2343), so R code written as `.Call("_MatrixExtra_<fn>", ...)` (R/RcppExports.R) dispatches
 // unchanged, plus mxgpu_register() to add them to a DllInfo.  Written against the plain R C API
@@ -259,6 +259,88 @@ SEXP _MatrixExtra_copy_csr_rows_numeric(SEXP p_, SEXP j_, SEXP x_, SEXP rows) { 
 SEXP _MatrixExtra_copy_csr_rows_logical(SEXP p_, SEXP j_, SEXP x_, SEXP rows) { return copy_rows(p_, j_, x_, rows, MX_LGL); }
 SEXP _MatrixExtra_copy_csr_rows_binary(SEXP p_, SEXP j_, SEXP rows) { return copy_rows(p_, j_, R_NilValue, rows, MX_NONE); }
 
+// ---- X[rows, cols] (§8f rank 2) -----------------------------------------------------------------------------
+static SEXP col_seq(SEXP p_, SEXP j_, SEXP x_, SEXP rows, SEXP cols, SEXP index1, int dtype)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); rows = as_type(rows, INTSXP, p); cols = as_type(cols, INTSXP, p);
+    const void *v = nullptr; int64_t nv = 0;
+    if (dtype == MX_F64) { x_ = as_type(x_, REALSXP, p); v = REAL(x_); nv = XLENGTH(x_); }
+    else if (dtype == MX_LGL) { x_ = as_type(x_, LGLSXP, p); v = LOGICAL(x_); nv = XLENGTH(x_); }
+    mx_result *res = nullptr; mx_result_info info;
+    if (mx_copy_csr_rows_col_seq_begin(INTEGER(p_), (int)XLENGTH(p_) - 1, INTEGER(j_), v, dtype, nv, INTEGER(rows),
+                                       (int64_t)XLENGTH(rows), INTEGER(cols), (int64_t)XLENGTH(cols),
+                                       Rf_asLogical(index1), &res, &info))
+        fail();
+    return finish_guarded(res, info, R_NilValue, R_NilValue);         // values: numeric vector (slice.cpp:363)
+}
+SEXP _MatrixExtra_copy_csr_rows_col_seq_numeric(SEXP p_, SEXP j_, SEXP x_, SEXP rows, SEXP cols, SEXP index1)
+{ return col_seq(p_, j_, x_, rows, cols, index1, MX_F64); }
+SEXP _MatrixExtra_copy_csr_rows_col_seq_logical(SEXP p_, SEXP j_, SEXP x_, SEXP rows, SEXP cols, SEXP index1)
+{ return col_seq(p_, j_, x_, rows, cols, index1, MX_LGL); }
+SEXP _MatrixExtra_copy_csr_rows_col_seq_binary(SEXP p_, SEXP j_, SEXP rows, SEXP cols, SEXP index1)
+{ return col_seq(p_, j_, R_NilValue, rows, cols, index1, MX_NONE); }
+
+static SEXP arbitrary(SEXP p_, SEXP j_, SEXP x_, SEXP rows, SEXP cols, int dtype)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); rows = as_type(rows, INTSXP, p); cols = as_type(cols, INTSXP, p);
+    const void *v = nullptr; int64_t nv = 0;
+    if (dtype == MX_F64) { x_ = as_type(x_, REALSXP, p); v = REAL(x_); nv = XLENGTH(x_); }
+    else if (dtype == MX_LGL) { x_ = as_type(x_, LGLSXP, p); v = LOGICAL(x_); nv = XLENGTH(x_); }
+    mx_result *res = nullptr; mx_result_info info;
+    if (mx_copy_csr_arbitrary_begin(INTEGER(p_), (int)XLENGTH(p_) - 1, INTEGER(j_), v, dtype, nv, INTEGER(rows),
+                                    (int64_t)XLENGTH(rows), INTEGER(cols), (int64_t)XLENGTH(cols), &res, &info))
+        fail();
+    const bool no_values = info.values_dtype == MX_NONE;
+    SEXP out = p(finish_guarded(res, info, R_NilValue, R_NilValue));
+    if (!no_values) return out;
+    // the reference's list has no `values` element when the matrix has none (slice.cpp:565)
+    SEXP two = p(Rf_allocVector(VECSXP, 2));
+    SET_VECTOR_ELT(two, 0, VECTOR_ELT(out, 0));
+    SET_VECTOR_ELT(two, 1, VECTOR_ELT(out, 1));
+    SEXP nm = p(Rf_allocVector(STRSXP, 2));
+    SET_STRING_ELT(nm, 0, Rf_mkChar("indptr"));
+    SET_STRING_ELT(nm, 1, Rf_mkChar("indices"));
+    Rf_setAttrib(two, R_NamesSymbol, nm);
+    return two;
+}
+SEXP _MatrixExtra_copy_csr_arbitrary_numeric(SEXP p_, SEXP j_, SEXP x_, SEXP rows, SEXP cols) { return arbitrary(p_, j_, x_, rows, cols, MX_F64); }
+SEXP _MatrixExtra_copy_csr_arbitrary_logical(SEXP p_, SEXP j_, SEXP x_, SEXP rows, SEXP cols) { return arbitrary(p_, j_, x_, rows, cols, MX_LGL); }
+SEXP _MatrixExtra_copy_csr_arbitrary_binary(SEXP p_, SEXP j_, SEXP rows, SEXP cols) { return arbitrary(p_, j_, R_NilValue, rows, cols, MX_NONE); }
+
+static SEXP reverse_rows(SEXP p_, SEXP j_, SEXP x_, int dtype)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p);
+    const void *v = nullptr; int64_t nv = 0;
+    if (dtype == MX_F64) { x_ = as_type(x_, REALSXP, p); v = REAL(x_); nv = XLENGTH(x_); }
+    else if (dtype == MX_LGL) { x_ = as_type(x_, LGLSXP, p); v = LOGICAL(x_); nv = XLENGTH(x_); }
+    mx_result *res = nullptr; mx_result_info info;
+    if (mx_reverse_rows_begin(INTEGER(p_), (int)XLENGTH(p_) - 1, INTEGER(j_), v, dtype, nv, &res, &info)) fail();
+    if (dtype == MX_LGL) info.values_dtype = info.values_len ? MX_LGL : info.values_dtype;
+    return finish_guarded(res, info, R_NilValue, R_NilValue);
+}
+SEXP _MatrixExtra_reverse_rows_numeric(SEXP p_, SEXP j_, SEXP x_) { return reverse_rows(p_, j_, x_, MX_F64); }
+SEXP _MatrixExtra_reverse_rows_logical(SEXP p_, SEXP j_, SEXP x_) { return reverse_rows(p_, j_, x_, MX_LGL); }
+SEXP _MatrixExtra_reverse_rows_binary(SEXP p_, SEXP j_) { return reverse_rows(p_, j_, R_NilValue, MX_NONE); }
+
+// in place on the caller's vectors, like the reference (the R glue only passes freshly created results here)
+static SEXP reverse_cols(SEXP p_, SEXP j_, SEXP x_, SEXP ncol, int dtype)
+{
+    void *v = nullptr; int64_t nv = 0;
+    if (dtype == MX_F64 && TYPEOF(x_) == REALSXP) { v = REAL(x_); nv = XLENGTH(x_); }
+    else if (dtype == MX_LGL && TYPEOF(x_) == LGLSXP) { v = LOGICAL(x_); nv = XLENGTH(x_); }
+    if (TYPEOF(p_) != INTSXP || TYPEOF(j_) != INTSXP) Rf_error("reverse_columns_inplace: integer index vectors required");
+    if (mx_reverse_columns_inplace(INTEGER(p_), (int)XLENGTH(p_) - 1, INTEGER(j_), v, nv ? dtype : MX_NONE, nv,
+                                   Rf_asInteger(ncol)))
+        fail();
+    return R_NilValue;
+}
+SEXP _MatrixExtra_reverse_columns_inplace_numeric(SEXP p_, SEXP j_, SEXP x_, SEXP ncol) { return reverse_cols(p_, j_, x_, ncol, MX_F64); }
+SEXP _MatrixExtra_reverse_columns_inplace_logical(SEXP p_, SEXP j_, SEXP x_, SEXP ncol) { return reverse_cols(p_, j_, x_, ncol, MX_LGL); }
+SEXP _MatrixExtra_reverse_columns_inplace_binary(SEXP p_, SEXP j_, SEXP x_, SEXP ncol) { return reverse_cols(p_, j_, x_, ncol, MX_NONE); }
+
 SEXP _MatrixExtra_check_is_seq(SEXP idx)
 {
     Protect p;
@@ -287,6 +369,12 @@ static const R_CallMethodDef mxgpu_call_entries[] = {
     MX_ENTRY(add_csr_elemwise, 7), MX_ENTRY(logicalor_csr_elemwise, 7),
     MX_ENTRY(copy_csr_rows_numeric, 4), MX_ENTRY(copy_csr_rows_logical, 4), MX_ENTRY(copy_csr_rows_binary, 3),
     MX_ENTRY(check_is_seq, 1), MX_ENTRY(check_is_rev_seq, 1),
+    MX_ENTRY(copy_csr_rows_col_seq_numeric, 6), MX_ENTRY(copy_csr_rows_col_seq_logical, 6),
+    MX_ENTRY(copy_csr_rows_col_seq_binary, 5),
+    MX_ENTRY(copy_csr_arbitrary_numeric, 5), MX_ENTRY(copy_csr_arbitrary_logical, 5), MX_ENTRY(copy_csr_arbitrary_binary, 4),
+    MX_ENTRY(reverse_rows_numeric, 3), MX_ENTRY(reverse_rows_logical, 3), MX_ENTRY(reverse_rows_binary, 2),
+    MX_ENTRY(reverse_columns_inplace_numeric, 4), MX_ENTRY(reverse_columns_inplace_logical, 4),
+    MX_ENTRY(reverse_columns_inplace_binary, 4),
     {NULL, NULL, 0}
 };
 

@@ -332,6 +332,64 @@ def reverse_columns_inplace_binary(indptr, indices, ncol):
     _reverse_columns_inplace(indptr, indices, None, ncol, MX_NONE)
 
 
+# ----------------------------------------------------------------------------- cbind / rbind (§8f-3)
+def _cbind(Xp, Xj, Xx, Yp, Yj_plus_ncol, Yx, value_dtype, vdt):
+    lib = _lib.load()
+    Xp, Xj, Yp, Yj = _i32(Xp), _i32(Xj), _i32(Yp), _i32(Yj_plus_ncol)
+    xv = None if Xx is None else np.ascontiguousarray(Xx, dtype=vdt)
+    yv = None if Yx is None else np.ascontiguousarray(Yx, dtype=vdt)
+    res = C.c_void_p()
+    info = ResultInfo()
+    check(lib.mx_cbind_csr_begin(ptr(Xp), C.c_int(Xp.size - 1), ptr(Xj), ptr(xv), C.c_int64(0 if xv is None else xv.size),
+                                 ptr(Yp), C.c_int(Yp.size - 1), ptr(Yj), ptr(yv), C.c_int64(0 if yv is None else yv.size),
+                                 C.c_int(value_dtype), C.byref(res), C.byref(info)))
+    return _finish(res, info)
+
+
+def cbind_csr_numeric(X_csr_indptr, X_csr_indices, X_csr_values, Y_csr_indptr, Y_csr_indices_plus_ncol, Y_csr_values):
+    """src/cbind.cpp:101-119."""
+    return _cbind(X_csr_indptr, X_csr_indices, X_csr_values, Y_csr_indptr, Y_csr_indices_plus_ncol, Y_csr_values,
+                  MX_F64, np.float64)
+
+
+def cbind_csr_logical(X_csr_indptr, X_csr_indices, X_csr_values, Y_csr_indptr, Y_csr_indices_plus_ncol, Y_csr_values):
+    """src/cbind.cpp:121-139."""
+    return _cbind(X_csr_indptr, X_csr_indices, X_csr_values, Y_csr_indptr, Y_csr_indices_plus_ncol, Y_csr_values,
+                  MX_LGL, np.int32)
+
+
+def cbind_csr_binary(X_csr_indptr, X_csr_indices, Y_csr_indptr, Y_csr_indices_plus_ncol):
+    """src/cbind.cpp:141-157."""
+    return _cbind(X_csr_indptr, X_csr_indices, None, Y_csr_indptr, Y_csr_indices_plus_ncol, None, MX_NONE, None)
+
+
+class _RbindInput(C.Structure):
+    _fields_ = [("kind", C.c_int), ("indptr", C.c_void_p), ("indices", C.c_void_p), ("values", C.c_void_p),
+                ("nrows", C.c_int), ("nnz", C.c_int64)]
+
+
+def concat_csr_batch(objects, out_kind):
+    """concat_csr_batch (src/rbind.cpp:24-173) over plain arrays: objects = list of
+    (kind, indptr|None, indices, values|None, nrows) with kind 0 dgR, 1 lgR, 2 ngR, 3/4/5/6 d/i/l/n sparseVector
+    (1-based indices, one row); out_kind 0 dgR, 1 lgR, 2 ngR.  Returns dict(indptr, indices, values)."""
+    lib = _lib.load()
+    keep, arr = [], (_RbindInput * max(len(objects), 1))()
+    for k, (kind, p, j, x, nr) in enumerate(objects):
+        jj = _i32(j)
+        pp = None if p is None else _i32(p)
+        xx = None if x is None else np.ascontiguousarray(x, dtype=np.float64 if kind in (0, 3) else np.int32)
+        keep += [jj, pp, xx]
+        arr[k] = _RbindInput(kind, None if pp is None else pp.ctypes.data, jj.ctypes.data,
+                             None if xx is None else xx.ctypes.data, int(nr), jj.size)
+    res = C.c_void_p()
+    info = ResultInfo()
+    check(lib.mx_concat_csr_batch_begin(arr, C.c_int(len(objects)), C.c_int(out_kind), C.byref(res), C.byref(info)))
+    out = _finish(res, info)
+    if out_kind == 2:
+        out["values"] = None
+    return out
+
+
 def check_is_seq(indices) -> bool:
     """src/slice.cpp:25-35."""
     a = _i32(indices)

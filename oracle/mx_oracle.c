@@ -481,3 +481,73 @@ void mxo_reverse_columns_inplace(const int *indptr, int *indices, void *values, 
         }
     }
 }
+
+/* ==== §8(f) rank 3: cbind / rbind of CSR ====================================================== */
+
+/* ---- cbind_csr (cbind.cpp:4-99) ------------------------------------------- */
+/* Y's column ids arrive already shifted by ncol(X) (R/cbind.R:87-97).  value_bytes 0/4/8 (0 when BOTH value
+ * vectors are empty).  indptr[nrows+1], indices[nnzX+nnzY], values likewise.  nX / nY = number of rows. */
+void mxo_cbind_csr(const int *Xp, const int *Xj, const void *Xx, int nX, const int *Yp, const int *Yj, const void *Yx,
+                   int nY, int value_bytes, int *indptr, int *indices, void *values)
+{
+    const int nrows = nX > nY ? nX : nY, nmin = nX < nY ? nX : nY;
+    indptr[0] = 0;
+    for (int row = 0; row < nrows; row++) {
+        const int lx = row < nX ? Xp[row + 1] - Xp[row] : 0;
+        const int ly = row < nY ? Yp[row + 1] - Yp[row] : 0;
+        indptr[row + 1] = indptr[row] + lx + ly;
+        if (lx) memcpy(indices + indptr[row], Xj + Xp[row], (size_t)lx * sizeof(int));
+        if (ly) memcpy(indices + indptr[row] + lx, Yj + Yp[row], (size_t)ly * sizeof(int));
+        if (value_bytes) {
+            if (lx) memcpy((char *)values + (size_t)indptr[row] * value_bytes, (const char *)Xx + (size_t)Xp[row] * value_bytes, (size_t)lx * value_bytes);
+            if (ly) memcpy((char *)values + (size_t)(indptr[row] + lx) * value_bytes, (const char *)Yx + (size_t)Yp[row] * value_bytes, (size_t)ly * value_bytes);
+        }
+    }
+    (void)nmin;
+}
+
+/* ---- concat_indptr2 (rbind.cpp:9-21) --------------------------------------- */
+void mxo_concat_indptr2(const int *ptr1, int n1, const int *ptr2, int n2, int *out)
+{
+    memcpy(out, ptr1, (size_t)n1 * sizeof(int));
+    const int offset = ptr1[n1 - 1];
+    for (int row = 1; row < n2; row++) out[n1 + row - 1] = offset + ptr2[row];
+}
+
+/* ---- concat_csr_batch (rbind.cpp:24-173): one input appended at (curr_row, curr_pos) ---------------
+ * in_kind: 0 dgRMatrix (f64), 1 lgRMatrix (int32), 2 ngRMatrix (no values),
+ *          3 dsparseVector, 4 isparseVector, 5 lsparseVector, 6 nsparseVector (1-based `i`, one row)
+ * out_kind: 0 dgRMatrix, 1 lgRMatrix, 2 ngRMatrix.  Returns the number of rows appended. */
+int mxo_concat_csr_append(int in_kind, const int *indptr_obj, const int *indices_obj, const void *values_obj,
+                          int nrows_add, int nnz_add, int out_kind, int curr_row, int curr_pos,
+                          int *indptr_out, int *indices_out, void *values_out)
+{
+    const double NA = na_real();
+    double *vd = (double *)values_out;
+    int *vl = (int *)values_out;
+    if (in_kind <= 2) {
+        for (int row = 0; row < nrows_add; row++) indptr_out[row + curr_row + 1] = indptr_out[curr_row] + indptr_obj[row + 1];
+        memcpy(indices_out + curr_pos, indices_obj, (size_t)nnz_add * sizeof(int));
+    } else {
+        indptr_out[curr_row + 1] = indptr_out[curr_row] + nnz_add;
+        for (int el = 0; el < nnz_add; el++) indices_out[el + curr_pos] = indices_obj[el] - 1;
+        nrows_add = 1;
+    }
+    const double *xd = (const double *)values_obj;
+    const int *xi = (const int *)values_obj;
+    for (int el = 0; el < nnz_add; el++) {
+        if (out_kind == 0) {
+            if (in_kind == 0 || in_kind == 3) vd[el + curr_pos] = xd[el];
+            else if (in_kind == 1) vd[el + curr_pos] = xi[el] == NA_INT ? NA : xi[el];               /* rbind.cpp:76 */
+            else if (in_kind == 4) vd[el + curr_pos] = xi[el] == NA_INT ? NA : xi[el];
+            else if (in_kind == 5) vd[el + curr_pos] = xi[el] == NA_INT ? NA : (double)(xi[el] != 0);
+            else vd[el + curr_pos] = 1.0;
+        } else if (out_kind == 1) {
+            if (in_kind == 1 || in_kind == 5) vl[el + curr_pos] = xi[el];
+            else if (in_kind == 0 || in_kind == 3) vl[el + curr_pos] = isnan(xd[el]) ? NA_INT : (xd[el] != 0);
+            else if (in_kind == 4) vl[el + curr_pos] = xi[el] == NA_INT ? NA_INT : (xi[el] != 0);
+            else vl[el + curr_pos] = 1;
+        }
+    }
+    return nrows_add;
+}

@@ -415,3 +415,69 @@ def reverse_columns_inplace(indptr, indices, values, ncol):
     p = _i32(indptr)
     vb = 0 if values is None else values.dtype.itemsize
     lib().mxo_reverse_columns_inplace(_p(p), _p(indices), _p(values), C.c_int(vb), C.c_int(p.size - 1), C.c_int(int(ncol)))
+
+
+# ----------------------------------------------------------------------------- cbind / rbind (§8f-3)
+def _cbind(Xp, Xj, Xx, Yp, Yj_plus_ncol, Yx, vdt):
+    Xp, Xj, Yp, Yj = _i32(Xp), _i32(Xj), _i32(Yp), _i32(Yj_plus_ncol)
+    hx = Xx is not None and np.asarray(Xx).size > 0
+    hy = Yx is not None and np.asarray(Yx).size > 0
+    has_values = hx or hy
+    nnz = Xj.size + Yj.size
+    nrows = max(Xp.size, Yp.size) - 1
+    indptr = np.zeros(nrows + 1, dtype=np.int32)
+    indices = np.zeros(nnz, dtype=np.int32)
+    values = np.zeros(nnz if has_values else 0, dtype=vdt if vdt is not None else np.float64)
+    if nnz == 0:
+        return dict(indptr=indptr, indices=indices, values=values)
+    xv = np.ascontiguousarray(Xx, dtype=vdt) if has_values else None
+    yv = np.ascontiguousarray(Yx, dtype=vdt) if has_values else None
+    lib().mxo_cbind_csr(_p(Xp), _p(Xj), _p(xv), C.c_int(Xp.size - 1), _p(Yp), _p(Yj), _p(yv), C.c_int(Yp.size - 1),
+                        C.c_int(values.dtype.itemsize if has_values else 0), _p(indptr), _p(indices),
+                        _p(values) if has_values else None)
+    return dict(indptr=indptr, indices=indices, values=values)
+
+
+def cbind_csr_numeric(Xp, Xj, Xx, Yp, Yj_plus_ncol, Yx):
+    """src/cbind.cpp:101-119"""
+    return _cbind(Xp, Xj, Xx, Yp, Yj_plus_ncol, Yx, np.float64)
+
+
+def cbind_csr_logical(Xp, Xj, Xx, Yp, Yj_plus_ncol, Yx):
+    """src/cbind.cpp:121-139"""
+    return _cbind(Xp, Xj, Xx, Yp, Yj_plus_ncol, Yx, np.int32)
+
+
+def cbind_csr_binary(Xp, Xj, Yp, Yj_plus_ncol):
+    """src/cbind.cpp:141-157"""
+    return _cbind(Xp, Xj, None, Yp, Yj_plus_ncol, None, None)
+
+
+def concat_indptr2(ptr1, ptr2):
+    """src/rbind.cpp:9-21"""
+    a, b = _i32(ptr1), _i32(ptr2)
+    out = np.empty(a.size + b.size - 1, dtype=np.int32)
+    lib().mxo_concat_indptr2(_p(a), C.c_int(a.size), _p(b), C.c_int(b.size), _p(out))
+    return out
+
+
+def concat_csr_batch(objects, out_kind):
+    """src/rbind.cpp:24-173.  objects: list of (in_kind, indptr|None, indices, values|None, nrows); kinds as in
+    mx_oracle.c (0 dgR, 1 lgR, 2 ngR, 3..6 d/i/l/n sparse vectors with 1-based indices).  out_kind 0 dgR, 1 lgR, 2 ngR."""
+    nrows = sum(o[4] if o[0] <= 2 else 1 for o in objects)
+    nnz = sum(np.asarray(o[2]).size for o in objects)
+    indptr = np.zeros(nrows + 1, dtype=np.int32)
+    indices = np.zeros(nnz, dtype=np.int32)
+    values = None if out_kind == 2 else np.zeros(nnz, dtype=np.float64 if out_kind == 0 else np.int32)
+    row = pos = 0
+    for kind, p, j, x, nr in objects:
+        j = _i32(j)
+        pp = _i32(p) if p is not None else None
+        xv = None
+        if x is not None:
+            xv = np.ascontiguousarray(x, dtype=np.float64 if kind in (0, 3) else np.int32)
+        row += lib().mxo_concat_csr_append(C.c_int(kind), _p(pp), _p(j), _p(xv), C.c_int(nr), C.c_int(j.size),
+                                           C.c_int(out_kind), C.c_int(row), C.c_int(pos), _p(indptr), _p(indices),
+                                           _p(values))
+        pos += j.size
+    return dict(indptr=indptr, indices=indices, values=values)

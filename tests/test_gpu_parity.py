@@ -362,3 +362,38 @@ def test_reverse_rows_and_columns(gpu):
             np.testing.assert_array_equal(xg, xo)
     e = G.reverse_rows_numeric(np.zeros(4, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0))
     assert e["indptr"].tolist() == [0, 0, 0, 0] and e["indices"].size == 0
+
+
+# ----------------------------------------------------------------------------- §8(f) rank 3: cbind / rbind
+def test_cbind_csr(gpu):
+    rng = np.random.default_rng(8)
+    for (m1, m2, d1, d2) in [(400, 400, 0.2, 0.3), (400, 250, 0.2, 0.3), (250, 400, 0.0, 0.3), (50, 50, 0.0, 0.0)]:
+        p1, j1, x1 = rand_csr(m1, 130, d1, seed=51 + m2, empty_rows=(2,))
+        p2, j2, x2 = rand_csr(m2, 90, d2, seed=52 + m1, empty_rows=(2, 3))
+        j2s = (j2 + 130).astype(np.int32)
+        _eq_lists(G.cbind_csr_numeric(p1, j1, x1, p2, j2s, x2), O.cbind_csr_numeric(p1, j1, x1, p2, j2s, x2))
+        l1 = rng.choice(np.array([0, 1, NA], dtype=np.int32), size=x1.size)
+        l2 = rng.choice(np.array([0, 1, NA], dtype=np.int32), size=x2.size)
+        _eq_lists(G.cbind_csr_logical(p1, j1, l1, p2, j2s, l2), O.cbind_csr_logical(p1, j1, l1, p2, j2s, l2))
+        _eq_lists(G.cbind_csr_binary(p1, j1, p2, j2s), O.cbind_csr_binary(p1, j1, p2, j2s))
+
+
+def test_concat_csr_batch(gpu):
+    p1, j1, x1 = rand_csr(40, 13, 0.3, seed=51, empty_rows=(2,))
+    p2, j2, x2 = rand_csr(25, 13, 0.4, seed=52, empty_rows=(2, 3))
+    xl = np.where(np.arange(j2.size) % 7 == 0, NA, (x2 > 0).astype(np.int32)).astype(np.int32)
+    x1n = x1.copy(); x1n[::5] = np.nan
+    objs = [(0, p1, j1, x1n, 40), (1, p2, j2, xl, 25), (2, p2, j2, None, 25),
+            (3, None, np.array([2, 5], np.int32), np.array([1.5, np.nan]), 1),
+            (4, None, np.array([1, 3], np.int32), np.array([NA, 7], np.int32), 1),
+            (5, None, np.array([3, 4], np.int32), np.array([1, NA], np.int32), 1),
+            (6, None, np.array([9], np.int32), None, 1), (0, np.zeros(4, np.int32), np.zeros(0, np.int32), np.zeros(0), 3)]
+    for out_kind in (0, 1, 2):
+        g, o = G.concat_csr_batch(objs, out_kind), O.concat_csr_batch(objs, out_kind)
+        np.testing.assert_array_equal(g["indptr"], o["indptr"])
+        np.testing.assert_array_equal(g["indices"], o["indices"])
+        if out_kind == 2:
+            assert g["values"] is None
+        else:
+            assert g["values"].dtype == o["values"].dtype
+            np.testing.assert_array_equal(g["values"], o["values"])     # NaN == NaN positionally (assert_array_equal)

@@ -300,3 +300,40 @@ def test_reverse_rows_and_columns():
     E = sp.csr_matrix(A[:, ::-1])
     E.sort_indices()
     assert jj.tolist() == E.indices.tolist() and xx.tolist() == E.data.tolist()
+
+
+# ----------------------------------------------------------------------------- §8(f) rank 3: cbind / rbind
+def test_cbind_rbind_vs_scipy():
+    p1, j1, x1 = rand_csr(40, 13, 0.3, seed=51, empty_rows=(2,))
+    p2, j2, x2 = rand_csr(40, 9, 0.4, seed=52, empty_rows=(2, 3))
+    A, B = sp.csr_matrix((x1, j1, p1), shape=(40, 13)), sp.csr_matrix((x2, j2, p2), shape=(40, 9))
+    r = O.cbind_csr_numeric(p1, j1, x1, p2, j2 + 13, x2)
+    E = sp.hstack([A, B]).tocsr(); E.sort_indices()
+    assert r["indptr"].tolist() == E.indptr.tolist() and r["indices"].tolist() == E.indices.tolist()
+    assert r["values"].tolist() == E.data.tolist()
+    rb = O.cbind_csr_binary(p1, j1, p2, j2 + 13)
+    assert rb["indices"].tolist() == E.indices.tolist() and rb["values"].size == 0
+    # unequal row counts (cbind.cpp:33-38, 75-97): the shorter operand contributes nothing past its end
+    r = O.cbind_csr_numeric(p1, j1, x1, p2[:21], j2[:p2[20]] + 13, x2[:p2[20]])
+    E = sp.hstack([A, sp.vstack([B[:20], sp.csr_matrix((20, 9))])]).tocsr(); E.sort_indices()
+    assert r["indptr"].tolist() == E.indptr.tolist() and r["values"].tolist() == E.data.tolist()
+    assert O.concat_indptr2(p1, p2).tolist() == np.concatenate([p1, p1[-1] + p2[1:]]).tolist()
+    # rbind batch: dgR + lgR (with NA) + ngR + d/i/l/n sparse vectors -> dgRMatrix
+    xl = np.where(np.arange(j2.size) % 7 == 0, NA, (x2 > 0).astype(np.int32)).astype(np.int32)
+    objs = [(0, p1, j1, x1, 40), (1, p2, j2, xl, 40), (2, p2, j2, None, 40),
+            (3, None, np.array([2, 5], np.int32), np.array([1.5, -2.0]), 1),
+            (4, None, np.array([1], np.int32), np.array([NA], np.int32), 1),
+            (5, None, np.array([3, 4], np.int32), np.array([1, NA], np.int32), 1),
+            (6, None, np.array([9], np.int32), None, 1)]
+    r = O.concat_csr_batch(objs, 0)
+    assert r["indptr"].size == 40 * 3 + 4 + 1 and r["indptr"][-1] == r["indices"].size
+    np.testing.assert_array_equal(r["values"][: x1.size], x1)
+    seg = r["values"][x1.size: x1.size + xl.size]
+    np.testing.assert_array_equal(np.isnan(seg), xl == NA)
+    np.testing.assert_array_equal(seg[~np.isnan(seg)], xl[xl != NA].astype(float))
+    assert (r["values"][x1.size + xl.size: x1.size + 2 * xl.size] == 1.0).all()
+    assert r["indices"][-6:].tolist() == [1, 4, 0, 2, 3, 8]                    # 1-based -> 0-based
+    tail = r["values"][-6:]
+    assert tail[0] == 1.5 and tail[1] == -2.0 and np.isnan(tail[2]) and tail[3] == 1.0 and np.isnan(tail[4]) and tail[5] == 1.0
+    rl = O.concat_csr_batch(objs, 1)
+    assert rl["values"].dtype == np.int32 and rl["values"][0] == int(x1[0] != 0)

@@ -194,6 +194,18 @@ int mxd_csr_rbind_append(int in_kind, const int32_t *indptr_in, const int32_t *i
                          int nrows_in, int64_t nnz_in, int out_kind, int row_offset, int64_t entry_offset,
                          int32_t *out_indptr, int32_t *out_indices, void *out_values, void *stream);
 
+/* SURVEY §8f rank 4.
+ * CSR x sparse vector (matmul_csr_svec<>, src/matmul.cpp:486-641): y given as sorted 1-based indices + values;
+ *   kind 0 numeric (f64), 1 integer, 2 logical, 3 binary (no values), 4 float32; out f64[m].
+ * CSR (.) dense (multiply_csr_by_dense_elemwise<>, src/operators.cpp:239-334): dense column-major m x ncol;
+ *   kind 0 double, 1 float32, 2 integer, 3 logical (f64 values in/out), 4 logical AND (int32 values in/out). */
+int mxd_spmv_csr_svec(int m, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
+                      const int32_t *y_indices_base1, int ny, const void *y_values, int kind, double *out,
+                      void *stream);
+int mxd_csr_by_dense_elemwise(int m, int64_t nnz, const int32_t *indptr, const int32_t *indices,
+                              const void *values, const void *dense_colmajor, int kind, void *values_out,
+                              void *stream);
+
 /* check_is_seq / check_is_rev_seq (src/slice.cpp:25-47) on a device vector.
  * *flag_host receives 0/1 after an internal stream sync. */
 int mxd_check_is_seq(const int32_t *idx, int64_t n, int reversed, int32_t *workspace4,
@@ -318,6 +330,14 @@ int mx_reverse_rows_begin(const int32_t *indptr, int nrows, const int32_t *indic
 /* reverse_columns_inplace_{numeric,logical,binary}  src/slice.cpp:172-221: modifies indices / values */
 int mx_reverse_columns_inplace(const int32_t *indptr, int nrows, int32_t *indices, void *values,
                                int value_dtype, int64_t n_values, int ncol);
+/* matmul_csr_svec_{numeric,integer,logical,binary,float32}  src/matmul.cpp:555-641 (kind as mxd_spmv_csr_svec) */
+int mx_matmul_csr_svec(const int32_t *X_indptr, const int32_t *X_indices, const double *X_values, int nrows_X,
+                       const int32_t *y_indices_base1, int64_t ny, const void *y_values, int kind, int nthreads,
+                       double *out);
+/* multiply_csr_by_dense_elemwise_{double,float32,int,bool} + logicaland_csr_by_dense_cpp  src/operators.cpp:289-334:
+ * dense_mat column-major nrows x ncols; values_out has nnz entries (f64, or int32 for kind 4). */
+int mx_multiply_csr_by_dense_elemwise(const int32_t *indptr, const int32_t *indices, const void *values, int nrows,
+                                      const void *dense_mat, int64_t ncols, int kind, void *values_out);
 /* cbind_csr_{numeric,logical,binary}  src/cbind.cpp:101-157 (value_dtype MX_F64 / MX_LGL / MX_NONE) */
 int mx_cbind_csr_begin(const int32_t *X_indptr, int nrows_X, const int32_t *X_indices, const void *X_values,
                        int64_t n_values_X, const int32_t *Y_indptr, int nrows_Y,

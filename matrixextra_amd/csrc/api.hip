@@ -547,6 +547,44 @@ int mx_reverse_columns_inplace(const int32_t *indptr, int nrows, int32_t *indice
     return 0;
 }
 
+// ---- CSR x sparse vector, CSR (.) dense (§8f rank 4) ---------------------------------------------------------
+int mx_matmul_csr_svec(const int32_t *Xp, const int32_t *Xj, const double *Xx, int nrows, const int32_t *yi, int64_t ny,
+                       const void *yv, int kind, int nthreads, double *out)
+{
+    (void)nthreads;
+    MX_REQUIRE(nrows >= 0 && ny >= 0 && ny <= INT_MAX && kind >= 0 && kind <= 4, "mx_matmul_csr_svec: bad arguments");
+    if (nrows == 0) return 0;
+    if (ny == 0) { memset(out, 0, sizeof(double) * (size_t)nrows); return 0; }
+    Csr A;
+    if (A.upload(Xp, Xj, Xx, nrows, sizeof(double))) return 1;
+    DevBuf di, dv, o;
+    if (di.upload(yi, sizeof(int32_t) * (size_t)ny)) return 1;
+    const size_t vb = kind == 0 ? 8 : kind == 3 ? 0 : 4;
+    if (vb && dv.upload(yv, vb * (size_t)ny)) return 1;
+    if (o.alloc(sizeof(double) * (size_t)nrows)) return 1;
+    if (mxd_spmv_csr_svec(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), di.as<int32_t>(), (int)ny,
+                          vb ? dv.p : nullptr, kind, o.as<double>(), nullptr)) return 1;
+    MX_HIP(hipMemcpy(out, o.p, sizeof(double) * (size_t)nrows, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mx_multiply_csr_by_dense_elemwise(const int32_t *indptr, const int32_t *indices, const void *values, int nrows,
+                                      const void *dense_mat, int64_t ncols, int kind, void *values_out)
+{
+    MX_REQUIRE(nrows >= 0 && ncols >= 0 && kind >= 0 && kind <= 4, "mx_multiply_csr_by_dense_elemwise: bad arguments");
+    if (nrows == 0) return 0;
+    const size_t vb = kind == 4 ? 4 : 8, db = kind == 0 ? 8 : 4;
+    Csr A;
+    if (A.upload(indptr, indices, values, nrows, vb)) return 1;
+    if (A.nnz == 0) return 0;
+    DevBuf D, o;
+    if (D.upload(dense_mat, db * (size_t)nrows * (size_t)ncols)) return 1;
+    if (o.alloc(vb * (size_t)A.nnz)) return 1;
+    if (mxd_csr_by_dense_elemwise(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, D.p, kind, o.p, nullptr)) return 1;
+    MX_HIP(hipMemcpy(values_out, o.p, vb * (size_t)A.nnz, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // ---- cbind / rbind (§8f rank 3) ----------------------------------------------------------------------------
 int mx_cbind_csr_begin(const int32_t *Xp, int nX, const int32_t *Xj, const void *Xx, int64_t nvX, const int32_t *Yp,
                        int nY, const int32_t *Yj, const void *Yx, int64_t nvY, int value_dtype, mx_result **res_out,

@@ -332,6 +332,85 @@ def reverse_columns_inplace_binary(indptr, indices, ncol):
     _reverse_columns_inplace(indptr, indices, None, ncol, MX_NONE)
 
 
+# ----------------------------------------------------------------------------- CSR x sparse vector, CSR (.) dense (§8f-4)
+def _svec(kind, X_csr_indptr, X_csr_indices, X_csr_values, y_indices_base1, y_values, nthreads):
+    p, j, x, yi = _i32(X_csr_indptr), _i32(X_csr_indices), _f64(X_csr_values), _i32(y_indices_base1)
+    yv = None
+    if kind == 0:
+        yv = _f64(y_values)
+    elif kind in (1, 2):
+        yv = _i32(y_values)
+    elif kind == 4:
+        yv = np.ascontiguousarray(y_values, dtype=np.float32)
+    out = np.empty(p.size - 1, dtype=np.float64)
+    check(_lib.load().mx_matmul_csr_svec(ptr(p), ptr(j), ptr(x), C.c_int(p.size - 1), ptr(yi), C.c_int64(yi.size),
+                                         ptr(yv), C.c_int(kind), C.c_int(int(nthreads)), ptr(out)))
+    return out
+
+
+def matmul_csr_svec_numeric(X_csr_indptr, X_csr_indices, X_csr_values, y_indices_base1, y_values, nthreads=1):
+    """src/matmul.cpp:555-571."""
+    return _svec(0, X_csr_indptr, X_csr_indices, X_csr_values, y_indices_base1, y_values, nthreads)
+
+
+def matmul_csr_svec_integer(X_csr_indptr, X_csr_indices, X_csr_values, y_indices_base1, y_values, nthreads=1):
+    """src/matmul.cpp:573-589."""
+    return _svec(1, X_csr_indptr, X_csr_indices, X_csr_values, y_indices_base1, y_values, nthreads)
+
+
+def matmul_csr_svec_logical(X_csr_indptr, X_csr_indices, X_csr_values, y_indices_base1, y_values, nthreads=1):
+    """src/matmul.cpp:591-607."""
+    return _svec(2, X_csr_indptr, X_csr_indices, X_csr_values, y_indices_base1, y_values, nthreads)
+
+
+def matmul_csr_svec_binary(X_csr_indptr, X_csr_indices, X_csr_values, y_indices_base1, nthreads=1):
+    """src/matmul.cpp:609-624."""
+    return _svec(3, X_csr_indptr, X_csr_indices, X_csr_values, y_indices_base1, None, nthreads)
+
+
+def matmul_csr_svec_float32(X_csr_indptr, X_csr_indices, X_csr_values, y_indices_base1, y_values, nthreads=1):
+    """src/matmul.cpp:626-641."""
+    return _svec(4, X_csr_indptr, X_csr_indices, X_csr_values, y_indices_base1, y_values, nthreads)
+
+
+def _csr_by_dense(kind, indptr, indices, values, dense_mat):
+    p, j = _i32(indptr), _i32(indices)
+    ddt = {0: np.float64, 1: np.float32, 2: np.int32, 3: np.int32, 4: np.int32}[kind]
+    D = _dense(dense_mat, ddt)
+    if D.shape[0] != p.size - 1:
+        raise ValueError("dense operand must have as many rows as the sparse one")
+    xv = np.ascontiguousarray(values, dtype=np.int32 if kind == 4 else np.float64)
+    out = np.empty(xv.size, dtype=xv.dtype)
+    check(_lib.load().mx_multiply_csr_by_dense_elemwise(ptr(p), ptr(j), ptr(xv), C.c_int(p.size - 1), ptr(D),
+                                                        C.c_int64(D.shape[1]), C.c_int(kind), ptr(out)))
+    return out
+
+
+def multiply_csr_by_dense_elemwise_double(indptr, indices, values, dense_mat):
+    """src/operators.cpp:289-296."""
+    return _csr_by_dense(0, indptr, indices, values, dense_mat)
+
+
+def multiply_csr_by_dense_elemwise_float32(indptr, indices, values, dense_mat):
+    """src/operators.cpp:298-305."""
+    return _csr_by_dense(1, indptr, indices, values, dense_mat)
+
+
+def multiply_csr_by_dense_elemwise_int(indptr, indices, values, dense_mat):
+    """src/operators.cpp:307-314."""
+    return _csr_by_dense(2, indptr, indices, values, dense_mat)
+
+
+def multiply_csr_by_dense_elemwise_bool(indptr, indices, values, dense_mat):
+    """src/operators.cpp:316-323."""
+    return _csr_by_dense(3, indptr, indices, values, dense_mat)
+
+
+def logicaland_csr_by_dense_cpp(indptr, indices, values, dense_mat):
+    """src/operators.cpp:325-334."""
+    return _csr_by_dense(4, indptr, indices, values, dense_mat)
+
+
 # ----------------------------------------------------------------------------- cbind / rbind (§8f-3)
 def _cbind(Xp, Xj, Xx, Yp, Yj_plus_ncol, Yx, value_dtype, vdt):
     lib = _lib.load()

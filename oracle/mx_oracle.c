@@ -551,3 +551,61 @@ int mxo_concat_csr_append(int in_kind, const int *indptr_obj, const int *indices
     }
     return nrows_add;
 }
+
+/* ==== §8(f) rank 4: CSR x sparse vector, CSR (.) dense elementwise ============================== */
+
+/* ---- matmul_csr_svec (matmul.cpp:486-551) --------------------------------- */
+/* kind: 0 numeric, 1 integer, 2 logical, 3 binary (no y values), 4 float32 (y float).  y_indices 1-based sorted. */
+void mxo_matmul_csr_svec(int nrows, const int *indptr, const int *indices, const double *values,
+                         const int *y_indices_base1, size_t ny, const void *y_values, int kind, double *out, int nthreads)
+{
+    for (int r = 0; r < nrows; r++) out[r] = 0;
+    if (!ny) return;
+    if (nthreads < 1) nthreads = 1;
+    const double NA = na_real();
+    #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int row = 0; row < nrows; row++) {
+        const int *ptr1 = indices + indptr[row], *end1 = indices + indptr[row + 1];
+        const int *ptr2 = y_indices_base1, *end_y = y_indices_base1 + ny;
+        while (1) {
+            if (ptr1 >= end1 || ptr2 >= end_y) break;
+            else if (*ptr1 == (*ptr2) - 1) {
+                const size_t iy = (size_t)(ptr2 - y_indices_base1), ix = (size_t)(ptr1 - indices);
+                if (kind == 1) { const int yv = ((const int *)y_values)[iy]; out[row] += yv == NA_INT ? NA : values[ix] * yv; }
+                else if (kind == 2) { const int yv = ((const int *)y_values)[iy]; out[row] += yv == NA_INT ? NA : values[ix] * (double)(yv != 0); }
+                else if (kind == 3) out[row] += values[ix];
+                else if (kind == 4) out[row] += values[ix] * ((const float *)y_values)[iy];
+                else out[row] += values[ix] * ((const double *)y_values)[iy];
+                ptr1++; ptr2++;
+            }
+            else if (*ptr2 - 1 > *ptr1) ptr1 = lower_bound_int(ptr1, end1, *ptr2 - 1);
+            else ptr2 = lower_bound_int(ptr2, end_y, *ptr1 + 1);
+        }
+    }
+}
+
+/* ---- multiply_csr_by_dense_elemwise (operators.cpp:239-334) ---------------- */
+/* dense_mat column-major nrows x ncol.  kind: 0 double, 1 float32, 2 integer, 3 logical (values f64, out f64);
+ * kind 4: logical values AND logical dense (R_logical_and), out int32. */
+void mxo_multiply_csr_by_dense_elemwise(int nrows, const int *indptr, const int *indices, const void *values,
+                                        const void *dense_mat, int kind, void *values_out)
+{
+    const double NA = na_real();
+    const size_t nr = (size_t)nrows;
+    for (size_t row = 0; row < nr; row++) {
+        for (int el = indptr[row]; el < indptr[row + 1]; el++) {
+            const size_t at = row + nr * (size_t)indices[el];
+            if (kind == 4) {
+                ((int *)values_out)[el] = r_and(((const int *)values)[el], ((const int *)dense_mat)[at]);
+                continue;
+            }
+            const double v = ((const double *)values)[el];
+            double o;
+            if (kind == 0) o = v * ((const double *)dense_mat)[at];
+            else if (kind == 1) o = v * ((const float *)dense_mat)[at];
+            else if (kind == 2) { const int d = ((const int *)dense_mat)[at]; o = d == NA_INT ? NA : v * d; }
+            else { const int d = ((const int *)dense_mat)[at]; o = d == NA_INT ? NA : v * (double)(d != 0); }
+            ((double *)values_out)[el] = o;
+        }
+    }
+}

@@ -481,3 +481,82 @@ def concat_csr_batch(objects, out_kind):
                                            _p(values))
         pos += j.size
     return dict(indptr=indptr, indices=indices, values=values)
+
+
+# ----------------------------------------------------------------------------- CSR x sparse vector, CSR (.) dense (§8f-4)
+def _svec(kind, p, j, x, y_indices_base1, y_values, nthreads):
+    p, j, x, yi = _i32(p), _i32(j), _f64(x), _i32(y_indices_base1)
+    yv = None
+    if kind in (0,):
+        yv = _f64(y_values)
+    elif kind in (1, 2):
+        yv = _i32(y_values)
+    elif kind == 4:
+        yv = np.ascontiguousarray(y_values, dtype=np.float32)
+    out = np.zeros(p.size - 1, dtype=np.float64)
+    lib().mxo_matmul_csr_svec(C.c_int(p.size - 1), _p(p), _p(j), _p(x), _p(yi), C.c_size_t(yi.size), _p(yv),
+                              C.c_int(kind), _p(out), C.c_int(nthreads))
+    return out
+
+
+def matmul_csr_svec_numeric(p, j, x, yi, yv, nthreads=1):
+    """src/matmul.cpp:555-571"""
+    return _svec(0, p, j, x, yi, yv, nthreads)
+
+
+def matmul_csr_svec_integer(p, j, x, yi, yv, nthreads=1):
+    """src/matmul.cpp:573-589"""
+    return _svec(1, p, j, x, yi, yv, nthreads)
+
+
+def matmul_csr_svec_logical(p, j, x, yi, yv, nthreads=1):
+    """src/matmul.cpp:591-607"""
+    return _svec(2, p, j, x, yi, yv, nthreads)
+
+
+def matmul_csr_svec_binary(p, j, x, yi, nthreads=1):
+    """src/matmul.cpp:609-624"""
+    return _svec(3, p, j, x, yi, None, nthreads)
+
+
+def matmul_csr_svec_float32(p, j, x, yi, yv, nthreads=1):
+    """src/matmul.cpp:626-641 (y values are float32 bits)"""
+    return _svec(4, p, j, x, yi, yv, nthreads)
+
+
+def _csr_by_dense(kind, p, j, x, dense_mat):
+    p, j = _i32(p), _i32(j)
+    nrows = p.size - 1
+    ddt = {0: np.float64, 1: np.float32, 2: np.int32, 3: np.int32, 4: np.int32}[kind]
+    D = np.asfortranarray(dense_mat, dtype=ddt)
+    assert D.shape[0] == nrows
+    xv = np.ascontiguousarray(x, dtype=np.int32 if kind == 4 else np.float64)
+    out = np.empty(xv.size, dtype=np.int32 if kind == 4 else np.float64)
+    lib().mxo_multiply_csr_by_dense_elemwise(C.c_int(nrows), _p(p), _p(j), _p(xv), _p(D.reshape(-1, order="F")),
+                                             C.c_int(kind), _p(out))
+    return out
+
+
+def multiply_csr_by_dense_elemwise_double(p, j, x, D):
+    """src/operators.cpp:289-296"""
+    return _csr_by_dense(0, p, j, x, D)
+
+
+def multiply_csr_by_dense_elemwise_float32(p, j, x, D):
+    """src/operators.cpp:298-305"""
+    return _csr_by_dense(1, p, j, x, D)
+
+
+def multiply_csr_by_dense_elemwise_int(p, j, x, D):
+    """src/operators.cpp:307-314"""
+    return _csr_by_dense(2, p, j, x, D)
+
+
+def multiply_csr_by_dense_elemwise_bool(p, j, x, D):
+    """src/operators.cpp:316-323"""
+    return _csr_by_dense(3, p, j, x, D)
+
+
+def logicaland_csr_by_dense_cpp(p, j, x, D):
+    """src/operators.cpp:325-334"""
+    return _csr_by_dense(4, p, j, x, D)

@@ -397,3 +397,43 @@ def test_concat_csr_batch(gpu):
         else:
             assert g["values"].dtype == o["values"].dtype
             np.testing.assert_array_equal(g["values"], o["values"])     # NaN == NaN positionally (assert_array_equal)
+
+
+# ----------------------------------------------------------------------------- §8(f) rank 4
+def test_csr_svec(gpu):
+    rng = np.random.default_rng(62)
+    for (m, K, dens, ny) in [(80, 60, 0.2, 20), (500, 3000, 0.05, 700), (30, 10, 1.0, 10), (64, 200, 0.3, 0)]:
+        p, j, x = rand_csr(m, K, dens, seed=61 + m, empty_rows=(1,))
+        yi = (np.sort(rng.permutation(K)[:ny]) + 1).astype(np.int32)
+        yv = rng.normal(size=ny)
+        yint = rng.integers(-4, 5, size=ny).astype(np.int32)
+        ylg = rng.integers(0, 2, size=ny).astype(np.int32)
+        if ny > 3:
+            yint[2] = NA; ylg[1] = NA
+        cases = [(G.matmul_csr_svec_numeric, O.matmul_csr_svec_numeric, (yi, yv)),
+                 (G.matmul_csr_svec_integer, O.matmul_csr_svec_integer, (yi, yint)),
+                 (G.matmul_csr_svec_logical, O.matmul_csr_svec_logical, (yi, ylg)),
+                 (G.matmul_csr_svec_binary, O.matmul_csr_svec_binary, (yi,)),
+                 (G.matmul_csr_svec_float32, O.matmul_csr_svec_float32, (yi, yv.astype(np.float32)))]
+        for gf, of, args in cases:
+            g, o = gf(p, j, x, *args), of(p, j, x, *args)
+            np.testing.assert_array_equal(np.isnan(g), np.isnan(o))
+            np.testing.assert_allclose(g[~np.isnan(g)], o[~np.isnan(o)], rtol=1e-11, atol=1e-12)
+
+
+def test_csr_by_dense_elemwise(gpu):
+    rng = np.random.default_rng(63)
+    p, j, x = rand_csr(300, 70, 0.15, seed=64, empty_rows=(0, 299))
+    D = rng.normal(size=(300, 70))
+    np.testing.assert_array_equal(G.multiply_csr_by_dense_elemwise_double(p, j, x, D),
+                                  O.multiply_csr_by_dense_elemwise_double(p, j, x, D))
+    D32 = D.astype(np.float32)
+    np.testing.assert_array_equal(G.multiply_csr_by_dense_elemwise_float32(p, j, x, D32),
+                                  O.multiply_csr_by_dense_elemwise_float32(p, j, x, D32))
+    Di = rng.integers(-3, 4, size=(300, 70)).astype(np.int32); Di[5, :] = NA
+    for gf, of in [(G.multiply_csr_by_dense_elemwise_int, O.multiply_csr_by_dense_elemwise_int),
+                   (G.multiply_csr_by_dense_elemwise_bool, O.multiply_csr_by_dense_elemwise_bool)]:
+        np.testing.assert_array_equal(gf(p, j, x, Di), of(p, j, x, Di))
+    xl = rng.choice(np.array([0, 1, NA], np.int32), size=x.size)
+    Dl = rng.choice(np.array([0, 1, NA], np.int32), size=(300, 70))
+    np.testing.assert_array_equal(G.logicaland_csr_by_dense_cpp(p, j, xl, Dl), O.logicaland_csr_by_dense_cpp(p, j, xl, Dl))

@@ -337,3 +337,35 @@ def test_cbind_rbind_vs_scipy():
     assert tail[0] == 1.5 and tail[1] == -2.0 and np.isnan(tail[2]) and tail[3] == 1.0 and np.isnan(tail[4]) and tail[5] == 1.0
     rl = O.concat_csr_batch(objs, 1)
     assert rl["values"].dtype == np.int32 and rl["values"][0] == int(x1[0] != 0)
+
+
+# ----------------------------------------------------------------------------- §8(f) rank 4
+def test_csr_svec_and_csr_by_dense():
+    p, j, x = rand_csr(80, 60, 0.2, seed=61, empty_rows=(1,))
+    Ad = csr_to_dense(p, j, x, 60)
+    rng = np.random.default_rng(62)
+    yi = np.sort(rng.permutation(60)[:20]).astype(np.int32) + 1            # 1-based sorted
+    yv = rng.normal(size=20)
+    ydense = np.zeros(60); ydense[yi - 1] = yv
+    np.testing.assert_allclose(O.matmul_csr_svec_numeric(p, j, x, yi, yv, 2), Ad @ ydense, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(O.matmul_csr_svec_binary(p, j, x, yi), Ad @ (ydense != 0), rtol=1e-12, atol=1e-12)
+    yint = rng.integers(1, 5, size=20).astype(np.int32)
+    yd2 = np.zeros(60); yd2[yi - 1] = yint
+    np.testing.assert_allclose(O.matmul_csr_svec_integer(p, j, x, yi, yint), Ad @ yd2, rtol=1e-12, atol=1e-12)
+    yint[3] = NA
+    r = O.matmul_csr_svec_integer(p, j, x, yi, yint)
+    touched = Ad[:, yi[3] - 1] != 0
+    assert np.isnan(r[touched]).all() and not np.isnan(r[~touched]).any()
+    assert not O.matmul_csr_svec_numeric(p, j, x, np.zeros(0, np.int32), np.zeros(0)).any()
+    D = rng.normal(size=(80, 60))
+    out = O.multiply_csr_by_dense_elemwise_double(p, j, x, D)
+    rows = np.repeat(np.arange(80), np.diff(p))
+    np.testing.assert_array_equal(out, x * D[rows, j])
+    Di = rng.integers(-2, 3, size=(80, 60)).astype(np.int32); Di[0, :] = NA
+    oi = O.multiply_csr_by_dense_elemwise_int(p, j, x, Di)
+    assert np.isnan(oi[rows == 0]).all() and np.array_equal(oi[rows != 0], (x * Di[rows, j])[rows != 0])
+    xl = rng.choice(np.array([0, 1, NA], np.int32), size=x.size)
+    Dl = rng.choice(np.array([0, 1, NA], np.int32), size=(80, 60))
+    ol = O.logicaland_csr_by_dense_cpp(p, j, xl, Dl)
+    f = O.lib().mxo_r_logical
+    assert ol.tolist() == [f(1, int(a), int(b)) for a, b in zip(xl, Dl[rows, j])]

@@ -192,9 +192,9 @@ def main():
             blk = C_full[(world - 1) * m:(world - 1) * m + 4].cpu().numpy()
             assert np.isfinite(blk).all()
 
-    kernel_name = "spmm_slab_kernel" if args.algo == 2 else "spmm_rowwave_kernel"
-    default_workload = (m, K, n, args.nnz_row, args.dtype, args.layout) == (1_000_000, 100_000, 128, 32, "f64", "colmajor") \
-        and world == 1
+    kernel_name = _lib.load().mxd_spmm_last_kernel().decode()      # which kernel AUTO / --algo actually launched
+    default_workload = (m, K, n, args.nnz_row, args.dtype, args.layout, args.algo, args.panels, args.wg_per_cu) == \
+        (1_000_000, 100_000, 128, 32, "f64", "colmajor", 0, 0, 0) and world == 1
     traffic = committed_traffic(kernel_name, default_workload) if rank == 0 else None
     out = None
     if rank == 0:

@@ -108,6 +108,9 @@ int mxd_spmm_csr_dense_ex(int m, int n, int K,
                           int dense_dtype, int colmajor_out, int algo, int rows_sorted,
                           int npanels, int wg_per_cu, void *stream);
 
+/* name of the SpMM kernel the last mxd_spmm_csr_dense_ex call of this thread launched (reporting only) */
+const char *mxd_spmm_last_kernel(void);
+
 /* SpMV  y = A * v  (matmul_csr_dvec<>, src/matmul.cpp:381-419).
  * v_dtype MX_F64 / MX_I32 / MX_LGL -> y f64[m];  MX_F32 -> y f32[m]
  * (float accumulate).  NA_INTEGER / NA_LOGICAL entries contribute NA_REAL. */

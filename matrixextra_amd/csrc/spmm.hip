@@ -346,7 +346,7 @@ void spmm_slab_kernel(int m, int n,
                       const real_t *__restrict__ B, size_t ldb,
                       real_t *__restrict__ C, size_t ldc,
                       int npanels, int panel_cols, int nslabs, int nrowblocks, int c_vec_ok,
-                      unsigned *__restrict__ sync_ctr, int sync_mode)
+                      unsigned *__restrict__ sync_ctr, int sync_mode, size_t slab_stride)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
     constexpr int W = SLAB_GROUP * VEC;             // columns per slab
@@ -371,7 +371,10 @@ void spmm_slab_kernel(int m, int n,
         const int row0 = rb * RB + grp * RPG;
         const int col = slab * W + lg * VEC;
         const bool active = col < n;
-        const unsigned lcol = active ? (unsigned)col : (unsigned)(n - VEC);
+        // slab_stride != 0: B was repacked slab-major ([slab][K][W], zero padded) so that a slab is contiguous and
+        // spreads over all L2 channels; the caller then passes ldb = W and this adds the slab's base.
+        const unsigned lcol = slab_stride ? (unsigned)(lg * VEC) : (active ? (unsigned)col : (unsigned)(n - VEC));
+        const real_t *__restrict__ Bs = B + (size_t)slab * slab_stride;
 
         int cur[RPG], end[RPG];
         real_t acc[RPG][VEC];
@@ -412,7 +415,7 @@ void spmm_slab_kernel(int m, int n,
                     // sorted row: in-panel entries are a prefix of the chunk
                     const int cnt = __popc((unsigned)(inpanel >> (lane_id() & ~(SLAB_GROUP - 1))) & 0xFFu);
                     // entry 0 of an empty chunk may be INT_MAX: slab_load only dereferences entries < cnt (else row 0)
-                    slab_chunk<real_t, VEC>(cnt, jv[r], av[r], B, ldb, lcol, acc[r]);
+                    slab_chunk<real_t, VEC>(cnt, jv[r], av[r], Bs, ldb, lcol, acc[r]);
                     cur[r] += cnt;
                     if (cnt < SLAB_GROUP) pending &= ~(1u << r);          // panel (or row) exhausted
                 }
@@ -459,6 +462,45 @@ static int pick_panels(int K, size_t l2_budget)
     return p;
 }
 
+// B (K x n row-major, leading dimension ldb) -> slab-major [nslabs][K][W], zero padded past column n.
+// One thread per 16-byte piece; reads are row-contiguous, each 8-lane group writes one full 128-byte line.
+template <typename real_t>
+__global__ __launch_bounds__(256)
+void repack_slabs_kernel(int K, int n, int nslabs, const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ Bp)
+{
+    constexpr int VEC = 16 / (int)sizeof(real_t);
+    constexpr int W = SLAB_GROUP * VEC;
+    const long long pieces_per_row = (long long)nslabs * SLAB_GROUP;
+    const long long total = (long long)K * pieces_per_row;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(t / pieces_per_row);
+        const int piece = (int)(t % pieces_per_row);
+        const int slab = piece / SLAB_GROUP, lg = piece % SLAB_GROUP;
+        const int col = slab * W + lg * VEC;
+        real_t v[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; q++) v[q] = 0;
+        if (col < n) vload<real_t, VEC>(v, B + (size_t)j * ldb + col);       // n % VEC == 0 (slab_ok)
+        vstore<real_t, VEC>(Bp + ((size_t)slab * K + j) * W + lg * VEC, v);
+    }
+}
+
+// grow-only per-device scratch for the packed copy of B
+static void *slab_pack_workspace(size_t bytes)
+{
+    static thread_local void *ws[64] = {};
+    static thread_local size_t cap[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (cap[dev] < bytes) {
+        if (ws[dev]) (void)hipFree(ws[dev]);
+        ws[dev] = nullptr; cap[dev] = 0;
+        if (hipMalloc(&ws[dev], bytes) != hipSuccess) return nullptr;
+        cap[dev] = bytes;
+    }
+    return ws[dev];
+}
+
 // per-device counters for the timing barrier (8 groups x 256 B), allocated once
 static unsigned *slab_sync_workspace()
 {
@@ -495,14 +537,30 @@ static int launch_spmm_slab_rpg(int m, int n, int K, const int32_t *indptr, cons
     unsigned *sync = slab_sync_workspace();
     if (!sync) sync_mode = 0;
     if (sync_mode) MX_HIP(hipMemsetAsync(sync, 0, 8 * 64 * sizeof(unsigned), stream));
+    // slab-major copy of B (MXGPU_SLAB_PACK=0 disables): with B row-major a slab is 128 B out of every ldb*s
+    // bytes — a power-of-two stride that lands on a fraction of the L2 channels
+    size_t slab_stride = 0;
+    int pack = 1;
+    if (const char *e = getenv("MXGPU_SLAB_PACK")) pack = atoi(e);
+    if (pack) {
+        const size_t bytes = (size_t)nslabs * (size_t)K * W * sizeof(real_t);
+        real_t *Bp = (real_t *)slab_pack_workspace(bytes);
+        if (Bp) {
+            const long long pieces = (long long)K * nslabs * SLAB_GROUP;
+            const unsigned g = (unsigned)(ceil_div(pieces, 256) < 8192 ? ceil_div(pieces, 256) : 8192);
+            hipLaunchKernelGGL((repack_slabs_kernel<real_t>), dim3(g), dim3(256), 0, stream, K, n, nslabs, B, ldb, Bp);
+            MX_LAUNCH_CHECK();
+            B = Bp; ldb = W; slab_stride = (size_t)K * W;
+        }
+    }
     if (colmajor)
         hipLaunchKernelGGL((spmm_slab_kernel<real_t, RPG, true>), dim3((unsigned)grid), dim3(SLAB_BLOCK), 0, stream,
                            m, n, indptr, indices, values, B, ldb, C, ldc, npanels, panel_cols, nslabs, nrowblocks,
-                           c_vec_ok, sync, sync_mode);
+                           c_vec_ok, sync, sync_mode, slab_stride);
     else
         hipLaunchKernelGGL((spmm_slab_kernel<real_t, RPG, false>), dim3((unsigned)grid), dim3(SLAB_BLOCK), 0, stream,
                            m, n, indptr, indices, values, B, ldb, C, ldc, npanels, panel_cols, nslabs, nrowblocks,
-                           c_vec_ok, sync, sync_mode);
+                           c_vec_ok, sync, sync_mode, slab_stride);
     MX_LAUNCH_CHECK();
     return 0;
 }
@@ -537,6 +595,9 @@ static bool slab_ok(int n, const real_t *B, size_t ldb, const real_t *C, size_t 
 
 }  // namespace mx
 
+static thread_local const char *g_last_spmm_kernel = "none";
+extern "C" const char *mxd_spmm_last_kernel(void) { return g_last_spmm_kernel; }
+
 extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
                                      const int32_t *indptr, const int32_t *indices, const double *values,
                                      const void *B, size_t ldb, void *C, size_t ldc,
@@ -551,15 +612,21 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
     const bool ok = dense_dtype == MX_F64
         ? mx::slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor_out)
         : mx::slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor_out);
+    bool auto_pick = false;
     if (algo == MX_SPMM_AUTO) {
-        // Measured on MI355X (profiles/r01_*): without a per-panel XCD barrier the workgroups of an XCD
-        // drift apart, the slab-panel working set degenerates to the whole slab (28-37 % L2 hits) and the
-        // slab kernel is slower than the row-wave kernel (5.6 vs 4.45 ms on the headline config), so AUTO
-        // keeps the row-wave kernel; MX_SPMM_SLAB stays selectable for experiments.
-        algo = MX_SPMM_ROWWAVE;
+        // Measured on MI355X, headline config (profiles/r01_*): row-wave 4.45 ms; slab kernel with B repacked
+        // slab-major, one panel, no barrier 4.05 ms (the slab-major copy spreads a slab over all L2 channels);
+        // slab + column panels + XCD barrier 5.9 ms (L2 hits 28 -> 60 %, but every panel visit re-reads the row's
+        // (j, a) and the kernel turns VALU-bound).  So AUTO = one-panel packed slab kernel when B outgrows one
+        // XCD's L2 and there is enough work to fill the persistent grid, else the row-wave kernel.
+        const size_t b_bytes = (size_t)K * (size_t)n * (dense_dtype == MX_F64 ? 8 : 4);
+        auto_pick = ok && b_bytes > ((size_t)8 << 20) && (long long)m * n >= (1LL << 24);
+        algo = auto_pick ? MX_SPMM_SLAB : MX_SPMM_ROWWAVE;
+        if (auto_pick) { npanels = 1; if (wg_per_cu <= 0) wg_per_cu = 4; }
     }
     if (algo == MX_SPMM_SLAB) {
         MX_REQUIRE(ok, "mxd_spmm_csr_dense_ex: operands do not meet the slab kernel's 16-byte alignment rules");
+        g_last_spmm_kernel = "spmm_slab_kernel";
         if (npanels <= 0) npanels = rows_sorted ? mx::pick_panels(K, (size_t)2560 << 10) : 1;
         if (!rows_sorted) npanels = 1;                 // panels need column-sorted rows
         if (wg_per_cu <= 0) wg_per_cu = 4;
@@ -569,6 +636,7 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
         return mx::launch_spmm_slab<float>(m, n, K, indptr, indices, values, (const float *)B, ldb, (float *)C, ldc,
                                            colmajor_out, npanels, wg_per_cu, st);
     }
+    g_last_spmm_kernel = "spmm_rowwave_kernel";
     return mxd_spmm_csr_dense(m, n, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor_out, stream);
 }
 

@@ -38,7 +38,10 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--layout", default="colmajor", choices=["colmajor", "rowmajor"],
                     help="C layout at N=1 (colmajor = what tcrossprod_csr_dense returns to R)")
-    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 row-wave kernel, 2 slab/panel kernel")
+    ap.add_argument("--algo", type=int, default=0,
+                    help="0 auto, 1 row-wave kernel, 2 slab/panel kernel, 3 planned kernel (plan cached), "
+                         "4 planned kernel with the plan rebuilt inside every timed step")
+    ap.add_argument("--sync", type=int, default=-1, help="planned kernel: 0 no barrier, 1 per row block, 2 per panel")
     ap.add_argument("--panels", type=int, default=0)
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -131,6 +134,13 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    def run_spmm(A_, B_, out_, colmajor_):
+        if args.algo in (3, 4):
+            D.spmm_planned(A_, B_, out=out_, colmajor=colmajor_, npanels=args.panels, wg_per_cu=args.wg_per_cu,
+                           sync_mode=args.sync, rebuild_plan=(args.algo == 4))
+        else:
+            D.spmm(A_, B_, out=out_, colmajor=colmajor_, algo=args.algo, npanels=args.panels, wg_per_cu=args.wg_per_cu)
+
     sharded = None
     if world > 1:
         # matrixextra_amd.distributed: equal row blocks -> compute into my slot of C_full, one RCCL all-gather in place
@@ -139,7 +149,7 @@ def main():
         def timed_local(local_A, Bt, out, _k=[None]):
             if _k[0] is not None:
                 ev[_k[0]][0].record()
-            D.spmm(local_A, Bt, out=out, colmajor=False, algo=args.algo, npanels=args.panels, wg_per_cu=args.wg_per_cu)
+            run_spmm(local_A, Bt, out, False)
             if _k[0] is not None:
                 ev[_k[0]][1].record()
         timed_local.k = timed_local.__defaults__[0]
@@ -152,7 +162,7 @@ def main():
             return
         if k is not None:
             ev[k][0].record()
-        D.spmm(A, B, out=C_loc, colmajor=colmajor, algo=args.algo, npanels=args.panels, wg_per_cu=args.wg_per_cu)
+        run_spmm(A, B, C_loc, colmajor)
         if k is not None:
             ev[k][1].record()
 

@@ -108,6 +108,22 @@ int mxd_spmm_csr_dense_ex(int m, int n, int K,
                           int dense_dtype, int colmajor_out, int algo, int rows_sorted,
                           int npanels, int wg_per_cu, void *stream);
 
+/* Planned SpMM (v3): a device-resident regrouping of A's entries by (row bundle, column panel), wave-interleaved,
+ * so that the panel-sweep kernel reads every entry once, coalesced, while B's current slab-panel stays in L2.
+ * The plan depends on A and npanels only; build it once per matrix and run it against any number of B.
+ * mxd_spmm_plan_create: *plan = NULL creates, a previous plan re-uses its buffers (grow-only); one internal
+ * stream sync (the padded size comes back to the host).  npanels <= 0 picks K*128 B / 2.5 MB.
+ * mxd_spmm_plan_run: sync_mode 0 = no locality window; k >= 1 = a wave may enter a panel once every wave of its XCD
+ * group has finished the panel k steps back (1 = lock step, 2 = two panels in flight, ...); -1 = default.
+ * Needs 16-B aligned rows of B. */
+typedef struct mx_spmm_plan mx_spmm_plan;
+int mxd_spmm_plan_create(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+                         int npanels, void *stream, mx_spmm_plan **plan);
+int mxd_spmm_plan_destroy(mx_spmm_plan *plan);
+int mxd_spmm_plan_info(const mx_spmm_plan *plan, int *npanels, int64_t *padded_entries);
+int mxd_spmm_plan_run(const mx_spmm_plan *plan, int n, const void *B, size_t ldb, void *C, size_t ldc,
+                      int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream);
+
 /* name of the SpMM kernel the last mxd_spmm_csr_dense_ex call of this thread launched (reporting only) */
 const char *mxd_spmm_last_kernel(void);
 

@@ -26,6 +26,7 @@
 // served by L2 / Infinity Cache (B = 102 MB for the headline config).
 #include "mx_common.h"
 #include <cstdlib>
+#include <new>
 
 namespace mx {
 
@@ -338,6 +339,42 @@ __device__ __forceinline__ void xcd_timing_barrier(unsigned *ctr, unsigned targe
     __syncthreads();
 }
 
+// Windowed form: a workgroup may START step t once every workgroup of its group has FINISHED step t-1-slack.
+// slack = 0 is the hard barrier above; slack = 1 lets the group spread over two consecutive panels (working set
+// two panels) but nobody stalls unless a straggler is more than one step behind, and the memory pipeline does
+// not drain at every step.
+__device__ __forceinline__ void xcd_window_wait(unsigned *ctr, long long need)
+{
+    if (need > 0) {
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while ((long long)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < 4096)
+                __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void xcd_window_arrive(unsigned *ctr)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave-level forms (every lane runs the same loop on the same word: uniform control flow, no __syncthreads)
+__device__ __forceinline__ void wave_window_wait(unsigned *ctr, long long need)
+{
+    if (need > 0) {
+        int spins = 0;
+        while ((long long)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need &&
+               ++spins < 8192)
+            __builtin_amdgcn_s_sleep(2);
+    }
+}
+__device__ __forceinline__ void wave_window_arrive(unsigned *ctr)
+{
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename real_t, int RPG, bool COLMAJOR>
 __global__ __launch_bounds__(SLAB_BLOCK)
 void spmm_slab_kernel(int m, int n,
@@ -582,6 +619,382 @@ static int launch_spmm_slab(int m, int n, int K, const int32_t *indptr, const in
                                            wg_per_cu, sync_mode, stream);
 }
 
+// =====================================================================================================
+// v3 "planned panel sweep".
+//
+// PMC on v2 (profiles/r01_v2_*): with column panels + the XCD timing barrier the L2 hit rate only reaches
+// 60 % because every (row, panel) visit re-reads the row's (j, a) chunk — with P panels the CSR arrays are
+// streamed ~2P times per XCD and that traffic, not B, dominates and evicts the panel.  v3 fixes the data
+// layout instead of the loop: a *plan* regroups A's entries by (octet of 8 row-bundles, panel) and
+// interleaves the 8 bundles of an octet step by step, so that
+//   * one wavefront (8 lane groups = 8 bundles) reads 8 consecutive plan entries per step — every entry of A
+//     is read exactly once per slab, coalesced, with no cursor / ballot / broadcast logic;
+//   * entries of a bundle inside a panel are ordered by row, the group accumulates the current row in
+//     registers and folds it into the bundle's accumulators in LDS when the row changes (only that group
+//     touches those LDS rows: plain read-modify-write, no atomics);
+//   * all workgroups of an XCD group stay on the same panel (timing barrier), whose slab-major copy of B
+//     (K/P x 128 B, contiguous) fits the XCD's L2.
+// Entry = int32 (col | local_row << 27, -1 = padding) + f64 value; plan bytes ~ 1.2 x the CSR arrays.
+// Summation order: CSR order inside a (row, panel), panels added in ascending order — a regrouping of the
+// reference's sequential sum (tolerance-level difference, not bitwise).  Works for unsorted rows too.
+// =====================================================================================================
+constexpr int PLAN_RB = 8;                         // rows per bundle (owned by one 8-lane group)
+constexpr int PLAN_OCT_ROWS = PLAN_RB * 8;         // rows per octet (one wavefront)
+constexpr int PLAN_WAVES = 16;                     // wavefronts per workgroup: ONE 1024-thread workgroup per CU
+constexpr int PLAN_BLOCK = PLAN_WAVES * 64;
+constexpr int PLAN_WG_ROWS = PLAN_OCT_ROWS * PLAN_WAVES;   // rows per workgroup generation (1024 rows = 128 KiB of LDS)
+constexpr int PLAN_MAXP = 64;
+constexpr int PLAN_ROW_SHIFT = 27;                 // col < 2^27
+
+// pass 1: per (row, panel) prefix inside the bundle, per (octet, panel) number of steps.
+// One wavefront per octet, one 8-lane group per bundle.
+__global__ __launch_bounds__(256)
+void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
+                       const int32_t *__restrict__ indices, int32_t *__restrict__ rowpre, int32_t *__restrict__ steps,
+                       int noct)
+{
+    __shared__ int seg[4][8][PLAN_MAXP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 3, lg = lane & 7;
+    const int oct = blockIdx.x * 4 + wave;
+    for (int p = lg; p < npanels; p += 8) seg[wave][g][p] = 0;
+    __syncthreads();
+    if (oct < noct) {
+        const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
+        for (int r = 0; r < PLAN_RB; r++) {
+            const int row = row0 + r;
+            if (row >= m) break;                                   // uniform inside the group
+            for (int p = lg; p < npanels; p += 8) rowpre[(size_t)row * npanels + p] = seg[wave][g][p];
+            const int s = indptr[row], e = indptr[row + 1];
+            for (int k0 = s; k0 < e; k0 += 8) {
+                const int k = k0 + lg;
+                int pan = -1;
+                if (k < e) { pan = indices[k] / panel_cols; if (pan >= npanels) pan = npanels - 1; }
+                unsigned todo = group8_ballot(pan >= 0);
+                while (todo) {                                      // one round per distinct panel in the chunk
+                    const int q = __shfl(pan, __ffs(todo) - 1, 8);
+                    const unsigned same = group8_ballot(pan == q);
+                    if (lg == 0) seg[wave][g][q] += __popc(same);
+                    todo &= ~same;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (oct < noct)
+        for (int p = lane; p < npanels; p += 64) {
+            int mx = 0;
+#pragma unroll
+            for (int gg = 0; gg < 8; gg++) mx = max(mx, seg[wave][gg][p]);
+            steps[(size_t)oct * npanels + p] = mx;
+        }
+}
+
+// pass 2: scatter the entries to their interleaved slots
+__global__ __launch_bounds__(256)
+void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
+                      const int32_t *__restrict__ indices, const double *__restrict__ values,
+                      const int32_t *__restrict__ rowpre, const int32_t *__restrict__ step_off,
+                      int32_t *__restrict__ pcol, double *__restrict__ pval, int noct)
+{
+    __shared__ int running[4][8][PLAN_MAXP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 3, lg = lane & 7;
+    const int oct = blockIdx.x * 4 + wave;
+    if (oct >= noct) return;                                        // no block-wide barrier below
+    const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
+    const unsigned below = (1u << lg) - 1u;
+    for (int r = 0; r < PLAN_RB; r++) {
+        const int row = row0 + r;
+        if (row >= m) break;
+        for (int p = lg; p < npanels; p += 8) running[wave][g][p] = 0;
+        const int s = indptr[row], e = indptr[row + 1];
+        for (int k0 = s; k0 < e; k0 += 8) {
+            const int k = k0 + lg;
+            int pan = -1, col = 0;
+            double a = 0.0;
+            if (k < e) { col = indices[k]; a = values[k]; pan = col / panel_cols; if (pan >= npanels) pan = npanels - 1; }
+            unsigned todo = group8_ballot(pan >= 0);
+            while (todo) {
+                const int q = __shfl(pan, __ffs(todo) - 1, 8);
+                const unsigned same = group8_ballot(pan == q);
+                const int base = running[wave][g][q];               // all lanes read before lane 0 updates
+                if (pan == q) {
+                    const long long step = (long long)step_off[(size_t)oct * npanels + q] +
+                                           rowpre[(size_t)row * npanels + q] + base + __popc(same & below);
+                    const long long dst = step * 8 + g;
+                    pcol[dst] = col | (r << PLAN_ROW_SHIFT);
+                    pval[dst] = a;
+                }
+                if (lg == 0) running[wave][g][q] = base + __popc(same);
+                todo &= ~same;
+            }
+        }
+    }
+}
+
+// main kernel
+template <typename real_t, bool COLMAJOR>
+__global__ __launch_bounds__(PLAN_BLOCK)
+void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ step_off,
+                      const int32_t *__restrict__ pcol, const double *__restrict__ pval,
+                      const real_t *__restrict__ Bp, size_t slab_stride,
+                      real_t *__restrict__ C, size_t ldc, int nslabs, int ngens, int noct, int c_vec_ok,
+                      unsigned *__restrict__ sync_ctr, int sync_mode)
+{
+    constexpr int VEC = 16 / (int)sizeof(real_t);
+    constexpr int W = SLAB_GROUP * VEC;
+    constexpr int U = 8;                                            // plan steps in flight per wavefront
+    __shared__ real_t accs[PLAN_WG_ROWS * W];                       // 1024 rows x 128 B = 128 KiB
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, lg = lane & 7;
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
+    const long long total = (long long)nslabs * ngens;
+    const long long lo = total * xcd / 8, hi = total * (xcd + 1) / 8;
+    const int niter = (int)((hi - lo + nwg - 1) / nwg);
+    unsigned *const my_ctr = sync_ctr + xcd * 64;
+    real_t *const my_rows = accs + (size_t)(wave * 8 + g) * PLAN_RB * W + lg * VEC;    // this group's bundle
+
+    for (int it = 0; it < niter; it++) {
+        const long long item_raw = lo + wg + (long long)it * nwg;
+        const bool have = item_raw < hi;
+        const long long item = have ? item_raw : lo;
+        const int slab = (int)(item / ngens), gen = (int)(item % ngens);
+        const int oct = gen * PLAN_WAVES + wave;
+        const bool oct_ok = have && oct < noct;
+        // slab base is wave-uniform (scalar registers), the per-lane part is a 32-bit byte offset: one VALU op per
+        // address.  A slab is K x 128 B < 4 GiB because K < 2^27... checked on the host (K * 128 < 2^32).
+        const char *__restrict__ Bbase = reinterpret_cast<const char *>(Bp + (size_t)slab * slab_stride);
+        const unsigned lane_off = (unsigned)(lg * VEC * sizeof(real_t));
+
+        for (int i = threadIdx.x; i < PLAN_WG_ROWS * W; i += PLAN_BLOCK) accs[i] = 0;
+        __syncthreads();
+
+        // One continuous, software-pipelined stream over the octet's entries of ALL panels (they are contiguous in
+        // the plan).  Panel boundaries only matter for locality: when the stream crosses one, the 16 waves of the
+        // CU's single workgroup meet at a __syncthreads (no global traffic, no pipeline restart: the prefetched
+        // plan entries stay in flight).  Across the 32 CUs of the XCD group there is ONE global timing barrier per
+        // generation (32 pollers per counter); in between the CUs run identical code on statistically identical
+        // data and drift by a fraction of a panel.
+        {
+            if (sync_mode >= 2) xcd_timing_barrier(my_ctr, (unsigned)(it + 1) * (unsigned)nwg);
+            int sbeg = 0, send = 0, next_b = 0;
+            if (oct_ok) {
+                sbeg = step_off[(size_t)oct * npanels];
+                send = step_off[(size_t)oct * npanels + npanels];
+                next_b = npanels > 1 ? step_off[(size_t)oct * npanels + 1] : send;
+            }
+            int p = 0;
+            int cur = -1;
+            real_t acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] = 0;
+            // A batch = U = 8 steps = 64 consecutive plan slots: lane l reads slot (8 s + l) — one fully coalesced
+            // 256 B + 512 B read per batch — and step u's entry for group g is then fetched from lane 8u+g with a
+            // cross-lane read.  (Reading slot 8(s+u)+g from all 8 lanes of group g instead costs the texture
+            // addresser 8x the lane-bytes: PMC showed TA_BUSY 71 % and the kernel TA-bound.)
+            static_assert(U == 8, "one batch = one wavefront of plan slots");
+            const long long slot_end = (long long)send * 8;
+            int pcw = -1, pcwn = -1;
+            double pvw = 0.0, pvwn = 0.0;
+            {
+                const long long e = (long long)sbeg * 8 + lane;
+                if (e < slot_end) { pcw = pcol[e]; pvw = pval[e]; }
+            }
+            for (int s = sbeg; s < send; s += U) {                  // sbeg, send are wave-uniform
+                int pc[U];
+                double pv[U];
+                real_t b[U][VEC];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    pc[u] = __shfl(pcw, u * 8 + g, 64);
+                    pv[u] = __shfl(pvw, u * 8 + g, 64);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const unsigned off = (pc[u] >= 0 ? ((unsigned)(pc[u] & ((1 << PLAN_ROW_SHIFT) - 1)) * (unsigned)(W * sizeof(real_t))) : 0u)
+                                         + lane_off;
+                    vload<real_t, VEC>(b[u], reinterpret_cast<const real_t *>(Bbase + off));
+                }
+                const int sn = s + U;
+                {                                                   // prefetch the next batch of plan slots
+                    const long long e = (long long)sn * 8 + lane;
+                    pcwn = -1;
+                    if (e < slot_end) { pcwn = pcol[e]; pvwn = pval[e]; }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (pc[u] >= 0) {
+                        const int lrow = pc[u] >> PLAN_ROW_SHIFT;
+                        if (lrow != cur) {
+                            if (cur >= 0) {
+                                real_t *d = my_rows + cur * W;
+#pragma unroll
+                                for (int v = 0; v < VEC; v++) { d[v] += acc[v]; acc[v] = 0; }
+                            }
+                            cur = lrow;
+                        }
+                        const real_t a = (real_t)pv[u];
+#pragma unroll
+                        for (int v = 0; v < VEC; v++) acc[v] = mx_fma(a, b[u][v], acc[v]);
+                    }
+                }
+                pcw = pcwn; pvw = pvwn;
+                if (sync_mode > 0) {
+                    while (p < npanels - 1 && sn >= next_b) {       // the stream moved into the next panel
+                        p++;
+                        __syncthreads();
+                        next_b = p < npanels - 1 ? step_off[(size_t)oct * npanels + p + 1] : send;
+                    }
+                }
+            }
+            if (cur >= 0) {
+                real_t *d = my_rows + cur * W;
+#pragma unroll
+                for (int v = 0; v < VEC; v++) d[v] += acc[v];
+            }
+            if (sync_mode > 0)
+                for (; p < npanels - 1; p++) __syncthreads();           // every wave meets npanels-1 times per generation
+        }
+        __syncthreads();
+
+        // write the generation's 256 x W tile of C
+        if (have) {
+            const int row_base = gen * PLAN_WG_ROWS;
+            const int ncols = min(W, n - slab * W);
+            if constexpr (!COLMAJOR) {
+                for (int r = threadIdx.x >> 3; r < PLAN_WG_ROWS; r += PLAN_BLOCK / 8) {
+                    const int row = row_base + r;
+                    if (row < m && lg * VEC < ncols) {
+                        real_t t[VEC];
+#pragma unroll
+                        for (int v = 0; v < VEC; v++) t[v] = accs[(size_t)r * W + lg * VEC + v];
+                        vstore<real_t, VEC>(C + (size_t)row * ldc + slab * W + lg * VEC, t);
+                    }
+                }
+            } else {
+                // consecutive threads -> consecutive rows of one output column
+                for (int idx = threadIdx.x; idx < PLAN_WG_ROWS * W; idx += PLAN_BLOCK) {
+                    const int c = idx / PLAN_WG_ROWS, r = idx % PLAN_WG_ROWS;
+                    const int row = row_base + r;
+                    if (row < m && c < ncols) C[(size_t)(slab * W + c) * ldc + row] = accs[(size_t)r * W + c];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int exclusive_scan_i32(const int32_t *counts, int64_t n, int32_t *out, int64_t *total_dev, void *workspace,
+                       hipStream_t st);
+size_t scan_workspace_bytes(int64_t n);
+
+}  // namespace mx
+
+// device-resident plan of one CSR matrix (see the v3 comment above)
+struct mx_spmm_plan {
+    int m = 0, K = 0, npanels = 0, panel_cols = 0, noct = 0;
+    long long total_steps = 0;
+    int32_t *step_off = nullptr; size_t step_off_cap = 0;
+    int32_t *pcol = nullptr;     size_t pcol_cap = 0;
+    double *pval = nullptr;      size_t pval_cap = 0;
+    void *scratch = nullptr;     size_t scratch_cap = 0;       // rowpre + steps + scan workspace (build only)
+    double build_ms = 0.0;
+};
+
+namespace mx {
+
+static int grow(void **p, size_t *cap, size_t bytes)
+{
+    if (*cap >= bytes && *p) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    MX_HIP(hipMalloc(p, bytes ? bytes : 16));
+    *cap = bytes;
+    return 0;
+}
+
+static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, const int32_t *indices,
+                      const double *values, int npanels, hipStream_t st)
+{
+    MX_REQUIRE(K < (1 << 25), "spmm plan: more than 2^25 columns (32-bit slab offsets)");
+    if (npanels <= 0) npanels = pick_panels(K, (size_t)2560 << 10);
+    if (npanels > PLAN_MAXP) npanels = PLAN_MAXP;
+    pl->m = m; pl->K = K; pl->npanels = npanels;
+    pl->panel_cols = (int)ceil_div(K > 0 ? K : 1, npanels);
+    pl->noct = (int)ceil_div(m, PLAN_OCT_ROWS);
+    const size_t nop = (size_t)pl->noct * npanels;
+    const size_t rowpre_b = (((size_t)m * npanels * 4) + 255) & ~(size_t)255;
+    const size_t steps_b = ((nop * 4) + 255) & ~(size_t)255;
+    if (grow(&pl->scratch, &pl->scratch_cap, rowpre_b + steps_b + scan_workspace_bytes((int64_t)nop))) return 1;
+    if (grow((void **)&pl->step_off, &pl->step_off_cap, (nop + 1) * 4)) return 1;
+    int32_t *rowpre = (int32_t *)pl->scratch;
+    int32_t *steps = (int32_t *)((char *)pl->scratch + rowpre_b);
+    void *scan_ws = (char *)pl->scratch + rowpre_b + steps_b;
+    const unsigned blocks = (unsigned)ceil_div(pl->noct, 4);
+    hipLaunchKernelGGL(plan_count_kernel, dim3(blocks), dim3(256), 0, st, m, npanels, pl->panel_cols, indptr, indices,
+                       rowpre, steps, pl->noct);
+    MX_LAUNCH_CHECK();
+    if (exclusive_scan_i32(steps, (int64_t)nop, pl->step_off, (int64_t *)scan_ws, scan_ws, st)) return 1;
+    long long total = 0;
+    MX_HIP(hipMemcpyAsync(&total, scan_ws, sizeof(total), hipMemcpyDeviceToHost, st));
+    MX_HIP(hipStreamSynchronize(st));
+    MX_REQUIRE(total >= 0 && total * 8 <= (long long)INT_MAX * 4LL, "spmm plan: too many steps (%lld)", total);
+    MX_REQUIRE(total <= (long long)INT_MAX, "spmm plan: step offsets exceed int32");
+    pl->total_steps = total;
+    const size_t slots = (size_t)(total > 0 ? total : 1) * 8;
+    if (grow((void **)&pl->pcol, &pl->pcol_cap, slots * 4)) return 1;
+    if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
+    MX_HIP(hipMemsetAsync(pl->pcol, 0xFF, slots * 4, st));                       // -1 = padding slot
+    hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(256), 0, st, m, npanels, pl->panel_cols, indptr, indices,
+                       values, rowpre, pl->step_off, pl->pcol, pl->pval, pl->noct);
+    MX_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename real_t>
+static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor,
+                    int wg_per_cu, int sync_mode, hipStream_t st)
+{
+    constexpr int VEC = 16 / (int)sizeof(real_t);
+    constexpr int W = SLAB_GROUP * VEC;
+    const int m = pl->m, K = pl->K;
+    const int nslabs = (int)ceil_div(n, W);
+    const int ngens = (int)ceil_div(m, PLAN_WG_ROWS);
+    // slab-major copy of B
+    real_t *Bp = (real_t *)slab_pack_workspace((size_t)nslabs * (size_t)K * W * sizeof(real_t));
+    MX_REQUIRE(Bp, "spmm plan: cannot allocate the packed copy of B");
+    {
+        const long long pieces = (long long)K * nslabs * SLAB_GROUP;
+        const unsigned gsz = (unsigned)(ceil_div(pieces, 256) < 8192 ? ceil_div(pieces, 256) : 8192);
+        hipLaunchKernelGGL((repack_slabs_kernel<real_t>), dim3(gsz), dim3(256), 0, st, K, n, nslabs, B, ldb, Bp);
+        MX_LAUNCH_CHECK();
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    wg_per_cu = 1;                      // one 1024-thread workgroup (128 KiB of LDS) per CU
+    long long grid = (long long)cus * wg_per_cu;
+    const long long total = (long long)nslabs * ngens;
+    if (grid > total + 7) grid = total + 7;
+    grid = (grid / 8) * 8;
+    if (grid < 8) grid = 8;
+    unsigned *sync = slab_sync_workspace();
+    if (!sync || pl->npanels <= 1) sync_mode = 0;
+    if (sync_mode) MX_HIP(hipMemsetAsync(sync, 0, 8 * 64 * sizeof(unsigned), st));
+    const int c_vec_ok = 0;
+    if (colmajor)
+        hipLaunchKernelGGL((spmm_plan_kernel<real_t, true>), dim3((unsigned)grid), dim3(PLAN_BLOCK), 0, st, m, n,
+                           pl->npanels, pl->step_off, pl->pcol, pl->pval, Bp, (size_t)K * W, C, ldc, nslabs, ngens,
+                           pl->noct, c_vec_ok, sync, sync_mode);
+    else
+        hipLaunchKernelGGL((spmm_plan_kernel<real_t, false>), dim3((unsigned)grid), dim3(PLAN_BLOCK), 0, st, m, n,
+                           pl->npanels, pl->step_off, pl->pcol, pl->pval, Bp, (size_t)K * W, C, ldc, nslabs, ngens,
+                           pl->noct, c_vec_ok, sync, sync_mode);
+    MX_LAUNCH_CHECK();
+    return 0;
+}
+
 // can the slab kernel take these operands?  (16-B aligned rows of B, whole vectors per row;
 // row-major C additionally needs 16-B aligned rows of C)
 template <typename real_t>
@@ -595,7 +1008,63 @@ static bool slab_ok(int n, const real_t *B, size_t ldb, const real_t *C, size_t 
 
 }  // namespace mx
 
+extern "C" int mxd_spmm_plan_create(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+                                    int npanels, void *stream, mx_spmm_plan **plan_out)
+{
+    MX_REQUIRE(plan_out && m >= 0 && K >= 0, "mxd_spmm_plan_create: bad arguments");
+    mx_spmm_plan *pl = *plan_out ? *plan_out : new (std::nothrow) mx_spmm_plan();      // pass an old plan to reuse its buffers
+    MX_REQUIRE(pl, "out of host memory");
+    if (mx::plan_build(pl, m, K, indptr, indices, values, npanels, mx::as_stream(stream))) {
+        if (!*plan_out) { mxd_spmm_plan_destroy(pl); }
+        return 1;
+    }
+    *plan_out = pl;
+    return 0;
+}
+
+extern "C" int mxd_spmm_plan_destroy(mx_spmm_plan *pl)
+{
+    if (!pl) return 0;
+    if (pl->step_off) (void)hipFree(pl->step_off);
+    if (pl->pcol) (void)hipFree(pl->pcol);
+    if (pl->pval) (void)hipFree(pl->pval);
+    if (pl->scratch) (void)hipFree(pl->scratch);
+    delete pl;
+    return 0;
+}
+
+extern "C" int mxd_spmm_plan_info(const mx_spmm_plan *pl, int *npanels, int64_t *padded_entries)
+{
+    MX_REQUIRE(pl, "mxd_spmm_plan_info: null plan");
+    if (npanels) *npanels = pl->npanels;
+    if (padded_entries) *padded_entries = pl->total_steps * 8;
+    return 0;
+}
+
 static thread_local const char *g_last_spmm_kernel = "none";
+
+extern "C" int mxd_spmm_plan_run(const mx_spmm_plan *pl, int n, const void *B, size_t ldb, void *C, size_t ldc,
+                                 int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream)
+{
+    MX_REQUIRE(pl && n >= 0, "mxd_spmm_plan_run: bad arguments");
+    if (pl->m == 0 || n == 0) return 0;
+    MX_REQUIRE(B && C, "mxd_spmm_plan_run: null pointer");
+    hipStream_t st = mx::as_stream(stream);
+    if (sync_mode < 0) sync_mode = 2;
+    g_last_spmm_kernel = "spmm_plan_kernel";
+    if (dense_dtype == MX_F64) {
+        MX_REQUIRE(mx::slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor_out),
+                   "mxd_spmm_plan_run: operands do not meet the 16-byte alignment rules");
+        return mx::plan_run<double>(pl, n, (const double *)B, ldb, (double *)C, ldc, colmajor_out, wg_per_cu, sync_mode, st);
+    }
+    if (dense_dtype == MX_F32) {
+        MX_REQUIRE(mx::slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor_out),
+                   "mxd_spmm_plan_run: operands do not meet the 16-byte alignment rules");
+        return mx::plan_run<float>(pl, n, (const float *)B, ldb, (float *)C, ldc, colmajor_out, wg_per_cu, sync_mode, st);
+    }
+    return mx::set_error("mxd_spmm_plan_run: unsupported dense dtype %d", dense_dtype);
+}
+
 extern "C" const char *mxd_spmm_last_kernel(void) { return g_last_spmm_kernel; }
 
 extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,

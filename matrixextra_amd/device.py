@@ -35,6 +35,31 @@ class DeviceCSR:
     K: int
     nnz: int
     _sorted: bool | None = None
+    _plan: object = None
+    _plan_panels: int = -1
+
+    def plan(self, npanels: int = 0, rebuild: bool = False):
+        """Device-resident SpMM plan (mxd_spmm_plan_create); cached per DeviceCSR, buffers re-used on rebuild."""
+        lib = _lib.load()
+        if self._plan is None or rebuild or self._plan_panels != npanels:
+            handle = self._plan if self._plan is not None else C.c_void_p()
+            check(lib.mxd_spmm_plan_create(C.c_int(self.m), C.c_int(self.K), _dp(self.indptr), _dp(self.indices),
+                                           _dp(self.values), C.c_int(npanels), _stream(), C.byref(handle)))
+            self._plan, self._plan_panels = handle, npanels
+        return self._plan
+
+    def plan_info(self):
+        lib = _lib.load()
+        P, padded = C.c_int(0), C.c_int64(0)
+        check(lib.mxd_spmm_plan_info(self._plan, C.byref(P), C.byref(padded)))
+        return dict(npanels=P.value, padded_entries=padded.value)
+
+    def __del__(self):
+        try:
+            if self._plan is not None:
+                _lib.load().mxd_spmm_plan_destroy(self._plan)
+        except Exception:
+            pass
 
     def rows_sorted(self) -> bool:
         """check_is_sorted per row on the device (src/misc.cpp:118-128); cached."""
@@ -88,6 +113,32 @@ def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajo
                                     _dp(A.values), _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),
                                     C.c_int(dt), C.c_int(1 if colmajor else 0), C.c_int(algo),
                                     C.c_int(int(sorted_rows)), C.c_int(npanels), C.c_int(wg_per_cu), _stream()))
+    return out.t() if colmajor else out
+
+
+def spmm_planned(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajor: bool = False,
+                 npanels: int = 0, wg_per_cu: int = 0, sync_mode: int = -1, rebuild_plan: bool = False):
+    """C = A @ B through the planned panel-sweep kernel (v3).  The plan is built on first use (or every call with
+    rebuild_plan=True, which is what a one-shot product from plain CSR costs) and cached on the DeviceCSR."""
+    lib = _lib.load()
+    assert B.is_cuda and B.dim() == 2 and B.stride(1) == 1 and B.shape[0] == A.K
+    n = int(B.shape[1])
+    dt = MX_F64 if B.dtype == torch.float64 else MX_F32
+    if colmajor:
+        if out is None:
+            out = torch.empty((n, A.m), dtype=B.dtype, device=B.device)
+        ldc = A.m
+    else:
+        if out is None:
+            out = torch.empty((A.m, n), dtype=B.dtype, device=B.device)
+        ldc = n
+    if A.nnz == 0:
+        out.zero_()
+        return out.t() if colmajor else out
+    plan = A.plan(npanels, rebuild=rebuild_plan)
+    check(lib.mxd_spmm_plan_run(plan, C.c_int(n), _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),
+                                C.c_int(dt), C.c_int(1 if colmajor else 0), C.c_int(wg_per_cu), C.c_int(sync_mode),
+                                _stream()))
     return out.t() if colmajor else out
 
 

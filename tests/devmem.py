@@ -50,3 +50,23 @@ def spmm_device(p, j, x, B_rowmajor, colmajor, algo, rows_sorted, npanels=0, wg_
     check(lib.mx_stream_sync(None))
     out = dC.download(B_rowmajor.dtype, (n, m) if colmajor else (m, n))
     return out.T if colmajor else out
+
+
+def spmm_planned_device(p, j, x, B_rowmajor, colmajor, npanels=0, wg_per_cu=0, sync_mode=-1):
+    """C = A @ B through mxd_spmm_plan_create / mxd_spmm_plan_run; returns C as an (m, n) numpy array."""
+    lib = _lib.load()
+    m, (K, n) = p.size - 1, B_rowmajor.shape
+    dt = _lib.MX_F64 if B_rowmajor.dtype == np.float64 else _lib.MX_F32
+    dp, dj, dx, dB = Dev(p.astype(np.int32)), Dev(j.astype(np.int32)), Dev(x.astype(np.float64)), Dev(B_rowmajor)
+    dC = Dev(nbytes=m * n * B_rowmajor.dtype.itemsize)
+    check(lib.mx_dev_memset(dC.ptr, 0xFF, C.c_size_t(dC.nbytes), None))
+    plan = C.c_void_p()
+    check(lib.mxd_spmm_plan_create(C.c_int(m), C.c_int(K), dp.ptr, dj.ptr, dx.ptr, C.c_int(npanels), None, C.byref(plan)))
+    try:
+        check(lib.mxd_spmm_plan_run(plan, C.c_int(n), dB.ptr, C.c_size_t(n), dC.ptr, C.c_size_t(m if colmajor else n),
+                                    C.c_int(dt), C.c_int(int(colmajor)), C.c_int(wg_per_cu), C.c_int(sync_mode), None))
+        check(lib.mx_stream_sync(None))
+    finally:
+        lib.mxd_spmm_plan_destroy(plan)
+    out = dC.download(B_rowmajor.dtype, (n, m) if colmajor else (m, n))
+    return out.T if colmajor else out

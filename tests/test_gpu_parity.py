@@ -437,3 +437,48 @@ def test_csr_by_dense_elemwise(gpu):
     xl = rng.choice(np.array([0, 1, NA], np.int32), size=x.size)
     Dl = rng.choice(np.array([0, 1, NA], np.int32), size=(300, 70))
     np.testing.assert_array_equal(G.logicaland_csr_by_dense_cpp(p, j, xl, Dl), O.logicaland_csr_by_dense_cpp(p, j, xl, Dl))
+
+
+# ----------------------------------------------------------------------------- planned SpMM kernel (v3)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("colmajor", [False, True])
+@pytest.mark.parametrize("m,K,n,per_row,npanels", [
+    (3000, 5000, 128, 32, 4), (3000, 5000, 128, 32, 1), (1000, 700, 64, 9, 3), (777, 900, 16, 20, 7),
+    (515, 300, 132, 40, 5), (2050, 64, 256, 12, 2), (300, 4000, 8, 70, 16), (63, 50, 16, 5, 64)])
+def test_spmm_planned_kernel_vs_oracle(gpu, dtype, colmajor, m, K, n, per_row, npanels):
+    from devmem import spmm_planned_device
+    p, j, x = synth.csr_fixed(m, K, per_row, seed=m + n)
+    B = synth.dense_normal(K, n, dtype=dtype)
+    ref = O.tcrossprod_csr_dense(p, j, x, np.asfortranarray(B.T), 1, use_fma=True).astype(np.float64)
+    scale = (np.abs(csr_abs_dense(p, j, x, K)) @ np.abs(B.astype(np.float64)))
+    tol = (1e-14 if dtype == np.float64 else 1e-6) * scale + 1e-300
+    for sync in (0, 2):
+        got = spmm_planned_device(p, j, x, B, colmajor, npanels=npanels, sync_mode=sync).astype(np.float64)
+        assert got.shape == ref.shape
+        assert (np.abs(got - ref) <= tol).all()
+
+
+def csr_abs_dense(p, j, x, K):
+    import scipy.sparse as sp
+    return sp.csr_matrix((np.abs(x), j, p), shape=(p.size - 1, K)).toarray()
+
+
+def test_spmm_planned_kernel_skewed_unsorted_special(gpu):
+    from devmem import spmm_planned_device
+    p, j, x = synth.csr_skewed(4000, 2500, 24, seed=3)               # empty rows, very long rows
+    B = synth.dense_normal(2500, 128)
+    ref = O.tcrossprod_csr_dense(p, j, x, np.asfortranarray(B.T), 1, use_fma=True)
+    for npanels in (1, 2, 5, 33):
+        got = spmm_planned_device(p, j, x, B, True, npanels=npanels)
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-11)
+    pu, ju, xu = rand_csr(500, 300, 0.2, seed=8, sorted_cols=False)  # unsorted rows, duplicates-free
+    Bu = synth.dense_normal(300, 32)
+    refu = O.tcrossprod_csr_dense(pu, ju, xu, np.asfortranarray(Bu.T), 1, use_fma=True)
+    np.testing.assert_allclose(spmm_planned_device(pu, ju, xu, Bu, False, npanels=3), refu, rtol=1e-12, atol=1e-12)
+    # NaN / Inf in values and in B propagate like in the reference
+    ps = np.array([0, 3, 3, 5], dtype=np.int32); js = np.array([1, 1, 0, 1, 0], dtype=np.int32)
+    xs = np.array([2.0, 3.0, 1.0, np.inf, np.nan])
+    Bs = np.zeros((2, 16)); Bs[0, :] = 1.0; Bs[1, :] = np.arange(16); Bs[0, 3] = np.inf
+    got, refs = spmm_planned_device(ps, js, xs, Bs, True), O.tcrossprod_csr_dense(ps, js, xs, np.asfortranarray(Bs.T), 1)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(refs))
+    np.testing.assert_array_equal(got[~np.isnan(got)], refs[~np.isnan(refs)])

@@ -99,9 +99,12 @@ int mxd_spmm_csr_dense(int m, int n,
  *                          accumulators in registers (needs 16-B aligned rows of B; npanels > 1 needs
  *                          rows sorted by column — pass rows_sorted = 1 only when that is known, e.g. from
  *                          mxd_csr_rows_sorted)
- *   algo MX_SPMM_AUTO    : SLAB when B is larger than an XCD's L2 and the operands qualify, else ROWWAVE
+ *   algo MX_SPMM_PLANNED : build a plan (see mxd_spmm_plan_create below) and run the planned panel-sweep kernel;
+ *                          the plan is rebuilt on every call here — hold a plan yourself to amortise it
+ *   algo MX_SPMM_AUTO    : PLANNED when B is larger than an XCD's L2, the operands qualify and there is enough
+ *                          work to fill the chip, else ROWWAVE
  * npanels <= 0 / wg_per_cu <= 0 pick defaults. */
-typedef enum { MX_SPMM_AUTO = 0, MX_SPMM_ROWWAVE = 1, MX_SPMM_SLAB = 2 } mx_spmm_algo;
+typedef enum { MX_SPMM_AUTO = 0, MX_SPMM_ROWWAVE = 1, MX_SPMM_SLAB = 2, MX_SPMM_PLANNED = 3 } mx_spmm_algo;
 int mxd_spmm_csr_dense_ex(int m, int n, int K,
                           const int32_t *indptr, const int32_t *indices, const double *values,
                           const void *B, size_t ldb, void *C, size_t ldc,
@@ -113,9 +116,9 @@ int mxd_spmm_csr_dense_ex(int m, int n, int K,
  * The plan depends on A and npanels only; build it once per matrix and run it against any number of B.
  * mxd_spmm_plan_create: *plan = NULL creates, a previous plan re-uses its buffers (grow-only); one internal
  * stream sync (the padded size comes back to the host).  npanels <= 0 picks K*128 B / 2.5 MB.
- * mxd_spmm_plan_run: sync_mode 0 = no locality window; k >= 1 = a wave may enter a panel once every wave of its XCD
- * group has finished the panel k steps back (1 = lock step, 2 = two panels in flight, ...); -1 = default.
- * Needs 16-B aligned rows of B. */
+ * mxd_spmm_plan_run: sync_mode 0 = free running, 1 = the waves of a CU's workgroup meet at every panel boundary,
+ * 2 = 1 + one timing barrier per generation among the workgroups of an XCD group; -1 = default (1).
+ * Needs 16-B aligned rows of B; wg_per_cu is ignored (one 1024-thread workgroup per CU). */
 typedef struct mx_spmm_plan mx_spmm_plan;
 int mxd_spmm_plan_create(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
                          int npanels, void *stream, mx_spmm_plan **plan);
@@ -123,6 +126,11 @@ int mxd_spmm_plan_destroy(mx_spmm_plan *plan);
 int mxd_spmm_plan_info(const mx_spmm_plan *plan, int *npanels, int64_t *padded_entries);
 int mxd_spmm_plan_run(const mx_spmm_plan *plan, int n, const void *B, size_t ldb, void *C, size_t ldc,
                       int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream);
+
+/* HIP-event timing of the dominant kernel of every SpMM launch of this thread (events recorded on the launch stream
+ * right around that kernel): enable, run, then read the per-launch milliseconds (the read synchronises). */
+int mxd_spmm_kernel_timing(int enable);
+int mxd_spmm_kernel_times(float *out_ms, int max_out, int *count);
 
 /* name of the SpMM kernel the last mxd_spmm_csr_dense_ex call of this thread launched (reporting only) */
 const char *mxd_spmm_last_kernel(void);

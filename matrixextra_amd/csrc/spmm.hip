@@ -67,6 +67,9 @@ __device__ __forceinline__ void vstore(real_t *__restrict__ p, const real_t (&sr
 __device__ __forceinline__ double mx_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float mx_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+static void kt_begin(hipStream_t st);
+static void kt_end(hipStream_t st);
+
 constexpr int SPMM_WAVES = 4;     // wavefronts per workgroup
 constexpr int SPMM_UNROLL = 8;    // B-row reads in flight per wavefront
 
@@ -203,8 +206,10 @@ static int launch_spmm(int m, int n, const int32_t *indptr, const int32_t *indic
     constexpr int TR = 32;
     constexpr int W = MX_WAVE * VEC;
     dim3 grid((unsigned)ceil_div(m, TR), (unsigned)ceil_div(n, W));
+    kt_begin(stream);
     hipLaunchKernelGGL((spmm_rowwave_kernel<real_t, VEC, COLMAJOR, VSTORE, TR>), grid,
                        dim3(SPMM_WAVES * MX_WAVE), 0, stream, m, n, indptr, indices, values, B, ldb, C, ldc);
+    kt_end(stream);
     MX_LAUNCH_CHECK();
     return 0;
 }
@@ -590,6 +595,7 @@ static int launch_spmm_slab_rpg(int m, int n, int K, const int32_t *indptr, cons
             B = Bp; ldb = W; slab_stride = (size_t)K * W;
         }
     }
+    kt_begin(stream);
     if (colmajor)
         hipLaunchKernelGGL((spmm_slab_kernel<real_t, RPG, true>), dim3((unsigned)grid), dim3(SLAB_BLOCK), 0, stream,
                            m, n, indptr, indices, values, B, ldb, C, ldc, npanels, panel_cols, nslabs, nrowblocks,
@@ -598,6 +604,7 @@ static int launch_spmm_slab_rpg(int m, int n, int K, const int32_t *indptr, cons
         hipLaunchKernelGGL((spmm_slab_kernel<real_t, RPG, false>), dim3((unsigned)grid), dim3(SLAB_BLOCK), 0, stream,
                            m, n, indptr, indices, values, B, ldb, C, ldc, npanels, panel_cols, nslabs, nrowblocks,
                            c_vec_ok, sync, sync_mode, slab_stride);
+    kt_end(stream);
     MX_LAUNCH_CHECK();
     return 0;
 }
@@ -950,6 +957,28 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     return 0;
 }
 
+// Optional HIP-event ring around the dominant kernel of every SpMM launch (bench.py's roofline figure): events sit
+// on the launch stream right before / after the kernel, nothing else in between.
+struct KernelTimer {
+    static constexpr int N = 256;
+    hipEvent_t a[N], b[N];
+    bool made = false, on = false;
+    int count = 0;
+};
+static thread_local KernelTimer g_kt;
+static void kt_begin(hipStream_t st)
+{
+    if (!g_kt.on || g_kt.count >= KernelTimer::N) return;
+    if (!g_kt.made) { for (int i = 0; i < KernelTimer::N; i++) { (void)hipEventCreate(&g_kt.a[i]); (void)hipEventCreate(&g_kt.b[i]); } g_kt.made = true; }
+    (void)hipEventRecord(g_kt.a[g_kt.count], st);
+}
+static void kt_end(hipStream_t st)
+{
+    if (!g_kt.on || g_kt.count >= KernelTimer::N) return;
+    (void)hipEventRecord(g_kt.b[g_kt.count], st);
+    g_kt.count++;
+}
+
 template <typename real_t>
 static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor,
                     int wg_per_cu, int sync_mode, hipStream_t st)
@@ -983,6 +1012,7 @@ static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, 
     if (!sync || pl->npanels <= 1) sync_mode = 0;
     if (sync_mode) MX_HIP(hipMemsetAsync(sync, 0, 8 * 64 * sizeof(unsigned), st));
     const int c_vec_ok = 0;
+    kt_begin(st);
     if (colmajor)
         hipLaunchKernelGGL((spmm_plan_kernel<real_t, true>), dim3((unsigned)grid), dim3(PLAN_BLOCK), 0, st, m, n,
                            pl->npanels, pl->step_off, pl->pcol, pl->pval, Bp, (size_t)K * W, C, ldc, nslabs, ngens,
@@ -991,6 +1021,7 @@ static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, 
         hipLaunchKernelGGL((spmm_plan_kernel<real_t, false>), dim3((unsigned)grid), dim3(PLAN_BLOCK), 0, st, m, n,
                            pl->npanels, pl->step_off, pl->pcol, pl->pval, Bp, (size_t)K * W, C, ldc, nslabs, ngens,
                            pl->noct, c_vec_ok, sync, sync_mode);
+    kt_end(st);
     MX_LAUNCH_CHECK();
     return 0;
 }
@@ -1043,6 +1074,26 @@ extern "C" int mxd_spmm_plan_info(const mx_spmm_plan *pl, int *npanels, int64_t 
 
 static thread_local const char *g_last_spmm_kernel = "none";
 
+extern "C" int mxd_spmm_kernel_timing(int enable)
+{
+    mx::g_kt.on = enable != 0;
+    mx::g_kt.count = 0;
+    return 0;
+}
+// elapsed ms of the dominant kernel of each SpMM launch since mxd_spmm_kernel_timing(1) (synchronises on the events)
+extern "C" int mxd_spmm_kernel_times(float *out_ms, int max_out, int *count)
+{
+    MX_REQUIRE(count, "mxd_spmm_kernel_times: null count pointer");
+    const int n = mx::g_kt.count < max_out ? mx::g_kt.count : max_out;
+    for (int i = 0; i < n; i++) {
+        MX_HIP(hipEventSynchronize(mx::g_kt.b[i]));
+        MX_HIP(hipEventElapsedTime(&out_ms[i], mx::g_kt.a[i], mx::g_kt.b[i]));
+    }
+    *count = n;
+    mx::g_kt.count = 0;
+    return 0;
+}
+
 extern "C" int mxd_spmm_plan_run(const mx_spmm_plan *pl, int n, const void *B, size_t ldb, void *C, size_t ldc,
                                  int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream)
 {
@@ -1050,7 +1101,7 @@ extern "C" int mxd_spmm_plan_run(const mx_spmm_plan *pl, int n, const void *B, s
     if (pl->m == 0 || n == 0) return 0;
     MX_REQUIRE(B && C, "mxd_spmm_plan_run: null pointer");
     hipStream_t st = mx::as_stream(stream);
-    if (sync_mode < 0) sync_mode = 2;
+    if (sync_mode < 0) sync_mode = 1;       // panel meetings inside the CU's workgroup; 2 adds one XCD barrier per generation
     g_last_spmm_kernel = "spmm_plan_kernel";
     if (dense_dtype == MX_F64) {
         MX_REQUIRE(mx::slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor_out),
@@ -1081,17 +1132,21 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
     const bool ok = dense_dtype == MX_F64
         ? mx::slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor_out)
         : mx::slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor_out);
-    bool auto_pick = false;
     if (algo == MX_SPMM_AUTO) {
-        // Measured on MI355X, headline config (profiles/r01_*): row-wave 4.45 ms; slab kernel with B repacked
-        // slab-major, one panel, no barrier 4.05 ms (the slab-major copy spreads a slab over all L2 channels);
-        // slab + column panels + XCD barrier 5.9 ms (L2 hits 28 -> 60 %, but every panel visit re-reads the row's
-        // (j, a) and the kernel turns VALU-bound).  So AUTO = one-panel packed slab kernel when B outgrows one
-        // XCD's L2 and there is enough work to fill the persistent grid, else the row-wave kernel.
+        // Measured on MI355X, headline config (profiles/r01_*): row-wave 4.45 ms; one-panel slab kernel on the
+        // slab-major copy of B 4.05 ms; planned panel sweep 2.6 ms + 0.65 ms to build the plan from plain CSR.
+        // AUTO = planned (plan rebuilt on every call: nothing is assumed about A between calls) when B outgrows
+        // one XCD's L2 and there is enough work to fill the persistent grid, else the row-wave kernel.
         const size_t b_bytes = (size_t)K * (size_t)n * (dense_dtype == MX_F64 ? 8 : 4);
-        auto_pick = ok && b_bytes > ((size_t)8 << 20) && (long long)m * n >= (1LL << 24);
-        algo = auto_pick ? MX_SPMM_SLAB : MX_SPMM_ROWWAVE;
-        if (auto_pick) { npanels = 1; if (wg_per_cu <= 0) wg_per_cu = 4; }
+        const bool big = ok && b_bytes > ((size_t)8 << 20) && (long long)m * n >= (1LL << 24);
+        algo = big ? (K < (1 << 25) ? MX_SPMM_PLANNED : MX_SPMM_SLAB) : MX_SPMM_ROWWAVE;
+        if (algo == MX_SPMM_SLAB) { npanels = 1; if (wg_per_cu <= 0) wg_per_cu = 4; }
+    }
+    if (algo == MX_SPMM_PLANNED) {
+        MX_REQUIRE(ok, "mxd_spmm_csr_dense_ex: operands do not meet the planned kernel's 16-byte alignment rules");
+        static thread_local mx_spmm_plan *auto_plan = nullptr;      // buffers re-used from call to call (grow-only)
+        if (mxd_spmm_plan_create(m, K, indptr, indices, values, npanels, stream, &auto_plan)) return 1;
+        return mxd_spmm_plan_run(auto_plan, n, B, ldb, C, ldc, dense_dtype, colmajor_out, 0, -1, stream);
     }
     if (algo == MX_SPMM_SLAB) {
         MX_REQUIRE(ok, "mxd_spmm_csr_dense_ex: operands do not meet the slab kernel's 16-byte alignment rules");

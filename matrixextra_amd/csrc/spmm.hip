@@ -658,7 +658,7 @@ constexpr int PLAN_ROW_SHIFT = 27;                 // col < 2^27
 __global__ __launch_bounds__(256)
 void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
                        const int32_t *__restrict__ indices, int32_t *__restrict__ rowpre, int32_t *__restrict__ steps,
-                       int noct)
+                       int32_t *__restrict__ bpo, int noct)
 {
     __shared__ int seg[4][8][PLAN_MAXP];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 3, lg = lane & 7;
@@ -687,20 +687,48 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
         }
     }
     __syncthreads();
-    if (oct < noct)
-        for (int p = lane; p < npanels; p += 64) {
-            int mx = 0;
-#pragma unroll
-            for (int gg = 0; gg < 8; gg++) mx = max(mx, seg[wave][gg][p]);
-            steps[(size_t)oct * npanels + p] = mx;
+    if (oct < noct) {
+        // a bundle's entries form ONE stream (panel after panel); only the end of the octet is padded.
+        // bpo = where each panel starts inside the bundle's stream; octet length = longest bundle.
+        int total = 0;
+        if (lg == 0) {
+            int run = 0;
+            for (int p = 0; p < npanels; p++) {
+                bpo[((size_t)oct * 8 + g) * npanels + p] = run;
+                run += seg[wave][g][p];
+            }
+            total = run;
         }
+        total = __shfl(total, g * 8, 64);
+        int mx = total;
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+        if (lane == 0) steps[oct] = mx;
+    }
+}
+
+// panel boundaries of an octet for the kernel's panel meetings: mean start of the panel over the 8 bundles
+__global__ __launch_bounds__(256)
+void plan_bounds_kernel(int noct, int npanels, const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
+                        int32_t *__restrict__ step_off)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)noct * npanels;
+    if (t > n) return;
+    if (t == n) { step_off[n] = oct_off[noct]; return; }
+    const int oct = (int)(t / npanels), p = (int)(t % npanels);
+    int sum = 0;
+#pragma unroll
+    for (int g = 0; g < 8; g++) sum += bpo[((size_t)oct * 8 + g) * npanels + p];
+    step_off[t] = oct_off[oct] + (p == 0 ? 0 : sum / 8);
 }
 
 // pass 2: scatter the entries to their interleaved slots
 __global__ __launch_bounds__(256)
 void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
                       const int32_t *__restrict__ indices, const double *__restrict__ values,
-                      const int32_t *__restrict__ rowpre, const int32_t *__restrict__ step_off,
+                      const int32_t *__restrict__ rowpre, const int32_t *__restrict__ oct_off,
+                      const int32_t *__restrict__ bpo,
                       int32_t *__restrict__ pcol, double *__restrict__ pval, int noct)
 {
     __shared__ int running[4][8][PLAN_MAXP];
@@ -712,7 +740,9 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
     for (int r = 0; r < PLAN_RB; r++) {
         const int row = row0 + r;
         if (row >= m) break;
-        for (int p = lg; p < npanels; p += 8) running[wave][g][p] = 0;
+        // running[q] starts at this row's first step of panel q (octet start + bundle's panel start + rows before)
+        for (int p = lg; p < npanels; p += 8)
+            running[wave][g][p] = oct_off[oct] + bpo[((size_t)oct * 8 + g) * npanels + p] + rowpre[(size_t)row * npanels + p];
         const int s = indptr[row], e = indptr[row + 1];
         for (int k0 = s; k0 < e; k0 += 8) {
             const int k = k0 + lg;
@@ -725,8 +755,7 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
                 const unsigned same = group8_ballot(pan == q);
                 const int base = running[wave][g][q];               // all lanes read before lane 0 updates
                 if (pan == q) {
-                    const long long step = (long long)step_off[(size_t)oct * npanels + q] +
-                                           rowpre[(size_t)row * npanels + q] + base + __popc(same & below);
+                    const long long step = (long long)base + __popc(same & below);
                     const long long dst = step * 8 + g;
                     pcol[dst] = col | (r << PLAN_ROW_SHIFT);
                     pval[dst] = a;
@@ -900,6 +929,7 @@ size_t scan_workspace_bytes(int64_t n);
 struct mx_spmm_plan {
     int m = 0, K = 0, npanels = 0, panel_cols = 0, noct = 0;
     long long total_steps = 0;
+    long long nnz = 0;
     int32_t *step_off = nullptr; size_t step_off_cap = 0;
     int32_t *pcol = nullptr;     size_t pcol_cap = 0;
     double *pval = nullptr;      size_t pval_cap = 0;
@@ -923,27 +953,38 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
                       const double *values, int npanels, hipStream_t st)
 {
     MX_REQUIRE(K < (1 << 25), "spmm plan: more than 2^25 columns (32-bit slab offsets)");
-    if (npanels <= 0) npanels = pick_panels(K, (size_t)2560 << 10);
+    if (npanels <= 0) npanels = pick_panels(K, (size_t)3328 << 10);     // measured: 3.2 MB panels (P=4) beat 2.6 MB (P=5)
     if (npanels > PLAN_MAXP) npanels = PLAN_MAXP;
     pl->m = m; pl->K = K; pl->npanels = npanels;
     pl->panel_cols = (int)ceil_div(K > 0 ? K : 1, npanels);
     pl->noct = (int)ceil_div(m, PLAN_OCT_ROWS);
     const size_t nop = (size_t)pl->noct * npanels;
-    const size_t rowpre_b = (((size_t)m * npanels * 4) + 255) & ~(size_t)255;
-    const size_t steps_b = ((nop * 4) + 255) & ~(size_t)255;
-    if (grow(&pl->scratch, &pl->scratch_cap, rowpre_b + steps_b + scan_workspace_bytes((int64_t)nop))) return 1;
+    const size_t al = 255;
+    const size_t rowpre_b = (((size_t)m * npanels * 4) + al) & ~al;
+    const size_t steps_b = (((size_t)pl->noct * 4) + al) & ~al;
+    const size_t octoff_b = ((((size_t)pl->noct + 1) * 4) + al) & ~al;
+    const size_t bpo_b = ((nop * 8 * 4) + al) & ~al;
+    if (grow(&pl->scratch, &pl->scratch_cap, rowpre_b + steps_b + octoff_b + bpo_b + scan_workspace_bytes((int64_t)pl->noct))) return 1;
     if (grow((void **)&pl->step_off, &pl->step_off_cap, (nop + 1) * 4)) return 1;
     int32_t *rowpre = (int32_t *)pl->scratch;
     int32_t *steps = (int32_t *)((char *)pl->scratch + rowpre_b);
-    void *scan_ws = (char *)pl->scratch + rowpre_b + steps_b;
+    int32_t *oct_off = (int32_t *)((char *)steps + steps_b);
+    int32_t *bpo = (int32_t *)((char *)oct_off + octoff_b);
+    void *scan_ws = (char *)bpo + bpo_b;
     const unsigned blocks = (unsigned)ceil_div(pl->noct, 4);
     hipLaunchKernelGGL(plan_count_kernel, dim3(blocks), dim3(256), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       rowpre, steps, pl->noct);
+                       rowpre, steps, bpo, pl->noct);
     MX_LAUNCH_CHECK();
-    if (exclusive_scan_i32(steps, (int64_t)nop, pl->step_off, (int64_t *)scan_ws, scan_ws, st)) return 1;
+    if (exclusive_scan_i32(steps, (int64_t)pl->noct, oct_off, (int64_t *)scan_ws, scan_ws, st)) return 1;
+    hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)ceil_div((long long)nop + 1, 256)), dim3(256), 0, st, pl->noct,
+                       npanels, oct_off, bpo, pl->step_off);
+    MX_LAUNCH_CHECK();
     long long total = 0;
+    int32_t nnz32 = 0;
     MX_HIP(hipMemcpyAsync(&total, scan_ws, sizeof(total), hipMemcpyDeviceToHost, st));
+    MX_HIP(hipMemcpyAsync(&nnz32, indptr + m, sizeof(nnz32), hipMemcpyDeviceToHost, st));
     MX_HIP(hipStreamSynchronize(st));
+    pl->nnz = nnz32;
     MX_REQUIRE(total >= 0 && total * 8 <= (long long)INT_MAX * 4LL, "spmm plan: too many steps (%lld)", total);
     MX_REQUIRE(total <= (long long)INT_MAX, "spmm plan: step offsets exceed int32");
     pl->total_steps = total;
@@ -952,7 +993,7 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
     MX_HIP(hipMemsetAsync(pl->pcol, 0xFF, slots * 4, st));                       // -1 = padding slot
     hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(256), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       values, rowpre, pl->step_off, pl->pcol, pl->pval, pl->noct);
+                       values, rowpre, oct_off, bpo, pl->pcol, pl->pval, pl->noct);
     MX_LAUNCH_CHECK();
     return 0;
 }
@@ -1132,6 +1173,7 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
     const bool ok = dense_dtype == MX_F64
         ? mx::slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor_out)
         : mx::slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor_out);
+    bool auto_pick_planned = false;
     if (algo == MX_SPMM_AUTO) {
         // Measured on MI355X, headline config (profiles/r01_*): row-wave 4.45 ms; one-panel slab kernel on the
         // slab-major copy of B 4.05 ms; planned panel sweep 2.6 ms + 0.65 ms to build the plan from plain CSR.
@@ -1140,13 +1182,18 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
         const size_t b_bytes = (size_t)K * (size_t)n * (dense_dtype == MX_F64 ? 8 : 4);
         const bool big = ok && b_bytes > ((size_t)8 << 20) && (long long)m * n >= (1LL << 24);
         algo = big ? (K < (1 << 25) ? MX_SPMM_PLANNED : MX_SPMM_SLAB) : MX_SPMM_ROWWAVE;
+        auto_pick_planned = algo == MX_SPMM_PLANNED;
         if (algo == MX_SPMM_SLAB) { npanels = 1; if (wg_per_cu <= 0) wg_per_cu = 4; }
     }
     if (algo == MX_SPMM_PLANNED) {
         MX_REQUIRE(ok, "mxd_spmm_csr_dense_ex: operands do not meet the planned kernel's 16-byte alignment rules");
         static thread_local mx_spmm_plan *auto_plan = nullptr;      // buffers re-used from call to call (grow-only)
         if (mxd_spmm_plan_create(m, K, indptr, indices, values, npanels, stream, &auto_plan)) return 1;
-        return mxd_spmm_plan_run(auto_plan, n, B, ldb, C, ldc, dense_dtype, colmajor_out, 0, -1, stream);
+        // rows of very uneven length pad the 8-way interleave (an octet is as long as its longest bundle): when the
+        // plan would be more than 1.5x the CSR the row-wave kernel is the better choice
+        if (!auto_pick_planned || auto_plan->total_steps * 8 <= auto_plan->nnz + auto_plan->nnz / 2 + 65536)
+            return mxd_spmm_plan_run(auto_plan, n, B, ldb, C, ldc, dense_dtype, colmajor_out, 0, -1, stream);
+        algo = MX_SPMM_ROWWAVE;
     }
     if (algo == MX_SPMM_SLAB) {
         MX_REQUIRE(ok, "mxd_spmm_csr_dense_ex: operands do not meet the slab kernel's 16-byte alignment rules");

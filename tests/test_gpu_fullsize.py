@@ -135,3 +135,29 @@ def test_cfg4_merge_properties(gpu):
         o = O.multiply_csr_elemwise(a[0], b[0], a[1], b[1], a[2], b[2])
         np.testing.assert_array_equal(mj[mp_[r0]:mp_[r1]], o["indices"])
         np.testing.assert_array_equal(mx_[mp_[r0]:mp_[r1]], o["values"])
+
+
+def test_auto_spmm_on_skewed_rows_large(gpu):
+    """AUTO on a big matrix with log-normal row lengths (some rows thousands of entries long, some empty): whichever
+    kernel AUTO settles on (planned, or row-wave when the interleave would pad too much) must match the oracle."""
+    from matrixextra_amd import device as D
+    m, K, n = 300_000, 120_000, 128
+    p, j, x = synth.csr_skewed(m, K, 20, seed=11, sigma=1.4)
+    A = D.DeviceCSR.from_host(p, j, x, K)
+    B = synth.dense_normal(K, n, seed=3)
+    C = D.spmm(A, torch.from_numpy(B).cuda(), colmajor=True)
+    Cp = D.spmm_planned(A, torch.from_numpy(B).cuda(), colmajor=True)
+    w = np.bincount(j, weights=x, minlength=K)
+    scale = np.abs(x).sum() * np.abs(B).max()
+    for got in (C, Cp):
+        assert np.max(np.abs(got.sum(dim=0).cpu().numpy() - w @ B)) <= 1e-12 * scale
+    long_row = int(np.argmax(np.diff(p)))
+    for r0 in (0, max(0, long_row - 100), m - 400):
+        rows = 400
+        pp = (p[r0:r0 + rows + 1] - p[r0]).astype(np.int32)
+        ref = np.zeros(rows * n)
+        O.gemm_csr_drm_as_drm(rows, n, pp, j[p[r0]:p[r0 + rows]].copy(), x[p[r0]:p[r0 + rows]].copy(), B.reshape(-1), n,
+                              ref, n, 4, True)
+        for got in (C, Cp):
+            np.testing.assert_allclose(got[r0:r0 + rows].cpu().numpy(), ref.reshape(rows, n), rtol=1e-11, atol=1e-11)
+    print("kernel picked by AUTO:", _lib.load().mxd_spmm_last_kernel().decode(), "plan:", A.plan_info(), "nnz", A.nnz)

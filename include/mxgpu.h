@@ -127,6 +127,9 @@ int mxd_spmm_plan_info(const mx_spmm_plan *plan, int *npanels, int64_t *padded_e
 int mxd_spmm_plan_run(const mx_spmm_plan *plan, int n, const void *B, size_t ldb, void *C, size_t ldc,
                       int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream);
 
+/* AUTO's plan and the slab-major copy of B live in grow-only per-thread device buffers between calls; this frees them */
+int mxd_release_workspaces(void);
+
 /* HIP-event timing of the dominant kernel of every SpMM launch of this thread (events recorded on the launch stream
  * right around that kernel): enable, run, then read the per-launch milliseconds (the read synchronises). */
 int mxd_spmm_kernel_timing(int enable);

@@ -528,12 +528,13 @@ void repack_slabs_kernel(int K, int n, int nslabs, const real_t *__restrict__ B,
 }
 
 // grow-only per-device scratch for the packed copy of B
-static void *slab_pack_workspace(size_t bytes)
+static void *slab_pack_workspace(size_t bytes, bool release = false)
 {
     static thread_local void *ws[64] = {};
     static thread_local size_t cap[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (release) { if (ws[dev]) (void)hipFree(ws[dev]); ws[dev] = nullptr; cap[dev] = 0; return nullptr; }
     if (cap[dev] < bytes) {
         if (ws[dev]) (void)hipFree(ws[dev]);
         ws[dev] = nullptr; cap[dev] = 0;
@@ -939,6 +940,8 @@ struct mx_spmm_plan {
 
 namespace mx {
 
+static thread_local mx_spmm_plan *g_auto_plan = nullptr;
+
 static int grow(void **p, size_t *cap, size_t bytes)
 {
     if (*cap >= bytes && *p) return 0;
@@ -1115,6 +1118,14 @@ extern "C" int mxd_spmm_plan_info(const mx_spmm_plan *pl, int *npanels, int64_t 
 
 static thread_local const char *g_last_spmm_kernel = "none";
 
+// frees this thread's grow-only scratch (AUTO's plan, the slab-major copy of B); they are re-created on demand
+extern "C" int mxd_release_workspaces(void)
+{
+    if (mx::g_auto_plan) { mxd_spmm_plan_destroy(mx::g_auto_plan); mx::g_auto_plan = nullptr; }
+    mx::slab_pack_workspace(0, true);
+    return 0;
+}
+
 extern "C" int mxd_spmm_kernel_timing(int enable)
 {
     mx::g_kt.on = enable != 0;
@@ -1187,7 +1198,7 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
     }
     if (algo == MX_SPMM_PLANNED) {
         MX_REQUIRE(ok, "mxd_spmm_csr_dense_ex: operands do not meet the planned kernel's 16-byte alignment rules");
-        static thread_local mx_spmm_plan *auto_plan = nullptr;      // buffers re-used from call to call (grow-only)
+        mx_spmm_plan *&auto_plan = mx::g_auto_plan;                  // buffers re-used from call to call (grow-only)
         if (mxd_spmm_plan_create(m, K, indptr, indices, values, npanels, stream, &auto_plan)) return 1;
         // rows of very uneven length pad the 8-way interleave (an octet is as long as its longest bundle): when the
         // plan would be more than 1.5x the CSR the row-wave kernel is the better choice

@@ -344,42 +344,6 @@ __device__ __forceinline__ void xcd_timing_barrier(unsigned *ctr, unsigned targe
     __syncthreads();
 }
 
-// Windowed form: a workgroup may START step t once every workgroup of its group has FINISHED step t-1-slack.
-// slack = 0 is the hard barrier above; slack = 1 lets the group spread over two consecutive panels (working set
-// two panels) but nobody stalls unless a straggler is more than one step behind, and the memory pipeline does
-// not drain at every step.
-__device__ __forceinline__ void xcd_window_wait(unsigned *ctr, long long need)
-{
-    if (need > 0) {
-        if (threadIdx.x == 0) {
-            int spins = 0;
-            while ((long long)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < 4096)
-                __builtin_amdgcn_s_sleep(4);
-        }
-        __syncthreads();
-    }
-}
-__device__ __forceinline__ void xcd_window_arrive(unsigned *ctr)
-{
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// wave-level forms (every lane runs the same loop on the same word: uniform control flow, no __syncthreads)
-__device__ __forceinline__ void wave_window_wait(unsigned *ctr, long long need)
-{
-    if (need > 0) {
-        int spins = 0;
-        while ((long long)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need &&
-               ++spins < 8192)
-            __builtin_amdgcn_s_sleep(2);
-    }
-}
-__device__ __forceinline__ void wave_window_arrive(unsigned *ctr)
-{
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <typename real_t, int RPG, bool COLMAJOR>
 __global__ __launch_bounds__(SLAB_BLOCK)
 void spmm_slab_kernel(int m, int n,

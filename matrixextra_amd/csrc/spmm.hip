@@ -618,57 +618,47 @@ constexpr int PLAN_WG_ROWS = PLAN_OCT_ROWS * PLAN_WAVES;   // rows per workgroup
 constexpr int PLAN_MAXP = 64;
 constexpr int PLAN_ROW_SHIFT = 27;                 // col < 2^27
 
-// pass 1: per (row, panel) prefix inside the bundle, per (octet, panel) number of steps.
-// One wavefront per octet, one 8-lane group per bundle.
-__global__ __launch_bounds__(256)
+// Plan construction: one 512-thread workgroup per octet, one wavefront per bundle.  A bundle's entries are contiguous
+// in the CSR arrays (8 consecutive rows), so the wavefront streams them 64 at a time, fully coalesced; the position
+// of an entry inside its (bundle, panel) stream is a per-panel running count kept in scalar registers plus a
+// ballot prefix — no LDS, no per-row bookkeeping.
+// pass 1: bpo[bundle][p] = where panel p starts in the bundle's stream; steps[oct] = longest bundle of the octet.
+__global__ __launch_bounds__(512)
 void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
-                       const int32_t *__restrict__ indices, int32_t *__restrict__ rowpre, int32_t *__restrict__ steps,
+                       const int32_t *__restrict__ indices, int32_t *__restrict__ steps,
                        int32_t *__restrict__ bpo, int noct)
 {
-    __shared__ int seg[4][8][PLAN_MAXP];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 3, lg = lane & 7;
-    const int oct = blockIdx.x * 4 + wave;
-    for (int p = lg; p < npanels; p += 8) seg[wave][g][p] = 0;
-    __syncthreads();
-    if (oct < noct) {
-        const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
-        for (int r = 0; r < PLAN_RB; r++) {
-            const int row = row0 + r;
-            if (row >= m) break;                                   // uniform inside the group
-            for (int p = lg; p < npanels; p += 8) rowpre[(size_t)row * npanels + p] = seg[wave][g][p];
-            const int s = indptr[row], e = indptr[row + 1];
-            for (int k0 = s; k0 < e; k0 += 8) {
-                const int k = k0 + lg;
-                int pan = -1;
-                if (k < e) { pan = indices[k] / panel_cols; if (pan >= npanels) pan = npanels - 1; }
-                unsigned todo = group8_ballot(pan >= 0);
-                while (todo) {                                      // one round per distinct panel in the chunk
-                    const int q = __shfl(pan, __ffs(todo) - 1, 8);
-                    const unsigned same = group8_ballot(pan == q);
-                    if (lg == 0) seg[wave][g][q] += __popc(same);
-                    todo &= ~same;
-                }
-            }
+    __shared__ int totals[8];
+    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int oct = blockIdx.x;
+    const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
+    const int r0 = min(row0, m), r1 = min(row0 + PLAN_RB, m);
+    const int s = indptr[r0], e = indptr[r1];
+    int mine = 0;                                                    // lane p accumulates the count of panel p (+64, ...)
+    for (int k0 = s; k0 < e; k0 += 64) {
+        const int k = k0 + lane;
+        int pan = -1;
+        if (k < e) { pan = indices[k] / panel_cols; if (pan >= npanels) pan = npanels - 1; }
+        for (int q = 0; q < npanels; q++) {
+            const int c = __popcll(__ballot(pan == q));
+            if (lane == (q & 63)) mine += c;                         // npanels <= 64: one lane per panel
         }
     }
-    __syncthreads();
-    if (oct < noct) {
-        // a bundle's entries form ONE stream (panel after panel); only the end of the octet is padded.
-        // bpo = where each panel starts inside the bundle's stream; octet length = longest bundle.
-        int total = 0;
-        if (lg == 0) {
-            int run = 0;
-            for (int p = 0; p < npanels; p++) {
-                bpo[((size_t)oct * 8 + g) * npanels + p] = run;
-                run += seg[wave][g][p];
-            }
-            total = run;
-        }
-        total = __shfl(total, g * 8, 64);
-        int mx = total;
+    // exclusive prefix over the panels (lanes 0..npanels-1)
+    int incl = lane < npanels ? mine : 0;
 #pragma unroll
-        for (int off = 8; off < 64; off <<= 1) mx = max(mx, __shfl_xor(mx, off, 64));
-        if (lane == 0) steps[oct] = mx;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane < npanels) bpo[((size_t)oct * 8 + g) * npanels + lane] = incl - mine;
+    if (lane == 0) totals[g] = e - s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int mx = 0;
+#pragma unroll
+        for (int gg = 0; gg < 8; gg++) mx = max(mx, totals[gg]);
+        steps[oct] = mx;
     }
 }
 
@@ -688,46 +678,44 @@ void plan_bounds_kernel(int noct, int npanels, const int32_t *__restrict__ oct_o
     step_off[t] = oct_off[oct] + (p == 0 ? 0 : sum / 8);
 }
 
-// pass 2: scatter the entries to their interleaved slots
-__global__ __launch_bounds__(256)
+// pass 2: scatter the entries to their interleaved slots (slot = 8 * step + bundle-in-octet)
+__global__ __launch_bounds__(512)
 void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
                       const int32_t *__restrict__ indices, const double *__restrict__ values,
-                      const int32_t *__restrict__ rowpre, const int32_t *__restrict__ oct_off,
-                      const int32_t *__restrict__ bpo,
+                      const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
                       int32_t *__restrict__ pcol, double *__restrict__ pval, int noct)
 {
-    __shared__ int running[4][8][PLAN_MAXP];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 3, lg = lane & 7;
-    const int oct = blockIdx.x * 4 + wave;
-    if (oct >= noct) return;                                        // no block-wide barrier below
+    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int oct = blockIdx.x;
     const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
-    const unsigned below = (1u << lg) - 1u;
-    for (int r = 0; r < PLAN_RB; r++) {
-        const int row = row0 + r;
-        if (row >= m) break;
-        // running[q] starts at this row's first step of panel q (octet start + bundle's panel start + rows before)
-        for (int p = lg; p < npanels; p += 8)
-            running[wave][g][p] = oct_off[oct] + bpo[((size_t)oct * 8 + g) * npanels + p] + rowpre[(size_t)row * npanels + p];
-        const int s = indptr[row], e = indptr[row + 1];
-        for (int k0 = s; k0 < e; k0 += 8) {
-            const int k = k0 + lg;
-            int pan = -1, col = 0;
-            double a = 0.0;
-            if (k < e) { col = indices[k]; a = values[k]; pan = col / panel_cols; if (pan >= npanels) pan = npanels - 1; }
-            unsigned todo = group8_ballot(pan >= 0);
-            while (todo) {
-                const int q = __shfl(pan, __ffs(todo) - 1, 8);
-                const unsigned same = group8_ballot(pan == q);
-                const int base = running[wave][g][q];               // all lanes read before lane 0 updates
-                if (pan == q) {
-                    const long long step = (long long)base + __popc(same & below);
-                    const long long dst = step * 8 + g;
-                    pcol[dst] = col | (r << PLAN_ROW_SHIFT);
-                    pval[dst] = a;
-                }
-                if (lg == 0) running[wave][g][q] = base + __popc(same);
-                todo &= ~same;
+    int rp[PLAN_RB + 1];                                             // the bundle's row pointers (wave-uniform)
+#pragma unroll
+    for (int r = 0; r <= PLAN_RB; r++) rp[r] = uniform(indptr[min(row0 + r, m)]);
+    const int s = rp[0], e = rp[PLAN_RB];
+    const long long base = oct_off[oct];
+    // lane q keeps the next free step of panel q's stream
+    int nextstep = lane < npanels ? bpo[((size_t)oct * 8 + g) * npanels + lane] : 0;
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    for (int k0 = s; k0 < e; k0 += 64) {
+        const int k = k0 + lane;
+        int pan = -1, col = 0, lrow = 0;
+        double a = 0.0;
+        if (k < e) {
+            col = indices[k]; a = values[k];
+            pan = col / panel_cols; if (pan >= npanels) pan = npanels - 1;
+#pragma unroll
+            for (int r = 1; r < PLAN_RB; r++) lrow += k >= rp[r];
+        }
+        for (int q = 0; q < npanels; q++) {
+            const unsigned long long same = __ballot(pan == q);
+            if (same == 0ULL) continue;                              // uniform
+            const int start = __shfl(nextstep, q & 63, 64);
+            if (pan == q) {
+                const long long dst = (base + start + __popcll(same & below)) * 8 + g;
+                pcol[dst] = col | (lrow << PLAN_ROW_SHIFT);
+                pval[dst] = a;
             }
+            if (lane == (q & 63)) nextstep += __popcll(same);
         }
     }
 }
@@ -927,20 +915,18 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     pl->noct = (int)ceil_div(m, PLAN_OCT_ROWS);
     const size_t nop = (size_t)pl->noct * npanels;
     const size_t al = 255;
-    const size_t rowpre_b = (((size_t)m * npanels * 4) + al) & ~al;
     const size_t steps_b = (((size_t)pl->noct * 4) + al) & ~al;
     const size_t octoff_b = ((((size_t)pl->noct + 1) * 4) + al) & ~al;
     const size_t bpo_b = ((nop * 8 * 4) + al) & ~al;
-    if (grow(&pl->scratch, &pl->scratch_cap, rowpre_b + steps_b + octoff_b + bpo_b + scan_workspace_bytes((int64_t)pl->noct))) return 1;
+    if (grow(&pl->scratch, &pl->scratch_cap, steps_b + octoff_b + bpo_b + scan_workspace_bytes((int64_t)pl->noct))) return 1;
     if (grow((void **)&pl->step_off, &pl->step_off_cap, (nop + 1) * 4)) return 1;
-    int32_t *rowpre = (int32_t *)pl->scratch;
-    int32_t *steps = (int32_t *)((char *)pl->scratch + rowpre_b);
+    int32_t *steps = (int32_t *)pl->scratch;
     int32_t *oct_off = (int32_t *)((char *)steps + steps_b);
     int32_t *bpo = (int32_t *)((char *)oct_off + octoff_b);
     void *scan_ws = (char *)bpo + bpo_b;
-    const unsigned blocks = (unsigned)ceil_div(pl->noct, 4);
-    hipLaunchKernelGGL(plan_count_kernel, dim3(blocks), dim3(256), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       rowpre, steps, bpo, pl->noct);
+    const unsigned blocks = (unsigned)pl->noct;
+    hipLaunchKernelGGL(plan_count_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
+                       steps, bpo, pl->noct);
     MX_LAUNCH_CHECK();
     if (exclusive_scan_i32(steps, (int64_t)pl->noct, oct_off, (int64_t *)scan_ws, scan_ws, st)) return 1;
     hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)ceil_div((long long)nop + 1, 256)), dim3(256), 0, st, pl->noct,
@@ -959,8 +945,8 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     if (grow((void **)&pl->pcol, &pl->pcol_cap, slots * 4)) return 1;
     if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
     MX_HIP(hipMemsetAsync(pl->pcol, 0xFF, slots * 4, st));                       // -1 = padding slot
-    hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(256), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       values, rowpre, oct_off, bpo, pl->pcol, pl->pval, pl->noct);
+    hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
+                       values, oct_off, bpo, pl->pcol, pl->pval, pl->noct);
     MX_LAUNCH_CHECK();
     return 0;
 }

@@ -658,7 +658,7 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
         int mx = 0;
 #pragma unroll
         for (int gg = 0; gg < 8; gg++) mx = max(mx, totals[gg]);
-        steps[oct] = mx;
+        steps[oct] = (mx + 7) & ~7;                                  // whole batches of 8 steps (slot layout below)
     }
 }
 
@@ -678,7 +678,7 @@ void plan_bounds_kernel(int noct, int npanels, const int32_t *__restrict__ oct_o
     step_off[t] = oct_off[oct] + (p == 0 ? 0 : sum / 8);
 }
 
-// pass 2: scatter the entries to their interleaved slots (slot = 8 * step + bundle-in-octet)
+// pass 2: scatter the entries to their interleaved slots (batch of 8 steps = 64 slots laid out [bundle][step])
 __global__ __launch_bounds__(512)
 void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
                       const int32_t *__restrict__ indices, const double *__restrict__ values,
@@ -711,13 +711,35 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
             if (same == 0ULL) continue;                              // uniform
             const int start = __shfl(nextstep, q & 63, 64);
             if (pan == q) {
-                const long long dst = (base + start + __popcll(same & below)) * 8 + g;
+                // slot layout inside a batch of 8 steps: [bundle g][step u] — lane 8g+u of the reading wavefront holds
+                // bundle g's entry for step u, i.e. inside g's own lane group (intra-group DPP broadcast, no LDS)
+                const long long t = start + __popcll(same & below);      // step inside the octet
+                const long long dst = (base + (t & ~7LL)) * 8 + g * 8 + (t & 7);
                 pcol[dst] = col | (lrow << PLAN_ROW_SHIFT);
                 pval[dst] = a;
             }
             if (lane == (q & 63)) nextstep += __popcll(same);
         }
     }
+}
+
+// broadcast lane U of every 8-lane group: row_newbcast takes lane n of each 16-lane DPP row; bank_mask restricts the
+// write to the low / high half of the row (banks of 4 lanes), so two moves serve the two groups of a row
+template <int U>
+__device__ __forceinline__ int group8_dpp_bcast(int v)
+{
+    int t = __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0x3, false);
+    return __builtin_amdgcn_update_dpp(t, v, 0x150 + 8 + U, 0xF, 0xC, false);
+}
+template <int U>
+__device__ __forceinline__ void plan_bcast(int pcw, double pvw, int &pc, double &pv)
+{
+    union { double d; int i[2]; } a, b;
+    a.d = pvw;
+    pc = group8_dpp_bcast<U>(pcw);
+    b.i[0] = group8_dpp_bcast<U>(a.i[0]);
+    b.i[1] = group8_dpp_bcast<U>(a.i[1]);
+    pv = b.d;
 }
 
 // main kernel
@@ -776,9 +798,9 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             real_t acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; v++) acc[v] = 0;
-            // A batch = U = 8 steps = 64 consecutive plan slots: lane l reads slot (8 s + l) — one fully coalesced
-            // 256 B + 512 B read per batch — and step u's entry for group g is then fetched from lane 8u+g with a
-            // cross-lane read.  (Reading slot 8(s+u)+g from all 8 lanes of group g instead costs the texture
+            // A batch = U = 8 steps = 64 consecutive plan slots, laid out [bundle g][step u]: lane l reads slot
+            // (8 s + l) — one fully coalesced 256 B + 512 B read per batch — and step u's entry is broadcast from
+            // lane u of each group.  (Reading the slot from all 8 lanes of a group instead costs the texture
             // addresser 8x the lane-bytes: PMC showed TA_BUSY 71 % and the kernel TA-bound.)
             static_assert(U == 8, "one batch = one wavefront of plan slots");
             const long long slot_end = (long long)send * 8;
@@ -792,11 +814,12 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                 int pc[U];
                 double pv[U];
                 real_t b[U][VEC];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    pc[u] = __shfl(pcw, u * 8 + g, 64);
-                    pv[u] = __shfl(pvw, u * 8 + g, 64);
-                }
+                // lane 8g+u holds bundle g's entry of step u: broadcast lane u of every 8-lane group (two DPP moves
+                // per dword on the VALU; the first version used ds_bpermute and kept the LDS pipe 50 % busy)
+                plan_bcast<0>(pcw, pvw, pc[0], pv[0]); plan_bcast<1>(pcw, pvw, pc[1], pv[1]);
+                plan_bcast<2>(pcw, pvw, pc[2], pv[2]); plan_bcast<3>(pcw, pvw, pc[3], pv[3]);
+                plan_bcast<4>(pcw, pvw, pc[4], pv[4]); plan_bcast<5>(pcw, pvw, pc[5], pv[5]);
+                plan_bcast<6>(pcw, pvw, pc[6], pv[6]); plan_bcast<7>(pcw, pvw, pc[7], pv[7]);
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const unsigned off = (pc[u] >= 0 ? ((unsigned)(pc[u] & ((1 << PLAN_ROW_SHIFT) - 1)) * (unsigned)(W * sizeof(real_t))) : 0u)

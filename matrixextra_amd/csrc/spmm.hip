@@ -936,6 +936,8 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     pl->m = m; pl->K = K; pl->npanels = npanels;
     pl->panel_cols = (int)ceil_div(K > 0 ? K : 1, npanels);
     pl->noct = (int)ceil_div(m, PLAN_OCT_ROWS);
+    pl->total_steps = 0; pl->nnz = 0;
+    if (m == 0) return 0;                                           // nothing to plan (and no zero-sized launches)
     const size_t nop = (size_t)pl->noct * npanels;
     const size_t al = 255;
     const size_t steps_b = (((size_t)pl->noct * 4) + al) & ~al;

@@ -482,3 +482,21 @@ def test_spmm_planned_kernel_skewed_unsorted_special(gpu):
     got, refs = spmm_planned_device(ps, js, xs, Bs, True), O.tcrossprod_csr_dense(ps, js, xs, np.asfortranarray(Bs.T), 1)
     np.testing.assert_array_equal(np.isnan(got), np.isnan(refs))
     np.testing.assert_array_equal(got[~np.isnan(got)], refs[~np.isnan(refs)])
+
+
+def test_spmm_planned_edge_shapes(gpu):
+    from devmem import spmm_planned_device
+    B = synth.dense_normal(40, 16)
+    # all-empty matrix, single row, single entry, rows that are all padding in their octet
+    z = spmm_planned_device(np.zeros(6, np.int32), np.zeros(0, np.int32), np.zeros(0), B, True)
+    assert z.shape == (5, 16) and not z.any()
+    p = np.array([0, 1], np.int32); j = np.array([39], np.int32); x = np.array([2.5])
+    np.testing.assert_array_equal(spmm_planned_device(p, j, x, B, False), 2.5 * B[39:40])
+    p = np.zeros(131, np.int32); p[70:] = 3                     # only row 69 has entries (second octet)
+    j = np.array([0, 7, 39], np.int32); x = np.array([1.0, -1.0, 0.5])
+    got = spmm_planned_device(p, j, x, B, True, npanels=7)
+    ref = np.zeros((130, 16)); ref[69] = B[0] - B[7] + 0.5 * B[39]
+    np.testing.assert_allclose(got, ref, rtol=1e-15, atol=1e-15)
+    # duplicate column ids inside a row accumulate (SpMM does not need unique columns)
+    p = np.array([0, 4], np.int32); j = np.array([3, 3, 3, 1], np.int32); x = np.array([1.0, 2.0, 3.0, 4.0])
+    np.testing.assert_allclose(spmm_planned_device(p, j, x, B, True, npanels=2), (6 * B[3] + 4 * B[1])[None, :], rtol=1e-15)

@@ -598,15 +598,17 @@ static int launch_spmm_slab(int m, int n, int K, const int32_t *indptr, const in
 // 60 % because every (row, panel) visit re-reads the row's (j, a) chunk — with P panels the CSR arrays are
 // streamed ~2P times per XCD and that traffic, not B, dominates and evicts the panel.  v3 fixes the data
 // layout instead of the loop: a *plan* regroups A's entries by (octet of 8 row-bundles, panel) and
-// interleaves the 8 bundles of an octet step by step, so that
-//   * one wavefront (8 lane groups = 8 bundles) reads 8 consecutive plan entries per step — every entry of A
-//     is read exactly once per slab, coalesced, with no cursor / ballot / broadcast logic;
+// interleaves the 8 bundles of an octet in batches of 8 steps (slot 64*batch + 8*g + u = step 8*batch + u of
+// bundle g), so that
+//   * one wavefront (8 lane groups = 8 bundles) reads 64 consecutive plan entries per 8 steps — every entry of A
+//     is read exactly once per slab, coalesced, and reaches its lane group by a DPP row broadcast;
 //   * entries of a bundle inside a panel are ordered by row, the group accumulates the current row in
 //     registers and folds it into the bundle's accumulators in LDS when the row changes (only that group
 //     touches those LDS rows: plain read-modify-write, no atomics);
-//   * all workgroups of an XCD group stay on the same panel (timing barrier), whose slab-major copy of B
+//   * all workgroups of an XCD group stay close to the same panel (same code on statistically identical data;
+//     optional timing barrier), whose slab-major copy of B
 //     (K/P x 128 B, contiguous) fits the XCD's L2.
-// Entry = int32 (col | local_row << 27, -1 = padding) + f64 value; plan bytes ~ 1.2 x the CSR arrays.
+// Entry = int32 (col | local_row << 27, -1 = padding) + f64 value; plan bytes ~ the CSR arrays (octet lengths rounded to 8 steps).
 // Summation order: CSR order inside a (row, panel), panels added in ascending order — a regrouping of the
 // reference's sequential sum (tolerance-level difference, not bitwise).  Works for unsorted rows too.
 // =====================================================================================================

@@ -472,12 +472,12 @@ static int pick_panels(int K, size_t l2_budget)
 // One thread per 16-byte piece; reads are row-contiguous, each 8-lane group writes one full 128-byte line.
 template <typename real_t>
 __global__ __launch_bounds__(256)
-void repack_slabs_kernel(int K, int n, int nslabs, const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ Bp)
+void repack_slabs_kernel(int K, int Kp, int n, int nslabs, const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ Bp)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
     constexpr int W = SLAB_GROUP * VEC;
     const long long pieces_per_row = (long long)nslabs * SLAB_GROUP;
-    const long long total = (long long)K * pieces_per_row;
+    const long long total = (long long)Kp * pieces_per_row;          // rows K..Kp-1 of every slab are zero (plan padding)
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(t / pieces_per_row);
         const int piece = (int)(t % pieces_per_row);
@@ -486,8 +486,8 @@ void repack_slabs_kernel(int K, int n, int nslabs, const real_t *__restrict__ B,
         real_t v[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; q++) v[q] = 0;
-        if (col < n) vload<real_t, VEC>(v, B + (size_t)j * ldb + col);       // n % VEC == 0 (slab_ok)
-        vstore<real_t, VEC>(Bp + ((size_t)slab * K + j) * W + lg * VEC, v);
+        if (col < n && j < K) vload<real_t, VEC>(v, B + (size_t)j * ldb + col);       // n % VEC == 0 (slab_ok)
+        vstore<real_t, VEC>(Bp + ((size_t)slab * Kp + j) * W + lg * VEC, v);
     }
 }
 
@@ -555,7 +555,7 @@ static int launch_spmm_slab_rpg(int m, int n, int K, const int32_t *indptr, cons
         if (Bp) {
             const long long pieces = (long long)K * nslabs * SLAB_GROUP;
             const unsigned g = (unsigned)(ceil_div(pieces, 256) < 8192 ? ceil_div(pieces, 256) : 8192);
-            hipLaunchKernelGGL((repack_slabs_kernel<real_t>), dim3(g), dim3(256), 0, stream, K, n, nslabs, B, ldb, Bp);
+            hipLaunchKernelGGL((repack_slabs_kernel<real_t>), dim3(g), dim3(256), 0, stream, K, K, n, nslabs, B, ldb, Bp);
             MX_LAUNCH_CHECK();
             B = Bp; ldb = W; slab_stride = (size_t)K * W;
         }
@@ -608,16 +608,18 @@ static int launch_spmm_slab(int m, int n, int K, const int32_t *indptr, const in
 //   * all workgroups of an XCD group stay close to the same panel (same code on statistically identical data;
 //     optional timing barrier), whose slab-major copy of B
 //     (K/P x 128 B, contiguous) fits the XCD's L2.
-// Entry = int32 (col | local_row << 27, -1 = padding) + f64 value; plan bytes ~ the CSR arrays (octet lengths rounded to 8 steps).
+// Entry = int32 (col | local_row << 27; padding = zero row of the packed B, value 0) + f64 value; plan bytes ~ the CSR arrays (octet lengths rounded to 8 steps).
 // Summation order: CSR order inside a (row, panel), panels added in ascending order — a regrouping of the
 // reference's sequential sum (tolerance-level difference, not bitwise).  Works for unsorted rows too.
 // =====================================================================================================
 constexpr int PLAN_RB = 8;                         // rows per bundle (owned by one 8-lane group)
 constexpr int PLAN_OCT_ROWS = PLAN_RB * 8;         // rows per octet (one wavefront)
-constexpr int PLAN_WAVES = 16;                     // wavefronts per workgroup: ONE 1024-thread workgroup per CU
-constexpr int PLAN_BLOCK = PLAN_WAVES * 64;
-constexpr int PLAN_WG_ROWS = PLAN_OCT_ROWS * PLAN_WAVES;   // rows per workgroup generation (1024 rows = 128 KiB of LDS)
+// wavefronts per workgroup (template parameter WAVES): 16 = ONE 1024-thread workgroup with 128 KiB of LDS per CU,
+// 8 = two 512-thread workgroups with 64 KiB each (one's epilogue overlaps the other's sweep), 4 = four.
 constexpr int PLAN_MAXP = 64;
+constexpr int PLAN_DEFAULT_WG_PER_CU = 1;
+constexpr int PLAN_CHUNK = 4;                      // batches of 8 steps fetched per plan read (octets are whole chunks)
+constexpr int PLAN_TAIL_SLOTS = 512;               // readable padding behind the last octet (2 chunks)
 constexpr int PLAN_ROW_SHIFT = 27;                 // col < 2^27
 
 // Plan construction: one 512-thread workgroup per octet, one wavefront per bundle.  A bundle's entries are contiguous
@@ -660,7 +662,7 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
         int mx = 0;
 #pragma unroll
         for (int gg = 0; gg < 8; gg++) mx = max(mx, totals[gg]);
-        steps[oct] = (mx + 7) & ~7;                                  // whole batches of 8 steps (slot layout below)
+        steps[oct] = (mx + 8 * PLAN_CHUNK - 1) & ~(8 * PLAN_CHUNK - 1);    // whole chunks of 4 batches of 8 steps (slot layout below)
     }
 }
 
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(512)
 void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
                       const int32_t *__restrict__ indices, const double *__restrict__ values,
                       const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
-                      int32_t *__restrict__ pcol, double *__restrict__ pval, int noct)
+                      int32_t *__restrict__ pcol, double *__restrict__ pval, int noct, int pad_col)
 {
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int oct = blockIdx.x;
@@ -723,6 +725,27 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
             if (lane == (q & 63)) nextstep += __popcll(same);
         }
     }
+    // Padding up to the octet's length: a no-op entry — value 0, column `pad_col` (the all-zero extra row of the
+    // packed B), row = the bundle's last entry's row so that it does not even trigger a row switch.  0 * 0 added to
+    // an accumulator that is never -0.0 leaves it unchanged bit for bit.
+    int last_lrow = 0;
+    if (e > s) {
+#pragma unroll
+        for (int r = 1; r < PLAN_RB; r++) last_lrow += (e - 1) >= rp[r];
+    }
+    const int steps_oct = oct_off[oct + 1] - (int)base;
+    for (long long t = (e - s) + lane; t < steps_oct; t += 64) {
+        const long long dst = (base + (t & ~7LL)) * 8 + g * 8 + (t & 7);
+        pcol[dst] = pad_col | (last_lrow << PLAN_ROW_SHIFT);
+        pval[dst] = 0.0;
+    }
+    // PLAN_TAIL_SLOTS padding slots behind the last octet: the kernel's read-ahead runs two batches past an octet
+    if (oct == noct - 1) {
+        static_assert(PLAN_TAIL_SLOTS == 512, "one slot per thread of the last block");
+        const long long dst = (long long)oct_off[noct] * 8 + threadIdx.x;
+        pcol[dst] = pad_col;
+        pval[dst] = 0.0;
+    }
 }
 
 // broadcast lane U of every 8-lane group: row_newbcast takes lane n of each 16-lane DPP row; bank_mask restricts the
@@ -730,7 +753,7 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
 template <int U>
 __device__ __forceinline__ int group8_dpp_bcast(int v)
 {
-    int t = __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0x3, false);
+    int t = __builtin_amdgcn_mov_dpp(v, 0x150 + U, 0xF, 0x3, false);      // lanes of the other half: don't care
     return __builtin_amdgcn_update_dpp(t, v, 0x150 + 8 + U, 0xF, 0xC, false);
 }
 template <int U>
@@ -745,18 +768,20 @@ __device__ __forceinline__ void plan_bcast(int pcw, double pvw, int &pc, double 
 }
 
 // main kernel
-template <typename real_t, bool COLMAJOR>
-__global__ __launch_bounds__(PLAN_BLOCK)
+template <typename real_t, bool COLMAJOR, int PLAN_WAVES>
+__global__ __launch_bounds__(PLAN_WAVES * 64)
 void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ step_off,
                       const int32_t *__restrict__ pcol, const double *__restrict__ pval,
                       const real_t *__restrict__ Bp, size_t slab_stride,
-                      real_t *__restrict__ C, size_t ldc, int nslabs, int ngens, int noct, int c_vec_ok,
+                      real_t *__restrict__ C, size_t ldc, int nslabs, int ngens, int noct, int pad_col,
                       unsigned *__restrict__ sync_ctr, int sync_mode)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
     constexpr int W = SLAB_GROUP * VEC;
     constexpr int U = 8;                                            // plan steps in flight per wavefront
-    __shared__ real_t accs[PLAN_WG_ROWS * W];                       // 1024 rows x 128 B = 128 KiB
+    constexpr int PLAN_BLOCK = PLAN_WAVES * 64;
+    constexpr int PLAN_WG_ROWS = PLAN_OCT_ROWS * PLAN_WAVES;        // rows per workgroup generation
+    __shared__ real_t accs[PLAN_WG_ROWS * W];                       // 16 waves: 1024 rows x 128 B = 128 KiB
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, lg = lane & 7;
     const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
@@ -795,8 +820,11 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                 send = step_off[(size_t)oct * npanels + npanels];
                 next_b = npanels > 1 ? step_off[(size_t)oct * npanels + 1] : send;
             }
+            sbeg = __builtin_amdgcn_readfirstlane(sbeg);            // wave-uniform: keep the loop control scalar
+            send = __builtin_amdgcn_readfirstlane(send);
+            next_b = __builtin_amdgcn_readfirstlane(next_b);
             int p = 0;
-            int cur = -1;
+            int cur = 0;
             real_t acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; v++) acc[v] = 0;
@@ -804,63 +832,93 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             // (8 s + l) — one fully coalesced 256 B + 512 B read per batch — and step u's entry is broadcast from
             // lane u of each group.  (Reading the slot from all 8 lanes of a group instead costs the texture
             // addresser 8x the lane-bytes: PMC showed TA_BUSY 71 % and the kernel TA-bound.)
+            // Every slot is a valid entry: padding is (zero row of B, value 0, current row) — no per-step validity
+            // test, no clamp.
             static_assert(U == 8, "one batch = one wavefront of plan slots");
-            const long long slot_end = (long long)send * 8;
-            int pcw = -1, pcwn = -1;
-            double pvw = 0.0, pvwn = 0.0;
-            {
-                const long long e = (long long)sbeg * 8 + lane;
-                if (e < slot_end) { pcw = pcol[e]; pvw = pval[e]; }
+            static_assert(W * sizeof(real_t) == 128, "slab line");
+            auto b_offset = [&](int c) -> unsigned {                // the row bits (27..29) fall off the 32-bit shift
+                return ((unsigned)c * (unsigned)(W * sizeof(real_t))) + lane_off;
+            };
+            // The plan slots are fetched a CHUNK (PLAN_CHUNK = 4 batches = 32 steps) at a time, one chunk ahead.
+            // Vector loads return in order, so a slot read that misses to HBM (the plan is a pure stream) holds back
+            // every younger B-line load behind it; fetching one batch per iteration put that full latency into every
+            // iteration (measured: 1.95 us per 8 steps per wave, whatever the locality of B).  Now it is paid once
+            // per 32 steps.  Reads run one chunk past the octet (next octet's slots / the padding behind the last
+            // octet): they only ever become addresses of valid B lines, never FMAs.
+            int rc[PLAN_CHUNK], rn[PLAN_CHUNK];
+            double rv[PLAN_CHUNK], rvn[PLAN_CHUNK];
+            auto load_chunk = [&](int step, int (&c)[PLAN_CHUNK], double (&v)[PLAN_CHUNK]) {
+                const long long e = (long long)step * 8 + lane;
+#pragma unroll
+                for (int k = 0; k < PLAN_CHUNK; k++) { c[k] = pcol[e + 64 * k]; v[k] = pval[e + 64 * k]; }
+            };
+            int pc[U];
+            double pv[U];
+            real_t b[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                pc[u] = 0;
+                pv[u] = 0.0;
+#pragma unroll
+                for (int v = 0; v < VEC; v++) b[u][v] = 0;
             }
-            for (int s = sbeg; s < send; s += U) {                  // sbeg, send are wave-uniform
-                int pc[U];
-                double pv[U];
-                real_t b[U][VEC];
-                // lane 8g+u holds bundle g's entry of step u: broadcast lane u of every 8-lane group (two DPP moves
-                // per dword on the VALU; the first version used ds_bpermute and kept the LDS pipe 50 % busy)
-                plan_bcast<0>(pcw, pvw, pc[0], pv[0]); plan_bcast<1>(pcw, pvw, pc[1], pv[1]);
-                plan_bcast<2>(pcw, pvw, pc[2], pv[2]); plan_bcast<3>(pcw, pvw, pc[3], pv[3]);
-                plan_bcast<4>(pcw, pvw, pc[4], pv[4]); plan_bcast<5>(pcw, pvw, pc[5], pv[5]);
-                plan_bcast<6>(pcw, pvw, pc[6], pv[6]); plan_bcast<7>(pcw, pvw, pc[7], pv[7]);
+            // consume step u of the batch in (pc, pv, b): row switch -> fold the finished row into LDS, then FMA
+            auto consume = [&](int u) {
+                const int lrow = (int)((unsigned)pc[u] >> PLAN_ROW_SHIFT);
+                if (lrow != cur) {
+                    real_t *d = my_rows + cur * W;
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const unsigned off = (pc[u] >= 0 ? ((unsigned)(pc[u] & ((1 << PLAN_ROW_SHIFT) - 1)) * (unsigned)(W * sizeof(real_t))) : 0u)
-                                         + lane_off;
-                    vload<real_t, VEC>(b[u], reinterpret_cast<const real_t *>(Bbase + off));
+                    for (int v = 0; v < VEC; v++) { d[v] += acc[v]; acc[v] = 0; }
+                    cur = lrow;
                 }
-                const int sn = s + U;
-                {                                                   // prefetch the next batch of plan slots
-                    const long long e = (long long)sn * 8 + lane;
-                    pcwn = -1;
-                    if (e < slot_end) { pcwn = pcol[e]; pvwn = pval[e]; }
-                }
+                const real_t a = (real_t)pv[u];
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    if (pc[u] >= 0) {
-                        const int lrow = pc[u] >> PLAN_ROW_SHIFT;
-                        if (lrow != cur) {
-                            if (cur >= 0) {
-                                real_t *d = my_rows + cur * W;
+                for (int v = 0; v < VEC; v++) acc[v] = mx_fma(a, b[u][v], acc[v]);
+                // keep the reload BEHIND the FMAs that read the old line (and the FMAs where they are): letting the two
+                // cross renames b[u] and ends in a register copy at the back edge that waits for every load in flight
 #pragma unroll
-                                for (int v = 0; v < VEC; v++) { d[v] += acc[v]; acc[v] = 0; }
-                            }
-                            cur = lrow;
+                for (int v = 0; v < VEC; v++) asm volatile("" : "+v"(acc[v]));
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (send > sbeg) {
+                load_chunk(sbeg, rc, rv);
+                // the first chunk has to be there before anything can start; with it complete at loop entry the
+                // compiler's vmcnt bookkeeping is exact on both edges of the loop
+#pragma unroll
+                for (int k = 0; k < PLAN_CHUNK; k++) asm volatile("" : "+v"(rc[k]), "+v"(rv[k]));
+            }
+            // Consumption lags one batch behind the broadcast + B-line load: while batch t is consumed step by step,
+            // the line of the same step of batch t+1 is requested into the registers the FMA just released, so 8
+            // B-line loads per wavefront are in flight all the time.  The first pass consumes the no-op batch set up
+            // above, the last batch is consumed after the loop.
+            for (int s = sbeg; s < send; s += U * PLAN_CHUNK) {      // sbeg, send are wave-uniform
+                load_chunk(s + U * PLAN_CHUNK, rn, rvn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < PLAN_CHUNK; k++) {
+#define MX_PLAN_STEP(UU)                                                                                              \
+                    consume(UU);                                                                                      \
+                    plan_bcast<UU>(rc[k], rv[k], pc[UU], pv[UU]);                                                     \
+                    vload<real_t, VEC>(b[UU], reinterpret_cast<const real_t *>(Bbase + b_offset(pc[UU])));            \
+                    __builtin_amdgcn_sched_barrier(0);
+                    MX_PLAN_STEP(0) MX_PLAN_STEP(1) MX_PLAN_STEP(2) MX_PLAN_STEP(3)
+                    MX_PLAN_STEP(4) MX_PLAN_STEP(5) MX_PLAN_STEP(6) MX_PLAN_STEP(7)
+#undef MX_PLAN_STEP
+                    if (sync_mode > 0) {
+                        const int sn = s + U * k;                   // steps consumed so far
+                        while (p < npanels - 1 && sn >= next_b) {   // the stream moved into the next panel
+                            p++;
+                            __syncthreads();
+                            next_b = __builtin_amdgcn_readfirstlane(p < npanels - 1 ? step_off[(size_t)oct * npanels + p + 1] : send);
                         }
-                        const real_t a = (real_t)pv[u];
+                    }
+                }
 #pragma unroll
-                        for (int v = 0; v < VEC; v++) acc[v] = mx_fma(a, b[u][v], acc[v]);
-                    }
-                }
-                pcw = pcwn; pvw = pvwn;
-                if (sync_mode > 0) {
-                    while (p < npanels - 1 && sn >= next_b) {       // the stream moved into the next panel
-                        p++;
-                        __syncthreads();
-                        next_b = p < npanels - 1 ? step_off[(size_t)oct * npanels + p + 1] : send;
-                    }
-                }
+                for (int k = 0; k < PLAN_CHUNK; k++) { rc[k] = rn[k]; rv[k] = rvn[k]; }
             }
-            if (cur >= 0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) consume(u);
+            {
                 real_t *d = my_rows + cur * W;
 #pragma unroll
                 for (int v = 0; v < VEC; v++) d[v] += acc[v];
@@ -968,12 +1026,11 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     MX_REQUIRE(total >= 0 && total * 8 <= (long long)INT_MAX * 4LL, "spmm plan: too many steps (%lld)", total);
     MX_REQUIRE(total <= (long long)INT_MAX, "spmm plan: step offsets exceed int32");
     pl->total_steps = total;
-    const size_t slots = (size_t)(total > 0 ? total : 1) * 8;
+    const size_t slots = (size_t)total * 8 + PLAN_TAIL_SLOTS;
     if (grow((void **)&pl->pcol, &pl->pcol_cap, slots * 4)) return 1;
     if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
-    MX_HIP(hipMemsetAsync(pl->pcol, 0xFF, slots * 4, st));                       // -1 = padding slot
     hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       values, oct_off, bpo, pl->pcol, pl->pval, pl->noct);
+                       values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K);
     MX_LAUNCH_CHECK();
     return 0;
 }
@@ -1008,14 +1065,14 @@ static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, 
     constexpr int W = SLAB_GROUP * VEC;
     const int m = pl->m, K = pl->K;
     const int nslabs = (int)ceil_div(n, W);
-    const int ngens = (int)ceil_div(m, PLAN_WG_ROWS);
-    // slab-major copy of B
-    real_t *Bp = (real_t *)slab_pack_workspace((size_t)nslabs * (size_t)K * W * sizeof(real_t));
+    // slab-major copy of B with one extra all-zero row (index K) per slab: the plan's padding slots point at it
+    const int Kp = K + 1;
+    real_t *Bp = (real_t *)slab_pack_workspace((size_t)nslabs * (size_t)Kp * W * sizeof(real_t));
     MX_REQUIRE(Bp, "spmm plan: cannot allocate the packed copy of B");
     {
-        const long long pieces = (long long)K * nslabs * SLAB_GROUP;
+        const long long pieces = (long long)Kp * nslabs * SLAB_GROUP;
         const unsigned gsz = (unsigned)(ceil_div(pieces, 256) < 8192 ? ceil_div(pieces, 256) : 8192);
-        hipLaunchKernelGGL((repack_slabs_kernel<real_t>), dim3(gsz), dim3(256), 0, st, K, n, nslabs, B, ldb, Bp);
+        hipLaunchKernelGGL((repack_slabs_kernel<real_t>), dim3(gsz), dim3(256), 0, st, K, Kp, n, nslabs, B, ldb, Bp);
         MX_LAUNCH_CHECK();
     }
     int dev = 0, cus = 256;
@@ -1023,7 +1080,9 @@ static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, 
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    wg_per_cu = 1;                      // one 1024-thread workgroup (128 KiB of LDS) per CU
+    if (wg_per_cu != 1 && wg_per_cu != 2 && wg_per_cu != 4) wg_per_cu = PLAN_DEFAULT_WG_PER_CU;
+    const int waves = 16 / wg_per_cu;
+    const int ngens = (int)ceil_div(m, PLAN_OCT_ROWS * waves);
     long long grid = (long long)cus * wg_per_cu;
     const long long total = (long long)nslabs * ngens;
     if (grid > total + 7) grid = total + 7;
@@ -1032,16 +1091,17 @@ static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, 
     unsigned *sync = slab_sync_workspace();
     if (!sync || pl->npanels <= 1) sync_mode = 0;
     if (sync_mode) MX_HIP(hipMemsetAsync(sync, 0, 8 * 64 * sizeof(unsigned), st));
-    const int c_vec_ok = 0;
     kt_begin(st);
-    if (colmajor)
-        hipLaunchKernelGGL((spmm_plan_kernel<real_t, true>), dim3((unsigned)grid), dim3(PLAN_BLOCK), 0, st, m, n,
-                           pl->npanels, pl->step_off, pl->pcol, pl->pval, Bp, (size_t)K * W, C, ldc, nslabs, ngens,
-                           pl->noct, c_vec_ok, sync, sync_mode);
-    else
-        hipLaunchKernelGGL((spmm_plan_kernel<real_t, false>), dim3((unsigned)grid), dim3(PLAN_BLOCK), 0, st, m, n,
-                           pl->npanels, pl->step_off, pl->pcol, pl->pval, Bp, (size_t)K * W, C, ldc, nslabs, ngens,
-                           pl->noct, c_vec_ok, sync, sync_mode);
+#define MX_PLAN_LAUNCH(CM, WV)                                                                                           \
+    hipLaunchKernelGGL((spmm_plan_kernel<real_t, CM, WV>), dim3((unsigned)grid), dim3(WV * 64), 0, st, m, n, pl->npanels, \
+                       pl->step_off, pl->pcol, pl->pval, Bp, (size_t)Kp * W, C, ldc, nslabs, ngens, pl->noct, K,         \
+                       sync, sync_mode)
+    if (colmajor) {
+        if (waves == 16) MX_PLAN_LAUNCH(true, 16); else if (waves == 8) MX_PLAN_LAUNCH(true, 8); else MX_PLAN_LAUNCH(true, 4);
+    } else {
+        if (waves == 16) MX_PLAN_LAUNCH(false, 16); else if (waves == 8) MX_PLAN_LAUNCH(false, 8); else MX_PLAN_LAUNCH(false, 4);
+    }
+#undef MX_PLAN_LAUNCH
     kt_end(st);
     MX_LAUNCH_CHECK();
     return 0;

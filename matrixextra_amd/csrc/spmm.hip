@@ -767,6 +767,23 @@ __device__ __forceinline__ void plan_bcast(int pcw, double pvw, int &pc, double 
     pv = b.d;
 }
 
+// Fold a finished row's partial sums into its LDS accumulators.  Only this lane ever touches these words and one
+// wavefront's LDS operations execute in order, so both forms are the same sequence of additions.  f64: two
+// fire-and-forget ds_add_f64 (no return value, nothing to wait for; the read-modify-write cost an LDS round trip on
+// ~70 % of the steps).  f32: read-modify-write of one 16-byte word (four ds_add_f32 measured 2.4x slower overall).
+template <int VEC>
+__device__ __forceinline__ void lds_fold(double *d, double (&acc)[VEC])
+{
+#pragma unroll
+    for (int v = 0; v < VEC; v++) __hip_atomic_fetch_add(d + v, acc[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int VEC>
+__device__ __forceinline__ void lds_fold(float *d, float (&acc)[VEC])
+{
+#pragma unroll
+    for (int v = 0; v < VEC; v++) d[v] += acc[v];
+}
+
 // main kernel
 template <typename real_t, bool COLMAJOR, int PLAN_WAVES>
 __global__ __launch_bounds__(PLAN_WAVES * 64)
@@ -866,9 +883,9 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             auto consume = [&](int u) {
                 const int lrow = (int)((unsigned)pc[u] >> PLAN_ROW_SHIFT);
                 if (lrow != cur) {
-                    real_t *d = my_rows + cur * W;
+                    lds_fold<VEC>(my_rows + cur * W, acc);
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) { d[v] += acc[v]; acc[v] = 0; }
+                    for (int v = 0; v < VEC; v++) acc[v] = 0;
                     cur = lrow;
                 }
                 const real_t a = (real_t)pv[u];
@@ -918,11 +935,7 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             }
 #pragma unroll
             for (int u = 0; u < U; u++) consume(u);
-            {
-                real_t *d = my_rows + cur * W;
-#pragma unroll
-                for (int v = 0; v < VEC; v++) d[v] += acc[v];
-            }
+            lds_fold<VEC>(my_rows + cur * W, acc);
             if (sync_mode > 0)
                 for (; p < npanels - 1; p++) __syncthreads();           // every wave meets npanels-1 times per generation
         }
@@ -991,7 +1004,7 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
                       const double *values, int npanels, hipStream_t st)
 {
     MX_REQUIRE(K < (1 << 25), "spmm plan: more than 2^25 columns (32-bit slab offsets)");
-    if (npanels <= 0) npanels = pick_panels(K, (size_t)3328 << 10);     // measured: 3.2 MB panels (P=4) beat 2.6 MB (P=5)
+    if (npanels <= 0) npanels = pick_panels(K, (size_t)2600 << 10);     // measured (cfg2): kernel alone is best at 1.6 MB panels (P=8), kernel + plan build at 2.6 MB (P=5)
     if (npanels > PLAN_MAXP) npanels = PLAN_MAXP;
     pl->m = m; pl->K = K; pl->npanels = npanels;
     pl->panel_cols = (int)ceil_div(K > 0 ? K : 1, npanels);

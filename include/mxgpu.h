@@ -236,6 +236,17 @@ int mxd_csr_by_dense_elemwise(int m, int64_t nnz, const int32_t *indptr, const i
                               const void *values, const void *dense_colmajor, int kind, void *values_out,
                               void *stream);
 
+/* CSR (op) dense vector with R's recycling (multiply_csr_by_dvec_no_NAs<>, src/operators.cpp:1604-2140): a
+ * values-only transform, out[k] = values[k] op dvec[(row + col*m) mod dvec_len] (`recyle_pos`, :1478; the reference's
+ * four length branches :1640,1773,1870,2033 all reduce to it).  op: R's * ^ / %% %/% on f64 values with the sparse
+ * matrix on the left (x_is_lhs) or right, or R's 3-valued & on int32 logicals (MX_DV_LOGICAL_AND; values, dvec and out
+ * int32).  ^ %% %/% follow R_pow / R_modulus / R_intdiv (:1482-1601).  nnz < 0 = unknown (launch shape only). */
+typedef enum { MX_DV_MULTIPLY = 0, MX_DV_POWERTO = 1, MX_DV_DIVIDE = 2, MX_DV_DIVREST = 3, MX_DV_INTDIV = 4,
+               MX_DV_LOGICAL_AND = 5 } mx_dvec_op;
+int mxd_csr_by_dvec(int m, int ncols, int64_t nnz, const int32_t *indptr, const int32_t *indices,
+                    const void *values, const void *dvec, int64_t dvec_len, int op, int x_is_lhs,
+                    void *values_out, void *stream);
+
 /* check_is_seq / check_is_rev_seq (src/slice.cpp:25-47) on a device vector.
  * *flag_host receives 0/1 after an internal stream sync. */
 int mxd_check_is_seq(const int32_t *idx, int64_t n, int reversed, int32_t *workspace4,
@@ -368,6 +379,17 @@ int mx_matmul_csr_svec(const int32_t *X_indptr, const int32_t *X_indices, const 
  * dense_mat column-major nrows x ncols; values_out has nnz entries (f64, or int32 for kind 4). */
 int mx_multiply_csr_by_dense_elemwise(const int32_t *indptr, const int32_t *indices, const void *values, int nrows,
                                       const void *dense_mat, int64_t ncols, int kind, void *values_out);
+/* multiply_csr_by_dvec_no_NAs_numeric  src/operators.cpp:2142-2175: exactly one of the five flags is set (as the R
+ * caller passes them, R/operators.R:1134-1137); values_out f64[nnz].  The structure-changing NA route
+ * (multiply_csr_by_dvec_with_NAs, :2258-) is not provided. */
+int mx_multiply_csr_by_dvec_no_NAs_numeric(const int32_t *indptr, const int32_t *indices, const double *values,
+                                           int nrows, const double *dvec, int64_t dvec_len, int ncols, int multiply,
+                                           int powerto, int divide, int divrest, int intdiv, int X_is_LHS,
+                                           double *values_out);
+/* logicaland_csr_by_dvec_internal  src/operators.cpp:2177-2200: R logicals (int32), values_out int32[nnz] */
+int mx_logicaland_csr_by_dvec_internal(const int32_t *indptr, const int32_t *indices, const int32_t *values,
+                                       int nrows, const int32_t *dvec, int64_t dvec_len, int ncols,
+                                       int32_t *values_out);
 /* cbind_csr_{numeric,logical,binary}  src/cbind.cpp:101-157 (value_dtype MX_F64 / MX_LGL / MX_NONE) */
 int mx_cbind_csr_begin(const int32_t *X_indptr, int nrows_X, const int32_t *X_indices, const void *X_values,
                        int64_t n_values_X, const int32_t *Y_indptr, int nrows_Y,

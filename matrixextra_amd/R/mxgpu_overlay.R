@@ -31,7 +31,9 @@
     "copy_csr_rows_col_seq_numeric", "copy_csr_rows_col_seq_logical", "copy_csr_rows_col_seq_binary",
     "copy_csr_arbitrary_numeric", "copy_csr_arbitrary_logical", "copy_csr_arbitrary_binary",
     "reverse_rows_numeric", "reverse_rows_logical", "reverse_rows_binary",
-    "reverse_columns_inplace_numeric", "reverse_columns_inplace_logical", "reverse_columns_inplace_binary"
+    "reverse_columns_inplace_numeric", "reverse_columns_inplace_logical", "reverse_columns_inplace_binary",
+    ## rank 4: values-only CSR (op) vector
+    "multiply_csr_by_dvec_no_NAs_numeric", "logicaland_csr_by_dvec_internal"
 )
 
 mxgpu_enable <- function(shim_path, min_nnz = 0L) {

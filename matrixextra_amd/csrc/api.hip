@@ -585,6 +585,49 @@ int mx_multiply_csr_by_dense_elemwise(const int32_t *indptr, const int32_t *indi
     return 0;
 }
 
+// ---- CSR (op) dense vector (§8f rank 4) ----------------------------------------------------------------------
+static int csr_by_dvec_export(const int32_t *indptr, const int32_t *indices, const void *values, int nrows,
+                              const void *dvec, int64_t dvec_len, int ncols, int op, int lhs, void *values_out)
+{
+    MX_REQUIRE(nrows >= 0 && ncols >= 0 && dvec_len >= 0, "csr (op) vector: negative size");
+    if (nrows == 0) return 0;
+    const size_t eb = op == MX_DV_LOGICAL_AND ? 4 : 8;
+    Csr A;
+    if (A.upload(indptr, indices, values, nrows, eb)) return 1;
+    if (A.nnz == 0) return 0;
+    MX_REQUIRE(dvec_len > 0, "csr (op) vector: empty vector");
+    DevBuf D, o;
+    if (D.upload(dvec, eb * (size_t)dvec_len)) return 1;
+    if (o.alloc(eb * (size_t)A.nnz)) return 1;
+    if (mxd_csr_by_dvec(nrows, ncols, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, D.p, dvec_len, op, lhs, o.p, nullptr))
+        return 1;
+    MX_HIP(hipMemcpy(values_out, o.p, eb * (size_t)A.nnz, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mx_multiply_csr_by_dvec_no_NAs_numeric(const int32_t *indptr, const int32_t *indices, const double *values,
+                                           int nrows, const double *dvec, int64_t dvec_len, int ncols, int multiply,
+                                           int powerto, int divide, int divrest, int intdiv, int X_is_LHS,
+                                           double *values_out)
+{
+    // same precedence as the reference's if/else chain (operators.cpp:1620-1632)
+    int op;
+    if (multiply) op = MX_DV_MULTIPLY;
+    else if (powerto) op = MX_DV_POWERTO;
+    else if (divide) op = MX_DV_DIVIDE;
+    else if (divrest) op = MX_DV_DIVREST;
+    else if (intdiv) op = MX_DV_INTDIV;
+    else return set_error("Internal error. Please file an issue in GitHub.");        // throw_internal_err()
+    return csr_by_dvec_export(indptr, indices, values, nrows, dvec, dvec_len, ncols, op, X_is_LHS, values_out);
+}
+
+int mx_logicaland_csr_by_dvec_internal(const int32_t *indptr, const int32_t *indices, const int32_t *values,
+                                       int nrows, const int32_t *dvec, int64_t dvec_len, int ncols,
+                                       int32_t *values_out)
+{
+    return csr_by_dvec_export(indptr, indices, values, nrows, dvec, dvec_len, ncols, MX_DV_LOGICAL_AND, 1, values_out);
+}
+
 // ---- cbind / rbind (§8f rank 3) ----------------------------------------------------------------------------
 int mx_cbind_csr_begin(const int32_t *Xp, int nX, const int32_t *Xj, const void *Xx, int64_t nvX, const int32_t *Yp,
                        int nY, const int32_t *Yj, const void *Yx, int64_t nvY, int value_dtype, mx_result **res_out,

@@ -358,6 +358,31 @@ SEXP _MatrixExtra_check_is_rev_seq(SEXP idx)
     return Rf_ScalarLogical(r);
 }
 
+// values-only CSR (op) vector  (src/operators.cpp:2142-2200; glue src/RcppExports.cpp `_MatrixExtra_multiply_csr_by_dvec_no_NAs_numeric`, 11 arguments)
+SEXP _MatrixExtra_multiply_csr_by_dvec_no_NAs_numeric(SEXP p_, SEXP j_, SEXP x_, SEXP dvec, SEXP ncols, SEXP multiply,
+                                                      SEXP powerto, SEXP divide, SEXP divrest, SEXP intdiv, SEXP lhs)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); x_ = as_type(x_, REALSXP, p); dvec = as_type(dvec, REALSXP, p);
+    SEXP out = p(Rf_allocVector(REALSXP, XLENGTH(x_)));
+    if (mx_multiply_csr_by_dvec_no_NAs_numeric(INTEGER(p_), INTEGER(j_), REAL(x_), (int)XLENGTH(p_) - 1, REAL(dvec),
+                                               (int64_t)XLENGTH(dvec), Rf_asInteger(ncols), Rf_asLogical(multiply),
+                                               Rf_asLogical(powerto), Rf_asLogical(divide), Rf_asLogical(divrest),
+                                               Rf_asLogical(intdiv), Rf_asLogical(lhs), REAL(out)))
+        fail();
+    return out;
+}
+SEXP _MatrixExtra_logicaland_csr_by_dvec_internal(SEXP p_, SEXP j_, SEXP x_, SEXP dvec, SEXP ncols)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); x_ = as_type(x_, LGLSXP, p); dvec = as_type(dvec, LGLSXP, p);
+    SEXP out = p(Rf_allocVector(LGLSXP, XLENGTH(x_)));
+    if (mx_logicaland_csr_by_dvec_internal(INTEGER(p_), INTEGER(j_), LOGICAL(x_), (int)XLENGTH(p_) - 1, LOGICAL(dvec),
+                                           (int64_t)XLENGTH(dvec), Rf_asInteger(ncols), LOGICAL(out)))
+        fail();
+    return out;
+}
+
 #define MX_ENTRY(name, n) {"_MatrixExtra_" #name, (DL_FUNC)&_MatrixExtra_##name, n}
 static const R_CallMethodDef mxgpu_call_entries[] = {
     MX_ENTRY(matmul_dense_csc_numeric, 5), MX_ENTRY(matmul_dense_csc_float32, 5),
@@ -375,6 +400,7 @@ static const R_CallMethodDef mxgpu_call_entries[] = {
     MX_ENTRY(reverse_rows_numeric, 3), MX_ENTRY(reverse_rows_logical, 3), MX_ENTRY(reverse_rows_binary, 2),
     MX_ENTRY(reverse_columns_inplace_numeric, 4), MX_ENTRY(reverse_columns_inplace_logical, 4),
     MX_ENTRY(reverse_columns_inplace_binary, 4),
+    MX_ENTRY(multiply_csr_by_dvec_no_NAs_numeric, 11), MX_ENTRY(logicaland_csr_by_dvec_internal, 5),
     {NULL, NULL, 0}
 };
 

@@ -509,3 +509,28 @@ def sort_sparse_indices_inplace(indptr, indices, values=None):
     else:
         raise TypeError("values must be float64 or int32 (R logical)")
     check(_lib.load().mx_sort_sparse_indices(ptr(p), ptr(indices), ptr(values), C.c_int(vd), C.c_int(p.size - 1)))
+
+
+def multiply_csr_by_dvec_no_NAs_numeric(indptr, indices, values, dvec, ncols, multiply, powerto, divide, divrest,
+                                        intdiv, X_is_LHS):
+    """src/operators.cpp:2142-2175 (R/RcppExports.R:480-482): values-only `X op v` / `v op X` with R's recycling."""
+    p, j = _i32(indptr), _i32(indices)
+    xv = np.ascontiguousarray(values, dtype=np.float64)
+    dv = np.ascontiguousarray(dvec, dtype=np.float64).reshape(-1)
+    out = np.empty(xv.size, dtype=np.float64)
+    check(_lib.load().mx_multiply_csr_by_dvec_no_NAs_numeric(
+        ptr(p), ptr(j), ptr(xv), C.c_int(p.size - 1), ptr(dv), C.c_int64(dv.size), C.c_int(int(ncols)),
+        C.c_int(bool(multiply)), C.c_int(bool(powerto)), C.c_int(bool(divide)), C.c_int(bool(divrest)),
+        C.c_int(bool(intdiv)), C.c_int(bool(X_is_LHS)), ptr(out)))
+    return out
+
+
+def logicaland_csr_by_dvec_internal(indptr, indices, values, dvec, ncols):
+    """src/operators.cpp:2177-2200 (R/RcppExports.R:484-486): R logicals in, R logicals out."""
+    p, j = _i32(indptr), _i32(indices)
+    xv = np.ascontiguousarray(values, dtype=np.int32)
+    dv = np.ascontiguousarray(dvec, dtype=np.int32).reshape(-1)
+    out = np.empty(xv.size, dtype=np.int32)
+    check(_lib.load().mx_logicaland_csr_by_dvec_internal(ptr(p), ptr(j), ptr(xv), C.c_int(p.size - 1), ptr(dv),
+                                                         C.c_int64(dv.size), C.c_int(int(ncols)), ptr(out)))
+    return out

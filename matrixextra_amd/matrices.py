@@ -111,13 +111,53 @@ class RsparseMatrix:
         from . import operators
         return operators.add_csr_matrices(self, other, True)
 
-    def __mul__(self, other):                         # R/operators.R:147
+    def __mul__(self, other):                         # R/operators.R:147 (CSR), :1217-1260 (vector)
         from . import operators
+        if not isinstance(other, RsparseMatrix):
+            return operators.csr_op_vector(self, other, "*")
         return operators.multiply_csr_by_csr(self, other, logical=False)
 
-    def __and__(self, other):                         # R/operators.R:183
+    def __rmul__(self, other):                        # v * X  (multiplication commutes: R/operators.R:1155-1161)
         from . import operators
+        return operators.csr_op_vector(self, other, "*")
+
+    def __and__(self, other):                         # R/operators.R:183 (CSR), :1163-1169 (vector)
+        from . import operators
+        if not isinstance(other, RsparseMatrix):
+            return operators.csr_op_vector(self, other, "&")
         return operators.multiply_csr_by_csr(self, other, logical=True)
+
+    def __truediv__(self, other):                     # X / v
+        from . import operators
+        return operators.csr_op_vector(self, other, "/")
+
+    def __rtruediv__(self, other):                    # v / X
+        from . import operators
+        return operators.csr_op_vector(self, other, "/", X_is_LHS=False)
+
+    def __pow__(self, other):                         # X ^ v   R/operators.R:1171-1177
+        from . import operators
+        return operators.csr_op_vector(self, other, "^")
+
+    def __rpow__(self, other):
+        from . import operators
+        return operators.csr_op_vector(self, other, "^", X_is_LHS=False)
+
+    def __mod__(self, other):                         # X %% v
+        from . import operators
+        return operators.csr_op_vector(self, other, "%%")
+
+    def __rmod__(self, other):
+        from . import operators
+        return operators.csr_op_vector(self, other, "%%", X_is_LHS=False)
+
+    def __floordiv__(self, other):                    # X %/% v
+        from . import operators
+        return operators.csr_op_vector(self, other, "%/%")
+
+    def __rfloordiv__(self, other):
+        from . import operators
+        return operators.csr_op_vector(self, other, "%/%", X_is_LHS=False)
 
     def __or__(self, other):                          # R/operators.R:889
         from . import operators

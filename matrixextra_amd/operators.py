@@ -1,6 +1,9 @@
 """Host-side mirror of the CSR (+) CSR part of R/operators.R
-(multiply_csr_by_csr :43-79, add_csr_matrices_internal :713-776 and their registrations)."""
+(multiply_csr_by_csr :43-79, add_csr_matrices_internal :713-776 and their registrations) and of
+`CSR op vector` (multiply_csr_by_dvec_elemwise_internal :950-1153)."""
 from __future__ import annotations
+
+import warnings
 
 import numpy as np
 
@@ -91,3 +94,80 @@ def logicalor_csr_matrices(e1, e2):
 def xor_csr_matrices(e1, e2):
     """R/operators.R:786-788."""
     return add_csr_matrices_internal(e1, e2, False, False, True)
+
+
+_NOT_ACCELERATED = ("This combination takes the reference's NA / dense route "
+                    "(multiply_csr_by_dvec_with_NAs or a CsparseMatrix fallback, R/operators.R:%s), "
+                    "which is not on the accelerated path.")
+
+
+def _as_logical(v):
+    """as.logical() for a numeric / bool vector -> R logical (int32 with NA_LOGICAL)."""
+    v = np.asarray(v)
+    if v.dtype == np.int32:
+        return v
+    if v.dtype.kind == "f":
+        return np.where(np.isnan(v), np.int32(-2147483648), (v != 0).astype(np.int32)).astype(np.int32)
+    return (v != 0).astype(np.int32)
+
+
+def multiply_csr_by_dvec_elemwise_internal(e1, e2, logical=False, X_is_LHS=True, op="*"):
+    """R/operators.R:950-1153 for RsparseMatrix `e1`: `e1 op e2` (or `e2 op e1` when X_is_LHS is false) with a dense
+    vector (or a same-shape dense matrix read as a vector), R's recycling, values-only result.  The routes the
+    reference sends through multiply_csr_by_dvec_with_NAs or through a CsparseMatrix (vector with NA, division by
+    zero, multiplication by Inf, `v op X` for ^ / %% %/% while NAs are kept) raise: they stay on the CPU."""
+    e2 = np.asarray(e2)
+    if e2.ndim == 2:                                                          # :952-959
+        if e1.Dim[0] != e2.shape[0] or e2.shape[1] != e2.shape[1]:            # (sic: the reference compares ncol(e2) with itself)
+            stop("Matrix dimensions do not match. Cannot perform the opertion.")
+        e2 = e2.reshape(-1, order="F")
+    e2 = e2.reshape(-1)
+    if e2.size == 0:                                                          # :961-966
+        return np.zeros(0, dtype=np.int32 if logical else np.float64)
+    if e2.size > e1.Dim[0] * e1.Dim[1]:
+        stop("Vector to multiply with has more entries than matrix.")
+    keep_NAs = not bool(options.get("MatrixExtra.ignore_na", False))
+    if (not X_is_LHS) and keep_NAs and op in ("^", "/", "%%", "%/%"):         # :973-978
+        stop(_NOT_ACCELERATED % "973-978")
+    check_valid_matrix(e1)
+    e2f = e2.astype(np.float64) if e2.dtype != np.int32 else np.where(e2 == np.int32(-2147483648), np.nan, e2.astype(np.float64))
+    take_route_NAs = (not logical) and keep_NAs and (
+        bool(np.isnan(e2f).any())
+        or (op in ("^", "/", "%%", "%/%") and bool((e2f == 0).any()))
+        or (op == "*" and bool(np.isinf(e2f).any()))
+        or (op == "^" and bool((e2f < 0).any())))                             # :981-988
+    if take_route_NAs:
+        stop(_NOT_ACCELERATED % "981-1131")
+    e2 = _as_logical(e2) if logical else e2f
+    e1 = as_csr_matrix(e1, logical=logical)                                   # :1020-1029
+    out = type(e1).__new__(type(e1))
+    out.p, out.j, out.Dim, out.Dimnames = e1.p, e1.j, e1.Dim, list(e1.Dimnames)
+    if e2.size == 1:                                                          # :1031-1108
+        if logical:
+            if e2[0] == np.int32(-2147483648):
+                out.x = np.where(e1.x == np.int32(-2147483648), np.int32(-2147483648), np.int32(0)).astype(np.int32)
+                return out
+            if e2[0] == 0:
+                res = lgRMatrix(np.zeros(e1.Dim[0] + 1, dtype=np.int32), np.zeros(0, dtype=np.int32),
+                                np.zeros(0, dtype=np.int32), e1.Dim, e1.Dimnames)
+                return res
+            return e1
+        if op in ("/", "%%", "%/%") and e2[0] == 0 and X_is_LHS:
+            warnings.warn("Warning: division by zero.")
+        if op == "^" and (not X_is_LHS) and (e2[0] == 1 or e2[0] == 0):
+            stop(_NOT_ACCELERATED % "1091-1095")
+    elif e1.Dim[0] % e2.size != 0:                                            # :1114-1115
+        warnings.warn("Number of elements in vector is not a multiple of matrix dimension.")
+    if logical:
+        out.x = exports.logicaland_csr_by_dvec_internal(e1.p, e1.j, e1.x, e2, e1.Dim[1])
+    else:
+        out.x = exports.multiply_csr_by_dvec_no_NAs_numeric(e1.p, e1.j, e1.x, e2, e1.Dim[1], op == "*", op == "^",
+                                                            op == "/", op == "%%", op == "%/%", X_is_LHS)
+    return out
+
+
+def csr_op_vector(e1, e2, op, X_is_LHS=True):
+    """`X * v`, `X / v`, `X ^ v`, `X %% v`, `X %/% v`, `X & v` and their mirrored forms (R/operators.R:1155-1215)."""
+    if op == "&":
+        return multiply_csr_by_dvec_elemwise_internal(e1, e2, logical=True)
+    return multiply_csr_by_dvec_elemwise_internal(e1, e2, logical=False, X_is_LHS=X_is_LHS, op=op)

@@ -609,3 +609,79 @@ void mxo_multiply_csr_by_dense_elemwise(int nrows, const int *indptr, const int 
         }
     }
 }
+
+/* ---- CSR (op) dense vector, values only (operators.cpp:1604-2200) ------------ */
+/* R's arithmetic as the reference restates it: R_intdiv :1500-1513, R_modulus :1526-1540 (both with a long double
+ * intermediate, as compiled on x86), R_pow = R's C API function whose body is quoted at :1555-1601. */
+#include <float.h>
+static double r_modulus_o(double x1, double x2)
+{
+    if (x2 == 0.0) return NAN;
+    if (fabs(x2) * LDBL_EPSILON > 1 && isfinite(x1) && fabs(x1) <= fabs(x2))
+        return (fabs(x1) == fabs(x2)) ? 0 : (((x1 < 0 && x2 > 0) || (x2 < 0 && x1 > 0)) ? x1 + x2 : x1);
+    double q = x1 / x2;
+    long double tmp = (long double)x1 - floor(q) * (long double)x2;
+    return (double)(tmp - floorl(tmp / x2) * x2);
+}
+static double r_intdiv_o(double x1, double x2)
+{
+    double q = x1 / x2;
+    if (x2 == 0.0 || fabs(q) * LDBL_EPSILON > 1 || !isfinite(q)) return q;
+    if (fabs(q) < 1) return (q < 0) ? -1 : (((x1 < 0 && x2 > 0) || (x1 > 0 && x2 < 0)) ? -1 : 0);
+    long double tmp = (long double)x1 - floor(q) * (long double)x2;
+    return (double)(floor(q) + floorl(tmp / x2));
+}
+static double r_pow_o(double x, double y)
+{
+    if (y == 2.0) return x * x;
+    if (x == 1. || y == 0.) return 1.;
+    if (x == 0.) {
+        if (y > 0.) return 0.;
+        else if (y < 0) return INFINITY;
+        else return y;
+    }
+    if (isfinite(x) && isfinite(y)) return pow(x, y);
+    if (isnan(x) || isnan(y)) return x + y;
+    if (!isfinite(x)) {
+        if (x > 0) return (y < 0.) ? 0. : INFINITY;
+        else if (isfinite(y) && y == floor(y)) return (y < 0.) ? 0. : (r_modulus_o(y, 2.) != 0 ? x : -x);
+    }
+    if (!isfinite(y)) {
+        if (x >= 0) {
+            if (y > 0) return (x >= 1) ? INFINITY : 0.;
+            else return (x < 1) ? INFINITY : 0.;
+        }
+    }
+    return NAN;
+}
+/* op: 0 multiply, 1 powerto, 2 divide, 3 divrest, 4 intdiv, 5 logical AND (int32 values / dvec / out).
+ * The four length branches of the reference (:1640 == nrows, :1773 >= nrows*ncols, :1870 divides nrows, :2033 general)
+ * are kept as written, not folded into one formula, so that the device's single formula is checked against them. */
+void mxo_csr_by_dvec(int nrows, int ncols, const int *indptr, const int *indices, const void *values,
+                     const void *dvec, size_t len, int op, int x_is_lhs, void *values_out)
+{
+    const size_t nr = (size_t)nrows;
+    for (size_t row = 0; row < nr; row++) {
+        for (int ix = indptr[row]; ix < indptr[row + 1]; ix++) {
+            size_t at;
+            if (len == nr) at = row;
+            else if ((unsigned long long)len >= (unsigned long long)nr * (unsigned long long)ncols) at = row + (size_t)indices[ix] * nr;
+            else if (len < nr && (nr % len) == 0) at = row % len;
+            else at = (size_t)(((unsigned long long)row + (unsigned long long)indices[ix] * (unsigned long long)nr) % (unsigned long long)len);
+            if (op == 5) {
+                ((int *)values_out)[ix] = r_and(((const int *)values)[ix], ((const int *)dvec)[at]);
+                continue;
+            }
+            const double x = ((const double *)values)[ix], d = ((const double *)dvec)[at];
+            double o;
+            switch (op) {
+                case 0: o = x * d; break;
+                case 2: o = x_is_lhs ? x / d : d / x; break;
+                case 3: o = x_is_lhs ? r_modulus_o(x, d) : r_modulus_o(d, x); break;
+                case 4: o = x_is_lhs ? r_intdiv_o(x, d) : r_intdiv_o(d, x); break;
+                default: o = x_is_lhs ? r_pow_o(x, d) : r_pow_o(d, x); break;
+            }
+            ((double *)values_out)[ix] = o;
+        }
+    }
+}

@@ -560,3 +560,40 @@ def multiply_csr_by_dense_elemwise_bool(p, j, x, D):
 def logicaland_csr_by_dense_cpp(p, j, x, D):
     """src/operators.cpp:325-334"""
     return _csr_by_dense(4, p, j, x, D)
+
+
+DV_OPS = {"multiply": 0, "powerto": 1, "divide": 2, "divrest": 3, "intdiv": 4, "logical_and": 5}
+
+
+def _csr_by_dvec(p, j, x, dvec, ncols, op, x_is_lhs):
+    p, j = _i32(p), _i32(j)
+    dt = np.int32 if op == 5 else np.float64
+    xv = np.ascontiguousarray(x, dtype=dt)
+    dv = np.ascontiguousarray(dvec, dtype=dt)
+    out = np.empty(xv.size, dtype=dt)
+    if xv.size:
+        lib().mxo_csr_by_dvec(C.c_int(p.size - 1), C.c_int(int(ncols)), _p(p), _p(j), _p(xv), _p(dv),
+                              C.c_size_t(dv.size), C.c_int(op), C.c_int(1 if x_is_lhs else 0), _p(out))
+    return out
+
+
+def multiply_csr_by_dvec_no_NAs_numeric(p, j, x, dvec, ncols, multiply, powerto, divide, divrest, intdiv, X_is_LHS):
+    """src/operators.cpp:2142-2175 (flag precedence of :1620-1632)"""
+    if multiply:
+        op = 0
+    elif powerto:
+        op = 1
+    elif divide:
+        op = 2
+    elif divrest:
+        op = 3
+    elif intdiv:
+        op = 4
+    else:
+        raise ValueError("Internal error. Please file an issue in GitHub.")
+    return _csr_by_dvec(p, j, x, dvec, ncols, op, X_is_LHS)
+
+
+def logicaland_csr_by_dvec_internal(p, j, x, dvec, ncols):
+    """src/operators.cpp:2177-2200"""
+    return _csr_by_dvec(p, j, x, dvec, ncols, 5, True)

@@ -97,6 +97,28 @@ lst("gather", "logical", O.copy_csr_rows_logical(p, j, (x > 0).astype(np.int32),
 lst("gather", "binary", O.copy_csr_rows_binary(p, j, rows))
 lst("gather", "none", O.copy_csr_rows_numeric(p, j, x, np.array([10, 11, 10], dtype=np.int32)))
 
+# ---- CSR (op) dense vector: the four recycling branches, both operand orders, special values
+p, j, x = rand_csr(12, 7, 0.45, seed=51, empty_rows=(5,))
+x = x.copy(); x[:4] = [np.inf, -np.inf, np.nan, -0.0]
+rng = np.random.default_rng(52)
+vecs = {"len_nrows": 12, "len_full": 84, "len_divides": 4, "len_general": 5, "len_1": 1, "len_between": 30}
+put("dvec", p=p, j=j, x=x, xl=rand_csr(12, 7, 0.45, seed=51, empty_rows=(5,), dtype="l")[2])
+for vname, ln in vecs.items():
+    v = (rng.uniform(0.5, 3.0, size=ln) * rng.choice([-1.0, 1.0], size=ln)).round(3)
+    vl = rng.integers(0, 2, size=ln).astype(np.int32)
+    if ln > 2:
+        vl[1] = NA
+    put("dvec", **{f"v_{vname}": v, f"vl_{vname}": vl})
+    rr = np.repeat(np.arange(12), np.diff(p)); full = np.resize(v, 84).reshape(7, 12).T[rr, j]
+    res = O.multiply_csr_by_dvec_no_NAs_numeric(p, j, x, v, 7, True, False, False, False, False, True)
+    np.testing.assert_array_equal(np.isnan(res), np.isnan(x * full)); ok = ~np.isnan(res)
+    np.testing.assert_array_equal(res[ok], (x * full)[ok])
+    for opname, flags in {"mul": (1, 0, 0, 0, 0), "pow": (0, 1, 0, 0, 0), "div": (0, 0, 1, 0, 0), "mod": (0, 0, 0, 1, 0),
+                          "idiv": (0, 0, 0, 0, 1)}.items():
+        for lhs in (True, False):
+            put("dvec", **{f"{opname}_{int(lhs)}_{vname}": O.multiply_csr_by_dvec_no_NAs_numeric(p, j, x, v, 7, *flags, lhs)})
+    put("dvec", **{f"and_{vname}": O.logicaland_csr_by_dvec_internal(p, j, out["dvec/xl"], vl, 7)})
+
 # ---- sort KAT (tests/testthat/test-utilities.R:32-49)
 put("sort_kat", p=np.array([0, 1, 4, 5, 6], np.int32), j=np.array([4, 2, 1, 4, 1, 0], np.int32),
     x=np.array([-0.91, 0.14, -0.12, -0.12, 1.1, 0.66]), j_sorted=np.array([4, 1, 2, 4, 1, 0], np.int32),

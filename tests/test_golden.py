@@ -80,6 +80,23 @@ def run_all(M, exact_spmm):
     eq_list(M.copy_csr_rows_binary(p, j, rows), c, "binary")
     eq_list(M.copy_csr_rows_numeric(p, j, x, g(c, "rows_none")), c, "none")
 
+    c = "dvec"
+    p, j, x, xl = g(c, "p"), g(c, "j"), g(c, "x"), g(c, "xl")
+    flags = {"mul": (1, 0, 0, 0, 0), "pow": (0, 1, 0, 0, 0), "div": (0, 0, 1, 0, 0), "mod": (0, 0, 0, 1, 0), "idiv": (0, 0, 0, 0, 1)}
+    for vname in ("len_nrows", "len_full", "len_divides", "len_general", "len_1", "len_between"):
+        v, vl = g(c, "v_" + vname), g(c, "vl_" + vname)
+        for opname, f in flags.items():
+            for lhs in (True, False):
+                got = M.multiply_csr_by_dvec_no_NAs_numeric(p, j, x, v, 7, *f, lhs)
+                want = g(c, f"{opname}_{int(lhs)}_{vname}")
+                if opname in ("mul", "div"):
+                    eq(got, want)                                   # one IEEE operation: bit-exact
+                else:                                               # %% %/% ^: long double / libm in the reference
+                    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+                    ok = ~np.isnan(want)
+                    np.testing.assert_allclose(got[ok], want[ok], rtol=1e-13, atol=1e-15)
+        eq(M.logicaland_csr_by_dvec_internal(p, j, xl, vl, 7), g(c, "and_" + vname))
+
 
 def test_oracle_reproduces_golden():
     run_all(O, exact_spmm=True)

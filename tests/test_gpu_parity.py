@@ -500,3 +500,78 @@ def test_spmm_planned_edge_shapes(gpu):
     # duplicate column ids inside a row accumulate (SpMM does not need unique columns)
     p = np.array([0, 4], np.int32); j = np.array([3, 3, 3, 1], np.int32); x = np.array([1.0, 2.0, 3.0, 4.0])
     np.testing.assert_allclose(spmm_planned_device(p, j, x, B, True, npanels=2), (6 * B[3] + 4 * B[1])[None, :], rtol=1e-15)
+
+
+# ----------------------------------------------------------------------------- CSR (op) dense vector (§8f rank 4)
+DV_FLAGS = {"mul": (1, 0, 0, 0, 0), "pow": (0, 1, 0, 0, 0), "div": (0, 0, 1, 0, 0), "mod": (0, 0, 0, 1, 0), "idiv": (0, 0, 0, 0, 1)}
+
+
+def _dv_check(got, want, exact):
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    if exact:       # one IEEE multiplication / division: bit for bit, sign of zero included
+        np.testing.assert_array_equal(got[ok].view(np.int64), want[ok].view(np.int64))
+    else:           # %% %/% go through long double in the reference, ^ through libm's pow: last-bit agreement
+        np.testing.assert_allclose(got[ok], want[ok], rtol=1e-13, atol=1e-300)
+
+
+@pytest.mark.parametrize("m,K,dens", [(200, 37, 0.2), (1, 9, 0.9), (64, 1, 1.0), (513, 700, 0.02)])
+def test_csr_by_dvec_all_ops_and_lengths(gpu, m, K, dens):
+    """multiply_csr_by_dvec_no_NAs_numeric (src/operators.cpp:1604-2175): the four recycling branches x five
+    operations x both operand orders (the kind of inputs test-operators.R:373-893 feeds it)."""
+    p, j, x = rand_csr(m, K, dens, seed=m + K, empty_rows=(0,) if m > 3 else ())
+    x = (x * 4).round(2)
+    x[x == 0] = 1.5
+    rng = np.random.default_rng(m * 7 + K)
+    lens = sorted({m, m * K, 1, max(1, m // 2) if m % 2 == 0 else 1, 5, min(m * K, m + 3)})
+    for ln in lens:
+        v = (rng.uniform(0.5, 3.0, size=ln) * rng.choice([-1.0, 1.0], size=ln)).round(2)
+        for opname, f in DV_FLAGS.items():
+            for lhs in (True, False):
+                got = G.multiply_csr_by_dvec_no_NAs_numeric(p, j, x, v, K, *f, lhs)
+                want = O.multiply_csr_by_dvec_no_NAs_numeric(p, j, x, v, K, *f, lhs)
+                assert got.dtype == np.float64 and got.shape == want.shape
+                _dv_check(got, want, exact=opname in ("mul", "div"))
+
+
+def test_csr_by_dvec_special_values(gpu):
+    """R_pow / R_modulus / R_intdiv corner cases (src/operators.cpp:1482-1601): zeros, infinities, NaN, huge
+    quotients, integer and non-integer exponents of negative bases."""
+    vals = np.array([0.0, -0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5, 3.0, -3.0, np.inf, -np.inf, np.nan, 1e300, -1e300,
+                     1e-300, 7.25, -7.25, 2.0 ** 70, -(2.0 ** 70)])
+    n = vals.size
+    p = np.arange(0, n * n + 1, n, dtype=np.int32)                  # n rows, every row holds all n columns
+    j = np.tile(np.arange(n, dtype=np.int32), n)
+    x = np.repeat(vals, n)                                          # row r has value vals[r] in every column
+    v = np.tile(vals, n).reshape(n, n).T.reshape(-1, order="F")     # full matrix: entry (r, c) -> vals[c]
+    for opname, f in DV_FLAGS.items():
+        for lhs in (True, False):
+            with np.errstate(all="ignore"):
+                got = G.multiply_csr_by_dvec_no_NAs_numeric(p, j, x, v, n, *f, lhs)
+            want = O.multiply_csr_by_dvec_no_NAs_numeric(p, j, x, v, n, *f, lhs)
+            np.testing.assert_array_equal(np.isnan(got), np.isnan(want), err_msg=f"{opname} lhs={lhs}")
+            ok = ~np.isnan(want)
+            np.testing.assert_array_equal(np.isinf(got[ok]), np.isinf(want[ok]), err_msg=f"{opname} lhs={lhs}")
+            fin = ok & np.isfinite(want)
+            np.testing.assert_allclose(got[fin], want[fin], rtol=1e-13, atol=0, err_msg=f"{opname} lhs={lhs}")
+            np.testing.assert_array_equal(np.signbit(got[ok]), np.signbit(want[ok]), err_msg=f"{opname} lhs={lhs}")
+
+
+def test_csr_by_dvec_logical_and(gpu):
+    """logicaland_csr_by_dvec_internal (src/operators.cpp:2177-2200): R's three-valued & with NA on either side."""
+    p, j, xl = rand_csr(90, 23, 0.3, seed=12, dtype="l", empty_rows=(7,))
+    rng = np.random.default_rng(13)
+    for ln in (90, 90 * 23, 45, 1, 7, 100):
+        vl = rng.integers(0, 2, size=ln).astype(np.int32)
+        vl[rng.random(ln) < 0.2] = NA
+        got = G.logicaland_csr_by_dvec_internal(p, j, xl, vl, 23)
+        assert got.dtype == np.int32
+        np.testing.assert_array_equal(got, O.logicaland_csr_by_dvec_internal(p, j, xl, vl, 23))
+
+
+def test_csr_by_dvec_empty_inputs(gpu):
+    p = np.zeros(6, dtype=np.int32); j = np.zeros(0, dtype=np.int32); x = np.zeros(0)
+    assert G.multiply_csr_by_dvec_no_NAs_numeric(p, j, x, np.ones(5), 4, 1, 0, 0, 0, 0, 1).size == 0
+    assert G.logicaland_csr_by_dvec_internal(p, j, np.zeros(0, np.int32), np.ones(5, np.int32), 4).size == 0
+    p0 = np.zeros(1, dtype=np.int32)
+    assert G.multiply_csr_by_dvec_no_NAs_numeric(p0, j, x, np.ones(1), 0, 0, 0, 1, 0, 0, 1).size == 0

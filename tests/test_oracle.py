@@ -369,3 +369,51 @@ def test_csr_svec_and_csr_by_dense():
     ol = O.logicaland_csr_by_dense_cpp(p, j, xl, Dl)
     f = O.lib().mxo_r_logical
     assert ol.tolist() == [f(1, int(a), int(b)) for a, b in zip(xl, Dl[rows, j])]
+
+
+def test_csr_by_dvec_against_numpy():
+    """multiply_csr_by_dvec_no_NAs (src/operators.cpp:1604-2140): each of the reference's four vector-length branches
+    equals base-R recycling of the vector down the columns; * and / are single IEEE operations, %% %/% ^ follow R's
+    arithmetic (numpy's mod / floor_divide / power agree on finite inputs)."""
+    p, j, x = rand_csr(48, 11, 0.3, seed=8, empty_rows=(2,))
+    x = (x * 6).round(2); x[x == 0] = 2.5
+    r = np.repeat(np.arange(48), np.diff(p))
+    rng = np.random.default_rng(9)
+    for ln in (48, 48 * 11, 12, 1, 7, 100):
+        v = (rng.uniform(0.5, 3.0, size=ln) * rng.choice([-1.0, 1.0], size=ln)).round(2)
+        d = np.resize(v, 48 * 11).reshape(11, 48).T[r, j]
+        f = lambda *fl: O.multiply_csr_by_dvec_no_NAs_numeric(p, j, x, v, 11, *fl)   # noqa: E731
+        np.testing.assert_array_equal(f(1, 0, 0, 0, 0, True), x * d)
+        np.testing.assert_array_equal(f(1, 0, 0, 0, 0, False), x * d)
+        np.testing.assert_array_equal(f(0, 0, 1, 0, 0, True), x / d)
+        np.testing.assert_array_equal(f(0, 0, 1, 0, 0, False), d / x)
+        np.testing.assert_allclose(f(0, 0, 0, 1, 0, True), np.mod(x, d), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(f(0, 0, 0, 1, 0, False), np.mod(d, x), rtol=1e-12, atol=1e-14)
+        np.testing.assert_array_equal(f(0, 0, 0, 0, 1, True), np.floor_divide(x, d))
+        np.testing.assert_array_equal(f(0, 0, 0, 0, 1, False), np.floor_divide(d, x))
+        with np.errstate(invalid="ignore"):
+            np.testing.assert_allclose(f(0, 1, 0, 0, 0, True), np.power(x, d), rtol=1e-14, equal_nan=True)
+            np.testing.assert_allclose(f(0, 1, 0, 0, 0, False), np.power(d, x), rtol=1e-14, equal_nan=True)
+    # R's documented corner cases of ^ %% %/% (?Arithmetic): x^0 = 1 and 1^y = 1 even for NaN, x %% 0 = NaN,
+    # x %/% 0 = +-Inf, the sign of %% follows the divisor, -Inf^odd = -Inf
+    one = lambda a, b, *fl: O.multiply_csr_by_dvec_no_NAs_numeric(np.array([0, 1], np.int32), np.array([0], np.int32),  # noqa: E731
+                                                                 np.array([a]), np.array([b]), 1, *fl, True)[0]
+    assert one(np.nan, 0.0, 0, 1, 0, 0, 0) == 1.0 and one(1.0, np.nan, 0, 1, 0, 0, 0) == 1.0
+    assert np.isnan(one(5.0, 0.0, 0, 0, 0, 1, 0)) and one(5.0, 0.0, 0, 0, 0, 0, 1) == np.inf
+    assert one(-5.0, 3.0, 0, 0, 0, 1, 0) == 1.0 and one(5.0, -3.0, 0, 0, 0, 1, 0) == -1.0
+    assert one(-5.0, 3.0, 0, 0, 0, 0, 1) == -2.0
+    assert one(-np.inf, 3.0, 0, 1, 0, 0, 0) == -np.inf and one(-np.inf, 2.0, 0, 1, 0, 0, 0) == np.inf
+    assert np.isnan(one(-8.0, 1.0 / 3.0, 0, 1, 0, 0, 0))
+
+
+def test_logicaland_csr_by_dvec():
+    """logicaland_csr_by_dvec_internal (src/operators.cpp:2177-2200) against R's truth table, NA included."""
+    p, j, xl = rand_csr(30, 9, 0.4, seed=21, dtype="l")
+    r = np.repeat(np.arange(30), np.diff(p))
+    NA = O.NA_INTEGER
+    for ln in (30, 270, 10, 4):
+        vl = np.random.default_rng(ln).integers(0, 2, size=ln).astype(np.int32)
+        vl[::3] = NA
+        d = np.resize(vl, 270).reshape(9, 30).T[r, j]
+        want = np.where((xl == 0) | (d == 0), 0, np.where((xl == NA) | (d == NA), NA, 1)).astype(np.int32)
+        np.testing.assert_array_equal(O.logicaland_csr_by_dvec_internal(p, j, xl, vl, 9), want)

@@ -313,7 +313,7 @@ def extras(args, A, B, torch, D, synth, p, j, x):
         G.tcrossprod_csr_dense_float32(p, j, x, Yc, 1)
     t = time.perf_counter() - t0
     res["export_call_end_to_end"] = {"ms": round(t * 1e3, 2), "GFLOP/s": round(2 * nnz * out.shape[1] / t / 1e9, 1),
-                                     "note": "pageable host buffers, hipMalloc/hipFree per call"}
+                                     "note": "pageable host buffers in and out, hipMalloc/hipFree per call, transfers pipelined through pinned slots (xfer.hip); includes the Python-side allocation of the 1 GB result"}
     return res
 
 

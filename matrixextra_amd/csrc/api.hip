@@ -5,6 +5,7 @@
 #include "mx_common.h"
 
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 
@@ -23,6 +24,30 @@ int set_error(const char *fmt, ...)
 
 int spmv_launch(int m, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
                 const void *v, int v_dtype, void *y, hipStream_t st);
+// xfer.hip: synchronous host <-> device copies, pipelined through pinned slots + a host copy pool when large
+int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes);
+
+// MXGPU_TRACE=1: wall-clock phases of an export-level call on stderr
+struct Trace {
+    bool on;
+    const char *what;
+    std::chrono::steady_clock::time_point t0, last;
+    explicit Trace(const char *w) : on(getenv("MXGPU_TRACE") != nullptr), what(w)
+    {
+        if (on) t0 = last = std::chrono::steady_clock::now();
+    }
+    ~Trace() { mark("release"); }                   // declared before the device buffers: runs after their hipFree
+    void mark(const char *phase)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mxgpu] %s: %-10s %8.3f ms (total %8.3f)\n", what, phase,
+                std::chrono::duration<double, std::milli>(now - last).count(),
+                std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
 
 // owning device buffer
 struct DevBuf {
@@ -42,7 +67,7 @@ struct DevBuf {
     int upload(const void *h, size_t n)
     {
         if (alloc(n)) return 1;
-        if (n) MX_HIP(hipMemcpy(p, h, n, hipMemcpyHostToDevice));
+        if (n && mx::xfer_h2d(p, h, n)) return 1;               // pipelined through pinned slots when large (xfer.hip)
         return 0;
     }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
@@ -78,11 +103,15 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     if (c_elems == 0) return 0;
     // reference early-out (matmul.cpp:128-129,160-161): result stays the zero-initialised matrix
     if (m == 0 || n == 0 || indptr[0] == indptr[m]) { memset(C_host, 0, c_elems * sizeof(real_t)); return 0; }
+    Trace tr("spmm export");
     Csr A;
     if (A.upload(indptr, indices, values, m, sizeof(double))) return 1;
+    tr.mark("H2D csr");
     DevBuf B, C;
     if (B.upload(B_host, sizeof(real_t) * (size_t)K_rows * ldb)) return 1;
+    tr.mark("H2D dense");
     if (C.alloc(sizeof(real_t) * c_elems)) return 1;
+    tr.mark("alloc C");
     const int dt = sizeof(real_t) == 8 ? MX_F64 : MX_F32;
     // kernel choice: AUTO unless the MXGPU_SPMM_ALGO / MXGPU_SPMM_PANELS tuning knobs say otherwise
     int algo = MX_SPMM_AUTO, npanels = 0;
@@ -97,8 +126,10 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     }
     if (mxd_spmm_csr_dense_ex(m, n, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), B.p, ldb, C.p, ldc,
                               dt, colmajor ? 1 : 0, algo, sorted, npanels, 0, nullptr)) return 1;
-    MX_HIP(hipMemcpy(C_host, C.p, sizeof(real_t) * c_elems, hipMemcpyDeviceToHost));
-    return 0;
+    if (tr.on) { MX_HIP(hipDeviceSynchronize()); tr.mark("kernels"); }
+    const int rc = mx::xfer_d2h(C_host, C.p, sizeof(real_t) * c_elems);
+    tr.mark("D2H C");
+    return rc;
 }
 
 template <typename vec_t, typename out_t>
@@ -114,7 +145,7 @@ static int spmv_host(int m, const int32_t *indptr, const int32_t *indices, const
     if (o.alloc(sizeof(out_t) * (size_t)m)) return 1;
     if (spmv_launch(m, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), v.p, v_dtype, o.p, nullptr))
         return 1;
-    MX_HIP(hipMemcpy(out, o.p, sizeof(out_t) * (size_t)m, hipMemcpyDeviceToHost));
+    if (mx::xfer_d2h(out, o.p, sizeof(out_t) * (size_t)m)) return 1;
     return 0;
 }
 
@@ -542,8 +573,8 @@ int mx_reverse_columns_inplace(const int32_t *indptr, int nrows, int32_t *indice
     if (A.nnz == 0) return 0;
     if (mxd_csr_reverse_columns(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p,
                                 has_values ? value_dtype : MX_NONE, ncol, nullptr)) return 1;
-    MX_HIP(hipMemcpy(indices, A.j.p, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
-    if (vb) MX_HIP(hipMemcpy(values, A.x.p, vb * (size_t)A.nnz, hipMemcpyDeviceToHost));
+    if (mx::xfer_d2h(indices, A.j.p, sizeof(int32_t) * (size_t)A.nnz)) return 1;
+    if (vb && mx::xfer_d2h(values, A.x.p, vb * (size_t)A.nnz)) return 1;
     return 0;
 }
 
@@ -564,7 +595,7 @@ int mx_matmul_csr_svec(const int32_t *Xp, const int32_t *Xj, const double *Xx, i
     if (o.alloc(sizeof(double) * (size_t)nrows)) return 1;
     if (mxd_spmv_csr_svec(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), di.as<int32_t>(), (int)ny,
                           vb ? dv.p : nullptr, kind, o.as<double>(), nullptr)) return 1;
-    MX_HIP(hipMemcpy(out, o.p, sizeof(double) * (size_t)nrows, hipMemcpyDeviceToHost));
+    if (mx::xfer_d2h(out, o.p, sizeof(double) * (size_t)nrows)) return 1;
     return 0;
 }
 
@@ -581,7 +612,7 @@ int mx_multiply_csr_by_dense_elemwise(const int32_t *indptr, const int32_t *indi
     if (D.upload(dense_mat, db * (size_t)nrows * (size_t)ncols)) return 1;
     if (o.alloc(vb * (size_t)A.nnz)) return 1;
     if (mxd_csr_by_dense_elemwise(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, D.p, kind, o.p, nullptr)) return 1;
-    MX_HIP(hipMemcpy(values_out, o.p, vb * (size_t)A.nnz, hipMemcpyDeviceToHost));
+    if (mx::xfer_d2h(values_out, o.p, vb * (size_t)A.nnz)) return 1;
     return 0;
 }
 
@@ -601,7 +632,7 @@ static int csr_by_dvec_export(const int32_t *indptr, const int32_t *indices, con
     if (o.alloc(eb * (size_t)A.nnz)) return 1;
     if (mxd_csr_by_dvec(nrows, ncols, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, D.p, dvec_len, op, lhs, o.p, nullptr))
         return 1;
-    MX_HIP(hipMemcpy(values_out, o.p, eb * (size_t)A.nnz, hipMemcpyDeviceToHost));
+    if (mx::xfer_d2h(values_out, o.p, eb * (size_t)A.nnz)) return 1;
     return 0;
 }
 
@@ -728,17 +759,17 @@ int mx_result_finish(mx_result *res, int32_t *out_indptr, int32_t *out_indices, 
         const mx_result_info &inf = res->info;
         if (!inf.alias_structure) {
             if (inf.indptr_len > 0 && out_indptr &&
-                hipMemcpy(out_indptr, res->indptr.p, sizeof(int32_t) * (size_t)inf.indptr_len, hipMemcpyDeviceToHost) != hipSuccess) {
+                mx::xfer_d2h(out_indptr, res->indptr.p, sizeof(int32_t) * (size_t)inf.indptr_len) != 0) {
                 rc = set_error("D2H copy of indptr failed"); break;
             }
             if (inf.nnz > 0 && out_indices &&
-                hipMemcpy(out_indices, res->indices.p, sizeof(int32_t) * (size_t)inf.nnz, hipMemcpyDeviceToHost) != hipSuccess) {
+                mx::xfer_d2h(out_indices, res->indices.p, sizeof(int32_t) * (size_t)inf.nnz) != 0) {
                 rc = set_error("D2H copy of indices failed"); break;
             }
         }
         const size_t vb = dtype_bytes(inf.values_dtype);
         if (vb && inf.values_len > 0 && out_values && res->values.p &&
-            hipMemcpy(out_values, res->values.p, vb * (size_t)inf.values_len, hipMemcpyDeviceToHost) != hipSuccess) {
+            mx::xfer_d2h(out_values, res->values.p, vb * (size_t)inf.values_len) != 0) {
             rc = set_error("D2H copy of values failed"); break;
         }
     } while (0);
@@ -792,8 +823,8 @@ int mx_sort_sparse_indices(const int32_t *indptr, int32_t *indices, void *values
     if (vb && tx.alloc(vb * (size_t)A.nnz)) return 1;
     if (mxd_csr_sort_rows(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), vb ? A.x.p : nullptr,
                           vb ? value_dtype : MX_NONE, tj.as<int32_t>(), tx.p, nullptr)) return 1;
-    MX_HIP(hipMemcpy(indices, A.j.p, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
-    if (vb) MX_HIP(hipMemcpy(values, A.x.p, vb * (size_t)A.nnz, hipMemcpyDeviceToHost));
+    if (mx::xfer_d2h(indices, A.j.p, sizeof(int32_t) * (size_t)A.nnz)) return 1;
+    if (vb && mx::xfer_d2h(values, A.x.p, vb * (size_t)A.nnz)) return 1;
     return 0;
 }
 

@@ -846,9 +846,11 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
     constexpr int VEC = 16 / (int)sizeof(real_t);
     constexpr int W = SLAB_GROUP * VEC;
     constexpr int U = 8;                                            // plan steps in flight per wavefront
-    constexpr int PLAN_BLOCK = PLAN_WAVES * 64;
     constexpr int PLAN_WG_ROWS = PLAN_OCT_ROWS * PLAN_WAVES;        // rows per workgroup generation
-    __shared__ real_t accs[PLAN_WG_ROWS * W];                       // 16 waves: 1024 rows x 128 B = 128 KiB
+    // accumulator rows are padded by 8 (f64) / 16 (f32) bytes: the column-major epilogue reads one column of 64
+    // consecutive rows per instruction, which at a 128-byte stride would hit a single LDS bank pair
+    constexpr int S = W + 16 / (int)sizeof(real_t) / 2;
+    __shared__ real_t accs[PLAN_WG_ROWS * S];                       // 16 waves: 1024 rows x 136 B = 136 KiB
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, lg = lane & 7;
     const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
@@ -856,7 +858,8 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
     const long long lo = total * xcd / 8, hi = total * (xcd + 1) / 8;
     const int niter = (int)((hi - lo + nwg - 1) / nwg);
     unsigned *const my_ctr = sync_ctr + xcd * 64;
-    real_t *const my_rows = accs + (size_t)(wave * 8 + g) * PLAN_RB * W + lg * VEC;    // this group's bundle
+    real_t *const my_oct = accs + (size_t)wave * PLAN_OCT_ROWS * S;                     // this wavefront's 64 rows
+    real_t *const my_rows = my_oct + (size_t)g * PLAN_RB * S + lg * VEC;                // this group's bundle
 
     for (int it = 0; it < niter; it++) {
         const long long item_raw = lo + wg + (long long)it * nwg;
@@ -870,8 +873,10 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
         const char *__restrict__ Bbase = reinterpret_cast<const char *>(Bp + (size_t)slab * slab_stride);
         const unsigned lane_off = (unsigned)(lg * VEC * sizeof(real_t));
 
-        for (int i = threadIdx.x; i < PLAN_WG_ROWS * W; i += PLAN_BLOCK) accs[i] = 0;
-        __syncthreads();
+        // A wavefront's accumulator rows are touched by that wavefront only (zeroing, folds, epilogue): no
+        // workgroup-wide synchronisation around a generation, the wavefronts only meet at the panel boundaries.
+        for (int i = lane; i < PLAN_OCT_ROWS * S; i += 64) my_oct[i] = 0;
+        if (sync_mode > 0) __syncthreads();                          // locality only: start the first panel together
 
         // One continuous, software-pipelined stream over the octet's entries of ALL panels (they are contiguous in
         // the plan).  Panel boundaries only matter for locality: when the stream crosses one, the 16 waves of the
@@ -933,7 +938,7 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             auto consume = [&](int u) {
                 const int lrow = (int)((unsigned)pc[u] >> PLAN_ROW_SHIFT);
                 if (lrow != cur) {
-                    lds_fold<VEC>(my_rows + cur * W, acc);
+                    lds_fold<VEC>(my_rows + cur * S, acc);
 #pragma unroll
                     for (int v = 0; v < VEC; v++) acc[v] = 0;
                     cur = lrow;
@@ -985,36 +990,36 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             }
 #pragma unroll
             for (int u = 0; u < U; u++) consume(u);
-            lds_fold<VEC>(my_rows + cur * W, acc);
+            lds_fold<VEC>(my_rows + cur * S, acc);
             if (sync_mode > 0)
                 for (; p < npanels - 1; p++) __syncthreads();           // every wave meets npanels-1 times per generation
         }
-        __syncthreads();
 
-        // write the generation's 256 x W tile of C
-        if (have) {
-            const int row_base = gen * PLAN_WG_ROWS;
+        // each wavefront writes the 64 x W tile of C it accumulated (streaming stores: C is not read again)
+        if (oct_ok) {
+            const int row_base = gen * PLAN_WG_ROWS + wave * PLAN_OCT_ROWS;
             const int ncols = min(W, n - slab * W);
             if constexpr (!COLMAJOR) {
-                for (int r = threadIdx.x >> 3; r < PLAN_WG_ROWS; r += PLAN_BLOCK / 8) {
+#pragma unroll
+                for (int rr = 0; rr < PLAN_OCT_ROWS / 8; rr++) {
+                    const int r = rr * 8 + g;
                     const int row = row_base + r;
                     if (row < m && lg * VEC < ncols) {
                         real_t t[VEC];
 #pragma unroll
-                        for (int v = 0; v < VEC; v++) t[v] = accs[(size_t)r * W + lg * VEC + v];
+                        for (int v = 0; v < VEC; v++) t[v] = my_oct[(size_t)r * S + lg * VEC + v];
                         vstore_nt<real_t, VEC>(C + (size_t)row * ldc + slab * W + lg * VEC, t);
                     }
                 }
             } else {
-                // consecutive threads -> consecutive rows of one output column
-                for (int idx = threadIdx.x; idx < PLAN_WG_ROWS * W; idx += PLAN_BLOCK) {
-                    const int c = idx / PLAN_WG_ROWS, r = idx % PLAN_WG_ROWS;
-                    const int row = row_base + r;
-                    if (row < m && c < ncols) __builtin_nontemporal_store(accs[(size_t)r * W + c], &C[(size_t)(slab * W + c) * ldc + row]);
+                // lane = row: one 512-byte (f64) segment of an output column per store instruction
+                const int row = row_base + lane;
+                if (row < m) {
+                    for (int c = 0; c < ncols; c++)
+                        __builtin_nontemporal_store(my_oct[(size_t)lane * S + c], &C[(size_t)(slab * W + c) * ldc + row]);
                 }
             }
         }
-        __syncthreads();
     }
 }
 

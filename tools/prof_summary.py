@@ -19,7 +19,13 @@ import sys
 
 def pmc(dirname, kernel_sub):
     acc = collections.defaultdict(list)
+    # gpurun merges new files into gpurun_out/ without deleting old ones: keep only the newest run of every pass
+    newest = {}
     for f in glob.glob(os.path.join(dirname, "pmc_*", "*", "*_counter_collection.csv")):
+        d = os.path.dirname(f)
+        if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+            newest[d] = f
+    for f in newest.values():
         for r in csv.DictReader(open(f)):
             if kernel_sub in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -29,7 +35,7 @@ def pmc(dirname, kernel_sub):
 def main():
     src, prefix = sys.argv[1], sys.argv[2]
     ksub = sys.argv[3] if len(sys.argv) > 3 else "spmm"
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
     rows = list(csv.DictReader(open(stats[0]))) if stats else []
     with open(prefix + "_kernel_stats.csv", "w") as f:
         w = csv.writer(f)

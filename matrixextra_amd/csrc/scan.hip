@@ -4,7 +4,7 @@
 // int indptr, operators.cpp:414,521).
 //
 // Three launches (reduce tiles -> scan tile sums in one workgroup -> scan tiles
-// with carried offset).  Row-count vectors are <= 32 MB here; the scan is a
+// with carried offset); vectors of up to 2^18 entries take one single-workgroup launch instead.  Row-count vectors are <= 32 MB here; the scan is a
 // bandwidth-trivial step between the count and fill passes of merge / gather.
 #include "mx_common.h"
 
@@ -98,6 +98,49 @@ void scan_tiles_kernel(const int32_t *__restrict__ counts, int64_t n, const long
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (int32_t)*total;
 }
 
+// Short vectors (the plan's per-octet step counts: 16 k entries for 1 M rows): ONE launch, one 1024-thread
+// workgroup walking the vector in tiles of 16 k elements with a carried offset.
+constexpr int SCAN1_BLOCK = 1024;
+constexpr int64_t SCAN1_MAX = (int64_t)1 << 18;
+
+__global__ __launch_bounds__(SCAN1_BLOCK)
+void scan_single_kernel(const int32_t *__restrict__ counts, int64_t n, int32_t *__restrict__ out,
+                        long long *__restrict__ total_out)
+{
+    __shared__ long long wave_sums[SCAN1_BLOCK / MX_WAVE];
+    const int lane = lane_id(), wave = threadIdx.x / MX_WAVE;
+    long long carry = 0;
+    for (int64_t t0 = 0; t0 < n; t0 += (int64_t)SCAN1_BLOCK * SCAN_ITEMS) {
+        const int64_t base = t0 + (int64_t)threadIdx.x * SCAN_ITEMS;
+        int32_t c[SCAN_ITEMS];
+        long long sum = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            c[i] = base + i < n ? counts[base + i] : 0;
+            sum += c[i];
+        }
+        const long long incl = wave_incl_scan(sum);
+        if (lane == MX_WAVE - 1) wave_sums[wave] = incl;
+        __syncthreads();
+        long long before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < SCAN1_BLOCK / MX_WAVE; w++) {
+            const long long ws = wave_sums[w];
+            if (w < wave) before += ws;
+            total += ws;
+        }
+        __syncthreads();
+        long long run = carry + before + incl - sum;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            if (base + i < n) out[base + i] = (int32_t)run;
+            run += c[i];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) { out[n] = (int32_t)carry; *total_out = carry; }
+}
+
 // workspace layout: [int64 total][int64 tile_sums[ntiles]]
 size_t scan_workspace_bytes(int64_t n)
 {
@@ -113,6 +156,11 @@ int exclusive_scan_i32(const int32_t *counts, int64_t n, int32_t *out, int64_t *
     if (n <= 0) {
         MX_HIP(hipMemsetAsync(out, 0, sizeof(int32_t), st));
         MX_HIP(hipMemsetAsync(total, 0, sizeof(long long), st));
+        return 0;
+    }
+    if (n <= SCAN1_MAX) {
+        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN1_BLOCK), 0, st, counts, n, out, total);
+        MX_LAUNCH_CHECK();
         return 0;
     }
     const int64_t ntiles = ceil_div(n, SCAN_TILE);

@@ -704,31 +704,24 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
     }
 }
 
-// panel boundaries of an octet for the kernel's panel meetings: mean start of the panel over the 8 bundles
-__global__ __launch_bounds__(256)
-void plan_bounds_kernel(int noct, int npanels, const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
-                        int32_t *__restrict__ step_off)
-{
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long n = (long long)noct * npanels;
-    if (t > n) return;
-    if (t == n) { step_off[n] = oct_off[noct]; return; }
-    const int oct = (int)(t / npanels), p = (int)(t % npanels);
-    int sum = 0;
-#pragma unroll
-    for (int g = 0; g < 8; g++) sum += bpo[((size_t)oct * 8 + g) * npanels + p];
-    step_off[t] = oct_off[oct] + (p == 0 ? 0 : sum / 8);
-}
-
 // pass 2: scatter the entries to their interleaved slots (batch of 8 steps = 64 slots laid out [bundle][step])
 __global__ __launch_bounds__(512)
 void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
                       const int32_t *__restrict__ indices, const double *__restrict__ values,
                       const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
-                      int32_t *__restrict__ pcol, double *__restrict__ pval, int noct, int pad_col)
+                      int32_t *__restrict__ pcol, double *__restrict__ pval, int noct, int pad_col,
+                      int32_t *__restrict__ step_off)
 {
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int oct = blockIdx.x;
+    // panel boundaries of the octet for the kernel's panel meetings: mean start of the panel over the 8 bundles
+    if (g == 0 && lane < npanels) {
+        int sum = 0;
+#pragma unroll
+        for (int gg = 0; gg < 8; gg++) sum += bpo[((size_t)oct * 8 + gg) * npanels + lane];
+        step_off[(size_t)oct * npanels + lane] = oct_off[oct] + (lane == 0 ? 0 : sum / 8);
+        if (oct == noct - 1 && lane == 0) step_off[(size_t)noct * npanels] = oct_off[noct];
+    }
     const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
     int rp[PLAN_RB + 1];                                             // the bundle's row pointers (wave-uniform)
 #pragma unroll
@@ -1097,9 +1090,6 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
                        steps, bpo, pl->noct);
     MX_LAUNCH_CHECK();
     if (exclusive_scan_i32(steps, (int64_t)pl->noct, oct_off, (int64_t *)scan_ws, scan_ws, st)) return 1;
-    hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)ceil_div((long long)nop + 1, 256)), dim3(256), 0, st, pl->noct,
-                       npanels, oct_off, bpo, pl->step_off);
-    MX_LAUNCH_CHECK();
     PlanReadback *rb = plan_readback();
     MX_REQUIRE(rb, "spmm plan: cannot allocate the pinned read-back buffer");
     rb->host[1] = 0;
@@ -1119,7 +1109,7 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     if (grow((void **)&pl->pcol, &pl->pcol_cap, slots * 4)) return 1;
     if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
     hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K);
+                       values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off);
     MX_LAUNCH_CHECK();
     return 0;
 }

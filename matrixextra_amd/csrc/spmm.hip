@@ -657,8 +657,9 @@ __device__ __forceinline__ int panel_of(int col, int panel_cols, float inv_pc, i
 __global__ __launch_bounds__(512)
 void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
                        const int32_t *__restrict__ indices, int32_t *__restrict__ steps,
-                       int32_t *__restrict__ bpo, int noct)
+                       int32_t *__restrict__ bpo, int noct, long long *__restrict__ nnz_out)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nnz_out = indptr[m];     // rides back with the step total (one copy)
     __shared__ int totals[8];
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int oct = blockIdx.x;
@@ -1079,22 +1080,22 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     const size_t steps_b = (((size_t)pl->noct * 4) + al) & ~al;
     const size_t octoff_b = ((((size_t)pl->noct + 1) * 4) + al) & ~al;
     const size_t bpo_b = ((nop * 8 * 4) + al) & ~al;
-    if (grow(&pl->scratch, &pl->scratch_cap, steps_b + octoff_b + bpo_b + scan_workspace_bytes((int64_t)pl->noct))) return 1;
+    const size_t rb_b = 256;                                        // [total steps][nnz], read back in one copy
+    if (grow(&pl->scratch, &pl->scratch_cap, steps_b + octoff_b + bpo_b + rb_b + scan_workspace_bytes((int64_t)pl->noct))) return 1;
     if (grow((void **)&pl->step_off, &pl->step_off_cap, (nop + 1) * 4)) return 1;
     int32_t *steps = (int32_t *)pl->scratch;
     int32_t *oct_off = (int32_t *)((char *)steps + steps_b);
     int32_t *bpo = (int32_t *)((char *)oct_off + octoff_b);
-    void *scan_ws = (char *)bpo + bpo_b;
+    long long *rb_dev = (long long *)((char *)bpo + bpo_b);
+    void *scan_ws = (char *)rb_dev + rb_b;
     const unsigned blocks = (unsigned)pl->noct;
     hipLaunchKernelGGL(plan_count_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       steps, bpo, pl->noct);
+                       steps, bpo, pl->noct, rb_dev + 1);
     MX_LAUNCH_CHECK();
-    if (exclusive_scan_i32(steps, (int64_t)pl->noct, oct_off, (int64_t *)scan_ws, scan_ws, st)) return 1;
+    if (exclusive_scan_i32(steps, (int64_t)pl->noct, oct_off, (int64_t *)rb_dev, scan_ws, st)) return 1;
     PlanReadback *rb = plan_readback();
     MX_REQUIRE(rb, "spmm plan: cannot allocate the pinned read-back buffer");
-    rb->host[1] = 0;
-    MX_HIP(hipMemcpyAsync(&rb->host[0], scan_ws, sizeof(long long), hipMemcpyDeviceToHost, st));
-    MX_HIP(hipMemcpyAsync(&rb->host[1], indptr + m, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MX_HIP(hipMemcpyAsync(rb->host, rb_dev, 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
     MX_HIP(hipEventRecord(rb->ev, st));
     // (Packing B here, behind the read-back, would hide the host round trip — but the fill that follows then
     // pushes the packed B out of the Infinity Cache and the sweep runs 2.75 ms instead of 2.05 ms.  B is packed right
@@ -1180,7 +1181,7 @@ static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, 
     if (grid < 8) grid = 8;
     unsigned *sync = slab_sync_workspace();
     if (!sync || pl->npanels <= 1) sync_mode = 0;
-    if (sync_mode) MX_HIP(hipMemsetAsync(sync, 0, 8 * 64 * sizeof(unsigned), st));
+    if (sync_mode >= 2) MX_HIP(hipMemsetAsync(sync, 0, 8 * 64 * sizeof(unsigned), st));   // counters of the XCD timing barrier
     kt_begin(st);
 #define MX_PLAN_LAUNCH(CM, WV)                                                                                           \
     hipLaunchKernelGGL((spmm_plan_kernel<real_t, CM, WV>), dim3((unsigned)grid), dim3(WV * 64), 0, st, m, n, pl->npanels, \

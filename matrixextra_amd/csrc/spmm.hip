@@ -1033,6 +1033,7 @@ struct mx_spmm_plan {
     double *pval = nullptr;      size_t pval_cap = 0;
     void *scratch = nullptr;     size_t scratch_cap = 0;       // rowpre + steps + scan workspace (build only)
     double build_ms = 0.0;
+    bool ready = false;                                            // false: sized but not filled (rejected by AUTO)
 };
 
 namespace mx {
@@ -1064,9 +1065,12 @@ static PlanReadback *plan_readback()
     return &rb;
 }
 
+// max_pad_ratio > 0: stop after the sizing pass when the plan would hold more than ratio x nnz slots (rows of very
+// uneven length pad the 8-way interleave: an octet is as long as its longest bundle) — pl->ready stays false.
 static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, const int32_t *indices,
-                      const double *values, int npanels, hipStream_t st)
+                      const double *values, int npanels, hipStream_t st, double max_pad_ratio = 0.0)
 {
+    pl->ready = false;
     MX_REQUIRE(K < (1 << 25), "spmm plan: more than 2^25 columns (32-bit slab offsets)");
     if (npanels <= 0) npanels = pick_panels(K, (size_t)2600 << 10);     // measured (cfg2): kernel alone is best at 1.6 MB panels (P=8), kernel + plan build at 2.6 MB (P=5)
     if (npanels > PLAN_MAXP) npanels = PLAN_MAXP;
@@ -1074,7 +1078,7 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     pl->panel_cols = (int)ceil_div(K > 0 ? K : 1, npanels);
     pl->noct = (int)ceil_div(m, PLAN_OCT_ROWS);
     pl->total_steps = 0; pl->nnz = 0;
-    if (m == 0) return 0;                                           // nothing to plan (and no zero-sized launches)
+    if (m == 0) { pl->ready = true; return 0; }                     // nothing to plan (and no zero-sized launches)
     const size_t nop = (size_t)pl->noct * npanels;
     const size_t al = 255;
     const size_t steps_b = (((size_t)pl->noct * 4) + al) & ~al;
@@ -1106,12 +1110,14 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     MX_REQUIRE(total >= 0 && total * 8 <= (long long)INT_MAX * 4LL, "spmm plan: too many steps (%lld)", total);
     MX_REQUIRE(total <= (long long)INT_MAX, "spmm plan: step offsets exceed int32");
     pl->total_steps = total;
+    if (max_pad_ratio > 0.0 && (double)total * 8.0 > (double)pl->nnz * max_pad_ratio + 65536.0) return 0;
     const size_t slots = (size_t)total * 8 + PLAN_TAIL_SLOTS;
     if (grow((void **)&pl->pcol, &pl->pcol_cap, slots * 4)) return 1;
     if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
     hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
                        values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off);
     MX_LAUNCH_CHECK();
+    pl->ready = true;
     return 0;
 }
 
@@ -1278,6 +1284,7 @@ extern "C" int mxd_spmm_plan_run(const mx_spmm_plan *pl, int n, const void *B, s
                                  int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream)
 {
     MX_REQUIRE(pl && n >= 0, "mxd_spmm_plan_run: bad arguments");
+    MX_REQUIRE(pl->ready, "mxd_spmm_plan_run: the plan was sized but not built");
     if (pl->m == 0 || n == 0) return 0;
     MX_REQUIRE(B && C, "mxd_spmm_plan_run: null pointer");
     hipStream_t st = mx::as_stream(stream);
@@ -1327,10 +1334,13 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
     if (algo == MX_SPMM_PLANNED) {
         MX_REQUIRE(ok, "mxd_spmm_csr_dense_ex: operands do not meet the planned kernel's 16-byte alignment rules");
         mx_spmm_plan *&auto_plan = mx::g_auto_plan;                  // buffers re-used from call to call (grow-only)
-        if (mxd_spmm_plan_create(m, K, indptr, indices, values, npanels, stream, &auto_plan)) return 1;
-        // rows of very uneven length pad the 8-way interleave (an octet is as long as its longest bundle): when the
-        // plan would be more than 1.5x the CSR the row-wave kernel is the better choice
-        if (!auto_pick_planned || auto_plan->total_steps * 8 <= auto_plan->nnz + auto_plan->nnz / 2 + 65536)
+        if (!auto_plan) auto_plan = new (std::nothrow) mx_spmm_plan();
+        MX_REQUIRE(auto_plan, "out of host memory");
+        // Measured with log-normal row lengths (tools/skew_probe.py): up to ~1.8x the CSR the planned sweep still
+        // beats the row-wave kernel even with the plan built per call; beyond that AUTO stops after the sizing pass
+        // (count + scan, ~0.1 ms) and uses the row-wave kernel.
+        if (mx::plan_build(auto_plan, m, K, indptr, indices, values, npanels, st, auto_pick_planned ? 1.75 : 0.0)) return 1;
+        if (auto_plan->ready)
             return mxd_spmm_plan_run(auto_plan, n, B, ldb, C, ldc, dense_dtype, colmajor_out, 0, -1, stream);
         algo = MX_SPMM_ROWWAVE;
     }

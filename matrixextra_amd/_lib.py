@@ -13,7 +13,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmxgpu.so")
+LIB_PATH = os.environ.get("MXGPU_LIB") or os.path.join(_HERE, "libmxgpu.so")      # MXGPU_LIB: A/B another build
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mxgpu.h")
 
 # mx_dtype / mx_merge_op (include/mxgpu.h)

@@ -654,37 +654,108 @@ __device__ __forceinline__ int panel_of(int col, int panel_cols, float inv_pc, i
     return q < npanels ? q : npanels - 1;
 }
 
+// Which of the octet's 64 rows sits in which (bundle, local row) slot.  Consecutive rows (slot = row offset) when that
+// is balanced; otherwise the rows are sorted by length (bitonic sort inside the wavefront) and dealt to the bundles in
+// serpentine order, which keeps the longest bundle — the octet's length, everything shorter is padding — close to
+// the mean.  Log-normal row lengths (sigma 1) pad the plan 1.84x with consecutive rows.  Every wavefront of the
+// workgroup computes the same answer from the same 65 row pointers: no LDS, no synchronisation.
+// Returns the row offset (0..63) assigned to slot `lane`.
+__device__ __forceinline__ int octet_assign(int m, const int32_t *__restrict__ indptr, int oct, int lane,
+                                            int &ptr_out, int &len_out)
+{
+    const long long row = (long long)oct * PLAN_OCT_ROWS + lane;
+    const int ptr = indptr[row < m ? row : m];                       // one load per lane + the octet's end pointer
+    const int pend = indptr[(long long)(oct + 1) * PLAN_OCT_ROWS < m ? (long long)(oct + 1) * PLAN_OCT_ROWS : m];
+    const int nxt = __shfl_down(ptr, 1, 64);
+    const int len = (lane == 63 ? pend : nxt) - ptr;
+    ptr_out = ptr;                                                   // row `lane` of the octet: [ptr, ptr + len)
+    len_out = len;
+    if (__ballot(len != __builtin_amdgcn_readfirstlane(len)) == 0ULL) return lane;     // all rows equally long
+    int idsum = len;                                                 // sum of my bundle with consecutive rows
+    idsum += __shfl_xor(idsum, 1, 64); idsum += __shfl_xor(idsum, 2, 64); idsum += __shfl_xor(idsum, 4, 64);
+    int idmax = idsum;
+    idmax = max(idmax, __shfl_xor(idmax, 8, 64)); idmax = max(idmax, __shfl_xor(idmax, 16, 64));
+    idmax = max(idmax, __shfl_xor(idmax, 32, 64));
+    // no assignment can beat ceil(total / 8): consecutive rows that already reach it (in whole chunks of 32 steps) stay
+    int total = idsum;
+    total += __shfl_xor(total, 8, 64); total += __shfl_xor(total, 16, 64); total += __shfl_xor(total, 32, 64);
+    if (((idmax + 31) >> 5) <= ((((total + 7) >> 3) + 31) >> 5)) return lane;          // wave-uniform
+    // descending bitonic sort of (length, lower row first)
+    unsigned long long key = ((unsigned long long)(unsigned)len << 6) | (unsigned)(63 - lane);
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const unsigned long long other = __shfl_xor(key, j, 64);
+            const bool keep_max = (((lane & k) == 0) == ((lane & j) == 0));   // descending overall
+            key = keep_max ? (key > other ? key : other) : (key < other ? key : other);
+        }
+    }
+    const int slen = (int)(key >> 6), sidx = 63 - (int)(key & 63);   // lane r: r-th longest row
+    // serpentine deal: rank r = 8k + pos goes to bundle (k even ? pos : 7 - pos), local row k
+    const int my_b = lane >> 3, my_k = lane & 7;                     // lane seen as slot (bundle, local row)
+    const int my_rank = my_k * 8 + ((my_k & 1) ? 7 - my_b : my_b);
+    int balsum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) balsum += __shfl(slen, k * 8 + ((k & 1) ? 7 - my_b : my_b), 64);
+    int balmax = balsum;
+    balmax = max(balmax, __shfl_xor(balmax, 8, 64)); balmax = max(balmax, __shfl_xor(balmax, 16, 64));
+    balmax = max(balmax, __shfl_xor(balmax, 32, 64));
+    const int dealt = __shfl(sidx, my_rank, 64);
+    // only when it shortens the octet by a whole chunk of 32 steps (uniform matrices keep consecutive rows)
+    const bool permute = ((balmax + 31) >> 5) < ((idmax + 31) >> 5);
+    return permute ? dealt : lane;
+}
+
 __global__ __launch_bounds__(512)
 void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
                        const int32_t *__restrict__ indices, int32_t *__restrict__ steps,
-                       int32_t *__restrict__ bpo, int noct, long long *__restrict__ nnz_out)
+                       int32_t *__restrict__ bpo, int noct, long long *__restrict__ nnz_out,
+                       unsigned char *__restrict__ rowmap)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *nnz_out = indptr[m];     // rides back with the step total (one copy)
     __shared__ int totals[8];
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int oct = blockIdx.x;
-    const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
-    const int r0 = min(row0, m), r1 = min(row0 + PLAN_RB, m);
-    const int s = indptr[r0], e = indptr[r1];
+    int rptr, rlen;                                                  // row pointers of the octet, one row per lane
+    const int rowof = octet_assign(m, indptr, oct, lane, rptr, rlen);
+    const bool identity = __ballot(rowof != lane) == 0ULL;
+    if (g == 0) rowmap[(size_t)oct * PLAN_OCT_ROWS + lane] = (unsigned char)rowof;
     int mine = 0;                                                    // lane p accumulates the count of panel p (+64, ...)
+    int total_b = 0;
     const float inv_pc = 1.0f / (float)panel_cols;
     // PLAN_LD chunks of 64 entries per pass: the loads of a pass are issued together (the kernel is latency-bound:
     // a bundle is only ~256 entries)
-    for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
-        int col[PLAN_LD];
+    auto count_range = [&](int s, int e) {
+        total_b += e - s;
+        for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
+            int col[PLAN_LD];
 #pragma unroll
-        for (int c = 0; c < PLAN_LD; c++) {
-            const int k = k0 + 64 * c + lane;
-            col[c] = k < e ? indices[k] : -1;
-        }
-#pragma unroll
-        for (int c = 0; c < PLAN_LD; c++) {
-            if (k0 + 64 * c >= e) break;                             // uniform
-            const int pan = col[c] >= 0 ? panel_of(col[c], panel_cols, inv_pc, npanels) : -1;
-            for (int q = 0; q < npanels; q++) {
-                const int cnt = __popcll(__ballot(pan == q));
-                if (lane == (q & 63)) mine += cnt;                   // npanels <= 64: one lane per panel
+            for (int c = 0; c < PLAN_LD; c++) {
+                const int k = k0 + 64 * c + lane;
+                col[c] = k < e ? indices[k] : -1;
             }
+#pragma unroll
+            for (int c = 0; c < PLAN_LD; c++) {
+                if (k0 + 64 * c >= e) break;                         // uniform
+                const int pan = col[c] >= 0 ? panel_of(col[c], panel_cols, inv_pc, npanels) : -1;
+                for (int q = 0; q < npanels; q++) {
+                    const int cnt = __popcll(__ballot(pan == q));
+                    if (lane == (q & 63)) mine += cnt;               // npanels <= 64: one lane per panel
+                }
+            }
+        }
+    };
+    if (identity) {                                                  // 8 consecutive rows: one contiguous range
+        const int s = __shfl(rptr, g * PLAN_RB, 64);
+        const int e = __shfl(rptr, g * PLAN_RB + PLAN_RB - 1, 64) + __shfl(rlen, g * PLAN_RB + PLAN_RB - 1, 64);
+        count_range(s, e);
+    } else {                                                         // my 8 rows, in local-row order
+#pragma unroll
+        for (int r = 0; r < PLAN_RB; r++) {
+            const int rr = __shfl(rowof, g * PLAN_RB + r, 64);
+            const int s = __shfl(rptr, rr, 64);
+            count_range(s, s + __shfl(rlen, rr, 64));
         }
     }
     // exclusive prefix over the panels (lanes 0..npanels-1)
@@ -695,7 +766,7 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
         if (lane >= off) incl += up;
     }
     if (lane < npanels) bpo[((size_t)oct * 8 + g) * npanels + lane] = incl - mine;
-    if (lane == 0) totals[g] = e - s;
+    if (lane == 0) totals[g] = total_b;
     __syncthreads();
     if (threadIdx.x == 0) {
         int mx = 0;
@@ -711,7 +782,7 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
                       const int32_t *__restrict__ indices, const double *__restrict__ values,
                       const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
                       int32_t *__restrict__ pcol, double *__restrict__ pval, int noct, int pad_col,
-                      int32_t *__restrict__ step_off)
+                      int32_t *__restrict__ step_off, const unsigned char *__restrict__ rowmap)
 {
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int oct = blockIdx.x;
@@ -723,62 +794,83 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
         step_off[(size_t)oct * npanels + lane] = oct_off[oct] + (lane == 0 ? 0 : sum / 8);
         if (oct == noct - 1 && lane == 0) step_off[(size_t)noct * npanels] = oct_off[noct];
     }
-    const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
-    int rp[PLAN_RB + 1];                                             // the bundle's row pointers (wave-uniform)
-#pragma unroll
-    for (int r = 0; r <= PLAN_RB; r++) rp[r] = uniform(indptr[min(row0 + r, m)]);
-    const int s = rp[0], e = rp[PLAN_RB];
+    const int rowof = rowmap[(size_t)oct * PLAN_OCT_ROWS + lane];    // written by the count pass (octet_assign)
+    const bool identity = __ballot(rowof != lane) == 0ULL;
     const long long base = oct_off[oct];
     // lane q keeps the next free step of panel q's stream
     int nextstep = lane < npanels ? bpo[((size_t)oct * 8 + g) * npanels + lane] : 0;
     const unsigned long long below = (1ULL << lane) - 1ULL;
     const float inv_pc = 1.0f / (float)panel_cols;
-    for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
-        int colv[PLAN_LD];
-        double av[PLAN_LD];
+    int total_b = 0, last_lrow = 0;
+    // entries [s, e) of the CSR arrays; local row of entry k = lrow0 + #(bounds rp[1..7] <= k)  (rp = INT_MAX: none)
+    auto fill_range = [&](int s, int e, int lrow0, const int (&rp)[PLAN_RB + 1]) {
+        total_b += e - s;
+        for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
+            int colv[PLAN_LD];
+            double av[PLAN_LD];
 #pragma unroll
-        for (int c = 0; c < PLAN_LD; c++) {                          // all loads of the pass in flight together
-            const int k = k0 + 64 * c + lane;
-            colv[c] = -1; av[c] = 0.0;
-            if (k < e) { colv[c] = indices[k]; av[c] = values[k]; }
-        }
-#pragma unroll
-        for (int c = 0; c < PLAN_LD; c++) {
-            if (k0 + 64 * c >= e) break;                             // uniform
-            const int k = k0 + 64 * c + lane;
-            const int col = colv[c];
-            int pan = -1, lrow = 0;
-            if (col >= 0) {
-                pan = panel_of(col, panel_cols, inv_pc, npanels);
-#pragma unroll
-                for (int r = 1; r < PLAN_RB; r++) lrow += k >= rp[r];
+            for (int c = 0; c < PLAN_LD; c++) {                      // all loads of the pass in flight together
+                const int k = k0 + 64 * c + lane;
+                colv[c] = -1; av[c] = 0.0;
+                if (k < e) { colv[c] = indices[k]; av[c] = values[k]; }
             }
-            for (int q = 0; q < npanels; q++) {
-                const unsigned long long same = __ballot(pan == q);
-                if (same == 0ULL) continue;                          // uniform
-                const int start = __shfl(nextstep, q & 63, 64);
-                if (pan == q) {
-                    // slot layout inside a batch of 8 steps: [bundle g][step u] — lane 8g+u of the reading wavefront
-                    // holds bundle g's entry for step u, i.e. inside g's own lane group (intra-group DPP broadcast)
-                    const long long t = start + __popcll(same & below);      // step inside the octet
-                    const long long dst = (base + (t & ~7LL)) * 8 + g * 8 + (t & 7);
-                    pcol[dst] = col | (lrow << PLAN_ROW_SHIFT);
-                    pval[dst] = av[c];
+#pragma unroll
+            for (int c = 0; c < PLAN_LD; c++) {
+                if (k0 + 64 * c >= e) break;                         // uniform
+                const int k = k0 + 64 * c + lane;
+                const int col = colv[c];
+                int pan = -1, lrow = lrow0;
+                if (col >= 0) {
+                    pan = panel_of(col, panel_cols, inv_pc, npanels);
+#pragma unroll
+                    for (int r = 1; r < PLAN_RB; r++) lrow += k >= rp[r];
                 }
-                if (lane == (q & 63)) nextstep += __popcll(same);
+                for (int q = 0; q < npanels; q++) {
+                    const unsigned long long same = __ballot(pan == q);
+                    if (same == 0ULL) continue;                      // uniform
+                    const int start = __shfl(nextstep, q & 63, 64);
+                    if (pan == q) {
+                        // slot layout inside a batch of 8 steps: [bundle g][step u] — lane 8g+u of the reading
+                        // wavefront holds bundle g's entry for step u, i.e. inside g's own lane group (DPP broadcast)
+                        const long long t = start + __popcll(same & below);      // step inside the octet
+                        const long long dst = (base + (t & ~7LL)) * 8 + g * 8 + (t & 7);
+                        pcol[dst] = col | (lrow << PLAN_ROW_SHIFT);
+                        pval[dst] = av[c];
+                    }
+                    if (lane == (q & 63)) nextstep += __popcll(same);
+                }
             }
+        }
+    };
+    if (identity) {
+        const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
+        int rp[PLAN_RB + 1];                                         // the bundle's row pointers (wave-uniform)
+#pragma unroll
+        for (int r = 0; r <= PLAN_RB; r++) rp[r] = uniform(indptr[min(row0 + r, m)]);
+        fill_range(rp[0], rp[PLAN_RB], 0, rp);
+        if (rp[PLAN_RB] > rp[0]) {
+#pragma unroll
+            for (int r = 1; r < PLAN_RB; r++) last_lrow += (rp[PLAN_RB] - 1) >= rp[r];
+        }
+    } else {
+        const int rr = __shfl(rowof, g * PLAN_RB + (lane & 7), 64);
+        const long long row = (long long)oct * PLAN_OCT_ROWS + rr;
+        const int ps = row < m ? indptr[row] : 0, pe = row < m ? indptr[row + 1] : 0;
+        int none[PLAN_RB + 1];
+#pragma unroll
+        for (int r = 0; r <= PLAN_RB; r++) none[r] = INT_MAX;
+#pragma unroll
+        for (int r = 0; r < PLAN_RB; r++) {
+            const int s = uniform(__shfl(ps, r, 64)), e = uniform(__shfl(pe, r, 64));
+            fill_range(s, e, r, none);
+            if (e > s) last_lrow = r;
         }
     }
     // Padding up to the octet's length: a no-op entry — value 0, column `pad_col` (the all-zero extra row of the
     // packed B), row = the bundle's last entry's row so that it does not even trigger a row switch.  0 * 0 added to
     // an accumulator that is never -0.0 leaves it unchanged bit for bit.
-    int last_lrow = 0;
-    if (e > s) {
-#pragma unroll
-        for (int r = 1; r < PLAN_RB; r++) last_lrow += (e - 1) >= rp[r];
-    }
     const int steps_oct = oct_off[oct + 1] - (int)base;
-    for (long long t = (e - s) + lane; t < steps_oct; t += 64) {
+    for (long long t = total_b + lane; t < steps_oct; t += 64) {
         const long long dst = (base + (t & ~7LL)) * 8 + g * 8 + (t & 7);
         pcol[dst] = pad_col | (last_lrow << PLAN_ROW_SHIFT);
         pval[dst] = 0.0;
@@ -835,7 +927,7 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                       const int32_t *__restrict__ pcol, const double *__restrict__ pval,
                       const real_t *__restrict__ Bp, size_t slab_stride,
                       real_t *__restrict__ C, size_t ldc, int nslabs, int ngens, int noct, int pad_col,
-                      unsigned *__restrict__ sync_ctr, int sync_mode)
+                      unsigned *__restrict__ sync_ctr, int sync_mode, const unsigned char *__restrict__ rowmap)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
     constexpr int W = SLAB_GROUP * VEC;
@@ -878,14 +970,19 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
         // plan entries stay in flight).  Across the 32 CUs of the XCD group there is ONE global timing barrier per
         // generation (32 pollers per counter); in between the CUs run identical code on statistically identical
         // data and drift by a fraction of a panel.
+        int rowof = lane;
         {
             if (sync_mode >= 2) xcd_timing_barrier(my_ctr, (unsigned)(it + 1) * (unsigned)nwg);
+            // The octet's stream bounds and its slot -> row map (identity unless the plan balanced the bundles; used by
+            // the epilogue only) are requested AFTER the barrier: a load in flight at a barrier makes all 16 wavefronts
+            // wait for the slowest one (measured: +0.03 ms per launch for each of the two).
             int sbeg = 0, send = 0, next_b = 0;
             if (oct_ok) {
                 sbeg = step_off[(size_t)oct * npanels];
                 send = step_off[(size_t)oct * npanels + npanels];
                 next_b = npanels > 1 ? step_off[(size_t)oct * npanels + 1] : send;
             }
+            rowof = oct_ok ? (int)rowmap[(size_t)oct * PLAN_OCT_ROWS + lane] : lane;
             sbeg = __builtin_amdgcn_readfirstlane(sbeg);            // wave-uniform: keep the loop control scalar
             send = __builtin_amdgcn_readfirstlane(send);
             next_b = __builtin_amdgcn_readfirstlane(next_b);
@@ -989,15 +1086,16 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                 for (; p < npanels - 1; p++) __syncthreads();           // every wave meets npanels-1 times per generation
         }
 
-        // each wavefront writes the 64 x W tile of C it accumulated (streaming stores: C is not read again)
+        // each wavefront writes the 64 x W tile of C it accumulated (streaming stores: C is not read again); slot ->
+        // row through the octet's row map (identity unless the plan balanced the bundles)
         if (oct_ok) {
-            const int row_base = gen * PLAN_WG_ROWS + wave * PLAN_OCT_ROWS;
+            const int row_base = oct * PLAN_OCT_ROWS;
             const int ncols = min(W, n - slab * W);
             if constexpr (!COLMAJOR) {
 #pragma unroll
                 for (int rr = 0; rr < PLAN_OCT_ROWS / 8; rr++) {
-                    const int r = rr * 8 + g;
-                    const int row = row_base + r;
+                    const int r = rr * 8 + g;                        // slot
+                    const int row = row_base + __shfl(rowof, r, 64);
                     if (row < m && lg * VEC < ncols) {
                         real_t t[VEC];
 #pragma unroll
@@ -1006,8 +1104,8 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                     }
                 }
             } else {
-                // lane = row: one 512-byte (f64) segment of an output column per store instruction
-                const int row = row_base + lane;
+                // lane = slot: the 64 rows of the octet are one 512-byte (f64) segment of an output column
+                const int row = row_base + rowof;
                 if (row < m) {
                     for (int c = 0; c < ncols; c++)
                         __builtin_nontemporal_store(my_oct[(size_t)lane * S + c], &C[(size_t)(slab * W + c) * ldc + row]);
@@ -1031,6 +1129,7 @@ struct mx_spmm_plan {
     int32_t *step_off = nullptr; size_t step_off_cap = 0;
     int32_t *pcol = nullptr;     size_t pcol_cap = 0;
     double *pval = nullptr;      size_t pval_cap = 0;
+    unsigned char *rowmap = nullptr; size_t rowmap_cap = 0;    // [noct][64]: slot -> row offset inside the octet
     void *scratch = nullptr;     size_t scratch_cap = 0;       // rowpre + steps + scan workspace (build only)
     double build_ms = 0.0;
     bool ready = false;                                            // false: sized but not filled (rejected by AUTO)
@@ -1087,6 +1186,7 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     const size_t rb_b = 256;                                        // [total steps][nnz], read back in one copy
     if (grow(&pl->scratch, &pl->scratch_cap, steps_b + octoff_b + bpo_b + rb_b + scan_workspace_bytes((int64_t)pl->noct))) return 1;
     if (grow((void **)&pl->step_off, &pl->step_off_cap, (nop + 1) * 4)) return 1;
+    if (grow((void **)&pl->rowmap, &pl->rowmap_cap, (size_t)pl->noct * PLAN_OCT_ROWS)) return 1;
     int32_t *steps = (int32_t *)pl->scratch;
     int32_t *oct_off = (int32_t *)((char *)steps + steps_b);
     int32_t *bpo = (int32_t *)((char *)oct_off + octoff_b);
@@ -1094,7 +1194,7 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     void *scan_ws = (char *)rb_dev + rb_b;
     const unsigned blocks = (unsigned)pl->noct;
     hipLaunchKernelGGL(plan_count_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       steps, bpo, pl->noct, rb_dev + 1);
+                       steps, bpo, pl->noct, rb_dev + 1, pl->rowmap);
     MX_LAUNCH_CHECK();
     if (exclusive_scan_i32(steps, (int64_t)pl->noct, oct_off, (int64_t *)rb_dev, scan_ws, st)) return 1;
     PlanReadback *rb = plan_readback();
@@ -1115,7 +1215,7 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     if (grow((void **)&pl->pcol, &pl->pcol_cap, slots * 4)) return 1;
     if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
     hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off);
+                       values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->rowmap);
     MX_LAUNCH_CHECK();
     pl->ready = true;
     return 0;
@@ -1192,7 +1292,7 @@ static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, 
 #define MX_PLAN_LAUNCH(CM, WV)                                                                                           \
     hipLaunchKernelGGL((spmm_plan_kernel<real_t, CM, WV>), dim3((unsigned)grid), dim3(WV * 64), 0, st, m, n, pl->npanels, \
                        pl->step_off, pl->pcol, pl->pval, Bp, (size_t)Kp * W, C, ldc, nslabs, ngens, pl->noct, K,         \
-                       sync, sync_mode)
+                       sync, sync_mode, pl->rowmap)
     if (colmajor) {
         if (waves == 16) MX_PLAN_LAUNCH(true, 16); else if (waves == 8) MX_PLAN_LAUNCH(true, 8); else MX_PLAN_LAUNCH(true, 4);
     } else {
@@ -1238,6 +1338,7 @@ extern "C" int mxd_spmm_plan_destroy(mx_spmm_plan *pl)
     if (pl->pcol) (void)hipFree(pl->pcol);
     if (pl->pval) (void)hipFree(pl->pval);
     if (pl->scratch) (void)hipFree(pl->scratch);
+    if (pl->rowmap) (void)hipFree(pl->rowmap);
     delete pl;
     return 0;
 }

@@ -502,6 +502,31 @@ def test_spmm_planned_edge_shapes(gpu):
     np.testing.assert_allclose(spmm_planned_device(p, j, x, B, True, npanels=2), (6 * B[3] + 4 * B[1])[None, :], rtol=1e-15)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("colmajor", [True, False])
+def test_spmm_planned_balanced_bundles(gpu, dtype, colmajor):
+    """Rows of very uneven length: the plan deals each octet's 64 rows to its 8 bundles by length (serpentine over
+    the sorted rows) and the kernel writes C through the octet's slot -> row map.  Shapes cover a last octet that is
+    cut by m, empty rows, one row far longer than the rest of its octet, and rows shorter than one batch."""
+    from devmem import spmm_planned_device
+    rng = np.random.default_rng(99)
+    K, n = 500, 32
+    for m in (64, 130, 1000, 1027):
+        lens = np.floor(rng.lognormal(1.5, 1.3, size=m)).astype(np.int64)
+        lens[rng.random(m) < 0.1] = 0
+        lens[m // 2] = 700                                           # > K: duplicate columns, one dominant row
+        p = np.zeros(m + 1, dtype=np.int32); p[1:] = np.cumsum(lens)
+        j = rng.integers(0, K, size=int(p[-1]), dtype=np.int32)     # unsorted, repeats allowed (SpMM does not care)
+        x = rng.uniform(-1, 1, size=int(p[-1])).round(3)
+        B = synth.dense_normal(K, n, dtype=dtype)
+        ref = np.zeros((m, n))
+        np.add.at(ref, np.repeat(np.arange(m), lens), x[:, None] * B[j].astype(np.float64))
+        for npanels in (1, 3):
+            got = spmm_planned_device(p, j, x, B, colmajor, npanels=npanels)
+            tol = 1e-12 if dtype == np.float64 else 2e-4
+            np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * 50)
+
+
 # ----------------------------------------------------------------------------- CSR (op) dense vector (§8f rank 4)
 DV_FLAGS = {"mul": (1, 0, 0, 0, 0), "pow": (0, 1, 0, 0, 0), "div": (0, 0, 1, 0, 0), "mod": (0, 0, 0, 1, 0), "idiv": (0, 0, 0, 0, 1)}
 

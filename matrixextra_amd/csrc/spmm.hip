@@ -976,16 +976,18 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             // The octet's stream bounds and its slot -> row map (identity unless the plan balanced the bundles; used by
             // the epilogue only) are requested AFTER the barrier: a load in flight at a barrier makes all 16 wavefronts
             // wait for the slowest one (measured: +0.03 ms per launch for each of the two).
-            int sbeg = 0, send = 0, next_b = 0;
+            // All panel boundaries of the octet come in with ONE load (lane p holds the start of the p-th panel) and
+            // are picked out with v_readlane when the stream crosses a panel: a load at every boundary had to be
+            // waited for with vmcnt(0), i.e. it drained the whole B-line pipeline once per panel.
+            int bounds = 0, send = 0;
             if (oct_ok) {
-                sbeg = step_off[(size_t)oct * npanels];
+                bounds = step_off[(size_t)oct * npanels + (lane < npanels ? lane : 0)];
                 send = step_off[(size_t)oct * npanels + npanels];
-                next_b = npanels > 1 ? step_off[(size_t)oct * npanels + 1] : send;
             }
             rowof = oct_ok ? (int)rowmap[(size_t)oct * PLAN_OCT_ROWS + lane] : lane;
-            sbeg = __builtin_amdgcn_readfirstlane(sbeg);            // wave-uniform: keep the loop control scalar
+            int sbeg = __builtin_amdgcn_readfirstlane(bounds);      // wave-uniform: keep the loop control scalar
             send = __builtin_amdgcn_readfirstlane(send);
-            next_b = __builtin_amdgcn_readfirstlane(next_b);
+            int next_b = npanels > 1 ? __builtin_amdgcn_readlane(bounds, 1) : send;
             int p = 0;
             int cur = 0;
             real_t acc[VEC];
@@ -1072,7 +1074,7 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                         while (p < npanels - 1 && sn >= next_b) {   // the stream moved into the next panel
                             p++;
                             __syncthreads();
-                            next_b = __builtin_amdgcn_readfirstlane(p < npanels - 1 ? step_off[(size_t)oct * npanels + p + 1] : send);
+                            next_b = p < npanels - 1 ? __builtin_amdgcn_readlane(bounds, p + 1) : send;
                         }
                     }
                 }

@@ -634,6 +634,7 @@ constexpr int PLAN_OCT_ROWS = PLAN_RB * 8;         // rows per octet (one wavefr
 // 8 = two 512-thread workgroups with 64 KiB each (one's epilogue overlaps the other's sweep), 4 = four.
 constexpr int PLAN_MAXP = 64;
 constexpr int PLAN_DEFAULT_WG_PER_CU = 1;
+constexpr int PLAN_GEN_OCTS = 16;                  // octets one 16-wavefront workgroup sweeps together
 constexpr int PLAN_CHUNK = 4;                      // batches of 8 steps fetched per plan read (octets are whole chunks)
 constexpr int PLAN_TAIL_SLOTS = 512;               // readable padding behind the last octet (2 chunks)
 constexpr int PLAN_ROW_SHIFT = 27;                 // col < 2^27
@@ -786,12 +787,24 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
 {
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int oct = blockIdx.x;
-    // panel boundaries of the octet for the kernel's panel meetings: mean start of the panel over the 8 bundles
+    // Where the kernel's wavefronts meet (locality only, any value is correct): the 16 octets that one workgroup
+    // sweeps together share the panel boundaries, as fractions of each octet's own length — the mean panel start over
+    // the 128 bundles of the group.  With per-octet boundaries every meeting waited for the wavefront whose panel
+    // happened to be longest (entries per octet and panel vary by ~4 %: the sum of the 5 maxima is ~8 % more than the
+    // common length); with shared boundaries equally long octets arrive together.
     if (g == 0 && lane < npanels) {
-        int sum = 0;
+        const int o0 = (oct / PLAN_GEN_OCTS) * PLAN_GEN_OCTS, o1 = min(o0 + PLAN_GEN_OCTS, noct);
+        long long sum = 0;
+        for (int o = o0; o < o1; o++) {
 #pragma unroll
-        for (int gg = 0; gg < 8; gg++) sum += bpo[((size_t)oct * 8 + gg) * npanels + lane];
-        step_off[(size_t)oct * npanels + lane] = oct_off[oct] + (lane == 0 ? 0 : sum / 8);
+            for (int gg = 0; gg < 8; gg++) sum += bpo[((size_t)o * 8 + gg) * npanels + lane];
+        }
+        const long long len = (long long)oct_off[o1] - oct_off[o0];                     // sum of the octets' lengths
+        const int mine = oct_off[oct + 1] - oct_off[oct];
+        const double frac = len > 0 ? (double)sum / (8.0 * (double)len) : 0.0;
+        int b = lane == 0 ? 0 : (int)(frac * (double)mine);
+        if (b > mine) b = mine;
+        step_off[(size_t)oct * npanels + lane] = oct_off[oct] + b;
         if (oct == noct - 1 && lane == 0) step_off[(size_t)noct * npanels] = oct_off[noct];
     }
     const int rowof = rowmap[(size_t)oct * PLAN_OCT_ROWS + lane];    // written by the count pass (octet_assign)
@@ -1173,7 +1186,9 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
 {
     pl->ready = false;
     MX_REQUIRE(K < (1 << 25), "spmm plan: more than 2^25 columns (32-bit slab offsets)");
-    if (npanels <= 0) npanels = pick_panels(K, (size_t)2600 << 10);     // measured (cfg2): kernel alone is best at 1.6 MB panels (P=8), kernel + plan build at 2.6 MB (P=5)
+    // measured (cfg2, after the shared panel boundaries): 1.6 MB panels (P = 8) are best for the kernel (1.77 vs 1.86 ms at
+    // P = 5) and, by a hair, for kernel + plan build
+    if (npanels <= 0) npanels = pick_panels(K, (size_t)1664 << 10);
     if (npanels > PLAN_MAXP) npanels = PLAN_MAXP;
     pl->m = m; pl->K = K; pl->npanels = npanels;
     pl->panel_cols = (int)ceil_div(K > 0 ? K : 1, npanels);

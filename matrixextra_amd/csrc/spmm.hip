@@ -960,6 +960,15 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
     real_t *const my_oct = accs + (size_t)wave * PLAN_OCT_ROWS * S;                     // this wavefront's 64 rows
     real_t *const my_rows = my_oct + (size_t)g * PLAN_RB * S + lg * VEC;                // this group's bundle
 
+    // Carried from one generation to the next: the stream bounds, the row map and the FIRST chunk of plan slots of the
+    // wavefront's next octet are requested during the last chunk of the current one, so that a generation does not
+    // start with two exposed memory latencies (bounds, then the first chunk: ~3-4 us of a ~58 us generation).
+    bool primed = false;                                            // wave-uniform
+    int bounds_c = 0, send_c = 0, rowof_c = 0;
+    int rc[PLAN_CHUNK];
+    double rv[PLAN_CHUNK];
+#pragma unroll
+    for (int k = 0; k < PLAN_CHUNK; k++) { rc[k] = 0; rv[k] = 0.0; }
     for (int it = 0; it < niter; it++) {
         const long long item_raw = lo + wg + (long long)it * nwg;
         const bool have = item_raw < hi;
@@ -967,6 +976,10 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
         const int slab = (int)(item / ngens), gen = (int)(item % ngens);
         const int oct = gen * PLAN_WAVES + wave;
         const bool oct_ok = have && oct < noct;
+        // this wavefront's octet of the next generation (if any)
+        const long long item_n = item_raw + nwg;
+        const int oct_n = (int)(item_n % ngens) * PLAN_WAVES + wave;
+        const bool octn_ok = it + 1 < niter && item_n < hi && oct_n < noct;
         // slab base is wave-uniform (scalar registers), the per-lane part is a 32-bit byte offset: one VALU op per
         // address.  A slab is K x 128 B < 4 GiB because K < 2^27... checked on the host (K * 128 < 2^32).
         const char *__restrict__ Bbase = reinterpret_cast<const char *>(Bp + (size_t)slab * slab_stride);
@@ -993,11 +1006,13 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             // are picked out with v_readlane when the stream crosses a panel: a load at every boundary had to be
             // waited for with vmcnt(0), i.e. it drained the whole B-line pipeline once per panel.
             int bounds = 0, send = 0;
-            if (oct_ok) {
+            if (primed) {                                           // requested during the previous generation
+                bounds = bounds_c; send = send_c; rowof = rowof_c;
+            } else if (oct_ok) {
                 bounds = step_off[(size_t)oct * npanels + (lane < npanels ? lane : 0)];
                 send = step_off[(size_t)oct * npanels + npanels];
+                rowof = (int)rowmap[(size_t)oct * PLAN_OCT_ROWS + lane];
             }
-            rowof = oct_ok ? (int)rowmap[(size_t)oct * PLAN_OCT_ROWS + lane] : lane;
             int sbeg = __builtin_amdgcn_readfirstlane(bounds);      // wave-uniform: keep the loop control scalar
             send = __builtin_amdgcn_readfirstlane(send);
             int next_b = npanels > 1 ? __builtin_amdgcn_readlane(bounds, 1) : send;
@@ -1023,8 +1038,8 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             // iteration (measured: 1.95 us per 8 steps per wave, whatever the locality of B).  Now it is paid once
             // per 32 steps.  Reads run one chunk past the octet (next octet's slots / the padding behind the last
             // octet): they only ever become addresses of valid B lines, never FMAs.
-            int rc[PLAN_CHUNK], rn[PLAN_CHUNK];
-            double rv[PLAN_CHUNK], rvn[PLAN_CHUNK];
+            int rn[PLAN_CHUNK];
+            double rvn[PLAN_CHUNK];
             auto load_chunk = [&](int step, int (&c)[PLAN_CHUNK], double (&v)[PLAN_CHUNK]) {
                 const long long e = (long long)step * 8 + lane;
 #pragma unroll
@@ -1059,7 +1074,7 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                 __builtin_amdgcn_sched_barrier(0);
             };
             if (send > sbeg) {
-                load_chunk(sbeg, rc, rv);
+                if (!primed) load_chunk(sbeg, rc, rv);
                 // the first chunk has to be there before anything can start; with it complete at loop entry the
                 // compiler's vmcnt bookkeeping is exact on both edges of the loop
 #pragma unroll
@@ -1069,8 +1084,24 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             // the line of the same step of batch t+1 is requested into the registers the FMA just released, so 8
             // B-line loads per wavefront are in flight all the time.  The first pass consumes the no-op batch set up
             // above, the last batch is consumed after the loop.
+            bool meta = false;                                      // next octet's bounds / row map requested
+            primed = false;
             for (int s = sbeg; s < send; s += U * PLAN_CHUNK) {      // sbeg, send are wave-uniform
-                load_chunk(s + U * PLAN_CHUNK, rn, rvn);
+                const bool last = s + U * PLAN_CHUNK >= send;
+                if (octn_ok && !meta && s + 2 * U * PLAN_CHUNK >= send) {        // one chunk before the last, if there is one
+                    bounds_c = step_off[(size_t)oct_n * npanels + (lane < npanels ? lane : 0)];
+                    send_c = step_off[(size_t)oct_n * npanels + npanels];
+                    rowof_c = (int)rowmap[(size_t)oct_n * PLAN_OCT_ROWS + lane];
+                    meta = true;
+                }
+                // the read-ahead of the last chunk fetches the first chunk of the next octet instead of running past
+                // this one
+                int ahead = s + U * PLAN_CHUNK;
+                if (last && octn_ok) {
+                    ahead = __builtin_amdgcn_readfirstlane(bounds_c);
+                    primed = true;
+                }
+                load_chunk(ahead, rn, rvn);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < PLAN_CHUNK; k++) {

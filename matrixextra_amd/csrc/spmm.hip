@@ -838,19 +838,21 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
 #pragma unroll
                     for (int r = 1; r < PLAN_RB; r++) lrow += k >= rp[r];
                 }
+                int t = 0;                                           // my entry's step inside the octet
                 for (int q = 0; q < npanels; q++) {
                     const unsigned long long same = __ballot(pan == q);
                     if (same == 0ULL) continue;                      // uniform
-                    const int start = __shfl(nextstep, q & 63, 64);
-                    if (pan == q) {
-                        // slot layout inside a batch of 8 steps: [bundle g][step u] — lane 8g+u of the reading
-                        // wavefront holds bundle g's entry for step u, i.e. inside g's own lane group (DPP broadcast)
-                        const long long t = start + __popcll(same & below);      // step inside the octet
-                        const long long dst = (base + (t & ~7LL)) * 8 + g * 8 + (t & 7);
-                        pcol[dst] = col | (lrow << PLAN_ROW_SHIFT);
-                        pval[dst] = av[c];
-                    }
-                    if (lane == (q & 63)) nextstep += __popcll(same);
+                    const int start = __builtin_amdgcn_readlane(nextstep, q);
+                    if (pan == q) t = start + __popcll(same & below);
+                    if (lane == q) nextstep += __popcll(same);
+                }
+                if (pan >= 0) {
+                    // ONE pair of stores per chunk (inside the panel loop it was one pair per panel, each with 1/P of
+                    // the lanes).  Slot layout inside a batch of 8 steps: [bundle g][step u] — lane 8g+u of the reading
+                    // wavefront holds bundle g's entry for step u, i.e. inside g's own lane group (DPP broadcast).
+                    const long long dst = (base + (t & ~7)) * 8 + g * 8 + (t & 7);
+                    pcol[dst] = col | (lrow << PLAN_ROW_SHIFT);
+                    pval[dst] = av[c];
                 }
             }
         }

@@ -1473,7 +1473,7 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
     bool auto_pick_planned = false;
     if (algo == MX_SPMM_AUTO) {
         // Measured on MI355X, headline config (profiles/r01_*): row-wave 4.45 ms; one-panel slab kernel on the
-        // slab-major copy of B 4.05 ms; planned panel sweep 1.79 ms + 0.33 ms to build the plan from plain CSR.
+        // slab-major copy of B 4.05 ms; planned panel sweep 1.74 ms + 0.33 ms to build the plan from plain CSR.
         // AUTO = planned (plan rebuilt on every call: nothing is assumed about A between calls) when B outgrows
         // one XCD's L2 and there is enough work to fill the persistent grid, else the row-wave kernel.
         const size_t b_bytes = (size_t)K * (size_t)n * (dense_dtype == MX_F64 ? 8 : 4);

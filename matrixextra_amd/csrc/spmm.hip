@@ -1,1275 +1,13 @@
-// spmm.hip — CSR x dense SpMM for gfx950 (MI355X), hand-written HIP.
+// spmm.hip — CSR x dense SpMM for gfx950 (MI355X): the device-level entry points and the choice of kernel.
 //
 // Replaces the two OpenMP loops of the reference:
 //   gemm_csr_drm_as_drm  src/matmul.cpp:118-142  (C row-major)
 //   gemm_csr_drm_as_dcm  src/matmul.cpp:150-185  (C column-major, what R needs)
-//
-// Design (v1, "row-wave"): a workgroup of 4 wavefronts owns a tile of TR
-// consecutive rows; each wavefront walks TR/4 rows.  For one row the 64 lanes
-// span 64*VEC consecutive columns of the output, so every nonzero a_ij turns
-// into ONE fully coalesced read of B[j, slab] (1 KiB for f64 n=128 / f32
-// n=256: 16 B per lane) with the row base address in SGPRs (v_readlane of the
-// column id), followed by VEC FMAs per lane.  (j, a) of the row are loaded
-// coalesced by the wave, kept in one VGPR pair and broadcast lane by lane; the
-// next row's first chunk is prefetched while the current row streams B.
-// Accumulation runs in CSR storage order, one FMA per nonzero per column —
-// the same order as the reference's axpy loop — so results differ from an
-// FMA-enabled BLAS in nothing and from a non-FMA one by one rounding per term.
-//
-// Column-major epilogue: the tile's rows are parked in LDS (row stride odd ->
-// conflict-free transposed reads) and written out as TR-row-contiguous
-// segments per output column (256 B for f64, TR=32), instead of the
-// stride-m scatter the CPU code does with dcopy.
-//
-// Roofline: HBM-bound.  Algorithmic bytes per launch =
-//   4(m+1) + 12 nnz + s*K*n + s*m*n   (SURVEY §8d).  The gather of B rows is
-// served by L2 / Infinity Cache (B = 102 MB for the headline config).
-#include "mx_common.h"
-#include <cstdlib>
-#include <new>
+// Three kernels, one measured progression: spmm_rowwave.hip (v1, any operands), spmm_slab.hip (v2,
+// opt-in), spmm_plan.hip (v3, what AUTO runs when B outgrows an XCD's L2).
+#include "spmm_common.h"
 
 namespace mx {
-
-template <typename T, int N> struct VecT;
-template <> struct VecT<double, 1> { using type = double; };
-template <> struct VecT<double, 2> { using type = double __attribute__((ext_vector_type(2))); };
-template <> struct VecT<float, 1>  { using type = float; };
-template <> struct VecT<float, 2>  { using type = float __attribute__((ext_vector_type(2))); };
-template <> struct VecT<float, 4>  { using type = float __attribute__((ext_vector_type(4))); };
-
-template <typename real_t, int VEC>
-__device__ __forceinline__ void vload(real_t (&dst)[VEC], const real_t *__restrict__ p)
-{
-    using V = typename VecT<real_t, VEC>::type;
-    if constexpr (VEC == 1) {
-        dst[0] = *p;
-    } else {
-        const V v = *reinterpret_cast<const V *>(p);
-#pragma unroll
-        for (int i = 0; i < VEC; i++) dst[i] = v[i];
-    }
-}
-
-template <typename real_t, int VEC>
-__device__ __forceinline__ void vstore(real_t *__restrict__ p, const real_t (&src)[VEC])
-{
-    using V = typename VecT<real_t, VEC>::type;
-    if constexpr (VEC == 1) {
-        *p = src[0];
-    } else {
-        V v;
-#pragma unroll
-        for (int i = 0; i < VEC; i++) v[i] = src[i];
-        *reinterpret_cast<V *>(p) = v;
-    }
-}
-
-// streaming store: C is written once and not read again by the kernel — keep it from displacing the packed B in L2 /
-// the Infinity Cache (measured on the planned kernel: 2.05 -> 1.98 ms)
-template <typename real_t, int VEC>
-__device__ __forceinline__ void vstore_nt(real_t *__restrict__ p, const real_t (&src)[VEC])
-{
-    using V = typename VecT<real_t, VEC>::type;
-    if constexpr (VEC == 1) {
-        __builtin_nontemporal_store(src[0], p);
-    } else {
-        V v;
-#pragma unroll
-        for (int i = 0; i < VEC; i++) v[i] = src[i];
-        __builtin_nontemporal_store(v, reinterpret_cast<V *>(p));
-    }
-}
-
-__device__ __forceinline__ double mx_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-__device__ __forceinline__ float mx_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-
-static void kt_begin(hipStream_t st);
-static void kt_end(hipStream_t st);
-
-constexpr int SPMM_WAVES = 4;     // wavefronts per workgroup
-constexpr int SPMM_UNROLL = 8;    // B-row reads in flight per wavefront
-
-// one chunk of <=64 nonzeros of the current row: lane k holds (jv, av) of entry k.
-// B is wave-uniform and `col` a per-lane element offset, so each read is
-// "SGPR row base + VGPR lane offset" (global_load ... s[base], no 64-bit VALU
-// address arithmetic per nonzero).  Lanes past the last column read a clamped,
-// valid column instead of branching; their results are never stored.
-template <typename real_t, int VEC>
-__device__ __forceinline__ void spmm_chunk(int cnt, int jv, double av,
-                                           const real_t *__restrict__ B, size_t ldb, unsigned col,
-                                           real_t (&acc)[VEC])
-{
-    int k = 0;
-    for (; k + SPMM_UNROLL <= cnt; k += SPMM_UNROLL) {
-        real_t b[SPMM_UNROLL][VEC];
-#pragma unroll
-        for (int u = 0; u < SPMM_UNROLL; u++) {
-            const int j = __builtin_amdgcn_readlane(jv, k + u);
-            const real_t *__restrict__ rowp = B + (size_t)j * ldb;
-            vload<real_t, VEC>(b[u], rowp + col);
-        }
-#pragma unroll
-        for (int u = 0; u < SPMM_UNROLL; u++) {
-            const real_t a = (real_t)readlane_f64(av, k + u);   // narrowed per nonzero for f32 (matmul.cpp:53-57)
-#pragma unroll
-            for (int v = 0; v < VEC; v++) acc[v] = mx_fma(a, b[u][v], acc[v]);
-        }
-    }
-    for (; k < cnt; k++) {
-        const int j = __builtin_amdgcn_readlane(jv, k);
-        const real_t a = (real_t)readlane_f64(av, k);
-        const real_t *__restrict__ rowp = B + (size_t)j * ldb;
-        real_t b[VEC];
-        vload<real_t, VEC>(b, rowp + col);
-#pragma unroll
-        for (int v = 0; v < VEC; v++) acc[v] = mx_fma(a, b[v], acc[v]);
-    }
-}
-
-// TR rows per workgroup.  COLMAJOR: stage the tile in LDS and write transposed.
-// VSTORE (COLMAJOR only): two consecutive rows per lane -> wider stores; needs
-// even ldc and 2*sizeof(real_t)-aligned C.
-template <typename real_t, int VEC, bool COLMAJOR, bool VSTORE, int TR>
-__global__ __launch_bounds__(SPMM_WAVES * MX_WAVE)
-void spmm_rowwave_kernel(int m, int n,
-                         const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                         const double *__restrict__ values,
-                         const real_t *__restrict__ B, size_t ldb,
-                         real_t *__restrict__ C, size_t ldc)
-{
-    constexpr int W = MX_WAVE * VEC;          // output columns per workgroup pass
-    constexpr int S = W + 1;                  // odd LDS row stride (elements)
-    constexpr int ROWS_PER_WAVE = TR / SPMM_WAVES;
-    __shared__ real_t tile[COLMAJOR ? TR * S : 1];
-
-    const int lane = lane_id();
-    const int wave = uniform(threadIdx.x / MX_WAVE);
-    const int row0 = blockIdx.x * TR;
-    const int c0 = blockIdx.y * W;
-    const int col = c0 + lane * VEC;
-    const bool active = col < n;
-    // clamped column for the reads of inactive lanes (n >= VEC always holds here)
-    const unsigned lcol = active ? (unsigned)col : (unsigned)(n - VEC);
-
-    const int r_begin = row0 + wave * ROWS_PER_WAVE;
-    const int r_end = min(r_begin + ROWS_PER_WAVE, m);
-
-    int s = 0, e = 0, jv = 0;
-    double av = 0.0;
-    if (r_begin < r_end) {
-        s = uniform(indptr[r_begin]);
-        e = uniform(indptr[r_begin + 1]);
-        if (s + lane < e) { jv = indices[s + lane]; av = values[s + lane]; }
-    }
-    for (int row = r_begin; row < r_end; row++) {
-        // prefetch the first chunk of the next row
-        int e2 = e, jv2 = 0;
-        double av2 = 0.0;
-        if (row + 1 < r_end) {
-            e2 = uniform(indptr[row + 2]);
-            if (e + lane < e2) { jv2 = indices[e + lane]; av2 = values[e + lane]; }
-        }
-        real_t acc[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; v++) acc[v] = 0;
-
-        spmm_chunk<real_t, VEC>(min(MX_WAVE, e - s), jv, av, B, ldb, lcol, acc);
-        for (int k0 = s + MX_WAVE; k0 < e; k0 += MX_WAVE) {   // rows longer than one wavefront
-            int jc = 0;
-            double ac = 0.0;
-            if (k0 + lane < e) { jc = indices[k0 + lane]; ac = values[k0 + lane]; }
-            spmm_chunk<real_t, VEC>(min(MX_WAVE, e - k0), jc, ac, B, ldb, lcol, acc);
-        }
-
-        if constexpr (COLMAJOR) {
-            real_t *t = tile + (row - row0) * S + lane * VEC;
-#pragma unroll
-            for (int v = 0; v < VEC; v++) t[v] = acc[v];
-        } else {
-            if (active) vstore<real_t, VEC>(C + (size_t)row * ldc + col, acc);
-        }
-        s = e; e = e2; jv = jv2; av = av2;
-    }
-
-    if constexpr (COLMAJOR) {
-        __syncthreads();
-        const int ncols = min(W, n - c0);
-        constexpr int RPL = VSTORE ? 2 : 1;        // rows per lane in the write-out
-        constexpr int LPC = TR / RPL;              // lanes per output column
-        constexpr int CPW = MX_WAVE / LPC;         // columns per wave-instruction
-        const int q = lane % LPC;
-        const int r = q * RPL;
-        const int grow = row0 + r;
-        for (int cb = wave * CPW; cb < ncols; cb += SPMM_WAVES * CPW) {
-            const int c = cb + lane / LPC;
-            if (c < ncols && grow < m) {
-                real_t *dst = C + (size_t)(c0 + c) * ldc + grow;
-                if constexpr (VSTORE) {
-                    real_t two[2] = { tile[r * S + c], tile[(r + 1) * S + c] };
-                    vstore<real_t, 2>(dst, two);   // m even & grow even => grow+1 < m
-                } else {
-                    *dst = tile[r * S + c];
-                }
-            }
-        }
-    }
-}
-
-template <typename real_t, int VEC, bool COLMAJOR, bool VSTORE>
-static int launch_spmm(int m, int n, const int32_t *indptr, const int32_t *indices, const double *values,
-                       const real_t *B, size_t ldb, real_t *C, size_t ldc, hipStream_t stream)
-{
-    constexpr int TR = 32;
-    constexpr int W = MX_WAVE * VEC;
-    dim3 grid((unsigned)ceil_div(m, TR), (unsigned)ceil_div(n, W));
-    kt_begin(stream);
-    hipLaunchKernelGGL((spmm_rowwave_kernel<real_t, VEC, COLMAJOR, VSTORE, TR>), grid,
-                       dim3(SPMM_WAVES * MX_WAVE), 0, stream, m, n, indptr, indices, values, B, ldb, C, ldc);
-    kt_end(stream);
-    MX_LAUNCH_CHECK();
-    return 0;
-}
-
-template <typename real_t, int VECMAX>
-static int dispatch_spmm(int m, int n, const int32_t *indptr, const int32_t *indices, const double *values,
-                         const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream)
-{
-    // widest per-lane access the operands allow (16 B when rows of B are 16-B aligned)
-    const bool b_vec = (n % VECMAX == 0) && (ldb % VECMAX == 0) && ((uintptr_t)B % (VECMAX * sizeof(real_t)) == 0);
-    if (colmajor) {
-        const bool vs = (ldc % 2 == 0) && ((uintptr_t)C % (2 * sizeof(real_t)) == 0);
-        if (b_vec) return vs ? launch_spmm<real_t, VECMAX, true, true>(m, n, indptr, indices, values, B, ldb, C, ldc, stream)
-                             : launch_spmm<real_t, VECMAX, true, false>(m, n, indptr, indices, values, B, ldb, C, ldc, stream);
-        return vs ? launch_spmm<real_t, 1, true, true>(m, n, indptr, indices, values, B, ldb, C, ldc, stream)
-                  : launch_spmm<real_t, 1, true, false>(m, n, indptr, indices, values, B, ldb, C, ldc, stream);
-    }
-    const bool c_vec = b_vec && (ldc % VECMAX == 0) && ((uintptr_t)C % (VECMAX * sizeof(real_t)) == 0);
-    if (c_vec) return launch_spmm<real_t, VECMAX, false, false>(m, n, indptr, indices, values, B, ldb, C, ldc, stream);
-    return launch_spmm<real_t, 1, false, false>(m, n, indptr, indices, values, B, ldb, C, ldc, stream);
-}
-
-
-// =====================================================================================================
-// v2 "slab / panel sweep" kernel.
-//
-// Why: with B = K x n row-major far larger than one XCD's 4 MiB L2 (102 MB for the headline config) the
-// row-wave kernel above gets a 7 % L2 hit rate and runs at the Infinity-Cache gather rate (~7 TB/s of
-// fabric reads for nnz*n*8 = 32.8 GB -> 4.5 ms; profiles/r01_v1_*).  The same kernel with a 4 MB B runs in
-// 1.5 ms.  This kernel restructures the iteration space so that each XCD's *working set* of B fits its L2:
-//
-//   * column slabs: the n output columns are cut into 128-byte slabs (16 f64 / 32 f32 columns = one cache
-//     line of a B row).  Work items (slab, row block) are dealt slab-major to the 8 XCDs (blockIdx % 8 is
-//     the XCD a workgroup lands on — a locality heuristic only, never a correctness assumption), so one
-//     XCD touches K x 128 B of B (12.8 MB) instead of all of it;
-//   * column panels: [0, K) is cut into `npanels` ranges so that one slab-panel (K/npanels x 128 B) fits
-//     L2.  A workgroup keeps the accumulators of its RB = 32*RPG rows in registers and sweeps the panels
-//     in order, visiting for each of its rows only the entries whose column lies in the current panel
-//     (rows are sorted, so a cursor per row suffices).  All workgroups of an XCD start together and do
-//     statistically equal work per panel, so they stay on the same panel (soft synchronisation).
-//     npanels > 1 requires rows sorted by column; npanels == 1 works for any order.
-//   * 8 lanes own one row (x 16 B per lane = the 128-B slab line), so a wave-instruction reads 8 full
-//     lines of B for 8 different rows; (j, a) are loaded coalesced 8 entries at a time per row and
-//     broadcast inside the 8-lane group with ds_swizzle.
-// Summation order inside a row is still CSR storage order (one FMA per entry), as in the reference.
-// =====================================================================================================
-constexpr int SLAB_BLOCK = 256;
-constexpr int SLAB_GROUP = 8;                       // lanes per row
-constexpr int SLAB_GROUPS = SLAB_BLOCK / SLAB_GROUP;
-
-template <int T>
-__device__ __forceinline__ int group8_bcast(int v)
-{
-    // ds_swizzle bit-mask mode: src lane = ((lane & and) | or) ^ xor inside each 32-lane half;
-    // and = 0b11000 keeps the 8-lane group, or = T picks entry T of the group.
-    return __builtin_amdgcn_ds_swizzle(v, 0x18 | (T << 5));
-}
-template <int T>
-__device__ __forceinline__ double group8_bcast(double v)
-{
-    union { double d; int i[2]; } u;
-    u.d = v;
-    u.i[0] = group8_bcast<T>(u.i[0]);
-    u.i[1] = group8_bcast<T>(u.i[1]);
-    return u.d;
-}
-
-__device__ __forceinline__ unsigned group8_ballot(bool pred)
-{
-    const unsigned long long b = __ballot(pred);
-    return (unsigned)(b >> (lane_id() & ~(SLAB_GROUP - 1))) & 0xFFu;
-}
-
-// One chunk (<= 8 entries, lane t of the group holds entry t) of one row: all B reads are issued before
-// the first FMA so that 8 line reads per group are in flight (a branch per entry would serialise them
-// behind s_waitcnt vmcnt(0)).  Entries past `cnt` read a valid address (entry 0's row) and are dropped
-// by a select, never by arithmetic (0 * Inf would poison the sum).
-template <typename real_t, int VEC, int T>
-__device__ __forceinline__ void slab_load(int cnt, int jv, const real_t *__restrict__ B, size_t ldb, unsigned lcol,
-                                          real_t (&b)[VEC])
-{
-    int j = group8_bcast<T>(jv);
-    j = (T < cnt) ? j : 0;
-    vload<real_t, VEC>(b, B + (size_t)j * ldb + lcol);
-}
-template <typename real_t, int VEC, int T>
-__device__ __forceinline__ void slab_fma(int cnt, double av, const real_t (&b)[VEC], real_t (&acc)[VEC])
-{
-    const real_t a = (real_t)group8_bcast<T>(av);
-#pragma unroll
-    for (int v = 0; v < VEC; v++) {
-        const real_t f = mx_fma(a, b[v], acc[v]);
-        acc[v] = (T < cnt) ? f : acc[v];
-    }
-}
-template <typename real_t, int VEC>
-__device__ __forceinline__ void slab_chunk(int cnt, int jv, double av, const real_t *__restrict__ B, size_t ldb,
-                                           unsigned lcol, real_t (&acc)[VEC])
-{
-    real_t b0[VEC], b1[VEC], b2[VEC], b3[VEC], b4[VEC], b5[VEC], b6[VEC], b7[VEC];
-    slab_load<real_t, VEC, 0>(cnt, jv, B, ldb, lcol, b0);
-    slab_load<real_t, VEC, 1>(cnt, jv, B, ldb, lcol, b1);
-    slab_load<real_t, VEC, 2>(cnt, jv, B, ldb, lcol, b2);
-    slab_load<real_t, VEC, 3>(cnt, jv, B, ldb, lcol, b3);
-    slab_load<real_t, VEC, 4>(cnt, jv, B, ldb, lcol, b4);
-    slab_load<real_t, VEC, 5>(cnt, jv, B, ldb, lcol, b5);
-    slab_load<real_t, VEC, 6>(cnt, jv, B, ldb, lcol, b6);
-    slab_load<real_t, VEC, 7>(cnt, jv, B, ldb, lcol, b7);
-    slab_fma<real_t, VEC, 0>(cnt, av, b0, acc);
-    slab_fma<real_t, VEC, 1>(cnt, av, b1, acc);
-    slab_fma<real_t, VEC, 2>(cnt, av, b2, acc);
-    slab_fma<real_t, VEC, 3>(cnt, av, b3, acc);
-    slab_fma<real_t, VEC, 4>(cnt, av, b4, acc);
-    slab_fma<real_t, VEC, 5>(cnt, av, b5, acc);
-    slab_fma<real_t, VEC, 6>(cnt, av, b6, acc);
-    slab_fma<real_t, VEC, 7>(cnt, av, b7, acc);
-}
-
-// Timing-only barrier among the workgroups that share blockIdx % 8 (the XCD group): it keeps them on the same
-// column panel so that the panel stays L2-resident.  No data is handed over, so no release/acquire is needed
-// and a timeout is harmless: the spin is bounded and falling through only costs locality, never correctness
-// (all co-resident by grid sizing; a block that is not resident simply makes the others time out).
-__device__ __forceinline__ void xcd_timing_barrier(unsigned *ctr, unsigned target)
-{
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < 4096)
-            __builtin_amdgcn_s_sleep(8);
-    }
-    __syncthreads();
-}
-
-template <typename real_t, int RPG, bool COLMAJOR>
-__global__ __launch_bounds__(SLAB_BLOCK)
-void spmm_slab_kernel(int m, int n,
-                      const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                      const double *__restrict__ values,
-                      const real_t *__restrict__ B, size_t ldb,
-                      real_t *__restrict__ C, size_t ldc,
-                      int npanels, int panel_cols, int nslabs, int nrowblocks, int c_vec_ok,
-                      unsigned *__restrict__ sync_ctr, int sync_mode, size_t slab_stride)
-{
-    constexpr int VEC = 16 / (int)sizeof(real_t);
-    constexpr int W = SLAB_GROUP * VEC;             // columns per slab
-    constexpr int RB = SLAB_GROUPS * RPG;           // rows per workgroup step
-    const int lg = threadIdx.x & (SLAB_GROUP - 1);
-    const int grp = threadIdx.x / SLAB_GROUP;
-    const int xcd = blockIdx.x & 7;
-    const int wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
-    const long long total = (long long)nslabs * nrowblocks;
-    const long long lo = total * xcd / 8, hi = total * (xcd + 1) / 8;
-
-    // every workgroup of the group runs the same number of steps (idle ones only keep the barrier count right)
-    const int niter = (int)((hi - lo + nwg - 1) / nwg);
-    unsigned *const my_ctr = sync_ctr + xcd * 64;    // one counter per group, 256 B apart
-    unsigned step = 0;
-    for (int it = 0; it < niter; it++) {
-        const long long item_raw = lo + wg + (long long)it * nwg;
-        const bool have = item_raw < hi;
-        const long long item = have ? item_raw : lo;
-        const int slab = (int)(item / nrowblocks);
-        const int rb = (int)(item % nrowblocks);
-        const int row0 = rb * RB + grp * RPG;
-        const int col = slab * W + lg * VEC;
-        const bool active = col < n;
-        // slab_stride != 0: B was repacked slab-major ([slab][K][W], zero padded) so that a slab is contiguous and
-        // spreads over all L2 channels; the caller then passes ldb = W and this adds the slab's base.
-        const unsigned lcol = slab_stride ? (unsigned)(lg * VEC) : (active ? (unsigned)col : (unsigned)(n - VEC));
-        const real_t *__restrict__ Bs = B + (size_t)slab * slab_stride;
-
-        int cur[RPG], end[RPG];
-        real_t acc[RPG][VEC];
-#pragma unroll
-        for (int r = 0; r < RPG; r++) {
-            const int row = row0 + r;
-            cur[r] = 0; end[r] = 0;
-            if (have && row < m) { cur[r] = indptr[row]; end[r] = indptr[row + 1]; }
-#pragma unroll
-            for (int v = 0; v < VEC; v++) acc[r][v] = 0;
-        }
-
-        for (int p = 0; p < npanels; p++) {
-            const int pend = (p == npanels - 1) ? INT_MAX : (p + 1) * panel_cols;
-            if (sync_mode == 2 || (sync_mode == 1 && p == 0)) {
-                step++;
-                xcd_timing_barrier(my_ctr, step * (unsigned)nwg);
-            }
-            unsigned pending = (1u << RPG) - 1u;          // rows that may still have entries in this panel
-            while (__ballot(pending != 0) != 0ULL) {
-                int jv[RPG];
-                double av[RPG];
-#pragma unroll
-                for (int r = 0; r < RPG; r++) {
-                    // unconditional reads (clamped to entry 0) so that all 2*RPG loads are in flight together
-                    const int k = cur[r] + lg;
-                    const bool valid = ((pending >> r) & 1u) && k < end[r];
-                    const int ks = valid ? k : 0;
-                    const int jl = indices[ks];
-                    const double al = values[ks];
-                    jv[r] = valid ? jl : INT_MAX;
-                    av[r] = al;
-                }
-#pragma unroll
-                for (int r = 0; r < RPG; r++) {
-                    const unsigned long long inpanel = __ballot(jv[r] < pend);
-                    if (inpanel == 0ULL) { pending &= ~(1u << r); continue; }   // no group of this wave has entries here
-                    // sorted row: in-panel entries are a prefix of the chunk
-                    const int cnt = __popc((unsigned)(inpanel >> (lane_id() & ~(SLAB_GROUP - 1))) & 0xFFu);
-                    // entry 0 of an empty chunk may be INT_MAX: slab_load only dereferences entries < cnt (else row 0)
-                    slab_chunk<real_t, VEC>(cnt, jv[r], av[r], Bs, ldb, lcol, acc[r]);
-                    cur[r] += cnt;
-                    if (cnt < SLAB_GROUP) pending &= ~(1u << r);          // panel (or row) exhausted
-                }
-            }
-        }
-
-        // epilogue: lane holds columns col..col+VEC-1 of rows row0..row0+RPG-1
-        if (active && have) {
-            if constexpr (!COLMAJOR) {
-#pragma unroll
-                for (int r = 0; r < RPG; r++)
-                    if (row0 + r < m) vstore<real_t, VEC>(C + (size_t)(row0 + r) * ldc + col, acc[r]);
-            } else {
-                constexpr int RV = 16 / (int)sizeof(real_t);               // rows per 16-B store
-#pragma unroll
-                for (int v = 0; v < VEC; v++) {
-                    real_t *__restrict__ dst = C + (size_t)(col + v) * ldc + row0;
-                    if (c_vec_ok && row0 + RPG <= m) {
-#pragma unroll
-                        for (int r = 0; r < RPG; r += RV) {
-                            real_t tmp[RV];
-#pragma unroll
-                            for (int q = 0; q < RV; q++) tmp[q] = acc[r + q][v];
-                            vstore<real_t, RV>(dst + r, tmp);
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < RPG; r++)
-                            if (row0 + r < m) dst[r] = acc[r][v];
-                    }
-                }
-            }
-        }
-    }
-}
-
-// panels so that one slab-panel (K/npanels rows x 128 B) stays within `l2_budget` bytes
-static int pick_panels(int K, size_t l2_budget)
-{
-    const size_t slab_bytes = (size_t)K * 128;
-    int p = (int)((slab_bytes + l2_budget - 1) / l2_budget);
-    if (p < 1) p = 1;
-    if (p > 64) p = 64;
-    return p;
-}
-
-// B (K x n row-major, leading dimension ldb) -> slab-major [nslabs][K][W], zero padded past column n.
-// One thread per 16-byte piece; reads are row-contiguous, each 8-lane group writes one full 128-byte line.
-template <typename real_t>
-__global__ __launch_bounds__(256)
-void repack_slabs_kernel(int K, int Kp, int n, int nslabs, const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ Bp)
-{
-    constexpr int VEC = 16 / (int)sizeof(real_t);
-    constexpr int W = SLAB_GROUP * VEC;
-    const long long pieces_per_row = (long long)nslabs * SLAB_GROUP;
-    const long long total = (long long)Kp * pieces_per_row;          // rows K..Kp-1 of every slab are zero (plan padding)
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const int j = (int)(t / pieces_per_row);
-        const int piece = (int)(t % pieces_per_row);
-        const int slab = piece / SLAB_GROUP, lg = piece % SLAB_GROUP;
-        const int col = slab * W + lg * VEC;
-        real_t v[VEC];
-#pragma unroll
-        for (int q = 0; q < VEC; q++) v[q] = 0;
-        if (col < n && j < K) vload<real_t, VEC>(v, B + (size_t)j * ldb + col);       // n % VEC == 0 (slab_ok)
-        vstore<real_t, VEC>(Bp + ((size_t)slab * Kp + j) * W + lg * VEC, v);
-    }
-}
-
-// grow-only per-device scratch for the packed copy of B
-static void *slab_pack_workspace(size_t bytes, bool release = false)
-{
-    static thread_local void *ws[64] = {};
-    static thread_local size_t cap[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (release) { if (ws[dev]) (void)hipFree(ws[dev]); ws[dev] = nullptr; cap[dev] = 0; return nullptr; }
-    if (cap[dev] < bytes) {
-        if (ws[dev]) (void)hipFree(ws[dev]);
-        ws[dev] = nullptr; cap[dev] = 0;
-        if (hipMalloc(&ws[dev], bytes) != hipSuccess) return nullptr;
-        cap[dev] = bytes;
-    }
-    return ws[dev];
-}
-
-// per-device counters for the timing barrier (8 groups x 256 B), allocated once
-static unsigned *slab_sync_workspace()
-{
-    static thread_local unsigned *ws[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!ws[dev] && hipMalloc((void **)&ws[dev], 8 * 64 * sizeof(unsigned)) != hipSuccess) ws[dev] = nullptr;
-    return ws[dev];
-}
-
-template <typename real_t, int RPG>
-static int launch_spmm_slab_rpg(int m, int n, int K, const int32_t *indptr, const int32_t *indices,
-                                const double *values, const real_t *B, size_t ldb, real_t *C, size_t ldc,
-                                int colmajor, int npanels, int wg_per_cu, int sync_mode, hipStream_t stream)
-{
-    constexpr int VEC = 16 / (int)sizeof(real_t);
-    constexpr int W = SLAB_GROUP * VEC;
-    constexpr int RB = SLAB_GROUPS * RPG;
-    const int nslabs = (int)ceil_div(n, W);
-    const int nrowblocks = (int)ceil_div(m, RB);
-    if (npanels < 1) npanels = 1;
-    const int panel_cols = (int)ceil_div(K > 0 ? K : 1, npanels);
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-    long long grid = (long long)cus * wg_per_cu;
-    const long long total = (long long)nslabs * nrowblocks;
-    if (grid > total + 7) grid = total + 7;
-    grid = (grid / 8) * 8;
-    if (grid < 8) grid = 8;
-    const int c_vec_ok = colmajor && (ldc % VEC == 0) && ((uintptr_t)C % 16 == 0);
-    unsigned *sync = slab_sync_workspace();
-    if (!sync) sync_mode = 0;
-    if (sync_mode) MX_HIP(hipMemsetAsync(sync, 0, 8 * 64 * sizeof(unsigned), stream));
-    // slab-major copy of B (MXGPU_SLAB_PACK=0 disables): with B row-major a slab is 128 B out of every ldb*s
-    // bytes — a power-of-two stride that lands on a fraction of the L2 channels
-    size_t slab_stride = 0;
-    int pack = 1;
-    if (const char *e = getenv("MXGPU_SLAB_PACK")) pack = atoi(e);
-    if (pack) {
-        const size_t bytes = (size_t)nslabs * (size_t)K * W * sizeof(real_t);
-        real_t *Bp = (real_t *)slab_pack_workspace(bytes);
-        if (Bp) {
-            const long long pieces = (long long)K * nslabs * SLAB_GROUP;
-            const unsigned g = (unsigned)(ceil_div(pieces, 256) < 8192 ? ceil_div(pieces, 256) : 8192);
-            hipLaunchKernelGGL((repack_slabs_kernel<real_t>), dim3(g), dim3(256), 0, stream, K, K, n, nslabs, B, ldb, Bp);
-            MX_LAUNCH_CHECK();
-            B = Bp; ldb = W; slab_stride = (size_t)K * W;
-        }
-    }
-    kt_begin(stream);
-    if (colmajor)
-        hipLaunchKernelGGL((spmm_slab_kernel<real_t, RPG, true>), dim3((unsigned)grid), dim3(SLAB_BLOCK), 0, stream,
-                           m, n, indptr, indices, values, B, ldb, C, ldc, npanels, panel_cols, nslabs, nrowblocks,
-                           c_vec_ok, sync, sync_mode, slab_stride);
-    else
-        hipLaunchKernelGGL((spmm_slab_kernel<real_t, RPG, false>), dim3((unsigned)grid), dim3(SLAB_BLOCK), 0, stream,
-                           m, n, indptr, indices, values, B, ldb, C, ldc, npanels, panel_cols, nslabs, nrowblocks,
-                           c_vec_ok, sync, sync_mode, slab_stride);
-    kt_end(stream);
-    MX_LAUNCH_CHECK();
-    return 0;
-}
-
-template <typename real_t>
-static int launch_spmm_slab(int m, int n, int K, const int32_t *indptr, const int32_t *indices,
-                            const double *values, const real_t *B, size_t ldb, real_t *C, size_t ldc,
-                            int colmajor, int npanels, int wg_per_cu, hipStream_t stream)
-{
-    // experiment knobs (tuning only): MXGPU_SLAB_SYNC 0 none / 1 per row-block / 2 per panel; MXGPU_SLAB_RPG 8 / 16
-    int sync_mode = 2, rpg = 8;
-    if (const char *e = getenv("MXGPU_SLAB_SYNC")) sync_mode = atoi(e);
-    if (const char *e = getenv("MXGPU_SLAB_RPG")) rpg = atoi(e);
-    if (npanels <= 1) sync_mode = 0;
-    if (rpg == 16)
-        return launch_spmm_slab_rpg<real_t, 16>(m, n, K, indptr, indices, values, B, ldb, C, ldc, colmajor, npanels,
-                                                wg_per_cu, sync_mode, stream);
-    return launch_spmm_slab_rpg<real_t, 8>(m, n, K, indptr, indices, values, B, ldb, C, ldc, colmajor, npanels,
-                                           wg_per_cu, sync_mode, stream);
-}
-
-// =====================================================================================================
-// v3 "planned panel sweep".
-//
-// PMC on v2 (profiles/r01_v2_*): with column panels + the XCD timing barrier the L2 hit rate only reaches
-// 60 % because every (row, panel) visit re-reads the row's (j, a) chunk — with P panels the CSR arrays are
-// streamed ~2P times per XCD and that traffic, not B, dominates and evicts the panel.  v3 fixes the data
-// layout instead of the loop: a *plan* regroups A's entries by (octet of 8 row-bundles, panel) and
-// interleaves the 8 bundles of an octet in batches of 8 steps (slot 64*batch + 8*g + u = step 8*batch + u of
-// bundle g), so that
-//   * one wavefront (8 lane groups = 8 bundles) reads 64 consecutive plan entries per 8 steps — every entry of A
-//     is read exactly once per slab, coalesced, and reaches its lane group by a DPP row broadcast;
-//   * entries of a bundle inside a panel are ordered by row, the group accumulates the current row in
-//     registers and folds it into the bundle's accumulators in LDS when the row changes (only that group
-//     touches those LDS rows: plain read-modify-write, no atomics);
-//   * all workgroups of an XCD group stay close to the same panel (same code on statistically identical data;
-//     optional timing barrier), whose slab-major copy of B
-//     (K/P x 128 B, contiguous) fits the XCD's L2.
-// Entry = int32 (col | local_row << 27; padding = zero row of the packed B, value 0) + f64 value; plan bytes ~ the CSR arrays (octet lengths rounded to 8 steps).
-// Summation order: CSR order inside a (row, panel), panels added in ascending order — a regrouping of the
-// reference's sequential sum (tolerance-level difference, not bitwise).  Works for unsorted rows too.
-// =====================================================================================================
-constexpr int PLAN_RB = 8;                         // rows per bundle (owned by one 8-lane group)
-constexpr int PLAN_OCT_ROWS = PLAN_RB * 8;         // rows per octet (one wavefront)
-// wavefronts per workgroup (template parameter WAVES): 16 = ONE 1024-thread workgroup with 128 KiB of LDS per CU,
-// 8 = two 512-thread workgroups with 64 KiB each (one's epilogue overlaps the other's sweep), 4 = four.
-constexpr int PLAN_MAXP = 64;
-constexpr int PLAN_DEFAULT_WG_PER_CU = 1;
-constexpr int PLAN_GEN_OCTS = 16;                  // octets one 16-wavefront workgroup sweeps together
-constexpr int PLAN_CHUNK = 4;                      // batches of 8 steps fetched per plan read (octets are whole chunks)
-constexpr int PLAN_TAIL_SLOTS = 512;               // readable padding behind the last octet (2 chunks)
-constexpr int PLAN_ROW_SHIFT = 27;                 // col < 2^27
-
-// Plan construction: one 512-thread workgroup per octet, one wavefront per bundle.  A bundle's entries are contiguous
-// in the CSR arrays (8 consecutive rows), so the wavefront streams them 64 at a time, fully coalesced; the position
-// of an entry inside its (bundle, panel) stream is a per-panel running count kept in scalar registers plus a
-// ballot prefix — no LDS, no per-row bookkeeping.
-// pass 1: bpo[bundle][p] = where panel p starts in the bundle's stream; steps[oct] = longest bundle of the octet.
-constexpr int PLAN_LD = 4;
-// col / panel_cols without the integer divide: float estimate (col < 2^25 is exact in float up to 2^24, so one
-// correction step either way), clamped to the last panel
-__device__ __forceinline__ int panel_of(int col, int panel_cols, float inv_pc, int npanels)
-{
-    int q = (int)((float)col * inv_pc);
-    const int r = col - q * panel_cols;
-    q += r >= panel_cols ? 1 : (r < 0 ? -1 : 0);
-    return q < npanels ? q : npanels - 1;
-}
-
-// Which of the octet's 64 rows sits in which (bundle, local row) slot.  Consecutive rows (slot = row offset) when that
-// is balanced; otherwise the rows are sorted by length (bitonic sort inside the wavefront) and dealt to the bundles in
-// serpentine order, which keeps the longest bundle — the octet's length, everything shorter is padding — close to
-// the mean.  Log-normal row lengths (sigma 1) pad the plan 1.84x with consecutive rows.  Every wavefront of the
-// workgroup computes the same answer from the same 65 row pointers: no LDS, no synchronisation.
-// Returns the row offset (0..63) assigned to slot `lane`.
-__device__ __forceinline__ int octet_assign(int m, const int32_t *__restrict__ indptr, int oct, int lane,
-                                            int &ptr_out, int &len_out)
-{
-    const long long row = (long long)oct * PLAN_OCT_ROWS + lane;
-    const int ptr = indptr[row < m ? row : m];                       // one load per lane + the octet's end pointer
-    const int pend = indptr[(long long)(oct + 1) * PLAN_OCT_ROWS < m ? (long long)(oct + 1) * PLAN_OCT_ROWS : m];
-    const int nxt = __shfl_down(ptr, 1, 64);
-    const int len = (lane == 63 ? pend : nxt) - ptr;
-    ptr_out = ptr;                                                   // row `lane` of the octet: [ptr, ptr + len)
-    len_out = len;
-    if (__ballot(len != __builtin_amdgcn_readfirstlane(len)) == 0ULL) return lane;     // all rows equally long
-    int idsum = len;                                                 // sum of my bundle with consecutive rows
-    idsum += __shfl_xor(idsum, 1, 64); idsum += __shfl_xor(idsum, 2, 64); idsum += __shfl_xor(idsum, 4, 64);
-    int idmax = idsum;
-    idmax = max(idmax, __shfl_xor(idmax, 8, 64)); idmax = max(idmax, __shfl_xor(idmax, 16, 64));
-    idmax = max(idmax, __shfl_xor(idmax, 32, 64));
-    // no assignment can beat ceil(total / 8): consecutive rows that already reach it (in whole chunks of 32 steps) stay
-    int total = idsum;
-    total += __shfl_xor(total, 8, 64); total += __shfl_xor(total, 16, 64); total += __shfl_xor(total, 32, 64);
-    if (((idmax + 31) >> 5) <= ((((total + 7) >> 3) + 31) >> 5)) return lane;          // wave-uniform
-    // descending bitonic sort of (length, lower row first)
-    unsigned long long key = ((unsigned long long)(unsigned)len << 6) | (unsigned)(63 - lane);
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const unsigned long long other = __shfl_xor(key, j, 64);
-            const bool keep_max = (((lane & k) == 0) == ((lane & j) == 0));   // descending overall
-            key = keep_max ? (key > other ? key : other) : (key < other ? key : other);
-        }
-    }
-    const int slen = (int)(key >> 6), sidx = 63 - (int)(key & 63);   // lane r: r-th longest row
-    // serpentine deal: rank r = 8k + pos goes to bundle (k even ? pos : 7 - pos), local row k
-    const int my_b = lane >> 3, my_k = lane & 7;                     // lane seen as slot (bundle, local row)
-    const int my_rank = my_k * 8 + ((my_k & 1) ? 7 - my_b : my_b);
-    int balsum = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) balsum += __shfl(slen, k * 8 + ((k & 1) ? 7 - my_b : my_b), 64);
-    int balmax = balsum;
-    balmax = max(balmax, __shfl_xor(balmax, 8, 64)); balmax = max(balmax, __shfl_xor(balmax, 16, 64));
-    balmax = max(balmax, __shfl_xor(balmax, 32, 64));
-    const int dealt = __shfl(sidx, my_rank, 64);
-    // only when it shortens the octet by a whole chunk of 32 steps (uniform matrices keep consecutive rows)
-    const bool permute = ((balmax + 31) >> 5) < ((idmax + 31) >> 5);
-    return permute ? dealt : lane;
-}
-
-__global__ __launch_bounds__(512)
-void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
-                       const int32_t *__restrict__ indices, int32_t *__restrict__ steps,
-                       int32_t *__restrict__ bpo, int noct, long long *__restrict__ nnz_out,
-                       unsigned char *__restrict__ rowmap)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) *nnz_out = indptr[m];     // rides back with the step total (one copy)
-    __shared__ int totals[8];
-    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int oct = blockIdx.x;
-    int rptr, rlen;                                                  // row pointers of the octet, one row per lane
-    const int rowof = octet_assign(m, indptr, oct, lane, rptr, rlen);
-    const bool identity = __ballot(rowof != lane) == 0ULL;
-    if (g == 0) rowmap[(size_t)oct * PLAN_OCT_ROWS + lane] = (unsigned char)rowof;
-    int mine = 0;                                                    // lane p accumulates the count of panel p (+64, ...)
-    int total_b = 0;
-    const float inv_pc = 1.0f / (float)panel_cols;
-    // PLAN_LD chunks of 64 entries per pass: the loads of a pass are issued together (the kernel is latency-bound:
-    // a bundle is only ~256 entries)
-    auto count_range = [&](int s, int e) {
-        total_b += e - s;
-        for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
-            int col[PLAN_LD];
-#pragma unroll
-            for (int c = 0; c < PLAN_LD; c++) {
-                const int k = k0 + 64 * c + lane;
-                col[c] = k < e ? indices[k] : -1;
-            }
-#pragma unroll
-            for (int c = 0; c < PLAN_LD; c++) {
-                if (k0 + 64 * c >= e) break;                         // uniform
-                const int pan = col[c] >= 0 ? panel_of(col[c], panel_cols, inv_pc, npanels) : -1;
-                for (int q = 0; q < npanels; q++) {
-                    const int cnt = __popcll(__ballot(pan == q));
-                    if (lane == (q & 63)) mine += cnt;               // npanels <= 64: one lane per panel
-                }
-            }
-        }
-    };
-    if (identity) {                                                  // 8 consecutive rows: one contiguous range
-        const int s = __shfl(rptr, g * PLAN_RB, 64);
-        const int e = __shfl(rptr, g * PLAN_RB + PLAN_RB - 1, 64) + __shfl(rlen, g * PLAN_RB + PLAN_RB - 1, 64);
-        count_range(s, e);
-    } else {                                                         // my 8 rows, in local-row order
-#pragma unroll
-        for (int r = 0; r < PLAN_RB; r++) {
-            const int rr = __shfl(rowof, g * PLAN_RB + r, 64);
-            const int s = __shfl(rptr, rr, 64);
-            count_range(s, s + __shfl(rlen, rr, 64));
-        }
-    }
-    // exclusive prefix over the panels (lanes 0..npanels-1)
-    int incl = lane < npanels ? mine : 0;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int up = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += up;
-    }
-    if (lane < npanels) bpo[((size_t)oct * 8 + g) * npanels + lane] = incl - mine;
-    if (lane == 0) totals[g] = total_b;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int mx = 0;
-#pragma unroll
-        for (int gg = 0; gg < 8; gg++) mx = max(mx, totals[gg]);
-        steps[oct] = (mx + 8 * PLAN_CHUNK - 1) & ~(8 * PLAN_CHUNK - 1);    // whole chunks of 4 batches of 8 steps (slot layout below)
-    }
-}
-
-// pass 2: scatter the entries to their interleaved slots (batch of 8 steps = 64 slots laid out [bundle][step])
-__global__ __launch_bounds__(512)
-void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
-                      const int32_t *__restrict__ indices, const double *__restrict__ values,
-                      const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
-                      int32_t *__restrict__ pcol, double *__restrict__ pval, int noct, int pad_col,
-                      int32_t *__restrict__ step_off, const unsigned char *__restrict__ rowmap)
-{
-    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int oct = blockIdx.x;
-    // Where the kernel's wavefronts meet (locality only, any value is correct): the 16 octets that one workgroup
-    // sweeps together share the panel boundaries, as fractions of each octet's own length — the mean panel start over
-    // the 128 bundles of the group.  With per-octet boundaries every meeting waited for the wavefront whose panel
-    // happened to be longest (entries per octet and panel vary by ~4 %: the sum of the 5 maxima is ~8 % more than the
-    // common length); with shared boundaries equally long octets arrive together.
-    if (g == 0 && lane < npanels) {
-        const int o0 = (oct / PLAN_GEN_OCTS) * PLAN_GEN_OCTS, o1 = min(o0 + PLAN_GEN_OCTS, noct);
-        long long sum = 0;
-        for (int o = o0; o < o1; o++) {
-#pragma unroll
-            for (int gg = 0; gg < 8; gg++) sum += bpo[((size_t)o * 8 + gg) * npanels + lane];
-        }
-        const long long len = (long long)oct_off[o1] - oct_off[o0];                     // sum of the octets' lengths
-        const int mine = oct_off[oct + 1] - oct_off[oct];
-        const double frac = len > 0 ? (double)sum / (8.0 * (double)len) : 0.0;
-        int b = lane == 0 ? 0 : (int)(frac * (double)mine);
-        if (b > mine) b = mine;
-        step_off[(size_t)oct * npanels + lane] = oct_off[oct] + b;
-        if (oct == noct - 1 && lane == 0) step_off[(size_t)noct * npanels] = oct_off[noct];
-    }
-    const int rowof = rowmap[(size_t)oct * PLAN_OCT_ROWS + lane];    // written by the count pass (octet_assign)
-    const bool identity = __ballot(rowof != lane) == 0ULL;
-    const long long base = oct_off[oct];
-    // lane q keeps the next free step of panel q's stream
-    int nextstep = lane < npanels ? bpo[((size_t)oct * 8 + g) * npanels + lane] : 0;
-    const unsigned long long below = (1ULL << lane) - 1ULL;
-    const float inv_pc = 1.0f / (float)panel_cols;
-    int total_b = 0, last_lrow = 0;
-    // entries [s, e) of the CSR arrays; local row of entry k = lrow0 + #(bounds rp[1..7] <= k)  (rp = INT_MAX: none)
-    auto fill_range = [&](int s, int e, int lrow0, const int (&rp)[PLAN_RB + 1]) {
-        total_b += e - s;
-        for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
-            int colv[PLAN_LD];
-            double av[PLAN_LD];
-#pragma unroll
-            for (int c = 0; c < PLAN_LD; c++) {                      // all loads of the pass in flight together
-                const int k = k0 + 64 * c + lane;
-                colv[c] = -1; av[c] = 0.0;
-                if (k < e) { colv[c] = indices[k]; av[c] = values[k]; }
-            }
-#pragma unroll
-            for (int c = 0; c < PLAN_LD; c++) {
-                if (k0 + 64 * c >= e) break;                         // uniform
-                const int k = k0 + 64 * c + lane;
-                const int col = colv[c];
-                int pan = -1, lrow = lrow0;
-                if (col >= 0) {
-                    pan = panel_of(col, panel_cols, inv_pc, npanels);
-#pragma unroll
-                    for (int r = 1; r < PLAN_RB; r++) lrow += k >= rp[r];
-                }
-                int t = 0;                                           // my entry's step inside the octet
-                for (int q = 0; q < npanels; q++) {
-                    const unsigned long long same = __ballot(pan == q);
-                    if (same == 0ULL) continue;                      // uniform
-                    const int start = __builtin_amdgcn_readlane(nextstep, q);
-                    if (pan == q) t = start + __popcll(same & below);
-                    if (lane == q) nextstep += __popcll(same);
-                }
-                if (pan >= 0) {
-                    // ONE pair of stores per chunk (inside the panel loop it was one pair per panel, each with 1/P of
-                    // the lanes).  Slot layout inside a batch of 8 steps: [bundle g][step u] — lane 8g+u of the reading
-                    // wavefront holds bundle g's entry for step u, i.e. inside g's own lane group (DPP broadcast).
-                    const long long dst = (base + (t & ~7)) * 8 + g * 8 + (t & 7);
-                    pcol[dst] = col | (lrow << PLAN_ROW_SHIFT);
-                    pval[dst] = av[c];
-                }
-            }
-        }
-    };
-    if (identity) {
-        const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
-        int rp[PLAN_RB + 1];                                         // the bundle's row pointers (wave-uniform)
-#pragma unroll
-        for (int r = 0; r <= PLAN_RB; r++) rp[r] = uniform(indptr[min(row0 + r, m)]);
-        fill_range(rp[0], rp[PLAN_RB], 0, rp);
-        if (rp[PLAN_RB] > rp[0]) {
-#pragma unroll
-            for (int r = 1; r < PLAN_RB; r++) last_lrow += (rp[PLAN_RB] - 1) >= rp[r];
-        }
-    } else {
-        const int rr = __shfl(rowof, g * PLAN_RB + (lane & 7), 64);
-        const long long row = (long long)oct * PLAN_OCT_ROWS + rr;
-        const int ps = row < m ? indptr[row] : 0, pe = row < m ? indptr[row + 1] : 0;
-        int none[PLAN_RB + 1];
-#pragma unroll
-        for (int r = 0; r <= PLAN_RB; r++) none[r] = INT_MAX;
-#pragma unroll
-        for (int r = 0; r < PLAN_RB; r++) {
-            const int s = uniform(__shfl(ps, r, 64)), e = uniform(__shfl(pe, r, 64));
-            fill_range(s, e, r, none);
-            if (e > s) last_lrow = r;
-        }
-    }
-    // Padding up to the octet's length: a no-op entry — value 0, column `pad_col` (the all-zero extra row of the
-    // packed B), row = the bundle's last entry's row so that it does not even trigger a row switch.  0 * 0 added to
-    // an accumulator that is never -0.0 leaves it unchanged bit for bit.
-    const int steps_oct = oct_off[oct + 1] - (int)base;
-    for (long long t = total_b + lane; t < steps_oct; t += 64) {
-        const long long dst = (base + (t & ~7LL)) * 8 + g * 8 + (t & 7);
-        pcol[dst] = pad_col | (last_lrow << PLAN_ROW_SHIFT);
-        pval[dst] = 0.0;
-    }
-    // PLAN_TAIL_SLOTS padding slots behind the last octet: the kernel's read-ahead runs two batches past an octet
-    if (oct == noct - 1) {
-        static_assert(PLAN_TAIL_SLOTS == 512, "one slot per thread of the last block");
-        const long long dst = (long long)oct_off[noct] * 8 + threadIdx.x;
-        pcol[dst] = pad_col;
-        pval[dst] = 0.0;
-    }
-}
-
-// broadcast lane U of every 8-lane group: row_newbcast takes lane n of each 16-lane DPP row; bank_mask restricts the
-// write to the low / high half of the row (banks of 4 lanes), so two moves serve the two groups of a row
-template <int U>
-__device__ __forceinline__ int group8_dpp_bcast(int v)
-{
-    int t = __builtin_amdgcn_mov_dpp(v, 0x150 + U, 0xF, 0x3, false);      // lanes of the other half: don't care
-    return __builtin_amdgcn_update_dpp(t, v, 0x150 + 8 + U, 0xF, 0xC, false);
-}
-template <int U>
-__device__ __forceinline__ void plan_bcast(int pcw, double pvw, int &pc, double &pv)
-{
-    union { double d; int i[2]; } a, b;
-    a.d = pvw;
-    pc = group8_dpp_bcast<U>(pcw);
-    b.i[0] = group8_dpp_bcast<U>(a.i[0]);
-    b.i[1] = group8_dpp_bcast<U>(a.i[1]);
-    pv = b.d;
-}
-
-// Fold a finished row's partial sums into its LDS accumulators.  Only this lane ever touches these words and one
-// wavefront's LDS operations execute in order, so both forms are the same sequence of additions.  f64: two
-// fire-and-forget ds_add_f64 (no return value, nothing to wait for; the read-modify-write cost an LDS round trip on
-// ~70 % of the steps).  f32: read-modify-write of one 16-byte word (four ds_add_f32 measured 2.4x slower overall).
-template <int VEC>
-__device__ __forceinline__ void lds_fold(double *d, double (&acc)[VEC])
-{
-#pragma unroll
-    for (int v = 0; v < VEC; v++) __hip_atomic_fetch_add(d + v, acc[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-template <int VEC>
-__device__ __forceinline__ void lds_fold(float *d, float (&acc)[VEC])
-{
-#pragma unroll
-    for (int v = 0; v < VEC; v++) d[v] += acc[v];
-}
-
-// main kernel
-template <typename real_t, bool COLMAJOR, int PLAN_WAVES>
-__global__ __launch_bounds__(PLAN_WAVES * 64)
-void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ step_off,
-                      const int32_t *__restrict__ pcol, const double *__restrict__ pval,
-                      const real_t *__restrict__ Bp, size_t slab_stride,
-                      real_t *__restrict__ C, size_t ldc, int nslabs, int ngens, int noct, int pad_col,
-                      unsigned *__restrict__ sync_ctr, int sync_mode, const unsigned char *__restrict__ rowmap)
-{
-    constexpr int VEC = 16 / (int)sizeof(real_t);
-    constexpr int W = SLAB_GROUP * VEC;
-    constexpr int U = 8;                                            // plan steps in flight per wavefront
-    constexpr int PLAN_WG_ROWS = PLAN_OCT_ROWS * PLAN_WAVES;        // rows per workgroup generation
-    // accumulator rows are padded by 8 (f64) / 16 (f32) bytes: the column-major epilogue reads one column of 64
-    // consecutive rows per instruction, which at a 128-byte stride would hit a single LDS bank pair
-    constexpr int S = W + 16 / (int)sizeof(real_t) / 2;
-    __shared__ real_t accs[PLAN_WG_ROWS * S];                       // 16 waves: 1024 rows x 136 B = 136 KiB
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, lg = lane & 7;
-    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
-    const long long total = (long long)nslabs * ngens;
-    const long long lo = total * xcd / 8, hi = total * (xcd + 1) / 8;
-    const int niter = (int)((hi - lo + nwg - 1) / nwg);
-    unsigned *const my_ctr = sync_ctr + xcd * 64;
-    real_t *const my_oct = accs + (size_t)wave * PLAN_OCT_ROWS * S;                     // this wavefront's 64 rows
-    real_t *const my_rows = my_oct + (size_t)g * PLAN_RB * S + lg * VEC;                // this group's bundle
-
-    // Carried from one generation to the next: the stream bounds, the row map and the FIRST chunk of plan slots of the
-    // wavefront's next octet are requested during the last chunk of the current one, so that a generation does not
-    // start with two exposed memory latencies (bounds, then the first chunk: ~3-4 us of a ~58 us generation).
-    bool primed = false;                                            // wave-uniform
-    int bounds_c = 0, send_c = 0, rowof_c = 0;
-    int rc[PLAN_CHUNK];
-    double rv[PLAN_CHUNK];
-#pragma unroll
-    for (int k = 0; k < PLAN_CHUNK; k++) { rc[k] = 0; rv[k] = 0.0; }
-    for (int it = 0; it < niter; it++) {
-        const long long item_raw = lo + wg + (long long)it * nwg;
-        const bool have = item_raw < hi;
-        const long long item = have ? item_raw : lo;
-        const int slab = (int)(item / ngens), gen = (int)(item % ngens);
-        const int oct = gen * PLAN_WAVES + wave;
-        const bool oct_ok = have && oct < noct;
-        // this wavefront's octet of the next generation (if any)
-        const long long item_n = item_raw + nwg;
-        const int oct_n = (int)(item_n % ngens) * PLAN_WAVES + wave;
-        const bool octn_ok = it + 1 < niter && item_n < hi && oct_n < noct;
-        // slab base is wave-uniform (scalar registers), the per-lane part is a 32-bit byte offset: one VALU op per
-        // address.  A slab is K x 128 B < 4 GiB because K < 2^27... checked on the host (K * 128 < 2^32).
-        const char *__restrict__ Bbase = reinterpret_cast<const char *>(Bp + (size_t)slab * slab_stride);
-        const unsigned lane_off = (unsigned)(lg * VEC * sizeof(real_t));
-
-        // A wavefront's accumulator rows are touched by that wavefront only (zeroing, folds, epilogue): no
-        // workgroup-wide synchronisation around a generation, the wavefronts only meet at the panel boundaries.
-        for (int i = lane; i < PLAN_OCT_ROWS * S; i += 64) my_oct[i] = 0;
-        if (sync_mode > 0) __syncthreads();                          // locality only: start the first panel together
-
-        // One continuous, software-pipelined stream over the octet's entries of ALL panels (they are contiguous in
-        // the plan).  Panel boundaries only matter for locality: when the stream crosses one, the 16 waves of the
-        // CU's single workgroup meet at a __syncthreads (no global traffic, no pipeline restart: the prefetched
-        // plan entries stay in flight).  Across the 32 CUs of the XCD group there is ONE global timing barrier per
-        // generation (32 pollers per counter); in between the CUs run identical code on statistically identical
-        // data and drift by a fraction of a panel.
-        int rowof = lane;
-        {
-            if (sync_mode >= 2) xcd_timing_barrier(my_ctr, (unsigned)(it + 1) * (unsigned)nwg);
-            // The octet's stream bounds and its slot -> row map (identity unless the plan balanced the bundles; used by
-            // the epilogue only) are requested AFTER the barrier: a load in flight at a barrier makes all 16 wavefronts
-            // wait for the slowest one (measured: +0.03 ms per launch for each of the two).
-            // All panel boundaries of the octet come in with ONE load (lane p holds the start of the p-th panel) and
-            // are picked out with v_readlane when the stream crosses a panel: a load at every boundary had to be
-            // waited for with vmcnt(0), i.e. it drained the whole B-line pipeline once per panel.
-            int bounds = 0, send = 0;
-            if (primed) {                                           // requested during the previous generation
-                bounds = bounds_c; send = send_c; rowof = rowof_c;
-            } else if (oct_ok) {
-                bounds = step_off[(size_t)oct * npanels + (lane < npanels ? lane : 0)];
-                send = step_off[(size_t)oct * npanels + npanels];
-                rowof = (int)rowmap[(size_t)oct * PLAN_OCT_ROWS + lane];
-            }
-            int sbeg = __builtin_amdgcn_readfirstlane(bounds);      // wave-uniform: keep the loop control scalar
-            send = __builtin_amdgcn_readfirstlane(send);
-            int next_b = npanels > 1 ? __builtin_amdgcn_readlane(bounds, 1) : send;
-            int p = 0;
-            int cur = 0;
-            real_t acc[VEC];
-#pragma unroll
-            for (int v = 0; v < VEC; v++) acc[v] = 0;
-            // A batch = U = 8 steps = 64 consecutive plan slots, laid out [bundle g][step u]: lane l reads slot
-            // (8 s + l) — one fully coalesced 256 B + 512 B read per batch — and step u's entry is broadcast from
-            // lane u of each group.  (Reading the slot from all 8 lanes of a group instead costs the texture
-            // addresser 8x the lane-bytes: PMC showed TA_BUSY 71 % and the kernel TA-bound.)
-            // Every slot is a valid entry: padding is (zero row of B, value 0, current row) — no per-step validity
-            // test, no clamp.
-            static_assert(U == 8, "one batch = one wavefront of plan slots");
-            static_assert(W * sizeof(real_t) == 128, "slab line");
-            auto b_offset = [&](int c) -> unsigned {                // the row bits (27..29) fall off the 32-bit shift
-                return ((unsigned)c * (unsigned)(W * sizeof(real_t))) + lane_off;
-            };
-            // The plan slots are fetched a CHUNK (PLAN_CHUNK = 4 batches = 32 steps) at a time, one chunk ahead.
-            // Vector loads return in order, so a slot read that misses to HBM (the plan is a pure stream) holds back
-            // every younger B-line load behind it; fetching one batch per iteration put that full latency into every
-            // iteration (measured: 1.95 us per 8 steps per wave, whatever the locality of B).  Now it is paid once
-            // per 32 steps.  Reads run one chunk past the octet (next octet's slots / the padding behind the last
-            // octet): they only ever become addresses of valid B lines, never FMAs.
-            int rn[PLAN_CHUNK];
-            double rvn[PLAN_CHUNK];
-            auto load_chunk = [&](int step, int (&c)[PLAN_CHUNK], double (&v)[PLAN_CHUNK]) {
-                const long long e = (long long)step * 8 + lane;
-#pragma unroll
-                for (int k = 0; k < PLAN_CHUNK; k++) { c[k] = pcol[e + 64 * k]; v[k] = pval[e + 64 * k]; }
-            };
-            int pc[U];
-            double pv[U];
-            real_t b[U][VEC];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                pc[u] = 0;
-                pv[u] = 0.0;
-#pragma unroll
-                for (int v = 0; v < VEC; v++) b[u][v] = 0;
-            }
-            // consume step u of the batch in (pc, pv, b): row switch -> fold the finished row into LDS, then FMA
-            auto consume = [&](int u) {
-                const int lrow = (int)((unsigned)pc[u] >> PLAN_ROW_SHIFT);
-                if (lrow != cur) {
-                    lds_fold<VEC>(my_rows + cur * S, acc);
-#pragma unroll
-                    for (int v = 0; v < VEC; v++) acc[v] = 0;
-                    cur = lrow;
-                }
-                const real_t a = (real_t)pv[u];
-#pragma unroll
-                for (int v = 0; v < VEC; v++) acc[v] = mx_fma(a, b[u][v], acc[v]);
-                // keep the reload BEHIND the FMAs that read the old line (and the FMAs where they are): letting the two
-                // cross renames b[u] and ends in a register copy at the back edge that waits for every load in flight
-#pragma unroll
-                for (int v = 0; v < VEC; v++) asm volatile("" : "+v"(acc[v]));
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            if (send > sbeg) {
-                if (!primed) load_chunk(sbeg, rc, rv);
-                // the first chunk has to be there before anything can start; with it complete at loop entry the
-                // compiler's vmcnt bookkeeping is exact on both edges of the loop
-#pragma unroll
-                for (int k = 0; k < PLAN_CHUNK; k++) asm volatile("" : "+v"(rc[k]), "+v"(rv[k]));
-            }
-            // Consumption lags one batch behind the broadcast + B-line load: while batch t is consumed step by step,
-            // the line of the same step of batch t+1 is requested into the registers the FMA just released, so 8
-            // B-line loads per wavefront are in flight all the time.  The first pass consumes the no-op batch set up
-            // above, the last batch is consumed after the loop.
-            bool meta = false;                                      // next octet's bounds / row map requested
-            primed = false;
-            for (int s = sbeg; s < send; s += U * PLAN_CHUNK) {      // sbeg, send are wave-uniform
-                const bool last = s + U * PLAN_CHUNK >= send;
-                if (octn_ok && !meta && s + 2 * U * PLAN_CHUNK >= send) {        // one chunk before the last, if there is one
-                    bounds_c = step_off[(size_t)oct_n * npanels + (lane < npanels ? lane : 0)];
-                    send_c = step_off[(size_t)oct_n * npanels + npanels];
-                    rowof_c = (int)rowmap[(size_t)oct_n * PLAN_OCT_ROWS + lane];
-                    meta = true;
-                }
-                // the read-ahead of the last chunk fetches the first chunk of the next octet instead of running past
-                // this one
-                int ahead = s + U * PLAN_CHUNK;
-                if (last && octn_ok) {
-                    ahead = __builtin_amdgcn_readfirstlane(bounds_c);
-                    primed = true;
-                }
-                load_chunk(ahead, rn, rvn);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < PLAN_CHUNK; k++) {
-#define MX_PLAN_STEP(UU)                                                                                              \
-                    consume(UU);                                                                                      \
-                    plan_bcast<UU>(rc[k], rv[k], pc[UU], pv[UU]);                                                     \
-                    vload<real_t, VEC>(b[UU], reinterpret_cast<const real_t *>(Bbase + b_offset(pc[UU])));            \
-                    __builtin_amdgcn_sched_barrier(0);
-                    MX_PLAN_STEP(0) MX_PLAN_STEP(1) MX_PLAN_STEP(2) MX_PLAN_STEP(3)
-                    MX_PLAN_STEP(4) MX_PLAN_STEP(5) MX_PLAN_STEP(6) MX_PLAN_STEP(7)
-#undef MX_PLAN_STEP
-                    if (sync_mode > 0) {
-                        const int sn = s + U * k;                   // steps consumed so far
-                        while (p < npanels - 1 && sn >= next_b) {   // the stream moved into the next panel
-                            p++;
-                            __syncthreads();
-                            next_b = p < npanels - 1 ? __builtin_amdgcn_readlane(bounds, p + 1) : send;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < PLAN_CHUNK; k++) { rc[k] = rn[k]; rv[k] = rvn[k]; }
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) consume(u);
-            lds_fold<VEC>(my_rows + cur * S, acc);
-            if (sync_mode > 0)
-                for (; p < npanels - 1; p++) __syncthreads();           // every wave meets npanels-1 times per generation
-        }
-
-        // each wavefront writes the 64 x W tile of C it accumulated (streaming stores: C is not read again); slot ->
-        // row through the octet's row map (identity unless the plan balanced the bundles)
-        if (oct_ok) {
-            const int row_base = oct * PLAN_OCT_ROWS;
-            const int ncols = min(W, n - slab * W);
-            if constexpr (!COLMAJOR) {
-#pragma unroll
-                for (int rr = 0; rr < PLAN_OCT_ROWS / 8; rr++) {
-                    const int r = rr * 8 + g;                        // slot
-                    const int row = row_base + __shfl(rowof, r, 64);
-                    if (row < m && lg * VEC < ncols) {
-                        real_t t[VEC];
-#pragma unroll
-                        for (int v = 0; v < VEC; v++) t[v] = my_oct[(size_t)r * S + lg * VEC + v];
-                        vstore_nt<real_t, VEC>(C + (size_t)row * ldc + slab * W + lg * VEC, t);
-                    }
-                }
-            } else {
-                // lane = slot: the 64 rows of the octet are one 512-byte (f64) segment of an output column
-                const int row = row_base + rowof;
-                if (row < m) {
-                    for (int c = 0; c < ncols; c++)
-                        __builtin_nontemporal_store(my_oct[(size_t)lane * S + c], &C[(size_t)(slab * W + c) * ldc + row]);
-                }
-            }
-        }
-    }
-}
-
-int exclusive_scan_i32(const int32_t *counts, int64_t n, int32_t *out, int64_t *total_dev, void *workspace,
-                       hipStream_t st);
-size_t scan_workspace_bytes(int64_t n);
-
-}  // namespace mx
-
-// device-resident plan of one CSR matrix (see the v3 comment above)
-struct mx_spmm_plan {
-    int m = 0, K = 0, npanels = 0, panel_cols = 0, noct = 0;
-    long long total_steps = 0;
-    long long nnz = 0;
-    int32_t *step_off = nullptr; size_t step_off_cap = 0;
-    int32_t *pcol = nullptr;     size_t pcol_cap = 0;
-    double *pval = nullptr;      size_t pval_cap = 0;
-    unsigned char *rowmap = nullptr; size_t rowmap_cap = 0;    // [noct][64]: slot -> row offset inside the octet
-    void *scratch = nullptr;     size_t scratch_cap = 0;       // rowpre + steps + scan workspace (build only)
-    double build_ms = 0.0;
-    bool ready = false;                                            // false: sized but not filled (rejected by AUTO)
-};
-
-namespace mx {
-
-static thread_local mx_spmm_plan *g_auto_plan = nullptr;
-
-static int grow(void **p, size_t *cap, size_t bytes)
-{
-    if (*cap >= bytes && *p) return 0;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr; *cap = 0;
-    MX_HIP(hipMalloc(p, bytes ? bytes : 16));
-    *cap = bytes;
-    return 0;
-}
-
-// pinned landing zone + event for the one host read-back of a plan build
-struct PlanReadback {
-    long long *host = nullptr;                                      // [0] total steps, [1] nnz (int32 in the low half)
-    hipEvent_t ev = nullptr;
-};
-static PlanReadback *plan_readback()
-{
-    static thread_local PlanReadback rb;
-    if (!rb.host) {
-        if (hipHostMalloc((void **)&rb.host, 2 * sizeof(long long), hipHostMallocDefault) != hipSuccess) { rb.host = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(rb.host); rb.host = nullptr; return nullptr; }
-    }
-    return &rb;
-}
-
-// max_pad_ratio > 0: stop after the sizing pass when the plan would hold more than ratio x nnz slots (rows of very
-// uneven length pad the 8-way interleave: an octet is as long as its longest bundle) — pl->ready stays false.
-static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, const int32_t *indices,
-                      const double *values, int npanels, hipStream_t st, double max_pad_ratio = 0.0)
-{
-    pl->ready = false;
-    MX_REQUIRE(K < (1 << 25), "spmm plan: more than 2^25 columns (32-bit slab offsets)");
-    // measured (cfg2, after the shared panel boundaries): 1.6 MB panels (P = 8) are best for the kernel (1.77 vs 1.86 ms at
-    // P = 5) and, by a hair, for kernel + plan build
-    if (npanels <= 0) npanels = pick_panels(K, (size_t)1664 << 10);
-    if (npanels > PLAN_MAXP) npanels = PLAN_MAXP;
-    pl->m = m; pl->K = K; pl->npanels = npanels;
-    pl->panel_cols = (int)ceil_div(K > 0 ? K : 1, npanels);
-    pl->noct = (int)ceil_div(m, PLAN_OCT_ROWS);
-    pl->total_steps = 0; pl->nnz = 0;
-    if (m == 0) { pl->ready = true; return 0; }                     // nothing to plan (and no zero-sized launches)
-    const size_t nop = (size_t)pl->noct * npanels;
-    const size_t al = 255;
-    const size_t steps_b = (((size_t)pl->noct * 4) + al) & ~al;
-    const size_t octoff_b = ((((size_t)pl->noct + 1) * 4) + al) & ~al;
-    const size_t bpo_b = ((nop * 8 * 4) + al) & ~al;
-    const size_t rb_b = 256;                                        // [total steps][nnz], read back in one copy
-    if (grow(&pl->scratch, &pl->scratch_cap, steps_b + octoff_b + bpo_b + rb_b + scan_workspace_bytes((int64_t)pl->noct))) return 1;
-    if (grow((void **)&pl->step_off, &pl->step_off_cap, (nop + 1) * 4)) return 1;
-    if (grow((void **)&pl->rowmap, &pl->rowmap_cap, (size_t)pl->noct * PLAN_OCT_ROWS)) return 1;
-    int32_t *steps = (int32_t *)pl->scratch;
-    int32_t *oct_off = (int32_t *)((char *)steps + steps_b);
-    int32_t *bpo = (int32_t *)((char *)oct_off + octoff_b);
-    long long *rb_dev = (long long *)((char *)bpo + bpo_b);
-    void *scan_ws = (char *)rb_dev + rb_b;
-    const unsigned blocks = (unsigned)pl->noct;
-    hipLaunchKernelGGL(plan_count_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       steps, bpo, pl->noct, rb_dev + 1, pl->rowmap);
-    MX_LAUNCH_CHECK();
-    if (exclusive_scan_i32(steps, (int64_t)pl->noct, oct_off, (int64_t *)rb_dev, scan_ws, st)) return 1;
-    PlanReadback *rb = plan_readback();
-    MX_REQUIRE(rb, "spmm plan: cannot allocate the pinned read-back buffer");
-    MX_HIP(hipMemcpyAsync(rb->host, rb_dev, 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
-    MX_HIP(hipEventRecord(rb->ev, st));
-    // (Packing B here, behind the read-back, would hide the host round trip — but the fill that follows then
-    // pushes the packed B out of the Infinity Cache and the sweep runs 2.75 ms instead of 2.05 ms.  B is packed right
-    // before the sweep.)
-    MX_HIP(hipEventSynchronize(rb->ev));
-    const long long total = rb->host[0];
-    pl->nnz = (int32_t)rb->host[1];
-    MX_REQUIRE(total >= 0 && total * 8 <= (long long)INT_MAX * 4LL, "spmm plan: too many steps (%lld)", total);
-    MX_REQUIRE(total <= (long long)INT_MAX, "spmm plan: step offsets exceed int32");
-    pl->total_steps = total;
-    if (max_pad_ratio > 0.0 && (double)total * 8.0 > (double)pl->nnz * max_pad_ratio + 65536.0) return 0;
-    const size_t slots = (size_t)total * 8 + PLAN_TAIL_SLOTS;
-    if (grow((void **)&pl->pcol, &pl->pcol_cap, slots * 4)) return 1;
-    if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
-    hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->rowmap);
-    MX_LAUNCH_CHECK();
-    pl->ready = true;
-    return 0;
-}
 
 // Optional HIP-event ring around the dominant kernel of every SpMM launch (bench.py's roofline figure): events sit
 // on the launch stream right before / after the kernel, nothing else in between.
@@ -1280,133 +18,28 @@ struct KernelTimer {
     int count = 0;
 };
 static thread_local KernelTimer g_kt;
-static void kt_begin(hipStream_t st)
+void kt_begin(hipStream_t st)
 {
     if (!g_kt.on || g_kt.count >= KernelTimer::N) return;
     if (!g_kt.made) { for (int i = 0; i < KernelTimer::N; i++) { (void)hipEventCreate(&g_kt.a[i]); (void)hipEventCreate(&g_kt.b[i]); } g_kt.made = true; }
     (void)hipEventRecord(g_kt.a[g_kt.count], st);
 }
-static void kt_end(hipStream_t st)
+void kt_end(hipStream_t st)
 {
     if (!g_kt.on || g_kt.count >= KernelTimer::N) return;
     (void)hipEventRecord(g_kt.b[g_kt.count], st);
     g_kt.count++;
 }
 
-// slab-major copy of B with one extra all-zero row (index K) per slab: the plan's padding slots point at it
-template <typename real_t>
-static int plan_repack(int K, int n, const real_t *B, size_t ldb, hipStream_t st, real_t **Bp_out)
-{
-    constexpr int VEC = 16 / (int)sizeof(real_t);
-    constexpr int W = SLAB_GROUP * VEC;
-    const int nslabs = (int)ceil_div(n, W);
-    const int Kp = K + 1;
-    real_t *Bp = (real_t *)slab_pack_workspace((size_t)nslabs * (size_t)Kp * W * sizeof(real_t));
-    MX_REQUIRE(Bp, "spmm plan: cannot allocate the packed copy of B");
-    const long long pieces = (long long)Kp * nslabs * SLAB_GROUP;
-    const unsigned gsz = (unsigned)(ceil_div(pieces, 256) < 8192 ? ceil_div(pieces, 256) : 8192);
-    hipLaunchKernelGGL((repack_slabs_kernel<real_t>), dim3(gsz), dim3(256), 0, st, K, Kp, n, nslabs, B, ldb, Bp);
-    MX_LAUNCH_CHECK();
-    *Bp_out = Bp;
-    return 0;
-}
-
-template <typename real_t>
-static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor,
-                    int wg_per_cu, int sync_mode, hipStream_t st)
-{
-    constexpr int VEC = 16 / (int)sizeof(real_t);
-    constexpr int W = SLAB_GROUP * VEC;
-    const int m = pl->m, K = pl->K;
-    const int nslabs = (int)ceil_div(n, W);
-    const int Kp = K + 1;
-    real_t *Bp = nullptr;
-    if (plan_repack<real_t>(K, n, B, ldb, st, &Bp)) return 1;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-    if (wg_per_cu != 1 && wg_per_cu != 2 && wg_per_cu != 4) wg_per_cu = PLAN_DEFAULT_WG_PER_CU;
-    const int waves = 16 / wg_per_cu;
-    const int ngens = (int)ceil_div(m, PLAN_OCT_ROWS * waves);
-    long long grid = (long long)cus * wg_per_cu;
-    const long long total = (long long)nslabs * ngens;
-    if (grid > total + 7) grid = total + 7;
-    grid = (grid / 8) * 8;
-    if (grid < 8) grid = 8;
-    unsigned *sync = slab_sync_workspace();
-    if (!sync || pl->npanels <= 1) sync_mode = 0;
-    if (sync_mode >= 2) MX_HIP(hipMemsetAsync(sync, 0, 8 * 64 * sizeof(unsigned), st));   // counters of the XCD timing barrier
-    kt_begin(st);
-#define MX_PLAN_LAUNCH(CM, WV)                                                                                           \
-    hipLaunchKernelGGL((spmm_plan_kernel<real_t, CM, WV>), dim3((unsigned)grid), dim3(WV * 64), 0, st, m, n, pl->npanels, \
-                       pl->step_off, pl->pcol, pl->pval, Bp, (size_t)Kp * W, C, ldc, nslabs, ngens, pl->noct, K,         \
-                       sync, sync_mode, pl->rowmap)
-    if (colmajor) {
-        if (waves == 16) MX_PLAN_LAUNCH(true, 16); else if (waves == 8) MX_PLAN_LAUNCH(true, 8); else MX_PLAN_LAUNCH(true, 4);
-    } else {
-        if (waves == 16) MX_PLAN_LAUNCH(false, 16); else if (waves == 8) MX_PLAN_LAUNCH(false, 8); else MX_PLAN_LAUNCH(false, 4);
-    }
-#undef MX_PLAN_LAUNCH
-    kt_end(st);
-    MX_LAUNCH_CHECK();
-    return 0;
-}
-
-// can the slab kernel take these operands?  (16-B aligned rows of B, whole vectors per row;
-// row-major C additionally needs 16-B aligned rows of C)
-template <typename real_t>
-static bool slab_ok(int n, const real_t *B, size_t ldb, const real_t *C, size_t ldc, int colmajor)
-{
-    constexpr int VEC = 16 / (int)sizeof(real_t);
-    if (n < VEC || n % VEC || ldb % VEC || (uintptr_t)B % 16) return false;
-    if (!colmajor && (ldc % VEC || (uintptr_t)C % 16)) return false;
-    return true;
-}
+static thread_local const char *g_last_spmm_kernel = "none";
+void set_last_spmm_kernel(const char *name) { g_last_spmm_kernel = name; }
 
 }  // namespace mx
-
-extern "C" int mxd_spmm_plan_create(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
-                                    int npanels, void *stream, mx_spmm_plan **plan_out)
-{
-    MX_REQUIRE(plan_out && m >= 0 && K >= 0, "mxd_spmm_plan_create: bad arguments");
-    mx_spmm_plan *pl = *plan_out ? *plan_out : new (std::nothrow) mx_spmm_plan();      // pass an old plan to reuse its buffers
-    MX_REQUIRE(pl, "out of host memory");
-    if (mx::plan_build(pl, m, K, indptr, indices, values, npanels, mx::as_stream(stream))) {
-        if (!*plan_out) { mxd_spmm_plan_destroy(pl); }
-        return 1;
-    }
-    *plan_out = pl;
-    return 0;
-}
-
-extern "C" int mxd_spmm_plan_destroy(mx_spmm_plan *pl)
-{
-    if (!pl) return 0;
-    if (pl->step_off) (void)hipFree(pl->step_off);
-    if (pl->pcol) (void)hipFree(pl->pcol);
-    if (pl->pval) (void)hipFree(pl->pval);
-    if (pl->scratch) (void)hipFree(pl->scratch);
-    if (pl->rowmap) (void)hipFree(pl->rowmap);
-    delete pl;
-    return 0;
-}
-
-extern "C" int mxd_spmm_plan_info(const mx_spmm_plan *pl, int *npanels, int64_t *padded_entries)
-{
-    MX_REQUIRE(pl, "mxd_spmm_plan_info: null plan");
-    if (npanels) *npanels = pl->npanels;
-    if (padded_entries) *padded_entries = pl->total_steps * 8;
-    return 0;
-}
-
-static thread_local const char *g_last_spmm_kernel = "none";
 
 // frees this thread's grow-only scratch (AUTO's plan, the slab-major copy of B); they are re-created on demand
 extern "C" int mxd_release_workspaces(void)
 {
-    if (mx::g_auto_plan) { mxd_spmm_plan_destroy(mx::g_auto_plan); mx::g_auto_plan = nullptr; }
+    mx::plan_auto_release();
     mx::slab_pack_workspace(0, true);
     return 0;
 }
@@ -1431,30 +64,7 @@ extern "C" int mxd_spmm_kernel_times(float *out_ms, int max_out, int *count)
     return 0;
 }
 
-extern "C" int mxd_spmm_plan_run(const mx_spmm_plan *pl, int n, const void *B, size_t ldb, void *C, size_t ldc,
-                                 int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream)
-{
-    MX_REQUIRE(pl && n >= 0, "mxd_spmm_plan_run: bad arguments");
-    MX_REQUIRE(pl->ready, "mxd_spmm_plan_run: the plan was sized but not built");
-    if (pl->m == 0 || n == 0) return 0;
-    MX_REQUIRE(B && C, "mxd_spmm_plan_run: null pointer");
-    hipStream_t st = mx::as_stream(stream);
-    if (sync_mode < 0) sync_mode = 1;       // panel meetings inside the CU's workgroup; 2 adds one XCD barrier per generation
-    g_last_spmm_kernel = "spmm_plan_kernel";
-    if (dense_dtype == MX_F64) {
-        MX_REQUIRE(mx::slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor_out),
-                   "mxd_spmm_plan_run: operands do not meet the 16-byte alignment rules");
-        return mx::plan_run<double>(pl, n, (const double *)B, ldb, (double *)C, ldc, colmajor_out, wg_per_cu, sync_mode, st);
-    }
-    if (dense_dtype == MX_F32) {
-        MX_REQUIRE(mx::slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor_out),
-                   "mxd_spmm_plan_run: operands do not meet the 16-byte alignment rules");
-        return mx::plan_run<float>(pl, n, (const float *)B, ldb, (float *)C, ldc, colmajor_out, wg_per_cu, sync_mode, st);
-    }
-    return mx::set_error("mxd_spmm_plan_run: unsupported dense dtype %d", dense_dtype);
-}
-
-extern "C" const char *mxd_spmm_last_kernel(void) { return g_last_spmm_kernel; }
+extern "C" const char *mxd_spmm_last_kernel(void) { return mx::g_last_spmm_kernel; }
 
 extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
                                      const int32_t *indptr, const int32_t *indices, const double *values,
@@ -1484,30 +94,27 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
     }
     if (algo == MX_SPMM_PLANNED) {
         MX_REQUIRE(ok, "mxd_spmm_csr_dense_ex: operands do not meet the planned kernel's 16-byte alignment rules");
-        mx_spmm_plan *&auto_plan = mx::g_auto_plan;                  // buffers re-used from call to call (grow-only)
-        if (!auto_plan) auto_plan = new (std::nothrow) mx_spmm_plan();
-        MX_REQUIRE(auto_plan, "out of host memory");
         // Measured with log-normal row lengths (tools/skew_probe.py): up to ~1.8x the CSR the planned sweep still
         // beats the row-wave kernel even with the plan built per call; beyond that AUTO stops after the sizing pass
         // (count + scan, ~0.1 ms) and uses the row-wave kernel.
-        if (mx::plan_build(auto_plan, m, K, indptr, indices, values, npanels, st, auto_pick_planned ? 1.75 : 0.0)) return 1;
-        if (auto_plan->ready)
-            return mxd_spmm_plan_run(auto_plan, n, B, ldb, C, ldc, dense_dtype, colmajor_out, 0, -1, stream);
+        bool ready = false;          // the plan's buffers are re-used from call to call (grow-only, per thread)
+        if (mx::plan_auto_build(m, K, indptr, indices, values, npanels, st, auto_pick_planned ? 1.75 : 0.0, &ready)) return 1;
+        if (ready) return mx::plan_auto_run(n, B, ldb, C, ldc, dense_dtype, colmajor_out, stream);
         algo = MX_SPMM_ROWWAVE;
     }
     if (algo == MX_SPMM_SLAB) {
         MX_REQUIRE(ok, "mxd_spmm_csr_dense_ex: operands do not meet the slab kernel's 16-byte alignment rules");
-        g_last_spmm_kernel = "spmm_slab_kernel";
+        mx::set_last_spmm_kernel("spmm_slab_kernel");
         if (npanels <= 0) npanels = rows_sorted ? mx::pick_panels(K, (size_t)2560 << 10) : 1;
         if (!rows_sorted) npanels = 1;                 // panels need column-sorted rows
         if (wg_per_cu <= 0) wg_per_cu = 4;
         if (dense_dtype == MX_F64)
-            return mx::launch_spmm_slab<double>(m, n, K, indptr, indices, values, (const double *)B, ldb, (double *)C,
+            return mx::slab_spmm<double>(m, n, K, indptr, indices, values, (const double *)B, ldb, (double *)C,
                                                 ldc, colmajor_out, npanels, wg_per_cu, st);
-        return mx::launch_spmm_slab<float>(m, n, K, indptr, indices, values, (const float *)B, ldb, (float *)C, ldc,
+        return mx::slab_spmm<float>(m, n, K, indptr, indices, values, (const float *)B, ldb, (float *)C, ldc,
                                            colmajor_out, npanels, wg_per_cu, st);
     }
-    g_last_spmm_kernel = "spmm_rowwave_kernel";
+    mx::set_last_spmm_kernel("spmm_rowwave_kernel");
     return mxd_spmm_csr_dense(m, n, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor_out, stream);
 }
 
@@ -1521,10 +128,10 @@ extern "C" int mxd_spmm_csr_dense(int m, int n,
     MX_REQUIRE(indptr && B && C, "mxd_spmm_csr_dense: null pointer");
     hipStream_t st = mx::as_stream(stream);
     if (dense_dtype == MX_F64)
-        return mx::dispatch_spmm<double, 2>(m, n, indptr, indices, values, (const double *)B, ldb,
-                                            (double *)C, ldc, colmajor_out, st);
+        return mx::rowwave_spmm<double>(m, n, indptr, indices, values, (const double *)B, ldb, (double *)C, ldc,
+                                        colmajor_out, st);
     if (dense_dtype == MX_F32)
-        return mx::dispatch_spmm<float, 4>(m, n, indptr, indices, values, (const float *)B, ldb,
-                                           (float *)C, ldc, colmajor_out, st);
+        return mx::rowwave_spmm<float>(m, n, indptr, indices, values, (const float *)B, ldb, (float *)C, ldc,
+                                       colmajor_out, st);
     return mx::set_error("mxd_spmm_csr_dense: unsupported dense dtype %d", dense_dtype);
 }

@@ -1,0 +1,807 @@
+// spmm_plan.hip — the planned panel-sweep SpMM (v3, what MX_SPMM_AUTO runs for large operands): plan construction
+// kernels, the sweep kernel, the plan object and its C-ABI (mxd_spmm_plan_*).
+#include "spmm_common.h"
+
+namespace mx {
+
+// =====================================================================================================
+// v3 "planned panel sweep".
+//
+// PMC on v2 (profiles/r01_v2_*): with column panels + the XCD timing barrier the L2 hit rate only reaches
+// 60 % because every (row, panel) visit re-reads the row's (j, a) chunk — with P panels the CSR arrays are
+// streamed ~2P times per XCD and that traffic, not B, dominates and evicts the panel.  v3 fixes the data
+// layout instead of the loop: a *plan* regroups A's entries by (octet of 8 row-bundles, panel) and
+// interleaves the 8 bundles of an octet in batches of 8 steps (slot 64*batch + 8*g + u = step 8*batch + u of
+// bundle g), so that
+//   * one wavefront (8 lane groups = 8 bundles) reads 64 consecutive plan entries per 8 steps — every entry of A
+//     is read exactly once per slab, coalesced, and reaches its lane group by a DPP row broadcast;
+//   * entries of a bundle inside a panel are ordered by row, the group accumulates the current row in
+//     registers and folds it into the bundle's accumulators in LDS when the row changes (only that group
+//     touches those LDS rows: plain read-modify-write, no atomics);
+//   * all workgroups of an XCD group stay close to the same panel (same code on statistically identical data;
+//     optional timing barrier), whose slab-major copy of B
+//     (K/P x 128 B, contiguous) fits the XCD's L2.
+// Entry = int32 (col | local_row << 27; padding = zero row of the packed B, value 0) + f64 value; plan bytes ~ the CSR arrays (octet lengths rounded to 8 steps).
+// Summation order: CSR order inside a (row, panel), panels added in ascending order — a regrouping of the
+// reference's sequential sum (tolerance-level difference, not bitwise).  Works for unsorted rows too.
+// =====================================================================================================
+constexpr int PLAN_RB = 8;                         // rows per bundle (owned by one 8-lane group)
+constexpr int PLAN_OCT_ROWS = PLAN_RB * 8;         // rows per octet (one wavefront)
+// wavefronts per workgroup (template parameter WAVES): 16 = ONE 1024-thread workgroup with 128 KiB of LDS per CU,
+// 8 = two 512-thread workgroups with 64 KiB each (one's epilogue overlaps the other's sweep), 4 = four.
+constexpr int PLAN_MAXP = 64;
+constexpr int PLAN_DEFAULT_WG_PER_CU = 1;
+constexpr int PLAN_GEN_OCTS = 16;                  // octets one 16-wavefront workgroup sweeps together
+constexpr int PLAN_CHUNK = 4;                      // batches of 8 steps fetched per plan read (octets are whole chunks)
+constexpr int PLAN_TAIL_SLOTS = 512;               // readable padding behind the last octet (2 chunks)
+constexpr int PLAN_ROW_SHIFT = 27;                 // col < 2^27
+
+// Plan construction: one 512-thread workgroup per octet, one wavefront per bundle.  A bundle's entries are contiguous
+// in the CSR arrays (8 consecutive rows), so the wavefront streams them 64 at a time, fully coalesced; the position
+// of an entry inside its (bundle, panel) stream is a per-panel running count kept in scalar registers plus a
+// ballot prefix — no LDS, no per-row bookkeeping.
+// pass 1: bpo[bundle][p] = where panel p starts in the bundle's stream; steps[oct] = longest bundle of the octet.
+constexpr int PLAN_LD = 4;
+// col / panel_cols without the integer divide: float estimate (col < 2^25 is exact in float up to 2^24, so one
+// correction step either way), clamped to the last panel
+__device__ __forceinline__ int panel_of(int col, int panel_cols, float inv_pc, int npanels)
+{
+    int q = (int)((float)col * inv_pc);
+    const int r = col - q * panel_cols;
+    q += r >= panel_cols ? 1 : (r < 0 ? -1 : 0);
+    return q < npanels ? q : npanels - 1;
+}
+
+// Which of the octet's 64 rows sits in which (bundle, local row) slot.  Consecutive rows (slot = row offset) when that
+// is balanced; otherwise the rows are sorted by length (bitonic sort inside the wavefront) and dealt to the bundles in
+// serpentine order, which keeps the longest bundle — the octet's length, everything shorter is padding — close to
+// the mean.  Log-normal row lengths (sigma 1) pad the plan 1.84x with consecutive rows.  Every wavefront of the
+// workgroup computes the same answer from the same 65 row pointers: no LDS, no synchronisation.
+// Returns the row offset (0..63) assigned to slot `lane`.
+__device__ __forceinline__ int octet_assign(int m, const int32_t *__restrict__ indptr, int oct, int lane,
+                                            int &ptr_out, int &len_out)
+{
+    const long long row = (long long)oct * PLAN_OCT_ROWS + lane;
+    const int ptr = indptr[row < m ? row : m];                       // one load per lane + the octet's end pointer
+    const int pend = indptr[(long long)(oct + 1) * PLAN_OCT_ROWS < m ? (long long)(oct + 1) * PLAN_OCT_ROWS : m];
+    const int nxt = __shfl_down(ptr, 1, 64);
+    const int len = (lane == 63 ? pend : nxt) - ptr;
+    ptr_out = ptr;                                                   // row `lane` of the octet: [ptr, ptr + len)
+    len_out = len;
+    if (__ballot(len != __builtin_amdgcn_readfirstlane(len)) == 0ULL) return lane;     // all rows equally long
+    int idsum = len;                                                 // sum of my bundle with consecutive rows
+    idsum += __shfl_xor(idsum, 1, 64); idsum += __shfl_xor(idsum, 2, 64); idsum += __shfl_xor(idsum, 4, 64);
+    int idmax = idsum;
+    idmax = max(idmax, __shfl_xor(idmax, 8, 64)); idmax = max(idmax, __shfl_xor(idmax, 16, 64));
+    idmax = max(idmax, __shfl_xor(idmax, 32, 64));
+    // no assignment can beat ceil(total / 8): consecutive rows that already reach it (in whole chunks of 32 steps) stay
+    int total = idsum;
+    total += __shfl_xor(total, 8, 64); total += __shfl_xor(total, 16, 64); total += __shfl_xor(total, 32, 64);
+    if (((idmax + 31) >> 5) <= ((((total + 7) >> 3) + 31) >> 5)) return lane;          // wave-uniform
+    // descending bitonic sort of (length, lower row first)
+    unsigned long long key = ((unsigned long long)(unsigned)len << 6) | (unsigned)(63 - lane);
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const unsigned long long other = __shfl_xor(key, j, 64);
+            const bool keep_max = (((lane & k) == 0) == ((lane & j) == 0));   // descending overall
+            key = keep_max ? (key > other ? key : other) : (key < other ? key : other);
+        }
+    }
+    const int slen = (int)(key >> 6), sidx = 63 - (int)(key & 63);   // lane r: r-th longest row
+    // serpentine deal: rank r = 8k + pos goes to bundle (k even ? pos : 7 - pos), local row k
+    const int my_b = lane >> 3, my_k = lane & 7;                     // lane seen as slot (bundle, local row)
+    const int my_rank = my_k * 8 + ((my_k & 1) ? 7 - my_b : my_b);
+    int balsum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) balsum += __shfl(slen, k * 8 + ((k & 1) ? 7 - my_b : my_b), 64);
+    int balmax = balsum;
+    balmax = max(balmax, __shfl_xor(balmax, 8, 64)); balmax = max(balmax, __shfl_xor(balmax, 16, 64));
+    balmax = max(balmax, __shfl_xor(balmax, 32, 64));
+    const int dealt = __shfl(sidx, my_rank, 64);
+    // only when it shortens the octet by a whole chunk of 32 steps (uniform matrices keep consecutive rows)
+    const bool permute = ((balmax + 31) >> 5) < ((idmax + 31) >> 5);
+    return permute ? dealt : lane;
+}
+
+__global__ __launch_bounds__(512)
+void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
+                       const int32_t *__restrict__ indices, int32_t *__restrict__ steps,
+                       int32_t *__restrict__ bpo, int noct, long long *__restrict__ nnz_out,
+                       unsigned char *__restrict__ rowmap)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nnz_out = indptr[m];     // rides back with the step total (one copy)
+    __shared__ int totals[8];
+    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int oct = blockIdx.x;
+    int rptr, rlen;                                                  // row pointers of the octet, one row per lane
+    const int rowof = octet_assign(m, indptr, oct, lane, rptr, rlen);
+    const bool identity = __ballot(rowof != lane) == 0ULL;
+    if (g == 0) rowmap[(size_t)oct * PLAN_OCT_ROWS + lane] = (unsigned char)rowof;
+    int mine = 0;                                                    // lane p accumulates the count of panel p (+64, ...)
+    int total_b = 0;
+    const float inv_pc = 1.0f / (float)panel_cols;
+    // PLAN_LD chunks of 64 entries per pass: the loads of a pass are issued together (the kernel is latency-bound:
+    // a bundle is only ~256 entries)
+    auto count_range = [&](int s, int e) {
+        total_b += e - s;
+        for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
+            int col[PLAN_LD];
+#pragma unroll
+            for (int c = 0; c < PLAN_LD; c++) {
+                const int k = k0 + 64 * c + lane;
+                col[c] = k < e ? indices[k] : -1;
+            }
+#pragma unroll
+            for (int c = 0; c < PLAN_LD; c++) {
+                if (k0 + 64 * c >= e) break;                         // uniform
+                const int pan = col[c] >= 0 ? panel_of(col[c], panel_cols, inv_pc, npanels) : -1;
+                for (int q = 0; q < npanels; q++) {
+                    const int cnt = __popcll(__ballot(pan == q));
+                    if (lane == (q & 63)) mine += cnt;               // npanels <= 64: one lane per panel
+                }
+            }
+        }
+    };
+    if (identity) {                                                  // 8 consecutive rows: one contiguous range
+        const int s = __shfl(rptr, g * PLAN_RB, 64);
+        const int e = __shfl(rptr, g * PLAN_RB + PLAN_RB - 1, 64) + __shfl(rlen, g * PLAN_RB + PLAN_RB - 1, 64);
+        count_range(s, e);
+    } else {                                                         // my 8 rows, in local-row order
+#pragma unroll
+        for (int r = 0; r < PLAN_RB; r++) {
+            const int rr = __shfl(rowof, g * PLAN_RB + r, 64);
+            const int s = __shfl(rptr, rr, 64);
+            count_range(s, s + __shfl(rlen, rr, 64));
+        }
+    }
+    // exclusive prefix over the panels (lanes 0..npanels-1)
+    int incl = lane < npanels ? mine : 0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane < npanels) bpo[((size_t)oct * 8 + g) * npanels + lane] = incl - mine;
+    if (lane == 0) totals[g] = total_b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int mx = 0;
+#pragma unroll
+        for (int gg = 0; gg < 8; gg++) mx = max(mx, totals[gg]);
+        steps[oct] = (mx + 8 * PLAN_CHUNK - 1) & ~(8 * PLAN_CHUNK - 1);    // whole chunks of 4 batches of 8 steps (slot layout below)
+    }
+}
+
+// pass 2: scatter the entries to their interleaved slots (batch of 8 steps = 64 slots laid out [bundle][step])
+__global__ __launch_bounds__(512)
+void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
+                      const int32_t *__restrict__ indices, const double *__restrict__ values,
+                      const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
+                      int32_t *__restrict__ pcol, double *__restrict__ pval, int noct, int pad_col,
+                      int32_t *__restrict__ step_off, const unsigned char *__restrict__ rowmap)
+{
+    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int oct = blockIdx.x;
+    // Where the kernel's wavefronts meet (locality only, any value is correct): the 16 octets that one workgroup
+    // sweeps together share the panel boundaries, as fractions of each octet's own length — the mean panel start over
+    // the 128 bundles of the group.  With per-octet boundaries every meeting waited for the wavefront whose panel
+    // happened to be longest (entries per octet and panel vary by ~4 %: the sum of the 5 maxima is ~8 % more than the
+    // common length); with shared boundaries equally long octets arrive together.
+    if (g == 0 && lane < npanels) {
+        const int o0 = (oct / PLAN_GEN_OCTS) * PLAN_GEN_OCTS, o1 = min(o0 + PLAN_GEN_OCTS, noct);
+        long long sum = 0;
+        for (int o = o0; o < o1; o++) {
+#pragma unroll
+            for (int gg = 0; gg < 8; gg++) sum += bpo[((size_t)o * 8 + gg) * npanels + lane];
+        }
+        const long long len = (long long)oct_off[o1] - oct_off[o0];                     // sum of the octets' lengths
+        const int mine = oct_off[oct + 1] - oct_off[oct];
+        const double frac = len > 0 ? (double)sum / (8.0 * (double)len) : 0.0;
+        int b = lane == 0 ? 0 : (int)(frac * (double)mine);
+        if (b > mine) b = mine;
+        step_off[(size_t)oct * npanels + lane] = oct_off[oct] + b;
+        if (oct == noct - 1 && lane == 0) step_off[(size_t)noct * npanels] = oct_off[noct];
+    }
+    const int rowof = rowmap[(size_t)oct * PLAN_OCT_ROWS + lane];    // written by the count pass (octet_assign)
+    const bool identity = __ballot(rowof != lane) == 0ULL;
+    const long long base = oct_off[oct];
+    // lane q keeps the next free step of panel q's stream
+    int nextstep = lane < npanels ? bpo[((size_t)oct * 8 + g) * npanels + lane] : 0;
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    const float inv_pc = 1.0f / (float)panel_cols;
+    int total_b = 0, last_lrow = 0;
+    // entries [s, e) of the CSR arrays; local row of entry k = lrow0 + #(bounds rp[1..7] <= k)  (rp = INT_MAX: none)
+    auto fill_range = [&](int s, int e, int lrow0, const int (&rp)[PLAN_RB + 1]) {
+        total_b += e - s;
+        for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
+            int colv[PLAN_LD];
+            double av[PLAN_LD];
+#pragma unroll
+            for (int c = 0; c < PLAN_LD; c++) {                      // all loads of the pass in flight together
+                const int k = k0 + 64 * c + lane;
+                colv[c] = -1; av[c] = 0.0;
+                if (k < e) { colv[c] = indices[k]; av[c] = values[k]; }
+            }
+#pragma unroll
+            for (int c = 0; c < PLAN_LD; c++) {
+                if (k0 + 64 * c >= e) break;                         // uniform
+                const int k = k0 + 64 * c + lane;
+                const int col = colv[c];
+                int pan = -1, lrow = lrow0;
+                if (col >= 0) {
+                    pan = panel_of(col, panel_cols, inv_pc, npanels);
+#pragma unroll
+                    for (int r = 1; r < PLAN_RB; r++) lrow += k >= rp[r];
+                }
+                int t = 0;                                           // my entry's step inside the octet
+                for (int q = 0; q < npanels; q++) {
+                    const unsigned long long same = __ballot(pan == q);
+                    if (same == 0ULL) continue;                      // uniform
+                    const int start = __builtin_amdgcn_readlane(nextstep, q);
+                    if (pan == q) t = start + __popcll(same & below);
+                    if (lane == q) nextstep += __popcll(same);
+                }
+                if (pan >= 0) {
+                    // ONE pair of stores per chunk (inside the panel loop it was one pair per panel, each with 1/P of
+                    // the lanes).  Slot layout inside a batch of 8 steps: [bundle g][step u] — lane 8g+u of the reading
+                    // wavefront holds bundle g's entry for step u, i.e. inside g's own lane group (DPP broadcast).
+                    const long long dst = (base + (t & ~7)) * 8 + g * 8 + (t & 7);
+                    pcol[dst] = col | (lrow << PLAN_ROW_SHIFT);
+                    pval[dst] = av[c];
+                }
+            }
+        }
+    };
+    if (identity) {
+        const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
+        int rp[PLAN_RB + 1];                                         // the bundle's row pointers (wave-uniform)
+#pragma unroll
+        for (int r = 0; r <= PLAN_RB; r++) rp[r] = uniform(indptr[min(row0 + r, m)]);
+        fill_range(rp[0], rp[PLAN_RB], 0, rp);
+        if (rp[PLAN_RB] > rp[0]) {
+#pragma unroll
+            for (int r = 1; r < PLAN_RB; r++) last_lrow += (rp[PLAN_RB] - 1) >= rp[r];
+        }
+    } else {
+        const int rr = __shfl(rowof, g * PLAN_RB + (lane & 7), 64);
+        const long long row = (long long)oct * PLAN_OCT_ROWS + rr;
+        const int ps = row < m ? indptr[row] : 0, pe = row < m ? indptr[row + 1] : 0;
+        int none[PLAN_RB + 1];
+#pragma unroll
+        for (int r = 0; r <= PLAN_RB; r++) none[r] = INT_MAX;
+#pragma unroll
+        for (int r = 0; r < PLAN_RB; r++) {
+            const int s = uniform(__shfl(ps, r, 64)), e = uniform(__shfl(pe, r, 64));
+            fill_range(s, e, r, none);
+            if (e > s) last_lrow = r;
+        }
+    }
+    // Padding up to the octet's length: a no-op entry — value 0, column `pad_col` (the all-zero extra row of the
+    // packed B), row = the bundle's last entry's row so that it does not even trigger a row switch.  0 * 0 added to
+    // an accumulator that is never -0.0 leaves it unchanged bit for bit.
+    const int steps_oct = oct_off[oct + 1] - (int)base;
+    for (long long t = total_b + lane; t < steps_oct; t += 64) {
+        const long long dst = (base + (t & ~7LL)) * 8 + g * 8 + (t & 7);
+        pcol[dst] = pad_col | (last_lrow << PLAN_ROW_SHIFT);
+        pval[dst] = 0.0;
+    }
+    // PLAN_TAIL_SLOTS padding slots behind the last octet: the kernel's read-ahead runs two batches past an octet
+    if (oct == noct - 1) {
+        static_assert(PLAN_TAIL_SLOTS == 512, "one slot per thread of the last block");
+        const long long dst = (long long)oct_off[noct] * 8 + threadIdx.x;
+        pcol[dst] = pad_col;
+        pval[dst] = 0.0;
+    }
+}
+
+// broadcast lane U of every 8-lane group: row_newbcast takes lane n of each 16-lane DPP row; bank_mask restricts the
+// write to the low / high half of the row (banks of 4 lanes), so two moves serve the two groups of a row
+template <int U>
+__device__ __forceinline__ int group8_dpp_bcast(int v)
+{
+    int t = __builtin_amdgcn_mov_dpp(v, 0x150 + U, 0xF, 0x3, false);      // lanes of the other half: don't care
+    return __builtin_amdgcn_update_dpp(t, v, 0x150 + 8 + U, 0xF, 0xC, false);
+}
+template <int U>
+__device__ __forceinline__ void plan_bcast(int pcw, double pvw, int &pc, double &pv)
+{
+    union { double d; int i[2]; } a, b;
+    a.d = pvw;
+    pc = group8_dpp_bcast<U>(pcw);
+    b.i[0] = group8_dpp_bcast<U>(a.i[0]);
+    b.i[1] = group8_dpp_bcast<U>(a.i[1]);
+    pv = b.d;
+}
+
+// Fold a finished row's partial sums into its LDS accumulators.  Only this lane ever touches these words and one
+// wavefront's LDS operations execute in order, so both forms are the same sequence of additions.  f64: two
+// fire-and-forget ds_add_f64 (no return value, nothing to wait for; the read-modify-write cost an LDS round trip on
+// ~70 % of the steps).  f32: read-modify-write of one 16-byte word (four ds_add_f32 measured 2.4x slower overall).
+template <int VEC>
+__device__ __forceinline__ void lds_fold(double *d, double (&acc)[VEC])
+{
+#pragma unroll
+    for (int v = 0; v < VEC; v++) __hip_atomic_fetch_add(d + v, acc[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int VEC>
+__device__ __forceinline__ void lds_fold(float *d, float (&acc)[VEC])
+{
+#pragma unroll
+    for (int v = 0; v < VEC; v++) d[v] += acc[v];
+}
+
+// main kernel
+template <typename real_t, bool COLMAJOR, int PLAN_WAVES>
+__global__ __launch_bounds__(PLAN_WAVES * 64)
+void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ step_off,
+                      const int32_t *__restrict__ pcol, const double *__restrict__ pval,
+                      const real_t *__restrict__ Bp, size_t slab_stride,
+                      real_t *__restrict__ C, size_t ldc, int nslabs, int ngens, int noct, int pad_col,
+                      unsigned *__restrict__ sync_ctr, int sync_mode, const unsigned char *__restrict__ rowmap)
+{
+    constexpr int VEC = 16 / (int)sizeof(real_t);
+    constexpr int W = SLAB_GROUP * VEC;
+    constexpr int U = 8;                                            // plan steps in flight per wavefront
+    constexpr int PLAN_WG_ROWS = PLAN_OCT_ROWS * PLAN_WAVES;        // rows per workgroup generation
+    // accumulator rows are padded by 8 (f64) / 16 (f32) bytes: the column-major epilogue reads one column of 64
+    // consecutive rows per instruction, which at a 128-byte stride would hit a single LDS bank pair
+    constexpr int S = W + 16 / (int)sizeof(real_t) / 2;
+    __shared__ real_t accs[PLAN_WG_ROWS * S];                       // 16 waves: 1024 rows x 136 B = 136 KiB
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, lg = lane & 7;
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
+    const long long total = (long long)nslabs * ngens;
+    const long long lo = total * xcd / 8, hi = total * (xcd + 1) / 8;
+    const int niter = (int)((hi - lo + nwg - 1) / nwg);
+    unsigned *const my_ctr = sync_ctr + xcd * 64;
+    real_t *const my_oct = accs + (size_t)wave * PLAN_OCT_ROWS * S;                     // this wavefront's 64 rows
+    real_t *const my_rows = my_oct + (size_t)g * PLAN_RB * S + lg * VEC;                // this group's bundle
+
+    // Carried from one generation to the next: the stream bounds, the row map and the FIRST chunk of plan slots of the
+    // wavefront's next octet are requested during the last chunk of the current one, so that a generation does not
+    // start with two exposed memory latencies (bounds, then the first chunk: ~3-4 us of a ~58 us generation).
+    bool primed = false;                                            // wave-uniform
+    int bounds_c = 0, send_c = 0, rowof_c = 0;
+    int rc[PLAN_CHUNK];
+    double rv[PLAN_CHUNK];
+#pragma unroll
+    for (int k = 0; k < PLAN_CHUNK; k++) { rc[k] = 0; rv[k] = 0.0; }
+    for (int it = 0; it < niter; it++) {
+        const long long item_raw = lo + wg + (long long)it * nwg;
+        const bool have = item_raw < hi;
+        const long long item = have ? item_raw : lo;
+        const int slab = (int)(item / ngens), gen = (int)(item % ngens);
+        const int oct = gen * PLAN_WAVES + wave;
+        const bool oct_ok = have && oct < noct;
+        // this wavefront's octet of the next generation (if any)
+        const long long item_n = item_raw + nwg;
+        const int oct_n = (int)(item_n % ngens) * PLAN_WAVES + wave;
+        const bool octn_ok = it + 1 < niter && item_n < hi && oct_n < noct;
+        // slab base is wave-uniform (scalar registers), the per-lane part is a 32-bit byte offset: one VALU op per
+        // address.  A slab is K x 128 B < 4 GiB because K < 2^27... checked on the host (K * 128 < 2^32).
+        const char *__restrict__ Bbase = reinterpret_cast<const char *>(Bp + (size_t)slab * slab_stride);
+        const unsigned lane_off = (unsigned)(lg * VEC * sizeof(real_t));
+
+        // A wavefront's accumulator rows are touched by that wavefront only (zeroing, folds, epilogue): no
+        // workgroup-wide synchronisation around a generation, the wavefronts only meet at the panel boundaries.
+        for (int i = lane; i < PLAN_OCT_ROWS * S; i += 64) my_oct[i] = 0;
+        if (sync_mode > 0) __syncthreads();                          // locality only: start the first panel together
+
+        // One continuous, software-pipelined stream over the octet's entries of ALL panels (they are contiguous in
+        // the plan).  Panel boundaries only matter for locality: when the stream crosses one, the 16 waves of the
+        // CU's single workgroup meet at a __syncthreads (no global traffic, no pipeline restart: the prefetched
+        // plan entries stay in flight).  Across the 32 CUs of the XCD group there is ONE global timing barrier per
+        // generation (32 pollers per counter); in between the CUs run identical code on statistically identical
+        // data and drift by a fraction of a panel.
+        int rowof = lane;
+        {
+            if (sync_mode >= 2) xcd_timing_barrier(my_ctr, (unsigned)(it + 1) * (unsigned)nwg);
+            // The octet's stream bounds and its slot -> row map (identity unless the plan balanced the bundles; used by
+            // the epilogue only) are requested AFTER the barrier: a load in flight at a barrier makes all 16 wavefronts
+            // wait for the slowest one (measured: +0.03 ms per launch for each of the two).
+            // All panel boundaries of the octet come in with ONE load (lane p holds the start of the p-th panel) and
+            // are picked out with v_readlane when the stream crosses a panel: a load at every boundary had to be
+            // waited for with vmcnt(0), i.e. it drained the whole B-line pipeline once per panel.
+            int bounds = 0, send = 0;
+            if (primed) {                                           // requested during the previous generation
+                bounds = bounds_c; send = send_c; rowof = rowof_c;
+            } else if (oct_ok) {
+                bounds = step_off[(size_t)oct * npanels + (lane < npanels ? lane : 0)];
+                send = step_off[(size_t)oct * npanels + npanels];
+                rowof = (int)rowmap[(size_t)oct * PLAN_OCT_ROWS + lane];
+            }
+            int sbeg = __builtin_amdgcn_readfirstlane(bounds);      // wave-uniform: keep the loop control scalar
+            send = __builtin_amdgcn_readfirstlane(send);
+            int next_b = npanels > 1 ? __builtin_amdgcn_readlane(bounds, 1) : send;
+            int p = 0;
+            int cur = 0;
+            real_t acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] = 0;
+            // A batch = U = 8 steps = 64 consecutive plan slots, laid out [bundle g][step u]: lane l reads slot
+            // (8 s + l) — one fully coalesced 256 B + 512 B read per batch — and step u's entry is broadcast from
+            // lane u of each group.  (Reading the slot from all 8 lanes of a group instead costs the texture
+            // addresser 8x the lane-bytes: PMC showed TA_BUSY 71 % and the kernel TA-bound.)
+            // Every slot is a valid entry: padding is (zero row of B, value 0, current row) — no per-step validity
+            // test, no clamp.
+            static_assert(U == 8, "one batch = one wavefront of plan slots");
+            static_assert(W * sizeof(real_t) == 128, "slab line");
+            auto b_offset = [&](int c) -> unsigned {                // the row bits (27..29) fall off the 32-bit shift
+                return ((unsigned)c * (unsigned)(W * sizeof(real_t))) + lane_off;
+            };
+            // The plan slots are fetched a CHUNK (PLAN_CHUNK = 4 batches = 32 steps) at a time, one chunk ahead.
+            // Vector loads return in order, so a slot read that misses to HBM (the plan is a pure stream) holds back
+            // every younger B-line load behind it; fetching one batch per iteration put that full latency into every
+            // iteration (measured: 1.95 us per 8 steps per wave, whatever the locality of B).  Now it is paid once
+            // per 32 steps.  Reads run one chunk past the octet (next octet's slots / the padding behind the last
+            // octet): they only ever become addresses of valid B lines, never FMAs.
+            int rn[PLAN_CHUNK];
+            double rvn[PLAN_CHUNK];
+            auto load_chunk = [&](int step, int (&c)[PLAN_CHUNK], double (&v)[PLAN_CHUNK]) {
+                const long long e = (long long)step * 8 + lane;
+#pragma unroll
+                for (int k = 0; k < PLAN_CHUNK; k++) { c[k] = pcol[e + 64 * k]; v[k] = pval[e + 64 * k]; }
+            };
+            int pc[U];
+            double pv[U];
+            real_t b[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                pc[u] = 0;
+                pv[u] = 0.0;
+#pragma unroll
+                for (int v = 0; v < VEC; v++) b[u][v] = 0;
+            }
+            // consume step u of the batch in (pc, pv, b): row switch -> fold the finished row into LDS, then FMA
+            auto consume = [&](int u) {
+                const int lrow = (int)((unsigned)pc[u] >> PLAN_ROW_SHIFT);
+                if (lrow != cur) {
+                    lds_fold<VEC>(my_rows + cur * S, acc);
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) acc[v] = 0;
+                    cur = lrow;
+                }
+                const real_t a = (real_t)pv[u];
+#pragma unroll
+                for (int v = 0; v < VEC; v++) acc[v] = mx_fma(a, b[u][v], acc[v]);
+                // keep the reload BEHIND the FMAs that read the old line (and the FMAs where they are): letting the two
+                // cross renames b[u] and ends in a register copy at the back edge that waits for every load in flight
+#pragma unroll
+                for (int v = 0; v < VEC; v++) asm volatile("" : "+v"(acc[v]));
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (send > sbeg) {
+                if (!primed) load_chunk(sbeg, rc, rv);
+                // the first chunk has to be there before anything can start; with it complete at loop entry the
+                // compiler's vmcnt bookkeeping is exact on both edges of the loop
+#pragma unroll
+                for (int k = 0; k < PLAN_CHUNK; k++) asm volatile("" : "+v"(rc[k]), "+v"(rv[k]));
+            }
+            // Consumption lags one batch behind the broadcast + B-line load: while batch t is consumed step by step,
+            // the line of the same step of batch t+1 is requested into the registers the FMA just released, so 8
+            // B-line loads per wavefront are in flight all the time.  The first pass consumes the no-op batch set up
+            // above, the last batch is consumed after the loop.
+            bool meta = false;                                      // next octet's bounds / row map requested
+            primed = false;
+            for (int s = sbeg; s < send; s += U * PLAN_CHUNK) {      // sbeg, send are wave-uniform
+                const bool last = s + U * PLAN_CHUNK >= send;
+                if (octn_ok && !meta && s + 2 * U * PLAN_CHUNK >= send) {        // one chunk before the last, if there is one
+                    bounds_c = step_off[(size_t)oct_n * npanels + (lane < npanels ? lane : 0)];
+                    send_c = step_off[(size_t)oct_n * npanels + npanels];
+                    rowof_c = (int)rowmap[(size_t)oct_n * PLAN_OCT_ROWS + lane];
+                    meta = true;
+                }
+                // the read-ahead of the last chunk fetches the first chunk of the next octet instead of running past
+                // this one
+                int ahead = s + U * PLAN_CHUNK;
+                if (last && octn_ok) {
+                    ahead = __builtin_amdgcn_readfirstlane(bounds_c);
+                    primed = true;
+                }
+                load_chunk(ahead, rn, rvn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < PLAN_CHUNK; k++) {
+#define MX_PLAN_STEP(UU)                                                                                              \
+                    consume(UU);                                                                                      \
+                    plan_bcast<UU>(rc[k], rv[k], pc[UU], pv[UU]);                                                     \
+                    vload<real_t, VEC>(b[UU], reinterpret_cast<const real_t *>(Bbase + b_offset(pc[UU])));            \
+                    __builtin_amdgcn_sched_barrier(0);
+                    MX_PLAN_STEP(0) MX_PLAN_STEP(1) MX_PLAN_STEP(2) MX_PLAN_STEP(3)
+                    MX_PLAN_STEP(4) MX_PLAN_STEP(5) MX_PLAN_STEP(6) MX_PLAN_STEP(7)
+#undef MX_PLAN_STEP
+                    if (sync_mode > 0) {
+                        const int sn = s + U * k;                   // steps consumed so far
+                        while (p < npanels - 1 && sn >= next_b) {   // the stream moved into the next panel
+                            p++;
+                            __syncthreads();
+                            next_b = p < npanels - 1 ? __builtin_amdgcn_readlane(bounds, p + 1) : send;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PLAN_CHUNK; k++) { rc[k] = rn[k]; rv[k] = rvn[k]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) consume(u);
+            lds_fold<VEC>(my_rows + cur * S, acc);
+            if (sync_mode > 0)
+                for (; p < npanels - 1; p++) __syncthreads();           // every wave meets npanels-1 times per generation
+        }
+
+        // each wavefront writes the 64 x W tile of C it accumulated (streaming stores: C is not read again); slot ->
+        // row through the octet's row map (identity unless the plan balanced the bundles)
+        if (oct_ok) {
+            const int row_base = oct * PLAN_OCT_ROWS;
+            const int ncols = min(W, n - slab * W);
+            if constexpr (!COLMAJOR) {
+#pragma unroll
+                for (int rr = 0; rr < PLAN_OCT_ROWS / 8; rr++) {
+                    const int r = rr * 8 + g;                        // slot
+                    const int row = row_base + __shfl(rowof, r, 64);
+                    if (row < m && lg * VEC < ncols) {
+                        real_t t[VEC];
+#pragma unroll
+                        for (int v = 0; v < VEC; v++) t[v] = my_oct[(size_t)r * S + lg * VEC + v];
+                        vstore_nt<real_t, VEC>(C + (size_t)row * ldc + slab * W + lg * VEC, t);
+                    }
+                }
+            } else {
+                // lane = slot: the 64 rows of the octet are one 512-byte (f64) segment of an output column
+                const int row = row_base + rowof;
+                if (row < m) {
+                    for (int c = 0; c < ncols; c++)
+                        __builtin_nontemporal_store(my_oct[(size_t)lane * S + c], &C[(size_t)(slab * W + c) * ldc + row]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace mx
+
+struct mx_spmm_plan {
+    int m = 0, K = 0, npanels = 0, panel_cols = 0, noct = 0;
+    long long total_steps = 0;
+    long long nnz = 0;
+    int32_t *step_off = nullptr; size_t step_off_cap = 0;
+    int32_t *pcol = nullptr;     size_t pcol_cap = 0;
+    double *pval = nullptr;      size_t pval_cap = 0;
+    unsigned char *rowmap = nullptr; size_t rowmap_cap = 0;    // [noct][64]: slot -> row offset inside the octet
+    void *scratch = nullptr;     size_t scratch_cap = 0;       // rowpre + steps + scan workspace (build only)
+    double build_ms = 0.0;
+    bool ready = false;                                            // false: sized but not filled (rejected by AUTO)
+};
+
+namespace mx {
+
+
+static thread_local mx_spmm_plan *g_auto_plan = nullptr;
+
+static int grow(void **p, size_t *cap, size_t bytes)
+{
+    if (*cap >= bytes && *p) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    MX_HIP(hipMalloc(p, bytes ? bytes : 16));
+    *cap = bytes;
+    return 0;
+}
+
+// pinned landing zone + event for the one host read-back of a plan build
+struct PlanReadback {
+    long long *host = nullptr;                                      // [0] total steps, [1] nnz (int32 in the low half)
+    hipEvent_t ev = nullptr;
+};
+static PlanReadback *plan_readback()
+{
+    static thread_local PlanReadback rb;
+    if (!rb.host) {
+        if (hipHostMalloc((void **)&rb.host, 2 * sizeof(long long), hipHostMallocDefault) != hipSuccess) { rb.host = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(rb.host); rb.host = nullptr; return nullptr; }
+    }
+    return &rb;
+}
+
+// max_pad_ratio > 0: stop after the sizing pass when the plan would hold more than ratio x nnz slots (rows of very
+// uneven length pad the 8-way interleave: an octet is as long as its longest bundle) — pl->ready stays false.
+static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, const int32_t *indices,
+                      const double *values, int npanels, hipStream_t st, double max_pad_ratio = 0.0)
+{
+    pl->ready = false;
+    MX_REQUIRE(K < (1 << 25), "spmm plan: more than 2^25 columns (32-bit slab offsets)");
+    // measured (cfg2, after the shared panel boundaries): 1.6 MB panels (P = 8) are best for the kernel (1.77 vs 1.86 ms at
+    // P = 5) and, by a hair, for kernel + plan build
+    if (npanels <= 0) npanels = pick_panels(K, (size_t)1664 << 10);
+    if (npanels > PLAN_MAXP) npanels = PLAN_MAXP;
+    pl->m = m; pl->K = K; pl->npanels = npanels;
+    pl->panel_cols = (int)ceil_div(K > 0 ? K : 1, npanels);
+    pl->noct = (int)ceil_div(m, PLAN_OCT_ROWS);
+    pl->total_steps = 0; pl->nnz = 0;
+    if (m == 0) { pl->ready = true; return 0; }                     // nothing to plan (and no zero-sized launches)
+    const size_t nop = (size_t)pl->noct * npanels;
+    const size_t al = 255;
+    const size_t steps_b = (((size_t)pl->noct * 4) + al) & ~al;
+    const size_t octoff_b = ((((size_t)pl->noct + 1) * 4) + al) & ~al;
+    const size_t bpo_b = ((nop * 8 * 4) + al) & ~al;
+    const size_t rb_b = 256;                                        // [total steps][nnz], read back in one copy
+    if (grow(&pl->scratch, &pl->scratch_cap, steps_b + octoff_b + bpo_b + rb_b + scan_workspace_bytes((int64_t)pl->noct))) return 1;
+    if (grow((void **)&pl->step_off, &pl->step_off_cap, (nop + 1) * 4)) return 1;
+    if (grow((void **)&pl->rowmap, &pl->rowmap_cap, (size_t)pl->noct * PLAN_OCT_ROWS)) return 1;
+    int32_t *steps = (int32_t *)pl->scratch;
+    int32_t *oct_off = (int32_t *)((char *)steps + steps_b);
+    int32_t *bpo = (int32_t *)((char *)oct_off + octoff_b);
+    long long *rb_dev = (long long *)((char *)bpo + bpo_b);
+    void *scan_ws = (char *)rb_dev + rb_b;
+    const unsigned blocks = (unsigned)pl->noct;
+    hipLaunchKernelGGL(plan_count_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
+                       steps, bpo, pl->noct, rb_dev + 1, pl->rowmap);
+    MX_LAUNCH_CHECK();
+    if (exclusive_scan_i32(steps, (int64_t)pl->noct, oct_off, (int64_t *)rb_dev, scan_ws, st)) return 1;
+    PlanReadback *rb = plan_readback();
+    MX_REQUIRE(rb, "spmm plan: cannot allocate the pinned read-back buffer");
+    MX_HIP(hipMemcpyAsync(rb->host, rb_dev, 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
+    MX_HIP(hipEventRecord(rb->ev, st));
+    // (Packing B here, behind the read-back, would hide the host round trip — but the fill that follows then
+    // pushes the packed B out of the Infinity Cache and the sweep runs 2.75 ms instead of 2.05 ms.  B is packed right
+    // before the sweep.)
+    MX_HIP(hipEventSynchronize(rb->ev));
+    const long long total = rb->host[0];
+    pl->nnz = (int32_t)rb->host[1];
+    MX_REQUIRE(total >= 0 && total * 8 <= (long long)INT_MAX * 4LL, "spmm plan: too many steps (%lld)", total);
+    MX_REQUIRE(total <= (long long)INT_MAX, "spmm plan: step offsets exceed int32");
+    pl->total_steps = total;
+    if (max_pad_ratio > 0.0 && (double)total * 8.0 > (double)pl->nnz * max_pad_ratio + 65536.0) return 0;
+    const size_t slots = (size_t)total * 8 + PLAN_TAIL_SLOTS;
+    if (grow((void **)&pl->pcol, &pl->pcol_cap, slots * 4)) return 1;
+    if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
+    hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
+                       values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->rowmap);
+    MX_LAUNCH_CHECK();
+    pl->ready = true;
+    return 0;
+}
+
+// slab-major copy of B with one extra all-zero row (index K) per slab: the plan's padding slots point at it
+template <typename real_t>
+static int plan_repack(int K, int n, const real_t *B, size_t ldb, hipStream_t st, real_t **Bp_out)
+{
+    constexpr int VEC = 16 / (int)sizeof(real_t);
+    constexpr int W = SLAB_GROUP * VEC;
+    const int nslabs = (int)ceil_div(n, W);
+    const int Kp = K + 1;
+    real_t *Bp = (real_t *)slab_pack_workspace((size_t)nslabs * (size_t)Kp * W * sizeof(real_t));
+    MX_REQUIRE(Bp, "spmm plan: cannot allocate the packed copy of B");
+    if (launch_repack<real_t>(K, Kp, n, B, ldb, Bp, st)) return 1;
+    *Bp_out = Bp;
+    return 0;
+}
+
+template <typename real_t>
+static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor,
+                    int wg_per_cu, int sync_mode, hipStream_t st)
+{
+    constexpr int VEC = 16 / (int)sizeof(real_t);
+    constexpr int W = SLAB_GROUP * VEC;
+    const int m = pl->m, K = pl->K;
+    const int nslabs = (int)ceil_div(n, W);
+    const int Kp = K + 1;
+    real_t *Bp = nullptr;
+    if (plan_repack<real_t>(K, n, B, ldb, st, &Bp)) return 1;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    if (wg_per_cu != 1 && wg_per_cu != 2 && wg_per_cu != 4) wg_per_cu = PLAN_DEFAULT_WG_PER_CU;
+    const int waves = 16 / wg_per_cu;
+    const int ngens = (int)ceil_div(m, PLAN_OCT_ROWS * waves);
+    long long grid = (long long)cus * wg_per_cu;
+    const long long total = (long long)nslabs * ngens;
+    if (grid > total + 7) grid = total + 7;
+    grid = (grid / 8) * 8;
+    if (grid < 8) grid = 8;
+    unsigned *sync = slab_sync_workspace();
+    if (!sync || pl->npanels <= 1) sync_mode = 0;
+    if (sync_mode >= 2) MX_HIP(hipMemsetAsync(sync, 0, 8 * 64 * sizeof(unsigned), st));   // counters of the XCD timing barrier
+    kt_begin(st);
+#define MX_PLAN_LAUNCH(CM, WV)                                                                                           \
+    hipLaunchKernelGGL((spmm_plan_kernel<real_t, CM, WV>), dim3((unsigned)grid), dim3(WV * 64), 0, st, m, n, pl->npanels, \
+                       pl->step_off, pl->pcol, pl->pval, Bp, (size_t)Kp * W, C, ldc, nslabs, ngens, pl->noct, K,         \
+                       sync, sync_mode, pl->rowmap)
+    if (colmajor) {
+        if (waves == 16) MX_PLAN_LAUNCH(true, 16); else if (waves == 8) MX_PLAN_LAUNCH(true, 8); else MX_PLAN_LAUNCH(true, 4);
+    } else {
+        if (waves == 16) MX_PLAN_LAUNCH(false, 16); else if (waves == 8) MX_PLAN_LAUNCH(false, 8); else MX_PLAN_LAUNCH(false, 4);
+    }
+#undef MX_PLAN_LAUNCH
+    kt_end(st);
+    MX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mx
+
+extern "C" int mxd_spmm_plan_create(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+                                    int npanels, void *stream, mx_spmm_plan **plan_out)
+{
+    MX_REQUIRE(plan_out && m >= 0 && K >= 0, "mxd_spmm_plan_create: bad arguments");
+    mx_spmm_plan *pl = *plan_out ? *plan_out : new (std::nothrow) mx_spmm_plan();      // pass an old plan to reuse its buffers
+    MX_REQUIRE(pl, "out of host memory");
+    if (mx::plan_build(pl, m, K, indptr, indices, values, npanels, mx::as_stream(stream))) {
+        if (!*plan_out) { mxd_spmm_plan_destroy(pl); }
+        return 1;
+    }
+    *plan_out = pl;
+    return 0;
+}
+
+extern "C" int mxd_spmm_plan_destroy(mx_spmm_plan *pl)
+{
+    if (!pl) return 0;
+    if (pl->step_off) (void)hipFree(pl->step_off);
+    if (pl->pcol) (void)hipFree(pl->pcol);
+    if (pl->pval) (void)hipFree(pl->pval);
+    if (pl->scratch) (void)hipFree(pl->scratch);
+    if (pl->rowmap) (void)hipFree(pl->rowmap);
+    delete pl;
+    return 0;
+}
+
+extern "C" int mxd_spmm_plan_info(const mx_spmm_plan *pl, int *npanels, int64_t *padded_entries)
+{
+    MX_REQUIRE(pl, "mxd_spmm_plan_info: null plan");
+    if (npanels) *npanels = pl->npanels;
+    if (padded_entries) *padded_entries = pl->total_steps * 8;
+    return 0;
+}
+
+extern "C" int mxd_spmm_plan_run(const mx_spmm_plan *pl, int n, const void *B, size_t ldb, void *C, size_t ldc,
+                                 int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream)
+{
+    MX_REQUIRE(pl && n >= 0, "mxd_spmm_plan_run: bad arguments");
+    MX_REQUIRE(pl->ready, "mxd_spmm_plan_run: the plan was sized but not built");
+    if (pl->m == 0 || n == 0) return 0;
+    MX_REQUIRE(B && C, "mxd_spmm_plan_run: null pointer");
+    hipStream_t st = mx::as_stream(stream);
+    if (sync_mode < 0) sync_mode = 1;       // panel meetings inside the CU's workgroup; 2 adds one XCD barrier per generation
+    mx::set_last_spmm_kernel("spmm_plan_kernel");
+    if (dense_dtype == MX_F64) {
+        MX_REQUIRE(mx::slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor_out),
+                   "mxd_spmm_plan_run: operands do not meet the 16-byte alignment rules");
+        return mx::plan_run<double>(pl, n, (const double *)B, ldb, (double *)C, ldc, colmajor_out, wg_per_cu, sync_mode, st);
+    }
+    if (dense_dtype == MX_F32) {
+        MX_REQUIRE(mx::slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor_out),
+                   "mxd_spmm_plan_run: operands do not meet the 16-byte alignment rules");
+        return mx::plan_run<float>(pl, n, (const float *)B, ldb, (float *)C, ldc, colmajor_out, wg_per_cu, sync_mode, st);
+    }
+    return mx::set_error("mxd_spmm_plan_run: unsupported dense dtype %d", dense_dtype);
+}
+
+// ---- the plan AUTO keeps (spmm.hip)
+namespace mx {
+
+int plan_auto_build(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values, int npanels,
+                    hipStream_t st, double max_pad_ratio, bool *ready)
+{
+    if (!g_auto_plan) g_auto_plan = new (std::nothrow) mx_spmm_plan();
+    MX_REQUIRE(g_auto_plan, "out of host memory");
+    if (plan_build(g_auto_plan, m, K, indptr, indices, values, npanels, st, max_pad_ratio)) return 1;
+    *ready = g_auto_plan->ready;
+    return 0;
+}
+
+int plan_auto_run(int n, const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, void *stream)
+{
+    return mxd_spmm_plan_run(g_auto_plan, n, B, ldb, C, ldc, dense_dtype, colmajor, 0, -1, stream);
+}
+
+void plan_auto_release()
+{
+    if (g_auto_plan) { mxd_spmm_plan_destroy(g_auto_plan); g_auto_plan = nullptr; }
+}
+
+}  // namespace mx

@@ -94,11 +94,11 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
     }
     if (algo == MX_SPMM_PLANNED) {
         MX_REQUIRE(ok, "mxd_spmm_csr_dense_ex: operands do not meet the planned kernel's 16-byte alignment rules");
-        // Measured with log-normal row lengths (tools/skew_probe.py): up to ~1.8x the CSR the planned sweep still
+        // Measured with log-normal row lengths (tools/skew_probe.py): up to ~1.55x the CSR the planned sweep still
         // beats the row-wave kernel even with the plan built per call; beyond that AUTO stops after the sizing pass
         // (count + scan, ~0.1 ms) and uses the row-wave kernel.
         bool ready = false;          // the plan's buffers are re-used from call to call (grow-only, per thread)
-        if (mx::plan_auto_build(m, K, indptr, indices, values, npanels, st, auto_pick_planned ? 1.75 : 0.0, &ready)) return 1;
+        if (mx::plan_auto_build(m, K, indptr, indices, values, npanels, st, auto_pick_planned ? 1.55 : 0.0, &ready)) return 1;
         if (ready) return mx::plan_auto_run(n, B, ldb, C, ldc, dense_dtype, colmajor_out, stream);
         algo = MX_SPMM_ROWWAVE;
     }

@@ -34,13 +34,20 @@ constexpr int PLAN_DEFAULT_WG_PER_CU = 1;
 constexpr int PLAN_GEN_OCTS = 16;                  // octets one 16-wavefront workgroup sweeps together
 constexpr int PLAN_CHUNK = 4;                      // batches of 8 steps fetched per plan read (octets are whole chunks)
 constexpr int PLAN_TAIL_SLOTS = 512;               // readable padding behind the last octet (2 chunks)
-constexpr int PLAN_ROW_SHIFT = 27;                 // col < 2^27
+constexpr int PLAN_ROW_SHIFT = 25;                 // entry = col (25 bits) | slot of the row in the octet (6 bits) << 25 | shared << 31
 
-// Plan construction: one 512-thread workgroup per octet, one wavefront per bundle.  A bundle's entries are contiguous
-// in the CSR arrays (8 consecutive rows), so the wavefront streams them 64 at a time, fully coalesced; the position
-// of an entry inside its (bundle, panel) stream is a per-panel running count kept in scalar registers plus a
-// ballot prefix — no LDS, no per-row bookkeeping.
-// pass 1: bpo[bundle][p] = where panel p starts in the bundle's stream; steps[oct] = longest bundle of the octet.
+// Plan construction: one 512-thread workgroup per octet, wavefront g streams the entries of rows 8g..8g+7 (contiguous
+// in the CSR arrays) 64 at a time, fully coalesced; the position of an entry inside a stream is a per-panel running
+// count kept one panel per lane plus a ballot prefix.
+//
+// An octet's entries are dealt to its 8 streams (the 8 lane groups of the sweeping wavefront) in one of two layouts:
+//   bundle layout  stream g = rows 8g..8g+7, panel after panel.  The octet is as long as its longest bundle.
+//   dealt layout   per panel, the octet's entries of that panel (row after row) are cut into 8 equal pieces, stream g
+//                  gets piece g: every stream is ceil(T_p / 8) long in panel p whatever the row lengths, a long row is
+//                  shared by several lane groups (entries flagged `shared`: their folds must be atomic).  The octet is
+//                  sum_p ceil(T_p / 8) long — at most 7 padding slots per panel.
+// The count pass picks the dealt layout when it saves at least one chunk of 32 steps: rows of equal length stay in the
+// bundle layout (no padding at all), log-normal row lengths (sigma 1: bundle layout 1.84x the CSR) are dealt.
 constexpr int PLAN_LD = 4;
 // col / panel_cols without the integer divide: float estimate (col < 2^25 is exact in float up to 2^24, so one
 // correction step either way), clamped to the last panel
@@ -52,108 +59,45 @@ __device__ __forceinline__ int panel_of(int col, int panel_cols, float inv_pc, i
     return q < npanels ? q : npanels - 1;
 }
 
-// Which of the octet's 64 rows sits in which (bundle, local row) slot.  Consecutive rows (slot = row offset) when that
-// is balanced; otherwise the rows are sorted by length (bitonic sort inside the wavefront) and dealt to the bundles in
-// serpentine order, which keeps the longest bundle — the octet's length, everything shorter is padding — close to
-// the mean.  Log-normal row lengths (sigma 1) pad the plan 1.84x with consecutive rows.  Every wavefront of the
-// workgroup computes the same answer from the same 65 row pointers: no LDS, no synchronisation.
-// Returns the row offset (0..63) assigned to slot `lane`.
-__device__ __forceinline__ int octet_assign(int m, const int32_t *__restrict__ indptr, int oct, int lane,
-                                            int &ptr_out, int &len_out)
-{
-    const long long row = (long long)oct * PLAN_OCT_ROWS + lane;
-    const int ptr = indptr[row < m ? row : m];                       // one load per lane + the octet's end pointer
-    const int pend = indptr[(long long)(oct + 1) * PLAN_OCT_ROWS < m ? (long long)(oct + 1) * PLAN_OCT_ROWS : m];
-    const int nxt = __shfl_down(ptr, 1, 64);
-    const int len = (lane == 63 ? pend : nxt) - ptr;
-    ptr_out = ptr;                                                   // row `lane` of the octet: [ptr, ptr + len)
-    len_out = len;
-    if (__ballot(len != __builtin_amdgcn_readfirstlane(len)) == 0ULL) return lane;     // all rows equally long
-    int idsum = len;                                                 // sum of my bundle with consecutive rows
-    idsum += __shfl_xor(idsum, 1, 64); idsum += __shfl_xor(idsum, 2, 64); idsum += __shfl_xor(idsum, 4, 64);
-    int idmax = idsum;
-    idmax = max(idmax, __shfl_xor(idmax, 8, 64)); idmax = max(idmax, __shfl_xor(idmax, 16, 64));
-    idmax = max(idmax, __shfl_xor(idmax, 32, 64));
-    // no assignment can beat ceil(total / 8): consecutive rows that already reach it (in whole chunks of 32 steps) stay
-    int total = idsum;
-    total += __shfl_xor(total, 8, 64); total += __shfl_xor(total, 16, 64); total += __shfl_xor(total, 32, 64);
-    if (((idmax + 31) >> 5) <= ((((total + 7) >> 3) + 31) >> 5)) return lane;          // wave-uniform
-    // descending bitonic sort of (length, lower row first)
-    unsigned long long key = ((unsigned long long)(unsigned)len << 6) | (unsigned)(63 - lane);
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const unsigned long long other = __shfl_xor(key, j, 64);
-            const bool keep_max = (((lane & k) == 0) == ((lane & j) == 0));   // descending overall
-            key = keep_max ? (key > other ? key : other) : (key < other ? key : other);
-        }
-    }
-    const int slen = (int)(key >> 6), sidx = 63 - (int)(key & 63);   // lane r: r-th longest row
-    // serpentine deal: rank r = 8k + pos goes to bundle (k even ? pos : 7 - pos), local row k
-    const int my_b = lane >> 3, my_k = lane & 7;                     // lane seen as slot (bundle, local row)
-    const int my_rank = my_k * 8 + ((my_k & 1) ? 7 - my_b : my_b);
-    int balsum = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) balsum += __shfl(slen, k * 8 + ((k & 1) ? 7 - my_b : my_b), 64);
-    int balmax = balsum;
-    balmax = max(balmax, __shfl_xor(balmax, 8, 64)); balmax = max(balmax, __shfl_xor(balmax, 16, 64));
-    balmax = max(balmax, __shfl_xor(balmax, 32, 64));
-    const int dealt = __shfl(sidx, my_rank, 64);
-    // only when it shortens the octet by a whole chunk of 32 steps (uniform matrices keep consecutive rows)
-    const bool permute = ((balmax + 31) >> 5) < ((idmax + 31) >> 5);
-    return permute ? dealt : lane;
-}
-
+// pass 1, per octet:  steps[oct] = length in steps (whole chunks); layout[oct]; pstart[oct][0..P] = relative start of
+// every panel in the streams (bundle layout: mean over the 8 bundles; [P] = unpadded length);
+// bpo[oct][g][p] = bundle layout: start of panel p in stream g / dealt layout: entries of panel p in rows before 8g;
+// bpo[oct][8][p] = entries of panel p in the octet (dealt layout).
 __global__ __launch_bounds__(512)
 void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
                        const int32_t *__restrict__ indices, int32_t *__restrict__ steps,
                        int32_t *__restrict__ bpo, int noct, long long *__restrict__ nnz_out,
-                       unsigned char *__restrict__ rowmap)
+                       unsigned char *__restrict__ layout, int32_t *__restrict__ pstart,
+                       long long *__restrict__ ndealt)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *nnz_out = indptr[m];     // rides back with the step total (one copy)
+    __shared__ int cnt_lds[8][64];                                   // entries per (stream, panel)
+    __shared__ int exc_lds[8][64];                                   // start of the panel in the bundle's stream
     __shared__ int totals[8];
+    __shared__ int dealt_flag;
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int oct = blockIdx.x;
-    int rptr, rlen;                                                  // row pointers of the octet, one row per lane
-    const int rowof = octet_assign(m, indptr, oct, lane, rptr, rlen);
-    const bool identity = __ballot(rowof != lane) == 0ULL;
-    if (g == 0) rowmap[(size_t)oct * PLAN_OCT_ROWS + lane] = (unsigned char)rowof;
-    int mine = 0;                                                    // lane p accumulates the count of panel p (+64, ...)
-    int total_b = 0;
+    const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
+    const int s = indptr[min(row0, m)], e = indptr[min(row0 + PLAN_RB, m)];
+    int mine = 0;                                                    // lane p accumulates the count of panel p
     const float inv_pc = 1.0f / (float)panel_cols;
     // PLAN_LD chunks of 64 entries per pass: the loads of a pass are issued together (the kernel is latency-bound:
     // a bundle is only ~256 entries)
-    auto count_range = [&](int s, int e) {
-        total_b += e - s;
-        for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
-            int col[PLAN_LD];
+    for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
+        int col[PLAN_LD];
 #pragma unroll
-            for (int c = 0; c < PLAN_LD; c++) {
-                const int k = k0 + 64 * c + lane;
-                col[c] = k < e ? indices[k] : -1;
-            }
-#pragma unroll
-            for (int c = 0; c < PLAN_LD; c++) {
-                if (k0 + 64 * c >= e) break;                         // uniform
-                const int pan = col[c] >= 0 ? panel_of(col[c], panel_cols, inv_pc, npanels) : -1;
-                for (int q = 0; q < npanels; q++) {
-                    const int cnt = __popcll(__ballot(pan == q));
-                    if (lane == (q & 63)) mine += cnt;               // npanels <= 64: one lane per panel
-                }
-            }
+        for (int c = 0; c < PLAN_LD; c++) {
+            const int k = k0 + 64 * c + lane;
+            col[c] = k < e ? indices[k] : -1;
         }
-    };
-    if (identity) {                                                  // 8 consecutive rows: one contiguous range
-        const int s = __shfl(rptr, g * PLAN_RB, 64);
-        const int e = __shfl(rptr, g * PLAN_RB + PLAN_RB - 1, 64) + __shfl(rlen, g * PLAN_RB + PLAN_RB - 1, 64);
-        count_range(s, e);
-    } else {                                                         // my 8 rows, in local-row order
 #pragma unroll
-        for (int r = 0; r < PLAN_RB; r++) {
-            const int rr = __shfl(rowof, g * PLAN_RB + r, 64);
-            const int s = __shfl(rptr, rr, 64);
-            count_range(s, s + __shfl(rlen, rr, 64));
+        for (int c = 0; c < PLAN_LD; c++) {
+            if (k0 + 64 * c >= e) break;                             // uniform
+            const int pan = col[c] >= 0 ? panel_of(col[c], panel_cols, inv_pc, npanels) : -1;
+            for (int q = 0; q < npanels; q++) {
+                const int cnt = __popcll(__ballot(pan == q));
+                if (lane == q) mine += cnt;                          // npanels <= 64: one lane per panel
+            }
         }
     }
     // exclusive prefix over the panels (lanes 0..npanels-1)
@@ -163,129 +107,180 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
         const int up = __shfl_up(incl, off, 64);
         if (lane >= off) incl += up;
     }
-    if (lane < npanels) bpo[((size_t)oct * 8 + g) * npanels + lane] = incl - mine;
-    if (lane == 0) totals[g] = total_b;
+    cnt_lds[g][lane] = lane < npanels ? mine : 0;
+    exc_lds[g][lane] = incl - mine;
+    if (lane == 0) totals[g] = e - s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int mx = 0;
+    if (g == 0) {
+        int T = 0, meanstart = 0, bundle_len = 0;
 #pragma unroll
-        for (int gg = 0; gg < 8; gg++) mx = max(mx, totals[gg]);
-        steps[oct] = (mx + 8 * PLAN_CHUNK - 1) & ~(8 * PLAN_CHUNK - 1);    // whole chunks of 4 batches of 8 steps (slot layout below)
+        for (int gg = 0; gg < 8; gg++) {
+            T += cnt_lds[gg][lane];
+            meanstart += exc_lds[gg][lane];
+            bundle_len = max(bundle_len, totals[gg]);
+        }
+        const int L = (T + 7) >> 3;                                  // steps of panel `lane` in the dealt layout
+        int S = L;                                                   // inclusive prefix of L over the panels
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(S, off, 64);
+            if (lane >= off) S += up;
+        }
+        const int dealt_len = __shfl(S, 63, 64);
+        const bool dealt = ((dealt_len + 31) >> 5) < ((bundle_len + 31) >> 5);
+        const int len = dealt ? dealt_len : bundle_len;
+        if (lane < npanels) pstart[(size_t)oct * (npanels + 1) + lane] = dealt ? S - L : meanstart / 8;
+        if (lane == 0) {
+            pstart[(size_t)oct * (npanels + 1) + npanels] = len;
+            steps[oct] = (len + 8 * PLAN_CHUNK - 1) & ~(8 * PLAN_CHUNK - 1);      // whole chunks of 4 batches of 8 steps
+            layout[oct] = dealt ? 1 : 0;
+            dealt_flag = dealt ? 1 : 0;
+            if (dealt) atomicAdd((unsigned long long *)ndealt, 1ULL);
+        }
+        if (lane < npanels) bpo[((size_t)oct * 9 + 8) * npanels + lane] = T;
+    }
+    __syncthreads();
+    if (lane < npanels) {
+        int v = incl - mine;                                         // bundle layout: my stream's panel start
+        if (dealt_flag) {                                            // dealt layout: entries of the panel in earlier rows
+            v = 0;
+            for (int gg = 0; gg < g; gg++) v += cnt_lds[gg][lane];
+        }
+        bpo[((size_t)oct * 9 + g) * npanels + lane] = v;
     }
 }
 
-// pass 2: scatter the entries to their interleaved slots (batch of 8 steps = 64 slots laid out [bundle][step])
+// pass 2: scatter the entries to their interleaved slots (batch of 8 steps = 64 slots laid out [stream][step])
 __global__ __launch_bounds__(512)
 void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
                       const int32_t *__restrict__ indices, const double *__restrict__ values,
                       const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
                       int32_t *__restrict__ pcol, double *__restrict__ pval, int noct, int pad_col,
-                      int32_t *__restrict__ step_off, const unsigned char *__restrict__ rowmap)
+                      int32_t *__restrict__ step_off, const unsigned char *__restrict__ layout,
+                      const int32_t *__restrict__ pstart, long long *__restrict__ ndealt)
 {
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int oct = blockIdx.x;
+    if (oct == 0 && threadIdx.x == 0) *ndealt = 0;                   // read back already: ready for the next build
     // Where the kernel's wavefronts meet (locality only, any value is correct): the 16 octets that one workgroup
-    // sweeps together share the panel boundaries, as fractions of each octet's own length — the mean panel start over
-    // the 128 bundles of the group.  With per-octet boundaries every meeting waited for the wavefront whose panel
-    // happened to be longest (entries per octet and panel vary by ~4 %: the sum of the 5 maxima is ~8 % more than the
-    // common length); with shared boundaries equally long octets arrive together.
+    // sweeps together share the panel boundaries, as fractions of each octet's own length — the mean relative panel
+    // start over the group.  With per-octet boundaries every meeting waited for the wavefront whose panel happened to
+    // be longest (entries per octet and panel vary by ~4 %: the sum of the maxima is ~8 % more than the common length);
+    // with shared boundaries equally long octets arrive together.
     if (g == 0 && lane < npanels) {
         const int o0 = (oct / PLAN_GEN_OCTS) * PLAN_GEN_OCTS, o1 = min(o0 + PLAN_GEN_OCTS, noct);
-        long long sum = 0;
+        long long sum = 0, len = 0;
         for (int o = o0; o < o1; o++) {
-#pragma unroll
-            for (int gg = 0; gg < 8; gg++) sum += bpo[((size_t)o * 8 + gg) * npanels + lane];
+            sum += pstart[(size_t)o * (npanels + 1) + lane];
+            len += pstart[(size_t)o * (npanels + 1) + npanels];
         }
-        const long long len = (long long)oct_off[o1] - oct_off[o0];                     // sum of the octets' lengths
         const int mine = oct_off[oct + 1] - oct_off[oct];
-        const double frac = len > 0 ? (double)sum / (8.0 * (double)len) : 0.0;
+        const double frac = len > 0 ? (double)sum / (double)len : 0.0;
         int b = lane == 0 ? 0 : (int)(frac * (double)mine);
         if (b > mine) b = mine;
         step_off[(size_t)oct * npanels + lane] = oct_off[oct] + b;
         if (oct == noct - 1 && lane == 0) step_off[(size_t)noct * npanels] = oct_off[noct];
     }
-    const int rowof = rowmap[(size_t)oct * PLAN_OCT_ROWS + lane];    // written by the count pass (octet_assign)
-    const bool identity = __ballot(rowof != lane) == 0ULL;
+    const bool dealt = layout[oct] != 0;                             // uniform
+    const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
+    int rp[PLAN_RB + 1];                                             // the bundle's row pointers (wave-uniform)
+#pragma unroll
+    for (int r = 0; r <= PLAN_RB; r++) rp[r] = uniform(indptr[min(row0 + r, m)]);
+    const int s = rp[0], e = rp[PLAN_RB];
     const long long base = oct_off[oct];
-    // lane q keeps the next free step of panel q's stream
-    int nextstep = lane < npanels ? bpo[((size_t)oct * 8 + g) * npanels + lane] : 0;
+    // lane p: next free step of panel p in my stream (bundle layout) / next rank inside panel p (dealt layout)
+    int nextstep = lane < npanels ? bpo[((size_t)oct * 9 + g) * npanels + lane] : 0;
+    // dealt layout, lane p: steps per stream in panel p and where the panel starts
+    int Lp = 1, Sp = 0, Tp = 0;
+    if (dealt && lane < npanels) {
+        Tp = bpo[((size_t)oct * 9 + 8) * npanels + lane];
+        Lp = (Tp + 7) >> 3;
+        Sp = pstart[(size_t)oct * (npanels + 1) + lane];
+    }
     const unsigned long long below = (1ULL << lane) - 1ULL;
     const float inv_pc = 1.0f / (float)panel_cols;
-    int total_b = 0, last_lrow = 0;
-    // entries [s, e) of the CSR arrays; local row of entry k = lrow0 + #(bounds rp[1..7] <= k)  (rp = INT_MAX: none)
-    auto fill_range = [&](int s, int e, int lrow0, const int (&rp)[PLAN_RB + 1]) {
-        total_b += e - s;
-        for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
-            int colv[PLAN_LD];
-            double av[PLAN_LD];
+    const int shared_bit = dealt ? 64 : 0;                           // tag = slot | shared << 6  (bit 31 of the entry)
+    for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
+        int colv[PLAN_LD];
+        double av[PLAN_LD];
 #pragma unroll
-            for (int c = 0; c < PLAN_LD; c++) {                      // all loads of the pass in flight together
-                const int k = k0 + 64 * c + lane;
-                colv[c] = -1; av[c] = 0.0;
-                if (k < e) { colv[c] = indices[k]; av[c] = values[k]; }
-            }
-#pragma unroll
-            for (int c = 0; c < PLAN_LD; c++) {
-                if (k0 + 64 * c >= e) break;                         // uniform
-                const int k = k0 + 64 * c + lane;
-                const int col = colv[c];
-                int pan = -1, lrow = lrow0;
-                if (col >= 0) {
-                    pan = panel_of(col, panel_cols, inv_pc, npanels);
-#pragma unroll
-                    for (int r = 1; r < PLAN_RB; r++) lrow += k >= rp[r];
-                }
-                int t = 0;                                           // my entry's step inside the octet
-                for (int q = 0; q < npanels; q++) {
-                    const unsigned long long same = __ballot(pan == q);
-                    if (same == 0ULL) continue;                      // uniform
-                    const int start = __builtin_amdgcn_readlane(nextstep, q);
-                    if (pan == q) t = start + __popcll(same & below);
-                    if (lane == q) nextstep += __popcll(same);
-                }
-                if (pan >= 0) {
-                    // ONE pair of stores per chunk (inside the panel loop it was one pair per panel, each with 1/P of
-                    // the lanes).  Slot layout inside a batch of 8 steps: [bundle g][step u] — lane 8g+u of the reading
-                    // wavefront holds bundle g's entry for step u, i.e. inside g's own lane group (DPP broadcast).
-                    const long long dst = (base + (t & ~7)) * 8 + g * 8 + (t & 7);
-                    pcol[dst] = col | (lrow << PLAN_ROW_SHIFT);
-                    pval[dst] = av[c];
-                }
-            }
+        for (int c = 0; c < PLAN_LD; c++) {                          // all loads of the pass in flight together
+            const int k = k0 + 64 * c + lane;
+            colv[c] = -1; av[c] = 0.0;
+            if (k < e) { colv[c] = indices[k]; av[c] = values[k]; }
         }
-    };
-    if (identity) {
-        const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
-        int rp[PLAN_RB + 1];                                         // the bundle's row pointers (wave-uniform)
 #pragma unroll
-        for (int r = 0; r <= PLAN_RB; r++) rp[r] = uniform(indptr[min(row0 + r, m)]);
-        fill_range(rp[0], rp[PLAN_RB], 0, rp);
-        if (rp[PLAN_RB] > rp[0]) {
+        for (int c = 0; c < PLAN_LD; c++) {
+            if (k0 + 64 * c >= e) break;                             // uniform
+            const int k = k0 + 64 * c + lane;
+            const int col = colv[c];
+            int pan = -1, slot = g * PLAN_RB;                        // slot: position of the entry's row in the octet
+            if (col >= 0) {
+                pan = panel_of(col, panel_cols, inv_pc, npanels);
 #pragma unroll
-            for (int r = 1; r < PLAN_RB; r++) last_lrow += (rp[PLAN_RB] - 1) >= rp[r];
-        }
-    } else {
-        const int rr = __shfl(rowof, g * PLAN_RB + (lane & 7), 64);
-        const long long row = (long long)oct * PLAN_OCT_ROWS + rr;
-        const int ps = row < m ? indptr[row] : 0, pe = row < m ? indptr[row + 1] : 0;
-        int none[PLAN_RB + 1];
-#pragma unroll
-        for (int r = 0; r <= PLAN_RB; r++) none[r] = INT_MAX;
-#pragma unroll
-        for (int r = 0; r < PLAN_RB; r++) {
-            const int s = uniform(__shfl(ps, r, 64)), e = uniform(__shfl(pe, r, 64));
-            fill_range(s, e, r, none);
-            if (e > s) last_lrow = r;
+                for (int r = 1; r < PLAN_RB; r++) slot += k >= rp[r];
+            }
+            int t = 0;                                               // bundle: my step in the octet / dealt: rank in the panel
+            for (int q = 0; q < npanels; q++) {
+                const unsigned long long same = __ballot(pan == q);
+                if (same == 0ULL) continue;                          // uniform
+                const int start = __builtin_amdgcn_readlane(nextstep, q);
+                if (pan == q) t = start + __popcll(same & below);
+                if (lane == q) nextstep += __popcll(same);
+            }
+            int stream = g;
+            if (dealt) {                                             // rank t of panel `pan` -> (stream, step)
+                const int pl = pan >= 0 ? pan : 0;
+                const int L = max(__shfl(Lp, pl, 64), 1), S = __shfl(Sp, pl, 64);
+                stream = (int)((float)t / (float)L);
+                stream += (stream + 1) * L <= t ? 1 : (stream * L > t ? -1 : 0);
+                t = S + t - stream * L;
+            }
+            if (pan >= 0) {
+                // ONE pair of stores per chunk (inside the panel loop it was one pair per panel, each with 1/P of the
+                // lanes).  Slot layout inside a batch of 8 steps: [stream][step] — lane 8g+u of the reading wavefront
+                // holds stream g's entry for step u, i.e. inside g's own lane group (DPP broadcast).
+                const long long dst = (base + (t & ~7)) * 8 + stream * 8 + (t & 7);
+                pcol[dst] = col | ((slot | shared_bit) << PLAN_ROW_SHIFT);
+                pval[dst] = av[c];
+            }
         }
     }
-    // Padding up to the octet's length: a no-op entry — value 0, column `pad_col` (the all-zero extra row of the
-    // packed B), row = the bundle's last entry's row so that it does not even trigger a row switch.  0 * 0 added to
-    // an accumulator that is never -0.0 leaves it unchanged bit for bit.
+    // Padding: a no-op entry — value 0, column `pad_col` (the all-zero extra row of the packed B), and a row tag that
+    // is at worst one harmless extra fold.  0 * 0 added to an accumulator that is never -0.0 changes no bit.
     const int steps_oct = oct_off[oct + 1] - (int)base;
-    for (long long t = total_b + lane; t < steps_oct; t += 64) {
-        const long long dst = (base + (t & ~7LL)) * 8 + g * 8 + (t & 7);
-        pcol[dst] = pad_col | (last_lrow << PLAN_ROW_SHIFT);
-        pval[dst] = 0.0;
+    if (!dealt) {
+        int last_slot = g * PLAN_RB;                                 // my stream's last row: not even a row switch
+        if (e > s) {
+#pragma unroll
+            for (int r = 1; r < PLAN_RB; r++) last_slot += (e - 1) >= rp[r];
+        }
+        for (long long t = (e - s) + lane; t < steps_oct; t += 64) {
+            const long long dst = (base + (t & ~7LL)) * 8 + g * 8 + (t & 7);
+            pcol[dst] = pad_col | (last_slot << PLAN_ROW_SHIFT);
+            pval[dst] = 0.0;
+        }
+    } else {
+        const int padtag = (g * PLAN_RB) | 64;
+        // holes at the end of every panel (the last pieces are up to 7 entries short): wavefront g takes the panels
+        // p = g, g + 8, ...; lane j < 8 the j-th hole
+        for (int pq = g; pq < npanels; pq += 8) {
+            const int T = __shfl(Tp, pq, 64), L = __shfl(Lp, pq, 64), S = __shfl(Sp, pq, 64);
+            const int q = T + lane;
+            if (lane < 8 && q < 8 * L) {
+                const int stream = q / (L > 0 ? L : 1), t = S + q - stream * L;
+                const long long dst = (base + (t & ~7)) * 8 + stream * 8 + (t & 7);
+                pcol[dst] = pad_col | (padtag << PLAN_ROW_SHIFT);
+                pval[dst] = 0.0;
+            }
+        }
+        // tail of all 8 streams up to the octet's (chunk-rounded) length: wavefront g pads stream g
+        const int used = pstart[(size_t)oct * (npanels + 1) + npanels];
+        for (long long t = used + lane; t < steps_oct; t += 64) {
+            const long long dst = (base + (t & ~7LL)) * 8 + g * 8 + (t & 7);
+            pcol[dst] = pad_col | (padtag << PLAN_ROW_SHIFT);
+            pval[dst] = 0.0;
+        }
     }
     // PLAN_TAIL_SLOTS padding slots behind the last octet: the kernel's read-ahead runs two batches past an octet
     if (oct == noct - 1) {
@@ -315,31 +310,39 @@ __device__ __forceinline__ void plan_bcast(int pcw, double pvw, int &pc, double 
     pv = b.d;
 }
 
-// Fold a finished row's partial sums into its LDS accumulators.  Only this lane ever touches these words and one
-// wavefront's LDS operations execute in order, so both forms are the same sequence of additions.  f64: two
-// fire-and-forget ds_add_f64 (no return value, nothing to wait for; the read-modify-write cost an LDS round trip on
-// ~70 % of the steps).  f32: read-modify-write of one 16-byte word (four ds_add_f32 measured 2.4x slower overall).
+// Fold a finished row's partial sums into its LDS accumulators.  A row is either owned by one lane group of the
+// wavefront or marked `shared` in the plan (a long row dealt to several groups).  One wavefront's LDS operations execute
+// in order, so for an owned row every form below is the same sequence of additions.  f64: two fire-and-forget
+// ds_add_f64 (no return value, nothing to wait for — the read-modify-write cost an LDS round trip on ~70 % of the
+// steps; atomic, so shared rows need nothing extra).  f32: read-modify-write of one 16-byte word for owned rows (four
+// ds_add_f32 measured 2.4x slower overall), atomics for shared rows only.
 template <int VEC>
-__device__ __forceinline__ void lds_fold(double *d, double (&acc)[VEC])
+__device__ __forceinline__ void lds_fold(double *d, double (&acc)[VEC], bool)
 {
 #pragma unroll
     for (int v = 0; v < VEC; v++) __hip_atomic_fetch_add(d + v, acc[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 template <int VEC>
-__device__ __forceinline__ void lds_fold(float *d, float (&acc)[VEC])
+__device__ __forceinline__ void lds_fold(float *d, float (&acc)[VEC], bool shared)
 {
+    if (shared) {
 #pragma unroll
-    for (int v = 0; v < VEC; v++) d[v] += acc[v];
+        for (int v = 0; v < VEC; v++) __hip_atomic_fetch_add(d + v, acc[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) d[v] += acc[v];
+    }
 }
 
 // main kernel
-template <typename real_t, bool COLMAJOR, int PLAN_WAVES>
+// SHARED: the plan has octets in the dealt layout (folds of their rows must be atomic; only matters for f32)
+template <typename real_t, bool COLMAJOR, int PLAN_WAVES, bool SHARED>
 __global__ __launch_bounds__(PLAN_WAVES * 64)
 void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ step_off,
                       const int32_t *__restrict__ pcol, const double *__restrict__ pval,
                       const real_t *__restrict__ Bp, size_t slab_stride,
                       real_t *__restrict__ C, size_t ldc, int nslabs, int ngens, int noct, int pad_col,
-                      unsigned *__restrict__ sync_ctr, int sync_mode, const unsigned char *__restrict__ rowmap)
+                      unsigned *__restrict__ sync_ctr, int sync_mode)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
     constexpr int W = SLAB_GROUP * VEC;
@@ -357,13 +360,13 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
     const int niter = (int)((hi - lo + nwg - 1) / nwg);
     unsigned *const my_ctr = sync_ctr + xcd * 64;
     real_t *const my_oct = accs + (size_t)wave * PLAN_OCT_ROWS * S;                     // this wavefront's 64 rows
-    real_t *const my_rows = my_oct + (size_t)g * PLAN_RB * S + lg * VEC;                // this group's bundle
+    real_t *const my_rows = my_oct + lg * VEC;                                          // + slot * S: my 16 bytes of a row
 
     // Carried from one generation to the next: the stream bounds, the row map and the FIRST chunk of plan slots of the
     // wavefront's next octet are requested during the last chunk of the current one, so that a generation does not
     // start with two exposed memory latencies (bounds, then the first chunk: ~3-4 us of a ~58 us generation).
     bool primed = false;                                            // wave-uniform
-    int bounds_c = 0, send_c = 0, rowof_c = 0;
+    int bounds_c = 0, send_c = 0;
     int rc[PLAN_CHUNK];
     double rv[PLAN_CHUNK];
 #pragma unroll
@@ -395,7 +398,6 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
         // plan entries stay in flight).  Across the 32 CUs of the XCD group there is ONE global timing barrier per
         // generation (32 pollers per counter); in between the CUs run identical code on statistically identical
         // data and drift by a fraction of a panel.
-        int rowof = lane;
         {
             if (sync_mode >= 2) xcd_timing_barrier(my_ctr, (unsigned)(it + 1) * (unsigned)nwg);
             // The octet's stream bounds and its slot -> row map (identity unless the plan balanced the bundles; used by
@@ -406,17 +408,16 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             // waited for with vmcnt(0), i.e. it drained the whole B-line pipeline once per panel.
             int bounds = 0, send = 0;
             if (primed) {                                           // requested during the previous generation
-                bounds = bounds_c; send = send_c; rowof = rowof_c;
+                bounds = bounds_c; send = send_c;
             } else if (oct_ok) {
                 bounds = step_off[(size_t)oct * npanels + (lane < npanels ? lane : 0)];
                 send = step_off[(size_t)oct * npanels + npanels];
-                rowof = (int)rowmap[(size_t)oct * PLAN_OCT_ROWS + lane];
             }
             int sbeg = __builtin_amdgcn_readfirstlane(bounds);      // wave-uniform: keep the loop control scalar
             send = __builtin_amdgcn_readfirstlane(send);
             int next_b = npanels > 1 ? __builtin_amdgcn_readlane(bounds, 1) : send;
             int p = 0;
-            int cur = 0;
+            int cur = g * PLAN_RB;                                  // a slot to fold the initial zeros into (harmless)
             real_t acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; v++) acc[v] = 0;
@@ -455,13 +456,14 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                 for (int v = 0; v < VEC; v++) b[u][v] = 0;
             }
             // consume step u of the batch in (pc, pv, b): row switch -> fold the finished row into LDS, then FMA
+            bool oct_shared = false;                                // set once the first chunk is in
             auto consume = [&](int u) {
-                const int lrow = (int)((unsigned)pc[u] >> PLAN_ROW_SHIFT);
-                if (lrow != cur) {
-                    lds_fold<VEC>(my_rows + cur * S, acc);
+                const int tag = pc[u] >> PLAN_ROW_SHIFT;              // slot of the row (0..63), -64 if the row is shared
+                if (tag != cur) {
+                    lds_fold<VEC>(my_rows + (cur & 63) * S, acc, oct_shared);
 #pragma unroll
                     for (int v = 0; v < VEC; v++) acc[v] = 0;
-                    cur = lrow;
+                    cur = tag;
                 }
                 const real_t a = (real_t)pv[u];
 #pragma unroll
@@ -479,6 +481,9 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
 #pragma unroll
                 for (int k = 0; k < PLAN_CHUNK; k++) asm volatile("" : "+v"(rc[k]), "+v"(rv[k]));
             }
+            // dealt layout: every entry of the octet (padding included) carries the `shared` bit — rows may be folded by
+            // several lane groups, so the f32 fold must be atomic for this octet (wave-uniform choice)
+            if constexpr (SHARED) oct_shared = send > sbeg && __builtin_amdgcn_readfirstlane(rc[0]) < 0;
             // Consumption lags one batch behind the broadcast + B-line load: while batch t is consumed step by step,
             // the line of the same step of batch t+1 is requested into the registers the FMA just released, so 8
             // B-line loads per wavefront are in flight all the time.  The first pass consumes the no-op batch set up
@@ -490,7 +495,6 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                 if (octn_ok && !meta && s + 2 * U * PLAN_CHUNK >= send) {        // one chunk before the last, if there is one
                     bounds_c = step_off[(size_t)oct_n * npanels + (lane < npanels ? lane : 0)];
                     send_c = step_off[(size_t)oct_n * npanels + npanels];
-                    rowof_c = (int)rowmap[(size_t)oct_n * PLAN_OCT_ROWS + lane];
                     meta = true;
                 }
                 // the read-ahead of the last chunk fetches the first chunk of the next octet instead of running past
@@ -526,7 +530,7 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             }
 #pragma unroll
             for (int u = 0; u < U; u++) consume(u);
-            lds_fold<VEC>(my_rows + cur * S, acc);
+            lds_fold<VEC>(my_rows + (cur & 63) * S, acc, oct_shared);
             if (sync_mode > 0)
                 for (; p < npanels - 1; p++) __syncthreads();           // every wave meets npanels-1 times per generation
         }
@@ -540,7 +544,7 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
 #pragma unroll
                 for (int rr = 0; rr < PLAN_OCT_ROWS / 8; rr++) {
                     const int r = rr * 8 + g;                        // slot
-                    const int row = row_base + __shfl(rowof, r, 64);
+                    const int row = row_base + r;
                     if (row < m && lg * VEC < ncols) {
                         real_t t[VEC];
 #pragma unroll
@@ -550,7 +554,7 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                 }
             } else {
                 // lane = slot: the 64 rows of the octet are one 512-byte (f64) segment of an output column
-                const int row = row_base + rowof;
+                const int row = row_base + lane;
                 if (row < m) {
                     for (int c = 0; c < ncols; c++)
                         __builtin_nontemporal_store(my_oct[(size_t)lane * S + c], &C[(size_t)(slab * W + c) * ldc + row]);
@@ -569,7 +573,10 @@ struct mx_spmm_plan {
     int32_t *step_off = nullptr; size_t step_off_cap = 0;
     int32_t *pcol = nullptr;     size_t pcol_cap = 0;
     double *pval = nullptr;      size_t pval_cap = 0;
-    unsigned char *rowmap = nullptr; size_t rowmap_cap = 0;    // [noct][64]: slot -> row offset inside the octet
+    unsigned char *layout = nullptr; size_t layout_cap = 0;    // [noct]: 0 bundle layout, 1 dealt layout
+    int32_t *pstart = nullptr;     size_t pstart_cap = 0;     // [noct][P + 1]: relative panel starts, unpadded length
+    long long *rbdev = nullptr;                                // [total steps][nnz][dealt octets], read back in one copy
+    long long ndealt = 0;                                      // octets in the dealt layout (rows shared by lane groups)
     void *scratch = nullptr;     size_t scratch_cap = 0;       // rowpre + steps + scan workspace (build only)
     double build_ms = 0.0;
     bool ready = false;                                            // false: sized but not filled (rejected by AUTO)
@@ -592,14 +599,14 @@ static int grow(void **p, size_t *cap, size_t bytes)
 
 // pinned landing zone + event for the one host read-back of a plan build
 struct PlanReadback {
-    long long *host = nullptr;                                      // [0] total steps, [1] nnz (int32 in the low half)
+    long long *host = nullptr;                                      // [0] total steps, [1] nnz, [2] dealt octets
     hipEvent_t ev = nullptr;
 };
 static PlanReadback *plan_readback()
 {
     static thread_local PlanReadback rb;
     if (!rb.host) {
-        if (hipHostMalloc((void **)&rb.host, 2 * sizeof(long long), hipHostMallocDefault) != hipSuccess) { rb.host = nullptr; return nullptr; }
+        if (hipHostMalloc((void **)&rb.host, 4 * sizeof(long long), hipHostMallocDefault) != hipSuccess) { rb.host = nullptr; return nullptr; }
         if (hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(rb.host); rb.host = nullptr; return nullptr; }
     }
     return &rb;
@@ -625,24 +632,28 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     const size_t al = 255;
     const size_t steps_b = (((size_t)pl->noct * 4) + al) & ~al;
     const size_t octoff_b = ((((size_t)pl->noct + 1) * 4) + al) & ~al;
-    const size_t bpo_b = ((nop * 8 * 4) + al) & ~al;
-    const size_t rb_b = 256;                                        // [total steps][nnz], read back in one copy
-    if (grow(&pl->scratch, &pl->scratch_cap, steps_b + octoff_b + bpo_b + rb_b + scan_workspace_bytes((int64_t)pl->noct))) return 1;
+    const size_t bpo_b = ((nop * 9 * 4) + al) & ~al;
+    if (grow(&pl->scratch, &pl->scratch_cap, steps_b + octoff_b + bpo_b + scan_workspace_bytes((int64_t)pl->noct))) return 1;
+    if (!pl->rbdev) {                                               // [2] counts dealt octets: zero now, re-zeroed after every read-back
+        MX_HIP(hipMalloc((void **)&pl->rbdev, 256));
+        MX_HIP(hipMemsetAsync(pl->rbdev, 0, 256, st));
+    }
     if (grow((void **)&pl->step_off, &pl->step_off_cap, (nop + 1) * 4)) return 1;
-    if (grow((void **)&pl->rowmap, &pl->rowmap_cap, (size_t)pl->noct * PLAN_OCT_ROWS)) return 1;
+    if (grow((void **)&pl->layout, &pl->layout_cap, (size_t)pl->noct)) return 1;
+    if (grow((void **)&pl->pstart, &pl->pstart_cap, (size_t)pl->noct * (npanels + 1) * 4)) return 1;
     int32_t *steps = (int32_t *)pl->scratch;
     int32_t *oct_off = (int32_t *)((char *)steps + steps_b);
     int32_t *bpo = (int32_t *)((char *)oct_off + octoff_b);
-    long long *rb_dev = (long long *)((char *)bpo + bpo_b);
-    void *scan_ws = (char *)rb_dev + rb_b;
+    long long *rb_dev = pl->rbdev;
+    void *scan_ws = (char *)bpo + bpo_b;
     const unsigned blocks = (unsigned)pl->noct;
     hipLaunchKernelGGL(plan_count_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       steps, bpo, pl->noct, rb_dev + 1, pl->rowmap);
+                       steps, bpo, pl->noct, rb_dev + 1, pl->layout, pl->pstart, rb_dev + 2);
     MX_LAUNCH_CHECK();
     if (exclusive_scan_i32(steps, (int64_t)pl->noct, oct_off, (int64_t *)rb_dev, scan_ws, st)) return 1;
     PlanReadback *rb = plan_readback();
     MX_REQUIRE(rb, "spmm plan: cannot allocate the pinned read-back buffer");
-    MX_HIP(hipMemcpyAsync(rb->host, rb_dev, 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
+    MX_HIP(hipMemcpyAsync(rb->host, rb_dev, 3 * sizeof(long long), hipMemcpyDeviceToHost, st));
     MX_HIP(hipEventRecord(rb->ev, st));
     // (Packing B here, behind the read-back, would hide the host round trip — but the fill that follows then
     // pushes the packed B out of the Infinity Cache and the sweep runs 2.75 ms instead of 2.05 ms.  B is packed right
@@ -650,15 +661,19 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     MX_HIP(hipEventSynchronize(rb->ev));
     const long long total = rb->host[0];
     pl->nnz = (int32_t)rb->host[1];
+    pl->ndealt = rb->host[2];
     MX_REQUIRE(total >= 0 && total * 8 <= (long long)INT_MAX * 4LL, "spmm plan: too many steps (%lld)", total);
     MX_REQUIRE(total <= (long long)INT_MAX, "spmm plan: step offsets exceed int32");
     pl->total_steps = total;
-    if (max_pad_ratio > 0.0 && (double)total * 8.0 > (double)pl->nnz * max_pad_ratio + 65536.0) return 0;
+    if (max_pad_ratio > 0.0 && (double)total * 8.0 > (double)pl->nnz * max_pad_ratio + 65536.0) {
+        MX_HIP(hipMemsetAsync(rb_dev + 2, 0, sizeof(long long), st));                    // the fill would have done it
+        return 0;
+    }
     const size_t slots = (size_t)total * 8 + PLAN_TAIL_SLOTS;
     if (grow((void **)&pl->pcol, &pl->pcol_cap, slots * 4)) return 1;
     if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
     hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->rowmap);
+                       values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->layout, pl->pstart, rb_dev + 2);
     MX_LAUNCH_CHECK();
     pl->ready = true;
     return 0;
@@ -707,16 +722,22 @@ static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, 
     if (!sync || pl->npanels <= 1) sync_mode = 0;
     if (sync_mode >= 2) MX_HIP(hipMemsetAsync(sync, 0, 8 * 64 * sizeof(unsigned), st));   // counters of the XCD timing barrier
     kt_begin(st);
-#define MX_PLAN_LAUNCH(CM, WV)                                                                                           \
-    hipLaunchKernelGGL((spmm_plan_kernel<real_t, CM, WV>), dim3((unsigned)grid), dim3(WV * 64), 0, st, m, n, pl->npanels, \
-                       pl->step_off, pl->pcol, pl->pval, Bp, (size_t)Kp * W, C, ldc, nslabs, ngens, pl->noct, K,         \
-                       sync, sync_mode, pl->rowmap)
+    // f64 folds are atomic anyway: one variant; f32 keeps its cheaper read-modify-write when no row is shared
+    const bool shared = sizeof(real_t) == 4 && pl->ndealt > 0;
+#define MX_PLAN_LAUNCH2(CM, WV, SH)                                                                                          \
+    hipLaunchKernelGGL((spmm_plan_kernel<real_t, CM, WV, SH>), dim3((unsigned)grid), dim3(WV * 64), 0, st, m, n, pl->npanels, \
+                       pl->step_off, pl->pcol, pl->pval, Bp, (size_t)Kp * W, C, ldc, nslabs, ngens, pl->noct, K,             \
+                       sync, sync_mode)
+#define MX_PLAN_LAUNCH(CM, WV)                                                                                               \
+    do { if constexpr (sizeof(real_t) == 4) { if (shared) MX_PLAN_LAUNCH2(CM, WV, true); else MX_PLAN_LAUNCH2(CM, WV, false); } \
+         else MX_PLAN_LAUNCH2(CM, WV, false); } while (0)
     if (colmajor) {
         if (waves == 16) MX_PLAN_LAUNCH(true, 16); else if (waves == 8) MX_PLAN_LAUNCH(true, 8); else MX_PLAN_LAUNCH(true, 4);
     } else {
         if (waves == 16) MX_PLAN_LAUNCH(false, 16); else if (waves == 8) MX_PLAN_LAUNCH(false, 8); else MX_PLAN_LAUNCH(false, 4);
     }
 #undef MX_PLAN_LAUNCH
+#undef MX_PLAN_LAUNCH2
     kt_end(st);
     MX_LAUNCH_CHECK();
     return 0;
@@ -745,7 +766,9 @@ extern "C" int mxd_spmm_plan_destroy(mx_spmm_plan *pl)
     if (pl->pcol) (void)hipFree(pl->pcol);
     if (pl->pval) (void)hipFree(pl->pval);
     if (pl->scratch) (void)hipFree(pl->scratch);
-    if (pl->rowmap) (void)hipFree(pl->rowmap);
+    if (pl->layout) (void)hipFree(pl->layout);
+    if (pl->pstart) (void)hipFree(pl->pstart);
+    if (pl->rbdev) (void)hipFree(pl->rbdev);
     delete pl;
     return 0;
 }

@@ -505,9 +505,9 @@ def test_spmm_planned_edge_shapes(gpu):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("colmajor", [True, False])
 def test_spmm_planned_balanced_bundles(gpu, dtype, colmajor):
-    """Rows of very uneven length: the plan deals each octet's 64 rows to its 8 bundles by length (serpentine over
-    the sorted rows) and the kernel writes C through the octet's slot -> row map.  Shapes cover a last octet that is
-    cut by m, empty rows, one row far longer than the rest of its octet, and rows shorter than one batch."""
+    """Rows of very uneven length: octets switch to the dealt layout (per panel, the octet's entries are cut into 8
+    equal pieces; long rows are shared by several lane groups and folded atomically).  Shapes cover a last octet that
+    is cut by m, empty rows, one row far longer than the rest of its octet, and rows shorter than one batch."""
     from devmem import spmm_planned_device
     rng = np.random.default_rng(99)
     K, n = 500, 32
@@ -525,6 +525,28 @@ def test_spmm_planned_balanced_bundles(gpu, dtype, colmajor):
             got = spmm_planned_device(p, j, x, B, colmajor, npanels=npanels)
             tol = 1e-12 if dtype == np.float64 else 2e-4
             np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * 50)
+
+
+def test_spmm_plan_dealt_layout_keeps_skewed_plans_small(gpu):
+    """Log-normal row lengths: with whole rows per lane group the plan is 1.8x the CSR; dealing every panel's entries
+    in 8 equal pieces keeps it near 1x (at most 7 holes per panel and octet + the rounding to 32 steps)."""
+    import torch
+    from matrixextra_amd import device as D
+    rng = np.random.default_rng(3)
+    m, K = 64 * 400, 20_000
+    lens = np.minimum(np.floor(rng.lognormal(np.log(48) - 0.5, 1.0, size=m)).astype(np.int64), 3000)
+    p = np.zeros(m + 1, dtype=np.int64); p[1:] = np.cumsum(lens)
+    j = rng.integers(0, K, size=int(p[-1]), dtype=np.int32)
+    x = rng.uniform(-1, 1, size=int(p[-1]))
+    A = D.DeviceCSR.from_host(p.astype(np.int32), j, x, K)
+    A.plan(npanels=4)
+    info = A.plan_info()
+    assert info["padded_entries"] <= 1.15 * A.nnz, info
+    B = torch.from_numpy(synth.dense_normal(K, 32)).cuda()
+    got = D.spmm_planned(A, B, npanels=4).cpu().numpy()
+    ref = np.zeros((m, 32))
+    np.add.at(ref, np.repeat(np.arange(m), lens), x[:, None] * B.cpu().numpy()[j])
+    np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-11)
 
 
 # ----------------------------------------------------------------------------- CSR (op) dense vector (§8f rank 4)

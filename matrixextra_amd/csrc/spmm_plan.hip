@@ -32,7 +32,7 @@ constexpr int PLAN_OCT_ROWS = PLAN_RB * 8;         // rows per octet (one wavefr
 constexpr int PLAN_MAXP = 64;
 constexpr int PLAN_DEFAULT_WG_PER_CU = 1;
 constexpr int PLAN_GEN_OCTS = 16;                  // octets one 16-wavefront workgroup sweeps together
-constexpr int PLAN_CHUNK = 4;                      // batches of 8 steps fetched per plan read (octets are whole chunks)
+constexpr int PLAN_CHUNK = 4;                      // batches of 8 steps fetched per plan read
 constexpr int PLAN_TAIL_SLOTS = 512;               // readable padding behind the last octet (2 chunks)
 constexpr int PLAN_ROW_SHIFT = 25;                 // entry = col (25 bits) | slot of the row in the octet (6 bits) << 25 | shared << 31
 
@@ -59,7 +59,7 @@ __device__ __forceinline__ int panel_of(int col, int panel_cols, float inv_pc, i
     return q < npanels ? q : npanels - 1;
 }
 
-// pass 1, per octet:  steps[oct] = length in steps (whole chunks); layout[oct]; pstart[oct][0..P] = relative start of
+// pass 1, per octet:  steps[oct] = length in steps (whole batches of 8); layout[oct]; pstart[oct][0..P] = relative start of
 // every panel in the streams (bundle layout: mean over the 8 bundles; [P] = unpadded length);
 // bpo[oct][g][p] = bundle layout: start of panel p in stream g / dealt layout: entries of panel p in rows before 8g;
 // bpo[oct][8][p] = entries of panel p in the octet (dealt layout).
@@ -127,12 +127,12 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
             if (lane >= off) S += up;
         }
         const int dealt_len = __shfl(S, 63, 64);
-        const bool dealt = ((dealt_len + 31) >> 5) < ((bundle_len + 31) >> 5);
+        const bool dealt = ((dealt_len + 7) >> 3) < ((bundle_len + 7) >> 3);
         const int len = dealt ? dealt_len : bundle_len;
         if (lane < npanels) pstart[(size_t)oct * (npanels + 1) + lane] = dealt ? S - L : meanstart / 8;
         if (lane == 0) {
             pstart[(size_t)oct * (npanels + 1) + npanels] = len;
-            steps[oct] = (len + 8 * PLAN_CHUNK - 1) & ~(8 * PLAN_CHUNK - 1);      // whole chunks of 4 batches of 8 steps
+            steps[oct] = (len + 7) & ~7;                                 // whole batches of 8 steps
             layout[oct] = dealt ? 1 : 0;
             dealt_flag = dealt ? 1 : 0;
             if (dealt) atomicAdd((unsigned long long *)ndealt, 1ULL);
@@ -274,7 +274,7 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
                 pval[dst] = 0.0;
             }
         }
-        // tail of all 8 streams up to the octet's (chunk-rounded) length: wavefront g pads stream g
+        // tail of all 8 streams up to the octet's (batch-rounded) length: wavefront g pads stream g
         const int used = pstart[(size_t)oct * (npanels + 1) + npanels];
         for (long long t = used + lane; t < steps_oct; t += 64) {
             const long long dst = (base + (t & ~7LL)) * 8 + g * 8 + (t & 7);
@@ -508,6 +508,7 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < PLAN_CHUNK; k++) {
+                    if (k > 0 && s + U * k >= send) break;             // octets end on a batch, not on a chunk (uniform)
 #define MX_PLAN_STEP(UU)                                                                                              \
                     consume(UU);                                                                                      \
                     plan_bcast<UU>(rc[k], rv[k], pc[UU], pv[UU]);                                                     \

@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SETUP_CALLS = 12          # untimed products before the warm-up: workspace allocation + clock ramp (see main)
 
 
 def parse():
@@ -168,6 +169,15 @@ def main():
 
     import ctypes
     lib = _lib.load()
+    # one-time setup, not steps: the library's grow-only workspaces (plan arrays, packed copy of B, pinned read-back
+    # buffer, timing events) are allocated on first use, and after the idle seconds of input generation the GPU needs
+    # ~10 products (25 ms) to reach its steady clocks (tools/ramp_probe.py: 2.32 -> 2.09 ms per call).  SETUP_CALLS
+    # untimed calls here, reported in the JSON line, keep a short --warmup/--steps run from measuring that ramp.
+    lib.mxd_spmm_kernel_timing(1)
+    for _ in range(SETUP_CALLS):
+        step()
+    torch.cuda.synchronize()
+    lib.mxd_spmm_kernel_timing(0)
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -222,7 +232,7 @@ def main():
             "metric": "CSR x dense SpMM GFLOP/s (fp64, 1M x 100k, 32 nnz/row, k=128) + achieved HBM BW% vs CPU ref",
             "value": round(world * flops_rank_step * args.steps / elapsed / 1e9, 2),
             "unit": "GFLOP/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_calls": SETUP_CALLS,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",

@@ -23,7 +23,8 @@ for sigma in (0.0, 0.5, 1.0, 1.5):
     res = {}
     for name, fn in (("auto", lambda: D.spmm(A, B, out=C, colmajor=True, algo=0)),
                      ("rowwave", lambda: D.spmm(A, B, out=C, colmajor=True, algo=1)),
-                     ("planned(cached)", lambda: D.spmm_planned(A, B, out=C, colmajor=True))):
+                     ("planned(cached)", lambda: D.spmm_planned(A, B, out=C, colmajor=True)),
+                     ("planned(cached, XCD barrier)", lambda: D.spmm_planned(A, B, out=C, colmajor=True, sync_mode=2))):
         fn(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(5):

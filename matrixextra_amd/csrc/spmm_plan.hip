@@ -59,6 +59,26 @@ __device__ __forceinline__ int panel_of(int col, int panel_cols, float inv_pc, i
     return q < npanels ? q : npanels - 1;
 }
 
+// The lanes of the wavefront that hold an entry of the same panel as this lane: log2(P) ballots (one per bit of the panel
+// id) instead of one ballot per panel.  Lanes without an entry (pan < 0) take lane 0's panel and are masked out of
+// everybody's set by `valid`; their own result is not used.
+__device__ __forceinline__ unsigned long long same_panel_lanes(int pan, int nbits, unsigned long long valid)
+{
+    unsigned long long same = valid;
+    for (int b = 0; b < nbits; b++) {
+        const bool bit = (pan >> b) & 1;
+        const unsigned long long bb = __ballot(bit);
+        same &= bit ? bb : ~bb;
+    }
+    return same;
+}
+// counts[q] += (entries of panel q in this chunk), counts held one panel per lane: every lane pushes its panel's count to
+// lane `pan` (ds_permute: all pushers to one lane carry the same value; lanes nobody pushes to receive 0)
+__device__ __forceinline__ int push_panel_counts(int pan, int cnt)
+{
+    return __builtin_amdgcn_ds_permute(pan << 2, cnt);
+}
+
 // pass 1, per octet:  steps[oct] = length in steps (whole batches of 8); layout[oct]; pstart[oct][0..P] = relative start of
 // every panel in the streams (bundle layout: mean over the 8 bundles; [P] = unpadded length);
 // bpo[oct][g][p] = bundle layout: start of panel p in stream g / dealt layout: entries of panel p in rows before 8g;
@@ -81,6 +101,7 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
     const int s = indptr[min(row0, m)], e = indptr[min(row0 + PLAN_RB, m)];
     int mine = 0;                                                    // lane p accumulates the count of panel p
     const float inv_pc = 1.0f / (float)panel_cols;
+    const int nbits = 32 - __builtin_clz((unsigned)(npanels > 1 ? npanels - 1 : 1));    // bits of a panel id
     // PLAN_LD chunks of 64 entries per pass: the loads of a pass are issued together (the kernel is latency-bound:
     // a bundle is only ~256 entries)
     for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
@@ -93,11 +114,12 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
 #pragma unroll
         for (int c = 0; c < PLAN_LD; c++) {
             if (k0 + 64 * c >= e) break;                             // uniform
-            const int pan = col[c] >= 0 ? panel_of(col[c], panel_cols, inv_pc, npanels) : -1;
-            for (int q = 0; q < npanels; q++) {
-                const int cnt = __popcll(__ballot(pan == q));
-                if (lane == q) mine += cnt;                          // npanels <= 64: one lane per panel
-            }
+            const bool has = col[c] >= 0;
+            const unsigned long long valid = __ballot(has);
+            int pan = has ? panel_of(col[c], panel_cols, inv_pc, npanels) : 0;
+            pan = has ? pan : __builtin_amdgcn_readfirstlane(pan);   // lane 0 always holds an entry of a non-empty chunk
+            const unsigned long long same = same_panel_lanes(pan, nbits, valid);
+            mine += push_panel_counts(pan, __popcll(same));          // npanels <= 64: one lane per panel
         }
     }
     // exclusive prefix over the panels (lanes 0..npanels-1)
@@ -199,6 +221,7 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
     }
     const unsigned long long below = (1ULL << lane) - 1ULL;
     const float inv_pc = 1.0f / (float)panel_cols;
+    const int nbits = 32 - __builtin_clz((unsigned)(npanels > 1 ? npanels - 1 : 1));    // bits of a panel id
     const int shared_bit = dealt ? 64 : 0;                           // tag = slot | shared << 6  (bit 31 of the entry)
     for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
         int colv[PLAN_LD];
@@ -214,29 +237,27 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
             if (k0 + 64 * c >= e) break;                             // uniform
             const int k = k0 + 64 * c + lane;
             const int col = colv[c];
-            int pan = -1, slot = g * PLAN_RB;                        // slot: position of the entry's row in the octet
-            if (col >= 0) {
+            const bool has = col >= 0;
+            const unsigned long long valid = __ballot(has);
+            int pan = 0, slot = g * PLAN_RB;                         // slot: position of the entry's row in the octet
+            if (has) {
                 pan = panel_of(col, panel_cols, inv_pc, npanels);
 #pragma unroll
                 for (int r = 1; r < PLAN_RB; r++) slot += k >= rp[r];
             }
-            int t = 0;                                               // bundle: my step in the octet / dealt: rank in the panel
-            for (int q = 0; q < npanels; q++) {
-                const unsigned long long same = __ballot(pan == q);
-                if (same == 0ULL) continue;                          // uniform
-                const int start = __builtin_amdgcn_readlane(nextstep, q);
-                if (pan == q) t = start + __popcll(same & below);
-                if (lane == q) nextstep += __popcll(same);
-            }
+            pan = has ? pan : __builtin_amdgcn_readfirstlane(pan);   // lane 0 always holds an entry of a non-empty chunk
+            const unsigned long long same = same_panel_lanes(pan, nbits, valid);
+            // bundle: my step in the octet / dealt: rank in the panel  = my panel's running count + my rank in the chunk
+            int t = __shfl(nextstep, pan, 64) + __popcll(same & below);
+            nextstep += push_panel_counts(pan, __popcll(same));
             int stream = g;
             if (dealt) {                                             // rank t of panel `pan` -> (stream, step)
-                const int pl = pan >= 0 ? pan : 0;
-                const int L = max(__shfl(Lp, pl, 64), 1), S = __shfl(Sp, pl, 64);
+                const int L = max(__shfl(Lp, pan, 64), 1), S = __shfl(Sp, pan, 64);
                 stream = (int)((float)t / (float)L);
                 stream += (stream + 1) * L <= t ? 1 : (stream * L > t ? -1 : 0);
                 t = S + t - stream * L;
             }
-            if (pan >= 0) {
+            if (has) {
                 // ONE pair of stores per chunk (inside the panel loop it was one pair per panel, each with 1/P of the
                 // lanes).  Slot layout inside a batch of 8 steps: [stream][step] — lane 8g+u of the reading wavefront
                 // holds stream g's entry for step u, i.e. inside g's own lane group (DPP broadcast).

@@ -1,6 +1,7 @@
 // spmm_plan.hip — the planned panel-sweep SpMM (v3, what MX_SPMM_AUTO runs for large operands): plan construction
 // kernels, the sweep kernel, the plan object and its C-ABI (mxd_spmm_plan_*).
 #include "spmm_common.h"
+#include <algorithm>
 
 namespace mx {
 
@@ -179,11 +180,13 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
                       const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
                       int32_t *__restrict__ pcol, double *__restrict__ pval, int noct, int pad_col,
                       int32_t *__restrict__ step_off, const unsigned char *__restrict__ layout,
-                      const int32_t *__restrict__ pstart, long long *__restrict__ ndealt)
+                      const int32_t *__restrict__ pstart, long long *__restrict__ ndealt, long long cap_slots)
 {
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int oct = blockIdx.x;
     if (oct == 0 && threadIdx.x == 0) *ndealt = 0;                   // read back already: ready for the next build
+    // launched before the host knew the plan's size (plan_build): nothing is written unless it fits
+    if ((long long)oct_off[noct] * 8 + PLAN_TAIL_SLOTS > cap_slots) return;
     // Where the kernel's wavefronts meet (locality only, any value is correct): the 16 octets that one workgroup
     // sweeps together share the panel boundaries, as fractions of each octet's own length — the mean relative panel
     // start over the group.  With per-octet boundaries every meeting waited for the wavefront whose panel happened to
@@ -677,9 +680,18 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     MX_REQUIRE(rb, "spmm plan: cannot allocate the pinned read-back buffer");
     MX_HIP(hipMemcpyAsync(rb->host, rb_dev, 3 * sizeof(long long), hipMemcpyDeviceToHost, st));
     MX_HIP(hipEventRecord(rb->ev, st));
-    // (Packing B here, behind the read-back, would hide the host round trip — but the fill that follows then
-    // pushes the packed B out of the Infinity Cache and the sweep runs 2.75 ms instead of 2.05 ms.  B is packed right
-    // before the sweep.)
+    // The host needs the plan's size to (re)allocate its arrays.  While it waits for the read-back the GPU would idle
+    // (~25 us): when arrays from an earlier build exist, the fill is launched right away against their capacity — it
+    // checks the size itself (on the device) and writes nothing if the plan does not fit; the host then re-allocates
+    // and launches it again.  (Packing B in that gap instead is worse: the fill that follows pushes the packed B out of
+    // the Infinity Cache and the sweep runs 2.75 ms instead of 2.05 ms.  B is packed right before the sweep.)
+    const size_t cap_slots = pl->pcol && pl->pval ? std::min(pl->pcol_cap / 4, pl->pval_cap / 8) : 0;
+    if (cap_slots) {
+        hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
+                           values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->layout, pl->pstart,
+                           rb_dev + 2, (long long)cap_slots);
+        MX_LAUNCH_CHECK();
+    }
     MX_HIP(hipEventSynchronize(rb->ev));
     const long long total = rb->host[0];
     pl->nnz = (int32_t)rb->host[1];
@@ -688,15 +700,18 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     MX_REQUIRE(total <= (long long)INT_MAX, "spmm plan: step offsets exceed int32");
     pl->total_steps = total;
     if (max_pad_ratio > 0.0 && (double)total * 8.0 > (double)pl->nnz * max_pad_ratio + 65536.0) {
-        MX_HIP(hipMemsetAsync(rb_dev + 2, 0, sizeof(long long), st));                    // the fill would have done it
+        MX_HIP(hipMemsetAsync(rb_dev + 2, 0, sizeof(long long), st));                    // (the fill does it when it runs)
         return 0;
     }
     const size_t slots = (size_t)total * 8 + PLAN_TAIL_SLOTS;
-    if (grow((void **)&pl->pcol, &pl->pcol_cap, slots * 4)) return 1;
-    if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
-    hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
-                       values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->layout, pl->pstart, rb_dev + 2);
-    MX_LAUNCH_CHECK();
+    if (slots > cap_slots) {                                        // first build, or the early fill found the arrays too small
+        if (grow((void **)&pl->pcol, &pl->pcol_cap, slots * 4)) return 1;
+        if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
+        hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
+                           values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->layout, pl->pstart,
+                           rb_dev + 2, (long long)slots);
+        MX_LAUNCH_CHECK();
+    }
     pl->ready = true;
     return 0;
 }

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Randomised stress of the structure-producing exports (merges, row gather, column slices, sort, SpMV, CSR op vector)
+against the CPU oracle, bit for bit (run on the GPU box):  python tools/fuzz_structure.py [seconds] [seed]"""
+import sys, time
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import numpy as np
+from conftest import rand_csr
+from matrixextra_amd import exports as G
+from oracle import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+NA = int(O.NA_INTEGER)
+
+
+def same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, (what, a.shape, b.shape, a.dtype, b.dtype)
+    if a.dtype.kind == "f":
+        assert np.array_equal(np.isnan(a), np.isnan(b)), what
+        ok = ~np.isnan(a)
+        assert np.array_equal(a[ok].view(np.int64), b[ok].view(np.int64)), what
+    else:
+        assert np.array_equal(a, b), what
+
+
+def same_list(g, o, what):
+    for k in ("indptr", "indices", "values"):
+        if k in o:
+            same(g[k], o[k], f"{what}/{k}")
+
+
+t_end = time.time() + budget
+cases = 0
+while time.time() < t_end:
+    m = int(rng.choice([1, 3, 64, 65, 200, 1000, 4000]))
+    K = int(rng.choice([1, 2, 9, 70, 400, 3000]))
+    d1, d2 = float(rng.choice([0.0, 0.02, 0.2, 0.7])), float(rng.choice([0.0, 0.05, 0.3, 0.9]))
+    s1, s2 = int(rng.integers(1 << 30)), int(rng.integers(1 << 30))
+    er = tuple(int(r) for r in rng.integers(0, m, size=min(3, m)))
+    p1, j1, x1 = rand_csr(m, K, d1, seed=s1, empty_rows=er)
+    p2, j2, x2 = rand_csr(m, K, d2, seed=s2)
+    if rng.random() < 0.3:                                          # overlapping pattern with cancellation
+        p2, j2, x2 = p1.copy(), j1.copy(), -x1.copy()
+    what = None
+    try:
+        for sub in (False, True):
+            what = f"add sub={sub}"
+            same_list(G.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub), O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub), what)
+        what = "mul"
+        same_list(G.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2), O.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2), what)
+        l1 = rand_csr(m, K, d1, seed=s1, dtype="l")
+        l2 = rand_csr(m, K, d2, seed=s2, dtype="l")
+        for xor in (False, True):
+            what = f"or xor={xor}"
+            same_list(G.logicalor_csr_elemwise(l1[0], l2[0], l1[1], l2[1], l1[2], l2[2], xor),
+                      O.logicalor_csr_elemwise(l1[0], l2[0], l1[1], l2[1], l1[2], l2[2], xor), what)
+        what = "and"
+        same_list(G.logicaland_csr_elemwise(l1[0], l2[0], l1[1], l2[1], l1[2], l2[2]),
+                  O.logicaland_csr_elemwise(l1[0], l2[0], l1[1], l2[1], l1[2], l2[2]), what)
+        rows = rng.integers(0, m, size=int(rng.integers(0, 2 * m + 1)), dtype=np.int32)
+        what = "gather"
+        same_list(G.copy_csr_rows_numeric(p1, j1, x1, rows), O.copy_csr_rows_numeric(p1, j1, x1, rows), what)
+        if rows.size:
+            c0 = int(rng.integers(0, K)); c1 = int(rng.integers(c0, K))
+            cols_seq = np.arange(c0 + 1, c1 + 2, dtype=np.int32)    # 1-based, as R passes them
+            what = "col_seq"
+            same_list(G.copy_csr_rows_col_seq_numeric(p1, j1, x1, rows, cols_seq, True),
+                      O.copy_csr_rows_col_seq_numeric(p1, j1, x1, rows, cols_seq, True), what)
+            cols = rng.integers(0, K, size=int(rng.integers(1, K + 3)), dtype=np.int32)
+            what = "arbitrary"
+            same_list(G.copy_csr_arbitrary_numeric(p1, j1, x1, rows, cols), O.copy_csr_arbitrary_numeric(p1, j1, x1, rows, cols), what)
+        what = "sort"
+        pu, ju, xu = rand_csr(m, K, d2, seed=s2 + 1, sorted_cols=False)
+        jg, xg = ju.copy(), xu.copy()
+        G.sort_sparse_indices_inplace(pu, jg, xg)
+        jo, xo = O.sort_sparse_indices(pu, ju, xu)
+        same(jg, jo, "sort/j"); same(xg, xo, "sort/x")
+        what = "spmv"
+        v = rng.normal(size=K).round(3)
+        np.testing.assert_allclose(G.matmul_csr_dvec_numeric(pu, ju, xu, v), O.matmul_csr_dvec_numeric(pu, ju, xu, v), rtol=1e-11, atol=1e-12)
+        what = "dvec mul"
+        ln = int(rng.choice([1, m, m * K, max(1, m // 2), 7]))
+        dv = rng.uniform(0.5, 2.0, size=ln).round(3)
+        same(G.multiply_csr_by_dvec_no_NAs_numeric(p1, j1, x1, dv, K, 1, 0, 0, 0, 0, 1),
+             O.multiply_csr_by_dvec_no_NAs_numeric(p1, j1, x1, dv, K, 1, 0, 0, 0, 0, 1), what)
+    except Exception as exc:
+        print("FAIL", dict(m=m, K=K, d1=d1, d2=d2, s1=s1, s2=s2, seed=seed, case=cases, what=what), repr(exc)[:600])
+        sys.exit(1)
+    cases += 1
+print(f"fuzz OK: {cases} cases in {budget:.0f} s (seed {seed})")

@@ -243,7 +243,12 @@ def main():
                          "traffic_source": traffic[1] if traffic else None,
                          "kernel": kernel_name, "kernel_avg_ms": round(kern_avg_s * 1e3, 4),
                          "kernel_min_ms": round(float(kern_ms.min()), 4),
-                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         # secondary, non-scoring: what actually bounds the kernel.  Every nonzero gathers one B row:
+                         # nnz * n * s bytes move from L2 into the CUs' L1 whatever the schedule
+                         "l2_to_l1_gather": {"bytes_per_launch": int(nnz) * n * s_dense,
+                                             "achieved_GBps": round(nnz * n * s_dense / kern_avg_s / 1e9, 0),
+                                             "guide_ceiling_GBps": [16000, 22000]}},
             "kernel_gflops": round(flops_rank_step / kern_avg_s / 1e9, 1),
             "parity_max_err_over_max_abs_vs_oracle": parity,
             "device": _lib.device_name(),

@@ -4,7 +4,7 @@
 // int indptr, operators.cpp:414,521).
 //
 // Three launches (reduce tiles -> scan tile sums in one workgroup -> scan tiles
-// with carried offset); vectors of up to 2^18 entries take one single-workgroup launch instead.  Row-count vectors are <= 32 MB here; the scan is a
+// with carried offset); vectors of up to 2^15 entries take one single-workgroup launch instead.  Row-count vectors are <= 32 MB here; the scan is a
 // bandwidth-trivial step between the count and fill passes of merge / gather.
 #include "mx_common.h"
 
@@ -101,7 +101,7 @@ void scan_tiles_kernel(const int32_t *__restrict__ counts, int64_t n, const long
 // Short vectors (the plan's per-octet step counts: 16 k entries for 1 M rows): ONE launch, one 1024-thread
 // workgroup walking the vector in tiles of 16 k elements with a carried offset.
 constexpr int SCAN1_BLOCK = 1024;
-constexpr int64_t SCAN1_MAX = (int64_t)1 << 18;
+constexpr int64_t SCAN1_MAX = (int64_t)1 << 15;         // two tiles: beyond that the three-launch scan is faster (200 k elements: 0.2 ms in one workgroup)
 
 __global__ __launch_bounds__(SCAN1_BLOCK)
 void scan_single_kernel(const int32_t *__restrict__ counts, int64_t n, int32_t *__restrict__ out,

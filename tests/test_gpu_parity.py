@@ -527,6 +527,27 @@ def test_spmm_planned_balanced_bundles(gpu, dtype, colmajor):
             np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * 50)
 
 
+def test_spmm_plan_limits_and_errors(gpu):
+    """The planned kernel addresses a slab with 32-bit byte offsets: K >= 2^25 columns is refused with a message (AUTO
+    never picks it there), a plan that was only sized cannot be run, and errors do not poison later calls."""
+    import ctypes as C
+    from devmem import Dev, spmm_planned_device
+    from matrixextra_amd import _lib
+    lib = _lib.load()
+    p = np.array([0, 2, 3], np.int32); j = np.array([0, (1 << 25) + 3, 7], np.int32); x = np.array([1.0, 2.0, 3.0])
+    dp, dj, dx = Dev(p), Dev(j), Dev(x)
+    plan = C.c_void_p()
+    rc = lib.mxd_spmm_plan_create(C.c_int(2), C.c_int((1 << 25) + 5), dp.ptr, dj.ptr, dx.ptr, C.c_int(0), None, C.byref(plan))
+    assert rc != 0 and b"2^25" in lib.mx_last_error()
+    assert not plan.value
+    rc = lib.mxd_spmm_plan_run(None, C.c_int(4), None, C.c_size_t(4), None, C.c_size_t(4), C.c_int(_lib.MX_F64),
+                               C.c_int(0), C.c_int(0), C.c_int(-1), None)
+    assert rc != 0
+    B = synth.dense_normal(40, 16)
+    pp = np.array([0, 1], np.int32); jj = np.array([39], np.int32); xx = np.array([2.5])
+    np.testing.assert_array_equal(spmm_planned_device(pp, jj, xx, B, False), 2.5 * B[39:40])   # still healthy
+
+
 def test_spmm_plan_dealt_layout_keeps_skewed_plans_small(gpu):
     """Log-normal row lengths: with whole rows per lane group the plan is 1.8x the CSR; dealing every panel's entries
     in 8 equal pieces keeps it near 1x (at most 7 holes per panel and octet + the rounding to 32 steps)."""

@@ -36,7 +36,7 @@ struct Protect {          // PROTECT counter that unwinds on scope exit (normal 
     ~Protect() { if (n) UNPROTECT(n); }
 };
 
-inline SEXP as_type(SEXP x, SEXPTYPE t, Protect &p) { return TYPEOF(x) == t ? x : p(Rf_coerceVector(x, t)); }
+inline SEXP as_type(SEXP x, SEXPTYPE t, Protect &p) { return (SEXPTYPE)TYPEOF(x) == t ? x : p(Rf_coerceVector(x, t)); }
 inline void fail() { Rf_error("%s", mx_last_error()); }
 
 // float32@Data is an INTSXP matrix carrying binary32 bit patterns (R/matmul.R:260,276; matmul.cpp:213)

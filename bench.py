@@ -126,7 +126,10 @@ def main():
     nnz = A.nnz
     A.rows_sorted()                  # once per matrix, outside the timed region (cached on the DeviceCSR)
     colmajor = (args.layout == "colmajor") and world == 1
-    if world > 1:
+    overlap = world > 1 and os.environ.get("MXGPU_BENCH_OVERLAP", "1") != "0"
+    if overlap:
+        C_full = C_loc = None                                                # the pipeline owns two gathered buffers
+    elif world > 1:
         C_full = torch.empty((world * m, n), dtype=tdt, device="cuda")     # gathered row-major blocks
         C_loc = C_full[rank * m:(rank + 1) * m]                              # compute straight into my slot
     else:
@@ -156,10 +159,19 @@ def main():
         timed_local.k = timed_local.__defaults__[0]
         sharded = MD.RowShardedSpMM(A, [(r * m, (r + 1) * m) for r in range(world)], timed_local)
 
+    # N > 1: the all-gather of step k runs under the product of step k + 1 (two gathered buffers alternate;
+    # MXGPU_BENCH_OVERLAP=0 gathers in line instead).  Everything is complete before the timed region closes.
+    pipe = None
+    if overlap:
+        pipe = MD.PipelinedRowShardedSpMM(sharded, n, tdt, "cuda")
+
     def step(k=None):
         if world > 1:
             timed_local.k[0] = k
-            sharded(B, out=C_full)
+            if pipe is not None:
+                pipe.step(B)
+            else:
+                sharded(B, out=C_full)
             return
         run_spmm(A, B, C_loc, colmajor)     # no per-step events here: each one is a packet the queue drains between kernels
 
@@ -183,6 +195,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    if pipe is not None:
+        C_last = pipe.finish()            # waits for the gathers still in flight
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -211,12 +225,16 @@ def main():
         rows_chk = 2048
         ref = np.zeros(rows_chk * n, dtype=ndt)
         O.gemm_csr_drm_as_drm(rows_chk, n, p[: rows_chk + 1], j, x, B_host.reshape(-1), n, ref, n, O.max_threads(), True)
-        got = (C_loc[:, :rows_chk].t() if colmajor else C_loc[:rows_chk]).cpu().numpy()
+        if pipe is not None:
+            got = C_last[rank * m:rank * m + rows_chk].cpu().numpy()
+        else:
+            got = (C_loc[:, :rows_chk].t() if colmajor else C_loc[:rows_chk]).cpu().numpy()
         # normalised max error: |got - ref| / max|ref| over the checked block (element-wise relative error is
         # meaningless for entries that cancel to ~0)
         parity = float(np.max(np.abs(got.astype(np.float64) - ref.reshape(rows_chk, n))) / np.max(np.abs(ref)))
         if world > 1:
-            blk = C_full[(world - 1) * m:(world - 1) * m + 4].cpu().numpy()
+            Cg = C_last if pipe is not None else C_full
+            blk = Cg[(world - 1) * m:(world - 1) * m + 4].cpu().numpy()
             assert np.isfinite(blk).all()
 
     kernel_name = _lib.load().mxd_spmm_last_kernel().decode()      # which kernel AUTO / --algo actually launched
@@ -235,7 +253,9 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"dgRMatrix {m}x{K} nnz/row={args.nnz_row} {args.dtype} %*% dense {K}x{n} "
                                    f"(BASELINE configs[1]); C {'col' if colmajor else 'row'}-major"
-                                   + (f"; row-block per GPU + RCCL all-gather of C ({world}x{m} rows)" if world > 1 else ""),
+                                   + (f"; row-block per GPU + RCCL all-gather of C ({world}x{m} rows)"
+                                      + (", gather of step k under the product of step k+1" if pipe is not None else "")
+                                      if world > 1 else ""),
                        "rows_per_gpu": m, "cols": K, "nnz_per_row": args.nnz_row, "dense_cols": n,
                        "parallelism": f"rowshard{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -87,6 +87,63 @@ class RowShardedSpMM:
         return out
 
 
+class PipelinedRowShardedSpMM:
+    """A stream of products with the same A: the all-gather of product k runs while product k + 1 is computed.
+
+    Two gathered buffers alternate; `step(B)` computes this rank's block straight into its slot of the next buffer and
+    starts the all-gather asynchronously (RCCL on its own stream; on xGMI the exchange is ~10x longer than the product,
+    so hiding the product behind it is all there is to gain).  A buffer is handed out again only after its previous
+    all-gather has completed.  `finish()` waits for everything and returns the most recent full C.
+    Equal row blocks only (the block is computed in place inside the gathered buffer)."""
+
+    def __init__(self, sharded: RowShardedSpMM, n: int, dtype, device):
+        assert sharded.equal, "PipelinedRowShardedSpMM needs equal row blocks"
+        self.s = sharded
+        m_total = sum(sharded.rows)
+        self.bufs = [torch.empty((m_total, n), dtype=dtype, device=device) for _ in range(2)]
+        self.pending = [None, None]
+        self.k = 0
+
+    def _wait(self, i):
+        w = self.pending[i]
+        if w is not None:
+            w.wait()                     # NCCL: the current stream waits, the host does not; gloo: blocks the host
+            if not self.bufs[i].is_cuda:
+                _copy_back(self.bufs[i], self._chunks[i], self.s.rows)
+            self.pending[i] = None
+
+    def step(self, B: torch.Tensor) -> int:
+        i = self.k % 2
+        self._wait(i)
+        out = self.bufs[i]
+        r0, r1 = self.s.row_blocks[self.s.rank]
+        mine = out[r0:r1]
+        self.s.spmm_local(self.s.local_A, B, mine)
+        if self.s.world > 1:
+            if out.is_cuda:
+                self.pending[i] = dist.all_gather_into_tensor(out, mine, group=self.s.group, async_op=True)
+            else:
+                if not hasattr(self, "_chunks"):
+                    self._chunks = [None, None]
+                self._chunks[i] = list(torch.split(out, self.s.rows, dim=0))
+                self.pending[i] = dist.all_gather(self._chunks[i], mine.clone(), group=self.s.group, async_op=True)
+        self.k += 1
+        return i
+
+    def finish(self) -> torch.Tensor:
+        for i in (0, 1):
+            self._wait(i)
+        return self.bufs[(self.k - 1) % 2]
+
+
+def _copy_back(out, chunks, rows):
+    off = 0
+    for c, r in zip(chunks, rows):
+        if c.data_ptr() != out[off:off + r].data_ptr():
+            out[off:off + r] = c
+        off += r
+
+
 def _has_into_tensor(t: torch.Tensor) -> bool:
     return t.is_cuda          # gloo has no all_gather_into_tensor on CPU tensors in every build: use the list form there
 

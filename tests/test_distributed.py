@@ -54,6 +54,16 @@ def _worker(rank, world, port, m, K, n, balanced, q):
         full = np.zeros(m * n)
         O.gemm_csr_drm_as_drm(m, n, p, j, x, B.reshape(-1), n, full, n, 1, False)
         ok = np.array_equal(C, full.reshape(m, n))
+        if balanced:
+            # a stream of products with the all-gather of one running under the next: every product must come out right
+            pipe = MD.PipelinedRowShardedSpMM(op, n, torch.float64, "cpu")
+            for k in range(5):
+                Bk = torch.from_numpy(B * 2.0 ** k)                  # powers of two: the products scale exactly
+                i = pipe.step(Bk)
+                if k >= 1:                                           # the other buffer holds product k - 1 once waited for
+                    pipe._wait(1 - i)
+                    ok = ok and np.array_equal(pipe.bufs[1 - i].numpy(), full.reshape(m, n) * 2.0 ** (k - 1))
+            ok = ok and np.array_equal(pipe.finish().numpy(), full.reshape(m, n) * 2.0 ** 4)
         q.put((rank, bool(ok), blocks))
     finally:
         dist.destroy_process_group()

@@ -100,6 +100,24 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
     const int oct = blockIdx.x;
     const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
     const int s = indptr[min(row0, m)], e = indptr[min(row0 + PLAN_RB, m)];
+    // Bundles that are already balanced (longest = ceil(total / 8), in whole batches — rows of equal length): no deal
+    // can be shorter, so the layout is decided from the row pointers alone and the fill counts the panels itself
+    // (layout 2) — this pass does not touch the 4 bytes per entry of `indices` for such octets.
+    if (lane == 0) totals[g] = e - s;
+    __syncthreads();
+    {
+        int bundle_len = 0, total = 0;
+#pragma unroll
+        for (int gg = 0; gg < 8; gg++) { bundle_len = max(bundle_len, totals[gg]); total += totals[gg]; }
+        if (((bundle_len + 7) >> 3) == ((((total + 7) >> 3) + 7) >> 3)) {                // uniform over the workgroup
+            if (threadIdx.x == 0) {
+                steps[oct] = (bundle_len + 7) & ~7;
+                layout[oct] = 2;
+                pstart[(size_t)oct * (npanels + 1) + npanels] = bundle_len;
+            }
+            return;
+        }
+    }
     int mine = 0;                                                    // lane p accumulates the count of panel p
     const float inv_pc = 1.0f / (float)panel_cols;
     const int nbits = 32 - __builtin_clz((unsigned)(npanels > 1 ? npanels - 1 : 1));    // bits of a panel id
@@ -132,7 +150,6 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
     }
     cnt_lds[g][lane] = lane < npanels ? mine : 0;
     exc_lds[g][lane] = incl - mine;
-    if (lane == 0) totals[g] = e - s;
     __syncthreads();
     if (g == 0) {
         int T = 0, meanstart = 0, bundle_len = 0;
@@ -180,33 +197,15 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
                       const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
                       int32_t *__restrict__ pcol, double *__restrict__ pval, int noct, int pad_col,
                       int32_t *__restrict__ step_off, const unsigned char *__restrict__ layout,
-                      const int32_t *__restrict__ pstart, long long *__restrict__ ndealt, long long cap_slots)
+                      int32_t *__restrict__ pstart, long long *__restrict__ ndealt, long long cap_slots)
 {
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int oct = blockIdx.x;
     if (oct == 0 && threadIdx.x == 0) *ndealt = 0;                   // read back already: ready for the next build
     // launched before the host knew the plan's size (plan_build): nothing is written unless it fits
     if ((long long)oct_off[noct] * 8 + PLAN_TAIL_SLOTS > cap_slots) return;
-    // Where the kernel's wavefronts meet (locality only, any value is correct): the 16 octets that one workgroup
-    // sweeps together share the panel boundaries, as fractions of each octet's own length — the mean relative panel
-    // start over the group.  With per-octet boundaries every meeting waited for the wavefront whose panel happened to
-    // be longest (entries per octet and panel vary by ~4 %: the sum of the maxima is ~8 % more than the common length);
-    // with shared boundaries equally long octets arrive together.
-    if (g == 0 && lane < npanels) {
-        const int o0 = (oct / PLAN_GEN_OCTS) * PLAN_GEN_OCTS, o1 = min(o0 + PLAN_GEN_OCTS, noct);
-        long long sum = 0, len = 0;
-        for (int o = o0; o < o1; o++) {
-            sum += pstart[(size_t)o * (npanels + 1) + lane];
-            len += pstart[(size_t)o * (npanels + 1) + npanels];
-        }
-        const int mine = oct_off[oct + 1] - oct_off[oct];
-        const double frac = len > 0 ? (double)sum / (double)len : 0.0;
-        int b = lane == 0 ? 0 : (int)(frac * (double)mine);
-        if (b > mine) b = mine;
-        step_off[(size_t)oct * npanels + lane] = oct_off[oct] + b;
-        if (oct == noct - 1 && lane == 0) step_off[(size_t)noct * npanels] = oct_off[noct];
-    }
-    const bool dealt = layout[oct] != 0;                             // uniform
+    const int lay = layout[oct];                                     // uniform: 0 bundle, 1 dealt, 2 bundle, not counted yet
+    const bool dealt = lay == 1;
     const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
     int rp[PLAN_RB + 1];                                             // the bundle's row pointers (wave-uniform)
 #pragma unroll
@@ -214,7 +213,7 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
     const int s = rp[0], e = rp[PLAN_RB];
     const long long base = oct_off[oct];
     // lane p: next free step of panel p in my stream (bundle layout) / next rank inside panel p (dealt layout)
-    int nextstep = lane < npanels ? bpo[((size_t)oct * 9 + g) * npanels + lane] : 0;
+    int nextstep = lane < npanels && lay != 2 ? bpo[((size_t)oct * 9 + g) * npanels + lane] : 0;
     // dealt layout, lane p: steps per stream in panel p and where the panel starts
     int Lp = 1, Sp = 0, Tp = 0;
     if (dealt && lane < npanels) {
@@ -226,15 +225,54 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
     const float inv_pc = 1.0f / (float)panel_cols;
     const int nbits = 32 - __builtin_clz((unsigned)(npanels > 1 ? npanels - 1 : 1));    // bits of a panel id
     const int shared_bit = dealt ? 64 : 0;                           // tag = slot | shared << 6  (bit 31 of the entry)
-    for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
-        int colv[PLAN_LD];
-        double av[PLAN_LD];
+    int colv[PLAN_LD];
+    double av[PLAN_LD];
+    auto load_pass = [&](int k0) {                                   // all loads of a pass in flight together
 #pragma unroll
-        for (int c = 0; c < PLAN_LD; c++) {                          // all loads of the pass in flight together
+        for (int c = 0; c < PLAN_LD; c++) {
             const int k = k0 + 64 * c + lane;
             colv[c] = -1; av[c] = 0.0;
             if (k < e) { colv[c] = indices[k]; av[c] = values[k]; }
         }
+    };
+    if (lay == 2) {
+        // not counted by pass 1 (bundles already balanced): count my stream's entries per panel here — from the
+        // registers of the first pass, which the placement below re-uses (bundles of up to 256 entries are read once)
+        __shared__ int exc2[8][64];
+        int mine = 0;
+        load_pass(s);
+        auto count_pass = [&](int k0) {
+#pragma unroll
+            for (int c = 0; c < PLAN_LD; c++) {
+                if (k0 + 64 * c >= e) break;                         // uniform
+                const bool has = colv[c] >= 0;
+                const unsigned long long valid = __ballot(has);
+                int pan = has ? panel_of(colv[c], panel_cols, inv_pc, npanels) : 0;
+                pan = has ? pan : __builtin_amdgcn_readfirstlane(pan);
+                mine += push_panel_counts(pan, __popcll(same_panel_lanes(pan, nbits, valid)));
+            }
+        };
+        count_pass(s);
+        for (int k0 = s + 64 * PLAN_LD; k0 < e; k0 += 64 * PLAN_LD) { load_pass(k0); count_pass(k0); }
+        int incl = lane < npanels ? mine : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        nextstep = incl - mine;                                      // start of panel `lane` in my stream
+        exc2[g][lane] = nextstep;
+        __syncthreads();
+        if (g == 0 && lane < npanels) {                              // mean panel start over the 8 bundles (meeting points)
+            int sum = 0;
+#pragma unroll
+            for (int gg = 0; gg < 8; gg++) sum += exc2[gg][lane];
+            pstart[(size_t)oct * (npanels + 1) + lane] = sum / 8;
+        }
+        if (e - s > 64 * PLAN_LD) load_pass(s);                      // longer bundles: the first pass again
+    }
+    for (int k0 = s; k0 < e; k0 += 64 * PLAN_LD) {
+        if (lay != 2 || k0 > s) load_pass(k0);
 #pragma unroll
         for (int c = 0; c < PLAN_LD; c++) {
             if (k0 + 64 * c >= e) break;                             // uniform
@@ -313,6 +351,34 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
         pcol[dst] = pad_col;
         pval[dst] = 0.0;
     }
+}
+
+// Where the sweep's wavefronts meet (locality only, any value is correct): the 16 octets that one workgroup sweeps
+// together share the panel boundaries, as fractions of each octet's own length — the mean relative panel start over
+// the group.  With per-octet boundaries every meeting waited for the wavefront whose panel happened to be longest
+// (entries per octet and panel vary by ~4 %: the sum of the maxima is ~8 % more than the common length); with shared
+// boundaries equally long octets arrive together.  Runs after the fill (which supplies pstart for layout-2 octets).
+__global__ __launch_bounds__(256)
+void plan_bounds_kernel(int noct, int npanels, const int32_t *__restrict__ oct_off, const int32_t *__restrict__ pstart,
+                        int32_t *__restrict__ step_off, long long cap_slots)
+{
+    if ((long long)oct_off[noct] * 8 + PLAN_TAIL_SLOTS > cap_slots) return;      // the fill wrote nothing either
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nn = (long long)noct * npanels;
+    if (t > nn) return;
+    if (t == nn) { step_off[nn] = oct_off[noct]; return; }
+    const int oct = (int)(t / npanels), q = (int)(t % npanels);
+    const int o0 = (oct / PLAN_GEN_OCTS) * PLAN_GEN_OCTS, o1 = min(o0 + PLAN_GEN_OCTS, noct);
+    long long sum = 0, len = 0;
+    for (int o = o0; o < o1; o++) {
+        sum += pstart[(size_t)o * (npanels + 1) + q];
+        len += pstart[(size_t)o * (npanels + 1) + npanels];
+    }
+    const int mine = oct_off[oct + 1] - oct_off[oct];
+    const double frac = len > 0 ? (double)sum / (double)len : 0.0;
+    int b = q == 0 ? 0 : (int)(frac * (double)mine);
+    if (b > mine) b = mine;
+    step_off[t] = oct_off[oct] + b;
 }
 
 // broadcast lane U of every 8-lane group: row_newbcast takes lane n of each 16-lane DPP row; bank_mask restricts the
@@ -690,6 +756,8 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
         hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
                            values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->layout, pl->pstart,
                            rb_dev + 2, (long long)cap_slots);
+        hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)ceil_div((long long)nop + 1, 256)), dim3(256), 0, st, pl->noct,
+                           npanels, oct_off, pl->pstart, pl->step_off, (long long)cap_slots);
         MX_LAUNCH_CHECK();
     }
     MX_HIP(hipEventSynchronize(rb->ev));
@@ -710,6 +778,8 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
         hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
                            values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->layout, pl->pstart,
                            rb_dev + 2, (long long)slots);
+        hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)ceil_div((long long)nop + 1, 256)), dim3(256), 0, st, pl->noct,
+                           npanels, oct_off, pl->pstart, pl->step_off, (long long)slots);
         MX_LAUNCH_CHECK();
     }
     pl->ready = true;

@@ -144,6 +144,24 @@ const char *mxd_spmm_last_kernel(void);
 int mxd_spmv_csr_dvec(int m, int64_t nnz /* lanes-per-row hint, -1 = unknown */,
                       const int32_t *indptr, const int32_t *indices, const double *values,
                       const void *v, int v_dtype, void *y, void *stream);
+/* Same product with K = length of v (= ncol A), the exact nnz, and a kernel choice:
+ *   MX_SPMV_GROUP : G lanes per row, v[j] gathered from L2 (any operands; what mxd_spmv_csr_dvec runs)
+ *   MX_SPMV_FLAT  : 256-thread workgroups over equal slices of ~3.8 k entries (16-B loads, all in flight), v[j] gathered
+ *                   from L2, rows summed one thread per row in storage order from separately rounded products — bit
+ *                   for bit the reference's loop without FMA contraction for rows of up to 256 entries (needs the exact
+ *                   nnz >= 4 and 16-B aligned indices / values)
+ *   MX_SPMV_TILE  : one 1024-thread workgroup per ~24 k entries, v swept through LDS in 16 k-column panels instead of
+ *                   gathered; same summation as FLAT (additionally needs 16-B aligned v and K <= 24 * 16384).  Wins when
+ *                   v fits one panel or the rows are very uneven; see DESIGN.md §4.3
+ *   MX_SPMV_AUTO  : FLAT when it applies and nnz >= 2^20, else GROUP */
+typedef enum { MX_SPMV_AUTO = 0, MX_SPMV_GROUP = 1, MX_SPMV_TILE = 2, MX_SPMV_FLAT = 3 } mx_spmv_algo;
+int mxd_spmv_csr_dvec_ex(int m, int K, int64_t nnz,
+                         const int32_t *indptr, const int32_t *indices, const double *values,
+                         const void *v, int v_dtype, void *y, int algo, void *stream);
+
+/* diagnostic (tools/spmv_stamps.py): a device buffer of 8 x ceil(nnz / 23552) uint64 makes MX_SPMV_TILE run its stamped
+ * build, which records the shader clock at its phase boundaries per workgroup; NULL switches back */
+int mxd_debug_spmv_tile_stamps(void *stamps_dev);
 
 /* CSR (+) CSR, pass 1: per-row output lengths (union for ADD/SUB/OR/XOR,
  * intersection for MUL/AND) then exclusive scan into out_indptr[m+1].

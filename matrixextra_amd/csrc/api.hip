@@ -22,8 +22,8 @@ int set_error(const char *fmt, ...)
     return 1;
 }
 
-int spmv_launch(int m, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
-                const void *v, int v_dtype, void *y, hipStream_t st);
+int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
+                const void *v, int v_dtype, void *y, int algo, hipStream_t st);
 // xfer.hip: synchronous host <-> device copies, pipelined through pinned slots + a host copy pool when large
 int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes);
@@ -143,7 +143,8 @@ static int spmv_host(int m, const int32_t *indptr, const int32_t *indices, const
     DevBuf v, o;
     if (v.upload(y, sizeof(vec_t) * (size_t)len_y)) return 1;
     if (o.alloc(sizeof(out_t) * (size_t)m)) return 1;
-    if (spmv_launch(m, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), v.p, v_dtype, o.p, nullptr))
+    if (spmv_launch(m, len_y, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), v.p, v_dtype, o.p,
+                    MX_SPMV_AUTO, nullptr))
         return 1;
     if (mx::xfer_d2h(out, o.p, sizeof(out_t) * (size_t)m)) return 1;
     return 0;

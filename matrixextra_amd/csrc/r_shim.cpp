@@ -57,7 +57,7 @@ SEXP named_list3(SEXP indptr, SEXP indices, SEXP values, Protect &p)
     return out;
 }
 
-SEXP finish_list(mx_result *res, const mx_result_info &info, SEXP alias_p, SEXP alias_j, Protect &p)
+SEXP finish_list(mx_result *&res, const mx_result_info &info, SEXP alias_p, SEXP alias_j, Protect &p)
 {
     const SEXPTYPE vt = info.values_dtype == MX_F64 ? REALSXP : (info.values_dtype == MX_LGL ? LGLSXP : REALSXP);
     const R_xlen_t nv = info.values_dtype == MX_NONE ? 0 : (R_xlen_t)info.values_len;
@@ -68,7 +68,11 @@ SEXP finish_list(mx_result *res, const mx_result_info &info, SEXP alias_p, SEXP 
         indptr = p(Rf_allocVector(INTSXP, (R_xlen_t)info.indptr_len));
         indices = p(Rf_allocVector(INTSXP, (R_xlen_t)info.nnz));
     }
-    if (mx_result_finish(res, info.alias_structure ? nullptr : INTEGER(indptr),
+    // mx_result_finish releases the handle whether or not the copy succeeds: forget it first, so that the cleanup
+    // handler (which runs when fail() long-jumps) does not release it a second time
+    mx_result *handle = res;
+    res = nullptr;
+    if (mx_result_finish(handle, info.alias_structure ? nullptr : INTEGER(indptr),
                          info.alias_structure ? nullptr : INTEGER(indices), nv ? vptr : nullptr))
         fail();
     return named_list3(indptr, indices, values, p);
@@ -80,8 +84,7 @@ void finish_body(void *d)
 {
     FinishArgs *a = static_cast<FinishArgs *>(d);
     Protect p;
-    a->out = finish_list(a->res, a->info, a->alias_p, a->alias_j, p);
-    a->res = nullptr;                      // consumed by mx_result_finish
+    a->out = finish_list(a->res, a->info, a->alias_p, a->alias_j, p);     // nulls a->res once the handle is consumed
     R_PreserveObject(a->out);              // survives p's UNPROTECT; released by the caller
 }
 void finish_cleanup(void *d)

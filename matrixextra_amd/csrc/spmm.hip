@@ -17,18 +17,30 @@ struct KernelTimer {
     bool made = false, on = false;
     int count = 0;
 };
-static thread_local KernelTimer g_kt;
+// per thread and per device: events belong to the device that was current when they were created
+static thread_local KernelTimer g_kts[16];
+static inline KernelTimer &kt_cur()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) d = 0;
+    return g_kts[d];
+}
 void kt_begin(hipStream_t st)
 {
-    if (!g_kt.on || g_kt.count >= KernelTimer::N) return;
-    if (!g_kt.made) { for (int i = 0; i < KernelTimer::N; i++) { (void)hipEventCreate(&g_kt.a[i]); (void)hipEventCreate(&g_kt.b[i]); } g_kt.made = true; }
-    (void)hipEventRecord(g_kt.a[g_kt.count], st);
+    KernelTimer &kt = kt_cur();
+    if (!kt.on || kt.count >= KernelTimer::N) return;
+    if (!kt.made) {
+        for (int i = 0; i < KernelTimer::N; i++) { (void)hipEventCreate(&kt.a[i]); (void)hipEventCreate(&kt.b[i]); }
+        kt.made = true;
+    }
+    (void)hipEventRecord(kt.a[kt.count], st);
 }
 void kt_end(hipStream_t st)
 {
-    if (!g_kt.on || g_kt.count >= KernelTimer::N) return;
-    (void)hipEventRecord(g_kt.b[g_kt.count], st);
-    g_kt.count++;
+    KernelTimer &kt = kt_cur();
+    if (!kt.on || kt.count >= KernelTimer::N) return;
+    (void)hipEventRecord(kt.b[kt.count], st);
+    kt.count++;
 }
 
 static thread_local const char *g_last_spmm_kernel = "none";
@@ -46,21 +58,23 @@ extern "C" int mxd_release_workspaces(void)
 
 extern "C" int mxd_spmm_kernel_timing(int enable)
 {
-    mx::g_kt.on = enable != 0;
-    mx::g_kt.count = 0;
+    mx::KernelTimer &kt = mx::kt_cur();
+    kt.on = enable != 0;
+    kt.count = 0;
     return 0;
 }
 // elapsed ms of the dominant kernel of each SpMM launch since mxd_spmm_kernel_timing(1) (synchronises on the events)
 extern "C" int mxd_spmm_kernel_times(float *out_ms, int max_out, int *count)
 {
     MX_REQUIRE(count, "mxd_spmm_kernel_times: null count pointer");
-    const int n = mx::g_kt.count < max_out ? mx::g_kt.count : max_out;
+    mx::KernelTimer &kt = mx::kt_cur();
+    const int n = kt.count < max_out ? kt.count : max_out;
     for (int i = 0; i < n; i++) {
-        MX_HIP(hipEventSynchronize(mx::g_kt.b[i]));
-        MX_HIP(hipEventElapsedTime(&out_ms[i], mx::g_kt.a[i], mx::g_kt.b[i]));
+        MX_HIP(hipEventSynchronize(kt.b[i]));
+        MX_HIP(hipEventElapsedTime(&out_ms[i], kt.a[i], kt.b[i]));
     }
     *count = n;
-    mx::g_kt.count = 0;
+    kt.count = 0;
     return 0;
 }
 

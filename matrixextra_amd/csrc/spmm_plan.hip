@@ -190,6 +190,11 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
     }
 }
 
+__device__ __forceinline__ bool plan_fits(long long total_steps, long long cap_slots)
+{
+    return total_steps >= 0 && total_steps <= (long long)INT_MAX && total_steps * 8 + PLAN_TAIL_SLOTS <= cap_slots;
+}
+
 // pass 2: scatter the entries to their interleaved slots (batch of 8 steps = 64 slots laid out [stream][step])
 __global__ __launch_bounds__(512)
 void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restrict__ indptr,
@@ -197,13 +202,15 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
                       const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
                       int32_t *__restrict__ pcol, double *__restrict__ pval, int noct, int pad_col,
                       int32_t *__restrict__ step_off, const unsigned char *__restrict__ layout,
-                      int32_t *__restrict__ pstart, long long *__restrict__ ndealt, long long cap_slots)
+                      int32_t *__restrict__ pstart, long long *__restrict__ ndealt, long long cap_slots,
+                      const long long *__restrict__ total_steps)
 {
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int oct = blockIdx.x;
     if (oct == 0 && threadIdx.x == 0) *ndealt = 0;                   // read back already: ready for the next build
-    // launched before the host knew the plan's size (plan_build): nothing is written unless it fits
-    if ((long long)oct_off[noct] * 8 + PLAN_TAIL_SLOTS > cap_slots) return;
+    // launched before the host knew the plan's size (plan_build): nothing is written unless it fits.  The test reads
+    // the scan's int64 total, not the int32 oct_off[noct] (which wraps for a corrupt indptr and could pass).
+    if (!plan_fits(*total_steps, cap_slots)) return;
     const int lay = layout[oct];                                     // uniform: 0 bundle, 1 dealt, 2 bundle, not counted yet
     const bool dealt = lay == 1;
     const int row0 = oct * PLAN_OCT_ROWS + g * PLAN_RB;
@@ -360,9 +367,10 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
 // boundaries equally long octets arrive together.  Runs after the fill (which supplies pstart for layout-2 octets).
 __global__ __launch_bounds__(256)
 void plan_bounds_kernel(int noct, int npanels, const int32_t *__restrict__ oct_off, const int32_t *__restrict__ pstart,
-                        int32_t *__restrict__ step_off, long long cap_slots)
+                        int32_t *__restrict__ step_off, long long cap_slots,
+                        const long long *__restrict__ total_steps)
 {
-    if ((long long)oct_off[noct] * 8 + PLAN_TAIL_SLOTS > cap_slots) return;      // the fill wrote nothing either
+    if (!plan_fits(*total_steps, cap_slots)) return;                             // the fill wrote nothing either
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nn = (long long)noct * npanels;
     if (t > nn) return;
@@ -676,7 +684,17 @@ struct mx_spmm_plan {
 namespace mx {
 
 
-static thread_local mx_spmm_plan *g_auto_plan = nullptr;
+// AUTO's plan and the read-back landing zone are per thread AND per device (a thread may move between GPUs with
+// mx_set_device / torch.cuda.set_device): indexed by hipGetDevice(), like the packed-B workspace.  One stream per
+// (thread, device) at a time: two AUTO calls of one thread on different streams would share these buffers unordered.
+constexpr int PLAN_MAX_DEVICES = 16;
+static thread_local mx_spmm_plan *g_auto_plan[PLAN_MAX_DEVICES] = {};
+static inline int cur_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= PLAN_MAX_DEVICES) d = 0;
+    return d;
+}
 
 static int grow(void **p, size_t *cap, size_t bytes)
 {
@@ -695,7 +713,8 @@ struct PlanReadback {
 };
 static PlanReadback *plan_readback()
 {
-    static thread_local PlanReadback rb;
+    static thread_local PlanReadback rbs[PLAN_MAX_DEVICES];
+    PlanReadback &rb = rbs[cur_device()];
     if (!rb.host) {
         if (hipHostMalloc((void **)&rb.host, 4 * sizeof(long long), hipHostMallocDefault) != hipSuccess) { rb.host = nullptr; return nullptr; }
         if (hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(rb.host); rb.host = nullptr; return nullptr; }
@@ -755,9 +774,9 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     if (cap_slots) {
         hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
                            values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->layout, pl->pstart,
-                           rb_dev + 2, (long long)cap_slots);
+                           rb_dev + 2, (long long)cap_slots, rb_dev);
         hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)ceil_div((long long)nop + 1, 256)), dim3(256), 0, st, pl->noct,
-                           npanels, oct_off, pl->pstart, pl->step_off, (long long)cap_slots);
+                           npanels, oct_off, pl->pstart, pl->step_off, (long long)cap_slots, rb_dev);
         MX_LAUNCH_CHECK();
     }
     MX_HIP(hipEventSynchronize(rb->ev));
@@ -777,9 +796,9 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
         if (grow((void **)&pl->pval, &pl->pval_cap, slots * 8)) return 1;
         hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
                            values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->layout, pl->pstart,
-                           rb_dev + 2, (long long)slots);
+                           rb_dev + 2, (long long)slots, rb_dev);
         hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)ceil_div((long long)nop + 1, 256)), dim3(256), 0, st, pl->noct,
-                           npanels, oct_off, pl->pstart, pl->step_off, (long long)slots);
+                           npanels, oct_off, pl->pstart, pl->step_off, (long long)slots, rb_dev);
         MX_LAUNCH_CHECK();
     }
     pl->ready = true;
@@ -917,21 +936,23 @@ namespace mx {
 int plan_auto_build(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values, int npanels,
                     hipStream_t st, double max_pad_ratio, bool *ready)
 {
-    if (!g_auto_plan) g_auto_plan = new (std::nothrow) mx_spmm_plan();
-    MX_REQUIRE(g_auto_plan, "out of host memory");
-    if (plan_build(g_auto_plan, m, K, indptr, indices, values, npanels, st, max_pad_ratio)) return 1;
-    *ready = g_auto_plan->ready;
+    mx_spmm_plan *&pl = g_auto_plan[cur_device()];
+    if (!pl) pl = new (std::nothrow) mx_spmm_plan();
+    MX_REQUIRE(pl, "out of host memory");
+    if (plan_build(pl, m, K, indptr, indices, values, npanels, st, max_pad_ratio)) return 1;
+    *ready = pl->ready;
     return 0;
 }
 
 int plan_auto_run(int n, const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, void *stream)
 {
-    return mxd_spmm_plan_run(g_auto_plan, n, B, ldb, C, ldc, dense_dtype, colmajor, 0, -1, stream);
+    return mxd_spmm_plan_run(g_auto_plan[cur_device()], n, B, ldb, C, ldc, dense_dtype, colmajor, 0, -1, stream);
 }
 
 void plan_auto_release()
 {
-    if (g_auto_plan) { mxd_spmm_plan_destroy(g_auto_plan); g_auto_plan = nullptr; }
+    for (int d = 0; d < PLAN_MAX_DEVICES; d++)
+        if (g_auto_plan[d]) { mxd_spmm_plan_destroy(g_auto_plan[d]); g_auto_plan[d] = nullptr; }
 }
 
 }  // namespace mx

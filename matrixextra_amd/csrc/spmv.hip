@@ -12,6 +12,7 @@
 // the headline config), then a butterfly __shfl_xor reduction inside the group.
 // HBM-bound: algorithmic bytes = 4(m+1) + 12 nnz + s*K + s*m.
 #include "mx_common.h"
+#include <cstdlib>
 
 namespace mx {
 
@@ -138,10 +139,37 @@ static int launch_spmv(int G, int m, const int32_t *indptr, const int32_t *indic
     return 0;
 }
 
-// nnz is only used to pick the group width; pass <0 when unknown (=> 32 lanes per row)
-int spmv_launch(int m, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
-                const void *v, int v_dtype, void *y, hipStream_t st)
+// spmv_tile.hip: the LDS-panel kernel (v staged through LDS, rows summed in storage order)
+bool spmv_tile_ok(int m, int64_t nnz, int K, const int32_t *indices, const double *values, const void *v, bool forced);
+int spmv_tile_launch(int m, int64_t nnz, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+                     const void *v, int v_dtype, void *y, hipStream_t st);
+
+// spmv_flat.hip: the flat-stream kernel (slices of entries, v gathered, rows summed in storage order)
+bool spmv_flat_ok(int m, int64_t nnz, const int32_t *indices, const double *values);
+int spmv_flat_launch(int m, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
+                     const void *v, int v_dtype, void *y, hipStream_t st);
+
+// algo: MX_SPMV_AUTO picks the flat kernel when it applies (exact nnz known and >= 2^20, aligned arrays), else the
+// lane-group kernel; the LDS-panel tile kernel runs on request only.  nnz < 0 = unknown (=> lane-group kernel, 32
+// lanes per row).  MXGPU_SPMV_ALGO=1|2|3 overrides AUTO (A/B runs).
+int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
+                const void *v, int v_dtype, void *y, int algo, hipStream_t st)
 {
+    if (algo == MX_SPMV_AUTO) {
+        static const int forced = [] { const char *e = getenv("MXGPU_SPMV_ALGO"); return e ? atoi(e) : 0; }();
+        algo = forced;
+    }
+    const bool tile_ok = K > 0 && nnz >= 0 && spmv_tile_ok(m, nnz, K, indices, values, v, algo == MX_SPMV_TILE);
+    if (algo == MX_SPMV_TILE && !tile_ok)
+        return set_error("spmv: the tile kernel needs K, nnz >= 4, 16-byte aligned arrays and K <= %d columns", 24 * 16384);
+    if (algo == MX_SPMV_TILE) return spmv_tile_launch(m, nnz, K, indptr, indices, values, v, v_dtype, y, st);
+    const bool flat_ok = nnz >= 0 && spmv_flat_ok(m, nnz, indices, values);
+    if (algo == MX_SPMV_FLAT && !flat_ok)
+        return set_error("spmv: the flat kernel needs the exact nnz (>= 4) and 16-byte aligned index / value arrays");
+    // AUTO: the flat kernel once there are enough entries to fill the chip (measured on MI355X: 1M x 100k, 32 / row:
+    // flat vs lane-group in DESIGN.md §4.3); small products stay on the lane-group kernel
+    if (algo == MX_SPMV_FLAT || (algo == MX_SPMV_AUTO && flat_ok && nnz >= ((int64_t)1 << 20)))
+        return spmv_flat_launch(m, nnz, indptr, indices, values, v, v_dtype, y, st);
     const int G = nnz < 0 ? 32 : pick_group((double)nnz / (double)(m > 0 ? m : 1));
     switch (v_dtype) {
         case MX_F64: return launch_spmv<MX_F64>(G, m, indptr, indices, values, v, y, st);
@@ -160,5 +188,15 @@ extern "C" int mxd_spmv_csr_dvec(int m, int64_t nnz, const int32_t *indptr, cons
     MX_REQUIRE(m >= 0, "mxd_spmv_csr_dvec: negative m");
     if (m == 0) return 0;
     MX_REQUIRE(indptr && y, "mxd_spmv_csr_dvec: null pointer");
-    return mx::spmv_launch(m, nnz, indptr, indices, values, v, v_dtype, y, mx::as_stream(stream));
+    return mx::spmv_launch(m, 0, nnz, indptr, indices, values, v, v_dtype, y, MX_SPMV_GROUP, mx::as_stream(stream));
+}
+
+extern "C" int mxd_spmv_csr_dvec_ex(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices,
+                                    const double *values, const void *v, int v_dtype, void *y, int algo, void *stream)
+{
+    MX_REQUIRE(m >= 0, "mxd_spmv_csr_dvec_ex: negative m");
+    MX_REQUIRE(algo >= MX_SPMV_AUTO && algo <= MX_SPMV_FLAT, "mxd_spmv_csr_dvec_ex: unknown algo %d", algo);
+    if (m == 0) return 0;
+    MX_REQUIRE(indptr && y, "mxd_spmv_csr_dvec_ex: null pointer");
+    return mx::spmv_launch(m, K, nnz, indptr, indices, values, v, v_dtype, y, algo, mx::as_stream(stream));
 }

@@ -142,16 +142,18 @@ def spmm_planned(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None,
     return out.t() if colmajor else out
 
 
-def spmv(A: DeviceCSR, v: torch.Tensor, v_dtype=None, out=None):
-    """y = A @ v (matmul_csr_dvec).  v float64 / float32 / int32 (v_dtype MX_I32 or MX_LGL for int32)."""
+def spmv(A: DeviceCSR, v: torch.Tensor, v_dtype=None, out=None, algo: int = 0):
+    """y = A @ v (matmul_csr_dvec).  v float64 / float32 / int32 (v_dtype MX_I32 or MX_LGL for int32).
+    algo: 0 auto, 1 lane-group kernel, 2 LDS-panel tile kernel (include/mxgpu.h mx_spmv_algo)."""
     lib = _lib.load()
     if v_dtype is None:
         v_dtype = {torch.float64: MX_F64, torch.float32: MX_F32}[v.dtype]
     odt = torch.float32 if v_dtype == MX_F32 else torch.float64
     if out is None:
         out = torch.empty(A.m, dtype=odt, device=v.device)
-    check(lib.mxd_spmv_csr_dvec(C.c_int(A.m), C.c_int64(A.nnz), _dp(A.indptr), _dp(A.indices), _dp(A.values),
-                                _dp(v), C.c_int(v_dtype), _dp(out), _stream()))
+    assert int(v.numel()) == A.K and v.is_contiguous()
+    check(lib.mxd_spmv_csr_dvec_ex(C.c_int(A.m), C.c_int(A.K), C.c_int64(A.nnz), _dp(A.indptr), _dp(A.indices),
+                                   _dp(A.values), _dp(v), C.c_int(v_dtype), _dp(out), C.c_int(algo), _stream()))
     return out
 
 

@@ -87,6 +87,42 @@ def csr_overlapping(indptr, indices, K, nnz_row, share=0.5, seed=SEED_A2):
     return indptr2.astype(np.int32), indices2.astype(np.int32), values2
 
 
+# ---- the same generators on the device (torch RNG, seeded): bench.py's cfg4 operands are 2 x 1e8 entries, which
+# numpy draws and sorts in ~45 s on one host core and torch on the GPU in well under a second.  Inputs only.
+def device_csr_fixed(m, K, nnz_row, seed=SEED_A, device="cuda"):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    c = torch.randint(0, K - nnz_row + 1, (m, nnz_row), dtype=torch.int32, device=device, generator=g)
+    c = torch.sort(c, dim=1).values
+    c += torch.arange(nnz_row, dtype=torch.int32, device=device)
+    indptr = (torch.arange(m + 1, dtype=torch.int64, device=device) * nnz_row).to(torch.int32)
+    values = torch.rand(m * nnz_row, dtype=torch.float64, device=device, generator=g) * 2.0 - 1.0
+    return indptr, c.reshape(-1).contiguous(), values
+
+
+def device_csr_overlapping(indices, m, K, nnz_row, share=0.5, seed=SEED_A2, device="cuda"):
+    """Device twin of csr_overlapping: ~share of A's columns per row plus fresh draws, sorted, duplicates dropped."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    keep = int(round(nnz_row * share))
+    a_cols = indices.reshape(m, nnz_row)
+    pick = torch.rand((m, nnz_row), dtype=torch.float32, device=device, generator=g).argsort(dim=1)[:, :keep]
+    shared = torch.gather(a_cols, 1, pick)
+    fresh = torch.randint(0, K - nnz_row + 1, (m, nnz_row), dtype=torch.int32, device=device, generator=g)
+    fresh = torch.sort(fresh, dim=1).values + torch.arange(nnz_row, dtype=torch.int32, device=device)
+    cols = torch.sort(torch.cat([shared, fresh[:, : nnz_row - keep]], dim=1), dim=1).values
+    dup = torch.zeros_like(cols, dtype=torch.bool)
+    dup[:, 1:] = cols[:, 1:] == cols[:, :-1]
+    lens = (~dup).sum(dim=1)
+    indptr = torch.zeros(m + 1, dtype=torch.int64, device=device)
+    torch.cumsum(lens, 0, out=indptr[1:])
+    ind2 = cols[~dup].contiguous()
+    values = torch.rand(ind2.numel(), dtype=torch.float64, device=device, generator=g) * 2.0 - 1.0
+    return indptr.to(torch.int32), ind2, values
+
+
 def spmm_algorithmic_bytes(m, K, n, nnz, s_dense):
     """4(m+1) + 4 nnz + 8 nnz + s*K*n + s*m*n."""
     return 4 * (m + 1) + 12 * nnz + s_dense * K * n + s_dense * m * n

@@ -27,10 +27,36 @@ NA_LOGICAL = NA_INTEGER
 NA_REAL = np.frombuffer(np.uint64(0x7FF00000000007A2).tobytes(), dtype=np.float64)[0]
 
 
+def _cpu_stamp() -> str:
+    """md5 of this machine's CPU model + ISA flags (what `make` records next to a -march=native build)."""
+    import hashlib
+    model = flags = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if not model and line.startswith("model name"):
+                    model = line
+                elif not flags and line.startswith("flags"):
+                    flags = line
+                if model and flags:
+                    break
+    except OSError:
+        pass
+    return hashlib.md5((model + flags).encode()).hexdigest()
+
+
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
+    """The library is built -march=native: rebuild when it is missing, older than the source, or was made on another
+    CPU model (the prebuilt file travels from the build container to the GPU box)."""
+    stamp = os.path.join(_HERE, "_build", "cpu_stamp")
+    try:
+        with open(stamp) as f:
+            same_cpu = f.read().strip() == _cpu_stamp()
+    except OSError:
+        same_cpu = False
+    if force or not same_cpu or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
             os.path.join(_HERE, "mx_oracle.c")):
-        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-B", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
     return _SO
 
 

@@ -70,3 +70,17 @@ def spmm_planned_device(p, j, x, B_rowmajor, colmajor, npanels=0, wg_per_cu=0, s
         lib.mxd_spmm_plan_destroy(plan)
     out = dC.download(B_rowmajor.dtype, (n, m) if colmajor else (m, n))
     return out.T if colmajor else out
+
+
+def spmv_device(p, j, x, v, v_dtype, algo=0):
+    """y = A @ v through mxd_spmv_csr_dvec_ex (algo 0 auto, 1 lane-group kernel, 2 LDS-panel tile kernel)."""
+    lib = _lib.load()
+    m, K = p.size - 1, v.size
+    dp, dj, dx, dv = Dev(p.astype(np.int32)), Dev(j.astype(np.int32)), Dev(x.astype(np.float64)), Dev(v)
+    odt = np.float32 if v_dtype == _lib.MX_F32 else np.float64
+    dy = Dev(nbytes=m * np.dtype(odt).itemsize)
+    check(lib.mx_dev_memset(dy.ptr, 0xFF, C.c_size_t(dy.nbytes), None))      # poison: every row must be written
+    check(lib.mxd_spmv_csr_dvec_ex(C.c_int(m), C.c_int(K), C.c_int64(int(p[-1])), dp.ptr, dj.ptr, dx.ptr, dv.ptr,
+                                   C.c_int(v_dtype), dy.ptr, C.c_int(algo), None))
+    check(lib.mx_stream_sync(None))
+    return dy.download(odt, (m,))

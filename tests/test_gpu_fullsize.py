@@ -9,6 +9,9 @@
   cfg3  SpMV + gather of 200k random rows (with replacement):
         y == (A B)[:, 0] of a one-column SpMM; sum(y) checksum;  gathered row sums == row sums[rows];
         indptr of the result == cumsum of the picked row lengths (bit-exact)
+  cfg5  one GPU's row block of configs[4]: 1M x 200k, 64/row (CSR values f64) x dense 200k x 256 FLOAT32, both layouts,
+        AUTO and the explicitly planned kernel: column checksum (f64 sum of the f32 result), sampled rows against
+        mxo_gemm_csr_drm_as_drm_f32 at 1e-5, linearity  (alpha narrowed per nonzero: matmul.cpp:53-57,361-375)
   cfg4  CSR + CSR, CSR - CSR, CSR * CSR on 2M x 2M, 50/row (nnz 1e8 each, ~50 % shared pattern):
         rows sorted & unique; nnz(A+B) + nnz(A*B) == nnz(A) + nnz(B) (inclusion-exclusion);
         sum(values(A+B)) == sum(A) + sum(B); (A-B) has the same structure as (A+B); A + A == 2 A exactly
@@ -96,6 +99,41 @@ def test_cfg3_spmv_and_gather(cfg2):
         np.testing.assert_array_equal(gx[gp[t]:gp[t + 1]], x[p[r]:p[r + 1]])
     rowsum = np.add.reduceat(x, p[:-1])
     np.testing.assert_allclose(np.add.reduceat(gx, gp[:-1]), rowsum[rows], rtol=0, atol=0)
+
+
+def test_cfg5_shard_spmm_f32(gpu):
+    from matrixextra_amd import device as D
+    m, K, n, k = 1_000_000, 200_000, 256, 64
+    p, j, x = synth.csr_fixed(m, K, k)
+    A = D.DeviceCSR.from_host(p, j, x, K)
+    B1 = synth.dense_normal(K, n, seed=2, dtype=np.float32)
+    B2 = synth.dense_normal(K, n, seed=22, dtype=np.float32)
+    tB1, tB2 = torch.from_numpy(B1).cuda(), torch.from_numpy(B2).cuda()
+    w = np.bincount(j, weights=x, minlength=K)                    # A^T 1 in f64
+    expect = w @ B1.astype(np.float64)
+    scale = np.abs(x).sum() * np.abs(B1).max()
+    blocks = {}
+    for r0 in (0, 499_744, m - 256):                              # oracle rows (f32 arithmetic, FMA like the GPU)
+        pp = (p[r0:r0 + 257] - p[r0]).astype(np.int32)
+        ref = np.zeros(256 * n, dtype=np.float32)
+        O.gemm_csr_drm_as_drm(256, n, pp, j[p[r0]:p[r0 + 256]].copy(), x[p[r0]:p[r0 + 256]].copy(), B1.reshape(-1), n,
+                              ref, n, 4, True)
+        blocks[r0] = ref.reshape(256, n)
+    for colmajor in (True, False):
+        for planned in (False, True):
+            C1 = D.spmm_planned(A, tB1, colmajor=colmajor) if planned else D.spmm(A, tB1, colmajor=colmajor)
+            assert C1.dtype == torch.float32 and C1.shape == (m, n)
+            if not planned:
+                assert _lib.load().mxd_spmm_last_kernel().decode() == "spmm_plan_kernel"   # what AUTO picks at this size
+            got = C1.double().sum(dim=0).cpu().numpy()
+            assert np.max(np.abs(got - expect)) <= 1e-8 * scale
+            for r0, ref in blocks.items():
+                np.testing.assert_allclose(C1[r0:r0 + 256].cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    C1, C2 = D.spmm(A, tB1), D.spmm(A, tB2)
+    C12 = D.spmm(A, tB1 + 2.0 * tB2)
+    err = (C12.double() - (C1.double() + 2.0 * C2.double())).abs().max().item()
+    assert err <= 2e-5 * (C1.abs().max().item() + 2 * C2.abs().max().item())
+    print("cfg5 shard plan:", A.plan_info())
 
 
 def test_cfg4_merge_properties(gpu):

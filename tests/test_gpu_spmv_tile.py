@@ -1,0 +1,133 @@
+"""The flat-stream SpMV kernel (csrc/spmv_flat.hip, MX_SPMV_FLAT, what AUTO runs for large matrices) and the LDS-panel
+kernel (csrc/spmv_tile.hip, MX_SPMV_TILE) against the oracle (matmul_csr_dvec<>,
+src/matmul.cpp:381-419).  Rows of up to 256 entries are summed in storage order from separately rounded products, i.e.
+exactly the reference's loop without FMA contraction: compared BITWISE with the oracle (built -ffp-contract=off); longer
+rows are summed by a wavefront (reassociated): 1e-12."""
+import numpy as np
+import pytest
+
+from matrixextra_amd import _lib, synth
+from oracle import oracle as O
+from tests.conftest import rand_csr
+from tests.devmem import spmv_device
+
+pytestmark = pytest.mark.gpu
+NA = np.int32(-2147483648)
+TILE, GROUP, FLAT = 2, 1, 3
+
+
+def ragged_csr(lens, K, seed, sort=True, dup=False):
+    rng = np.random.default_rng(seed)
+    lens = np.asarray(lens, dtype=np.int64)
+    p = np.zeros(lens.size + 1, dtype=np.int64)
+    np.cumsum(lens, out=p[1:])
+    j = rng.integers(0, K, size=int(p[-1]), dtype=np.int32)         # duplicates inside a row are allowed (they add up)
+    if sort:
+        for r in range(lens.size):
+            j[p[r]:p[r + 1]].sort()
+    if not dup and K >= lens.max(initial=0):
+        for r in range(lens.size):
+            if lens[r]:
+                j[p[r]:p[r + 1]] = np.sort(rng.choice(K, size=lens[r], replace=False)) if sort else \
+                    rng.choice(K, size=lens[r], replace=False)
+    x = np.round(rng.normal(size=int(p[-1])), 3)
+    return p.astype(np.int32), j, x
+
+
+def compare(got, ref, lens, rtol):
+    """Rows of at most 256 entries: bitwise; longer rows (summed by a wavefront): rtol."""
+    short = lens <= 256
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    np.testing.assert_array_equal(got[short & ok], ref[short & ok])
+    if (~short & ok).any():
+        np.testing.assert_allclose(got[~short & ok], ref[~short & ok], rtol=rtol, atol=rtol * np.abs(ref[ok]).max())
+
+
+def check_all_kinds(p, j, x, K, seed):
+    for algo in (FLAT, TILE):
+        _check_all_kinds(p, j, x, K, seed, algo)
+
+
+def _check_all_kinds(p, j, x, K, seed, TILE):
+    rng = np.random.default_rng(seed)
+    lens = np.diff(p)
+    v = rng.normal(size=K)
+    compare(spmv_device(p, j, x, v, _lib.MX_F64, TILE), O.matmul_csr_dvec_numeric(p, j, x, v), lens, 1e-12)
+    vf = v.astype(np.float32)
+    got = spmv_device(p, j, x, vf, _lib.MX_F32, TILE)
+    assert got.dtype == np.float32
+    compare(got, O.matmul_csr_dvec_float32(p, j, x, vf), lens, 1e-5)
+    vi = rng.integers(-9, 9, size=K).astype(np.int32)
+    vl = rng.integers(0, 2, size=K).astype(np.int32)
+    for k in rng.integers(0, K, size=max(1, K // 50)):
+        vi[k] = NA
+        vl[k] = NA
+    for kind, of, vv in ((_lib.MX_I32, O.matmul_csr_dvec_integer, vi), (_lib.MX_LGL, O.matmul_csr_dvec_logical, vl)):
+        got, ref = spmv_device(p, j, x, vv, kind, TILE), of(p, j, x, vv)
+        compare(got, ref, lens, 1e-12)
+        na_rows = np.isnan(ref)
+        if na_rows.any():                                             # R's NA_real_ (low word 1954) where an NA entry is touched
+            assert (got[na_rows].view(np.uint64) & 0xFFFFFFFF == 1954).all()
+        # and the same answer as the lane-group kernel
+        np.testing.assert_allclose(spmv_device(p, j, x, vv, kind, GROUP)[~na_rows], ref[~na_rows], rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("m,K,dens", [(60, 25, 0.3), (1, 10, 0.9), (500, 700, 0.02), (300, 40, 1.0), (64, 2000, 0.2),
+                                      (3000, 16384, 0.002), (2000, 16385, 0.004), (900, 40_000, 0.003)])
+def test_tile_small_shapes_all_kinds(gpu, m, K, dens):
+    p, j, x = rand_csr(m, K, dens, seed=m + K, sorted_cols=False, empty_rows=(0,) if m > 2 else ())
+    if p[-1] < 4:
+        pytest.skip("fewer than 4 entries")
+    check_all_kinds(p, j, x, K, seed=K)
+
+
+def test_tile_many_tiles_uniform_and_odd_lengths(gpu):
+    # several tiles (cuts every 23552 entries), rows of 32 (the headline shape), of 31 and of 7 entries; 100k columns = 7 panels
+    for per_row, m in ((32, 9000), (31, 7000), (7, 40_000)):
+        p, j, x = synth.csr_fixed(m, 100_000, per_row, seed=per_row)
+        check_all_kinds(p, j, x, 100_000, seed=per_row)
+
+
+def test_tile_ragged_rows_empty_rows_unsorted_duplicates(gpu):
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 90, size=6000)
+    lens[rng.random(6000) < 0.3] = 0                                   # many empty rows, some at both ends
+    lens[:40] = 0
+    lens[-25:] = 0
+    p, j, x = ragged_csr(lens, 50_000, seed=6, sort=False, dup=True)
+    check_all_kinds(p, j, x, 50_000, seed=7)
+    # a stretch of more empty rows than a workgroup has threads, in the middle of a tile
+    lens = np.concatenate([np.full(300, 20), np.zeros(5000, dtype=np.int64), np.full(3000, 25)])
+    p, j, x = ragged_csr(lens, 20_000, seed=8)
+    check_all_kinds(p, j, x, 20_000, seed=9)
+
+
+def test_tile_long_rows_cross_passes(gpu):
+    # rows longer than a pass (32768 entries), than a tile cut, than the wavefront-sum threshold; short rows in between
+    lens = np.array([5, 70_000, 3, 0, 300, 257, 256, 40_000, 12, 33_000, 1, 0, 0, 2000] + [30] * 500)
+    p, j, x = ragged_csr(lens, 120_000, seed=10, dup=True)
+    check_all_kinds(p, j, x, 120_000, seed=11)
+
+
+def test_tile_special_values(gpu):
+    p, j, x = synth.csr_fixed(3000, 30_000, 24, seed=3)
+    x = x.copy()
+    x[5] = np.inf; x[700] = -np.inf; x[9000] = np.nan; x[100] = 0.0; x[101] = -0.0
+    v = np.random.default_rng(4).normal(size=30_000)
+    v[j[100]] = np.inf                                                 # 0 * Inf = NaN, as in the reference
+    v[j[20_000]] = np.nan
+    ref = O.matmul_csr_dvec_numeric(p, j, x, v)
+    for algo in (FLAT, TILE):
+        got = spmv_device(p, j, x, v, _lib.MX_F64, algo)
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+        np.testing.assert_array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])
+
+
+def test_tile_refuses_what_it_cannot_run(gpu):
+    p, j, x = synth.csr_fixed(100, 500_000, 8, seed=1)                 # 500k columns: more than 24 panels
+    v = np.zeros(500_000)
+    with pytest.raises(_lib.MxError):
+        spmv_device(p, j, x, v, _lib.MX_F64, TILE)
+    got = spmv_device(p, j, x, v + 1.0, _lib.MX_F64, 0)               # AUTO falls back to the lane-group kernel
+    np.testing.assert_allclose(got, np.add.reduceat(x, p[:-1]), rtol=1e-12)

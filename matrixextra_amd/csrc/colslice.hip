@@ -219,8 +219,7 @@ static int finish_count(int r, int32_t *lens, int32_t *new_indptr, void *scan_ws
     const int rc = mx::exclusive_scan_i32(lens, r, new_indptr, total_dev, scan_ws, st);
     if (rc) return rc;
     if (nnz_out_host) {
-        MX_HIP(hipMemcpyAsync(nnz_out_host, total_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        MX_HIP(hipStreamSynchronize(st));
+        if (mx::read_back_small(nnz_out_host, total_dev, sizeof(int64_t), st)) return 1;
         MX_REQUIRE(*nnz_out_host <= (int64_t)INT_MAX, "result has %lld entries: exceeds R's int32 index range",
                    (long long)*nnz_out_host);
     }

@@ -330,8 +330,7 @@ extern "C" int mxd_csr_merge_count(int op, int m, const int32_t *indptr1, const 
     const int rc = mx::exclusive_scan_i32(counts, m, out_indptr, total_dev, scan_ws, st);
     if (rc) return rc;
     if (nnz_out_host) {
-        MX_HIP(hipMemcpyAsync(nnz_out_host, total_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        MX_HIP(hipStreamSynchronize(st));
+        if (mx::read_back_small(nnz_out_host, total_dev, sizeof(int64_t), st)) return 1;
         MX_REQUIRE(*nnz_out_host <= (int64_t)INT_MAX, "result has %lld entries: exceeds R's int32 index range",
                    (long long)*nnz_out_host);
     }

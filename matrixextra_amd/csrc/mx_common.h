@@ -38,6 +38,19 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// The one host round trip of the count -> fill operations (a size, a flag): `bytes` <= 64 from device memory into
+// `host_dst`, through a pinned landing zone and an event of the calling thread and current device (a hipMemcpyAsync into
+// pageable memory + hipStreamSynchronize costs ~100 us of runtime staging per call; this is ~10 us).  Returns when the
+// value is there: everything enqueued on `st` before it has completed.  (scan.hip)
+int read_back_small(void *host_dst, const void *dev_src, size_t bytes, hipStream_t st);
+
+// Grow-only device scratch of the calling thread and current device, one buffer per `slot` (kernels' internal tables: the
+// SpMV slice table, per-workgroup partial counts ...).  Like AUTO's SpMM plan it assumes one stream per thread and device
+// at a time.  nullptr when the allocation fails.  (scan.hip)
+enum { MX_SCRATCH_SPMV_SLICES = 0, MX_SCRATCH_PARTIALS = 1, MX_SCRATCH_MERGE = 2, MX_SCRATCH_SLOTS = 4 };
+void *scratch_buffer(int slot, size_t bytes);
+void scratch_release();
+
 // lanes-per-row for the sub-wave ("group") kernels: smallest power of two
 // >= avg row length, clamped to [lo, 64]
 inline int pick_group(double avg_len, int lo = 4)

@@ -7,6 +7,7 @@
 // with carried offset); vectors of up to 2^15 entries take one single-workgroup launch instead.  Row-count vectors are <= 32 MB here; the scan is a
 // bandwidth-trivial step between the count and fill passes of merge / gather.
 #include "mx_common.h"
+#include <cstring>
 
 namespace mx {
 
@@ -139,6 +140,53 @@ void scan_single_kernel(const int32_t *__restrict__ counts, int64_t n, int32_t *
         carry += total;
     }
     if (threadIdx.x == 0) { out[n] = (int32_t)carry; *total_out = carry; }
+}
+
+namespace {
+struct Scratch { void *p = nullptr; size_t cap = 0; };
+thread_local Scratch g_scratch[16][MX_SCRATCH_SLOTS];
+}
+void *scratch_buffer(int slot, size_t bytes)
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) d = 0;
+    Scratch &w = g_scratch[d][slot];
+    if (w.cap < bytes || !w.p) {
+        if (w.p) (void)hipFree(w.p);
+        w.p = nullptr; w.cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        if (hipMalloc(&w.p, want) != hipSuccess) { w.p = nullptr; return nullptr; }
+        w.cap = want;
+    }
+    return w.p;
+}
+void scratch_release()
+{
+    for (auto &dev : g_scratch)
+        for (auto &w : dev) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.cap = 0; }
+}
+
+int read_back_small(void *host_dst, const void *dev_src, size_t bytes, hipStream_t st)
+{
+    struct Rb { void *host = nullptr; hipEvent_t ev = nullptr; };
+    static thread_local Rb rbs[16];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) d = 0;
+    Rb &rb = rbs[d];
+    MX_REQUIRE(bytes <= 64, "read_back_small: %zu bytes", bytes);
+    if (!rb.host) {
+        MX_HIP(hipHostMalloc(&rb.host, 64, hipHostMallocDefault));
+        if (hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipHostFree(rb.host);
+            rb.host = nullptr;
+            return set_error("read_back_small: cannot create an event");
+        }
+    }
+    MX_HIP(hipMemcpyAsync(rb.host, dev_src, bytes, hipMemcpyDeviceToHost, st));
+    MX_HIP(hipEventRecord(rb.ev, st));
+    MX_HIP(hipEventSynchronize(rb.ev));
+    memcpy(host_dst, rb.host, bytes);
+    return 0;
 }
 
 // workspace layout: [int64 total][int64 tile_sums[ntiles]]

@@ -53,6 +53,7 @@ extern "C" int mxd_release_workspaces(void)
 {
     mx::plan_auto_release();
     mx::slab_pack_workspace(0, true);
+    mx::scratch_release();
     return 0;
 }
 

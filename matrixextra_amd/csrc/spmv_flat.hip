@@ -134,29 +134,11 @@ bool spmv_flat_ok(int m, int64_t nnz, const int32_t *indices, const double *valu
     return m > 0 && nnz >= 4 && !(((uintptr_t)indices | (uintptr_t)values) & 15);
 }
 
-// grow-only per-thread, per-device scratch for slice_rows (like AUTO's SpMM plan: one stream per thread and device at a time)
-static int32_t *slice_rows_workspace(size_t count)
-{
-    struct Ws { int32_t *p = nullptr; size_t cap = 0; };
-    static thread_local Ws ws[16];
-    int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) d = 0;
-    Ws &w = ws[d];
-    if (w.cap < count) {
-        if (w.p) (void)hipFree(w.p);
-        w.p = nullptr; w.cap = 0;
-        const size_t want = count + count / 2 + 1024;
-        if (hipMalloc((void **)&w.p, want * sizeof(int32_t)) != hipSuccess) return nullptr;
-        w.cap = want;
-    }
-    return w.p;
-}
-
 int spmv_flat_launch(int m, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
                      const void *v, int v_dtype, void *y, hipStream_t st)
 {
     const unsigned grid = (unsigned)(nnz / FL_TARGET + 1);            // slices cover the starts 0 .. nnz (trailing empty rows)
-    int32_t *slice_rows = slice_rows_workspace((size_t)grid + 1);
+    int32_t *slice_rows = (int32_t *)scratch_buffer(MX_SCRATCH_SPMV_SLICES, ((size_t)grid + 1) * sizeof(int32_t));
     MX_REQUIRE(slice_rows, "spmv: cannot allocate the slice table");
     hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)ceil_div((int64_t)m + 1, 256)), dim3(256), 0, st, m, indptr,
                        slice_rows, (int)grid);

@@ -76,7 +76,22 @@ def lib():
 
 
 def max_threads() -> int:
-    return int(lib().mxo_max_threads())
+    """Threads the OpenMP loops may usefully use: the OpenMP default, capped by the CPU affinity mask and by the cgroup's
+    CPU quota (the GPU boxes show 256 logical CPUs but grant 16 CPUs' worth of time: 128 threads there run 8x SLOWER
+    than one)."""
+    n = int(lib().mxo_max_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def _p(a):

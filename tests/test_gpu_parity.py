@@ -258,6 +258,54 @@ def test_sort_indices_kat_and_random(gpu):
         assert G.check_indices_are_sorted(pp, jj)
 
 
+def test_sort_rows_bitonic_and_rank_paths_with_duplicates(gpu):
+    # rows of 2 .. 511 entries (bitonic network in LDS), of exactly 512 / 513 and ~1500 (rank sort), duplicates inside rows
+    # (stable: ties keep their storage order, like the oracle), rows that are already sorted (left alone), empty rows
+    rng = np.random.default_rng(21)
+    lens = np.concatenate([[0, 1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1500, 0, 40],
+                           rng.integers(0, 300, size=400)])
+    p = np.zeros(lens.size + 1, dtype=np.int32)
+    p[1:] = np.cumsum(lens)
+    j = rng.integers(0, 200, size=p[-1]).astype(np.int32)              # 200 columns: plenty of duplicates
+    for r in (5, 30, 77):                                              # some rows sorted to begin with
+        j[p[r]:p[r + 1]].sort()
+    x = rng.normal(size=p[-1])
+    js, xs = O.sort_sparse_indices(p, j.copy(), x.copy())
+    assert not G.check_indices_are_sorted(p, j)
+    jj, xx = j.copy(), x.copy()
+    G.sort_sparse_indices_inplace(p, jj, xx)
+    np.testing.assert_array_equal(jj, js)
+    np.testing.assert_array_equal(xx, xs)
+    assert G.check_indices_are_sorted(p, jj)
+    xl = rng.choice(np.array([0, 1, NA], dtype=np.int32), size=p[-1])
+    jl, xls = O.sort_sparse_indices(p, j.copy(), xl.copy())
+    jj, xx = j.copy(), xl.copy()
+    G.sort_sparse_indices_inplace(p, jj, xx)
+    np.testing.assert_array_equal(jj, jl)
+    np.testing.assert_array_equal(xx, xls)
+
+
+def test_check_indices_are_sorted_edges(gpu):
+    # descents only AT row starts (sorted), one descent inside the last row, inside the first row, in a one-quad matrix,
+    # array lengths that are not multiples of 4, rows separated by empty rows
+    p = np.array([0, 3, 3, 6, 6, 6, 11], dtype=np.int32)
+    j = np.array([5, 7, 9, 0, 1, 8, 2, 3, 3, 4, 6], dtype=np.int32)
+    assert G.check_indices_are_sorted(p, j) and O.check_indices_are_sorted(p, j)
+    for k in (1, 4, 10):                                               # a descent inside a row
+        jb = j.copy()
+        jb[k] = jb[k - 1] - 1
+        assert not G.check_indices_are_sorted(p, jb) and not O.check_indices_are_sorted(p, jb)
+    pp, jj, _ = synth.csr_fixed(20_000, 3000, 7, seed=9)               # 140 000 entries: several workgroups, ragged tail
+    assert G.check_indices_are_sorted(pp, jj)
+    for k in (6, 7, 69_999, 139_999):
+        jb = jj.copy()
+        jb[k], jb[k - 1] = jb[k - 1], jb[k]
+        assert G.check_indices_are_sorted(pp, jb) == O.check_indices_are_sorted(pp, jb)
+    assert G.check_indices_are_sorted(np.array([0, 1], dtype=np.int32), np.array([3], dtype=np.int32))
+    assert not G.check_indices_are_sorted(np.array([0, 2, 5], dtype=np.int32), np.array([3, 4, 9, 1, 2], dtype=np.int32))
+    assert G.check_indices_are_sorted(np.array([0, 2, 5], dtype=np.int32), np.array([3, 4, 1, 2, 9], dtype=np.int32))
+
+
 # ----------------------------------------------------------------------------- SpMM kernel variants (device level)
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("colmajor", [False, True])

@@ -183,6 +183,18 @@ int mxd_csr_merge_fill(int op, int m,
                        const int32_t *indptr2, const int32_t *indices2, const void *values2, int64_t nnz2,
                        const int32_t *out_indptr, int32_t *out_indices, void *out_values,
                        void *stream);
+/* The same merge in ONE pass over the inputs (what the exports and bench.py use): every workgroup sizes its tile of
+ * rows from the registers it has just loaded, finds its place in the output with a decoupled look-back over the tiles'
+ * totals, and places the entries.  out_indices / out_values must hold the UPPER BOUND of the result — nnz1 + nnz2
+ * entries for ADD / SUB / OR / XOR, min(nnz1, nnz2) for MUL / AND, like the reference's scratch arrays
+ * (operators.cpp:402-406, :139-143); the bound must fit int32 (else use the count -> fill pair).
+ * workspace: mxd_merge_fused_workspace_bytes(m).  *nnz_out_host as above. */
+size_t mxd_merge_fused_workspace_bytes(int m);
+int mxd_csr_merge_fused(int op, int m,
+                        const int32_t *indptr1, const int32_t *indices1, const void *values1, int64_t nnz1,
+                        const int32_t *indptr2, const int32_t *indices2, const void *values2, int64_t nnz2,
+                        int32_t *out_indptr, int32_t *out_indices, void *out_values,
+                        void *workspace, int64_t *nnz_out_host, void *stream);
 /* identical-pattern fast path (operators.cpp:104-132, :343-395): values only */
 int mxd_values_elemwise(int op, int64_t nnz, const void *values1, const void *values2,
                         void *out_values, void *stream);

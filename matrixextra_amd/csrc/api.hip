@@ -329,18 +329,34 @@ int mx_csr_elemwise_begin(int op, int nrows, const int32_t *indptr1, const int32
         if ((rc = A.upload(indptr1, indices1, values1, nrows, vb))) break;
         if ((rc = B.upload(indptr2, indices2, values2, nrows, vb))) break;
         DevBuf ws;
-        if ((rc = ws.alloc(mxd_merge_workspace_bytes(nrows)))) break;
         if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
         int64_t nnz_out = 0;
-        if ((rc = mxd_csr_merge_count(op, nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.nnz, B.p.as<int32_t>(),
-                                      B.j.as<int32_t>(), B.nnz, res->indptr.as<int32_t>(), ws.p, &nnz_out, nullptr)))
-            break;
-        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
-        if ((rc = res->values.alloc(vb * (size_t)nnz_out))) break;
-        if ((rc = mxd_csr_merge_fill(op, nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, A.nnz, B.p.as<int32_t>(),
-                                     B.j.as<int32_t>(), B.x.p, B.nnz, res->indptr.as<int32_t>(),
-                                     res->indices.as<int32_t>(), res->values.p, nullptr)))
-            break;
+        const bool isect = op == MX_OP_MUL || op == MX_OP_AND;
+        const int64_t bound = isect ? (A.nnz < B.nnz ? A.nnz : B.nnz) : A.nnz + B.nnz;
+        // MXGPU_MERGE_FUSED=1: the one-pass kernel (arrays sized for the upper bound, like the reference's own scratch,
+        // operators.cpp:402-406, :139-143).  Measured at 2M x 2M / nnz 1e8 it ties count -> scan -> fill (1.6 vs 1.35 ms:
+        // the tile's index re-read does not stay in L2), so the exactly-sized two-pass form is the default.
+        static const bool fused = [] { const char *e = getenv("MXGPU_MERGE_FUSED"); return e && atoi(e) == 1; }();
+        if (fused && bound <= (int64_t)INT_MAX) {
+            if ((rc = ws.alloc(mxd_merge_fused_workspace_bytes(nrows)))) break;
+            if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)bound))) break;
+            if ((rc = res->values.alloc(vb * (size_t)bound))) break;
+            if ((rc = mxd_csr_merge_fused(op, nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, A.nnz, B.p.as<int32_t>(),
+                                          B.j.as<int32_t>(), B.x.p, B.nnz, res->indptr.as<int32_t>(),
+                                          res->indices.as<int32_t>(), res->values.p, ws.p, &nnz_out, nullptr)))
+                break;
+        } else {
+            if ((rc = ws.alloc(mxd_merge_workspace_bytes(nrows)))) break;
+            if ((rc = mxd_csr_merge_count(op, nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.nnz, B.p.as<int32_t>(),
+                                          B.j.as<int32_t>(), B.nnz, res->indptr.as<int32_t>(), ws.p, &nnz_out, nullptr)))
+                break;
+            if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
+            if ((rc = res->values.alloc(vb * (size_t)nnz_out))) break;
+            if ((rc = mxd_csr_merge_fill(op, nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, A.nnz, B.p.as<int32_t>(),
+                                         B.j.as<int32_t>(), B.x.p, B.nnz, res->indptr.as<int32_t>(),
+                                         res->indices.as<int32_t>(), res->values.p, nullptr)))
+                break;
+        }
         if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
         res->info.indptr_len = (int64_t)nrows + 1;
         res->info.nnz = nnz_out;

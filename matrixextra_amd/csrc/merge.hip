@@ -27,6 +27,7 @@
 // Roofline: HBM-bound; algorithmic bytes = 2*(12 nnz + 4(m+1)) read + 12 nnz_out + 4(m+1)
 // written; the count pass re-reads the indices (8 nnz) on top of that.
 #include "mx_common.h"
+#include <cstdlib>
 
 namespace mx {
 
@@ -70,36 +71,17 @@ __device__ __forceinline__ int group_lower_bound(int tbl, int key, bool &hit)
     return lo;
 }
 
+// hits / output length of a row pair that does not fit the lane group (searches in memory); uniform inside the group
 template <int G, bool INTERSECT>
-__global__ __launch_bounds__(MERGE_BLOCK)
-void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__restrict__ j1,
-                        const int32_t *__restrict__ p2, const int32_t *__restrict__ j2,
-                        int32_t *__restrict__ counts)
+__device__ __forceinline__ int count_row_slow(int lg, const int32_t *__restrict__ a_idx, int n1,
+                                              const int32_t *__restrict__ b_idx, int n2)
 {
-    const int lg = threadIdx.x % G;
-    const long long row_ll = (long long)blockIdx.x * (MERGE_BLOCK / G) + threadIdx.x / G;
-    const bool valid = row_ll < m;
-    const int row = valid ? (int)row_ll : 0;
-    int s1 = 0, e1 = 0, s2 = 0, e2 = 0;
-    if (valid) { s1 = p1[row]; e1 = p1[row + 1]; s2 = p2[row]; e2 = p2[row + 1]; }
-    const int n1 = e1 - s1, n2 = e2 - s2;
-    if (__ballot(n1 > G || n2 > G) == 0ULL) {
-        // every row of this wavefront fits its lane group: both rows live in registers
-        const int a = lg < n1 ? j1[s1 + lg] : INT_MAX;
-        const int b = lg < n2 ? j2[s2 + lg] : INT_MAX;
-        bool hit;
-        group_lower_bound<G>(b, a, hit);
-        const int hits = __popcll(group_ballot<G>(hit && lg < n1));
-        if (valid && lg == 0) counts[row] = INTERSECT ? hits : n1 + n2 - hits;
-        return;
-    }
-    // search the shorter row's entries in the longer row
     const bool a_short = n1 <= n2;
-    const int32_t *__restrict__ q = a_short ? j1 + s1 : j2 + s2;   // queries
-    const int32_t *__restrict__ t = a_short ? j2 + s2 : j1 + s1;   // table
+    const int32_t *__restrict__ q = a_short ? a_idx : b_idx;
+    const int32_t *__restrict__ t = a_short ? b_idx : a_idx;
     const int nq = a_short ? n1 : n2, nt = a_short ? n2 : n1;
     int hits = 0;
-    for (int i0 = 0; i0 < nq; i0 += G) {      // nq is uniform inside the group
+    for (int i0 = 0; i0 < nq; i0 += G) {
         const int i = i0 + lg;
         bool hit = false;
         if (i < nq && nt > 0) {
@@ -109,7 +91,50 @@ void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
         }
         hits += __popcll(group_ballot<G>(hit));
     }
-    if (valid && lg == 0) counts[row] = INTERSECT ? hits : n1 + n2 - hits;
+    return INTERSECT ? hits : n1 + n2 - hits;
+}
+
+// Every lane group sizes COUNT_U consecutive row pairs per call: the row pointers of all of them, then the index loads
+// of all of them, are in flight together (one pair at a time — three dependent loads — ran at 1.8 TB/s).
+constexpr int COUNT_U = 4;
+template <int G, bool INTERSECT>
+__global__ __launch_bounds__(MERGE_BLOCK)
+void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__restrict__ j1,
+                        const int32_t *__restrict__ p2, const int32_t *__restrict__ j2,
+                        int32_t *__restrict__ counts)
+{
+    const int lg = threadIdx.x % G;
+    const long long grp = (long long)blockIdx.x * (MERGE_BLOCK / G) + threadIdx.x / G;
+    int s1[COUNT_U], n1[COUNT_U], s2[COUNT_U], n2[COUNT_U], a[COUNT_U], b[COUNT_U];
+#pragma unroll
+    for (int u = 0; u < COUNT_U; u++) {
+        const long long row = grp * COUNT_U + u;
+        const bool valid = row < m;
+        const long long rs = valid ? row : 0;
+        const int a0 = p1[rs], a1 = p1[rs + 1], b0 = p2[rs], b1 = p2[rs + 1];
+        s1[u] = a0; n1[u] = valid ? a1 - a0 : 0;
+        s2[u] = b0; n2[u] = valid ? b1 - b0 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < COUNT_U; u++) {
+        a[u] = lg < n1[u] && n1[u] <= G ? j1[s1[u] + lg] : INT_MAX;
+        b[u] = lg < n2[u] && n2[u] <= G ? j2[s2[u] + lg] : INT_MAX;
+    }
+#pragma unroll
+    for (int u = 0; u < COUNT_U; u++) {
+        const long long row = grp * COUNT_U + u;
+        int c;
+        if (__ballot(n1[u] > G || n2[u] > G) == 0ULL) {
+            // every row of this wavefront fits its lane group: both rows live in registers
+            bool hit;
+            group_lower_bound<G>(b[u], a[u], hit);
+            const int hits = __popcll(group_ballot<G>(hit && lg < n1[u]));
+            c = INTERSECT ? hits : n1[u] + n2[u] - hits;
+        } else {
+            c = count_row_slow<G, INTERSECT>(lg, j1 + s1[u], n1[u], j2 + s2[u], n2[u]);
+        }
+        if (row < m && lg == 0) counts[row] = c;
+    }
 }
 
 // OP: mx_merge_op.  VT = double (ADD/SUB/MUL) or int32_t (OR/XOR/AND).
@@ -124,64 +149,14 @@ __device__ __forceinline__ VT combine(VT a, VT b)
     else return r_logical_and(a, b);
 }
 
+// fill of such a row pair at output offset o
 template <int G, int OP, typename VT>
-__global__ __launch_bounds__(MERGE_BLOCK)
-void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__restrict__ j1,
-                       const VT *__restrict__ x1,
-                       const int32_t *__restrict__ p2, const int32_t *__restrict__ j2,
-                       const VT *__restrict__ x2,
-                       const int32_t *__restrict__ po, int32_t *__restrict__ jo, VT *__restrict__ xo)
+__device__ __forceinline__ void fill_row_slow(int lg, const int32_t *__restrict__ a_idx, const VT *__restrict__ xa, int n1,
+                                              const int32_t *__restrict__ b_idx, const VT *__restrict__ xb, int n2,
+                                              long long o, int32_t *__restrict__ jo, VT *__restrict__ xo)
 {
     constexpr bool INTERSECT = (OP == MX_OP_MUL || OP == MX_OP_AND);
-    const int lg = threadIdx.x % G;
-    const long long row_ll = (long long)blockIdx.x * (MERGE_BLOCK / G) + threadIdx.x / G;
-    const bool valid = row_ll < m;
-    const int row = valid ? (int)row_ll : 0;
-    int s1 = 0, e1 = 0, s2 = 0, e2 = 0, o = 0;
-    if (valid) { s1 = p1[row]; e1 = p1[row + 1]; s2 = p2[row]; e2 = p2[row + 1]; o = po[row]; }
-    const int n1 = e1 - s1, n2 = e2 - s2;
-    const int32_t *__restrict__ a_idx = j1 + s1;
-    const int32_t *__restrict__ b_idx = j2 + s2;
-    const unsigned long long below = (1ULL << lg) - 1ULL;   // lg < 64 always
-
-    if (__ballot(n1 > G || n2 > G) == 0ULL) {
-        // register-resident rows: one entry of A and one of B per lane, searches by cross-lane probes
-        const bool va = lg < n1, vb = lg < n2;
-        const int a = va ? a_idx[lg] : INT_MAX;
-        const int b = vb ? b_idx[lg] : INT_MAX;
-        VT xa = VT(0), xb = VT(0);
-        if (va) xa = x1[s1 + lg];
-        if (vb) xb = x2[s2 + lg];
-        bool hit_a, hit_b;
-        const int lb_a = group_lower_bound<G>(b, a, hit_a);     // entries of B below a
-        hit_a = hit_a && va;
-        const VT partner = __shfl(xb, lb_a < G ? lb_a : G - 1, G);
-        const int before_a = __popcll(group_ballot<G>(hit_a) & below);
-        if constexpr (INTERSECT) {
-            if (hit_a) {
-                const int pos = o + before_a;
-                jo[pos] = a;
-                xo[pos] = combine<OP, VT>(xa, partner);
-            }
-        } else {
-            if (va) {
-                const int pos = o + lg + lb_a - before_a;
-                jo[pos] = a;
-                xo[pos] = hit_a ? combine<OP, VT>(xa, partner) : xa;
-            }
-            const int lb_b = group_lower_bound<G>(a, b, hit_b);  // entries of A below b
-            hit_b = hit_b && vb;
-            const int before_b = __popcll(group_ballot<G>(hit_b) & below);
-            if (vb && !hit_b) {
-                const int pos = o + lb_b + lg - before_b;
-                jo[pos] = b;
-                if constexpr (OP == MX_OP_SUB) xo[pos] = -xb; else xo[pos] = xb;
-            }
-        }
-        return;
-    }
-
-    // entries of A
+    const unsigned long long below = (1ULL << lg) - 1ULL;
     int hits_before = 0;
     for (int i0 = 0; i0 < n1; i0 += G) {
         const int i = i0 + lg;
@@ -196,22 +171,17 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
         const int before = hits_before + __popcll(hb & below);
         if (i < n1) {
             if constexpr (INTERSECT) {
-                if (hit) {
-                    const int pos = o + before;
-                    jo[pos] = key;
-                    xo[pos] = combine<OP, VT>(x1[s1 + i], x2[s2 + lb]);
-                }
+                if (hit) { jo[o + before] = key; xo[o + before] = combine<OP, VT>(xa[i], xb[lb]); }
             } else {
-                const int pos = o + i + lb - before;
+                const long long pos = o + i + lb - before;
                 jo[pos] = key;
-                const VT va = x1[s1 + i];
-                xo[pos] = hit ? combine<OP, VT>(va, x2[s2 + lb]) : va;
+                const VT va = xa[i];
+                xo[pos] = hit ? combine<OP, VT>(va, xb[lb]) : va;
             }
         }
         hits_before += __popcll(hb);
     }
     if constexpr (!INTERSECT) {
-        // entries of B that have no partner in A
         hits_before = 0;
         for (int u0 = 0; u0 < n2; u0 += G) {
             const int u = u0 + lg;
@@ -225,12 +195,307 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
             const unsigned long long hb = group_ballot<G>(hit);
             const int before = hits_before + __popcll(hb & below);
             if (u < n2 && !hit) {
-                const int pos = o + lb + u - before;
+                const long long pos = o + lb + u - before;
                 jo[pos] = key;
-                const VT vb = x2[s2 + u];
+                const VT vb = xb[u];
                 if constexpr (OP == MX_OP_SUB) xo[pos] = -vb; else xo[pos] = vb;
             }
             hits_before += __popcll(hb);
+        }
+    }
+}
+
+// FILL_U consecutive row pairs per lane group: row pointers, then indices + values of all of them in flight together
+constexpr int FILL_U = 2;
+template <int G, int OP, typename VT>
+__global__ __launch_bounds__(MERGE_BLOCK)
+void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__restrict__ j1,
+                       const VT *__restrict__ x1,
+                       const int32_t *__restrict__ p2, const int32_t *__restrict__ j2,
+                       const VT *__restrict__ x2,
+                       const int32_t *__restrict__ po, int32_t *__restrict__ jo, VT *__restrict__ xo)
+{
+    constexpr bool INTERSECT = (OP == MX_OP_MUL || OP == MX_OP_AND);
+    const int lg = threadIdx.x % G;
+    const long long grp = (long long)blockIdx.x * (MERGE_BLOCK / G) + threadIdx.x / G;
+    const unsigned long long below = (1ULL << lg) - 1ULL;   // lg < 64 always
+    int s1[FILL_U], n1[FILL_U], s2[FILL_U], n2[FILL_U], o[FILL_U], a[FILL_U], b[FILL_U];
+    VT xa[FILL_U], xb[FILL_U];
+#pragma unroll
+    for (int u = 0; u < FILL_U; u++) {
+        const long long row = grp * FILL_U + u;
+        const bool valid = row < m;
+        const long long rs = valid ? row : 0;
+        const int a0 = p1[rs], a1 = p1[rs + 1], b0 = p2[rs], b1 = p2[rs + 1];
+        o[u] = po[rs];
+        s1[u] = a0; n1[u] = valid ? a1 - a0 : 0;
+        s2[u] = b0; n2[u] = valid ? b1 - b0 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < FILL_U; u++) {
+        const bool va = lg < n1[u] && n1[u] <= G, vb = lg < n2[u] && n2[u] <= G;
+        a[u] = INT_MAX; b[u] = INT_MAX; xa[u] = VT(0); xb[u] = VT(0);
+        if (va) { a[u] = j1[s1[u] + lg]; xa[u] = x1[s1[u] + lg]; }
+        if (vb) { b[u] = j2[s2[u] + lg]; xb[u] = x2[s2[u] + lg]; }
+    }
+#pragma unroll
+    for (int u = 0; u < FILL_U; u++) {
+        const long long row = grp * FILL_U + u;
+        const bool fits = __ballot(n1[u] > G || n2[u] > G) == 0ULL;
+        if (row >= m) continue;
+        if (!fits) {
+            fill_row_slow<G, OP, VT>(lg, j1 + s1[u], x1 + s1[u], n1[u], j2 + s2[u], x2 + s2[u], n2[u], o[u], jo, xo);
+            continue;
+        }
+        // register-resident rows: one entry of A and one of B per lane, searches by cross-lane probes
+        const bool va = lg < n1[u], vb = lg < n2[u];
+        bool hit_a, hit_b;
+        const int lb_a = group_lower_bound<G>(b[u], a[u], hit_a);     // entries of B below a
+        hit_a = hit_a && va;
+        const VT partner = __shfl(xb[u], lb_a < G ? lb_a : G - 1, G);
+        const int before_a = __popcll(group_ballot<G>(hit_a) & below);
+        if constexpr (INTERSECT) {
+            if (hit_a) {
+                const int pos = o[u] + before_a;
+                jo[pos] = a[u];
+                xo[pos] = combine<OP, VT>(xa[u], partner);
+            }
+        } else {
+            if (va) {
+                const int pos = o[u] + lg + lb_a - before_a;
+                jo[pos] = a[u];
+                xo[pos] = hit_a ? combine<OP, VT>(xa[u], partner) : xa[u];
+            }
+            const int lb_b = group_lower_bound<G>(a[u], b[u], hit_b);  // entries of A below b
+            hit_b = hit_b && vb;
+            const int before_b = __popcll(group_ballot<G>(hit_b) & below);
+            if (vb && !hit_b) {
+                const int pos = o[u] + lb_b + lg - before_b;
+                jo[pos] = b[u];
+                if constexpr (OP == MX_OP_SUB) xo[pos] = -xb[u]; else xo[pos] = xb[u];
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// One pass over the inputs: merge_fused_kernel.
+//
+// count -> scan -> fill reads the index arrays twice (the count pass re-reads 8 nnz bytes and, one row pair per lane
+// group with three dependent loads, ran at 1.8 TB/s: 0.45 of the 1.55 ms of CSR + CSR at 2M x 2M / nnz 1e8).  Here a
+// 512-thread workgroup takes a tile of consecutive rows, every wavefront K row steps of 64 / G rows each: all loads of
+// the K steps are issued up front (both rows of a pair, one entry per lane, stay in registers), the rows' output lengths
+// come from the cross-lane searches, and the tile's position in the output comes from a decoupled look-back over the
+// tiles' totals (one 64-bit word per tile: 2 flag bits + value, relaxed agent-scope loads / stores — the value travels
+// in the same word as its flag, so nothing else needs ordering; tiles are numbered by an atomic ticket so that every
+// predecessor of a running tile has started).  The entries are then placed from the registers.  The caller provides
+// out_indices / out_values for the upper bound (nnz1 + nnz2, or min(nnz1, nnz2) for the intersection) like the
+// reference's own scratch arrays (operators.cpp:402-406, :139-143); nnz_out comes back with the last tile.
+// Row pairs that do not fit a lane group take the searches in global memory (both phases), as in the two-pass kernels.
+// =====================================================================================================
+constexpr int FUSED_WAVES = 8;
+constexpr int FUSED_BLOCK = FUSED_WAVES * 64;
+constexpr int FUSED_LOOK = 8;                         // windows of 64 predecessor tiles read per look-back round trip
+constexpr unsigned long long FUSED_FLAG_AGG = 1ULL << 62, FUSED_FLAG_PRE = 2ULL << 62, FUSED_VALUE = (1ULL << 62) - 1;
+
+// rows per tile: FUSED_STEPS row steps per wavefront (64 / G rows each)
+constexpr int FUSED_STEPS = 32;
+constexpr int FUSED_U = 2;                             // row steps whose loads are in flight together
+
+template <int G, int OP, typename VT>
+__global__ __launch_bounds__(FUSED_BLOCK)
+void merge_fused_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__restrict__ j1, const VT *__restrict__ x1,
+                        const int32_t *__restrict__ p2, const int32_t *__restrict__ j2, const VT *__restrict__ x2,
+                        int32_t *__restrict__ po, int32_t *__restrict__ jo, VT *__restrict__ xo,
+                        unsigned long long *__restrict__ tile_state, unsigned *__restrict__ ticket,
+                        long long *__restrict__ total_out, int ntiles)
+{
+    constexpr bool INTERSECT = (OP == MX_OP_MUL || OP == MX_OP_AND);
+    constexpr int RPS = 64 / G;                                       // rows per wavefront and step
+    constexpr int WAVE_ROWS = RPS * FUSED_STEPS;
+    constexpr int TILE_ROWS = FUSED_WAVES * WAVE_ROWS;
+    constexpr int PER = (TILE_ROWS + FUSED_BLOCK - 1) / FUSED_BLOCK;  // rows per thread in the tile's scan
+    __shared__ int cnt[TILE_ROWS + 1];                                // output length of every row, then its exclusive offset
+    __shared__ int s_tile;
+    __shared__ long long s_base;
+    __shared__ int wave_tot[FUSED_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane % G, grp = lane / G;
+    if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);                 // tiles in starting order: predecessors are running or done
+    __syncthreads();
+    const int tile = s_tile;
+    const long long row0 = (long long)tile * TILE_ROWS;
+    const int wl0 = wave * WAVE_ROWS;                                 // this wavefront's first row inside the tile
+    const unsigned long long below = (1ULL << lg) - 1ULL;
+
+    // ---- phase 1: output length of every row of the tile (index arrays only)
+    for (int k0 = 0; k0 < FUSED_STEPS; k0 += FUSED_U) {
+        int s1[FUSED_U], n1[FUSED_U], s2[FUSED_U], n2[FUSED_U], a[FUSED_U], b[FUSED_U];
+#pragma unroll
+        for (int u = 0; u < FUSED_U; u++) {
+            const long long row = row0 + wl0 + (k0 + u) * RPS + grp;
+            const bool valid = row < m;
+            const long long rs = valid ? row : 0;
+            const int a0 = p1[rs], a1 = p1[rs + 1], b0 = p2[rs], b1 = p2[rs + 1];
+            s1[u] = a0; n1[u] = valid ? a1 - a0 : 0;
+            s2[u] = b0; n2[u] = valid ? b1 - b0 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < FUSED_U; u++) {
+            a[u] = lg < n1[u] && n1[u] <= G ? j1[s1[u] + lg] : INT_MAX;
+            b[u] = lg < n2[u] && n2[u] <= G ? j2[s2[u] + lg] : INT_MAX;
+        }
+#pragma unroll
+        for (int u = 0; u < FUSED_U; u++) {
+            int c;
+            if (__ballot(n1[u] > G || n2[u] > G) == 0ULL) {           // every pair of this step fits its lane group
+                bool hit;
+                group_lower_bound<G>(b[u], a[u], hit);
+                const int hits = __popcll(group_ballot<G>(hit && lg < n1[u]));
+                c = INTERSECT ? hits : n1[u] + n2[u] - hits;
+            } else {
+                c = count_row_slow<G, INTERSECT>(lg, j1 + s1[u], n1[u], j2 + s2[u], n2[u]);
+            }
+            if (lg == 0) cnt[wl0 + (k0 + u) * RPS + grp] = c;
+        }
+    }
+    __syncthreads();
+    // ---- exclusive scan of the tile's row lengths (in place), tile total
+    {
+        int v[PER], sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; i++) { const int r = tid * PER + i; v[i] = r < TILE_ROWS ? cnt[r] : 0; sum += v[i]; }
+        int incl = sum;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) { const int up = __shfl_up(incl, o2, 64); if (lane >= o2) incl += up; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int wbase = 0;
+#pragma unroll
+        for (int w = 0; w < FUSED_WAVES; w++) wbase += w < wave ? wave_tot[w] : 0;
+        int run = wbase + incl - sum;
+#pragma unroll
+        for (int i = 0; i < PER; i++) { const int r = tid * PER + i; if (r < TILE_ROWS) cnt[r] = run; run += v[i]; }
+        if (tid == FUSED_BLOCK - 1) cnt[TILE_ROWS] = run;             // the tile's total
+    }
+    __syncthreads();
+    const long long tile_total = cnt[TILE_ROWS];
+
+    // ---- decoupled look-back: exclusive prefix of the tile totals
+    if (wave == 0) {
+        long long excl = 0;
+        if (tile == 0) {
+            if (lane == 0)
+                __hip_atomic_store(&tile_state[0], FUSED_FLAG_PRE | (unsigned long long)tile_total, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0)
+                __hip_atomic_store(&tile_state[tile], FUSED_FLAG_AGG | (unsigned long long)tile_total, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            // A tile that is still counting or looking back itself only offers its own total, so the nearest known prefix
+            // is typically as many tiles back as are in flight: FUSED_LOOK windows of 64 predecessors per round trip.
+            int look = tile - 1;                                      // window u, lane i: tile look - 64 u - i
+            for (;;) {
+                unsigned long long st[FUSED_LOOK];
+#pragma unroll
+                for (int u = 0; u < FUSED_LOOK; u++) {
+                    const int t = look - 64 * u - lane;
+                    st[u] = FUSED_FLAG_PRE;                           // before tile 0: an empty prefix
+                    if (t >= 0) st[u] = __hip_atomic_load(&tile_state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                bool done = false, stalled = false;
+#pragma unroll
+                for (int u = 0; u < FUSED_LOOK; u++) {
+                    if (done || stalled) continue;                    // uniform
+                    const unsigned long long empty = __ballot((st[u] >> 62) == 0);
+                    const unsigned long long pre = __ballot((st[u] >> 62) == 2);
+                    // usable part of the window: the lanes before the first empty one, cut after the first prefix
+                    const int first_empty = empty ? __builtin_ctzll(empty) : 64;
+                    const int first_pre = pre ? __builtin_ctzll(pre) : 64;
+                    const int upto = first_pre < first_empty ? first_pre + 1 : first_empty;
+                    long long v = lane < upto ? (long long)(st[u] & FUSED_VALUE) : 0;
+#pragma unroll
+                    for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2, 64);
+                    excl += v;
+                    look -= upto;
+                    if (first_pre < first_empty) done = true;         // reached a tile that knows its prefix
+                    else if (upto < 64) stalled = true;               // a tile that has not published yet: read again from there
+                }
+                if (done) break;
+                if (stalled) __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0)
+                __hip_atomic_store(&tile_state[tile], FUSED_FLAG_PRE | (unsigned long long)(excl + tile_total),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_base = excl;
+            if (tile == ntiles - 1) {
+                *total_out = excl + tile_total;
+                if (excl + tile_total <= (long long)INT_MAX) po[m] = (int32_t)(excl + tile_total);
+            }
+        }
+    }
+    __syncthreads();
+    const long long base = s_base;
+
+    // ---- phase 2: place the entries (the index arrays come back from L2: the tile read them a moment ago)
+    for (int k0 = 0; k0 < FUSED_STEPS; k0 += FUSED_U) {
+        int s1[FUSED_U], n1[FUSED_U], s2[FUSED_U], n2[FUSED_U], a[FUSED_U], b[FUSED_U];
+        VT xa[FUSED_U], xb[FUSED_U];
+#pragma unroll
+        for (int u = 0; u < FUSED_U; u++) {
+            const long long row = row0 + wl0 + (k0 + u) * RPS + grp;
+            const bool valid = row < m;
+            const long long rs = valid ? row : 0;
+            const int a0 = p1[rs], a1 = p1[rs + 1], b0 = p2[rs], b1 = p2[rs + 1];
+            s1[u] = a0; n1[u] = valid ? a1 - a0 : 0;
+            s2[u] = b0; n2[u] = valid ? b1 - b0 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < FUSED_U; u++) {
+            const bool va = lg < n1[u] && n1[u] <= G, vb = lg < n2[u] && n2[u] <= G;
+            a[u] = INT_MAX; b[u] = INT_MAX; xa[u] = VT(0); xb[u] = VT(0);
+            if (va) { a[u] = j1[s1[u] + lg]; xa[u] = x1[s1[u] + lg]; }
+            if (vb) { b[u] = j2[s2[u] + lg]; xb[u] = x2[s2[u] + lg]; }
+        }
+#pragma unroll
+        for (int u = 0; u < FUSED_U; u++) {
+            const int lr = wl0 + (k0 + u) * RPS + grp;
+            const long long row = row0 + lr;
+            const bool fits = __ballot(n1[u] > G || n2[u] > G) == 0ULL;
+            if (row >= m) continue;
+            const long long o = base + cnt[lr];
+            if (lg == 0) po[row] = (int32_t)o;
+            if (!fits) {
+                fill_row_slow<G, OP, VT>(lg, j1 + s1[u], x1 + s1[u], n1[u], j2 + s2[u], x2 + s2[u], n2[u], o, jo, xo);
+                continue;
+            }
+            const bool va = lg < n1[u], vb = lg < n2[u];
+            bool hit_a, hit_b;
+            const int lb_a = group_lower_bound<G>(b[u], a[u], hit_a);  // entries of B below a
+            hit_a = hit_a && va;
+            const VT partner = __shfl(xb[u], lb_a < G ? lb_a : G - 1, G);
+            const int before_a = __popcll(group_ballot<G>(hit_a) & below);
+            if constexpr (INTERSECT) {
+                if (hit_a) {
+                    jo[o + before_a] = a[u];
+                    xo[o + before_a] = combine<OP, VT>(xa[u], partner);
+                }
+            } else {
+                if (va) {
+                    const long long pos = o + lg + lb_a - before_a;
+                    jo[pos] = a[u];
+                    xo[pos] = hit_a ? combine<OP, VT>(xa[u], partner) : xa[u];
+                }
+                const int lb_b = group_lower_bound<G>(a[u], b[u], hit_b);  // entries of A below b
+                hit_b = hit_b && vb;
+                const int before_b = __popcll(group_ballot<G>(hit_b) & below);
+                if (vb && !hit_b) {
+                    const long long pos = o + lb_b + lg - before_b;
+                    jo[pos] = b[u];
+                    if constexpr (OP == MX_OP_SUB) xo[pos] = -xb[u]; else xo[pos] = xb[u];
+                }
+            }
         }
     }
 }
@@ -259,7 +524,7 @@ int merge_count_launch(int op, int G, int m, const int32_t *p1, const int32_t *j
     const bool isect = op_is_intersect(op);
 #define MX_CASE(GG)                                                                                   \
     case GG: {                                                                                        \
-        const unsigned grid = (unsigned)ceil_div(m, MERGE_BLOCK / GG);                                \
+        const unsigned grid = (unsigned)ceil_div(m, (MERGE_BLOCK / GG) * COUNT_U);                    \
         if (isect) hipLaunchKernelGGL((merge_count_kernel<GG, true>), dim3(grid), dim3(MERGE_BLOCK), 0, st, \
                                       m, p1, j1, p2, j2, counts);                                     \
         else hipLaunchKernelGGL((merge_count_kernel<GG, false>), dim3(grid), dim3(MERGE_BLOCK), 0, st, \
@@ -278,7 +543,7 @@ static int merge_fill_op(int G, int m, const int32_t *p1, const int32_t *j1, con
 {
 #define MX_CASE(GG)                                                                                   \
     case GG: {                                                                                        \
-        const unsigned grid = (unsigned)ceil_div(m, MERGE_BLOCK / GG);                                \
+        const unsigned grid = (unsigned)ceil_div(m, (MERGE_BLOCK / GG) * FILL_U);                     \
         hipLaunchKernelGGL((merge_fill_kernel<GG, OP, VT>), dim3(grid), dim3(MERGE_BLOCK), 0, st, m,  \
                            p1, j1, (const VT *)x1, p2, j2, (const VT *)x2, po, jo, (VT *)xo);         \
         break;                                                                                        \
@@ -299,6 +564,46 @@ int merge_fill_launch(int op, int G, int m, const int32_t *p1, const int32_t *j1
         case MX_OP_OR:  return merge_fill_op<MX_OP_OR, int32_t>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, st);
         case MX_OP_XOR: return merge_fill_op<MX_OP_XOR, int32_t>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, st);
         case MX_OP_AND: return merge_fill_op<MX_OP_AND, int32_t>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, st);
+        default: return set_error("merge: unknown op %d", op);
+    }
+}
+
+template <int OP, typename VT>
+static int merge_fused_op(int G, int m, const int32_t *p1, const int32_t *j1, const void *x1, const int32_t *p2,
+                          const int32_t *j2, const void *x2, int32_t *po, int32_t *jo, void *xo,
+                          unsigned long long *tile_state, unsigned *ticket, long long *total, hipStream_t st)
+{
+#define MX_CASE(GG)                                                                                               \
+    case GG: {                                                                                                    \
+        const int ntiles = (int)ceil_div(m, FUSED_WAVES * (64 / GG) * FUSED_STEPS);                               \
+        hipLaunchKernelGGL((merge_fused_kernel<GG, OP, VT>), dim3((unsigned)ntiles), dim3(FUSED_BLOCK), 0, st, m,  \
+                           p1, j1, (const VT *)x1, p2, j2, (const VT *)x2, po, jo, (VT *)xo, tile_state, ticket,   \
+                           total, ntiles);                                                                        \
+        break;                                                                                                    \
+    }
+    switch (G) { MX_CASE(8) MX_CASE(16) MX_CASE(32) MX_CASE(64) default: return set_error("merge: bad group %d", G); }
+#undef MX_CASE
+    MX_LAUNCH_CHECK();
+    return 0;
+}
+
+int merge_fused_launch(int op, int G, int m, const int32_t *p1, const int32_t *j1, const void *x1, const int32_t *p2,
+                       const int32_t *j2, const void *x2, int32_t *po, int32_t *jo, void *xo, void *workspace,
+                       hipStream_t st)
+{
+    // workspace: [int64 total][uint32 ticket, pad][uint64 tile_state[ntiles]]
+    const int64_t ntiles = ceil_div(m, FUSED_WAVES * (64 / G) * FUSED_STEPS);
+    long long *total = (long long *)workspace;
+    unsigned *ticket = (unsigned *)(total + 1);
+    unsigned long long *tile_state = (unsigned long long *)(total + 2);
+    MX_HIP(hipMemsetAsync(workspace, 0, 16 + (size_t)ntiles * 8, st));
+    switch (op) {
+        case MX_OP_ADD: return merge_fused_op<MX_OP_ADD, double>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, tile_state, ticket, total, st);
+        case MX_OP_SUB: return merge_fused_op<MX_OP_SUB, double>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, tile_state, ticket, total, st);
+        case MX_OP_MUL: return merge_fused_op<MX_OP_MUL, double>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, tile_state, ticket, total, st);
+        case MX_OP_OR:  return merge_fused_op<MX_OP_OR, int32_t>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, tile_state, ticket, total, st);
+        case MX_OP_XOR: return merge_fused_op<MX_OP_XOR, int32_t>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, tile_state, ticket, total, st);
+        case MX_OP_AND: return merge_fused_op<MX_OP_AND, int32_t>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, tile_state, ticket, total, st);
         default: return set_error("merge: unknown op %d", op);
     }
 }
@@ -367,5 +672,40 @@ extern "C" int mxd_values_elemwise(int op, int64_t nnz, const void *values1, con
     }
 #undef MX_CASE
     MX_LAUNCH_CHECK();
+    return 0;
+}
+
+// One pass (merge_fused_kernel).  out_indices / out_values must hold the upper bound of the result — nnz1 + nnz2 entries
+// for ADD / SUB / OR / XOR, min(nnz1, nnz2) for MUL / AND; out_indptr[m+1].  workspace: mxd_merge_fused_workspace_bytes(m).
+// *nnz_out_host is written after an internal synchronisation (the one host round trip).
+extern "C" size_t mxd_merge_fused_workspace_bytes(int m)
+{
+    // tiles hold at least FUSED_WAVES * FUSED_STEPS rows (G = 64)
+    return 16 + 8 * (size_t)mx::ceil_div(m > 0 ? m : 1, mx::FUSED_WAVES * mx::FUSED_STEPS) + 64;
+}
+
+extern "C" int mxd_csr_merge_fused(int op, int m, const int32_t *indptr1, const int32_t *indices1, const void *values1,
+                                   int64_t nnz1, const int32_t *indptr2, const int32_t *indices2, const void *values2,
+                                   int64_t nnz2, int32_t *out_indptr, int32_t *out_indices, void *out_values,
+                                   void *workspace, int64_t *nnz_out_host, void *stream)
+{
+    MX_REQUIRE(m >= 0, "mxd_csr_merge_fused: negative m");
+    MX_REQUIRE(out_indptr && workspace, "mxd_csr_merge_fused: null pointer");
+    MX_REQUIRE((mx::op_is_intersect(op) ? (nnz1 < nnz2 ? nnz1 : nnz2) : nnz1 + nnz2) <= (int64_t)INT_MAX || nnz1 < 0 || nnz2 < 0,
+               "mxd_csr_merge_fused: the result's upper bound exceeds R's int32 index range (use the count -> fill pair)");
+    hipStream_t st = mx::as_stream(stream);
+    if (m == 0) {
+        MX_HIP(hipMemsetAsync(out_indptr, 0, sizeof(int32_t), st));
+        if (nnz_out_host) *nnz_out_host = 0;
+        return 0;
+    }
+    const int rc = mx::merge_fused_launch(op, mx::merge_group(m, nnz1, nnz2), m, indptr1, indices1, values1, indptr2, indices2,
+                                          values2, out_indptr, out_indices, out_values, workspace, st);
+    if (rc) return rc;
+    if (nnz_out_host) {
+        if (mx::read_back_small(nnz_out_host, workspace, sizeof(int64_t), st)) return 1;
+        MX_REQUIRE(*nnz_out_host <= (int64_t)INT_MAX, "result has %lld entries: exceeds R's int32 index range",
+                   (long long)*nnz_out_host);
+    }
     return 0;
 }

@@ -157,18 +157,32 @@ def spmv(A: DeviceCSR, v: torch.Tensor, v_dtype=None, out=None, algo: int = 0):
     return out
 
 
-def csr_elemwise(op, A: DeviceCSR, B: DeviceCSR):
-    """CSR (+) CSR on device-resident operands: count -> scan -> (one host round trip for nnz) -> fill."""
+def csr_elemwise(op, A: DeviceCSR, B: DeviceCSR, two_pass: bool = True):
+    """CSR (+) CSR on device-resident operands.  Default (two_pass=True): count -> scan -> (host round trip for nnz) ->
+    fill into exactly sized arrays.  two_pass=False: ONE pass (mxd_csr_merge_fused) into arrays sized for the upper
+    bound of the result (nnz1 + nnz2, or min for the intersection), returned as views of their first nnz_out entries."""
     lib = _lib.load()
     assert A.m == B.m
     dev = A.indptr.device
+    logical = op in (_lib.MX_OP_OR, _lib.MX_OP_XOR, _lib.MX_OP_AND)
+    bound = min(A.nnz, B.nnz) if op in (_lib.MX_OP_MUL, _lib.MX_OP_AND) else A.nnz + B.nnz
+    if not two_pass and bound < 2 ** 31:
+        ws = torch.empty(lib.mxd_merge_fused_workspace_bytes(A.m), dtype=torch.uint8, device=dev)
+        out_p = torch.empty(A.m + 1, dtype=torch.int32, device=dev)
+        out_j = torch.empty(bound, dtype=torch.int32, device=dev)
+        out_x = torch.empty(bound, dtype=torch.int32 if logical else torch.float64, device=dev)
+        nnz_out = C.c_int64(0)
+        check(lib.mxd_csr_merge_fused(C.c_int(op), C.c_int(A.m), _dp(A.indptr), _dp(A.indices), _dp(A.values),
+                                      C.c_int64(A.nnz), _dp(B.indptr), _dp(B.indices), _dp(B.values), C.c_int64(B.nnz),
+                                      _dp(out_p), _dp(out_j), _dp(out_x), _dp(ws), C.byref(nnz_out), _stream()))
+        n = int(nnz_out.value)
+        return DeviceCSR(out_p, out_j[:n], out_x[:n], A.m, A.K, n)
     ws = torch.empty(lib.mxd_merge_workspace_bytes(A.m), dtype=torch.uint8, device=dev)
     out_p = torch.empty(A.m + 1, dtype=torch.int32, device=dev)
     nnz_out = C.c_int64(0)
     check(lib.mxd_csr_merge_count(C.c_int(op), C.c_int(A.m), _dp(A.indptr), _dp(A.indices), C.c_int64(A.nnz),
                                   _dp(B.indptr), _dp(B.indices), C.c_int64(B.nnz), _dp(out_p), _dp(ws),
                                   C.byref(nnz_out), _stream()))
-    logical = op in (_lib.MX_OP_OR, _lib.MX_OP_XOR, _lib.MX_OP_AND)
     out_j = torch.empty(nnz_out.value, dtype=torch.int32, device=dev)
     out_x = torch.empty(nnz_out.value, dtype=torch.int32 if logical else torch.float64, device=dev)
     check(lib.mxd_csr_merge_fill(C.c_int(op), C.c_int(A.m), _dp(A.indptr), _dp(A.indices), _dp(A.values),

@@ -84,3 +84,22 @@ def spmv_device(p, j, x, v, v_dtype, algo=0):
                                    C.c_int(v_dtype), dy.ptr, C.c_int(algo), None))
     check(lib.mx_stream_sync(None))
     return dy.download(odt, (m,))
+
+
+def merge_fused_device(op, p1, j1, x1, p2, j2, x2):
+    """A (op) B through the one-pass kernel (mxd_csr_merge_fused); returns (indptr, indices, values)."""
+    lib = _lib.load()
+    m = p1.size - 1
+    logical = op in (_lib.MX_OP_OR, _lib.MX_OP_XOR, _lib.MX_OP_AND)
+    vdt = np.int32 if logical else np.float64
+    n1, n2 = int(p1[-1]), int(p2[-1])
+    bound = min(n1, n2) if op in (_lib.MX_OP_MUL, _lib.MX_OP_AND) else n1 + n2
+    d = [Dev(np.asarray(a, dtype=t)) for a, t in ((p1, np.int32), (j1, np.int32), (x1, vdt), (p2, np.int32), (j2, np.int32),
+                                                   (x2, vdt))]
+    dp, dj, dx = Dev(nbytes=4 * (m + 1)), Dev(nbytes=4 * max(bound, 1)), Dev(nbytes=np.dtype(vdt).itemsize * max(bound, 1))
+    ws = Dev(nbytes=int(lib.mxd_merge_fused_workspace_bytes(C.c_int(m))))
+    nnz = C.c_int64(-1)
+    check(lib.mxd_csr_merge_fused(C.c_int(op), C.c_int(m), d[0].ptr, d[1].ptr, d[2].ptr, C.c_int64(n1), d[3].ptr, d[4].ptr,
+                                  d[5].ptr, C.c_int64(n2), dp.ptr, dj.ptr, dx.ptr, ws.ptr, C.byref(nnz), None))
+    n = int(nnz.value)
+    return dp.download(np.int32, (m + 1,)), dj.download(np.int32, (max(bound, 1),))[:n], dx.download(vdt, (max(bound, 1),))[:n]

@@ -146,6 +146,11 @@ def test_cfg4_merge_properties(gpu):
     Dm = D.csr_elemwise(_lib.MX_OP_SUB, A, B)
     M = D.csr_elemwise(_lib.MX_OP_MUL, A, B)
     assert S.nnz + M.nnz == A.nnz + B.nnz                       # inclusion-exclusion on the patterns
+    for R, op in ((S, _lib.MX_OP_ADD), (M, _lib.MX_OP_MUL)):    # the one-pass kernel == count -> scan -> fill (default)
+        R2 = D.csr_elemwise(op, A, B, two_pass=False)
+        assert R2.nnz == R.nnz and torch.equal(R2.indptr, R.indptr) and torch.equal(R2.indices, R.indices) \
+            and torch.equal(R2.values, R.values)
+        del R2
     assert torch.equal(S.indptr, Dm.indptr) and torch.equal(S.indices, Dm.indices)
     assert abs(S.values.sum().item() - (x1.sum() + x2.sum())) <= 1e-9 * (np.abs(x1).sum() + np.abs(x2).sum())
     assert abs(Dm.values.sum().item() - (x1.sum() - x2.sum())) <= 1e-9 * (np.abs(x1).sum() + np.abs(x2).sum())

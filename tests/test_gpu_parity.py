@@ -9,7 +9,7 @@ import pytest
 
 from conftest import rand_csr
 from matrixextra_amd import exports as G
-from matrixextra_amd import synth
+from matrixextra_amd import _lib, synth
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -205,6 +205,33 @@ def test_merge_mid_size_overlap(gpu):
 
 
 # ----------------------------------------------------------------------------- gather
+def test_merge_one_pass_kernel_vs_oracle(gpu):
+    """mxd_csr_merge_fused (one pass, decoupled look-back over tile totals): every op, rows longer than a lane group,
+    empty rows, several tiles, one operand empty — bit-exact against the oracle like the two-pass form."""
+    from devmem import merge_fused_device
+    cases = [(100, 35, 0.4, 0.6), (3, 300, 0.9, 0.9), (5000, 64, 0.1, 0.1), (40, 200, 0.7, 0.02), (50, 20, 0.0, 0.5),
+             (9000, 900, 0.02, 0.03), (700, 3000, 0.05, 0.001)]
+    for m, K, d1, d2 in cases:
+        p1, j1, x1 = rand_csr(m, K, d1, seed=31 + m, empty_rows=(1,) if m > 2 else ())
+        p2, j2, x2 = rand_csr(m, K, d2, seed=32 + K, empty_rows=(1, 2) if m > 3 else ())
+        for op, ref in ((_lib.MX_OP_ADD, O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, False)),
+                        (_lib.MX_OP_SUB, O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, True)),
+                        (_lib.MX_OP_MUL, O.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2))):
+            gp, gj, gx = merge_fused_device(op, p1, j1, x1, p2, j2, x2)
+            np.testing.assert_array_equal(gp, ref["indptr"])
+            np.testing.assert_array_equal(gj, ref["indices"])
+            np.testing.assert_array_equal(gx, ref["values"])
+        l1 = np.random.default_rng(m).choice(np.array([0, 1, NA], dtype=np.int32), size=j1.size)
+        l2 = np.random.default_rng(K).choice(np.array([0, 1, NA], dtype=np.int32), size=j2.size)
+        for op, ref in ((_lib.MX_OP_OR, O.logicalor_csr_elemwise(p1, p2, j1, j2, l1, l2, False)),
+                        (_lib.MX_OP_XOR, O.logicalor_csr_elemwise(p1, p2, j1, j2, l1, l2, True)),
+                        (_lib.MX_OP_AND, O.logicaland_csr_elemwise(p1, p2, j1, j2, l1, l2))):
+            gp, gj, gx = merge_fused_device(op, p1, j1, l1, p2, j2, l2)
+            np.testing.assert_array_equal(gp, ref["indptr"])
+            np.testing.assert_array_equal(gj, ref["indices"])
+            np.testing.assert_array_equal(gx, ref["values"])
+
+
 def test_copy_csr_rows(gpu):
     p, j, x = rand_csr(1000, 500, 0.1, seed=7, empty_rows=(10, 11))     # test-slice.R:6-16 fixture shape
     rng = np.random.default_rng(9)

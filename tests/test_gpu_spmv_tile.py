@@ -8,8 +8,8 @@ import pytest
 
 from matrixextra_amd import _lib, synth
 from oracle import oracle as O
-from tests.conftest import rand_csr
-from tests.devmem import spmv_device
+from conftest import rand_csr
+from devmem import spmv_device
 
 pytestmark = pytest.mark.gpu
 NA = np.int32(-2147483648)

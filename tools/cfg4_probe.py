@@ -2,7 +2,7 @@
 """BASELINE configs[3] timing: CSR + CSR and CSR * CSR on 2M x 2M, 50/row (nnz 1e8 each, ~50 % shared pattern), operands
 resident in HBM (run on the GPU box): python tools/cfg4_probe.py"""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from matrixextra_amd import _lib, device as D, synth
 m = K = 2_000_000

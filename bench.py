@@ -460,12 +460,17 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
     from matrixextra_amd import exports as G
     Yc = np.asfortranarray(B_host.T)
     fn = G.tcrossprod_csr_dense_numeric if B_host.dtype == np.float64 else G.tcrossprod_csr_dense_float32
-    fn(p[:1001], j, x, Yc, 1)
-    ts = []
-    for _ in range(3):
+    lib = _lib.load()
+    out = fn(p, j, x, Yc, 1)                       # first call of the process: allocates the library's grow-only device scratch
+    cold, cached = [], []
+    for k in range(5):
+        del out                                   # (freeing the previous 1 GB result is not part of the next call)
+        if k < 2:
+            lib.mx_cache_invalidate(None)         # CSR not on the device: upload + compute + download
         t0 = time.perf_counter()
         out = fn(p, j, x, Yc, 1)
-        ts.append(time.perf_counter() - t0)
+        (cold if k < 2 else cached).append(time.perf_counter() - t0)
+    ts = [min(cold), min(cached)]
     n = out.shape[1]
     ref = np.zeros(2048 * n, dtype=B_host.dtype)
     O.gemm_csr_drm_as_drm(2048, n, p[:2049], j, x, B_host.reshape(-1), n, ref, n, threads, True)
@@ -473,11 +478,13 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
               float(abs(out[-1].sum() - (x[p[-2]:p[-1]] @ B_host[j[p[-2]:p[-1]]]).sum()) / np.max(np.abs(ref))))
     assert err <= 1e-9, f"export-level SpMM differs from the oracle: {err}"
     res["export_call_end_to_end"] = {
-        "ms_first": round(ts[0] * 1e3, 2), "ms_repeat": round(min(ts[1:]) * 1e3, 2),
-        "GFLOP/s_first": round(2 * nnz * n / ts[0] / 1e9, 1), "GFLOP/s_repeat": round(2 * nnz * n / min(ts[1:]) / 1e9, 1),
+        "ms_cold": round(ts[0] * 1e3, 2), "ms_csr_cached": round(ts[1] * 1e3, 2),
+        "GFLOP/s_cold": round(2 * nnz * n / ts[0] / 1e9, 1), "GFLOP/s_csr_cached": round(2 * nnz * n / ts[1] / 1e9, 1),
         "parity_max_err_over_max_abs_vs_oracle": err,
-        "note": "mx_tcrossprod_csr_dense_* on cfg2: pageable host vectors in, host matrix out (H2D + plan + kernel + "
-                "D2H); repeat = same host CSR again (device-side CSR cache); includes the numpy allocation of the result"}
+        "note": "mx_tcrossprod_csr_dense_* on cfg2: ordinary (pageable) host vectors in, a freshly allocated host matrix "
+                "out; cold = CSR not on the device (upload, compute and download pipelined over row blocks; best of 2), "
+                "csr_cached = the same host vectors again (device-side CSR cache; download-bound: 1 GB over PCIe; best of 3); "
+                "both include the numpy allocation of the result"}
     return res
 
 

@@ -52,8 +52,22 @@ int  mx_dev_memset(void *dptr, int value, size_t bytes, void *stream);
 int  mx_memcpy_h2d(void *dptr, const void *hptr, size_t bytes, void *stream);
 int  mx_memcpy_d2h(void *hptr, const void *dptr, size_t bytes, void *stream);
 int  mx_stream_sync(void *stream);
+/* synchronous copies of ordinary (pageable) caller memory through the library's transfer engine (csrc/xfer.hip: large
+ * buffers are registered and moved by one direct DMA — the destination of a download is first-touched by a team of host
+ * threads; a pipeline over pinned slots when registration fails).  What the export-level calls use. */
+int  mx_upload(void *dptr, const void *hptr, size_t bytes);
+int  mx_download(void *hptr, const void *dptr, size_t bytes);
 int  mx_host_register(void *hptr, size_t bytes);   /* pin caller memory for async H2D/D2H */
 int  mx_host_unregister(void *hptr);
+
+/* Device-side cache of the CSR operands that the export-level calls receive by host address: a later call with the same
+ * three vectors (same addresses, nrows, nnz AND the same sampled fingerprint of their contents) skips the upload.  LRU,
+ * capped at max_bytes (default 8 GiB or MXGPU_CSR_CACHE_MB; 0 disables and empties it).  The library's own in-place
+ * routines invalidate what they rewrite; a caller that mutates a cached operand in place must call mx_cache_invalidate
+ * (host_ptr = any of the operand's three vectors; NULL = everything). */
+int  mx_cache_configure(int64_t max_bytes);
+int  mx_cache_invalidate(const void *host_ptr);
+int  mx_cache_stats(int64_t *bytes, int *entries, int64_t *hits, int64_t *misses);
 
 /* ---- element types --------------------------------------------------------- */
 typedef enum {

@@ -4,10 +4,14 @@
 // CPU fallback: without a usable GPU every call fails with an error.
 #include "mx_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <vector>
 
 namespace mx {
 
@@ -27,6 +31,10 @@ int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t 
 // xfer.hip: synchronous host <-> device copies, pipelined through pinned slots + a host copy pool when large
 int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes);
+void prefault_begin(void *p, size_t bytes);
+void prefault_wait();
+bool pin_host(const void *p, size_t bytes);
+void unpin_host(const void *p);
 
 // MXGPU_TRACE=1: wall-clock phases of an export-level call on stderr
 struct Trace {
@@ -49,14 +57,15 @@ struct Trace {
     }
 };
 
-// owning device buffer
+// device buffer: owning (alloc / upload) or an alias of memory owned elsewhere (the CSR cache)
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    bool own = true;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p && own) (void)hipFree(p); }
     int alloc(size_t n)
     {
         bytes = n;
@@ -64,10 +73,11 @@ struct DevBuf {
         MX_HIP(hipMalloc(&p, n));
         return 0;
     }
+    void alias(void *ptr, size_t n) { p = ptr; bytes = n; own = false; }
     int upload(const void *h, size_t n)
     {
         if (alloc(n)) return 1;
-        if (n && mx::xfer_h2d(p, h, n)) return 1;               // pipelined through pinned slots when large (xfer.hip)
+        if (n && mx::xfer_h2d(p, h, n)) return 1;               // register + direct DMA when large (xfer.hip)
         return 0;
     }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
@@ -78,23 +88,225 @@ static inline size_t dtype_bytes(int dt)
     switch (dt) { case MX_F64: return 8; case MX_F32: case MX_I32: case MX_LGL: return 4; default: return 0; }
 }
 
-struct Csr {
+// ---------------------------------------------------------------------------------------------------------------
+// Device-side cache of CSR operands handed over by host address (SURVEY §7 "PCIe dominates": every .Call of the
+// reference's API passes the same three R vectors again; re-uploading 388 MB costs 8 ms of a 25 ms product).
+// Key: device, the three host addresses, nrows, nnz, value width.  A hit additionally needs the operand's FINGERPRINT
+// to match: lengths + first / last 4 KiB + 64 evenly spaced 512-byte blocks of each array (R vectors are immutable by
+// convention, but MatrixExtra's own in-place routines — sort_sparse_indices(copy = FALSE), reverse_columns_inplace — do
+// rewrite @j / @x in place; the exports of this library that do so invalidate the entry themselves).  A caller that
+// mutates an operand in place in a way the samples miss must call mx_cache_invalidate.  LRU, capped
+// (MXGPU_CSR_CACHE_MB, default 8192; 0 disables; mx_cache_configure at run time).  Entries are shared_ptr-held for the
+// duration of a call, so eviction never pulls memory from under a running export.
+struct CsrDev {
     DevBuf p, j, x;
+    const void *hp = nullptr, *hj = nullptr, *hx = nullptr;
+    int m = 0, device = 0;
     int64_t nnz = 0;
-    // uploads indptr[0..m], indices/values[0..indptr[m]); value_bytes 0 => no values
-    int upload(const int32_t *indptr, const int32_t *indices, const void *values, int m, size_t value_bytes)
+    size_t vb = 0, bytes = 0;
+    uint64_t fp = 0, tick = 0;
+};
+
+static uint64_t fnv_block(uint64_t h, const void *p, size_t n)
+{
+    const unsigned char *c = (const unsigned char *)p;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, c + i, 8); h = (h ^ w) * 0x100000001b3ULL; }
+    for (; i < n; i++) h = (h ^ c[i]) * 0x100000001b3ULL;
+    return h;
+}
+static uint64_t fingerprint_array(uint64_t h, const void *p, size_t bytes)
+{
+    h = fnv_block(h, &bytes, sizeof(bytes));
+    if (!p || bytes == 0) return h;
+    if (bytes <= 64 * 1024) return fnv_block(h, p, bytes);
+    const char *c = (const char *)p;
+    h = fnv_block(h, c, 4096);
+    h = fnv_block(h, c + bytes - 4096, 4096);
+    const size_t step = (bytes - 8192) / 64;
+    for (int i = 0; i < 64; i++) h = fnv_block(h, c + 4096 + (size_t)i * step, 512);
+    return h;
+}
+
+class CsrCache {
+public:
+    static CsrCache &get() { static CsrCache *c = new CsrCache(); return *c; }   // leaked: no HIP calls at exit
+    std::shared_ptr<CsrDev> find(const int32_t *hp, const int32_t *hj, const void *hx, int m, int64_t nnz, size_t vb, uint64_t fp)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu_);
+        for (auto it = items_.begin(); it != items_.end(); ++it) {
+            CsrDev &e = **it;
+            if (e.device == dev && e.hp == hp && e.hj == hj && e.hx == hx && e.m == m && e.nnz == nnz && e.vb == vb) {
+                if (e.fp != fp) { total_ -= e.bytes; items_.erase(it); break; }           // same addresses, new content
+                e.tick = ++clock_;
+                hits_++;
+                return *it;
+            }
+        }
+        misses_++;
+        return nullptr;
+    }
+    void insert(const std::shared_ptr<CsrDev> &e)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (e->bytes > cap_) return;
+        e->tick = ++clock_;
+        items_.push_back(e);
+        total_ += e->bytes;
+        while (total_ > cap_ && !items_.empty()) {                                        // evict least recently used
+            auto lru = items_.begin();
+            for (auto it = items_.begin(); it != items_.end(); ++it) if ((*it)->tick < (*lru)->tick) lru = it;
+            total_ -= (*lru)->bytes;
+            items_.erase(lru);
+        }
+    }
+    void invalidate(const void *host_ptr)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (auto it = items_.begin(); it != items_.end();) {
+            if (!host_ptr || (*it)->hp == host_ptr || (*it)->hj == host_ptr || (*it)->hx == host_ptr) {
+                total_ -= (*it)->bytes;
+                it = items_.erase(it);
+            } else ++it;
+        }
+    }
+    void configure(int64_t max_bytes)
+    {
+        { std::lock_guard<std::mutex> lk(mu_); cap_ = max_bytes > 0 ? (size_t)max_bytes : 0; }
+        if (max_bytes <= 0) invalidate(nullptr);
+    }
+    bool enabled() { std::lock_guard<std::mutex> lk(mu_); return cap_ > 0; }
+    void stats(int64_t *bytes, int *entries, int64_t *hits, int64_t *misses)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (bytes) *bytes = (int64_t)total_;
+        if (entries) *entries = (int)items_.size();
+        if (hits) *hits = hits_;
+        if (misses) *misses = misses_;
+    }
+
+private:
+    CsrCache()
+    {
+        cap_ = (size_t)8192 << 20;
+        if (const char *e = getenv("MXGPU_CSR_CACHE_MB")) cap_ = (size_t)(atoll(e) > 0 ? atoll(e) : 0) << 20;
+    }
+    std::mutex mu_;
+    std::vector<std::shared_ptr<CsrDev>> items_;
+    size_t cap_ = 0, total_ = 0;
+    uint64_t clock_ = 0;
+    int64_t hits_ = 0, misses_ = 0;
+};
+
+struct Csr {
+    DevBuf p, j, x;                          // aliases of `hold`'s buffers
+    std::shared_ptr<CsrDev> hold;
+    int64_t nnz = 0;
+    bool resident = false;                   // indices / values are on the device (false only between prepare() and the
+                                             // caller's own block-wise upload, see spmm_host)
+    // Finds the operand in the cache or allocates device arrays for it (indptr uploaded, indices / values NOT yet):
+    // the caller uploads them — in one go with finish_upload(), or block by block — and then calls publish().
+    int prepare(const int32_t *indptr, const int32_t *indices, const void *values, int m, size_t value_bytes, bool use_cache)
     {
         MX_REQUIRE(m >= 0 && indptr, "CSR upload: bad arguments");
         nnz = indptr[m];
         MX_REQUIRE(nnz >= 0 && indptr[0] >= 0, "CSR upload: negative index pointer");
-        if (p.upload(indptr, sizeof(int32_t) * ((size_t)m + 1))) return 1;
-        if (j.upload(indices, sizeof(int32_t) * (size_t)nnz)) return 1;
-        if (value_bytes && x.upload(values, value_bytes * (size_t)nnz)) return 1;
+        const size_t pb = sizeof(int32_t) * ((size_t)m + 1), jb = sizeof(int32_t) * (size_t)nnz, xb = value_bytes * (size_t)nnz;
+        use_cache = use_cache && pb + jb + xb >= ((size_t)1 << 20) && CsrCache::get().enabled();
+        uint64_t fp = 0;
+        if (use_cache) {
+            fp = fingerprint_array(fingerprint_array(fingerprint_array(0xcbf29ce484222325ULL, indptr, pb), indices, jb),
+                                   value_bytes ? values : nullptr, xb);
+            hold = CsrCache::get().find(indptr, indices, value_bytes ? values : nullptr, m, nnz, value_bytes, fp);
+        }
+        if (hold) {
+            resident = true;
+        } else {
+            hold = std::make_shared<CsrDev>();
+            CsrDev &e = *hold;
+            e.hp = indptr; e.hj = indices; e.hx = value_bytes ? values : nullptr;
+            e.m = m; e.nnz = nnz; e.vb = value_bytes; e.bytes = pb + jb + xb; e.fp = fp;
+            (void)hipGetDevice(&e.device);
+            if (e.p.upload(indptr, pb)) return 1;
+            if (e.j.alloc(jb)) return 1;
+            if (value_bytes && e.x.alloc(xb)) return 1;
+            cacheable = use_cache;
+        }
+        p.alias(hold->p.p, pb); j.alias(hold->j.p, jb); x.alias(hold->x.p, xb);
         return 0;
     }
+    int finish_upload()
+    {
+        if (resident) return 0;
+        if (nnz && mx::xfer_h2d(hold->j.p, hold->hj, sizeof(int32_t) * (size_t)nnz)) return 1;
+        if (hold->vb && nnz && mx::xfer_h2d(hold->x.p, hold->hx, hold->vb * (size_t)nnz)) return 1;
+        publish();
+        return 0;
+    }
+    void publish()
+    {
+        if (!resident && cacheable) CsrCache::get().insert(hold);
+        resident = true;
+    }
+    // uploads indptr[0..m], indices/values[0..indptr[m]) (or finds them in the cache); value_bytes 0 => no values
+    int upload(const int32_t *indptr, const int32_t *indices, const void *values, int m, size_t value_bytes)
+    {
+        if (prepare(indptr, indices, values, m, value_bytes, true)) return 1;
+        return finish_upload();
+    }
+    // a private copy the caller may modify on the device (the in-place exports)
+    int upload_private(const int32_t *indptr, const int32_t *indices, const void *values, int m, size_t value_bytes)
+    {
+        if (prepare(indptr, indices, values, m, value_bytes, false)) return 1;
+        return finish_upload();
+    }
+    bool cacheable = false;
 };
 
-// C(m x n) = A(CSR, m rows) * B(row-major rows of length ldb); host in, host out
+// per-thread streams and events of the export pipeline (upload / compute / download run on their own queues)
+struct Lanes {
+    hipStream_t up = nullptr, run = nullptr, down = nullptr;
+    std::vector<hipEvent_t> ev;
+    int dev = -1;
+    int init(size_t nev)
+    {
+        int d = 0;
+        MX_HIP(hipGetDevice(&d));
+        if (dev != d) {
+            up = run = down = nullptr; ev.clear();               // (streams of another device are left to the runtime)
+            MX_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+            MX_HIP(hipStreamCreateWithFlags(&run, hipStreamNonBlocking));
+            MX_HIP(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+            dev = d;
+        }
+        while (ev.size() < nev) {
+            hipEvent_t e;
+            MX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev.push_back(e);
+        }
+        return 0;
+    }
+    void drain() { if (up) (void)hipStreamSynchronize(up); if (run) (void)hipStreamSynchronize(run); if (down) (void)hipStreamSynchronize(down); }
+};
+static Lanes &lanes() { static thread_local Lanes l; return l; }
+
+// host memory registered for the duration of a scope
+struct Pin {
+    const void *p = nullptr;
+    bool ok = false;
+    bool pin(const void *ptr, size_t bytes) { ok = mx::pin_host(ptr, bytes); p = ptr; return ok; }
+    ~Pin() { if (ok) mx::unpin_host(p); }
+};
+
+// C(m x n) = A(CSR, m rows) * B(row-major rows of length ldb); host in, host out.
+//
+// Large products run as a pipeline over row blocks on three queues: the block's slice of (indices, values) goes up (direct
+// DMA from the caller's registered vectors) while the previous block is multiplied and the one before that comes down
+// (direct DMA into the caller's registered result, whose pages a team of host threads first-touches meanwhile: R has
+// only just allocated it).  PCIe is full duplex, so a cold call costs about max(upload, download) instead of their sum,
+// and a call whose CSR is still on the device (cache above) pays the download only.
 template <typename real_t>
 static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int32_t *indices, const double *values,
                      const real_t *B_host, size_t ldb, real_t *C_host, size_t ldc, size_t c_elems, bool colmajor)
@@ -104,32 +316,155 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     // reference early-out (matmul.cpp:128-129,160-161): result stays the zero-initialised matrix
     if (m == 0 || n == 0 || indptr[0] == indptr[m]) { memset(C_host, 0, c_elems * sizeof(real_t)); return 0; }
     Trace tr("spmm export");
-    Csr A;
-    if (A.upload(indptr, indices, values, m, sizeof(double))) return 1;
-    tr.mark("H2D csr");
-    DevBuf B, C;
-    if (B.upload(B_host, sizeof(real_t) * (size_t)K_rows * ldb)) return 1;
-    tr.mark("H2D dense");
-    if (C.alloc(sizeof(real_t) * c_elems)) return 1;
-    tr.mark("alloc C");
+    const size_t c_bytes = sizeof(real_t) * c_elems, b_bytes = sizeof(real_t) * (size_t)K_rows * ldb;
     const int dt = sizeof(real_t) == 8 ? MX_F64 : MX_F32;
     // kernel choice: AUTO unless the MXGPU_SPMM_ALGO / MXGPU_SPMM_PANELS tuning knobs say otherwise
     int algo = MX_SPMM_AUTO, npanels = 0;
     if (const char *e = getenv("MXGPU_SPMM_ALGO")) algo = atoi(e);
     if (const char *e = getenv("MXGPU_SPMM_PANELS")) npanels = atoi(e);
-    int sorted = 0;
-    if (algo == MX_SPMM_SLAB) {
-        // column panels need rows sorted by column id: one pass over the indices on the device
-        DevBuf flag;
-        if (flag.alloc(16)) return 1;
-        if (mxd_csr_rows_sorted(m, A.p.as<int32_t>(), A.j.as<int32_t>(), flag.as<int32_t>(), &sorted, nullptr)) return 1;
+    static const int pipeline_on = [] { const char *e = getenv("MXGPU_EXPORT_PIPELINE"); return e ? atoi(e) : 1; }();
+    const bool pipelined = pipeline_on && c_bytes >= ((size_t)64 << 20) && m >= 4096 && algo != MX_SPMM_SLAB;
+    Csr A;
+    if (A.prepare(indptr, indices, values, m, sizeof(double), true)) return 1;
+    // column-major result + CSR still on the host: the whole result is first-touched under the upload (see below)
+    if (pipelined && colmajor && !A.resident) mx::prefault_begin(C_host, c_bytes);
+    if (!pipelined) {
+        if (A.finish_upload()) return 1;
+        tr.mark("H2D csr");
+        DevBuf B, C;
+        if (B.upload(B_host, b_bytes)) return 1;
+        tr.mark("H2D dense");
+        if (C.alloc(c_bytes)) return 1;
+        int sorted = 0;
+        if (algo == MX_SPMM_SLAB) {
+            // column panels need rows sorted by column id: one pass over the indices on the device
+            DevBuf flag;
+            if (flag.alloc(16)) return 1;
+            if (mxd_csr_rows_sorted(m, A.p.as<int32_t>(), A.j.as<int32_t>(), flag.as<int32_t>(), &sorted, nullptr)) return 1;
+        }
+        if (mxd_spmm_csr_dense_ex(m, n, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), B.p, ldb, C.p, ldc,
+                                  dt, colmajor ? 1 : 0, algo, sorted, npanels, 0, nullptr)) return 1;
+        if (tr.on) { MX_HIP(hipDeviceSynchronize()); tr.mark("kernels"); }
+        const int rc = mx::xfer_d2h(C_host, C.p, c_bytes);
+        tr.mark("D2H C");
+        return rc;
     }
-    if (mxd_spmm_csr_dense_ex(m, n, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), B.p, ldb, C.p, ldc,
-                              dt, colmajor ? 1 : 0, algo, sorted, npanels, 0, nullptr)) return 1;
-    if (tr.on) { MX_HIP(hipDeviceSynchronize()); tr.mark("kernels"); }
-    const int rc = mx::xfer_d2h(C_host, C.p, sizeof(real_t) * c_elems);
+
+    // ---- pipelined path.  Three shapes, by what is contiguous in the caller's result:
+    //   ROWS (row-major C, dense x CSC / dense x CSR^T): row blocks; a block of C is one contiguous range, so the result is
+    //        first-touched, registered and downloaded block by block;
+    //   COLS (column-major C, CSR already on the device): column blocks of B / C, same incremental scheme — the download
+    //        starts as soon as the first block is computed (~0.5 ms into the call);
+    //   ROWS_STRIDED (column-major C, CSR still on the host): row blocks, so that a block's slice of (indices, values) can
+    //        go up while earlier blocks are multiplied and come down (rows of a column-major matrix are strided: the whole
+    //        result is first-touched — under the upload — and registered before the first block comes down).
+    enum { ROWS, COLS, ROWS_STRIDED } shape = !colmajor ? ROWS : (A.resident ? COLS : ROWS_STRIDED);
+    constexpr int VEC = 16 / (int)sizeof(real_t);
+    const int col_gran = 8 * VEC;                                    // column blocks in whole 128-byte slabs
+    int nblk = (int)std::min<size_t>(16, std::max<size_t>(2, c_bytes / ((size_t)96 << 20)));
+    if (shape == COLS) nblk = std::max(1, std::min(nblk, n / col_gran));
+    Lanes &L = lanes();
+    if (L.init(2 * (size_t)nblk + 2)) return 1;
+    // device B and C from the thread's grow-only scratch (no hipMalloc / hipFree of gigabytes per call)
+    real_t *dB = (real_t *)mx::scratch_buffer(mx::MX_SCRATCH_EXPORT_B, b_bytes);
+    real_t *dC = (real_t *)mx::scratch_buffer(mx::MX_SCRATCH_EXPORT_C, c_bytes);
+    MX_REQUIRE(dB && dC, "spmm export: cannot allocate the device operands");
+    // registrations are declared before `fence`: on every exit the queues drain first, then the memory is unpinned
+    Pin pinB, pinJ, pinX, pinC;
+    std::vector<Pin> pinBlk((size_t)nblk);
+    struct Fence { Lanes &l; ~Fence() { mx::prefault_wait(); l.drain(); } } fence{L};
+    hipEvent_t evB = L.ev[2 * nblk];
+    if (pinB.pin(B_host, b_bytes)) {
+        MX_HIP(hipMemcpyAsync(dB, B_host, b_bytes, hipMemcpyHostToDevice, L.up));
+    } else if (mx::xfer_h2d(dB, B_host, b_bytes)) return 1;
+    MX_HIP(hipEventRecord(evB, L.up));
+    const int64_t nnz = A.nnz;
+    if (!A.resident) {
+        const bool direct_up = pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz) && pinX.pin(values, sizeof(double) * (size_t)nnz);
+        if (!direct_up) { if (A.finish_upload()) return 1; }     // staged, whole arrays; the blocks below then only compute
+    }
+    // block b = rows [cut[b], cut[b+1]) (ROWS, ROWS_STRIDED) or columns (COLS)
+    std::vector<int> cut((size_t)nblk + 1);
+    for (int b = 0; b <= nblk; b++)
+        cut[b] = shape == COLS ? (b == nblk ? n : (int)((int64_t)(n / col_gran) * b / nblk) * col_gran) : (int)((int64_t)m * b / nblk);
+    const bool uploading = !A.resident;
+    if (uploading) {
+        for (int b = 0; b < nblk; b++) {                         // the whole upload is queued up front
+            const int64_t e0 = indptr[cut[b]], e1 = indptr[cut[b + 1]];
+            if (e1 > e0) {
+                MX_HIP(hipMemcpyAsync(A.j.as<int32_t>() + e0, indices + e0, sizeof(int32_t) * (size_t)(e1 - e0),
+                                      hipMemcpyHostToDevice, L.up));
+                MX_HIP(hipMemcpyAsync(A.x.as<double>() + e0, values + e0, sizeof(double) * (size_t)(e1 - e0),
+                                      hipMemcpyHostToDevice, L.up));
+            }
+            MX_HIP(hipEventRecord(L.ev[b], L.up));
+        }
+    }
+    tr.mark("setup");
+    // where block b lives in the caller's result (contiguous shapes) and on the device
+    auto host_block = [&](int b) { return shape == ROWS ? C_host + (size_t)cut[b] * ldc : C_host + (size_t)cut[b] * ldc; };
+    auto block_bytes = [&](int b) { return (size_t)(cut[b + 1] - cut[b]) * ldc * sizeof(real_t); };
+    const bool incremental = shape != ROWS_STRIDED;
+    if (incremental) { mx::prefault_wait(); mx::prefault_begin(host_block(0), block_bytes(0)); }   // (the whole-result touch was not started)
+    // ---- compute: everything is queued before the host waits for anything
+    MX_HIP(hipStreamWaitEvent(L.run, evB, 0));
+    for (int b = 0; b < nblk; b++) {
+        const int c0 = cut[b], c1 = cut[b + 1];
+        if (c1 == c0) continue;
+        if (uploading) MX_HIP(hipStreamWaitEvent(L.run, L.ev[b], 0));
+        int rc = 0;
+        if (shape == COLS) {
+            rc = mxd_spmm_csr_dense_ex(m, c1 - c0, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), dB + c0, ldb,
+                                       dC + (size_t)c0 * ldc, ldc, dt, 1, algo, 0, npanels, 0, L.run);
+        } else {
+            real_t *dCb = colmajor ? dC + c0 : dC + (size_t)c0 * ldc;
+            if (indptr[c0] == indptr[c1]) {                      // a block without entries: zeros (the kernels' early-out)
+                if (colmajor) MX_HIP(hipMemset2DAsync(dCb, ldc * sizeof(real_t), 0, (size_t)(c1 - c0) * sizeof(real_t), n, L.run));
+                else MX_HIP(hipMemsetAsync(dCb, 0, (size_t)(c1 - c0) * ldc * sizeof(real_t), L.run));
+            } else {
+                rc = mxd_spmm_csr_dense_ex(c1 - c0, n, K_rows, A.p.as<int32_t>() + c0, A.j.as<int32_t>(), A.x.as<double>(), dB, ldb,
+                                           dCb, ldc, dt, colmajor ? 1 : 0, algo, 0, npanels, 0, L.run);
+            }
+        }
+        if (rc) return 1;
+        MX_HIP(hipEventRecord(L.ev[nblk + b], L.run));
+    }
+    tr.mark("queued");
+    // ---- download: first-touch (host team) -> register -> direct DMA, block by block where the blocks are contiguous
+    bool direct_down = true;
+    if (incremental) {
+        for (int b = 0; b < nblk && direct_down; b++) {
+            if (cut[b + 1] == cut[b]) continue;
+            mx::prefault_wait();                                 // block b's pages exist
+            if (b + 1 < nblk && cut[b + 2] > cut[b + 1]) mx::prefault_begin(host_block(b + 1), block_bytes(b + 1));
+            if (!pinBlk[b].pin(host_block(b), block_bytes(b))) { direct_down = false; break; }
+            MX_HIP(hipStreamWaitEvent(L.down, L.ev[nblk + b], 0));
+            MX_HIP(hipMemcpyAsync(host_block(b), shape == COLS ? dC + (size_t)cut[b] * ldc : dC + (size_t)cut[b] * ldc,
+                                  block_bytes(b), hipMemcpyDeviceToHost, L.down));
+        }
+    } else {
+        mx::prefault_wait();
+        tr.mark("touched C");
+        direct_down = pinC.pin(C_host, c_bytes);
+        tr.mark("pinned C");
+        for (int b = 0; b < nblk && direct_down; b++) {
+            const int r0 = cut[b], r1 = cut[b + 1];
+            if (r1 == r0) continue;
+            MX_HIP(hipStreamWaitEvent(L.down, L.ev[nblk + b], 0));
+            MX_HIP(hipMemcpy2DAsync(C_host + r0, ldc * sizeof(real_t), dC + r0, ldc * sizeof(real_t),
+                                    (size_t)(r1 - r0) * sizeof(real_t), n, hipMemcpyDeviceToHost, L.down));
+        }
+    }
+    MX_HIP(hipStreamSynchronize(L.run));
+    if (uploading) { MX_HIP(hipStreamSynchronize(L.up)); A.publish(); }
+    tr.mark("kernels");
+    if (direct_down) MX_HIP(hipStreamSynchronize(L.down));
+    else {                                                       // registration failed somewhere: staged copy of the whole result
+        L.drain();
+        if (mx::xfer_d2h(C_host, dC, c_bytes)) return 1;
+    }
     tr.mark("D2H C");
-    return rc;
+    return 0;
 }
 
 template <typename vec_t, typename out_t>
@@ -182,6 +517,13 @@ int mx_device_name(char *buf, size_t buflen)
     snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     return 0;
 }
+int mx_cache_configure(int64_t max_bytes) { CsrCache::get().configure(max_bytes); return 0; }
+int mx_cache_invalidate(const void *host_ptr) { CsrCache::get().invalidate(host_ptr); return 0; }
+int mx_cache_stats(int64_t *bytes, int *entries, int64_t *hits, int64_t *misses)
+{
+    CsrCache::get().stats(bytes, entries, hits, misses);
+    return 0;
+}
 int mx_dev_malloc(void **dptr, size_t bytes) { MX_HIP(hipMalloc(dptr, bytes ? bytes : 16)); return 0; }
 int mx_dev_free(void *dptr) { MX_HIP(hipFree(dptr)); return 0; }
 int mx_dev_memset(void *dptr, int value, size_t bytes, void *stream)
@@ -200,6 +542,8 @@ int mx_memcpy_d2h(void *hptr, const void *dptr, size_t bytes, void *stream)
     return 0;
 }
 int mx_stream_sync(void *stream) { MX_HIP(hipStreamSynchronize(as_stream(stream))); return 0; }
+int mx_upload(void *dptr, const void *hptr, size_t bytes) { return mx::xfer_h2d(dptr, hptr, bytes); }
+int mx_download(void *hptr, const void *dptr, size_t bytes) { return mx::xfer_d2h(hptr, dptr, bytes); }
 int mx_host_register(void *hptr, size_t bytes) { MX_HIP(hipHostRegister(hptr, bytes, hipHostRegisterDefault)); return 0; }
 int mx_host_unregister(void *hptr) { MX_HIP(hipHostUnregister(hptr)); return 0; }
 
@@ -586,8 +930,10 @@ int mx_reverse_columns_inplace(const int32_t *indptr, int nrows, int32_t *indice
     const bool has_values = value_dtype != MX_NONE && n_values > 0 && values;
     const size_t vb = has_values ? dtype_bytes(value_dtype) : 0;
     Csr A;
-    if (A.upload(indptr, indices, values, nrows, vb)) return 1;
+    if (A.upload_private(indptr, indices, values, nrows, vb)) return 1;
     if (A.nnz == 0) return 0;
+    CsrCache::get().invalidate(indices);                          // the host arrays are about to change under any cached copy
+    if (vb) CsrCache::get().invalidate(values);
     if (mxd_csr_reverse_columns(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p,
                                 has_values ? value_dtype : MX_NONE, ncol, nullptr)) return 1;
     if (mx::xfer_d2h(indices, A.j.p, sizeof(int32_t) * (size_t)A.nnz)) return 1;
@@ -829,13 +1175,15 @@ int mx_sort_sparse_indices(const int32_t *indptr, int32_t *indices, void *values
     if (nrows <= 0) return 0;
     const size_t vb = values ? dtype_bytes(value_dtype) : 0;
     Csr A;
-    if (A.upload(indptr, indices, values, nrows, vb)) return 1;
+    if (A.upload_private(indptr, indices, values, nrows, vb)) return 1;
     if (A.nnz < 2) return 0;
     DevBuf flag, tj, tx;
     if (flag.alloc(16)) return 1;
     int sorted = 0;
     if (mxd_csr_rows_sorted(nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), flag.as<int32_t>(), &sorted, nullptr)) return 1;
     if (sorted) return 0;                      // nothing to do, inputs untouched
+    CsrCache::get().invalidate(indices);       // the host arrays are about to change under any cached copy
+    if (vb) CsrCache::get().invalidate(values);
     if (tj.alloc(sizeof(int32_t) * (size_t)A.nnz)) return 1;
     if (vb && tx.alloc(vb * (size_t)A.nnz)) return 1;
     if (mxd_csr_sort_rows(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), vb ? A.x.p : nullptr,

@@ -91,7 +91,7 @@ void plan_count_kernel(int m, int npanels, int panel_cols, const int32_t *__rest
                        unsigned char *__restrict__ layout, int32_t *__restrict__ pstart,
                        long long *__restrict__ ndealt)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *nnz_out = indptr[m];     // rides back with the step total (one copy)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nnz_out = indptr[m] - indptr[0];     // rides back with the step total (a row block of a larger CSR keeps absolute offsets)
     __shared__ int cnt_lds[8][64];                                   // entries per (stream, panel)
     __shared__ int exc_lds[8][64];                                   // start of the panel in the bundle's stream
     __shared__ int totals[8];

@@ -1,13 +1,19 @@
 // Host <-> device transfers for the export-level calls (the R boundary hands over ordinary pageable vectors and
 // expects ordinary vectors back: INTEGRATION.md §5).
 //
-// hipMemcpy on pageable memory stages through the runtime's own bounce buffer with one CPU thread doing the
-// host-side copy, and the result matrix R (or numpy) just allocated has never been touched, so that thread also
-// takes a page fault per 4 KiB: 1 GB of C came back at ~10-14 GB/s.  Here large transfers run as a pipeline over
-// three pinned 8 MiB slots: the DMA engine moves slot k+1 while a small pool of host threads copies slot k to /
-// from the caller's buffer (page faults and memcpy spread over the pool).  Synchronous at return, like hipMemcpy.
+// Measured on the MI355X boxes (tools/host_xfer_probe.py): hipHostRegister of memory whose pages EXIST costs ~2 ms per
+// GB (0.9 ms for the 388 MB of the headline CSR) and a copy to / from registered memory is one DMA at the PCIe rate with
+// no CPU copy; registering FRESH memory (the result matrix R has just allocated and never touched) costs 43 ms per GB —
+// the page faults, taken by one thread.  So large transfers
+//   * H2D: register the caller's buffer, one direct DMA, unregister;
+//   * D2H: first-touch the destination with a pool of host threads (prefault_begin: started by the export as soon as it
+//     knows the result's address, i.e. it runs under the uploads and the kernels), then register + direct DMA.
+// Should registration fail (locked-memory limit, exotic mappings) the previous scheme takes over: a pipeline over three
+// pinned 8 MiB slots in which the DMA engine moves one slot while the pool copies the previous one to / from the
+// caller's buffer.  MXGPU_XFER=0: plain hipMemcpy; MXGPU_XFER=2: always the staged pipeline.  Synchronous at return.
 #include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -18,13 +24,14 @@ namespace mx {
 
 namespace {
 
-class CopyPool {
+// a fixed team of host threads; run(job) hands every worker (id, n) and returns at once, wait() joins the job
+class Pool {
 public:
-    explicit CopyPool(int n) : n_(n)
+    explicit Pool(int n) : n_(n)
     {
         for (int i = 0; i < n_; i++) th_.emplace_back([this, i] { loop(i); });
     }
-    ~CopyPool()
+    ~Pool()
     {
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -33,17 +40,44 @@ public:
         cv_.notify_all();
         for (auto &t : th_) t.join();
     }
-    // dst[0..n) = src[0..n), split over the pool in page-aligned pieces; returns when all pieces are done
-    void copy(void *dst, const void *src, size_t n)
+    void run(std::function<void(int, int)> job)
     {
-        if (n < ((size_t)1 << 20) || n_ <= 1) { memcpy(dst, src, n); return; }
-        std::unique_lock<std::mutex> lk(mu_);
-        dst_ = (char *)dst; src_ = (const char *)src; bytes_ = n;
-        piece_ = ((n + n_ - 1) / n_ + 4095) & ~(size_t)4095;
+        wait();
+        std::lock_guard<std::mutex> lk(mu_);
+        job_ = std::move(job);
         pending_ = n_;
         gen_++;
         cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
         done_.wait(lk, [this] { return pending_ == 0; });
+    }
+    // dst[0..n) = src[0..n), split over the team in page-aligned pieces
+    void copy(void *dst, const void *src, size_t n)
+    {
+        if (n < ((size_t)1 << 20) || n_ <= 1) { wait(); memcpy(dst, src, n); return; }
+        const size_t piece = ((n + n_ - 1) / n_ + 4095) & ~(size_t)4095;
+        run([=](int id, int) {
+            const size_t off = piece * (size_t)id;
+            if (off < n) memcpy((char *)dst + off, (const char *)src + off, n - off < piece ? n - off : piece);
+        });
+        wait();
+    }
+    // write-touch every page of [p, p + n) (contents kept): the first-touch faults of a fresh allocation, spread over
+    // the team.  Returns at once.
+    void touch(void *p, size_t n)
+    {
+        const size_t piece = ((n + n_ - 1) / n_ + 4095) & ~(size_t)4095;
+        run([=](int id, int) {
+            const size_t off = piece * (size_t)id;
+            if (off >= n) return;
+            const size_t len = n - off < piece ? n - off : piece;
+            volatile char *q = (volatile char *)p + off;
+            for (size_t i = 0; i < len; i += 4096) q[i] = q[i];
+            q[len - 1] = q[len - 1];
+        });
     }
     int threads() const { return n_; }
 
@@ -52,20 +86,18 @@ private:
     {
         unsigned long seen = 0;
         for (;;) {
-            char *d; const char *s; size_t off, len;
+            std::function<void(int, int)> job;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
                 if (stop_) return;
                 seen = gen_;
-                off = piece_ * (size_t)id;
-                len = off < bytes_ ? (bytes_ - off < piece_ ? bytes_ - off : piece_) : 0;
-                d = dst_ + off; s = src_ + off;
+                job = job_;
             }
-            if (len) memcpy(d, s, len);
+            job(id, n_);
             {
                 std::lock_guard<std::mutex> lk(mu_);
-                if (--pending_ == 0) done_.notify_one();
+                if (--pending_ == 0) done_.notify_all();
             }
         }
     }
@@ -76,28 +108,40 @@ private:
     bool stop_ = false;
     unsigned long gen_ = 0;
     int pending_ = 0;
-    char *dst_ = nullptr;
-    const char *src_ = nullptr;
-    size_t bytes_ = 0, piece_ = 0;
+    std::function<void(int, int)> job_;
 };
 
 constexpr int XF_SLOTS = 3;
 constexpr size_t XF_CHUNK = (size_t)8 << 20;
 constexpr size_t XF_MIN = (size_t)16 << 20;           // below this a plain hipMemcpy is as good
 
+int xfer_mode()
+{
+    static const int m = [] { const char *e = getenv("MXGPU_XFER"); return e ? atoi(e) : 1; }();
+    return m;                                          // 0 plain hipMemcpy, 1 register + direct DMA (default), 2 staged pipeline
+}
+
 struct Engine {
-    std::mutex mu;                                    // one transfer at a time (the exports are synchronous anyway)
-    CopyPool *pool = nullptr;
+    std::mutex mu;                                    // one staged transfer at a time (the exports are synchronous anyway)
+    Pool *pool = nullptr;
     void *slot[XF_SLOTS] = {};
     hipEvent_t ev[XF_SLOTS] = {};
     hipStream_t st = nullptr;
     int dev = -1;
     bool ok = false;
 
+    Pool *team()
+    {
+        if (!pool) {
+            unsigned hw = std::thread::hardware_concurrency();
+            int n = hw >= 32 ? 16 : (hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1));   // (the GPU boxes grant 16 CPUs' worth of time)
+            if (const char *e = getenv("MXGPU_COPY_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n = v; }
+            pool = new Pool(n);
+        }
+        return pool;
+    }
     bool init()
     {
-        static const bool disabled = [] { const char *e = getenv("MXGPU_XFER"); return e && atoi(e) == 0; }();
-        if (disabled) return false;                    // MXGPU_XFER=0: plain hipMemcpy (for comparison)
         int d = 0;
         if (hipGetDevice(&d) != hipSuccess) return false;
         if (ok && d == dev) return true;
@@ -107,12 +151,7 @@ struct Engine {
             if (hipHostMalloc(&slot[i], XF_CHUNK, hipHostMallocDefault) != hipSuccess) { slot[i] = nullptr; release_device(); return false; }
             if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { ev[i] = nullptr; release_device(); return false; }
         }
-        if (!pool) {
-            unsigned hw = std::thread::hardware_concurrency();
-            int n = hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1);
-            if (const char *e = getenv("MXGPU_COPY_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n = v; }
-            pool = new CopyPool(n);
-        }
+        team();
         dev = d;
         ok = true;
         return true;
@@ -134,16 +173,8 @@ Engine &engine()
     return *e;
 }
 
-}  // namespace
-
-// Everything previously enqueued on the null stream (kernels of the export that produced `src`) is complete before
-// the first chunk moves: callers synchronise the null stream, as hipMemcpy would.
-int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes)
+int staged_d2h(Engine &e, void *dst_host, const void *src_dev, size_t bytes)
 {
-    if (bytes == 0) return 0;
-    Engine &e = engine();
-    std::lock_guard<std::mutex> lk(e.mu);
-    if (bytes < XF_MIN || !e.init()) { MX_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); return 0; }
     MX_HIP(hipStreamSynchronize(nullptr));
     const size_t nch = (bytes + XF_CHUNK - 1) / XF_CHUNK;
     auto len_of = [&](size_t c) { return c + 1 < nch ? XF_CHUNK : bytes - c * XF_CHUNK; };
@@ -163,12 +194,8 @@ int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes)
     return 0;
 }
 
-int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes)
+int staged_h2d(Engine &e, void *dst_dev, const void *src_host, size_t bytes)
 {
-    if (bytes == 0) return 0;
-    Engine &e = engine();
-    std::lock_guard<std::mutex> lk(e.mu);
-    if (bytes < XF_MIN || !e.init()) { MX_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return 0; }
     const size_t nch = (bytes + XF_CHUNK - 1) / XF_CHUNK;
     for (size_t c = 0; c < nch; c++) {
         const int s = (int)(c % XF_SLOTS);
@@ -180,6 +207,78 @@ int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes)
     }
     MX_HIP(hipStreamSynchronize(e.st));
     return 0;
+}
+
+}  // namespace
+
+// ---- caller memory: first-touch, registration ----------------------------------------------------------------
+// Starts write-touching every page of [p, p + bytes) on the host team and returns; prefault_wait() joins.  For the
+// destination of a large D2H copy that the caller has just allocated: call it as early as the address is known.
+void prefault_begin(void *p, size_t bytes)
+{
+    if (!p || bytes < XF_MIN || xfer_mode() != 1) return;
+    Engine &e = engine();
+    std::lock_guard<std::mutex> lk(e.mu);
+    e.team()->touch(p, bytes);
+}
+void prefault_wait()
+{
+    Engine &e = engine();
+    std::lock_guard<std::mutex> lk(e.mu);
+    if (e.pool) e.pool->wait();
+}
+// hipHostRegister / hipHostUnregister of caller memory; false (and no error state left behind) when it cannot be pinned
+bool pin_host(const void *p, size_t bytes)
+{
+    if (!p || bytes == 0 || xfer_mode() != 1) return false;
+    if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+void unpin_host(const void *p)
+{
+    if (p && hipHostUnregister(const_cast<void *>(p)) != hipSuccess) (void)hipGetLastError();
+}
+
+// Everything previously enqueued on the null stream (kernels of the export that produced `src`) is complete before
+// the first byte moves, as with hipMemcpy.
+int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    if (bytes < XF_MIN || xfer_mode() == 0) { MX_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); return 0; }
+    Engine &e = engine();
+    if (xfer_mode() == 1) {
+        {
+            std::lock_guard<std::mutex> lk(e.mu);
+            e.team()->touch(dst_host, bytes);          // (a no-op pass when prefault_begin already did it)
+            e.pool->wait();
+        }
+        if (pin_host(dst_host, bytes)) {
+            const hipError_t rc = hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost);
+            unpin_host(dst_host);
+            MX_HIP(rc);
+            return 0;
+        }
+    }
+    std::lock_guard<std::mutex> lk(e.mu);
+    if (!e.init()) { MX_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); return 0; }
+    return staged_d2h(e, dst_host, src_dev, bytes);
+}
+
+int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    if (bytes < XF_MIN || xfer_mode() == 0) { MX_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return 0; }
+    if (xfer_mode() == 1 && pin_host(src_host, bytes)) {
+        const hipError_t rc = hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice);
+        unpin_host(src_host);
+        MX_HIP(rc);
+        return 0;
+    }
+    Engine &e = engine();
+    std::lock_guard<std::mutex> lk(e.mu);
+    if (!e.init()) { MX_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return 0; }
+    return staged_h2d(e, dst_dev, src_host, bytes);
 }
 
 }  // namespace mx

@@ -1,0 +1,124 @@
+"""The export-level boundary at full size (what one .Call from R goes through): the transfer engine (csrc/xfer.hip), the
+device-side CSR cache and the row-block pipeline of the SpMM exports (csrc/api.hip)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from matrixextra_amd import _lib, synth
+from matrixextra_amd import exports as G
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _roundtrip(nbytes, seed):
+    lib = _lib.load()
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+    d = C.c_void_p()
+    _lib.check(lib.mx_dev_malloc(C.byref(d), C.c_size_t(nbytes)))
+    try:
+        _lib.check(lib.mx_upload(d, C.c_void_p(src.ctypes.data), C.c_size_t(nbytes)))
+        dst = np.empty(nbytes, dtype=np.uint8)                       # fresh, untouched pages: the case of an R result
+        _lib.check(lib.mx_download(C.c_void_p(dst.ctypes.data), d, C.c_size_t(nbytes)))
+        assert np.array_equal(src, dst)
+        dst2 = np.zeros(nbytes + 4096, dtype=np.uint8)[37:37 + nbytes]  # touched, odd alignment
+        _lib.check(lib.mx_download(C.c_void_p(dst2.ctypes.data), d, C.c_size_t(nbytes)))
+        assert np.array_equal(src, dst2)
+    finally:
+        lib.mx_dev_free(d)
+
+
+def test_transfer_engine_moves_large_buffers_both_ways(gpu):
+    # >= 64 MiB each way (above the 16 MiB threshold: register + direct DMA), odd sizes, and just below the threshold
+    for nbytes, seed in ((96 << 20, 1), ((64 << 20) + 12345, 2), ((16 << 20) - 1, 3), (300 << 20, 4)):
+        _roundtrip(nbytes, seed)
+
+
+def test_transfer_engine_staged_fallback(gpu):
+    # MXGPU_XFER=2 forces the pipeline over pinned slots (what runs when the caller's memory cannot be registered)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_gpu_export_path import _roundtrip\n_roundtrip((80 << 20) + 777, 5); print('ok')") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MXGPU_XFER="2"), capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def _check_product(out, p, j, x, B, rows=(0, 333_333, -700)):
+    """sampled row blocks bitwise-close to the oracle + the column checksum 1^T C = (A^T 1)^T B"""
+    m, n = out.shape
+    for r0 in rows:
+        r0 = r0 % m
+        r1 = min(m, r0 + 512)
+        ref = np.zeros((r1 - r0) * n, dtype=B.dtype)
+        pp = (p[r0:r1 + 1] - p[r0]).astype(np.int32)
+        O.gemm_csr_drm_as_drm(r1 - r0, n, pp, j[p[r0]:p[r1]].copy(), x[p[r0]:p[r1]].copy(), B.reshape(-1), n, ref, n, 4, True)
+        tol = 1e-12 if B.dtype == np.float64 else 1e-5
+        np.testing.assert_allclose(out[r0:r1], ref.reshape(r1 - r0, n), rtol=tol, atol=tol * np.abs(ref).max())
+    w = np.bincount(j, weights=x, minlength=B.shape[0])
+    scale = np.abs(x).sum() * np.abs(B).max()
+    assert np.max(np.abs(out.sum(axis=0, dtype=np.float64) - w @ B.astype(np.float64))) <= (1e-12 if B.dtype == np.float64 else 1e-8) * scale
+
+
+def test_export_spmm_cfg2_pipeline_and_cache(gpu):
+    lib = _lib.load()
+    m, K, n = 1_000_000, 100_000, 128
+    p, j, x = synth.csr_fixed(m, K, 32)
+    B = synth.dense_normal(K, n)
+    Y = np.asfortranarray(B.T)
+    lib.mx_cache_invalidate(None)
+    st0 = _cache_stats(lib)
+    out1 = G.tcrossprod_csr_dense_numeric(p, j, x, Y, 1)             # cold: upload pipelined with compute and download
+    _check_product(out1, p, j, x, B)
+    st1 = _cache_stats(lib)
+    assert st1["entries"] == st0["entries"] + 1 and st1["bytes"] >= p.nbytes + j.nbytes + x.nbytes
+    out2 = G.tcrossprod_csr_dense_numeric(p, j, x, Y, 1)             # same host vectors again: CSR served from the device
+    st2 = _cache_stats(lib)
+    assert st2["hits"] == st1["hits"] + 1
+    np.testing.assert_array_equal(out1, out2)
+    # the same vectors rewritten in place: the fingerprint no longer matches, the stale copy must not be used
+    x *= 2.0
+    out3 = G.tcrossprod_csr_dense_numeric(p, j, x, Y, 1)
+    np.testing.assert_array_equal(out3, 2.0 * out1)
+    # row-major result (dense %*% CSC): C^T = A B^T with the CSC read as CSR of the transpose
+    X = np.asfortranarray(B.T[:64])                                  # 64 x 100k dense, Y = CSC 100k x 1M  ->  64 x 1M
+    out4 = G.matmul_dense_csc_numeric(X, p, j, x, 1)
+    ref_rows = out3[:, :64]                                          # same product, transposed layout
+    np.testing.assert_allclose(out4.T, ref_rows, rtol=1e-12, atol=1e-12 * np.abs(ref_rows).max())
+    # explicit invalidation and switching the cache off
+    lib.mx_cache_invalidate(C.c_void_p(x.ctypes.data))
+    assert _cache_stats(lib)["entries"] == 0
+    lib.mx_cache_configure(C.c_int64(0))
+    out5 = G.tcrossprod_csr_dense_numeric(p, j, x, Y, 1)
+    assert _cache_stats(lib)["entries"] == 0
+    np.testing.assert_array_equal(out5, out3)
+    lib.mx_cache_configure(C.c_int64(8192 << 20))
+
+
+def test_export_spmm_float32_and_blocks_without_entries(gpu):
+    # f32 dense operand through the pipeline; the first half of the rows has no entries at all (a block that is only
+    # zero-filled) and the last rows are empty too
+    m, K, n = 600_000, 50_000, 128
+    lens = np.zeros(m, dtype=np.int64)
+    lens[320_000:590_000] = 24
+    p = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(lens, out=p[1:])
+    p = p.astype(np.int32)
+    rng = np.random.default_rng(3)
+    j = rng.integers(0, K, size=int(p[-1]), dtype=np.int32)
+    x = rng.normal(size=int(p[-1]))
+    B = synth.dense_normal(K, n, dtype=np.float32)
+    out = G.tcrossprod_csr_dense_float32(p, j, x, np.asfortranarray(B.T), 1)
+    assert out.dtype == np.float32 and out.shape == (m, n)
+    assert not out[:320_000].any() and not out[590_000:].any()
+    _check_product(out, p, j, x, B, rows=(319_900, 450_000, 589_800))
+
+
+def _cache_stats(lib):
+    b, e, h, mi = C.c_int64(0), C.c_int(0), C.c_int64(0), C.c_int64(0)
+    lib.mx_cache_stats(C.byref(b), C.byref(e), C.byref(h), C.byref(mi))
+    return dict(bytes=b.value, entries=e.value, hits=h.value, misses=mi.value)

@@ -4,7 +4,7 @@
 ### exactly as they are: `%*%`, `tcrossprod`, `+`, `-`, `*`, `&`, `|`, `[` on dgRMatrix objects dispatch
 ### unchanged.  The glue reaches native code only through the one-line wrappers of R/RcppExports.R
 ### (e.g. :148-150 `tcrossprod_csr_dense_numeric <- function(...) .Call(`_MatrixExtra_tcrossprod_csr_dense_numeric`, ...)`).
-### This overlay rebinds those 19 wrappers inside the MatrixExtra namespace so that they `.Call` the routines of
+### This overlay rebinds the wrappers of the hot path and of its neighbours (SURVEY section 8f) inside the MatrixExtra namespace so that they `.Call` the routines of
 ### the same names registered by mxgpu_r.so (matrixextra_amd/csrc/r_shim.cpp), which forward to libmxgpu.so.
 ### Every other native routine (~140 of them) keeps pointing at MatrixExtra's own CPU code.
 ###
@@ -32,8 +32,18 @@
     "copy_csr_arbitrary_numeric", "copy_csr_arbitrary_logical", "copy_csr_arbitrary_binary",
     "reverse_rows_numeric", "reverse_rows_logical", "reverse_rows_binary",
     "reverse_columns_inplace_numeric", "reverse_columns_inplace_logical", "reverse_columns_inplace_binary",
-    ## rank 4: values-only CSR (op) vector
-    "multiply_csr_by_dvec_no_NAs_numeric", "logicaland_csr_by_dvec_internal"
+    ## rank 4: values-only CSR (op) vector, CSR x sparse vector, CSR (.) dense
+    "multiply_csr_by_dvec_no_NAs_numeric", "logicaland_csr_by_dvec_internal",
+    "matmul_csr_svec_numeric", "matmul_csr_svec_integer", "matmul_csr_svec_logical", "matmul_csr_svec_binary",
+    "matmul_csr_svec_float32",
+    "multiply_csr_by_dense_elemwise_double", "multiply_csr_by_dense_elemwise_float32",
+    "multiply_csr_by_dense_elemwise_int", "multiply_csr_by_dense_elemwise_bool", "logicaland_csr_by_dense_cpp",
+    ## rank 3: cbind / rbind
+    "cbind_csr_numeric", "cbind_csr_logical", "cbind_csr_binary", "concat_csr_batch",
+    ## rank 1: sortedness check and in-place sort (run before every CSR (+) CSR, R/operators.R:58,64,748,754)
+    "check_indices_are_unsorted",
+    "sort_sparse_indices_numeric", "sort_sparse_indices_logical", "sort_sparse_indices_numeric_known_ncol",
+    "sort_sparse_indices_logical_known_ncol", "sort_sparse_indices_binary"
 )
 
 mxgpu_enable <- function(shim_path, min_nnz = 0L) {

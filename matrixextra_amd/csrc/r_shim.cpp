@@ -1,6 +1,7 @@
 // r_shim.cpp — thin `.Call` translation unit between R and libmxgpu's C-ABI.
 //
-// Exports, for the 19 hot-path routines (+ 12 column-slice / reversal routines of SURVEY §8f rank 2), exactly the native-routine names and arities that the
+// Exports, for the 19 hot-path routines and the §8(f) routines (column slices / reversals, cbind / rbind, CSR x sparse
+// vector, CSR (.) dense, CSR op vector, sortedness check / in-place sort), exactly the native-routine names and arities that the
 // reference registers in CallEntries[] (src/RcppExports.cpp:2233-2242, 2290-2291, 2297-2298, 2333-2334,
 // 2341-2343), so R code written as `.Call("_MatrixExtra_<fn>", ...)` (R/RcppExports.R) dispatches
 // unchanged, plus mxgpu_register() to add them to a DllInfo.  Written against the plain R C API
@@ -386,6 +387,157 @@ SEXP _MatrixExtra_logicaland_csr_by_dvec_internal(SEXP p_, SEXP j_, SEXP x_, SEX
     return out;
 }
 
+// ---- cbind / rbind (§8f rank 3): src/cbind.cpp:101-157, src/rbind.cpp:23-173 ---------------------------------------------
+static SEXP cbind(SEXP Xp, SEXP Xj, SEXP Xx, SEXP Yp, SEXP Yj, SEXP Yx, int dtype)
+{
+    Protect p;
+    Xp = as_type(Xp, INTSXP, p); Xj = as_type(Xj, INTSXP, p); Yp = as_type(Yp, INTSXP, p); Yj = as_type(Yj, INTSXP, p);
+    const void *vx = nullptr, *vy = nullptr;
+    int64_t nvx = 0, nvy = 0;
+    if (dtype == MX_F64) {
+        Xx = as_type(Xx, REALSXP, p); Yx = as_type(Yx, REALSXP, p);
+        vx = REAL(Xx); vy = REAL(Yx); nvx = XLENGTH(Xx); nvy = XLENGTH(Yx);
+    } else if (dtype == MX_LGL) {
+        Xx = as_type(Xx, LGLSXP, p); Yx = as_type(Yx, LGLSXP, p);
+        vx = LOGICAL(Xx); vy = LOGICAL(Yx); nvx = XLENGTH(Xx); nvy = XLENGTH(Yx);
+    }
+    mx_result *res = nullptr;
+    mx_result_info info;
+    if (mx_cbind_csr_begin(INTEGER(Xp), (int)XLENGTH(Xp) - 1, INTEGER(Xj), vx, nvx, INTEGER(Yp), (int)XLENGTH(Yp) - 1,
+                           INTEGER(Yj), vy, nvy, dtype, &res, &info))
+        fail();
+    return finish_guarded(res, info, R_NilValue, R_NilValue);
+}
+SEXP _MatrixExtra_cbind_csr_numeric(SEXP Xp, SEXP Xj, SEXP Xx, SEXP Yp, SEXP Yj, SEXP Yx) { return cbind(Xp, Xj, Xx, Yp, Yj, Yx, MX_F64); }
+SEXP _MatrixExtra_cbind_csr_logical(SEXP Xp, SEXP Xj, SEXP Xx, SEXP Yp, SEXP Yj, SEXP Yx) { return cbind(Xp, Xj, Xx, Yp, Yj, Yx, MX_LGL); }
+SEXP _MatrixExtra_cbind_csr_binary(SEXP Xp, SEXP Xj, SEXP Yp, SEXP Yj) { return cbind(Xp, Xj, R_NilValue, Yp, Yj, R_NilValue, MX_NONE); }
+
+// concat_csr_batch(objects, out): `out` is a dgRMatrix / lgRMatrix / ngRMatrix whose slots the R caller has sized
+// (R/rbind.R:79-97); they are filled in place and `out` is returned, as the reference does (rbind.cpp:35-38,171)
+SEXP _MatrixExtra_concat_csr_batch(SEXP objects, SEXP out)
+{
+    if (TYPEOF(objects) != VECSXP) Rf_error("concat_csr_batch: a list of matrices / sparse vectors is required");
+    const int n_inputs = (int)XLENGTH(objects);
+    const int out_kind = Rf_inherits(out, "ngRMatrix") ? 2 : (Rf_inherits(out, "lgRMatrix") ? 1 : 0);
+    mx_rbind_input *in = (mx_rbind_input *)R_alloc((size_t)(n_inputs > 0 ? n_inputs : 1), sizeof(mx_rbind_input));
+    for (int k = 0; k < n_inputs; k++) {
+        SEXP o = VECTOR_ELT(objects, k);
+        mx_rbind_input &d = in[k];
+        d.indptr = nullptr; d.values = nullptr; d.nrows = 1;
+        if (R_has_slot(o, Rf_install("j"))) {                     // a CSR matrix (rbind.cpp:53)
+            d.indptr = INTEGER(R_do_slot(o, Rf_install("p")));
+            SEXP j = R_do_slot(o, Rf_install("j"));
+            d.indices = INTEGER(j);
+            d.nnz = (int64_t)XLENGTH(j);
+            d.nrows = INTEGER(R_do_slot(o, Rf_install("Dim")))[0];
+            if (Rf_inherits(o, "dgRMatrix")) { d.kind = 0; d.values = REAL(R_do_slot(o, Rf_install("x"))); }
+            else if (Rf_inherits(o, "lgRMatrix")) { d.kind = 1; d.values = LOGICAL(R_do_slot(o, Rf_install("x"))); }
+            else d.kind = 2;
+        } else {                                                 // a sparse vector: one row, 1-based @i (rbind.cpp:99-104)
+            SEXP i = R_do_slot(o, Rf_install("i"));
+            d.indices = INTEGER(i);
+            d.nnz = (int64_t)XLENGTH(i);
+            if (Rf_inherits(o, "dsparseVector")) { d.kind = 3; d.values = REAL(R_do_slot(o, Rf_install("x"))); }
+            else if (Rf_inherits(o, "isparseVector")) { d.kind = 4; d.values = INTEGER(R_do_slot(o, Rf_install("x"))); }
+            else if (Rf_inherits(o, "lsparseVector")) { d.kind = 5; d.values = LOGICAL(R_do_slot(o, Rf_install("x"))); }
+            else if (Rf_inherits(o, "nsparseVector")) d.kind = 6;
+            else Rf_error("Invalid vector type in argument %d.\n", k);     // rbind.cpp:131-135
+        }
+    }
+    mx_result *res = nullptr;
+    mx_result_info info;
+    if (mx_concat_csr_batch_begin(in, n_inputs, out_kind, &res, &info)) fail();
+    SEXP op = R_do_slot(out, Rf_install("p")), oj = R_do_slot(out, Rf_install("j"));
+    SEXP ox = out_kind == 2 ? R_NilValue : R_do_slot(out, Rf_install("x"));
+    if ((int64_t)XLENGTH(op) < info.indptr_len || (int64_t)XLENGTH(oj) < info.nnz ||
+        (out_kind != 2 && (int64_t)XLENGTH(ox) < info.values_len)) {
+        mx_result_discard(res);
+        Rf_error("concat_csr_batch: the slots of `out` are shorter than the result");
+    }
+    void *vx = out_kind == 0 ? (void *)REAL(ox) : (out_kind == 1 ? (void *)LOGICAL(ox) : nullptr);
+    if (mx_result_finish(res, INTEGER(op), INTEGER(oj), vx)) fail();
+    return out;
+}
+
+// ---- CSR x sparse vector, CSR (.) dense (§8f rank 4): src/matmul.cpp:555-641, src/operators.cpp:289-334 --------------------
+static SEXP csr_svec(SEXP p_, SEXP j_, SEXP x_, SEXP yi, SEXP yv, SEXP nthreads, int kind)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); x_ = as_type(x_, REALSXP, p); yi = as_type(yi, INTSXP, p);
+    const void *v = nullptr;
+    if (kind == 0) { yv = as_type(yv, REALSXP, p); v = REAL(yv); }
+    else if (kind == 1 || kind == 4) { yv = as_type(yv, INTSXP, p); v = INTEGER(yv); }     // float32: bits in an INTSXP
+    else if (kind == 2) { yv = as_type(yv, LGLSXP, p); v = LOGICAL(yv); }
+    const int m = (int)XLENGTH(p_) - 1;
+    SEXP out = p(Rf_allocVector(REALSXP, m));
+    if (mx_matmul_csr_svec(INTEGER(p_), INTEGER(j_), REAL(x_), m, INTEGER(yi), (int64_t)XLENGTH(yi), v, kind,
+                           Rf_asInteger(nthreads), REAL(out)))
+        fail();
+    return out;
+}
+SEXP _MatrixExtra_matmul_csr_svec_numeric(SEXP p_, SEXP j_, SEXP x_, SEXP yi, SEXP yv, SEXP nt) { return csr_svec(p_, j_, x_, yi, yv, nt, 0); }
+SEXP _MatrixExtra_matmul_csr_svec_integer(SEXP p_, SEXP j_, SEXP x_, SEXP yi, SEXP yv, SEXP nt) { return csr_svec(p_, j_, x_, yi, yv, nt, 1); }
+SEXP _MatrixExtra_matmul_csr_svec_logical(SEXP p_, SEXP j_, SEXP x_, SEXP yi, SEXP yv, SEXP nt) { return csr_svec(p_, j_, x_, yi, yv, nt, 2); }
+SEXP _MatrixExtra_matmul_csr_svec_binary(SEXP p_, SEXP j_, SEXP x_, SEXP yi, SEXP nt) { return csr_svec(p_, j_, x_, yi, R_NilValue, nt, 3); }
+SEXP _MatrixExtra_matmul_csr_svec_float32(SEXP p_, SEXP j_, SEXP x_, SEXP yi, SEXP yv, SEXP nt) { return csr_svec(p_, j_, x_, yi, yv, nt, 4); }
+
+// dense_mat arrives as the matrix itself (its length / nrow gives the column count, operators.cpp:246-248)
+static SEXP csr_by_dense(SEXP p_, SEXP j_, SEXP x_, SEXP dense, int kind)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p);
+    const int m = (int)XLENGTH(p_) - 1;
+    const void *v, *d;
+    SEXP out;
+    if (kind == 4) {                                              // logicaland_csr_by_dense_cpp: logical values in / out
+        x_ = as_type(x_, LGLSXP, p); dense = as_type(dense, LGLSXP, p);
+        v = LOGICAL(x_); d = LOGICAL(dense);
+        out = p(Rf_allocVector(LGLSXP, XLENGTH(x_)));
+    } else {
+        x_ = as_type(x_, REALSXP, p);
+        v = REAL(x_);
+        if (kind == 0) { dense = as_type(dense, REALSXP, p); d = REAL(dense); }
+        else if (kind == 3) { dense = as_type(dense, LGLSXP, p); d = LOGICAL(dense); }
+        else { dense = as_type(dense, INTSXP, p); d = INTEGER(dense); }                    // float32 bits / integer
+        out = p(Rf_allocVector(REALSXP, XLENGTH(x_)));
+    }
+    const int64_t ncols = m > 0 ? (int64_t)(XLENGTH(dense) / m) : 0;
+    void *o = kind == 4 ? (void *)LOGICAL(out) : (void *)REAL(out);
+    if (mx_multiply_csr_by_dense_elemwise(INTEGER(p_), INTEGER(j_), v, m, d, ncols, kind, o)) fail();
+    return out;
+}
+SEXP _MatrixExtra_multiply_csr_by_dense_elemwise_double(SEXP p_, SEXP j_, SEXP x_, SEXP d) { return csr_by_dense(p_, j_, x_, d, 0); }
+SEXP _MatrixExtra_multiply_csr_by_dense_elemwise_float32(SEXP p_, SEXP j_, SEXP x_, SEXP d) { return csr_by_dense(p_, j_, x_, d, 1); }
+SEXP _MatrixExtra_multiply_csr_by_dense_elemwise_int(SEXP p_, SEXP j_, SEXP x_, SEXP d) { return csr_by_dense(p_, j_, x_, d, 2); }
+SEXP _MatrixExtra_multiply_csr_by_dense_elemwise_bool(SEXP p_, SEXP j_, SEXP x_, SEXP d) { return csr_by_dense(p_, j_, x_, d, 3); }
+SEXP _MatrixExtra_logicaland_csr_by_dense_cpp(SEXP p_, SEXP j_, SEXP x_, SEXP d) { return csr_by_dense(p_, j_, x_, d, 4); }
+
+// ---- sortedness / in-place sort (§8f rank 1): src/misc.cpp:161-189, :300-378 --------------------------------------------
+// check_indices_are_unsorted returns TRUE when every row IS sorted — the reference's own (misnamed) behaviour, misc.cpp:169-174
+SEXP _MatrixExtra_check_indices_are_unsorted(SEXP p_, SEXP j_)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p);
+    int r = 0;
+    if (mx_check_indices_are_sorted(INTEGER(p_), INTEGER(j_), (int)XLENGTH(p_) - 1, &r)) fail();
+    return Rf_ScalarLogical(r);
+}
+// in place on the caller's vectors, as the reference (void exports)
+static SEXP sort_inplace(SEXP p_, SEXP j_, SEXP x_, int dtype)
+{
+    if (TYPEOF(p_) != INTSXP || TYPEOF(j_) != INTSXP) Rf_error("sort_sparse_indices: integer index vectors required");
+    void *v = nullptr;
+    if (dtype == MX_F64) { if (TYPEOF(x_) != REALSXP) Rf_error("sort_sparse_indices: numeric values required"); v = REAL(x_); }
+    else if (dtype == MX_LGL) { if (TYPEOF(x_) != LGLSXP) Rf_error("sort_sparse_indices: logical values required"); v = LOGICAL(x_); }
+    if (mx_sort_sparse_indices(INTEGER(p_), INTEGER(j_), v, dtype, (int)XLENGTH(p_) - 1)) fail();
+    return R_NilValue;
+}
+SEXP _MatrixExtra_sort_sparse_indices_numeric(SEXP p_, SEXP j_, SEXP x_) { return sort_inplace(p_, j_, x_, MX_F64); }
+SEXP _MatrixExtra_sort_sparse_indices_logical(SEXP p_, SEXP j_, SEXP x_) { return sort_inplace(p_, j_, x_, MX_LGL); }
+SEXP _MatrixExtra_sort_sparse_indices_numeric_known_ncol(SEXP p_, SEXP j_, SEXP x_, SEXP ncol) { (void)ncol; return sort_inplace(p_, j_, x_, MX_F64); }
+SEXP _MatrixExtra_sort_sparse_indices_logical_known_ncol(SEXP p_, SEXP j_, SEXP x_, SEXP ncol) { (void)ncol; return sort_inplace(p_, j_, x_, MX_LGL); }
+SEXP _MatrixExtra_sort_sparse_indices_binary(SEXP p_, SEXP j_) { return sort_inplace(p_, j_, R_NilValue, MX_NONE); }
+
 #define MX_ENTRY(name, n) {"_MatrixExtra_" #name, (DL_FUNC)&_MatrixExtra_##name, n}
 static const R_CallMethodDef mxgpu_call_entries[] = {
     MX_ENTRY(matmul_dense_csc_numeric, 5), MX_ENTRY(matmul_dense_csc_float32, 5),
@@ -404,10 +556,21 @@ static const R_CallMethodDef mxgpu_call_entries[] = {
     MX_ENTRY(reverse_columns_inplace_numeric, 4), MX_ENTRY(reverse_columns_inplace_logical, 4),
     MX_ENTRY(reverse_columns_inplace_binary, 4),
     MX_ENTRY(multiply_csr_by_dvec_no_NAs_numeric, 11), MX_ENTRY(logicaland_csr_by_dvec_internal, 5),
+    MX_ENTRY(cbind_csr_numeric, 6), MX_ENTRY(cbind_csr_logical, 6), MX_ENTRY(cbind_csr_binary, 4),
+    MX_ENTRY(concat_csr_batch, 2),
+    MX_ENTRY(matmul_csr_svec_numeric, 6), MX_ENTRY(matmul_csr_svec_integer, 6), MX_ENTRY(matmul_csr_svec_logical, 6),
+    MX_ENTRY(matmul_csr_svec_binary, 5), MX_ENTRY(matmul_csr_svec_float32, 6),
+    MX_ENTRY(multiply_csr_by_dense_elemwise_double, 4), MX_ENTRY(multiply_csr_by_dense_elemwise_float32, 4),
+    MX_ENTRY(multiply_csr_by_dense_elemwise_int, 4), MX_ENTRY(multiply_csr_by_dense_elemwise_bool, 4),
+    MX_ENTRY(logicaland_csr_by_dense_cpp, 4),
+    MX_ENTRY(check_indices_are_unsorted, 2),
+    MX_ENTRY(sort_sparse_indices_numeric, 3), MX_ENTRY(sort_sparse_indices_logical, 3),
+    MX_ENTRY(sort_sparse_indices_numeric_known_ncol, 4), MX_ENTRY(sort_sparse_indices_logical_known_ncol, 4),
+    MX_ENTRY(sort_sparse_indices_binary, 2),
     {NULL, NULL, 0}
 };
 
-// standalone use: dyn.load("mxgpu_r.so") registers the 19 routines under their reference names
+// standalone use: dyn.load("mxgpu_r.so") registers the routines above under their reference names
 void R_init_mxgpu_r(DllInfo *dll)
 {
     R_registerRoutines(dll, NULL, mxgpu_call_entries, NULL, NULL);

@@ -1,0 +1,68 @@
+"""The .Call shim (matrixextra_amd/csrc/r_shim.cpp) cannot be built or run here (no R): check what can be checked on the
+CPU — that it compiles (g++ -fsyntax-only) against hand-written declarations of the R C API it uses
+(tests/r_api_decls/), and that every routine it registers carries the name and arity of the reference's
+CallEntries[] table (src/RcppExports.cpp:2230-2349; the numbers below were read off that table)."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "matrixextra_amd", "csrc", "r_shim.cpp")
+
+# name -> arity in the reference's CallEntries[] (RcppExports.cpp line)
+REFERENCE_ARITY = {
+    "cbind_csr_numeric": 6, "cbind_csr_logical": 6, "cbind_csr_binary": 4,                               # :2230-2232
+    "matmul_dense_csc_numeric": 5, "matmul_dense_csc_float32": 5,                                        # :2233-2234
+    "tcrossprod_dense_csr_numeric": 6, "tcrossprod_dense_csr_float32": 6,                                # :2235-2236
+    "tcrossprod_csr_dense_numeric": 5, "tcrossprod_csr_dense_float32": 5,                                # :2237-2238
+    "matmul_csr_dvec_numeric": 5, "matmul_csr_dvec_integer": 5, "matmul_csr_dvec_logical": 5,
+    "matmul_csr_dvec_float32": 5,                                                                        # :2239-2242
+    "matmul_csr_svec_numeric": 6, "matmul_csr_svec_integer": 6, "matmul_csr_svec_logical": 6,
+    "matmul_csr_svec_binary": 5, "matmul_csr_svec_float32": 6,                                           # :2243-2247
+    "check_indices_are_unsorted": 2,                                                                     # :2262
+    "sort_sparse_indices_numeric": 3, "sort_sparse_indices_logical": 3,
+    "sort_sparse_indices_numeric_known_ncol": 4, "sort_sparse_indices_logical_known_ncol": 4,
+    "sort_sparse_indices_binary": 2,                                                                     # :2263-2267
+    "multiply_csr_elemwise": 6, "logicaland_csr_elemwise": 6,                                            # :2290-2291
+    "multiply_csr_by_dense_elemwise_double": 4, "multiply_csr_by_dense_elemwise_float32": 4,
+    "multiply_csr_by_dense_elemwise_int": 4, "multiply_csr_by_dense_elemwise_bool": 4,
+    "logicaland_csr_by_dense_cpp": 4,                                                                    # :2292-2296
+    "add_csr_elemwise": 7, "logicalor_csr_elemwise": 7,                                                  # :2297-2298
+    "multiply_csr_by_dvec_no_NAs_numeric": 11, "logicaland_csr_by_dvec_internal": 5,
+    "concat_csr_batch": 2,                                                                               # :2332
+    "check_is_seq": 1, "check_is_rev_seq": 1,                                                            # :2333-2334
+    "reverse_rows_numeric": 3, "reverse_rows_logical": 3, "reverse_rows_binary": 2,
+    "reverse_columns_inplace_numeric": 4, "reverse_columns_inplace_logical": 4, "reverse_columns_inplace_binary": 4,
+    "copy_csr_rows_numeric": 4, "copy_csr_rows_logical": 4, "copy_csr_rows_binary": 3,                   # :2341-2343
+    "copy_csr_rows_col_seq_numeric": 6, "copy_csr_rows_col_seq_logical": 6, "copy_csr_rows_col_seq_binary": 5,
+    "copy_csr_arbitrary_numeric": 5, "copy_csr_arbitrary_logical": 5, "copy_csr_arbitrary_binary": 4,
+}
+
+
+def test_shim_compiles_against_the_r_api_declarations():
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror=format", "-Werror=return-type",
+                        "-I", os.path.join(ROOT, "tests", "r_api_decls"), "-I", os.path.join(ROOT, "include"), SHIM],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+
+
+def test_registered_names_and_arities_match_the_reference_table():
+    src = open(SHIM).read()
+    entries = dict((n, int(a)) for n, a in re.findall(r"MX_ENTRY\((\w+),\s*(\d+)\)", src))
+    assert entries == REFERENCE_ARITY
+    # every registered routine is defined with that many SEXP parameters
+    for name, arity in entries.items():
+        m = re.search(r"SEXP _MatrixExtra_%s\(([^)]*)\)" % name, src)
+        assert m, name
+        params = [q for q in m.group(1).split(",") if q.strip()]
+        assert len(params) == arity and all(q.strip().startswith("SEXP") for q in params), (name, params)
+
+
+def test_reference_table_agrees(tmp_path):
+    """When the reference tree is present (the development container), the numbers above are re-read from it."""
+    ref = "/root/reference/src/RcppExports.cpp"
+    if not os.path.exists(ref):
+        return
+    table = dict((n, int(a)) for n, a in re.findall(r'\{"_MatrixExtra_(\w+)", \(DL_FUNC\) &_MatrixExtra_\w+, (\d+)\}', open(ref).read()))
+    for name, arity in REFERENCE_ARITY.items():
+        assert table.get(name) == arity, name

@@ -45,6 +45,16 @@ int  mx_abi_version(void);
 int  mx_device_count(int *count);
 int  mx_set_device(int device);
 int  mx_device_name(char *buf, size_t buflen);
+/* Several GPUs of the node behind the SAME exports: after mx_set_devices(list, n) with n > 1 the large
+ * CSR x dense products (mx_tcrossprod_csr_dense_*, mx_matmul_dense_csc_*, mx_tcrossprod_dense_csr_*) cut the rows of the
+ * sparse operand into one contiguous range per listed device (mx_partition_rows' balance: 12 bytes up per entry, one result
+ * row down per row), run one host thread and three queues per device, and let every device download its rows straight
+ * into the caller's result (the result lives on the host: no collective is needed; a device may be listed more than once —
+ * its shards then share the GPU).  n = 0 or 1: the calling thread's current device only (default).  Everything else stays
+ * on the current device. */
+int  mx_set_devices(const int *devices, int n);
+/* the row cuts that sharding uses: cuts[0 .. nparts], part k = rows [cuts[k], cuts[k+1]) — host arithmetic only */
+int  mx_partition_rows(const int32_t *indptr, int nrows, int nparts, int dense_cols, int dense_bytes, int *cuts);
 /* raw device memory for callers that do not bring their own allocator */
 int  mx_dev_malloc(void **dptr, size_t bytes);
 int  mx_dev_free(void *dptr);

@@ -9,8 +9,11 @@
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace mx {
@@ -33,7 +36,7 @@ int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes);
 void prefault_begin(void *p, size_t bytes);
 void prefault_wait();
-bool pin_host(const void *p, size_t bytes);
+bool pin_host(const void *p, size_t bytes, bool all_devices = false);
 void unpin_host(const void *p);
 
 // MXGPU_TRACE=1: wall-clock phases of an export-level call on stderr
@@ -289,6 +292,16 @@ struct Lanes {
         return 0;
     }
     void drain() { if (up) (void)hipStreamSynchronize(up); if (run) (void)hipStreamSynchronize(run); if (down) (void)hipStreamSynchronize(down); }
+    void destroy()
+    {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+        if (up) (void)hipStreamDestroy(up);
+        if (run) (void)hipStreamDestroy(run);
+        if (down) (void)hipStreamDestroy(down);
+        up = run = down = nullptr;
+        dev = -1;
+    }
 };
 static Lanes &lanes() { static thread_local Lanes l; return l; }
 
@@ -296,9 +309,148 @@ static Lanes &lanes() { static thread_local Lanes l; return l; }
 struct Pin {
     const void *p = nullptr;
     bool ok = false;
-    bool pin(const void *ptr, size_t bytes) { ok = mx::pin_host(ptr, bytes); p = ptr; return ok; }
+    bool pin(const void *ptr, size_t bytes, bool all_devices = false) { ok = mx::pin_host(ptr, bytes, all_devices); p = ptr; return ok; }
     ~Pin() { if (ok) mx::unpin_host(p); }
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Several GPUs behind the same export (mx_set_devices): the rows of A are cut into one contiguous range per
+// listed device, balanced by what a row costs (12 bytes of CSR up per entry, n result elements down); every device gets
+// B, multiplies its rows and downloads them straight into its rows of the caller's result (pitched copy: the host matrix
+// is column-major).  The result lives on the host, so the devices never talk to each other — no collective; with C wanted
+// on every GPU instead (matrixextra_amd/distributed.py) the same row blocks are exchanged by one RCCL all-gather.
+static std::mutex g_devices_mu;
+static std::vector<int> g_devices;                               // empty: the calling thread's current device only
+
+// cuts[0..nparts]: rows [cuts[k], cuts[k+1]) for part k; cumulative cost of the first r rows = w_entry * indptr[r] + w_row * r
+static void partition_rows(const int32_t *indptr, int m, int nparts, double w_entry, double w_row, int *cuts)
+{
+    const double base = w_entry * (double)indptr[0];
+    const double total = w_entry * (double)indptr[m] - base + w_row * (double)m;
+    cuts[0] = 0;
+    for (int k = 1; k < nparts; k++) {
+        const double target = total * (double)k / (double)nparts;
+        int lo = cuts[k - 1], hi = m;                            // first r with cost(r) >= target
+        while (lo < hi) {
+            const int mid = lo + (hi - lo) / 2;
+            const double c = w_entry * (double)indptr[mid] - base + w_row * (double)mid;
+            if (c < target) lo = mid + 1; else hi = mid;
+        }
+        cuts[k] = lo;
+    }
+    cuts[nparts] = m;
+}
+
+template <typename real_t>
+static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_rows, const int32_t *indptr,
+                           const int32_t *indices, const double *values, const real_t *B_host, size_t ldb, real_t *C_host,
+                           size_t ldc, size_t c_elems, bool colmajor, int algo, int npanels)
+{
+    const int nd = (int)devs.size();
+    const size_t c_bytes = sizeof(real_t) * c_elems, b_bytes = sizeof(real_t) * (size_t)K_rows * ldb;
+    const int64_t nnz = indptr[m];
+    const int dt = sizeof(real_t) == 8 ? MX_F64 : MX_F32;
+    Trace tr("spmm export (sharded)");
+    mx::prefault_begin(C_host, c_bytes);
+    std::vector<int> cut((size_t)nd + 1);
+    partition_rows(indptr, m, nd, 12.0, (double)n * sizeof(real_t), cut.data());
+    // host memory registered for every device; `gate` opens once the result is registered (downloads wait for it)
+    Pin pinB, pinJ, pinX, pinC;
+    const bool up_ok = pinB.pin(B_host, b_bytes, true) && pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz, true) &&
+                       pinX.pin(values, sizeof(double) * (size_t)nnz, true);
+    MX_REQUIRE(up_ok, "sharded spmm export: cannot register the operands for direct DMA");
+    std::mutex gate_mu;
+    std::condition_variable gate_cv;
+    int gate = 0;                                                // 0 closed, 1 result registered, -1 registration failed
+    std::vector<std::string> errors((size_t)nd);
+    auto shard = [&](int k) {
+        auto failed = [&](const char *what) { errors[k] = std::string(what) + ": " + mx_last_error(); };
+        if (hipSetDevice(devs[k]) != hipSuccess) { errors[k] = "hipSetDevice failed"; return; }
+        const int r_lo = cut[k], r_hi = cut[k + 1], mk = r_hi - r_lo;
+        if (mk == 0) return;
+        const int64_t e_lo = indptr[r_lo], e_hi = indptr[r_hi];
+        Lanes L;                                                 // this worker thread's queues, gone with it
+        const int nblk = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)mk * n * (int64_t)sizeof(real_t) / ((int64_t)96 << 20)));
+        struct Drain { Lanes &l; ~Drain() { l.drain(); l.destroy(); mxd_release_workspaces(); } } drain{L};
+        if (L.init(2 * (size_t)nblk + 2)) { failed("streams"); return; }
+        // the shard's own CSR arrays (indptr rebased on the host: mk + 1 ints), B, and its rows of C (column-major mk x n, or
+        // row-major)
+        DevBuf dp, dj, dx, dB, dC;
+        std::vector<int32_t> p_local((size_t)mk + 1);
+        for (int r = 0; r <= mk; r++) p_local[r] = (int32_t)(indptr[r_lo + r] - e_lo);
+        if (dp.upload(p_local.data(), sizeof(int32_t) * ((size_t)mk + 1)) || dj.alloc(sizeof(int32_t) * (size_t)(e_hi - e_lo)) ||
+            dx.alloc(sizeof(double) * (size_t)(e_hi - e_lo)) || dB.alloc(b_bytes) || dC.alloc(sizeof(real_t) * (size_t)mk * n)) {
+            failed("device allocation");
+            return;
+        }
+        const size_t ldc_k = colmajor ? (size_t)mk : ldc;
+        bool ok = hipMemcpyAsync(dB.p, B_host, b_bytes, hipMemcpyHostToDevice, L.up) == hipSuccess;
+        std::vector<int> bc((size_t)nblk + 1);
+        for (int b = 0; b <= nblk; b++) bc[b] = (int)((int64_t)mk * b / nblk);
+        for (int b = 0; b < nblk && ok; b++) {
+            const int64_t e0 = p_local[bc[b]], e1 = p_local[bc[b + 1]];
+            if (e1 > e0) {
+                ok = ok && hipMemcpyAsync(dj.as<int32_t>() + e0, indices + e_lo + e0, sizeof(int32_t) * (size_t)(e1 - e0),
+                                          hipMemcpyHostToDevice, L.up) == hipSuccess;
+                ok = ok && hipMemcpyAsync(dx.as<double>() + e0, values + e_lo + e0, sizeof(double) * (size_t)(e1 - e0),
+                                          hipMemcpyHostToDevice, L.up) == hipSuccess;
+            }
+            ok = ok && hipEventRecord(L.ev[b], L.up) == hipSuccess;
+        }
+        if (!ok) { errors[k] = "upload failed"; return; }
+        for (int b = 0; b < nblk; b++) {
+            const int r0 = bc[b], r1 = bc[b + 1];
+            if (r1 == r0) continue;
+            (void)hipStreamWaitEvent(L.run, L.ev[b], 0);
+            real_t *dCb = colmajor ? dC.as<real_t>() + r0 : dC.as<real_t>() + (size_t)r0 * ldc_k;
+            if (p_local[r0] == p_local[r1]) {
+                if (colmajor) (void)hipMemset2DAsync(dCb, ldc_k * sizeof(real_t), 0, (size_t)(r1 - r0) * sizeof(real_t), n, L.run);
+                else (void)hipMemsetAsync(dCb, 0, (size_t)(r1 - r0) * ldc_k * sizeof(real_t), L.run);
+            } else if (mxd_spmm_csr_dense_ex(r1 - r0, n, K_rows, dp.as<int32_t>() + r0, dj.as<int32_t>(), dx.as<double>(), dB.p,
+                                             ldb, dCb, ldc_k, dt, colmajor ? 1 : 0, algo, 0, npanels, 0, L.run)) {
+                failed("spmm");
+                return;
+            }
+            (void)hipEventRecord(L.ev[nblk + b], L.run);
+        }
+        {                                                        // downloads need the result registered
+            std::unique_lock<std::mutex> lk(gate_mu);
+            gate_cv.wait(lk, [&] { return gate != 0; });
+            if (gate < 0) { errors[k] = "result not registered"; return; }
+        }
+        for (int b = 0; b < nblk && ok; b++) {
+            const int r0 = bc[b], r1 = bc[b + 1];
+            if (r1 == r0) continue;
+            (void)hipStreamWaitEvent(L.down, L.ev[nblk + b], 0);
+            if (colmajor)
+                ok = hipMemcpy2DAsync(C_host + r_lo + r0, ldc * sizeof(real_t), dC.as<real_t>() + r0, ldc_k * sizeof(real_t),
+                                      (size_t)(r1 - r0) * sizeof(real_t), n, hipMemcpyDeviceToHost, L.down) == hipSuccess;
+            else
+                ok = hipMemcpyAsync(C_host + (size_t)(r_lo + r0) * ldc, dC.as<real_t>() + (size_t)r0 * ldc_k,
+                                    (size_t)(r1 - r0) * ldc * sizeof(real_t), hipMemcpyDeviceToHost, L.down) == hipSuccess;
+        }
+        if (!ok) { errors[k] = "download failed"; return; }
+        L.drain();
+    };
+    int dev0 = 0;
+    (void)hipGetDevice(&dev0);
+    std::vector<std::thread> workers;
+    for (int k = 0; k < nd; k++) workers.emplace_back(shard, k);
+    mx::prefault_wait();
+    const bool c_ok = pinC.pin(C_host, c_bytes, true);
+    {
+        std::lock_guard<std::mutex> lk(gate_mu);
+        gate = c_ok ? 1 : -1;
+    }
+    gate_cv.notify_all();
+    for (auto &w : workers) w.join();
+    (void)hipSetDevice(dev0);
+    tr.mark("shards");
+    MX_REQUIRE(c_ok, "sharded spmm export: cannot register the result for direct DMA");
+    for (int k = 0; k < nd; k++)
+        if (!errors[k].empty()) return set_error("sharded spmm export, device %d: %s", devs[k], errors[k].c_str());
+    return 0;
+}
 
 // C(m x n) = A(CSR, m rows) * B(row-major rows of length ldb); host in, host out.
 //
@@ -324,6 +476,13 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     if (const char *e = getenv("MXGPU_SPMM_PANELS")) npanels = atoi(e);
     static const int pipeline_on = [] { const char *e = getenv("MXGPU_EXPORT_PIPELINE"); return e ? atoi(e) : 1; }();
     const bool pipelined = pipeline_on && c_bytes >= ((size_t)64 << 20) && m >= 4096 && algo != MX_SPMM_SLAB;
+    if (pipelined) {
+        std::vector<int> devs;
+        { std::lock_guard<std::mutex> lk(g_devices_mu); devs = g_devices; }
+        if (devs.size() > 1)
+            return spmm_host_multi<real_t>(devs, m, n, K_rows, indptr, indices, values, B_host, ldb, C_host, ldc, c_elems, colmajor,
+                                           algo, npanels);
+    }
     Csr A;
     if (A.prepare(indptr, indices, values, m, sizeof(double), true)) return 1;
     // column-major result + CSR still on the host: the whole result is first-touched under the upload (see below)
@@ -508,6 +667,22 @@ int mx_device_count(int *count)
     return 0;
 }
 int mx_set_device(int device) { MX_HIP(hipSetDevice(device)); return 0; }
+int mx_set_devices(const int *devices, int n)
+{
+    MX_REQUIRE(n >= 0 && (n == 0 || devices), "mx_set_devices: bad arguments");
+    int count = 0;
+    MX_HIP(hipGetDeviceCount(&count));
+    for (int k = 0; k < n; k++) MX_REQUIRE(devices[k] >= 0 && devices[k] < count, "mx_set_devices: no device %d", devices[k]);
+    std::lock_guard<std::mutex> lk(g_devices_mu);
+    g_devices.assign(devices, devices + n);
+    return 0;
+}
+int mx_partition_rows(const int32_t *indptr, int nrows, int nparts, int dense_cols, int dense_bytes, int *cuts)
+{
+    MX_REQUIRE(indptr && cuts && nrows >= 0 && nparts >= 1, "mx_partition_rows: bad arguments");
+    partition_rows(indptr, nrows, nparts, 12.0, (double)dense_cols * dense_bytes, cuts);
+    return 0;
+}
 int mx_device_name(char *buf, size_t buflen)
 {
     int dev = 0;

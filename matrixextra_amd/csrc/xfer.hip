@@ -228,10 +228,11 @@ void prefault_wait()
     if (e.pool) e.pool->wait();
 }
 // hipHostRegister / hipHostUnregister of caller memory; false (and no error state left behind) when it cannot be pinned
-bool pin_host(const void *p, size_t bytes)
+bool pin_host(const void *p, size_t bytes, bool all_devices = false)
 {
     if (!p || bytes == 0 || xfer_mode() != 1) return false;
-    if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) return true;
+    if (hipHostRegister(const_cast<void *>(p), bytes, all_devices ? hipHostRegisterPortable : hipHostRegisterDefault) == hipSuccess)
+        return true;
     (void)hipGetLastError();
     return false;
 }

@@ -122,3 +122,28 @@ def _cache_stats(lib):
     b, e, h, mi = C.c_int64(0), C.c_int(0), C.c_int64(0), C.c_int64(0)
     lib.mx_cache_stats(C.byref(b), C.byref(e), C.byref(h), C.byref(mi))
     return dict(bytes=b.value, entries=e.value, hits=h.value, misses=mi.value)
+
+
+def test_sharded_export_on_one_gpu(gpu):
+    """mx_set_devices with the same GPU listed three times: the sharded path (row ranges balanced by cost, one host
+    thread + three queues per shard, pitched downloads into the caller's column-major result) runs on a one-GPU box
+    and must give the single-device answer bit for bit (each row is summed by the same kernel either way)."""
+    lib = _lib.load()
+    m, K, n = 700_000, 60_000, 128
+    p, j, x = synth.csr_skewed(m, K, 12, seed=5, sigma=1.0)
+    B = synth.dense_normal(K, n)
+    Y = np.asfortranarray(B.T)
+    single = G.tcrossprod_csr_dense_numeric(p, j, x, Y, 1)
+    devs = (C.c_int * 3)(0, 0, 0)
+    _lib.check(lib.mx_set_devices(devs, 3))
+    try:
+        sharded = G.tcrossprod_csr_dense_numeric(p, j, x, Y, 1)
+        np.testing.assert_allclose(sharded, single, rtol=1e-12, atol=1e-12 * np.abs(single).max())
+        _check_product(sharded, p, j, x, B, rows=(0, 233_000, 466_000, -600))
+        Xd = np.asfortranarray(B.T[:96])                              # row-major result: dense (96 x K) %*% CSC (K x m)
+        rm = G.matmul_dense_csc_numeric(Xd, p, j, x, 1)
+        np.testing.assert_allclose(rm.T, single[:, :96], rtol=1e-12, atol=1e-12 * np.abs(single).max())
+    finally:
+        _lib.check(lib.mx_set_devices(None, 0))
+    with pytest.raises(_lib.MxError):
+        _lib.check(lib.mx_set_devices((C.c_int * 1)(99), 1))

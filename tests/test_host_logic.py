@@ -74,3 +74,26 @@ def test_ngRMatrix_identity_shortcuts():
     assert isinstance(x, mx.lgRMatrix) and x.p.tolist() == [0, 0, 0] and x.j.size == 0
     s = operators.add_csr_matrices(A, B, True)
     assert isinstance(s, mx.dgRMatrix) and s.x.tolist() == [2.0, 2.0]
+
+
+def test_partition_rows_balances_cost_and_covers_all_rows():
+    """mx_partition_rows (what the sharded exports cut the sparse operand with): host arithmetic only."""
+    import ctypes as C
+    from matrixextra_amd import _lib, synth
+    lib = _lib.load()
+    for (m, K, mean, sigma) in ((50_000, 4000, 20, 1.3), (1000, 50, 3, 0.5), (7, 100, 5, 0.1)):
+        p, j, x = synth.csr_skewed(m, K, mean, seed=m, sigma=sigma)
+        for nparts in (1, 2, 3, 8):
+            cuts = (C.c_int * (nparts + 1))()
+            _lib.check(lib.mx_partition_rows(p.ctypes.data_as(C.c_void_p), C.c_int(m), C.c_int(nparts), C.c_int(128),
+                                             C.c_int(8), cuts))
+            cuts = list(cuts)
+            assert cuts[0] == 0 and cuts[-1] == m and all(a <= b for a, b in zip(cuts, cuts[1:]))
+            cost = [12.0 * (p[b] - p[a]) + 128 * 8.0 * (b - a) for a, b in zip(cuts, cuts[1:])]
+            longest = 12.0 * np.diff(p).max() + 128 * 8.0
+            assert max(cost) <= sum(cost) / nparts + longest          # no part exceeds its share by more than one row
+    # an all-empty matrix is cut by rows
+    p0 = np.zeros(101, dtype=np.int32)
+    cuts = (C.c_int * 5)()
+    _lib.check(lib.mx_partition_rows(p0.ctypes.data_as(C.c_void_p), C.c_int(100), C.c_int(4), C.c_int(16), C.c_int(4), cuts))
+    assert list(cuts) == [0, 25, 50, 75, 100]

@@ -46,8 +46,11 @@ def _cpu_stamp() -> str:
 
 
 def build(force: bool = False) -> str:
-    """The library is built -march=native: rebuild when it is missing, older than the source, or was made on another
+    """MXORACLE_SO=<path>: use that build as is (tools/sanitize.sh points it at an ASan + UBSan build).
+    The library is built -march=native: rebuild when it is missing, older than the source, or was made on another
     CPU model (the prebuilt file travels from the build container to the GPU box)."""
+    if os.environ.get("MXORACLE_SO"):
+        return os.environ["MXORACLE_SO"]
     stamp = os.path.join(_HERE, "_build", "cpu_stamp")
     try:
         with open(stamp) as f:

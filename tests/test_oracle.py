@@ -62,13 +62,18 @@ def test_kat_sort_indices():
     assert O.check_indices_are_sorted(p, js)
 
 
-def test_kat_readme_matrix_spmm():
-    # README.md:17-27 3x4 example matrix [[1,0,0,2... layout used only as a fixed small case vs dense
-    X = np.array([[1.0, 0, 0, 2], [0, 0, 3, 0], [0, 4, 0, 0]])
-    A = sp.csr_matrix(X)
+def test_readme_example_matrix_times_dense():
+    # the 3 x 4 CSR matrix the README builds (README.md:17-27: p = [0,2,3,3], j = [2,3,1], x = [2,1,3], i.e.
+    # [[0,0,2,1],[0,3,0,0],[0,0,0,0]] with an empty last row).  The README prints no product: this is a fixed small
+    # case against dense numpy, not a known answer held by the reference.
+    p = np.array([0, 2, 3, 3], dtype=np.int32)
+    j = np.array([2, 3, 1], dtype=np.int32)
+    x = np.array([2.0, 1.0, 3.0])
+    X = np.array([[0.0, 0, 2, 1], [0, 3, 0, 0], [0, 0, 0, 0]])
     B = np.arange(12, dtype=np.float64).reshape(4, 3) - 5
-    out = O.tcrossprod_csr_dense_numeric(A.indptr, A.indices, A.data, B.T.copy())
+    out = O.tcrossprod_csr_dense_numeric(p, j, x, B.T.copy())
     np.testing.assert_array_equal(out, X @ B)
+    np.testing.assert_array_equal(O.matmul_csr_dvec_numeric(p, j, x, B[:, 0].copy()), X @ B[:, 0])
 
 
 @pytest.mark.parametrize("use_fma", [False, True])

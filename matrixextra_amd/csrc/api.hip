@@ -305,11 +305,24 @@ struct Lanes {
 };
 static Lanes &lanes() { static thread_local Lanes l; return l; }
 
-// host memory registered for the duration of a scope
+// Host memory registered for the duration of a scope.  Only buffers of at least PIN_WHOLE_MIN bytes are registered as a
+// whole: an allocation that large is a mapping of its own (glibc serves nothing above 32 MiB from a shared heap), so its
+// first and last page belong to nobody else.  Smaller buffers may share their edge pages with a neighbouring heap
+// object, and a page pinned / unpinned through two overlapping registrations has been seen to leave the GPU with a stale
+// mapping (memory-access fault some calls later: tools/fuzz_structure.py, seed 5) — they go through xfer_h2d / xfer_d2h,
+// which register whole interior pages only.
+constexpr size_t PIN_WHOLE_MIN = (size_t)64 << 20;
 struct Pin {
     const void *p = nullptr;
     bool ok = false;
-    bool pin(const void *ptr, size_t bytes, bool all_devices = false) { ok = mx::pin_host(ptr, bytes, all_devices); p = ptr; return ok; }
+    bool pin(const void *ptr, size_t bytes, bool all_devices = false)
+    {
+        ok = bytes >= PIN_WHOLE_MIN && mx::pin_host(ptr, bytes, all_devices);
+        p = ptr;
+        return ok;
+    }
+    // a page-aligned piece of a buffer that is registered piece by piece (the pieces must not share pages)
+    bool pin_pages(const void *ptr, size_t bytes) { ok = mx::pin_host(ptr, bytes, false); p = ptr; return ok; }
     ~Pin() { if (ok) mx::unpin_host(p); }
 };
 
@@ -356,9 +369,9 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
     partition_rows(indptr, m, nd, 12.0, (double)n * sizeof(real_t), cut.data());
     // host memory registered for every device; `gate` opens once the result is registered (downloads wait for it)
     Pin pinB, pinJ, pinX, pinC;
-    const bool up_ok = pinB.pin(B_host, b_bytes, true) && pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz, true) &&
-                       pinX.pin(values, sizeof(double) * (size_t)nnz, true);
-    MX_REQUIRE(up_ok, "sharded spmm export: cannot register the operands for direct DMA");
+    // (arrays too small to own their pages, or that cannot be registered, go up through xfer_h2d inside every shard)
+    const bool dirB = pinB.pin(B_host, b_bytes, true);
+    const bool dirA = pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz, true) && pinX.pin(values, sizeof(double) * (size_t)nnz, true);
     std::mutex gate_mu;
     std::condition_variable gate_cv;
     int gate = 0;                                                // 0 closed, 1 result registered, -1 registration failed
@@ -384,12 +397,16 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
             return;
         }
         const size_t ldc_k = colmajor ? (size_t)mk : ldc;
-        bool ok = hipMemcpyAsync(dB.p, B_host, b_bytes, hipMemcpyHostToDevice, L.up) == hipSuccess;
+        bool ok = dirB ? hipMemcpyAsync(dB.p, B_host, b_bytes, hipMemcpyHostToDevice, L.up) == hipSuccess
+                       : mx::xfer_h2d(dB.p, B_host, b_bytes) == 0;
+        if (ok && !dirA && e_hi > e_lo)
+            ok = mx::xfer_h2d(dj.p, indices + e_lo, sizeof(int32_t) * (size_t)(e_hi - e_lo)) == 0 &&
+                 mx::xfer_h2d(dx.p, values + e_lo, sizeof(double) * (size_t)(e_hi - e_lo)) == 0;
         std::vector<int> bc((size_t)nblk + 1);
         for (int b = 0; b <= nblk; b++) bc[b] = (int)((int64_t)mk * b / nblk);
         for (int b = 0; b < nblk && ok; b++) {
             const int64_t e0 = p_local[bc[b]], e1 = p_local[bc[b + 1]];
-            if (e1 > e0) {
+            if (e1 > e0 && dirA) {
                 ok = ok && hipMemcpyAsync(dj.as<int32_t>() + e0, indices + e_lo + e0, sizeof(int32_t) * (size_t)(e1 - e0),
                                           hipMemcpyHostToDevice, L.up) == hipSuccess;
                 ok = ok && hipMemcpyAsync(dx.as<double>() + e0, values + e_lo + e0, sizeof(double) * (size_t)(e1 - e0),
@@ -540,7 +557,7 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     const int64_t nnz = A.nnz;
     if (!A.resident) {
         const bool direct_up = pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz) && pinX.pin(values, sizeof(double) * (size_t)nnz);
-        if (!direct_up) { if (A.finish_upload()) return 1; }     // staged, whole arrays; the blocks below then only compute
+        if (!direct_up) { if (A.finish_upload()) return 1; }     // whole arrays through xfer_h2d; the blocks below then only compute
     }
     // block b = rows [cut[b], cut[b+1]) (ROWS, ROWS_STRIDED) or columns (COLS)
     std::vector<int> cut((size_t)nblk + 1);
@@ -560,11 +577,22 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
         }
     }
     tr.mark("setup");
-    // where block b lives in the caller's result (contiguous shapes) and on the device
-    auto host_block = [&](int b) { return shape == ROWS ? C_host + (size_t)cut[b] * ldc : C_host + (size_t)cut[b] * ldc; };
-    auto block_bytes = [&](int b) { return (size_t)(cut[b + 1] - cut[b]) * ldc * sizeof(real_t); };
+    // Contiguous shapes: the result is first-touched, registered and downloaded in PIECES that follow the blocks but are cut
+    // at page boundaries of the caller's buffer (piece b = bytes [hb[b], hb[b+1]) of the result: block b without its last
+    // partial page, plus the last partial page of block b-1), so that no page is registered twice.
     const bool incremental = shape != ROWS_STRIDED;
-    if (incremental) { mx::prefault_wait(); mx::prefault_begin(host_block(0), block_bytes(0)); }   // (the whole-result touch was not started)
+    std::vector<size_t> hb((size_t)nblk + 1, 0);
+    if (incremental) {
+        for (int b = 1; b < nblk; b++) {
+            const uintptr_t start = (uintptr_t)(C_host + (size_t)cut[b] * ldc), page = start & ~(uintptr_t)4095;
+            const size_t off = page > (uintptr_t)C_host ? (size_t)(page - (uintptr_t)C_host) : 0;
+            hb[b] = std::max(hb[b - 1], std::min(off, c_bytes));
+        }
+        hb[nblk] = c_bytes;
+    }
+    auto piece_ptr = [&](int b) { return (char *)C_host + hb[b]; };
+    auto piece_bytes = [&](int b) { return hb[b + 1] - hb[b]; };
+    if (incremental) { mx::prefault_wait(); mx::prefault_begin(piece_ptr(0), piece_bytes(0)); }
     // ---- compute: everything is queued before the host waits for anything
     MX_HIP(hipStreamWaitEvent(L.run, evB, 0));
     for (int b = 0; b < nblk; b++) {
@@ -593,13 +621,12 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     bool direct_down = true;
     if (incremental) {
         for (int b = 0; b < nblk && direct_down; b++) {
-            if (cut[b + 1] == cut[b]) continue;
-            mx::prefault_wait();                                 // block b's pages exist
-            if (b + 1 < nblk && cut[b + 2] > cut[b + 1]) mx::prefault_begin(host_block(b + 1), block_bytes(b + 1));
-            if (!pinBlk[b].pin(host_block(b), block_bytes(b))) { direct_down = false; break; }
-            MX_HIP(hipStreamWaitEvent(L.down, L.ev[nblk + b], 0));
-            MX_HIP(hipMemcpyAsync(host_block(b), shape == COLS ? dC + (size_t)cut[b] * ldc : dC + (size_t)cut[b] * ldc,
-                                  block_bytes(b), hipMemcpyDeviceToHost, L.down));
+            mx::prefault_wait();                                 // piece b's pages exist
+            if (b + 1 < nblk && piece_bytes(b + 1)) mx::prefault_begin(piece_ptr(b + 1), piece_bytes(b + 1));
+            if (piece_bytes(b) == 0) continue;
+            if (!pinBlk[b].pin_pages(piece_ptr(b), piece_bytes(b))) { direct_down = false; break; }
+            MX_HIP(hipStreamWaitEvent(L.down, L.ev[nblk + b], 0));   // (blocks complete in order: piece b needs blocks <= b)
+            MX_HIP(hipMemcpyAsync(piece_ptr(b), (const char *)dC + hb[b], piece_bytes(b), hipMemcpyDeviceToHost, L.down));
         }
     } else {
         mx::prefault_wait();

@@ -154,6 +154,22 @@ void unpin_host(const void *p)
     if (p && hipHostUnregister(const_cast<void *>(p)) != hipSuccess) (void)hipGetLastError();
 }
 
+// Register only the whole pages INSIDE [p, p + bytes): the first and last partial page may be shared with a neighbouring
+// heap object (another operand of the same call, registered and unregistered on its own schedule), and a page that is
+// pinned and unpinned through two overlapping registrations has been seen to leave the GPU with a stale mapping (a GPU
+// memory-access fault some calls later).  Returns the registered interior; the fragments are copied separately.
+struct Interior { char *p = nullptr; size_t bytes = 0; };
+static Interior pin_interior(const void *ptr, size_t bytes)
+{
+    Interior in;
+    const uintptr_t a = ((uintptr_t)ptr + 4095) & ~(uintptr_t)4095, b = ((uintptr_t)ptr + bytes) & ~(uintptr_t)4095;
+    if (b <= a || b - a < XF_MIN / 2) return in;
+    if (!pin_host((const void *)a, b - a)) return in;
+    in.p = (char *)a;
+    in.bytes = b - a;
+    return in;
+}
+
 // Everything previously enqueued on the null stream (kernels of the export that produced `src`) is complete before
 // the first byte moves, as with hipMemcpy.
 int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes)
@@ -167,10 +183,16 @@ int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes)
             e.team()->touch(dst_host, bytes);          // (a no-op pass when prefault_begin already did it)
             e.pool->wait();
         }
-        if (pin_host(dst_host, bytes)) {
-            const hipError_t rc = hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost);
-            unpin_host(dst_host);
+        const Interior in = pin_interior(dst_host, bytes);
+        if (in.p) {
+            const size_t head = (size_t)(in.p - (char *)dst_host), tail = bytes - head - in.bytes;
+            hipError_t rc = hipMemcpyAsync(in.p, (const char *)src_dev + head, in.bytes, hipMemcpyDeviceToHost, nullptr);
+            const hipError_t rs = hipStreamSynchronize(nullptr);   // nothing may touch the pages once they are unpinned
+            if (rc == hipSuccess) rc = rs;
+            unpin_host(in.p);
             MX_HIP(rc);
+            if (head) MX_HIP(hipMemcpy(dst_host, src_dev, head, hipMemcpyDeviceToHost));
+            if (tail) MX_HIP(hipMemcpy((char *)dst_host + head + in.bytes, (const char *)src_dev + head + in.bytes, tail, hipMemcpyDeviceToHost));
             return 0;
         }
     }
@@ -183,11 +205,19 @@ int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes)
 {
     if (bytes == 0) return 0;
     if (bytes < XF_MIN || xfer_mode() == 0) { MX_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return 0; }
-    if (xfer_mode() == 1 && pin_host(src_host, bytes)) {
-        const hipError_t rc = hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice);
-        unpin_host(src_host);
-        MX_HIP(rc);
-        return 0;
+    if (xfer_mode() == 1) {
+        const Interior in = pin_interior(src_host, bytes);
+        if (in.p) {
+            const size_t head = (size_t)(in.p - (const char *)src_host), tail = bytes - head - in.bytes;
+            hipError_t rc = hipMemcpyAsync((char *)dst_dev + head, in.p, in.bytes, hipMemcpyHostToDevice, nullptr);
+            const hipError_t rs = hipStreamSynchronize(nullptr);   // nothing may touch the pages once they are unpinned
+            if (rc == hipSuccess) rc = rs;
+            unpin_host(in.p);
+            MX_HIP(rc);
+            if (head) MX_HIP(hipMemcpy(dst_dev, src_host, head, hipMemcpyHostToDevice));
+            if (tail) MX_HIP(hipMemcpy((char *)dst_dev + head + in.bytes, (const char *)src_host + head + in.bytes, tail, hipMemcpyHostToDevice));
+            return 0;
+        }
     }
     Engine &e = engine();
     std::lock_guard<std::mutex> lk(e.mu);

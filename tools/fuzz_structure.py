@@ -6,6 +6,8 @@ sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
 import numpy as np
 from conftest import rand_csr
+from devmem import merge_fused_device, spmv_device
+from matrixextra_amd import _lib
 from matrixextra_amd import exports as G
 from oracle import oracle as O
 
@@ -15,7 +17,17 @@ rng = np.random.default_rng(seed)
 NA = int(O.NA_INTEGER)
 
 
+import os
+TRACE = os.environ.get("FUZZ_TRACE")
+
+
+def trace(*a):
+    if TRACE:
+        print(*a, flush=True)
+
+
 def same(a, b, what):
+    trace("  checked", what)
     a, b = np.asarray(a), np.asarray(b)
     assert a.shape == b.shape and a.dtype == b.dtype, (what, a.shape, b.shape, a.dtype, b.dtype)
     if a.dtype.kind == "f":
@@ -45,43 +57,64 @@ while time.time() < t_end:
     if rng.random() < 0.3:                                          # overlapping pattern with cancellation
         p2, j2, x2 = p1.copy(), j1.copy(), -x1.copy()
     what = None
+    trace("case", cases, dict(m=m, K=K, d1=d1, d2=d2, s1=s1, s2=s2))
     try:
         for sub in (False, True):
-            what = f"add sub={sub}"
+            what = f"add sub={sub}"; trace("  start", what)
             same_list(G.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub), O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub), what)
-        what = "mul"
+        what = "mul"; trace("  start", what)
         same_list(G.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2), O.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2), what)
         l1 = rand_csr(m, K, d1, seed=s1, dtype="l")
         l2 = rand_csr(m, K, d2, seed=s2, dtype="l")
         for xor in (False, True):
-            what = f"or xor={xor}"
+            what = f"or xor={xor}"; trace("  start", what)
             same_list(G.logicalor_csr_elemwise(l1[0], l2[0], l1[1], l2[1], l1[2], l2[2], xor),
                       O.logicalor_csr_elemwise(l1[0], l2[0], l1[1], l2[1], l1[2], l2[2], xor), what)
-        what = "and"
+        what = "and"; trace("  start", what)
         same_list(G.logicaland_csr_elemwise(l1[0], l2[0], l1[1], l2[1], l1[2], l2[2]),
                   O.logicaland_csr_elemwise(l1[0], l2[0], l1[1], l2[1], l1[2], l2[2]), what)
         rows = rng.integers(0, m, size=int(rng.integers(0, 2 * m + 1)), dtype=np.int32)
-        what = "gather"
+        what = "gather"; trace("  start", what)
         same_list(G.copy_csr_rows_numeric(p1, j1, x1, rows), O.copy_csr_rows_numeric(p1, j1, x1, rows), what)
         if rows.size:
             c0 = int(rng.integers(0, K)); c1 = int(rng.integers(c0, K))
             cols_seq = np.arange(c0 + 1, c1 + 2, dtype=np.int32)    # 1-based, as R passes them
-            what = "col_seq"
+            what = "col_seq"; trace("  start", what)
             same_list(G.copy_csr_rows_col_seq_numeric(p1, j1, x1, rows, cols_seq, True),
                       O.copy_csr_rows_col_seq_numeric(p1, j1, x1, rows, cols_seq, True), what)
             cols = rng.integers(0, K, size=int(rng.integers(1, K + 3)), dtype=np.int32)
-            what = "arbitrary"
+            what = "arbitrary"; trace("  start", what)
             same_list(G.copy_csr_arbitrary_numeric(p1, j1, x1, rows, cols), O.copy_csr_arbitrary_numeric(p1, j1, x1, rows, cols), what)
-        what = "sort"
+        if p1[-1] + p2[-1] > 0:                                       # the one-pass merge kernel (device level)
+            for op, ref in ((_lib.MX_OP_ADD, O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, False)),
+                            (_lib.MX_OP_MUL, O.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2)),
+                            (_lib.MX_OP_XOR, O.logicalor_csr_elemwise(l1[0], l2[0], l1[1], l2[1], l1[2], l2[2], True))):
+                what = f"fused merge op={op}"; trace("  start", what)
+                lg = op == _lib.MX_OP_XOR
+                gp, gj, gx = merge_fused_device(op, l1[0] if lg else p1, l1[1] if lg else j1, l1[2] if lg else x1,
+                                                l2[0] if lg else p2, l2[1] if lg else j2, l2[2] if lg else x2)
+                same_list(dict(indptr=gp, indices=gj, values=gx), ref, what)
+        what = "sorted check"; trace("  start", what)
+        assert G.check_indices_are_sorted(p1, j1) == O.check_indices_are_sorted(p1, j1)
+        what = "sort"; trace("  start", what)
         pu, ju, xu = rand_csr(m, K, d2, seed=s2 + 1, sorted_cols=False)
+        assert G.check_indices_are_sorted(pu, ju) == O.check_indices_are_sorted(pu, ju)
         jg, xg = ju.copy(), xu.copy()
         G.sort_sparse_indices_inplace(pu, jg, xg)
         jo, xo = O.sort_sparse_indices(pu, ju, xu)
         same(jg, jo, "sort/j"); same(xg, xo, "sort/x")
-        what = "spmv"
+        what = "spmv"; trace("  start", what)
         v = rng.normal(size=K).round(3)
         np.testing.assert_allclose(G.matmul_csr_dvec_numeric(pu, ju, xu, v), O.matmul_csr_dvec_numeric(pu, ju, xu, v), rtol=1e-11, atol=1e-12)
-        what = "dvec mul"
+        if pu[-1] >= 4:                                               # flat / tile kernels: storage-order sums, bitwise for rows <= 256
+            ref = O.matmul_csr_dvec_numeric(pu, ju, xu, v)
+            short = np.diff(pu) <= 256
+            for algo in (3, 2):
+                what = f"spmv algo {algo}"; trace("  start", what)
+                got = spmv_device(pu, ju, xu, v, _lib.MX_F64, algo)
+                same(got[short], ref[short], what)
+                np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+        what = "dvec mul"; trace("  start", what)
         ln = int(rng.choice([1, m, m * K, max(1, m // 2), 7]))
         dv = rng.uniform(0.5, 2.0, size=ln).round(3)
         same(G.multiply_csr_by_dvec_no_NAs_numeric(p1, j1, x1, dv, K, 1, 0, 0, 0, 0, 1),

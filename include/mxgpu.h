@@ -127,6 +127,11 @@ int mxd_spmm_csr_dense(int m, int n,
  *                          the plan is rebuilt on every call here — hold a plan yourself to amortise it
  *   algo MX_SPMM_AUTO    : PLANNED when B is larger than an XCD's L2, the operands qualify and there is enough
  *                          work to fill the chip, else ROWWAVE
+ * Determinism: ROWWAVE and SLAB add a row's terms in CSR storage order (bitwise equal to a CPU loop with fused multiply-
+ * add, and reproducible).  PLANNED adds per-panel partial sums in panel order (a regrouping: equal to 1e-12 for f64);
+ * for matrices with very uneven row lengths some rows are shared by several lane groups and folded with LDS atomics,
+ * so the last bits of those rows can differ from run to run.  Callers that need run-to-run bitwise reproducibility
+ * pass MX_SPMM_ROWWAVE (the exports: MXGPU_SPMM_ALGO=1).
  * npanels <= 0 / wg_per_cu <= 0 pick defaults. */
 typedef enum { MX_SPMM_AUTO = 0, MX_SPMM_ROWWAVE = 1, MX_SPMM_SLAB = 2, MX_SPMM_PLANNED = 3 } mx_spmm_algo;
 int mxd_spmm_csr_dense_ex(int m, int n, int K,

@@ -392,6 +392,16 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
         e["cpu_baseline"] = {"value": round(2 * nnz / ta / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port",
                              "single_thread": {"value": round(2 * nnz / t1 / 1e9, 3), "unit": "GFLOP/s", "cores": 1},
                              "sample": "the whole cfg3 SpMV, matmul_csr_dvec restated (OpenMP over rows), best of 3"}
+    # the same product through a kept plan (entries regrouped by column panel so that v sits in LDS): what a solver that
+    # multiplies by the same X every iteration gets; the plan build is reported beside it, never inside the figure
+    A.spmv_plan(); torch.cuda.synchronize(); A.drop_spmv_plan()     # (the first build also pays for the allocator's first big blocks)
+    t0 = time.perf_counter(); A.spmv_plan(); torch.cuda.synchronize(); t_build = time.perf_counter() - t0
+    yp = D.spmv_planned(A, v)
+    errp = float(np.max(np.abs(yp.cpu().numpy() - ref)) / np.max(np.abs(ref)))
+    assert errp <= 1e-12, f"planned SpMV differs from the oracle: {errp}"
+    tp = timeit(lambda: D.spmv_planned(A, v), reps=20)
+    e["steady_state_kept_plan"] = {"ms": round(tp * 1e3, 4), "GFLOP/s": round(2 * nnz / tp / 1e9, 1), "roofline": roofline(byts, tp),
+                                   "plan_build_ms": round(t_build * 1e3, 3), "parity_max_err_over_max_abs_vs_oracle": errp}
     res["spmv_cfg3"] = e
 
     # ---- configs[2] gather of 200k random rows

@@ -188,6 +188,20 @@ int mxd_spmv_csr_dvec_ex(int m, int K, int64_t nnz,
                          const int32_t *indptr, const int32_t *indices, const double *values,
                          const void *v, int v_dtype, void *y, int algo, void *stream);
 
+/* Planned SpMV for repeated products with the same matrix (csrc/spmv_plan.hip): the plan regroups A's entries by
+ * (block of 4096 rows, panel of 6144 columns) so that the kernel can keep the panel of v it needs in LDS instead of
+ * gathering v[j] from L2 — the gather, not the (j, a) stream, bounds the one-shot kernels.  Build once per matrix
+ * (about the cost of two one-shot products; one internal stream sync), run against any number of vectors of any of
+ * the four kinds.  K <= 64 * 6144 columns.  Sums: panels in ascending order, entries of a row inside a panel added with
+ * LDS atomics — equal to the reference to 1e-12 (f64) / 1e-5 (float32 kind), not bitwise; the one-shot MX_SPMV_FLAT
+ * kernel is the bit-exact path. */
+typedef struct mx_spmv_plan mx_spmv_plan;
+int mxd_spmv_plan_create(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+                         void *stream, mx_spmv_plan **plan);
+int mxd_spmv_plan_info(const mx_spmv_plan *plan, int *npanels, int64_t *padded_entries);
+int mxd_spmv_plan_run(const mx_spmv_plan *plan, const void *v, int v_dtype, void *y, void *stream);
+int mxd_spmv_plan_destroy(mx_spmv_plan *plan);
+
 /* diagnostic (tools/spmv_stamps.py): a device buffer of 8 x ceil(nnz / 23552) uint64 makes MX_SPMV_TILE run its stamped
  * build, which records the shader clock at its phase boundaries per workgroup; NULL switches back */
 int mxd_debug_spmv_tile_stamps(void *stamps_dev);

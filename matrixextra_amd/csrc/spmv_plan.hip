@@ -1,0 +1,258 @@
+// spmv_plan.hip — planned SpMV for repeated products with the same matrix (X %*% v inside an iterative solver: the
+// L-BFGS loop of the reference's vignette calls it hundreds of times with one X).
+//
+// A one-shot SpMV is bound by the v[j] gather, not by the (j, a) stream: 32 M scattered 8-byte reads of a 0.8 MB vector
+// move 32 M 128-byte lines from L2 into the CUs, 131 us at the L2's request rate, against 64 us for the stream alone
+// (profiles/r02_spmv_ceiling.json).  Taking the gather off the L2 path needs the entries grouped by COLUMN PANEL so that
+// the panel of v they touch can sit in LDS — a regrouping that costs more than one product (a pass over A), hence a plan:
+//   * rows in blocks of 4096, columns in panels of 6144 (48 KiB of f64); the plan holds, for every (row block, panel),
+//     the block's entries of that panel as (row-in-block << 13 | column-in-panel, value), 12 bytes per entry like the CSR
+//     arrays, segments padded to 4 entries;
+//   * one 1024-thread workgroup per row block keeps the block's 4096 sums in LDS (32 KiB) and two panel buffers
+//     (2 x 48 KiB): while it streams panel p's segment — 16 B per lane, fully coalesced, the only HBM traffic — and adds
+//     a * v_lds[c] into the row's sum (fire-and-forget ds_add_f64), the next panel of v comes in through registers.
+//     v is read once per row block (0.8 MB per 1.5 MB of entries, from L2, coalesced).
+// Measured (cfg3, MI355X): DESIGN.md §4.3.  Summation order: per row, panels in ascending order; inside a panel the
+// entries of a row are added with LDS atomics in whatever order their wavefronts arrive: equal to the reference to
+// 1e-12 (f64), not bitwise and not run-to-run reproducible in the last bit — the one-shot flat kernel (spmv_flat.hip) is
+// the bit-exact path.  float32 kind: sums kept in f64, rounded once (the reference rounds after every term: 1e-5).
+#include "mx_common.h"
+#include <new>
+
+namespace mx {
+
+int exclusive_scan_i32(const int32_t *counts, int64_t n, int32_t *out, int64_t *total_dev, void *workspace, hipStream_t st);
+size_t scan_workspace_bytes(int64_t n);
+
+constexpr int SP_RB = 4096;                  // rows per block (one workgroup)
+constexpr int SP_PANEL = 6144;               // columns per panel: 48 KiB of f64
+constexpr int SP_THREADS = 1024;
+constexpr int SP_MAX_PANELS = 64;
+constexpr int SP_COL_BITS = 13;              // entry = row_in_block << 13 | col_in_panel  (row 4096 = the padding's dummy row)
+static_assert(SP_PANEL <= (1 << SP_COL_BITS), "column field");
+
+// entries of row block `rb` per panel, rounded up to 4 (segments are read 4 entries per lane)
+__global__ __launch_bounds__(SP_THREADS)
+void spmv_plan_count_kernel(int m, int npanels, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                            int32_t *__restrict__ counts)
+{
+    __shared__ int hist[SP_MAX_PANELS];
+    const int rb = blockIdx.x;
+    if (threadIdx.x < SP_MAX_PANELS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int r0 = rb * SP_RB, r1 = min(r0 + SP_RB, m);
+    const int s = indptr[r0], e = indptr[r1];
+    for (int k = s + threadIdx.x; k < e; k += SP_THREADS) atomicAdd(&hist[min(max(indices[k], 0) / SP_PANEL, npanels - 1)], 1);   // (ids outside [0, K) are the caller's bug: kept from corrupting memory)
+    __syncthreads();
+    if ((int)threadIdx.x < npanels) counts[(size_t)rb * npanels + threadIdx.x] = (hist[threadIdx.x] + 3) & ~3;
+}
+
+// scatter: the block's entries are read flat (coalesced); an entry's row comes from a binary search of the block's row
+// pointers held in LDS, its position from the segment start + an LDS cursor per panel (so the order of a segment's
+// entries varies from build to build — the sums' last bits with it)
+__global__ __launch_bounds__(SP_THREADS)
+void spmv_plan_fill_kernel(int m, int npanels, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                           const double *__restrict__ values, const int32_t *__restrict__ seg_off,
+                           int32_t *__restrict__ ent, double *__restrict__ val)
+{
+    __shared__ int cursor[SP_MAX_PANELS];
+    __shared__ int ip[SP_RB + 1];
+    const int rb = blockIdx.x;
+    if (threadIdx.x < SP_MAX_PANELS) cursor[threadIdx.x] = 0;
+    const int r0 = rb * SP_RB, r1 = min(r0 + SP_RB, m), nr = r1 - r0;
+    for (int i = threadIdx.x; i <= nr; i += SP_THREADS) ip[i] = indptr[r0 + i];
+    __syncthreads();
+    const int32_t *__restrict__ so = seg_off + (size_t)rb * npanels;
+    const int s = ip[0], e = ip[nr];
+    for (int k = s + threadIdx.x; k < e; k += SP_THREADS) {
+        int lo = 0, hi = nr;                                     // the row r with ip[r] <= k < ip[r + 1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ip[mid] <= k) lo = mid; else hi = mid; }
+        const int col = max(indices[k], 0), pan = min(col / SP_PANEL, npanels - 1);
+        const int pos = so[pan] + atomicAdd(&cursor[pan], 1);
+        ent[pos] = (lo << SP_COL_BITS) | min(col - pan * SP_PANEL, SP_PANEL - 1);
+        val[pos] = values[k];
+    }
+    __syncthreads();
+    // padding up to the rounded segment length: the dummy row SP_RB, column 0, value 0
+    for (int pan = threadIdx.x >> 2; pan < npanels; pan += SP_THREADS >> 2) {
+        const int pos = so[pan] + cursor[pan] + (threadIdx.x & 3);
+        if (pos < so[pan + 1]) { ent[pos] = SP_RB << SP_COL_BITS; val[pos] = 0.0; }
+    }
+}
+
+// v[cbase + c] as f64 (NA_INTEGER / NA_LOGICAL -> NA_real bits, logical -> 0 / 1: matmul.cpp:406-411)
+template <int KIND>
+__device__ __forceinline__ double sp_factor(const void *__restrict__ v_, int j)
+{
+    if constexpr (KIND == MX_F64) return ((const double *)v_)[j];
+    else if constexpr (KIND == MX_F32) return (double)((const float *)v_)[j];
+    else {
+        const int yv = ((const int32_t *)v_)[j];
+        if (yv == MX_NA_INT) return __longlong_as_double((long long)MX_NA_REAL_BITS);
+        if constexpr (KIND == MX_LGL) return (double)(yv != 0); else return (double)yv;
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(SP_THREADS)
+void spmv_plan_kernel(int m, int K, int npanels, const int32_t *__restrict__ seg_off, const int32_t *__restrict__ ent,
+                      const double *__restrict__ val, const void *__restrict__ v_, void *__restrict__ y_)
+{
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int PER = SP_PANEL / SP_THREADS;                        // panel elements staged per thread (6)
+    __shared__ double acc[SP_RB + 8];                                 // + the padding's dummy row
+    __shared__ double vpan[2][SP_PANEL];
+    const int tid = threadIdx.x, rb = blockIdx.x;
+    for (int i = tid; i < SP_RB + 8; i += SP_THREADS) acc[i] = 0.0;
+    const int32_t *__restrict__ so = seg_off + (size_t)rb * npanels;
+    // panel 0 -> buffer 0
+    double stage[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) { const int c = i * SP_THREADS + tid; stage[i] = c < K ? sp_factor<KIND>(v_, c) : 0.0; }
+#pragma unroll
+    for (int i = 0; i < PER; i++) vpan[0][i * SP_THREADS + tid] = stage[i];
+    __syncthreads();
+    for (int p = 0; p < npanels; p++) {
+        const double *__restrict__ vp = vpan[p & 1];
+        // the next panel's elements are requested now and written to the other buffer after this panel's stream
+        const int cb_next = (p + 1) * SP_PANEL;
+        if (p + 1 < npanels) {
+#pragma unroll
+            for (int i = 0; i < PER; i++) { const int c = cb_next + i * SP_THREADS + tid; stage[i] = c < K ? sp_factor<KIND>(v_, c) : 0.0; }
+        }
+        const int s = so[p], e = so[p + 1];                           // multiples of 4
+        for (int k0 = s + tid * 4; k0 < e; k0 += SP_THREADS * 4 * 2) {
+            // two quads per thread and trip: 6 loads in flight
+            const int k1 = k0 + SP_THREADS * 4;
+            const bool two = k1 < e;
+            const i4 c0 = *reinterpret_cast<const i4 *>(ent + k0);
+            const d2 a0 = *reinterpret_cast<const d2 *>(val + k0), a1 = *reinterpret_cast<const d2 *>(val + k0 + 2);
+            const int kb = two ? k1 : k0;
+            const i4 c1 = *reinterpret_cast<const i4 *>(ent + kb);
+            const d2 b0 = *reinterpret_cast<const d2 *>(val + kb), b1 = *reinterpret_cast<const d2 *>(val + kb + 2);
+            const double av[4] = {a0[0], a0[1], a1[0], a1[1]}, bv[4] = {b0[0], b0[1], b1[0], b1[1]};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double f = vp[c0[q] & ((1 << SP_COL_BITS) - 1)];
+                double t = av[q] * f;
+                if constexpr (KIND == MX_I32 || KIND == MX_LGL) t = __double_as_longlong(f) == (long long)MX_NA_REAL_BITS ? f : t;
+                __hip_atomic_fetch_add(&acc[c0[q] >> SP_COL_BITS], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (two) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const double f = vp[c1[q] & ((1 << SP_COL_BITS) - 1)];
+                    double t = bv[q] * f;
+                    if constexpr (KIND == MX_I32 || KIND == MX_LGL) t = __double_as_longlong(f) == (long long)MX_NA_REAL_BITS ? f : t;
+                    __hip_atomic_fetch_add(&acc[c1[q] >> SP_COL_BITS], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        if (p + 1 < npanels) {
+#pragma unroll
+            for (int i = 0; i < PER; i++) vpan[(p + 1) & 1][i * SP_THREADS + tid] = stage[i];
+        }
+        __syncthreads();               // the next panel is in LDS; every wavefront is done with this one's buffer and sums
+    }
+    const int r0 = rb * SP_RB;
+    for (int i = tid; i < SP_RB && r0 + i < m; i += SP_THREADS) {
+        const double sum = acc[i];
+        if constexpr (KIND == MX_F32) ((float *)y_)[r0 + i] = (float)sum;
+        else if constexpr (KIND == MX_I32 || KIND == MX_LGL) ((double *)y_)[r0 + i] = sum != sum ? na_real() : sum;
+        else ((double *)y_)[r0 + i] = sum;
+    }
+}
+
+}  // namespace mx
+
+struct mx_spmv_plan {
+    int m = 0, K = 0, nrb = 0, npanels = 0;
+    long long nnz = 0, slots = 0;
+    int32_t *seg_off = nullptr;
+    int32_t *ent = nullptr;
+    double *val = nullptr;
+};
+
+extern "C" int mxd_spmv_plan_destroy(mx_spmv_plan *pl)
+{
+    if (!pl) return 0;
+    if (pl->seg_off) (void)hipFree(pl->seg_off);
+    if (pl->ent) (void)hipFree(pl->ent);
+    if (pl->val) (void)hipFree(pl->val);
+    delete pl;
+    return 0;
+}
+
+extern "C" int mxd_spmv_plan_create(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+                                    void *stream, mx_spmv_plan **plan_out)
+{
+    using namespace mx;
+    MX_REQUIRE(plan_out && m >= 0 && K >= 0, "mxd_spmv_plan_create: bad arguments");
+    const int npanels = (int)ceil_div(K > 0 ? K : 1, SP_PANEL);
+    MX_REQUIRE(npanels <= SP_MAX_PANELS, "mxd_spmv_plan_create: more than %d columns (use the one-shot kernels)", SP_MAX_PANELS * SP_PANEL);
+    mx_spmv_plan *pl = new (std::nothrow) mx_spmv_plan();
+    MX_REQUIRE(pl, "out of host memory");
+    pl->m = m; pl->K = K; pl->npanels = npanels; pl->nrb = (int)ceil_div(m, SP_RB);
+    *plan_out = pl;
+    if (m == 0) return 0;
+    hipStream_t st = as_stream(stream);
+    const int64_t nseg = (int64_t)pl->nrb * npanels;
+    int32_t *counts = nullptr;
+    void *scan_ws = nullptr;
+    int rc = 1;
+    do {
+        if (hipMalloc((void **)&counts, (size_t)nseg * 4 + 16) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
+        if (hipMalloc(&scan_ws, scan_workspace_bytes(nseg) + 16) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
+        if (hipMalloc((void **)&pl->seg_off, ((size_t)nseg + 1) * 4) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
+        hipLaunchKernelGGL(spmv_plan_count_kernel, dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, m, npanels, indptr, indices, counts);
+        if (exclusive_scan_i32(counts, nseg, pl->seg_off, (int64_t *)scan_ws, scan_ws, st)) break;
+        long long total = 0;
+        if (read_back_small(&total, scan_ws, sizeof(total), st)) break;
+        if (total > (long long)INT_MAX) { set_error("spmv plan: too many entries"); break; }
+        pl->slots = total;
+        if (hipMalloc((void **)&pl->ent, (size_t)total * 4 + 64) != hipSuccess || hipMalloc((void **)&pl->val, (size_t)total * 8 + 64) != hipSuccess) {
+            set_error("spmv plan: allocation failed");
+            break;
+        }
+        hipLaunchKernelGGL(spmv_plan_fill_kernel, dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, m, npanels, indptr, indices, values,
+                           pl->seg_off, pl->ent, pl->val);
+        if (hipGetLastError() != hipSuccess) { set_error("spmv plan: launch failed"); break; }
+        if (hipStreamSynchronize(st) != hipSuccess) { set_error("spmv plan: build failed"); break; }     // scratch is freed below
+        rc = 0;
+    } while (0);
+    if (counts) (void)hipFree(counts);
+    if (scan_ws) (void)hipFree(scan_ws);
+    if (rc) { mxd_spmv_plan_destroy(pl); *plan_out = nullptr; }
+    return rc;
+}
+
+extern "C" int mxd_spmv_plan_info(const mx_spmv_plan *pl, int *npanels, int64_t *padded_entries)
+{
+    MX_REQUIRE(pl, "mxd_spmv_plan_info: null plan");
+    if (npanels) *npanels = pl->npanels;
+    if (padded_entries) *padded_entries = pl->slots;
+    return 0;
+}
+
+extern "C" int mxd_spmv_plan_run(const mx_spmv_plan *pl, const void *v, int v_dtype, void *y, void *stream)
+{
+    using namespace mx;
+    MX_REQUIRE(pl && y, "mxd_spmv_plan_run: bad arguments");
+    if (pl->m == 0) return 0;
+    MX_REQUIRE(v || pl->K == 0, "mxd_spmv_plan_run: null vector");
+    hipStream_t st = as_stream(stream);
+#define MX_SP(KIND)                                                                                                  \
+    hipLaunchKernelGGL((spmv_plan_kernel<KIND>), dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, pl->m, pl->K,     \
+                       pl->npanels, pl->seg_off, pl->ent, pl->val, v, y)
+    switch (v_dtype) {
+        case MX_F64: MX_SP(MX_F64); break;
+        case MX_I32: MX_SP(MX_I32); break;
+        case MX_LGL: MX_SP(MX_LGL); break;
+        case MX_F32: MX_SP(MX_F32); break;
+        default: return set_error("mxd_spmv_plan_run: unsupported vector dtype %d", v_dtype);
+    }
+#undef MX_SP
+    MX_LAUNCH_CHECK();
+    return 0;
+}

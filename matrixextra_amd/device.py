@@ -37,6 +37,7 @@ class DeviceCSR:
     _sorted: bool | None = None
     _plan: object = None
     _plan_panels: int = -1
+    _spmv_plan: object = None
 
     def plan(self, npanels: int = 0, rebuild: bool = False):
         """Device-resident SpMM plan (mxd_spmm_plan_create); cached per DeviceCSR, buffers re-used on rebuild."""
@@ -54,10 +55,26 @@ class DeviceCSR:
         check(lib.mxd_spmm_plan_info(self._plan, C.byref(P), C.byref(padded)))
         return dict(npanels=P.value, padded_entries=padded.value)
 
+    def spmv_plan(self):
+        """Planned-SpMV plan (mxd_spmv_plan_create): built on first use, cached on the DeviceCSR."""
+        if self._spmv_plan is None:
+            handle = C.c_void_p()
+            check(_lib.load().mxd_spmv_plan_create(C.c_int(self.m), C.c_int(self.K), _dp(self.indptr), _dp(self.indices),
+                                                   _dp(self.values), _stream(), C.byref(handle)))
+            self._spmv_plan = handle
+        return self._spmv_plan
+
+    def drop_spmv_plan(self):
+        if self._spmv_plan is not None:
+            _lib.load().mxd_spmv_plan_destroy(self._spmv_plan)
+            self._spmv_plan = None
+
     def __del__(self):
         try:
             if self._plan is not None:
                 _lib.load().mxd_spmm_plan_destroy(self._plan)
+            if self._spmv_plan is not None:
+                _lib.load().mxd_spmv_plan_destroy(self._spmv_plan)
         except Exception:
             pass
 
@@ -154,6 +171,19 @@ def spmv(A: DeviceCSR, v: torch.Tensor, v_dtype=None, out=None, algo: int = 0):
     assert int(v.numel()) == A.K and v.is_contiguous()
     check(lib.mxd_spmv_csr_dvec_ex(C.c_int(A.m), C.c_int(A.K), C.c_int64(A.nnz), _dp(A.indptr), _dp(A.indices),
                                    _dp(A.values), _dp(v), C.c_int(v_dtype), _dp(out), C.c_int(algo), _stream()))
+    return out
+
+
+def spmv_planned(A: DeviceCSR, v: torch.Tensor, v_dtype=None, out=None):
+    """y = A @ v through the planned kernel (v's panels staged in LDS); the plan is built on first use and kept on A."""
+    lib = _lib.load()
+    if v_dtype is None:
+        v_dtype = {torch.float64: MX_F64, torch.float32: MX_F32}[v.dtype]
+    odt = torch.float32 if v_dtype == MX_F32 else torch.float64
+    if out is None:
+        out = torch.empty(A.m, dtype=odt, device=v.device)
+    assert int(v.numel()) == A.K and v.is_contiguous()
+    check(lib.mxd_spmv_plan_run(A.spmv_plan(), _dp(v), C.c_int(v_dtype), _dp(out), _stream()))
     return out
 
 

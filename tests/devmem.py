@@ -103,3 +103,26 @@ def merge_fused_device(op, p1, j1, x1, p2, j2, x2):
                                   d[5].ptr, C.c_int64(n2), dp.ptr, dj.ptr, dx.ptr, ws.ptr, C.byref(nnz), None))
     n = int(nnz.value)
     return dp.download(np.int32, (m + 1,)), dj.download(np.int32, (max(bound, 1),))[:n], dx.download(vdt, (max(bound, 1),))[:n]
+
+
+def spmv_plan_device(p, j, x, vectors):
+    """[A @ v for (v, v_dtype) in vectors] through ONE planned-SpMV plan (mxd_spmv_plan_create / _run)."""
+    lib = _lib.load()
+    m = p.size - 1
+    K = vectors[0][0].size
+    dp, dj, dx = Dev(p.astype(np.int32)), Dev(j.astype(np.int32)), Dev(x.astype(np.float64))
+    plan = C.c_void_p()
+    check(lib.mxd_spmv_plan_create(C.c_int(m), C.c_int(K), dp.ptr, dj.ptr, dx.ptr, None, C.byref(plan)))
+    outs = []
+    try:
+        for v, v_dtype in vectors:
+            dv = Dev(v)
+            odt = np.float32 if v_dtype == _lib.MX_F32 else np.float64
+            dy = Dev(nbytes=max(m, 1) * np.dtype(odt).itemsize)
+            check(lib.mx_dev_memset(dy.ptr, 0xFF, C.c_size_t(dy.nbytes), None))
+            check(lib.mxd_spmv_plan_run(plan, dv.ptr, C.c_int(v_dtype), dy.ptr, None))
+            check(lib.mx_stream_sync(None))
+            outs.append(dy.download(odt, (m,)))
+    finally:
+        lib.mxd_spmv_plan_destroy(plan)
+    return outs

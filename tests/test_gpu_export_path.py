@@ -147,3 +147,30 @@ def test_sharded_export_on_one_gpu(gpu):
         _lib.check(lib.mx_set_devices(None, 0))
     with pytest.raises(_lib.MxError):
         _lib.check(lib.mx_set_devices((C.c_int * 1)(99), 1))
+
+
+def test_export_spmv_uses_a_plan_for_a_cached_matrix(gpu):
+    """matmul_csr_dvec_* on a matrix that is still on the device from the previous call goes through the planned kernel
+    (v's panels in LDS): same answers (1e-12) as the one-shot kernel of the first call, all four kinds."""
+    lib = _lib.load()
+    lib.mx_cache_invalidate(None)
+    m, K = 300_000, 50_000
+    p, j, x = synth.csr_fixed(m, K, 20, seed=6)                      # 6 M entries: above the planning threshold
+    rng = np.random.default_rng(2)
+    v = rng.normal(size=K)
+    first = G.matmul_csr_dvec_numeric(p, j, x, v)                    # miss: one-shot flat kernel, bitwise the oracle's loop
+    ref = O.matmul_csr_dvec_numeric(p, j, x, v)
+    np.testing.assert_array_equal(first, ref)
+    again = G.matmul_csr_dvec_numeric(p, j, x, v)                    # hit: plan built, planned kernel
+    np.testing.assert_allclose(again, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    v2 = rng.normal(size=K)
+    np.testing.assert_allclose(G.matmul_csr_dvec_numeric(p, j, x, v2), O.matmul_csr_dvec_numeric(p, j, x, v2), rtol=1e-12,
+                               atol=1e-12)
+    vi = rng.integers(-5, 6, size=K).astype(np.int32)
+    vi[::97] = -2147483648
+    gi, ri = G.matmul_csr_dvec_integer(p, j, x, vi), O.matmul_csr_dvec_integer(p, j, x, vi)
+    np.testing.assert_array_equal(np.isnan(gi), np.isnan(ri))
+    np.testing.assert_allclose(gi[~np.isnan(ri)], ri[~np.isnan(ri)], rtol=1e-12, atol=1e-12)
+    vf = v.astype(np.float32)
+    np.testing.assert_allclose(G.matmul_csr_dvec_float32(p, j, x, vf), O.matmul_csr_dvec_float32(p, j, x, vf), rtol=1e-5, atol=1e-5)
+    assert _cache_stats(lib)["hits"] >= 4

@@ -131,3 +131,57 @@ def test_tile_refuses_what_it_cannot_run(gpu):
         spmv_device(p, j, x, v, _lib.MX_F64, TILE)
     got = spmv_device(p, j, x, v + 1.0, _lib.MX_F64, 0)               # AUTO falls back to the lane-group kernel
     np.testing.assert_allclose(got, np.add.reduceat(x, p[:-1]), rtol=1e-12)
+
+
+# ----------------------------------------------------------------------------- planned SpMV (csrc/spmv_plan.hip)
+def _check_planned(p, j, x, K, seed):
+    from devmem import spmv_plan_device
+    rng = np.random.default_rng(seed)
+    v = rng.normal(size=K)
+    vf = v.astype(np.float32)
+    vi = rng.integers(-9, 9, size=K).astype(np.int32)
+    vl = rng.integers(0, 2, size=K).astype(np.int32)
+    for k in rng.integers(0, K, size=max(1, K // 50)):
+        vi[k] = NA
+        vl[k] = NA
+    got = spmv_plan_device(p, j, x, [(v, _lib.MX_F64), (vf, _lib.MX_F32), (vi, _lib.MX_I32), (vl, _lib.MX_LGL)])
+    ref = O.matmul_csr_dvec_numeric(p, j, x, v)
+    np.testing.assert_allclose(got[0], ref, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(ref).max()))
+    reff = O.matmul_csr_dvec_float32(p, j, x, vf)
+    assert got[1].dtype == np.float32
+    np.testing.assert_allclose(got[1], reff, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(reff).max()))
+    for g, of, vv in ((got[2], O.matmul_csr_dvec_integer, vi), (got[3], O.matmul_csr_dvec_logical, vl)):
+        r = of(p, j, x, vv)
+        np.testing.assert_array_equal(np.isnan(g), np.isnan(r))
+        ok = ~np.isnan(r)
+        np.testing.assert_allclose(g[ok], r[ok], rtol=1e-12, atol=1e-12 * max(1.0, np.abs(r[ok]).max(initial=0)))
+        if (~ok).any():
+            assert (g[~ok].view(np.uint64) & 0xFFFFFFFF == 1954).all()       # NA_real_ where an NA element is touched
+
+
+@pytest.mark.parametrize("m,K,dens", [(60, 25, 0.3), (1, 10, 0.9), (500, 700, 0.02), (5000, 6144, 0.002), (4097, 6145, 0.003),
+                                      (9000, 40_000, 0.0008), (300, 13_000, 0.05)])
+def test_planned_spmv_shapes_all_kinds(gpu, m, K, dens):
+    p, j, x = rand_csr(m, K, dens, seed=m + K, sorted_cols=False, empty_rows=(0,) if m > 2 else ())
+    _check_planned(p, j, x, K, seed=K)
+
+
+def test_planned_spmv_headline_shape_ragged_and_duplicates(gpu):
+    p, j, x = synth.csr_fixed(30_000, 100_000, 32, seed=4)                  # 17 panels, 8 row blocks
+    _check_planned(p, j, x, 100_000, seed=1)
+    rng = np.random.default_rng(8)
+    lens = rng.integers(0, 70, size=10_000)
+    lens[rng.random(10_000) < 0.3] = 0
+    lens[17] = 30_000                                                       # one row with more entries than a block's share
+    p, j, x = ragged_csr(lens, 50_000, seed=9, sort=False, dup=True)
+    _check_planned(p, j, x, 50_000, seed=2)
+
+
+def test_planned_spmv_limits(gpu):
+    from devmem import spmv_plan_device
+    p, j, x = synth.csr_fixed(100, 500_000, 8, seed=1)                      # more than 64 panels
+    with pytest.raises(_lib.MxError):
+        spmv_plan_device(p, j, x, [(np.zeros(500_000), _lib.MX_F64)])
+    p0 = np.zeros(11, dtype=np.int32)                                        # a matrix without entries
+    out = spmv_plan_device(p0, np.zeros(0, dtype=np.int32), np.zeros(0), [(np.ones(30), _lib.MX_F64)])
+    np.testing.assert_array_equal(out[0], np.zeros(10))

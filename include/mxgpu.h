@@ -50,8 +50,8 @@ int  mx_device_name(char *buf, size_t buflen);
  * sparse operand into one contiguous range per listed device (mx_partition_rows' balance: 12 bytes up per entry, one result
  * row down per row), run one host thread and three queues per device, and let every device download its rows straight
  * into the caller's result (the result lives on the host: no collective is needed; a device may be listed more than once —
- * its shards then share the GPU).  n = 0 or 1: the calling thread's current device only (default).  Everything else stays
- * on the current device. */
+ * its shards then share the GPU).  n = 1: that device becomes the calling thread's current device; n = 0: the current
+ * device, unsharded (default).  Everything else stays on the current device. */
 int  mx_set_devices(const int *devices, int n);
 /* the row cuts that sharding uses: cuts[0 .. nparts], part k = rows [cuts[k], cuts[k+1]) — host arithmetic only */
 int  mx_partition_rows(const int32_t *indptr, int nrows, int nparts, int dense_cols, int dense_bytes, int *cuts);

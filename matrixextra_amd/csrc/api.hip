@@ -722,6 +722,7 @@ int mx_set_devices(const int *devices, int n)
     int count = 0;
     MX_HIP(hipGetDeviceCount(&count));
     for (int k = 0; k < n; k++) MX_REQUIRE(devices[k] >= 0 && devices[k] < count, "mx_set_devices: no device %d", devices[k]);
+    if (n == 1) MX_HIP(hipSetDevice(devices[0]));                 // one device: it becomes the calling thread's current device
     std::lock_guard<std::mutex> lk(g_devices_mu);
     g_devices.assign(devices, devices + n);
     return 0;

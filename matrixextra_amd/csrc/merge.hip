@@ -104,7 +104,10 @@ void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
                         int32_t *__restrict__ counts)
 {
     const int lg = threadIdx.x % G;
-    const long long grp = (long long)blockIdx.x * (MERGE_BLOCK / G) + threadIdx.x / G;
+    // G = 64: the lane group is the wavefront, so its rows — and their row pointers — are wave-uniform: read once through
+    // the scalar cache instead of 64 identical lanes through the texture path (PMC: TA_BUSY 70 % of the count kernel)
+    const int grp_in_block = G == 64 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : (int)threadIdx.x / G;
+    const long long grp = (long long)blockIdx.x * (MERGE_BLOCK / G) + grp_in_block;
     int s1[COUNT_U], n1[COUNT_U], s2[COUNT_U], n2[COUNT_U], a[COUNT_U], b[COUNT_U];
 #pragma unroll
     for (int u = 0; u < COUNT_U; u++) {
@@ -217,7 +220,8 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
 {
     constexpr bool INTERSECT = (OP == MX_OP_MUL || OP == MX_OP_AND);
     const int lg = threadIdx.x % G;
-    const long long grp = (long long)blockIdx.x * (MERGE_BLOCK / G) + threadIdx.x / G;
+    const int grp_in_block = G == 64 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : (int)threadIdx.x / G;   // see merge_count_kernel
+    const long long grp = (long long)blockIdx.x * (MERGE_BLOCK / G) + grp_in_block;
     const unsigned long long below = (1ULL << lg) - 1ULL;   // lg < 64 always
     int s1[FILL_U], n1[FILL_U], s2[FILL_U], n2[FILL_U], o[FILL_U], a[FILL_U], b[FILL_U];
     VT xa[FILL_U], xb[FILL_U];

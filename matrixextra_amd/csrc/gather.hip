@@ -29,6 +29,63 @@ void gather_lengths_kernel(int r, const int32_t *__restrict__ indptr, const int3
     if (i < r) { const int row = rows[i]; lens[i] = indptr[row + 1] - indptr[row]; }
 }
 
+// new_indptr of the gather in ONE launch: row lengths, their scan (decoupled look-back over the tiles' totals) and the
+// grand total — lengths -> three scan launches cost more in launch gaps than in work for r = 200 k.  A thread sizes
+// GC_ITEMS consecutive output rows (all 2 * GC_ITEMS row-pointer gathers in flight).
+constexpr int GC_ITEMS = 8;
+constexpr int GC_TILE = GATHER_BLOCK * GC_ITEMS;
+__global__ __launch_bounds__(GATHER_BLOCK)
+void gather_count_kernel(int r, const int32_t *__restrict__ indptr, const int32_t *__restrict__ rows,
+                         int32_t *__restrict__ new_indptr, unsigned long long *__restrict__ tile_state,
+                         unsigned *__restrict__ ticket, long long *__restrict__ total_out, int ntiles)
+{
+    __shared__ int s_tile;
+    __shared__ long long s_base;
+    __shared__ int wave_tot[GATHER_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int tile = s_tile;
+    const long long i0 = (long long)tile * GC_TILE + (long long)tid * GC_ITEMS;
+    int row[GC_ITEMS], len[GC_ITEMS];
+#pragma unroll
+    for (int k = 0; k < GC_ITEMS; k++) row[k] = i0 + k < r ? rows[i0 + k] : -1;
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < GC_ITEMS; k++) {
+        const int rr = row[k] >= 0 ? row[k] : 0;
+        const int a = indptr[rr], b = indptr[rr + 1];
+        len[k] = row[k] >= 0 ? b - a : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < GC_ITEMS; k++) sum += len[k];
+    int incl = sum;
+#pragma unroll
+    for (int o2 = 1; o2 < 64; o2 <<= 1) { const int up = __shfl_up(incl, o2, 64); if (lane >= o2) incl += up; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int wbase = 0, tile_total = 0;
+#pragma unroll
+    for (int w = 0; w < GATHER_BLOCK / 64; w++) { wbase += w < wave ? wave_tot[w] : 0; tile_total += wave_tot[w]; }
+    if (wave == 0) {
+        const long long excl = lookback_exclusive<4>(tile_state, tile, tile_total);
+        if (lane == 0) {
+            s_base = excl;
+            if (tile == ntiles - 1) {
+                *total_out = excl + tile_total;
+                new_indptr[r] = excl + tile_total <= (long long)INT_MAX ? (int32_t)(excl + tile_total) : INT_MAX;
+            }
+        }
+    }
+    __syncthreads();
+    long long run = s_base + wbase + incl - sum;
+#pragma unroll
+    for (int k = 0; k < GC_ITEMS; k++) {
+        if (i0 + k < r) new_indptr[i0 + k] = (int32_t)run;
+        run += len[k];
+    }
+}
+
 template <int G, typename VT, bool HAS_VALUES>
 __global__ __launch_bounds__(GATHER_BLOCK)
 void gather_copy_kernel(int r, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
@@ -274,17 +331,19 @@ extern "C" int mxd_csr_gather_count(int r, const int32_t *indptr, const int32_t 
     MX_REQUIRE(r >= 0, "mxd_csr_gather_count: negative r");
     MX_REQUIRE(new_indptr && workspace, "mxd_csr_gather_count: null pointer");
     hipStream_t st = mx::as_stream(stream);
-    int32_t *lens = (int32_t *)workspace;
-    const size_t lens_bytes = ((size_t)(r > 0 ? r : 1) * sizeof(int32_t) + 15) & ~(size_t)15;
-    void *scan_ws = (char *)workspace + lens_bytes;
-    if (r > 0) {
-        hipLaunchKernelGGL(mx::gather_lengths_kernel, dim3((unsigned)mx::ceil_div(r, mx::GATHER_BLOCK)),
-                           dim3(mx::GATHER_BLOCK), 0, st, r, indptr, rows_take, lens);
+    // workspace: [int64 total][uint32 ticket, pad][uint64 tile_state[ntiles]]  (fits mxd_gather_workspace_bytes(r))
+    int64_t *total_dev = (int64_t *)workspace;
+    if (r == 0) {
+        MX_HIP(hipMemsetAsync(new_indptr, 0, sizeof(int32_t), st));
+        MX_HIP(hipMemsetAsync(total_dev, 0, sizeof(int64_t), st));
+    } else {
+        const int ntiles = (int)mx::ceil_div(r, mx::GC_TILE);
+        MX_HIP(hipMemsetAsync(workspace, 0, 16 + (size_t)ntiles * 8, st));
+        hipLaunchKernelGGL(mx::gather_count_kernel, dim3((unsigned)ntiles), dim3(mx::GATHER_BLOCK), 0, st, r, indptr, rows_take,
+                           new_indptr, (unsigned long long *)((char *)workspace + 16), (unsigned *)((char *)workspace + 8),
+                           (long long *)total_dev, ntiles);
         MX_LAUNCH_CHECK();
     }
-    int64_t *total_dev = (int64_t *)scan_ws;
-    const int rc = mx::exclusive_scan_i32(lens, r, new_indptr, total_dev, scan_ws, st);
-    if (rc) return rc;
     if (nnz_out_host) {
         if (mx::read_back_small(nnz_out_host, total_dev, sizeof(int64_t), st)) return 1;
         MX_REQUIRE(*nnz_out_host <= (int64_t)INT_MAX, "result has %lld entries: exceeds R's int32 index range",

@@ -300,7 +300,6 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
 constexpr int FUSED_WAVES = 8;
 constexpr int FUSED_BLOCK = FUSED_WAVES * 64;
 constexpr int FUSED_LOOK = 8;                         // windows of 64 predecessor tiles read per look-back round trip
-constexpr unsigned long long FUSED_FLAG_AGG = 1ULL << 62, FUSED_FLAG_PRE = 2ULL << 62, FUSED_VALUE = (1ULL << 62) - 1;
 
 // rows per tile: FUSED_STEPS row steps per wavefront (64 / G rows each)
 constexpr int FUSED_STEPS = 32;
@@ -384,53 +383,9 @@ void merge_fused_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
     __syncthreads();
     const long long tile_total = cnt[TILE_ROWS];
 
-    // ---- decoupled look-back: exclusive prefix of the tile totals
+    // ---- decoupled look-back over the tiles' totals (mx_common.h)
     if (wave == 0) {
-        long long excl = 0;
-        if (tile == 0) {
-            if (lane == 0)
-                __hip_atomic_store(&tile_state[0], FUSED_FLAG_PRE | (unsigned long long)tile_total, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (lane == 0)
-                __hip_atomic_store(&tile_state[tile], FUSED_FLAG_AGG | (unsigned long long)tile_total, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            // A tile that is still counting or looking back itself only offers its own total, so the nearest known prefix
-            // is typically as many tiles back as are in flight: FUSED_LOOK windows of 64 predecessors per round trip.
-            int look = tile - 1;                                      // window u, lane i: tile look - 64 u - i
-            for (;;) {
-                unsigned long long st[FUSED_LOOK];
-#pragma unroll
-                for (int u = 0; u < FUSED_LOOK; u++) {
-                    const int t = look - 64 * u - lane;
-                    st[u] = FUSED_FLAG_PRE;                           // before tile 0: an empty prefix
-                    if (t >= 0) st[u] = __hip_atomic_load(&tile_state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                bool done = false, stalled = false;
-#pragma unroll
-                for (int u = 0; u < FUSED_LOOK; u++) {
-                    if (done || stalled) continue;                    // uniform
-                    const unsigned long long empty = __ballot((st[u] >> 62) == 0);
-                    const unsigned long long pre = __ballot((st[u] >> 62) == 2);
-                    // usable part of the window: the lanes before the first empty one, cut after the first prefix
-                    const int first_empty = empty ? __builtin_ctzll(empty) : 64;
-                    const int first_pre = pre ? __builtin_ctzll(pre) : 64;
-                    const int upto = first_pre < first_empty ? first_pre + 1 : first_empty;
-                    long long v = lane < upto ? (long long)(st[u] & FUSED_VALUE) : 0;
-#pragma unroll
-                    for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2, 64);
-                    excl += v;
-                    look -= upto;
-                    if (first_pre < first_empty) done = true;         // reached a tile that knows its prefix
-                    else if (upto < 64) stalled = true;               // a tile that has not published yet: read again from there
-                }
-                if (done) break;
-                if (stalled) __builtin_amdgcn_s_sleep(1);
-            }
-            if (lane == 0)
-                __hip_atomic_store(&tile_state[tile], FUSED_FLAG_PRE | (unsigned long long)(excl + tile_total),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const long long excl = lookback_exclusive<FUSED_LOOK>(tile_state, tile, tile_total);
         if (lane == 0) {
             s_base = excl;
             if (tile == ntiles - 1) {

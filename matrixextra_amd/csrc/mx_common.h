@@ -99,6 +99,61 @@ __device__ __forceinline__ int r_logical_xor(int x, int y)
     return (x != 0) != (y != 0);
 }
 
+// Decoupled look-back over per-tile totals (one 64-bit word per tile: 2 flag bits + value; relaxed agent-scope loads /
+// stores — the value travels in the same word as its flag, so nothing else needs ordering).  Called by ONE whole
+// wavefront of the tile's workgroup; tiles must be numbered in starting order (atomic ticket) so that every predecessor
+// is running or done.  Publishes this tile's total, returns the sum of the totals of all earlier tiles (wave-uniform)
+// and publishes the inclusive prefix.  LOOK windows of 64 predecessors are read per round trip: a tile that is still in
+// flight only offers its own total, so the nearest known prefix is about as many tiles back as are resident.
+constexpr unsigned long long LB_FLAG_AGG = 1ULL << 62, LB_FLAG_PRE = 2ULL << 62, LB_VALUE = (1ULL << 62) - 1;
+template <int LOOK>
+__device__ __forceinline__ long long lookback_exclusive(unsigned long long *__restrict__ tile_state, int tile, long long tile_total)
+{
+    const int lane = lane_id();
+    long long excl = 0;
+    if (tile == 0) {
+        if (lane == 0)
+            __hip_atomic_store(&tile_state[0], LB_FLAG_PRE | (unsigned long long)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0)
+        __hip_atomic_store(&tile_state[tile], LB_FLAG_AGG | (unsigned long long)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int look = tile - 1;                                              // window u, lane i: tile look - 64 u - i
+    for (;;) {
+        unsigned long long st[LOOK];
+#pragma unroll
+        for (int u = 0; u < LOOK; u++) {
+            const int t = look - 64 * u - lane;
+            st[u] = LB_FLAG_PRE;                                      // before tile 0: an empty prefix
+            if (t >= 0) st[u] = __hip_atomic_load(&tile_state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool done = false, stalled = false;
+#pragma unroll
+        for (int u = 0; u < LOOK; u++) {
+            if (done || stalled) continue;                            // uniform
+            const unsigned long long empty = __ballot((st[u] >> 62) == 0);
+            const unsigned long long pre = __ballot((st[u] >> 62) == 2);
+            // usable part of the window: the lanes before the first empty one, cut after the first prefix
+            const int first_empty = empty ? __builtin_ctzll(empty) : 64;
+            const int first_pre = pre ? __builtin_ctzll(pre) : 64;
+            const int upto = first_pre < first_empty ? first_pre + 1 : first_empty;
+            long long v = lane < upto ? (long long)(st[u] & LB_VALUE) : 0;
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2, 64);
+            excl += v;
+            look -= upto;
+            if (first_pre < first_empty) done = true;                 // reached a tile that knows its prefix
+            else if (upto < 64) stalled = true;                       // a tile that has not published yet: read again from there
+        }
+        if (done) break;
+        if (stalled) __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane == 0)
+        __hip_atomic_store(&tile_state[tile], LB_FLAG_PRE | (unsigned long long)(excl + tile_total), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
 // first position in [first, first+count) whose value is >= key
 __device__ __forceinline__ int lower_bound_dev(const int32_t *__restrict__ first, int count, int key)
 {

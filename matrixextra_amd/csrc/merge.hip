@@ -28,6 +28,7 @@
 // written; the count pass re-reads the indices (8 nnz) on top of that.
 #include "mx_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace mx {
 
@@ -52,23 +53,24 @@ __device__ __forceinline__ unsigned long long group_ballot(bool pred)
 // lower_bound(key) in a sorted row held one entry per lane (lane u of the group holds tbl = entry u, lanes past
 // the row's end hold INT_MAX): binary search whose probes are cross-lane reads (ds_bpermute), not memory loads.
 // Returns the count of entries < key (0..G) and whether entry[count] == key.
+// The count and fill kernels are bound by VALU issue, not by memory (a wave64 VALU instruction occupies its SIMD for
+// four cycles; the first version of this search cost ~100 of them per row pair), so the search is branch-free and works
+// on byte addresses: log2(G) probes "is entry[lo + s - 1] < key" for s = G/2 .. 1 leave lo = #entries < key among the
+// first G - 1, one more probe at lo settles the last entry and the hit.  Three VALU instructions per probe
+// (compare, select, add; the constant part of the address rides in the instruction's offset field).
 template <int G>
 __device__ __forceinline__ int group_lower_bound(int tbl, int key, bool &hit)
 {
-    int lo = 0, len = G;
+    const int base4 = G == 64 ? 0 : (lane_id() & ~(G - 1)) << 2;      // byte address of the group's lane 0
+    int lo4 = base4;
 #pragma unroll
-    for (int it = 0; it < 7; it++) {                  // ceil(log2(64)) + 1 probes at most
-        if ((1 << it) > G) break;
-        const int half = len >> 1;
-        const int probe = __shfl(tbl, lo + half, G);  // all lanes take part; finished lanes ignore the value
-        if (len > 0) {
-            if (probe < key) { lo += half + 1; len -= half + 1; }
-            else len = half;
-        }
+    for (int s = G / 2; s >= 1; s >>= 1) {
+        const int probe = __builtin_amdgcn_ds_bpermute(lo4 + (s - 1) * 4, tbl);
+        lo4 += probe < key ? s * 4 : 0;
     }
-    const int at = __shfl(tbl, lo < G ? lo : G - 1, G);
-    hit = at == key;                                   // tbl[G-1] < key when lo == G, so no false hit
-    return lo;
+    const int at = __builtin_amdgcn_ds_bpermute(lo4, tbl);             // all lanes of the group take part
+    hit = at == key;
+    return ((lo4 - base4) >> 2) + (at < key ? 1 : 0);
 }
 
 // hits / output length of a row pair that does not fit the lane group (searches in memory); uniform inside the group
@@ -96,6 +98,11 @@ __device__ __forceinline__ int count_row_slow(int lg, const int32_t *__restrict_
 
 // Every lane group sizes COUNT_U consecutive row pairs per call: the row pointers of all of them, then the index loads
 // of all of them, are in flight together (one pair at a time — three dependent loads — ran at 1.8 TB/s).
+// Measured at the cfg4 shape (2M x 2M, 50 + 50 per row pair, 888 MB read): 0.385 ms with the first, branchy search
+// (VALU issue: ~100 instructions per row pair), 0.28 ms with group_lower_bound as it is now, 0.21 ms with the search
+// taken out (the floor of this load structure, 4.2 TB/s).  Tried and dropped: staging the workgroup's index window
+// through LDS with flat 16-byte loads (0.37-0.42 ms before the search was cheap; 0.44 ms as a persistent workgroup with
+// the next tile's loads in registers — 85 % of the wave cycles waiting), COUNT_U = 8 (0.29 ms).
 constexpr int COUNT_U = 4;
 template <int G, bool INTERSECT>
 __global__ __launch_bounds__(MERGE_BLOCK)

@@ -13,6 +13,14 @@
  *             the R .Call shim — can allocate R vectors of the right length
  *             and have the D2H copy land directly in them).  Synchronous at
  *             return, as the reference is (SURVEY §8b "Threading").
+ *             Large host buffers are registered with the HIP runtime for the
+ *             duration of a call (direct DMA).  R calls from one thread; a host
+ *             that calls from several threads at once must not hand the SAME
+ *             host buffer to two concurrent calls (one call's unregistration can
+ *             pull the range from under the other's copy: the HIP runtime aborts
+ *             with "Memobj map does not have ptr").  The sharded path
+ *             (mx_set_devices) does share its inputs between its own worker
+ *             threads and therefore registers them once, in the calling thread.
  *
  *  (2) mxd_*  "device level": the same operations on DEVICE pointers, enqueued
  *             on a caller-supplied hipStream_t (passed as void*), no

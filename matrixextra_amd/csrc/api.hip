@@ -15,10 +15,35 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <csignal>
+#include <execinfo.h>
+#include <unistd.h>
 
 namespace mx {
 
 static thread_local char g_err[512] = "";
+
+// MXGPU_ABORT_BACKTRACE=1 (debugging aid): native frames of the thread that raised SIGABRT / SIGSEGV on stderr, then the
+// default action.  Installed when the library is loaded; does nothing unless the variable is set.
+static void fatal_backtrace(int sig)
+{
+    const char msg[] = "\n[mxgpu] fatal signal, native frames of the raising thread:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static const bool g_backtrace_installed = [] {
+    const char *e = getenv("MXGPU_ABORT_BACKTRACE");
+    if (!e || atoi(e) != 1) return false;
+    void *warm[4];
+    (void)backtrace(warm, 4);                                        // loads the unwinder now, not inside the handler
+    signal(SIGABRT, fatal_backtrace);
+    signal(SIGSEGV, fatal_backtrace);
+    return true;
+}();
 
 int set_error(const char *fmt, ...)
 {
@@ -319,18 +344,45 @@ static Lanes &lanes() { static thread_local Lanes l; return l; }
 // which register whole interior pages only.
 constexpr size_t PIN_WHOLE_MIN = (size_t)64 << 20;
 struct Pin {
-    const void *p = nullptr;
+    const void *p = nullptr;                                     // start of the registered range
+    size_t bytes = 0;
     bool ok = false;
-    bool pin(const void *ptr, size_t bytes, bool all_devices = false)
+    bool pin(const void *ptr, size_t nbytes, bool all_devices = false)
     {
-        ok = bytes >= PIN_WHOLE_MIN && mx::pin_host(ptr, bytes, all_devices);
-        p = ptr;
+        ok = nbytes >= PIN_WHOLE_MIN && mx::pin_host(ptr, nbytes, all_devices);
+        p = ptr; bytes = nbytes;
         return ok;
     }
     // a page-aligned piece of a buffer that is registered piece by piece (the pieces must not share pages)
-    bool pin_pages(const void *ptr, size_t bytes) { ok = mx::pin_host(ptr, bytes, false); p = ptr; return ok; }
+    bool pin_pages(const void *ptr, size_t nbytes) { ok = mx::pin_host(ptr, nbytes, false); p = ptr; bytes = nbytes; return ok; }
+    // the whole pages INSIDE a buffer of any size, for every device: what the coordinating thread of a sharded call
+    // registers once for an input that all its workers read.  (The workers must not register such a buffer themselves:
+    // while one of them unregisters its range another one's hipMemcpy may have just found that range in the runtime's
+    // map — "Memobj map does not have ptr", abort.  Seen with B between 16 and 64 MiB on three workers.)
+    bool pin_inside(const void *ptr, size_t nbytes)
+    {
+        const uintptr_t a = ((uintptr_t)ptr + 4095) & ~(uintptr_t)4095, b = ((uintptr_t)ptr + nbytes) & ~(uintptr_t)4095;
+        ok = b > a && b - a >= ((size_t)4 << 20) && mx::pin_host((const void *)a, b - a, true);
+        p = (const void *)a; bytes = b - a;
+        return ok;
+    }
     ~Pin() { if (ok) mx::unpin_host(p); }
 };
+
+// [src, src + nbytes) of a host buffer -> device: the part inside `pin`'s registered range as one asynchronous DMA on
+// `st`, whatever lies outside (edge pages; everything when nothing is registered) by plain synchronous copies.
+static bool upload_through(const Pin &pin, void *dst, const void *src, size_t nbytes, hipStream_t st)
+{
+    if (nbytes == 0) return true;
+    const char *s0 = (const char *)src, *s1 = s0 + nbytes;
+    const char *r0 = pin.ok ? std::max(s0, (const char *)pin.p) : s1;
+    const char *r1 = pin.ok ? std::min(s1, (const char *)pin.p + pin.bytes) : s1;
+    if (r1 <= r0) return hipMemcpy(dst, src, nbytes, hipMemcpyHostToDevice) == hipSuccess;
+    bool ok = hipMemcpyAsync((char *)dst + (r0 - s0), r0, (size_t)(r1 - r0), hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok && r0 > s0) ok = hipMemcpy(dst, s0, (size_t)(r0 - s0), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && s1 > r1) ok = hipMemcpy((char *)dst + (r1 - s0), r1, (size_t)(s1 - r1), hipMemcpyHostToDevice) == hipSuccess;
+    return ok;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Several GPUs behind the same export (mx_set_devices): the rows of A are cut into one contiguous range per
@@ -375,9 +427,10 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
     partition_rows(indptr, m, nd, 12.0, (double)n * sizeof(real_t), cut.data());
     // host memory registered for every device; `gate` opens once the result is registered (downloads wait for it)
     Pin pinB, pinJ, pinX, pinC;
-    // (arrays too small to own their pages, or that cannot be registered, go up through xfer_h2d inside every shard)
-    const bool dirB = pinB.pin(B_host, b_bytes, true);
-    const bool dirA = pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz, true) && pinX.pin(values, sizeof(double) * (size_t)nnz, true);
+    // (large arrays as a whole, smaller ones by their interior pages; what cannot be registered goes up by plain copies)
+    if (!pinB.pin(B_host, b_bytes, true)) pinB.pin_inside(B_host, b_bytes);
+    if (!pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz, true)) pinJ.pin_inside(indices, sizeof(int32_t) * (size_t)nnz);
+    if (!pinX.pin(values, sizeof(double) * (size_t)nnz, true)) pinX.pin_inside(values, sizeof(double) * (size_t)nnz);
     std::mutex gate_mu;
     std::condition_variable gate_cv;
     int gate = 0;                                                // 0 closed, 1 result registered, -1 registration failed
@@ -403,20 +456,14 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
             return;
         }
         const size_t ldc_k = colmajor ? (size_t)mk : ldc;
-        bool ok = dirB ? hipMemcpyAsync(dB.p, B_host, b_bytes, hipMemcpyHostToDevice, L.up) == hipSuccess
-                       : mx::xfer_h2d(dB.p, B_host, b_bytes) == 0;
-        if (ok && !dirA && e_hi > e_lo)
-            ok = mx::xfer_h2d(dj.p, indices + e_lo, sizeof(int32_t) * (size_t)(e_hi - e_lo)) == 0 &&
-                 mx::xfer_h2d(dx.p, values + e_lo, sizeof(double) * (size_t)(e_hi - e_lo)) == 0;
+        bool ok = upload_through(pinB, dB.p, B_host, b_bytes, L.up);
         std::vector<int> bc((size_t)nblk + 1);
         for (int b = 0; b <= nblk; b++) bc[b] = (int)((int64_t)mk * b / nblk);
         for (int b = 0; b < nblk && ok; b++) {
             const int64_t e0 = p_local[bc[b]], e1 = p_local[bc[b + 1]];
-            if (e1 > e0 && dirA) {
-                ok = ok && hipMemcpyAsync(dj.as<int32_t>() + e0, indices + e_lo + e0, sizeof(int32_t) * (size_t)(e1 - e0),
-                                          hipMemcpyHostToDevice, L.up) == hipSuccess;
-                ok = ok && hipMemcpyAsync(dx.as<double>() + e0, values + e_lo + e0, sizeof(double) * (size_t)(e1 - e0),
-                                          hipMemcpyHostToDevice, L.up) == hipSuccess;
+            if (e1 > e0) {
+                ok = ok && upload_through(pinJ, dj.as<int32_t>() + e0, indices + e_lo + e0, sizeof(int32_t) * (size_t)(e1 - e0), L.up);
+                ok = ok && upload_through(pinX, dx.as<double>() + e0, values + e_lo + e0, sizeof(double) * (size_t)(e1 - e0), L.up);
             }
             ok = ok && hipEventRecord(L.ev[b], L.up) == hipSuccess;
         }

@@ -11,11 +11,12 @@ p1, j1, x1 = synth.csr_fixed(m, K, 50)
 p2, j2, x2 = synth.csr_overlapping(p1, j1, K, 50)
 print(f"generated in {time.time() - t0:.0f} s", flush=True)
 A, B = D.DeviceCSR.from_host(p1, j1, x1, K), D.DeviceCSR.from_host(p2, j2, x2, K)
+fused = len(sys.argv) > 1 and sys.argv[1] == "fused"          # the one-pass kernel instead of count -> scan -> fill
 for name, op in (("add", _lib.MX_OP_ADD), ("sub", _lib.MX_OP_SUB), ("mul", _lib.MX_OP_MUL)):
-    R = D.csr_elemwise(op, A, B); torch.cuda.synchronize()
+    R = D.csr_elemwise(op, A, B, two_pass=not fused); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(5): R = D.csr_elemwise(op, A, B)
+    for _ in range(5): R = D.csr_elemwise(op, A, B, two_pass=not fused)
     b.record(); torch.cuda.synchronize()
     t = a.elapsed_time(b) / 5 * 1e-3
     byts = 2 * (12 * A.nnz + 4 * (m + 1)) + 12 * R.nnz + 4 * (m + 1)

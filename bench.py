@@ -148,6 +148,28 @@ def committed_traffic(kernel_sub, workload_tag, kernel_avg_ms):
     return best
 
 
+def committed_kernels_traffic(kernels, call_ms):
+    """For a neighbouring operation timed as a whole call: the summed HBM-side bytes per call of the kernels it launches,
+    from the committed multi-kernel PMC summary (profiles/*_extras_pmc.json, tools/prof_summary_multi.py).  `kernels` =
+    [(name in the summary, launches per call)].  Refused (None) when a kernel is missing or when the kernels' summed
+    duration in that profile does not fit the call just timed (more than 5 % above it, or under 60 % of it): a changed
+    kernel with a stale profile reports null, not old counters."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extras_pmc.json")), reverse=True):
+        try:
+            ks = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        if any(k not in ks for k, _ in kernels):
+            continue
+        ns = sum(ks[k]["avg_ns"] * c for k, c in kernels)
+        if not (0.6 * call_ms <= ns / 1e6 <= 1.05 * call_ms):
+            continue
+        return {"traffic": int(sum(ks[k]["total_corrected"] * c for k, c in kernels)),
+                "traffic_source": os.path.relpath(f, ROOT), "traffic_kernels_ms": round(ns / 1e6, 4)}
+    return {}
+
+
 def roofline(alg_bytes, seconds, **extra):
     ach = alg_bytes / seconds / 1e9
     d = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -384,7 +406,8 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
     ref = O.matmul_csr_dvec_numeric(p, j, x, v_host, threads)
     err = float(np.max(np.abs(y.cpu().numpy() - ref)) / np.max(np.abs(ref)))
     assert err <= 1e-12, f"SpMV differs from the oracle: {err}"
-    e = {"ms": round(t * 1e3, 4), "GFLOP/s": round(2 * nnz / t / 1e9, 1), "roofline": roofline(byts, t),
+    e = {"ms": round(t * 1e3, 4), "GFLOP/s": round(2 * nnz / t / 1e9, 1),
+         "roofline": roofline(byts, t, **committed_kernels_traffic([("spmv_flat_kernel", 1), ("slice_rows_kernel", 1)], t * 1e3)),
          "parity_max_err_over_max_abs_vs_oracle": err}
     if want_cpu:
         ta, t1 = cpu_time(lambda: O.matmul_csr_dvec_numeric(p, j, x, v_host, threads), 3), \
@@ -400,7 +423,8 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
     errp = float(np.max(np.abs(yp.cpu().numpy() - ref)) / np.max(np.abs(ref)))
     assert errp <= 1e-12, f"planned SpMV differs from the oracle: {errp}"
     tp = timeit(lambda: D.spmv_planned(A, v), reps=20)
-    e["steady_state_kept_plan"] = {"ms": round(tp * 1e3, 4), "GFLOP/s": round(2 * nnz / tp / 1e9, 1), "roofline": roofline(byts, tp),
+    e["steady_state_kept_plan"] = {"ms": round(tp * 1e3, 4), "GFLOP/s": round(2 * nnz / tp / 1e9, 1),
+                                   "roofline": roofline(byts, tp, **committed_kernels_traffic([("spmv_plan_kernel", 1)], tp * 1e3)),
                                    "plan_build_ms": round(t_build * 1e3, 3), "parity_max_err_over_max_abs_vs_oracle": errp}
     res["spmv_cfg3"] = e
 
@@ -414,7 +438,8 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
     gp, gj, gx = g.to_host()
     assert np.array_equal(gp, o["indptr"]) and np.array_equal(gj, o["indices"]) and np.array_equal(gx, o["values"]), \
         "row gather differs from the oracle"
-    e = {"ms": round(t * 1e3, 4), "nnz_out": g.nnz, "Mnnz/s": round(g.nnz / t / 1e6, 1), "roofline": roofline(byts, t),
+    e = {"ms": round(t * 1e3, 4), "nnz_out": g.nnz, "Mnnz/s": round(g.nnz / t / 1e6, 1),
+         "roofline": roofline(byts, t, **committed_kernels_traffic([("gather_count_kernel", 1), ("gather_copy_kernel", 1)], t * 1e3)),
          "parity": "bit-exact vs oracle (indptr, indices, values)"}
     if want_cpu:
         t1 = cpu_time(lambda: O.copy_csr_rows_numeric(p, j, x, rows_host), 3)
@@ -446,7 +471,10 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
             np.array_equal(R.indices[:n_s].cpu().numpy(), o["indices"]) and \
             np.array_equal(R.values[:n_s].cpu().numpy(), o["values"]), f"CSR {name} CSR differs from the oracle"
         e = {"ms": round(t * 1e3, 4), "nnz_in": [A1.nnz, A2.nnz], "nnz_out": R.nnz,
-             "Gnnz_in/s": round((A1.nnz + A2.nnz) / t / 1e9, 2), "roofline": roofline(byts, t),
+             "Gnnz_in/s": round((A1.nnz + A2.nnz) / t / 1e9, 2),
+             "roofline": roofline(byts, t, **committed_kernels_traffic(
+                 [("merge_count_kernel<64, true>" if name == "mul" else "merge_count_kernel<64, false>", 1),
+                  ("merge_fill_kernel<64, %d" % op, 1)], t * 1e3)),
              "parity": f"bit-exact vs oracle on the first {rs} rows (indptr, indices, values)"}
         if want_cpu:
             t1 = cpu_time(ofn, 2)
@@ -461,7 +489,8 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
     A1._sorted = None
     t = timeit(lambda: (setattr(A1, "_sorted", None), A1.rows_sorted()), reps=10)
     byts = 4 * (m4 + 1) + 4 * A1.nnz
-    res["rows_sorted_check_cfg4"] = {"ms": round(t * 1e3, 4), "roofline": roofline(byts, t)}
+    res["rows_sorted_check_cfg4"] = {"ms": round(t * 1e3, 4),
+                                     "roofline": roofline(byts, t, **committed_kernels_traffic([("rows_sorted_count_kernel", 1)], t * 1e3))}
     del A1, A2, p1, j1, x1, p2, j2, x2
     torch.cuda.empty_cache()
 

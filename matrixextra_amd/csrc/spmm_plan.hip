@@ -49,7 +49,7 @@ constexpr int PLAN_ROW_SHIFT = 25;                 // entry = col (25 bits) | sl
 //                  sum_p ceil(T_p / 8) long — at most 7 padding slots per panel.
 // The count pass picks the dealt layout when it saves at least one chunk of 32 steps: rows of equal length stay in the
 // bundle layout (no padding at all), log-normal row lengths (sigma 1: bundle layout 1.84x the CSR) are dealt.
-constexpr int PLAN_LD = 4;
+constexpr int PLAN_LD = 8;
 // col / panel_cols without the integer divide: float estimate (col < 2^25 is exact in float up to 2^24, so one
 // correction step either way), clamped to the last panel
 __device__ __forceinline__ int panel_of(int col, int panel_cols, float inv_pc, int npanels)

@@ -99,8 +99,8 @@ __device__ __forceinline__ int count_row_slow(int lg, const int32_t *__restrict_
 // Every lane group sizes COUNT_U consecutive row pairs per call: the row pointers of all of them, then the index loads
 // of all of them, are in flight together (one pair at a time — three dependent loads — ran at 1.8 TB/s).
 // Measured at the cfg4 shape (2M x 2M, 50 + 50 per row pair, 888 MB read): 0.385 ms with the first, branchy search
-// (VALU issue: ~100 instructions per row pair), 0.28 ms with group_lower_bound as it is now, 0.21 ms with the search
-// taken out (the floor of this load structure, 4.2 TB/s).  Tried and dropped: staging the workgroup's index window
+// (VALU issue: ~100 instructions per row pair), 0.28 ms with group_lower_bound as it is now, 0.21-0.24 ms with the
+// COUNT_U searches behind one fit test (below) — 0.21 ms is this load structure with the search taken out (4.2 TB/s).  Tried and dropped: staging the workgroup's index window
 // through LDS with flat 16-byte loads (0.37-0.42 ms before the search was cheap; 0.44 ms as a persistent workgroup with
 // the next tile's loads in registers — 85 % of the wave cycles waiting), COUNT_U = 8 (0.29 ms).
 constexpr int COUNT_U = 4;
@@ -130,20 +130,37 @@ void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
         a[u] = lg < n1[u] && n1[u] <= G ? j1[s1[u] + lg] : INT_MAX;
         b[u] = lg < n2[u] && n2[u] <= G ? j2[s2[u] + lg] : INT_MAX;
     }
+    // One test for all COUNT_U pairs: when every row fits its lane group (the normal case) the searches are straight-line
+    // code, and the compiler interleaves their dependent chains of cross-lane reads (~100 cycles a probe).
+    bool big = false;
 #pragma unroll
-    for (int u = 0; u < COUNT_U; u++) {
-        const long long row = grp * COUNT_U + u;
-        int c;
-        if (__ballot(n1[u] > G || n2[u] > G) == 0ULL) {
-            // every row of this wavefront fits its lane group: both rows live in registers
+    for (int u = 0; u < COUNT_U; u++) big = big || n1[u] > G || n2[u] > G;
+    int c[COUNT_U];
+    if (__ballot(big) == 0ULL) {
+#pragma unroll
+        for (int u = 0; u < COUNT_U; u++) {
             bool hit;
             group_lower_bound<G>(b[u], a[u], hit);
             const int hits = __popcll(group_ballot<G>(hit && lg < n1[u]));
-            c = INTERSECT ? hits : n1[u] + n2[u] - hits;
-        } else {
-            c = count_row_slow<G, INTERSECT>(lg, j1 + s1[u], n1[u], j2 + s2[u], n2[u]);
+            c[u] = INTERSECT ? hits : n1[u] + n2[u] - hits;
         }
-        if (row < m && lg == 0) counts[row] = c;
+    } else {
+#pragma unroll
+        for (int u = 0; u < COUNT_U; u++) {
+            if (__ballot(n1[u] > G || n2[u] > G) == 0ULL) {
+                bool hit;
+                group_lower_bound<G>(b[u], a[u], hit);
+                const int hits = __popcll(group_ballot<G>(hit && lg < n1[u]));
+                c[u] = INTERSECT ? hits : n1[u] + n2[u] - hits;
+            } else {
+                c[u] = count_row_slow<G, INTERSECT>(lg, j1 + s1[u], n1[u], j2 + s2[u], n2[u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < COUNT_U; u++) {
+        const long long row = grp * COUNT_U + u;
+        if (row < m && lg == 0) counts[row] = c[u];
     }
 }
 
@@ -292,127 +309,96 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
 // =====================================================================================================
 // One pass over the inputs: merge_fused_kernel.
 //
-// count -> scan -> fill reads the index arrays twice.  Here a 256-thread workgroup owns a tile of consecutive row pairs
-// (F3<G>::TILE_ROWS: ~4096 / G, i.e. about as many entries whatever the row length):
-//   0. the tile's row pointers -> LDS; every wavefront at once requests the VALUES of all its rows (F3_STEPS row steps of
-//      64 / G rows, one entry per lane: they are only needed in the last phase and stay in flight meanwhile);
-//   1. the tile's index windows — contiguous in both operands — come in with flat 16-byte loads and stay in LDS;
-//   2. the rows' output lengths from cross-lane searches over rows read out of LDS; exclusive scan inside the tile;
-//   3. the tile's place in the output from a decoupled look-back over the tiles' totals (mx_common.h: one 64-bit word
-//      per tile, 2 flag bits + value, relaxed agent-scope loads / stores; tiles numbered by an atomic ticket so that every
-//      predecessor of a running tile has started);
-//   4. the entries are placed: rows from LDS again, values from the registers of step 0.
-// So every input byte is read from memory once.  The caller provides out_indices / out_values for the upper bound
-// (nnz1 + nnz2, or min(nnz1, nnz2) for the intersection) like the reference's own scratch arrays (operators.cpp:402-406,
-// :139-143); nnz_out comes back with the last tile.  A tile whose windows do not fit LDS (rows far above the mean) or
-// operands that are not 16-byte aligned read their rows from memory in phases 2 and 4; row pairs that do not fit a lane
-// group take the searches in global memory, as in the two-pass kernels.
-// History: the first form kept two row steps per wavefront in flight and re-read the indices in the second phase
-// (1.59 ms at cfg4, 1.40-1.46 with the cheaper search; two-pass 1.12-1.18): too few bytes in flight per CU.
+// count -> scan -> fill reads the index arrays twice (the count pass re-reads 8 nnz bytes and, one row pair per lane
+// group with three dependent loads, ran at 1.8 TB/s: 0.45 of the 1.55 ms of CSR + CSR at 2M x 2M / nnz 1e8).  Here a
+// 512-thread workgroup takes a tile of consecutive rows, every wavefront K row steps of 64 / G rows each: all loads of
+// the K steps are issued up front (both rows of a pair, one entry per lane, stay in registers), the rows' output lengths
+// come from the cross-lane searches, and the tile's position in the output comes from a decoupled look-back over the
+// tiles' totals (one 64-bit word per tile: 2 flag bits + value, relaxed agent-scope loads / stores — the value travels
+// in the same word as its flag, so nothing else needs ordering; tiles are numbered by an atomic ticket so that every
+// predecessor of a running tile has started).  The entries are then placed from the registers.  The caller provides
+// out_indices / out_values for the upper bound (nnz1 + nnz2, or min(nnz1, nnz2) for the intersection) like the
+// reference's own scratch arrays (operators.cpp:402-406, :139-143); nnz_out comes back with the last tile.
+// Row pairs that do not fit a lane group take the searches in global memory (both phases), as in the two-pass kernels.
+//
+// Measured at cfg4 (2M x 2M, nnz 1e8 each): 1.40-1.46 ms for `+`, the two-pass form 1.07-1.11 ms — this kernel is the
+// opt-in alternative (MXGPU_MERGE_FUSED=1), not the default.  A third form was tried and dropped: 64-row tiles whose index
+// windows are staged in LDS by flat 16-byte loads and whose values are requested up front (every input byte read from
+// memory once, searches out of LDS in batches of four): 1.55-1.60 ms.  Taken apart on the device: 1.14 ms with the
+// look-back removed, 1.07-1.2 ms with count AND fill removed — the tile protocol itself (31 k tickets on one address at
+// ~10 ns each, two dependent load round trips and three barriers per 134 KB tile, four 512-thread workgroups per CU)
+// costs what the whole two-pass merge does.
 // =====================================================================================================
-constexpr int F3_BLOCK = 256;
-constexpr int F3_WAVES = F3_BLOCK / 64;
-constexpr int F3_STEPS = 16;                           // row steps per wavefront (64 / G rows each)
-constexpr int F3_CAP = 4096;                           // index entries of one operand staged per tile
-constexpr int FUSED_LOOK = 8;                          // windows of 64 predecessor tiles read per look-back round trip
-template <int G> struct F3 {
-    static constexpr int RPS = 64 / G, WAVE_ROWS = RPS * F3_STEPS, TILE_ROWS = F3_WAVES * WAVE_ROWS;
-};
+constexpr int FUSED_WAVES = 8;
+constexpr int FUSED_BLOCK = FUSED_WAVES * 64;
+constexpr int FUSED_LOOK = 8;                         // windows of 64 predecessor tiles read per look-back round trip
+
+// rows per tile: FUSED_STEPS row steps per wavefront (64 / G rows each)
+constexpr int FUSED_STEPS = 32;
+constexpr int FUSED_U = 2;                             // row steps whose loads are in flight together
 
 template <int G, int OP, typename VT>
-__global__ __launch_bounds__(F3_BLOCK)
+__global__ __launch_bounds__(FUSED_BLOCK)
 void merge_fused_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__restrict__ j1, const VT *__restrict__ x1,
                         const int32_t *__restrict__ p2, const int32_t *__restrict__ j2, const VT *__restrict__ x2,
                         int32_t *__restrict__ po, int32_t *__restrict__ jo, VT *__restrict__ xo,
                         unsigned long long *__restrict__ tile_state, unsigned *__restrict__ ticket,
-                        long long *__restrict__ total_out, int ntiles, int aligned)
+                        long long *__restrict__ total_out, int ntiles)
 {
     constexpr bool INTERSECT = (OP == MX_OP_MUL || OP == MX_OP_AND);
-    using T = F3<G>;
-    constexpr int PER = (T::TILE_ROWS + F3_BLOCK - 1) / F3_BLOCK;     // rows per thread in the tile's scan
-    __shared__ __attribute__((aligned(16))) int32_t la[F3_CAP + 4], lb[F3_CAP + 4];
-    __shared__ int32_t lp1[T::TILE_ROWS + 1], lp2[T::TILE_ROWS + 1];
-    __shared__ int cnt[T::TILE_ROWS + 1];                             // output length of every row, then its exclusive offset
+    constexpr int RPS = 64 / G;                                       // rows per wavefront and step
+    constexpr int WAVE_ROWS = RPS * FUSED_STEPS;
+    constexpr int TILE_ROWS = FUSED_WAVES * WAVE_ROWS;
+    constexpr int PER = (TILE_ROWS + FUSED_BLOCK - 1) / FUSED_BLOCK;  // rows per thread in the tile's scan
+    __shared__ int cnt[TILE_ROWS + 1];                                // output length of every row, then its exclusive offset
     __shared__ int s_tile;
     __shared__ long long s_base;
-    __shared__ int wave_tot[F3_WAVES];
+    __shared__ int wave_tot[FUSED_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane % G, grp = lane / G;
     if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);                 // tiles in starting order: predecessors are running or done
     __syncthreads();
     const int tile = s_tile;
-    const long long row0 = (long long)tile * T::TILE_ROWS;
-    const int nr = (int)(m - row0 < T::TILE_ROWS ? m - row0 : T::TILE_ROWS);
-    const int wl0 = wave * T::WAVE_ROWS;                              // this wavefront's first row inside the tile
+    const long long row0 = (long long)tile * TILE_ROWS;
+    const int wl0 = wave * WAVE_ROWS;                                 // this wavefront's first row inside the tile
     const unsigned long long below = (1ULL << lg) - 1ULL;
 
-    // ---- 0: row pointers; the values of all my rows requested
-    for (int i = tid; i <= nr; i += F3_BLOCK) { lp1[i] = p1[row0 + i]; lp2[i] = p2[row0 + i]; }
-    __syncthreads();
-    VT xa[F3_STEPS], xb[F3_STEPS];
+    // ---- phase 1: output length of every row of the tile (index arrays only)
+    for (int k0 = 0; k0 < FUSED_STEPS; k0 += FUSED_U) {
+        int s1[FUSED_U], n1[FUSED_U], s2[FUSED_U], n2[FUSED_U], a[FUSED_U], b[FUSED_U];
 #pragma unroll
-    for (int k = 0; k < F3_STEPS; k++) {
-        const int lr = wl0 + k * T::RPS + grp;
-        xa[k] = VT(0); xb[k] = VT(0);
-        if (lr < nr) {
-            const int s1 = lp1[lr], n1 = lp1[lr + 1] - s1, s2 = lp2[lr], n2 = lp2[lr + 1] - s2;
-            if (lg < n1 && n1 <= G && n2 <= G) xa[k] = x1[s1 + lg];
-            if (lg < n2 && n1 <= G && n2 <= G) xb[k] = x2[s2 + lg];
+        for (int u = 0; u < FUSED_U; u++) {
+            const long long row = row0 + wl0 + (k0 + u) * RPS + grp;
+            const bool valid = row < m;
+            const long long rs = valid ? row : 0;
+            const int a0 = p1[rs], a1 = p1[rs + 1], b0 = p2[rs], b1 = p2[rs + 1];
+            s1[u] = a0; n1[u] = valid ? a1 - a0 : 0;
+            s2[u] = b0; n2[u] = valid ? b1 - b0 : 0;
         }
-    }
-    // ---- 1: index windows -> LDS
-    const int sA = lp1[0], eA = lp1[nr], sB = lp2[0], eB = lp2[nr];
-    const int baseA = sA & ~3, baseB = sB & ~3;
-    const bool staged = aligned && eA - baseA <= F3_CAP && eB - baseB <= F3_CAP;       // uniform over the workgroup
-    if (staged) {
-        // an aligned 16-byte chunk that holds one valid entry never leaves that entry's page: reading past e* is safe
-        for (int q = tid * 4; baseA + q < eA; q += F3_BLOCK * 4)
-            *reinterpret_cast<int4 *>(la + q) = *reinterpret_cast<const int4 *>(j1 + baseA + q);
-        for (int q = tid * 4; baseB + q < eB; q += F3_BLOCK * 4)
-            *reinterpret_cast<int4 *>(lb + q) = *reinterpret_cast<const int4 *>(j2 + baseB + q);
-    }
-    __syncthreads();
-    // the two rows of pair `lr`, one entry per lane (INT_MAX past the end); false if the pair does not fit the lane group
-    auto rows_of = [&](auto from_lds, int lr, int &s1, int &n1, int &s2, int &n2, int &a, int &b) {
-        s1 = 0; n1 = 0; s2 = 0; n2 = 0; a = INT_MAX; b = INT_MAX;
-        if (lr < nr) {
-            s1 = lp1[lr]; n1 = lp1[lr + 1] - s1; s2 = lp2[lr]; n2 = lp2[lr + 1] - s2;
-            if (n1 <= G && n2 <= G) {
-                if constexpr (decltype(from_lds)::value) {
-                    if (lg < n1) a = la[s1 - baseA + lg];
-                    if (lg < n2) b = lb[s2 - baseB + lg];
-                } else {
-                    if (lg < n1) a = j1[s1 + lg];
-                    if (lg < n2) b = j2[s2 + lg];
-                }
-            }
+#pragma unroll
+        for (int u = 0; u < FUSED_U; u++) {
+            a[u] = lg < n1[u] && n1[u] <= G ? j1[s1[u] + lg] : INT_MAX;
+            b[u] = lg < n2[u] && n2[u] <= G ? j2[s2[u] + lg] : INT_MAX;
         }
-    };
-
-    // ---- 2: output length of every row of the tile
-    auto count_phase = [&](auto from_lds) {
-#pragma unroll 4
-        for (int k = 0; k < F3_STEPS; k++) {
-            const int lr = wl0 + k * T::RPS + grp;
-            int s1, n1, s2, n2, a, b, c;
-            rows_of(from_lds, lr, s1, n1, s2, n2, a, b);
-            if (__ballot(n1 > G || n2 > G) == 0ULL) {                 // every pair of this step fits its lane group
+#pragma unroll
+        for (int u = 0; u < FUSED_U; u++) {
+            int c;
+            if (__ballot(n1[u] > G || n2[u] > G) == 0ULL) {           // every pair of this step fits its lane group
                 bool hit;
-                group_lower_bound<G>(b, a, hit);
-                const int hits = __popcll(group_ballot<G>(hit && lg < n1));
-                c = INTERSECT ? hits : n1 + n2 - hits;
+                group_lower_bound<G>(b[u], a[u], hit);
+                const int hits = __popcll(group_ballot<G>(hit && lg < n1[u]));
+                c = INTERSECT ? hits : n1[u] + n2[u] - hits;
             } else {
-                c = count_row_slow<G, INTERSECT>(lg, j1 + s1, n1, j2 + s2, n2);
+                c = count_row_slow<G, INTERSECT>(lg, j1 + s1[u], n1[u], j2 + s2[u], n2[u]);
             }
-            if (lg == 0) cnt[lr] = c;                                 // rows past the end: 0 + 0 - 0
+            if (lg == 0) cnt[wl0 + (k0 + u) * RPS + grp] = c;
         }
-    };
-    if (staged) count_phase(std::true_type{}); else count_phase(std::false_type{});
+    }
     __syncthreads();
-    // exclusive scan of the tile's row lengths (in place), tile total
+    // ---- exclusive scan of the tile's row lengths (in place), tile total
     {
         int v[PER], sum = 0;
 #pragma unroll
-        for (int i = 0; i < PER; i++) { const int r = tid * PER + i; v[i] = r < T::TILE_ROWS ? cnt[r] : 0; sum += v[i]; }
+        for (int i = 0; i < PER; i++) { const int r = tid * PER + i; v[i] = r < TILE_ROWS ? cnt[r] : 0; sum += v[i]; }
         int incl = sum;
 #pragma unroll
         for (int o2 = 1; o2 < 64; o2 <<= 1) { const int up = __shfl_up(incl, o2, 64); if (lane >= o2) incl += up; }
@@ -420,16 +406,16 @@ void merge_fused_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
         __syncthreads();
         int wbase = 0;
 #pragma unroll
-        for (int w = 0; w < F3_WAVES; w++) wbase += w < wave ? wave_tot[w] : 0;
+        for (int w = 0; w < FUSED_WAVES; w++) wbase += w < wave ? wave_tot[w] : 0;
         int run = wbase + incl - sum;
 #pragma unroll
-        for (int i = 0; i < PER; i++) { const int r = tid * PER + i; if (r < T::TILE_ROWS) cnt[r] = run; run += v[i]; }
-        if (tid == F3_BLOCK - 1) cnt[T::TILE_ROWS] = run;             // the tile's total
+        for (int i = 0; i < PER; i++) { const int r = tid * PER + i; if (r < TILE_ROWS) cnt[r] = run; run += v[i]; }
+        if (tid == FUSED_BLOCK - 1) cnt[TILE_ROWS] = run;             // the tile's total
     }
     __syncthreads();
-    const long long tile_total = cnt[T::TILE_ROWS];
+    const long long tile_total = cnt[TILE_ROWS];
 
-    // ---- 3: decoupled look-back over the tiles' totals (mx_common.h)
+    // ---- decoupled look-back over the tiles' totals (mx_common.h)
     if (wave == 0) {
         const long long excl = lookback_exclusive<FUSED_LOOK>(tile_state, tile, tile_total);
         if (lane == 0) {
@@ -443,50 +429,66 @@ void merge_fused_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
     __syncthreads();
     const long long base = s_base;
 
-    // ---- 4: place the entries
-    auto fill_phase = [&](auto from_lds) {
+    // ---- phase 2: place the entries (the index arrays come back from L2: the tile read them a moment ago)
+    for (int k0 = 0; k0 < FUSED_STEPS; k0 += FUSED_U) {
+        int s1[FUSED_U], n1[FUSED_U], s2[FUSED_U], n2[FUSED_U], a[FUSED_U], b[FUSED_U];
+        VT xa[FUSED_U], xb[FUSED_U];
 #pragma unroll
-        for (int k = 0; k < F3_STEPS; k++) {
-            const int lr = wl0 + k * T::RPS + grp;
-            int s1, n1, s2, n2, a, b;
-            rows_of(from_lds, lr, s1, n1, s2, n2, a, b);
-            const bool fits = __ballot(n1 > G || n2 > G) == 0ULL;
-            if (lr >= nr) continue;
+        for (int u = 0; u < FUSED_U; u++) {
+            const long long row = row0 + wl0 + (k0 + u) * RPS + grp;
+            const bool valid = row < m;
+            const long long rs = valid ? row : 0;
+            const int a0 = p1[rs], a1 = p1[rs + 1], b0 = p2[rs], b1 = p2[rs + 1];
+            s1[u] = a0; n1[u] = valid ? a1 - a0 : 0;
+            s2[u] = b0; n2[u] = valid ? b1 - b0 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < FUSED_U; u++) {
+            const bool va = lg < n1[u] && n1[u] <= G, vb = lg < n2[u] && n2[u] <= G;
+            a[u] = INT_MAX; b[u] = INT_MAX; xa[u] = VT(0); xb[u] = VT(0);
+            if (va) { a[u] = j1[s1[u] + lg]; xa[u] = x1[s1[u] + lg]; }
+            if (vb) { b[u] = j2[s2[u] + lg]; xb[u] = x2[s2[u] + lg]; }
+        }
+#pragma unroll
+        for (int u = 0; u < FUSED_U; u++) {
+            const int lr = wl0 + (k0 + u) * RPS + grp;
+            const long long row = row0 + lr;
+            const bool fits = __ballot(n1[u] > G || n2[u] > G) == 0ULL;
+            if (row >= m) continue;
             const long long o = base + cnt[lr];
-            if (lg == 0) po[row0 + lr] = (int32_t)o;
+            if (lg == 0) po[row] = (int32_t)o;
             if (!fits) {
-                fill_row_slow<G, OP, VT>(lg, j1 + s1, x1 + s1, n1, j2 + s2, x2 + s2, n2, o, jo, xo);
+                fill_row_slow<G, OP, VT>(lg, j1 + s1[u], x1 + s1[u], n1[u], j2 + s2[u], x2 + s2[u], n2[u], o, jo, xo);
                 continue;
             }
-            const bool va = lg < n1, vb = lg < n2;
+            const bool va = lg < n1[u], vb = lg < n2[u];
             bool hit_a, hit_b;
-            const int lb_a = group_lower_bound<G>(b, a, hit_a);       // entries of B below a
+            const int lb_a = group_lower_bound<G>(b[u], a[u], hit_a);  // entries of B below a
             hit_a = hit_a && va;
-            const VT partner = __shfl(xb[k], lb_a < G ? lb_a : G - 1, G);
+            const VT partner = __shfl(xb[u], lb_a < G ? lb_a : G - 1, G);
             const int before_a = __popcll(group_ballot<G>(hit_a) & below);
             if constexpr (INTERSECT) {
                 if (hit_a) {
-                    jo[o + before_a] = a;
-                    xo[o + before_a] = combine<OP, VT>(xa[k], partner);
+                    jo[o + before_a] = a[u];
+                    xo[o + before_a] = combine<OP, VT>(xa[u], partner);
                 }
             } else {
                 if (va) {
                     const long long pos = o + lg + lb_a - before_a;
-                    jo[pos] = a;
-                    xo[pos] = hit_a ? combine<OP, VT>(xa[k], partner) : xa[k];
+                    jo[pos] = a[u];
+                    xo[pos] = hit_a ? combine<OP, VT>(xa[u], partner) : xa[u];
                 }
-                const int lb_b = group_lower_bound<G>(a, b, hit_b);   // entries of A below b
+                const int lb_b = group_lower_bound<G>(a[u], b[u], hit_b);  // entries of A below b
                 hit_b = hit_b && vb;
                 const int before_b = __popcll(group_ballot<G>(hit_b) & below);
                 if (vb && !hit_b) {
                     const long long pos = o + lb_b + lg - before_b;
-                    jo[pos] = b;
-                    if constexpr (OP == MX_OP_SUB) xo[pos] = -xb[k]; else xo[pos] = xb[k];
+                    jo[pos] = b[u];
+                    if constexpr (OP == MX_OP_SUB) xo[pos] = -xb[u]; else xo[pos] = xb[u];
                 }
             }
         }
-    };
-    if (staged) fill_phase(std::true_type{}); else fill_phase(std::false_type{});
+    }
 }
 
 template <typename VT, int OP>
@@ -562,13 +564,12 @@ static int merge_fused_op(int G, int m, const int32_t *p1, const int32_t *j1, co
                           const int32_t *j2, const void *x2, int32_t *po, int32_t *jo, void *xo,
                           unsigned long long *tile_state, unsigned *ticket, long long *total, hipStream_t st)
 {
-    const int aligned = (((uintptr_t)j1 | (uintptr_t)j2) & 15) == 0;
 #define MX_CASE(GG)                                                                                               \
     case GG: {                                                                                                    \
-        const int ntiles = (int)ceil_div(m, F3<GG>::TILE_ROWS);                                                   \
-        hipLaunchKernelGGL((merge_fused_kernel<GG, OP, VT>), dim3((unsigned)ntiles), dim3(F3_BLOCK), 0, st, m,     \
+        const int ntiles = (int)ceil_div(m, FUSED_WAVES * (64 / GG) * FUSED_STEPS);                               \
+        hipLaunchKernelGGL((merge_fused_kernel<GG, OP, VT>), dim3((unsigned)ntiles), dim3(FUSED_BLOCK), 0, st, m,  \
                            p1, j1, (const VT *)x1, p2, j2, (const VT *)x2, po, jo, (VT *)xo, tile_state, ticket,   \
-                           total, ntiles, aligned);                                                               \
+                           total, ntiles);                                                                        \
         break;                                                                                                    \
     }
     switch (G) { MX_CASE(8) MX_CASE(16) MX_CASE(32) MX_CASE(64) default: return set_error("merge: bad group %d", G); }
@@ -582,7 +583,7 @@ int merge_fused_launch(int op, int G, int m, const int32_t *p1, const int32_t *j
                        hipStream_t st)
 {
     // workspace: [int64 total][uint32 ticket, pad][uint64 tile_state[ntiles]]
-    const int64_t ntiles = ceil_div(m, F3_WAVES * (64 / G) * F3_STEPS);
+    const int64_t ntiles = ceil_div(m, FUSED_WAVES * (64 / G) * FUSED_STEPS);
     long long *total = (long long *)workspace;
     unsigned *ticket = (unsigned *)(total + 1);
     unsigned long long *tile_state = (unsigned long long *)(total + 2);
@@ -670,8 +671,8 @@ extern "C" int mxd_values_elemwise(int op, int64_t nnz, const void *values1, con
 // *nnz_out_host is written after an internal synchronisation (the one host round trip).
 extern "C" size_t mxd_merge_fused_workspace_bytes(int m)
 {
-    // tiles hold at least F3_WAVES * F3_STEPS rows (G = 64)
-    return 16 + 8 * (size_t)mx::ceil_div(m > 0 ? m : 1, mx::F3_WAVES * mx::F3_STEPS) + 64;
+    // tiles hold at least FUSED_WAVES * FUSED_STEPS rows (G = 64)
+    return 16 + 8 * (size_t)mx::ceil_div(m > 0 ? m : 1, mx::FUSED_WAVES * mx::FUSED_STEPS) + 64;
 }
 
 extern "C" int mxd_csr_merge_fused(int op, int m, const int32_t *indptr1, const int32_t *indices1, const void *values1,

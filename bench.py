@@ -126,6 +126,9 @@ def cpu_baseline_spmm(args, p, j, x, B_host, dtype):
                       f"({dtype}), gemm_csr_drm_as_dcm restated with OpenMP schedule(dynamic), -march=native, best of 3"}
 
 
+FORCE_DIST = os.environ.get("MXGPU_BENCH_FORCE_DIST") == "1"
+
+
 def committed_traffic(kernel_sub, workload_tag, kernel_avg_ms):
     """HBM-side bytes per launch from the committed PMC summary (profiles/*_pmc.json, written by tools/prof_summary.py
     from separate rocprofv3 --pmc passes of this same command).  Used only when the summary is for the kernel and
@@ -181,8 +184,11 @@ def roofline(alg_bytes, seconds, **extra):
 # ------------------------------------------------------------------------------------------------ the SpMM leg
 def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, warmup, want_cpu, want_steady):
     """Times `steps` SpMM steps of workload `cfg` (dict rows/cols/nnz_row/n/dtype) on this rank (+ all-gather for
-    world > 1).  Returns the result dict on rank 0 (None elsewhere)."""
+    dist_on).  Returns the result dict on rank 0 (None elsewhere)."""
     import ctypes
+    # MXGPU_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, in-place RCCL all-gather, pipelined buffers,
+    # gathered-buffer parity check) with whatever WORLD_SIZE is — lets a ONE-GPU box exercise it (tests/test_gpu_rccl.py)
+    dist_on = world > 1 or FORCE_DIST
     m, K, n, nnz_row, dtype = cfg["rows"], cfg["cols"], cfg["n"], cfg["nnz_row"], cfg["dtype"]
     tdt = torch.float64 if dtype == "f64" else torch.float32
     ndt = np.float64 if dtype == "f64" else np.float32
@@ -195,17 +201,17 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
     B = torch.from_numpy(B_host).cuda()
     nnz = A.nnz
     A.rows_sorted()                  # once per matrix, outside the timed region (cached on the DeviceCSR)
-    colmajor = (args.layout == "colmajor") and world == 1
-    overlap = world > 1 and os.environ.get("MXGPU_BENCH_OVERLAP", "1") != "0"
+    colmajor = (args.layout == "colmajor") and not dist_on
+    overlap = dist_on and os.environ.get("MXGPU_BENCH_OVERLAP", "1") != "0"
     C_full = C_loc = None
-    if world > 1 and not overlap:
+    if dist_on and not overlap:
         C_full = torch.full((world * m, n), float("nan"), dtype=tdt, device="cuda")   # gathered row-major blocks
         C_loc = C_full[rank * m:(rank + 1) * m]                                          # compute straight into my slot
-    elif world == 1:
+    elif not dist_on:
         C_loc = torch.empty((n, m) if colmajor else (m, n), dtype=tdt, device="cuda")
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] \
-        if world > 1 else []
+        if dist_on else []
 
     def run_spmm(A_, B_, out_, colmajor_):
         if args.algo in (3, 4):
@@ -216,7 +222,7 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
 
     pipe = None
     cur = [None]
-    if world > 1:
+    if dist_on:
         # matrixextra_amd.distributed: equal row blocks -> compute into my slot, one RCCL all-gather in place
         from matrixextra_amd import distributed as MD
 
@@ -236,7 +242,7 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
                 b.fill_(float("nan"))          # anything not written by a product or a completed gather stays NaN
 
     def step(k=None):
-        if world > 1:
+        if dist_on:
             cur[0] = k
             if pipe is not None:
                 pipe.step(B)
@@ -256,7 +262,7 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
     lib.mxd_spmm_kernel_timing(0)
     for _ in range(warmup):
         step()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     lib.mxd_spmm_kernel_timing(1)           # HIP events right around the dominant kernel of every launch
@@ -266,16 +272,16 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
     if pipe is not None:
         pipe.finish()                     # waits for the gathers still in flight
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # local SpMM call (plan build + repack + kernel) of every step; only recorded when N > 1 (beside the all-gather)
-    step_ms = np.array([a.elapsed_time(b) for a, b in ev]) if world > 1 else np.array([elapsed / steps * 1e3])
+    step_ms = np.array([a.elapsed_time(b) for a, b in ev]) if dist_on else np.array([elapsed / steps * 1e3])
     kt = (ctypes.c_float * 256)()
     kcount = ctypes.c_int(0)
     _lib.check(lib.mxd_spmm_kernel_times(kt, 256, ctypes.byref(kcount)))
@@ -303,7 +309,7 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
         # meaningless for entries that cancel to ~0); NaN (unwritten / half-gathered data) propagates
         return float(np.max(np.abs(got.astype(np.float64) - ref)) / np.max(np.abs(ref)))
     ref0 = oracle_rows(p, j, x, 0)
-    if world == 1:
+    if not dist_on:
         got = (C_loc[:, :rows_chk].t() if colmajor else C_loc[:rows_chk]).cpu().numpy()
         parity = max_err(got, ref0)
     else:
@@ -322,7 +328,7 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
 
     kernel_name = lib.mxd_spmm_last_kernel().decode()      # which kernel AUTO / --algo actually launched
     tag = None
-    if not args.custom and (args.layout, args.algo, args.panels, args.wg_per_cu) == ("colmajor", 0, 0, 0) and world == 1:
+    if not args.custom and (args.layout, args.algo, args.panels, args.wg_per_cu) == ("colmajor", 0, 0, 0) and not dist_on:
         tag = {"cfg2": "cfg2-default", "cfg5": "cfg5-shard"}[cfg["name"]]
     traffic = committed_traffic(kernel_name, tag, kern_avg_s * 1e3) if tag else None
     gb = nnz * n * s_dense
@@ -333,7 +339,7 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
                     f"({cfg['label']}); C {'col' if colmajor else 'row'}-major"
                     + (f"; one such row block per GPU + RCCL all-gather of C ({world}x{m} rows)"
                        + (", gather of step k under the product of step k+1" if pipe is not None else "")
-                       if world > 1 else ""),
+                       if dist_on else ""),
         "roofline": roofline(alg_bytes, kern_avg_s, traffic=traffic[0] if traffic else None,
                              traffic_source=traffic[1] if traffic else None, kernel=kernel_name,
                              kernel_avg_ms=round(kern_avg_s * 1e3, 4), kernel_min_ms=round(float(kern_ms.min()), 4),
@@ -347,12 +353,12 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
         "spmm_call_avg_ms": round(float(step_ms.mean()), 4),
         "dims": {"rows_per_gpu": m, "cols": K, "nnz_per_row": nnz_row, "dense_cols": n},
     }
-    if world > 1:
+    if dist_on:
         gather_s = max(elapsed / steps - float(step_ms.mean()) / 1e3, 1e-9) if pipe is None else elapsed / steps
         res["allgather"] = {"bytes_received_per_gpu": int((world - 1) * m * n * s_dense),
                             "approx_ms": round(gather_s * 1e3, 3),
                             "approx_GBps_in_per_gpu": round((world - 1) * m * n * s_dense / gather_s / 1e9, 1)}
-    if want_steady and kernel_name == "spmm_plan_kernel" and args.algo in (0, 4) and world == 1:
+    if want_steady and kernel_name == "spmm_plan_kernel" and args.algo in (0, 4) and not dist_on:
         # `value` above pays for building the plan from plain CSR inside every step.  A caller that multiplies the
         # same matrix repeatedly keeps the plan (it depends on A only): steady-state figure, reported separately.
         for _ in range(2):
@@ -540,7 +546,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or FORCE_DIST:
+        if "MASTER_ADDR" not in os.environ:                 # forced one-rank run started without torchrun
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"),
+                              RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from matrixextra_amd import _lib, device as D, synth
@@ -548,7 +557,7 @@ def main():
 
     cfg = dict(name=args.config, rows=args.rows, cols=args.cols, nnz_row=args.nnz_row, n=args.n, dtype=args.dtype,
                label=WORKLOADS[args.config]["label"] if not args.custom else "custom shape")
-    want_cpu = world == 1 and not args.no_cpu_baseline
+    want_cpu = world == 1 and not FORCE_DIST and not args.no_cpu_baseline
     r = spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, args.steps, args.warmup, want_cpu, True)
     out = None
     if rank == 0:
@@ -571,7 +580,7 @@ def main():
         out["device"] = _lib.device_name()
         if cpu:
             out["cpu_baseline"] = cpu
-        if world == 1 and not args.no_extras and not args.custom and args.config == "cfg2" and args.algo == 0:
+        if world == 1 and not FORCE_DIST and not args.no_extras and not args.custom and args.config == "cfg2" and args.algo == 0:
             out["extras"] = extras(args, torch, D, synth, _lib, host, want_cpu)
             del host
             torch.cuda.empty_cache()
@@ -580,10 +589,20 @@ def main():
             r5 = spmm_leg(args, torch, dist, D, synth, lib, _lib, c5, 1, 0, max(5, args.steps // 2), 2, False, False)
             r5.pop("_host")
             out["extras"]["cfg5_shard"] = r5
-    if world > 1:
+    if world > 1 or FORCE_DIST:
+        # The JSON line must be the LAST line on stdout.  RCCL writes its version banner through C stdio, which — stdout
+        # being a pipe — sits in the C buffer until the process exits, i.e. lands AFTER a line printed from Python.  So:
+        # every rank empties its C buffers, the group is torn down, the other ranks leave, and only then rank 0 prints.
+        import ctypes
+        libc = ctypes.CDLL(None)
+        libc.fflush(None)
         dist.barrier()
         dist.destroy_process_group()
+        libc.fflush(None)
+        if rank == 0 and world > 1:
+            time.sleep(1.0)                                  # the other ranks' exit-time output, if any, comes first
     if rank == 0:
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
 
 

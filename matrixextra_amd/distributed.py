@@ -18,9 +18,15 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Callable, List, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+# MXGPU_DIST_ALWAYS_COLLECTIVE=1: issue the all-gather even in a one-rank group (a one-GPU box then exercises the RCCL
+# calls, in place and asynchronous, exactly as N ranks would: tests/test_gpu_rccl.py)
+ALWAYS_COLLECTIVE = os.environ.get("MXGPU_DIST_ALWAYS_COLLECTIVE") == "1"
 
 
 def nnz_balanced_row_blocks(indptr: np.ndarray, world: int) -> List[Tuple[int, int]]:
@@ -73,7 +79,7 @@ class RowShardedSpMM:
             # equal blocks: compute straight into my slot of the gathered buffer, one all-gather in place
             mine = out[r0:r1]
             self.spmm_local(self.local_A, B, mine)
-            if self.world > 1:
+            if self.world > 1 or ALWAYS_COLLECTIVE:
                 dist.all_gather_into_tensor(out, mine, group=self.group) if _has_into_tensor(B) else \
                     _all_gather_list(out, mine, self.rows, self.group)
             return out
@@ -119,7 +125,7 @@ class PipelinedRowShardedSpMM:
         r0, r1 = self.s.row_blocks[self.s.rank]
         mine = out[r0:r1]
         self.s.spmm_local(self.s.local_A, B, mine)
-        if self.s.world > 1:
+        if self.s.world > 1 or ALWAYS_COLLECTIVE:
             if out.is_cuda:
                 self.pending[i] = dist.all_gather_into_tensor(out, mine, group=self.s.group, async_op=True)
             else:

@@ -502,19 +502,35 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
 
     # ---- end to end through the export-level C-ABI (host pointers in, host matrix out: what one .Call from R costs;
     # never the headline `value`)
-    from matrixextra_amd import exports as G
+    # The result comes from plain libc malloc, untouched, as R's allocVector hands it over (no huge-page advice: on a
+    # THP=madvise machine that is 4-KiB pages unless the library asks — DESIGN §5.2); the operands are numpy arrays.
+    import ctypes as C
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
     Yc = np.asfortranarray(B_host.T)
-    fn = G.tcrossprod_csr_dense_numeric if B_host.dtype == np.float64 else G.tcrossprod_csr_dense_float32
     lib = _lib.load()
-    out = fn(p, j, x, Yc, 1)                       # first call of the process: allocates the library's grow-only device scratch
+    f64 = B_host.dtype == np.float64
+    cfn = lib.mx_tcrossprod_csr_dense_numeric if f64 else lib.mx_tcrossprod_csr_dense_float32
+    m_, n_, K_ = p.size - 1, Yc.shape[0], Yc.shape[1]
+    c_bytes = m_ * n_ * B_host.dtype.itemsize
+
+    def call():
+        q = libc.malloc(c_bytes)
+        t0 = time.perf_counter()
+        _lib.check(cfn(C.c_void_p(p.ctypes.data), C.c_void_p(j.ctypes.data), C.c_void_p(x.ctypes.data), C.c_int(m_),
+                       C.c_void_p(Yc.ctypes.data), C.c_int(n_), C.c_int(K_), C.c_int(1), C.c_void_p(q)))
+        return time.perf_counter() - t0, q
+    _, q = call()                                  # first call of the process: allocates the library's grow-only device scratch
     cold, cached = [], []
     for k in range(5):
-        del out                                   # (freeing the previous 1 GB result is not part of the next call)
+        libc.free(q)                              # (freeing the previous 1 GB result is not part of the next call)
         if k < 2:
             lib.mx_cache_invalidate(None)         # CSR not on the device: upload + compute + download
-        t0 = time.perf_counter()
-        out = fn(p, j, x, Yc, 1)
-        (cold if k < 2 else cached).append(time.perf_counter() - t0)
+        t, q = call()
+        (cold if k < 2 else cached).append(t)
+    out = np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_double if f64 else C.c_float)), shape=(n_, m_)).T   # view; freed below
     ts = [min(cold), min(cached)]
     n = out.shape[1]
     ref = np.zeros(2048 * n, dtype=B_host.dtype)
@@ -522,14 +538,16 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
     err = max(float(np.max(np.abs(out[:2048] - ref.reshape(2048, n))) / np.max(np.abs(ref))),
               float(abs(out[-1].sum() - (x[p[-2]:p[-1]] @ B_host[j[p[-2]:p[-1]]]).sum()) / np.max(np.abs(ref))))
     assert err <= 1e-9, f"export-level SpMM differs from the oracle: {err}"
+    del out
+    libc.free(q)
     res["export_call_end_to_end"] = {
         "ms_cold": round(ts[0] * 1e3, 2), "ms_csr_cached": round(ts[1] * 1e3, 2),
         "GFLOP/s_cold": round(2 * nnz * n / ts[0] / 1e9, 1), "GFLOP/s_csr_cached": round(2 * nnz * n / ts[1] / 1e9, 1),
         "parity_max_err_over_max_abs_vs_oracle": err,
-        "note": "mx_tcrossprod_csr_dense_* on cfg2: ordinary (pageable) host vectors in, a freshly allocated host matrix "
-                "out; cold = CSR not on the device (upload, compute and download pipelined over row blocks; best of 2), "
-                "csr_cached = the same host vectors again (device-side CSR cache; download-bound: 1 GB over PCIe; best of 3); "
-                "both include the numpy allocation of the result"}
+        "note": "mx_tcrossprod_csr_dense_* on cfg2: ordinary (pageable) host vectors in, a freshly malloc'ed, untouched host "
+                "matrix out (as R allocates it); cold = CSR not on the device (upload, compute and download pipelined over "
+                "row blocks; best of 2), csr_cached = the same host vectors again (device-side CSR cache; download-bound: "
+                "1 GB over PCIe; best of 3)"}
     return res
 
 

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <thread>
+#include <sys/mman.h>
 
 #include "host_pool.h"
 #include "mx_common.h"
@@ -127,9 +128,26 @@ int staged_h2d(Engine &e, void *dst_dev, const void *src_host, size_t bytes)
 // ---- caller memory: first-touch, registration ----------------------------------------------------------------
 // Starts write-touching every page of [p, p + bytes) on the host team and returns; prefault_wait() joins.  For the
 // destination of a large D2H copy that the caller has just allocated: call it as early as the address is known.
+// The destination of a large download is memory the caller has only just allocated.  R (and any plain malloc) gets it
+// from mmap without huge-page advice, and on a machine whose THP mode is "madvise" (the MI355X boxes) that means 4-KiB
+// pages: first-touching 1 GB of them from 16 threads took 313 ms (mmap-lock contention), registering them 37 ms more —
+// the cold cfg2 call cost 370-600 ms instead of 28 (tools/cold_export_probe.py malloc).  So the whole 2-MiB-aligned
+// interior is advised MADV_HUGEPAGE before the first touch: 28 ms for malloc'ed results as well.  Advice only: contents,
+// protection and ownership are untouched.  numpy already advises its large arrays; there the extra call costs 0-3 ms.
+// MXGPU_HUGEPAGE=0 switches it off.
+static void advise_huge(void *p, size_t bytes)
+{
+    static const int huge = [] { const char *e = getenv("MXGPU_HUGEPAGE"); return e ? atoi(e) : 1; }();
+    if (!huge) return;
+    const uintptr_t two = (uintptr_t)2 << 20;
+    const uintptr_t a = ((uintptr_t)p + two - 1) & ~(two - 1), b = ((uintptr_t)p + bytes) & ~(two - 1);
+    if (b > a) (void)madvise((void *)a, b - a, MADV_HUGEPAGE);
+}
+
 void prefault_begin(void *p, size_t bytes)
 {
     if (!p || bytes < XF_MIN || xfer_mode() != 1) return;
+    advise_huge(p, bytes);
     Engine &e = engine();
     std::lock_guard<std::mutex> lk(e.mu);
     e.team()->touch(p, bytes);
@@ -179,6 +197,7 @@ int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes)
     Engine &e = engine();
     if (xfer_mode() == 1) {
         {
+            advise_huge(dst_host, bytes);
             std::lock_guard<std::mutex> lk(e.mu);
             e.team()->touch(dst_host, bytes);          // (a no-op pass when prefault_begin already did it)
             e.pool->wait();

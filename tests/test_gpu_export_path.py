@@ -99,6 +99,51 @@ def test_export_spmm_cfg2_pipeline_and_cache(gpu):
     lib.mx_cache_configure(C.c_int64(8192 << 20))
 
 
+def test_export_into_plain_malloc_memory_like_r(gpu):
+    """What R hands over: vectors and a result from plain malloc — no huge-page advice, so 4-KiB pages on a THP=madvise
+    machine.  First-touching and registering 640 MB of those for the download took ~250 ms here (1 GB: 370-600 ms,
+    tools/cold_export_probe.py malloc) until the library advised MADV_HUGEPAGE on the destination before touching it.
+    Same bytes as the numpy call; the time bound only has to separate ~20 ms from ~250 ms."""
+    import time
+    lib = _lib.load()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    m, K, n = 640_000, 50_000, 128
+    p, j, x = synth.csr_fixed(m, K, 24)
+    B = synth.dense_normal(K, n)
+    Y = np.asfortranarray(B.T)
+    ref = G.tcrossprod_csr_dense_numeric(p, j, x, Y, 1)              # numpy result (and the warm-up of pool / scratch)
+
+    def from_malloc(a):
+        q = libc.malloc(a.nbytes)
+        C.memmove(q, a.ctypes.data, a.nbytes)
+        return q
+    bufs = [from_malloc(a) for a in (p, j, x, Y)]
+    fn = lib.mx_tcrossprod_csr_dense_numeric
+    best = None
+    try:
+        for _ in range(3):
+            lib.mx_cache_invalidate(None)
+            out = libc.malloc(8 * m * n)                             # untouched: the pages do not exist yet
+            try:
+                t0 = time.perf_counter()
+                _lib.check(fn(C.c_void_p(bufs[0]), C.c_void_p(bufs[1]), C.c_void_p(bufs[2]), C.c_int(m), C.c_void_p(bufs[3]),
+                              C.c_int(n), C.c_int(K), C.c_int(1), C.c_void_p(out)))
+                t = time.perf_counter() - t0
+                got = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_double)), shape=(n, m)).T
+                assert np.array_equal(got, ref)
+            finally:
+                libc.free(out)
+            best = t if best is None else min(best, t)
+    finally:
+        for q in bufs:
+            libc.free(q)
+        lib.mx_cache_invalidate(None)
+    assert best < 0.12, f"export into malloc'ed memory took {best * 1e3:.0f} ms"
+
+
 def test_export_spmm_float32_and_blocks_without_entries(gpu):
     # f32 dense operand through the pipeline; the first half of the rows has no entries at all (a block that is only
     # zero-filled) and the last rows are empty too

@@ -15,7 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_bench(extra_env, *argv):
-    env = dict(os.environ, MXGPU_BENCH_FORCE_DIST="1", MXGPU_DIST_ALWAYS_COLLECTIVE="1", MASTER_PORT="29547", **extra_env)
+    import socket
+    with socket.socket() as sk:                       # a free port for the one-rank rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MXGPU_BENCH_FORCE_DIST="1", MXGPU_DIST_ALWAYS_COLLECTIVE="1", MASTER_PORT=str(port), **extra_env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",

@@ -424,7 +424,11 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
     # the same product through a kept plan (entries regrouped by column panel so that v sits in LDS): what a solver that
     # multiplies by the same X every iteration gets; the plan build is reported beside it, never inside the figure
     A.spmv_plan(); torch.cuda.synchronize(); A.drop_spmv_plan()     # (the first build also pays for the allocator's first big blocks)
-    t0 = time.perf_counter(); A.spmv_plan(); torch.cuda.synchronize(); t_build = time.perf_counter() - t0
+    t_build = None
+    for _ in range(3):                                              # best of 3: one build in ~20 hits a 15 ms hipMalloc
+        A.drop_spmv_plan(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); A.spmv_plan(); torch.cuda.synchronize(); tb = time.perf_counter() - t0
+        t_build = tb if t_build is None else min(t_build, tb)
     yp = D.spmv_planned(A, v)
     errp = float(np.max(np.abs(yp.cpu().numpy() - ref)) / np.max(np.abs(ref)))
     assert errp <= 1e-12, f"planned SpMV differs from the oracle: {errp}"

@@ -79,10 +79,11 @@ int  mx_host_register(void *hptr, size_t bytes);   /* pin caller memory for asyn
 int  mx_host_unregister(void *hptr);
 
 /* Device-side cache of the CSR operands that the export-level calls receive by host address: a later call with the same
- * three vectors (same addresses, nrows, nnz AND the same sampled fingerprint of their contents) skips the upload.  LRU,
- * capped at max_bytes (default 8 GiB or MXGPU_CSR_CACHE_MB; 0 disables and empties it).  The library's own in-place
- * routines invalidate what they rewrite; a caller that mutates a cached operand in place must call mx_cache_invalidate
- * (host_ptr = any of the operand's three vectors; NULL = everything). */
+ * three vectors (same addresses, nrows, nnz AND the same hash of every byte of their contents) skips the upload.  LRU,
+ * capped at max_bytes (default 8 GiB or MXGPU_CSR_CACHE_MB; 0 disables and empties it).  With the default full hash an
+ * operand changed in place is simply a miss; with MXGPU_CACHE_FINGERPRINT=sampled (a few 512-byte samples per array) a
+ * caller that mutates a cached operand in place must call mx_cache_invalidate (host_ptr = any of the operand's three
+ * vectors; NULL = everything). */
 int  mx_cache_configure(int64_t max_bytes);
 int  mx_cache_invalidate(const void *host_ptr);
 int  mx_cache_stats(int64_t *bytes, int *entries, int64_t *hits, int64_t *misses);

@@ -61,6 +61,7 @@ int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes);
 void prefault_begin(void *p, size_t bytes);
 void prefault_wait();
+uint64_t host_hash(const void *p, size_t bytes, uint64_t seed);
 bool pin_host(const void *p, size_t bytes, bool all_devices = false);
 void unpin_host(const void *p);
 
@@ -120,10 +121,10 @@ static inline size_t dtype_bytes(int dt)
 // Device-side cache of CSR operands handed over by host address (SURVEY §7 "PCIe dominates": every .Call of the
 // reference's API passes the same three R vectors again; re-uploading 388 MB costs 8 ms of a 25 ms product).
 // Key: device, the three host addresses, nrows, nnz, value width.  A hit additionally needs the operand's FINGERPRINT
-// to match: lengths + first / last 4 KiB + 64 evenly spaced 512-byte blocks of each array (R vectors are immutable by
-// convention, but MatrixExtra's own in-place routines — sort_sparse_indices(copy = FALSE), reverse_columns_inplace — do
-// rewrite @j / @x in place; the exports of this library that do so invalidate the entry themselves).  A caller that
-// mutates an operand in place in a way the samples miss must call mx_cache_invalidate.  LRU, capped
+// to match: a hash of EVERY byte of the three arrays, computed by the host team (R vectors are immutable by convention,
+// but R does overwrite a vector in place when nothing else refers to it — X@x[i] <- v —, MatrixExtra's own in-place
+// routines rewrite @j / @x, and the allocator hands a freed vector's address to the next one of its size: a sampled
+// fingerprint would serve a stale matrix without any sign).  LRU, capped
 // (MXGPU_CSR_CACHE_MB, default 8192; 0 disables; mx_cache_configure at run time).  Entries are shared_ptr-held for the
 // duration of a call, so eviction never pulls memory from under a running export.
 struct CsrDev {
@@ -147,11 +148,20 @@ static uint64_t fnv_block(uint64_t h, const void *p, size_t n)
     for (; i < n; i++) h = (h ^ c[i]) * 0x100000001b3ULL;
     return h;
 }
+// MXGPU_CACHE_FINGERPRINT=sampled: lengths + first / last 4 KiB + 64 evenly spaced 512-byte blocks of each array (faster
+// — microseconds — but an element overwritten in place between the samples goes unnoticed: the caller must then call
+// mx_cache_invalidate).  Default: every byte, hashed by the host team (cfg2's 388 MB: ~3 ms on 16 threads).
+static bool fingerprint_sampled()
+{
+    static const bool s = [] { const char *e = getenv("MXGPU_CACHE_FINGERPRINT"); return e && strcmp(e, "sampled") == 0; }();
+    return s;
+}
 static uint64_t fingerprint_array(uint64_t h, const void *p, size_t bytes)
 {
     h = fnv_block(h, &bytes, sizeof(bytes));
     if (!p || bytes == 0) return h;
     if (bytes <= 64 * 1024) return fnv_block(h, p, bytes);
+    if (!fingerprint_sampled()) return mx::host_hash(p, bytes, h);
     const char *c = (const char *)p;
     h = fnv_block(h, c, 4096);
     h = fnv_block(h, c + bytes - 4096, 4096);

@@ -4,6 +4,7 @@
 #pragma once
 #include <condition_variable>
 #include <cstddef>
+#include <cstdint>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -66,6 +67,42 @@ public:
             for (size_t i = 0; i < len; i += 4096) q[i] = q[i];
             q[len - 1] = q[len - 1];
         });
+    }
+    // 64-bit content hash of [p, p + n): 1 MiB chunks over the team, four multiply-xor lanes of 64-bit words per chunk,
+    // chunk hashes folded in order.  Every step h -> (h ^ w) * odd is a bijection in h, so two buffers that differ in
+    // ONE word (an element overwritten in place) can never hash alike; unrelated contents collide with probability 2^-64.
+    uint64_t hash(const void *p, size_t n, uint64_t seed)
+    {
+        constexpr size_t CH = (size_t)1 << 20;
+        const size_t nch = (n + CH - 1) / CH;
+        auto one = [=](size_t c) -> uint64_t {
+            const unsigned char *q = (const unsigned char *)p + c * CH;
+            const size_t len = c + 1 < nch ? CH : n - c * CH;
+            const uint64_t P = 0x100000001b3ULL;
+            uint64_t h0 = seed ^ (0x9e3779b97f4a7c15ULL * (c + 1)), h1 = h0 ^ 0xbf58476d1ce4e5b9ULL,
+                     h2 = h0 ^ 0x94d049bb133111ebULL, h3 = h0 ^ 0xd6e8feb86659fd93ULL;
+            size_t i = 0;
+            for (; i + 32 <= len; i += 32) {
+                uint64_t w[4];
+                memcpy(w, q + i, 32);
+                h0 = (h0 ^ w[0]) * P; h1 = (h1 ^ w[1]) * P; h2 = (h2 ^ w[2]) * P; h3 = (h3 ^ w[3]) * P;
+            }
+            for (; i < len; i++) h0 = (h0 ^ q[i]) * P;
+            return (((h0 * P ^ h1) * P ^ h2) * P ^ h3) * P ^ (uint64_t)len;
+        };
+        std::vector<uint64_t> part(nch);
+        if (nch <= 2 || n_ <= 1) {
+            wait();
+            for (size_t c = 0; c < nch; c++) part[c] = one(c);
+        } else {
+            uint64_t *out = part.data();
+            const int team = n_;
+            run([=](int id, int) { for (size_t c = (size_t)id; c < nch; c += (size_t)team) out[c] = one(c); });
+            wait();
+        }
+        uint64_t h = seed ^ (uint64_t)n;
+        for (size_t c = 0; c < nch; c++) h = (h ^ part[c]) * 0x100000001b3ULL;
+        return h;
     }
     int threads() const { return n_; }
 

@@ -152,6 +152,13 @@ void prefault_begin(void *p, size_t bytes)
     std::lock_guard<std::mutex> lk(e.mu);
     e.team()->touch(p, bytes);
 }
+// content hash of caller memory on the host team (the CSR cache's fingerprint)
+uint64_t host_hash(const void *p, size_t bytes, uint64_t seed)
+{
+    Engine &e = engine();
+    std::lock_guard<std::mutex> lk(e.mu);
+    return e.team()->hash(p, bytes, seed);
+}
 void prefault_wait()
 {
     Engine &e = engine();

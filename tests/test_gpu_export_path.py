@@ -84,6 +84,15 @@ def test_export_spmm_cfg2_pipeline_and_cache(gpu):
     x *= 2.0
     out3 = G.tcrossprod_csr_dense_numeric(p, j, x, Y, 1)
     np.testing.assert_array_equal(out3, 2.0 * out1)
+    # ONE element overwritten in place, far from either end (what `X@x[i] <- v` does in R when nothing else refers to the
+    # vector): the fingerprint covers every byte, so this is a miss too and the row changes
+    k = int(p[m // 3]) + 5
+    row, old = m // 3, x[k]
+    x[k] = old + 1.0
+    out3b = G.tcrossprod_csr_dense_numeric(p, j, x, Y, 1)
+    np.testing.assert_allclose(out3b[row] - out3[row], B[j[k]], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(np.delete(out3b, row, axis=0)[::997], np.delete(out3, row, axis=0)[::997])
+    x[k] = old
     # row-major result (dense %*% CSC): C^T = A B^T with the CSC read as CSR of the transpose
     X = np.asfortranarray(B.T[:64])                                  # 64 x 100k dense, Y = CSC 100k x 1M  ->  64 x 1M
     out4 = G.matmul_dense_csc_numeric(X, p, j, x, 1)

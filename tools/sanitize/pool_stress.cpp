@@ -23,6 +23,22 @@ int main()
         pool.wait();
         if (memcmp(fresh.data(), src.data(), n) != 0) { printf("touch changed the data in round %d\n", round); return 1; }
     }
+    // content hash: the same for the same bytes whatever the team size, different after ONE byte changes anywhere
+    {
+        mx::HostPool one(1);
+        for (size_t n : {(size_t)0, (size_t)5, (size_t)4096, ((size_t)1 << 20) + 3, src.size() - 77}) {
+            const uint64_t h = pool.hash(src.data(), n, 42), h1 = one.hash(src.data(), n, 42);
+            if (h != h1 || h != pool.hash(src.data(), n, 42)) { printf("hash not reproducible at n = %zu\n", n); return 1; }
+            if (n == 0) continue;
+            for (size_t at : {(size_t)0, n / 3, n - 1}) {
+                src[at] ^= 1;
+                const bool same = pool.hash(src.data(), n, 42) == h;
+                src[at] ^= 1;
+                if (same) { printf("hash blind to a change at %zu of %zu\n", at, n); return 1; }
+            }
+            if (pool.hash(src.data(), n, 43) == h) { printf("hash ignores its seed\n"); return 1; }
+        }
+    }
     pool.copy(dst.data(), src.data(), 1000);                     // below the parallel threshold: inline
     printf("pool stress ok\n");
     return 0;

@@ -563,6 +563,28 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
             return spmm_host_multi<real_t>(devs, m, n, K_rows, indptr, indices, values, B_host, ldb, C_host, ldc, c_elems, colmajor,
                                            algo, npanels);
     }
+    // Pipelined calls start the upload of B before anything else: it then runs under the cache look-up, whose fingerprint
+    // reads every byte of the CSR on the host team (1.3-3 ms for cfg2).  Registrations are declared before `fence`: on
+    // every exit the queues drain first, then the memory is unpinned.
+    constexpr int MAX_BLK = 16;
+    Pin pinB, pinJ, pinX, pinC;
+    std::vector<Pin> pinBlk((size_t)MAX_BLK);
+    struct Fence { Lanes *l; ~Fence() { if (l) { mx::prefault_wait(); l->drain(); } } } fence{nullptr};
+    real_t *dB = nullptr;
+    hipEvent_t evB = nullptr;
+    if (pipelined) {
+        Lanes &L0 = lanes();
+        if (L0.init(2 * (size_t)MAX_BLK + 2)) return 1;
+        fence.l = &L0;
+        // device B from the thread's grow-only scratch (no hipMalloc / hipFree of gigabytes per call)
+        dB = (real_t *)mx::scratch_buffer(mx::MX_SCRATCH_EXPORT_B, b_bytes);
+        MX_REQUIRE(dB, "spmm export: cannot allocate the device operands");
+        evB = L0.ev[2 * MAX_BLK];
+        if (pinB.pin(B_host, b_bytes)) {
+            MX_HIP(hipMemcpyAsync(dB, B_host, b_bytes, hipMemcpyHostToDevice, L0.up));
+        } else if (mx::xfer_h2d(dB, B_host, b_bytes)) return 1;
+        MX_HIP(hipEventRecord(evB, L0.up));
+    }
     Csr A;
     if (A.prepare(indptr, indices, values, m, sizeof(double), true)) return 1;
     // column-major result + CSR still on the host: the whole result is first-touched under the upload (see below)
@@ -602,21 +624,10 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     const int col_gran = 8 * VEC;                                    // column blocks in whole 128-byte slabs
     int nblk = (int)std::min<size_t>(16, std::max<size_t>(2, c_bytes / ((size_t)96 << 20)));
     if (shape == COLS) nblk = std::max(1, std::min(nblk, n / col_gran));
+    static_assert(MAX_BLK == 16, "nblk above is capped at 16");
     Lanes &L = lanes();
-    if (L.init(2 * (size_t)nblk + 2)) return 1;
-    // device B and C from the thread's grow-only scratch (no hipMalloc / hipFree of gigabytes per call)
-    real_t *dB = (real_t *)mx::scratch_buffer(mx::MX_SCRATCH_EXPORT_B, b_bytes);
     real_t *dC = (real_t *)mx::scratch_buffer(mx::MX_SCRATCH_EXPORT_C, c_bytes);
-    MX_REQUIRE(dB && dC, "spmm export: cannot allocate the device operands");
-    // registrations are declared before `fence`: on every exit the queues drain first, then the memory is unpinned
-    Pin pinB, pinJ, pinX, pinC;
-    std::vector<Pin> pinBlk((size_t)nblk);
-    struct Fence { Lanes &l; ~Fence() { mx::prefault_wait(); l.drain(); } } fence{L};
-    hipEvent_t evB = L.ev[2 * nblk];
-    if (pinB.pin(B_host, b_bytes)) {
-        MX_HIP(hipMemcpyAsync(dB, B_host, b_bytes, hipMemcpyHostToDevice, L.up));
-    } else if (mx::xfer_h2d(dB, B_host, b_bytes)) return 1;
-    MX_HIP(hipEventRecord(evB, L.up));
+    MX_REQUIRE(dC, "spmm export: cannot allocate the device operands");
     const int64_t nnz = A.nnz;
     if (!A.resident) {
         const bool direct_up = pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz) && pinX.pin(values, sizeof(double) * (size_t)nnz);

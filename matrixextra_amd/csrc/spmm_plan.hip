@@ -569,6 +569,8 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             // iteration (measured: 1.95 us per 8 steps per wave, whatever the locality of B).  Now it is paid once
             // per 32 steps.  Reads run one chunk past the octet (next octet's slots / the padding behind the last
             // octet): they only ever become addresses of valid B lines, never FMAs.
+            // (Tried: nontemporal loads for this stream, so that it does not push B lines out of L2 — 1.90 ms instead
+            //  of 1.72 at cfg2, 3.84 instead of 3.60 at the cfg5 shard.)
             int rn[PLAN_CHUNK];
             double rvn[PLAN_CHUNK];
             auto load_chunk = [&](int step, int (&c)[PLAN_CHUNK], double (&v)[PLAN_CHUNK]) {

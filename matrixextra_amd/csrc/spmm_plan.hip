@@ -569,6 +569,8 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             // iteration (measured: 1.95 us per 8 steps per wave, whatever the locality of B).  Now it is paid once
             // per 32 steps.  Reads run one chunk past the octet (next octet's slots / the padding behind the last
             // octet): they only ever become addresses of valid B lines, never FMAs.
+            // (Tried: an XCD-wide timing barrier at EVERY panel boundary instead of the workgroup's own meeting — 2.18 ms;
+            //  one per generation — sync_mode 2 — 1.78; the workgroup-only meetings of sync_mode 1: 1.71.)
             // (Tried: nontemporal loads for this stream, so that it does not push B lines out of L2 — 1.90 ms instead
             //  of 1.72 at cfg2, 3.84 instead of 3.60 at the cfg5 shard.)
             int rn[PLAN_CHUNK];

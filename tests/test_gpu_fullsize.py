@@ -204,3 +204,43 @@ def test_auto_spmm_on_skewed_rows_large(gpu):
         for got in (C, Cp):
             np.testing.assert_allclose(got[r0:r0 + rows].cpu().numpy(), ref.reshape(rows, n), rtol=1e-11, atol=1e-11)
     print("kernel picked by AUTO:", _lib.load().mxd_spmm_last_kernel().decode(), "plan:", A.plan_info(), "nnz", A.nnz)
+
+
+def _direct_rows(p_host, j, x, B, rows):
+    out = []
+    for i in rows:
+        s, e = int(p_host[i]), int(p_host[i + 1])
+        out.append((x[s:e, None].to(torch.float64) * B[j[s:e].long()].to(torch.float64)).sum(dim=0).cpu().numpy())
+    return out
+
+
+@pytest.mark.parametrize("what", ["result", "dense"])
+def test_operands_above_4_gib(gpu, what):
+    """32-bit offset bugs: a 6.1 GB result (6M x 128 f64, both layouts) and a 5.1 GB dense operand (K = 5M), every SpMM
+    kernel, rows around the 2^32-byte marks against a direct evaluation (maximum sizes: SURVEY §4 edge cases)."""
+    from matrixextra_amd import device as D
+    if what == "result":
+        m, K, n, r, algos, layouts = 6_000_000, 50_000, 128, 8, (0, 1), (True, False)
+        rows = [0, 1, 4_194_303, 4_194_304, 4_500_000, m - 2, m - 1]      # 4 GiB / (128 * 8 B) = row 4,194,304
+    else:
+        m, K, n, r, algos, layouts = 300_000, 5_000_000, 128, 16, (0, 1, 2, 3), (True,)
+        rows = [0, 1, 150_000, m - 1]
+    p, j, x = synth.device_csr_fixed(m, K, r)
+    A = D.DeviceCSR(p, j, x, m, K, int(j.numel()))
+    B = torch.randn(K, n, dtype=torch.float64, device="cuda")
+    refs = _direct_rows(p.cpu().numpy(), j, x, B, rows)
+    if what == "dense":
+        assert int(j.max()) * n * 8 > 2 ** 32                             # rows of B beyond the 4 GiB mark are read
+    for colmajor in layouts:
+        for algo in algos:
+            C = torch.full((n, m) if colmajor else (m, n), float("nan"), dtype=torch.float64, device="cuda")
+            if algo == 3:
+                D.spmm_planned(A, B, out=C, colmajor=colmajor)
+            else:
+                D.spmm(A, B, out=C, colmajor=colmajor, algo=algo)
+            torch.cuda.synchronize()
+            for i, ref in zip(rows, refs):
+                got = (C[:, i] if colmajor else C[i]).cpu().numpy()
+                np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+            assert bool(torch.isfinite(C[:, ::4099] if colmajor else C[::4099]).all())   # nothing left unwritten
+            del C

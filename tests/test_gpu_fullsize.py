@@ -244,3 +244,25 @@ def test_operands_above_4_gib(gpu, what):
                 np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
             assert bool(torch.isfinite(C[:, ::4099] if colmajor else C[::4099]).all())   # nothing left unwritten
             del C
+
+
+def test_results_beyond_int32_are_refused(gpu):
+    """A union of 2 x 1.1e9 disjoint entries and a gather of 3e9 entries do not fit R's int32 index vectors: the count
+    passes must come back with an error (the reference would overflow its int counters, operators.cpp:402-406,
+    slice.cpp:234-235), not with a wrapped size."""
+    from matrixextra_amd import device as D
+    m, per = 11_000_000, 100
+    indptr = (torch.arange(m + 1, dtype=torch.int64, device="cuda") * per).to(torch.int32)
+    base = (torch.arange(m * per, dtype=torch.int32, device="cuda") % per)
+    A = D.DeviceCSR(indptr, base, None, m, 2 * per, m * per)
+    B = D.DeviceCSR(indptr, base + per, None, m, 2 * per, m * per)
+    A.values = B.values = torch.empty(0, dtype=torch.float64, device="cuda")     # the count pass never reads values
+    with pytest.raises(_lib.MxError, match="int32"):
+        D.csr_elemwise(_lib.MX_OP_ADD, A, B)
+    del A, B, base
+    # gather: 30M copies of 100-entry rows
+    small = D.DeviceCSR(indptr[:1001].clone(), (torch.arange(1000 * per, dtype=torch.int32, device="cuda") % per),
+                        torch.ones(1000 * per, dtype=torch.float64, device="cuda"), 1000, per, 1000 * per)
+    rows = (torch.arange(30_000_000, dtype=torch.int32, device="cuda") % 1000)
+    with pytest.raises(_lib.MxError, match="int32"):
+        D.csr_gather_rows(small, rows)

@@ -266,3 +266,16 @@ def test_results_beyond_int32_are_refused(gpu):
     rows = (torch.arange(30_000_000, dtype=torch.int32, device="cuda") % 1000)
     with pytest.raises(_lib.MxError, match="int32"):
         D.csr_gather_rows(small, rows)
+
+
+def test_kernels_at_the_int32_limit(gpu):
+    """nnz = 2.1e9 (just under R's int32 limit; values 16.8 GB): every SpMV kernel bit for bit, the sortedness check, the
+    gather, row-wave and planned SpMM, and merges whose union has 1.575e9 entries (offsets beyond 2^33 bytes) — the
+    maximum sizes the boundary admits.  tools/maxnnz_probe.py, run as a child process (it takes ~60 GB of HBM)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "maxnnz_probe.py")], cwd=root, capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0 and "max nnz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -160,6 +160,21 @@ def test_slice_rows_and_columns(gpu, slice_fixture):              # test-slice.R
     Ls = sp.csr_matrix(((A.x > 0).astype(float), A.j, A.p), shape=A.Dim)
     _chk(mx.subset_csr(L, rows, np.arange(100, 201)), Ls[r0][:, 99:200], mx.lgRMatrix)
     _chk(A[np.array([5, 2]), 10:20], As[[5, 2]][:, 10:20], mx.dgRMatrix)
+    # the literal index vectors of test-slice.R:65-81 ("non sequential", "repeated"), by position and by name
+    for ri, ci in (([5, 2, 1, 7, 4], [5, 2, 1, 7, 4, 10, 100]), ([2, 2, 2, 1, 1, 3], [3, 3, 4, 4, 1, 1, 1]),
+                   ([5, 2, 1, 7, 4, 1, 5], [5, 2, 1, 7, 4, 1, 10, 100, 5])):
+        want = As[np.array(ri) - 1][:, np.array(ci) - 1]
+        _chk(mx.subset_csr(A, ri, ci), want, mx.dgRMatrix)
+        _chk(mx.subset_csr(A, [f"r{k}" for k in ri], [f"c{k}" for k in ci]), want, mx.dgRMatrix)
+    # "subset empty" (test-slice.R:85-104): no rows, with and without a column selection
+    e0 = mx.subset_csr(A, np.zeros(0, dtype=np.int32), [3, 3, 4, 4, 1, 1, 1])
+    assert e0.Dim == (0, 7) and e0.p.tolist() == [0] and e0.j.size == 0
+    e1 = mx.subset_csr(A, np.zeros(0, dtype=np.int32), np.arange(3, 11))
+    assert e1.Dim == (0, 8) and e1.p.tolist() == [0]
+    e2 = mx.subset_csr(A, np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32))
+    assert e2.Dim == (0, 0) and e2.p.tolist() == [0]
+    e3 = mx.subset_csr(A, [2, 2, 2, 1, 1, 3], np.zeros(0, dtype=np.int32))
+    assert e3.Dim == (6, 0) and e3.p.tolist() == [0] * 7
 
 
 def test_sort_sparse_indices_kat(gpu):                            # tests/testthat/test-utilities.R:32-49

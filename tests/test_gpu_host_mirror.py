@@ -93,6 +93,17 @@ def test_csr_csr_operators(gpu):                                  # test-operato
             assert isinstance(ro, mx.lgRMatrix) and isinstance(ra, mx.lgRMatrix)
             np.testing.assert_array_equal(ro.toarray() != 0, (sa.toarray() != 0) | (sb.toarray() != 0))
             np.testing.assert_array_equal(ra.toarray() != 0, (sa.toarray() != 0) & (sb.toarray() != 0))
+    # both orders, and an operand with itself (test-operators.R:36,58,80,102,118): the identical-pattern fast paths of
+    # operators.cpp:104-132, :343-395 (aliased structure; X - X is the all-empty matrix)
+    np.testing.assert_allclose((M2 + M1).toarray(), (S2 + S1).toarray(), rtol=0, atol=0)
+    np.testing.assert_allclose((M2 - M1).toarray(), (S2 - S1).toarray(), rtol=0, atol=0)
+    np.testing.assert_allclose((M2 * M1).toarray(), S2.multiply(S1).toarray(), rtol=0, atol=0)
+    same_add, same_sub, same_mul = M1 + M1, M1 - M1, M1 * M1
+    for r_ in (same_add, same_sub, same_mul):
+        assert isinstance(r_, mx.dgRMatrix) and r_.Dim == (100, 35)
+    np.testing.assert_allclose(same_add.toarray(), 2 * S1.toarray(), rtol=0, atol=0)
+    np.testing.assert_allclose(same_sub.toarray(), np.zeros((100, 35)), rtol=0, atol=0)
+    np.testing.assert_allclose(same_mul.toarray(), S1.toarray() ** 2, rtol=0, atol=0)
     for before, after in zip(snap, (M1.p, M1.j, M1.x, M2.p, M2.j, M2.x)):        # expect_unmodified (:21-27)
         np.testing.assert_array_equal(before, after)
     # unsorted operand: the glue sorts a copy, the input stays as it was (R/operators.R:742-754)

@@ -54,6 +54,22 @@ def test_dense_csc_and_crossprod(gpu):                            # test-matmul.
     for shape in ((1, 50), (50, 1)):                              # 1-row / 1-col edge shapes (:24-26)
         Xs = np.random.default_rng(5).normal(size=(shape[0], 50))
         np.testing.assert_allclose(np.asarray(Xs @ Y), Xs @ As.toarray(), rtol=1e-10, atol=1e-12)
+    # A1 (1 x 50) and B1 (50 x 1) of test-matmul.R:16-17,24-26: a sparse operand with ONE column, results 7 x 1 and 1 x 1
+    B1s = sp.csc_matrix(rsparse(50, 1, 0.4, 7)[1])
+    Y1 = mx.dgCMatrix(B1s.indptr, B1s.indices, B1s.data, B1s.shape)
+    r71 = np.asarray(X @ Y1)
+    assert r71.shape == (7, 1)
+    np.testing.assert_allclose(r71, X @ B1s.toarray(), rtol=1e-10, atol=1e-12)
+    X1 = np.random.default_rng(8).normal(size=(1, 50))
+    r11 = np.asarray(X1 @ Y1)
+    assert r11.shape == (1, 1)
+    np.testing.assert_allclose(r11, X1 @ B1s.toarray(), rtol=1e-10, atol=1e-12)
+    # tcrossprod with one-row operands on either side (test-matmul.R:57-58,63-66)
+    A1, A1s = rsparse(1, 50, 0.4, 9)
+    Bd = np.random.default_rng(9).normal(size=(20, 50))
+    np.testing.assert_allclose(np.asarray(mx.tcrossprod(A1, Bd)), A1s.toarray() @ Bd.T, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(np.asarray(mx.tcrossprod(Bd, A1)), Bd @ A1s.toarray().T, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(np.asarray(mx.tcrossprod(Bd[:1], A1)), Bd[:1] @ A1s.toarray().T, rtol=1e-10, atol=1e-12)
 
 
 def test_matmult_csr_vectors(gpu):                                # test-matmul.R:134-165

@@ -4,7 +4,8 @@ with the page-size facts that explain it.  `malloc` mode hands the library buffe
 (no MADV_HUGEPAGE: on a THP=madvise machine they are 4-KiB pages), `numpy` mode numpy arrays (numpy advises huge pages).
   [MXGPU_HUGEPAGE=1] [MXGPU_TRACE=1] python tools/cold_export_probe.py [numpy|malloc] [calls]"""
 import ctypes as C, sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from matrixextra_amd import _lib, synth
 mode = sys.argv[1] if len(sys.argv) > 1 else "numpy"

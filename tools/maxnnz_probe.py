@@ -2,7 +2,9 @@
 """Kernels at nnz = 2.1e9 (just under R's int32 limit): 32-bit offset bugs in SpMV (all kernels), the sortedness check,
 the row gather, SpMM:  python tools/maxnnz_probe.py"""
 import sys
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from matrixextra_amd import _lib, device as D
 m, per, K = 21_000_000, 100, 128

@@ -3,7 +3,8 @@
 are plain malloc / mmap memory (4-KiB pages where THP is in madvise mode).  CSR + CSR with ~1 GB of results and the
 headline product:   [MXGPU_HUGEPAGE=0] python tools/rlike_probe.py"""
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 try:
     from numpy._core.multiarray import _set_madvise_hugepage

@@ -2,7 +2,8 @@
 """Kernel-only timing of the planned sweep on cfg2 / cfg5-shard without any parity check (for A/B builds whose results
 are deliberately wrong, e.g. a plan stream confined to cache):  MXGPU_LIB=... python tools/sweep_time.py [cfg2|cfg5]"""
 import sys, ctypes
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from matrixextra_amd import _lib, device as D, synth
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"

@@ -6,7 +6,10 @@ Workloads (config.workload):
         configuration: default at N = 1.
   cfg5  BASELINE configs[4] per GPU — 1M x 200k row block, 64 nnz/row (nnz 64M, CSR values f64), f32 dense 200k x 256
         (8 such blocks = the 8M x 200k matrix).  Default for N > 1; also timed briefly at N = 1 (`cfg5_shard`).
-One "step" = one SpMM over the rank's whole matrix, inputs resident in HBM, plan built from plain CSR inside the step.
+One "step" = one SpMM over the rank's whole matrix, inputs resident in HBM.  `value` (--algo 0): the plan AUTO uses — a
+regrouping of the CSR's entries that depends on the matrix alone — is kept on the DeviceCSR and built once per matrix
+(untimed, like rows_sorted()); `plan.rebuild_every_step` in the line is the same loop with the plan rebuilt from plain CSR
+inside every step (--algo 4 times that form as `value`).
 N GPUs (one rank per GPU; `python bench.py --gpus N` starts torch.distributed.run itself when it was not started by
 it): every rank owns a row block (weak scaling), B replicated, blocks of C exchanged with one RCCL all-gather so that
 every rank holds the full C.  value = total GFLOP/s over all ranks, 2*nnz*n flops per rank-step, max-over-ranks time,
@@ -173,11 +176,53 @@ def committed_kernels_traffic(kernels, call_ms):
     return {}
 
 
+STREAM = {"GBps": None}          # measured once per run (stream_copy_probe): the box's own float4-copy rate
+
+
+def stream_copy_probe(torch, lib, _lib, nbytes=1 << 30, reps=10):
+    """every fraction is quoted against the nominal 8 TB/s AND against a device-copy STREAM probe measured on
+    the box the benchmark runs on: one 1 GiB float4 copy kernel (csrc/stream.hip), read + write bytes / time."""
+    import ctypes
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    a.zero_()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def copy():
+        _lib.check(lib.mxd_stream_copy(ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()), ctypes.c_size_t(nbytes), st))
+    for _ in range(3):
+        copy()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        copy()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    STREAM["GBps"] = round(2 * nbytes / (ms / 1e3) / 1e9, 1)
+    del a, b
+    return {"GBps": STREAM["GBps"], "ms_per_GiB_copied": round(ms, 4), "bytes_copied": nbytes,
+            "kernel": "stream_copy_kernel (16 B per lane, nontemporal stores), read + write bytes / time",
+            "guide_figure_GBps": 6290}
+
+
 def roofline(alg_bytes, seconds, **extra):
+    """call- or kernel-level fraction of `alg_bytes` (SURVEY §8d algorithmic bytes) moved in `seconds`, against the nominal
+    HBM peak (`frac`) and against the STREAM-copy rate measured in this run (`frac_of_stream_copy`)"""
     ach = alg_bytes / seconds / 1e9
     d = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes)}
+    if STREAM["GBps"]:
+        d["frac_of_stream_copy"] = round(ach / STREAM["GBps"], 4)
     d.update(extra)
+    km = d.get("traffic_kernels_ms")
+    if km:                                                          # kernel-level figure beside the call-level one
+        ka = alg_bytes / (km / 1e3) / 1e9
+        d["kernels"] = {"ms": km, "achieved": round(ka, 1), "frac": round(ka / HBM_PEAK_GBS, 4),
+                        "source": "rocprofv3 kernel durations of the committed profile (checked against this run's call time)"}
+        if STREAM["GBps"]:
+            d["kernels"]["frac_of_stream_copy"] = round(ka / STREAM["GBps"], 4)
     return d
 
 
@@ -213,12 +258,15 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] \
         if dist_on else []
 
+    keep_plan = [True]              # --algo 0: AUTO's plan is kept on the DeviceCSR (built in the untimed setup calls)
+
     def run_spmm(A_, B_, out_, colmajor_):
         if args.algo in (3, 4):
             D.spmm_planned(A_, B_, out=out_, colmajor=colmajor_, npanels=args.panels, wg_per_cu=args.wg_per_cu,
                            sync_mode=args.sync, rebuild_plan=(args.algo == 4))
         else:
-            D.spmm(A_, B_, out=out_, colmajor=colmajor_, algo=args.algo, npanels=args.panels, wg_per_cu=args.wg_per_cu)
+            D.spmm(A_, B_, out=out_, colmajor=colmajor_, algo=args.algo, npanels=args.panels, wg_per_cu=args.wg_per_cu,
+                   keep_plan=keep_plan[0])
 
     pipe = None
     cur = [None]
@@ -329,7 +377,7 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
     kernel_name = lib.mxd_spmm_last_kernel().decode()      # which kernel AUTO / --algo actually launched
     tag = None
     if not args.custom and (args.layout, args.algo, args.panels, args.wg_per_cu) == ("colmajor", 0, 0, 0) and not dist_on:
-        tag = {"cfg2": "cfg2-default", "cfg5": "cfg5-shard"}[cfg["name"]]
+        tag = {"cfg2": "cfg2-default", "cfg5": "cfg5-shard-default"}.get(cfg["name"])   # the `workload` string of profiles/*_pmc.json
     traffic = committed_traffic(kernel_name, tag, kern_avg_s * 1e3) if tag else None
     gb = nnz * n * s_dense
     res = {
@@ -358,19 +406,31 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
         res["allgather"] = {"bytes_received_per_gpu": int((world - 1) * m * n * s_dense),
                             "approx_ms": round(gather_s * 1e3, 3),
                             "approx_GBps_in_per_gpu": round((world - 1) * m * n * s_dense / gather_s / 1e9, 1)}
+    if kernel_name == "spmm_plan_kernel" and args.algo in (0, 4):
+        res["plan"] = {"value_is": "plan kept on the DeviceCSR: built once per matrix in the untimed setup calls, every timed "
+                                   "step = repack of B + the sweep" if args.algo == 0 else
+                                   "plan rebuilt from plain CSR inside every timed step (--algo 4)",
+                       "info": A.plan_info() if A._plan is not None else None}
     if want_steady and kernel_name == "spmm_plan_kernel" and args.algo in (0, 4) and not dist_on:
-        # `value` above pays for building the plan from plain CSR inside every step.  A caller that multiplies the
-        # same matrix repeatedly keeps the plan (it depends on A only): steady-state figure, reported separately.
-        for _ in range(2):
-            D.spmm_planned(A, B, out=C_loc, colmajor=colmajor)
+        # the other form, same loop: --algo 0 -> the C-ABI's own AUTO (plan rebuilt from plain CSR inside every step: what a
+        # caller pays who brings a new matrix every time); --algo 4 -> the kept plan
+        other_keeps = args.algo == 4
+
+        def other():
+            if other_keeps:
+                D.spmm_planned(A, B, out=C_loc, colmajor=colmajor)
+            else:
+                D.spmm(A, B, out=C_loc, colmajor=colmajor, keep_plan=False)
+        for _ in range(3):
+            other()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(steps):
-            D.spmm_planned(A, B, out=C_loc, colmajor=colmajor)
+            other()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / steps
-        res["steady_state_cached_plan"] = {"ms_per_step": round(dt * 1e3, 4),
-                                           "GFLOP/s": round(flops_rank_step / dt / 1e9, 1), "plan": A.plan_info()}
+        res["plan"]["kept_plan" if other_keeps else "rebuild_every_step"] = {
+            "ms_per_step": round(dt * 1e3, 4), "GFLOP/s": round(flops_rank_step / dt / 1e9, 1)}
     if want_cpu:
         res["cpu_baseline"] = cpu_baseline_spmm(args, p, j, x, B_host, dtype)
     res["_host"] = (p, j, x, A, B, B_host)          # handed to the extras; removed before printing
@@ -420,6 +480,10 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
             cpu_time(lambda: O.matmul_csr_dvec_numeric(p, j, x, v_host, 1), 2)
         e["cpu_baseline"] = {"value": round(2 * nnz / ta / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port",
                              "single_thread": {"value": round(2 * nnz / t1 / 1e9, 3), "unit": "GFLOP/s", "cores": 1},
+                             "stronger_baseline": "single_thread" if t1 < ta else "all_threads",
+                             "note": "the reference's loop is `schedule(dynamic)` with one row per grab (matmul.cpp:396-397); with "
+                                     "32 entries per row the scheduling costs more than the row, so the restated loop is SLOWER on "
+                                     "all threads than on one — compare with the single-thread figure",
                              "sample": "the whole cfg3 SpMV, matmul_csr_dvec restated (OpenMP over rows), best of 3"}
     # the same product through a kept plan (entries regrouped by column panel so that v sits in LDS): what a solver that
     # multiplies by the same X every iteration gets; the plan build is reported beside it, never inside the figure
@@ -449,8 +513,11 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
     assert np.array_equal(gp, o["indptr"]) and np.array_equal(gj, o["indices"]) and np.array_equal(gx, o["values"]), \
         "row gather differs from the oracle"
     e = {"ms": round(t * 1e3, 4), "nnz_out": g.nnz, "Mnnz/s": round(g.nnz / t / 1e6, 1),
-         "roofline": roofline(byts, t, **committed_kernels_traffic([("gather_count_kernel", 1), ("gather_copy_kernel", 1)], t * 1e3)),
+         "roofline": roofline(byts, t, **committed_kernels_traffic([("gather_fused_kernel", 1)], t * 1e3)),
+         "kernel": "gather_fused_kernel: lengths + look-back scan + copy in one launch, size read back once behind it",
          "parity": "bit-exact vs oracle (indptr, indices, values)"}
+    t2 = timeit(lambda: D.csr_gather_rows(A, rows, one_launch=False))
+    e["two_launch_form_ms"] = round(t2 * 1e3, 4)
     if want_cpu:
         t1 = cpu_time(lambda: O.copy_csr_rows_numeric(p, j, x, rows_host), 3)
         e["cpu_baseline"] = {"value": round(byts / t1 / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
@@ -500,7 +567,7 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
     t = timeit(lambda: (setattr(A1, "_sorted", None), A1.rows_sorted()), reps=10)
     byts = 4 * (m4 + 1) + 4 * A1.nnz
     res["rows_sorted_check_cfg4"] = {"ms": round(t * 1e3, 4),
-                                     "roofline": roofline(byts, t, **committed_kernels_traffic([("rows_sorted_count_kernel", 1)], t * 1e3))}
+                                     "roofline": roofline(byts, t, **committed_kernels_traffic([("rows_sorted_tile_kernel", 1)], t * 1e3))}
     del A1, A2, p1, j1, x1, p2, j2, x2
     torch.cuda.empty_cache()
 
@@ -526,16 +593,27 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
         _lib.check(cfn(C.c_void_p(p.ctypes.data), C.c_void_p(j.ctypes.data), C.c_void_p(x.ctypes.data), C.c_int(m_),
                        C.c_void_p(Yc.ctypes.data), C.c_int(n_), C.c_int(K_), C.c_int(1), C.c_void_p(q)))
         return time.perf_counter() - t0, q
+    def phases():
+        buf = C.create_string_buffer(512)
+        lib.mx_last_call_phases(buf, C.c_size_t(512))
+        out_ = {}
+        for item in buf.value.decode().split(";")[1:]:
+            k, _, v = item.partition("=")
+            try:
+                out_[k] = float(v)
+            except ValueError:
+                out_[k] = v
+        return out_
     _, q = call()                                  # first call of the process: allocates the library's grow-only device scratch
-    cold, cached = [], []
-    for k in range(5):
+    cold, cached, ph_cold, ph_cached = [], [], [], []
+    for k in range(10):
         libc.free(q)                              # (freeing the previous 1 GB result is not part of the next call)
-        if k < 2:
+        if k < 5:
             lib.mx_cache_invalidate(None)         # CSR not on the device: upload + compute + download
         t, q = call()
-        (cold if k < 2 else cached).append(t)
+        (cold if k < 5 else cached).append(t)
+        (ph_cold if k < 5 else ph_cached).append(phases())
     out = np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_double if f64 else C.c_float)), shape=(n_, m_)).T   # view; freed below
-    ts = [min(cold), min(cached)]
     n = out.shape[1]
     ref = np.zeros(2048 * n, dtype=B_host.dtype)
     O.gemm_csr_drm_as_drm(2048, n, p[:2049], j, x, B_host.reshape(-1), n, ref, n, threads, True)
@@ -544,14 +622,27 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
     assert err <= 1e-9, f"export-level SpMM differs from the oracle: {err}"
     del out
     libc.free(q)
+
+    def med(v):
+        return float(np.median(v))
+
+    def phase_medians(ps):
+        keys = [k for k in ps[0] if all(isinstance(q_.get(k), float) for q_ in ps)]
+        return {k: round(med([q_[k] for q_ in ps]), 3) for k in keys}
     res["export_call_end_to_end"] = {
-        "ms_cold": round(ts[0] * 1e3, 2), "ms_csr_cached": round(ts[1] * 1e3, 2),
-        "GFLOP/s_cold": round(2 * nnz * n / ts[0] / 1e9, 1), "GFLOP/s_csr_cached": round(2 * nnz * n / ts[1] / 1e9, 1),
+        "ms_cold": round(med(cold) * 1e3, 2), "ms_csr_cached": round(med(cached) * 1e3, 2),
+        "ms_cold_all": [round(v * 1e3, 2) for v in cold], "ms_csr_cached_all": [round(v * 1e3, 2) for v in cached],
+        "phases_ms_cold": phase_medians(ph_cold), "phases_ms_csr_cached": phase_medians(ph_cached),
+        "csr_state_cached": ph_cached[-1].get("csr"),
+        "GFLOP/s_cold": round(2 * nnz * n / med(cold) / 1e9, 1), "GFLOP/s_csr_cached": round(2 * nnz * n / med(cached) / 1e9, 1),
         "parity_max_err_over_max_abs_vs_oracle": err,
         "note": "mx_tcrossprod_csr_dense_* on cfg2: ordinary (pageable) host vectors in, a freshly malloc'ed, untouched host "
                 "matrix out (as R allocates it); cold = CSR not on the device (upload, compute and download pipelined over "
-                "row blocks; best of 2), csr_cached = the same host vectors again (device-side CSR cache; download-bound: "
-                "1 GB over PCIe; best of 3)"}
+                "row blocks), csr_cached = the same host vectors again (device-side CSR cache and the matrix's kept plan; "
+                "download-bound: 1 GB over PCIe); medians of 5 calls each, phases = medians of mx_last_call_phases "
+                "(setup = B upload queued + cache look-up; block 0 = first product queued; touched C / pinned C = host pages of "
+                "the result exist / are registered; queued = all blocks and downloads queued; fingerprint = cache key of a new "
+                "operand hashed while the queues drain; kernels = compute queue empty; D2H C = download queue empty)"}
     return res
 
 

@@ -84,9 +84,29 @@ int  mx_host_unregister(void *hptr);
  * operand changed in place is simply a miss; with MXGPU_CACHE_FINGERPRINT=sampled (a few 512-byte samples per array) a
  * caller that mutates a cached operand in place must call mx_cache_invalidate (host_ptr = any of the operand's three
  * vectors; NULL = everything). */
+/* An entry also carries what has been derived from the operand on the device: the SpMM plan of the whole matrix (built
+ * the first time a product that AUTO would plan finds the operand in the cache; every later product, and every block of a
+ * pipelined call, skips the build) and, on request, an SpMV plan (option "spmv_planned").  Those arrays are about as large
+ * as the CSR itself and are NOT counted against max_bytes; mx_cache_invalidate frees them with the entry.  When a device
+ * allocation fails the library empties the cache, frees AUTO's per-thread plan and tries once more.  What a thread keeps
+ * beyond that (export scratch for B and C, grow-only) is freed with mxd_release_workspaces() from that thread. */
 int  mx_cache_configure(int64_t max_bytes);
 int  mx_cache_invalidate(const void *host_ptr);
 int  mx_cache_stats(int64_t *bytes, int *entries, int64_t *hits, int64_t *misses);
+
+/* Run-time options (the environment variable in brackets is the default when the option was never set):
+ *   "spmv_planned" [MXGPU_SPMV_PLANNED, default 0]  1: mx_matmul_csr_dvec_* on an operand found in the CSR cache builds / uses
+ *                  an SpMV plan (mxd_spmv_plan_*: ~2x faster per product, equal to the reference to 1e-12 but not bitwise
+ *                  and not bit-reproducible from run to run; the float32 kind rounds once from an f64 sum where the
+ *                  reference accumulates in float, src/matmul.cpp:403).  0: every call runs the one-shot kernel — MX_SPMV_FLAT
+ *                  for large operands: bit for bit the reference's loop, whatever the cache holds.
+ *   "spmv_algo"    [MXGPU_SPMV_ALGO, default 0 = AUTO]  mx_spmv_algo for the one-shot products of the exports
+ *   "spmv_planned_calls"  read-only: export-level products served by the planned kernel so far
+ * mx_last_call_phases: wall-clock phases of the calling thread's last SpMM export as "what;key=value;phase=ms;..."
+ * (bench.py reports them for the cold / cached export calls). */
+int  mx_set_option(const char *name, int64_t value);
+int  mx_get_option(const char *name, int64_t *value);
+int  mx_last_call_phases(char *buf, size_t buflen);
 
 /* ---- element types --------------------------------------------------------- */
 typedef enum {
@@ -164,6 +184,18 @@ int mxd_spmm_plan_destroy(mx_spmm_plan *plan);
 int mxd_spmm_plan_info(const mx_spmm_plan *plan, int *npanels, int64_t *padded_entries);
 int mxd_spmm_plan_run(const mx_spmm_plan *plan, int n, const void *B, size_t ldb, void *C, size_t ldc,
                       int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream);
+/* rows [row0, row0 + nrows) of the planned matrix only (row0 a multiple of 64); C points at the block's first row, ldc is the
+ * leading dimension of the whole result — what the export pipeline runs per row block once a matrix has a plan */
+int mxd_spmm_plan_run_rows(const mx_spmm_plan *plan, int row0, int nrows, int n, const void *B, size_t ldb, void *C,
+                           size_t ldc, int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream);
+/* What MX_SPMM_AUTO would run for these operands (*algo = MX_SPMM_PLANNED / _SLAB / _ROWWAVE; host arithmetic only), and
+ * mxd_spmm_plan_create with AUTO's padding limit: *ready = 0 when the plan would hold more than 1.55x the CSR's entries
+ * (very uneven rows) — the plan is then sized but not filled and the caller runs MX_SPMM_ROWWAVE, as AUTO does.  Together:
+ * keep AUTO's decision AND the plan across products with one matrix (matrixextra_amd/device.py DeviceCSR, the CSR cache). */
+int mxd_spmm_auto_algo(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
+                       int colmajor_out, int *algo);
+int mxd_spmm_plan_create_auto(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+                              int npanels, void *stream, mx_spmm_plan **plan, int *ready);
 
 /* AUTO's plan and the slab-major copy of B live in grow-only per-thread device buffers between calls; this frees them */
 int mxd_release_workspaces(void);
@@ -200,10 +232,13 @@ int mxd_spmv_csr_dvec_ex(int m, int K, int64_t nnz,
 /* Planned SpMV for repeated products with the same matrix (csrc/spmv_plan.hip): the plan regroups A's entries by
  * (block of 4096 rows, panel of 6144 columns) so that the kernel can keep the panel of v it needs in LDS instead of
  * gathering v[j] from L2 — the gather, not the (j, a) stream, bounds the one-shot kernels.  Build once per matrix
- * (about the cost of two one-shot products; one internal stream sync), run against any number of vectors of any of
+ * (about the cost of six one-shot products — ~1 ms at cfg3 —; one internal stream sync), run against any number of vectors of any of
  * the four kinds.  K <= 64 * 6144 columns.  Sums: panels in ascending order, entries of a row inside a panel added with
- * LDS atomics — equal to the reference to 1e-12 (f64) / 1e-5 (float32 kind), not bitwise; the one-shot MX_SPMV_FLAT
- * kernel is the bit-exact path. */
+ * LDS atomics — equal to the reference to 1e-12 (f64) / 1e-5 (float32 kind), not bitwise and not bit-reproducible from
+ * run to run; the float32 kind keeps f64 sums and rounds ONCE at the end, where the reference accumulates in float and
+ * rounds per term (src/matmul.cpp:403).  Integer / logical vectors: a row that meets an NA element yields NA_real_, a NaN
+ * that comes out of the arithmetic stays an ordinary NaN (as the reference).  The one-shot MX_SPMV_FLAT kernel is the
+ * bit-exact path. */
 typedef struct mx_spmv_plan mx_spmv_plan;
 int mxd_spmv_plan_create(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
                          void *stream, mx_spmv_plan **plan);
@@ -235,9 +270,10 @@ int mxd_csr_merge_fill(int op, int m,
                        const int32_t *indptr2, const int32_t *indices2, const void *values2, int64_t nnz2,
                        const int32_t *out_indptr, int32_t *out_indices, void *out_values,
                        void *stream);
-/* The same merge in ONE pass over the inputs (what the exports and bench.py use): every workgroup sizes its tile of
- * rows from the registers it has just loaded, finds its place in the output with a decoupled look-back over the tiles'
- * totals, and places the entries.  out_indices / out_values must hold the UPPER BOUND of the result — nnz1 + nnz2
+/* The same merge in ONE pass over the inputs — OPT-IN (the exports use it only with MXGPU_MERGE_FUSED=1; bench.py and the
+ * exports default to the count -> fill pair above, which is faster at cfg4: 1.07-1.14 ms against 1.40-1.6 ms, DESIGN.md
+ * §4.4): every workgroup sizes its tile of rows from the registers it has just loaded, finds its place in the output with
+ * a decoupled look-back over the tiles' totals, and places the entries.  out_indices / out_values must hold the UPPER BOUND of the result — nnz1 + nnz2
  * entries for ADD / SUB / OR / XOR, min(nnz1, nnz2) for MUL / AND, like the reference's scratch arrays
  * (operators.cpp:402-406, :139-143); the bound must fit int32 (else use the count -> fill pair).
  * workspace: mxd_merge_fused_workspace_bytes(m).  *nnz_out_host as above. */
@@ -261,6 +297,16 @@ int mxd_csr_gather_fill(int r, const int32_t *indptr, const int32_t *indices, co
                         const int32_t *rows_take, const int32_t *new_indptr,
                         int32_t *new_indices, void *new_values, int value_dtype,
                         int64_t nnz_out /* lanes-per-row hint, -1 = unknown */, void *stream);
+
+/* The same gather in ONE launch, for callers that can size the outputs from an estimate: new_indices / new_values hold
+ * `capacity` entries.  new_indptr[r+1] and *nnz_out_host (read back once, behind all the work) are always exact; when
+ * *nnz_out_host > capacity the entries beyond the capacity were not copied — allocate exactly and call mxd_csr_gather_fill
+ * with the new_indptr this call produced.  avg_row_len (mean entries of a source row, <= 0 unknown) picks the lanes per row.
+ * workspace: mxd_gather_workspace_bytes(r). */
+int mxd_csr_gather_fused(int r, const int32_t *indptr, const int32_t *indices, const void *values,
+                         const int32_t *rows_take, int32_t *new_indptr, int32_t *new_indices, void *new_values,
+                         int value_dtype, int64_t capacity, double avg_row_len, void *workspace,
+                         int64_t *nnz_out_host, void *stream);
 
 /* Column-filtering slices.  Same count -> scan -> fill shape as the row gather; workspace of
  * mxd_gather_workspace_bytes(r).  avg_row_len (mean entries per source row) only steers the lanes-per-row choice.
@@ -334,6 +380,11 @@ int mxd_csr_by_dvec(int m, int ncols, int64_t nnz, const int32_t *indptr, const 
 int mxd_check_is_seq(const int32_t *idx, int64_t n, int reversed, int32_t *workspace4,
                      int *flag_host, void *stream);
 
+/* STREAM-copy probe: dst[0..bytes) = src[0..bytes) with 16-byte loads / nontemporal stores (pointers and size multiples of
+ * 16).  bench.py times it in-run: rooflines are quoted against the nominal 8 TB/s AND against this kernel's rate
+ * (2 * bytes / time) on the box at hand. */
+int mxd_stream_copy(void *dst, const void *src, size_t bytes, void *stream);
+
 /* exclusive scan of int32 counts[n] -> out[n+1] (out[n] = total); total also
  * returned as int64 in *total_dev (device int64).  workspace: mxd_scan_workspace_bytes(n). */
 size_t mxd_scan_workspace_bytes(int64_t n);
@@ -343,6 +394,8 @@ int mxd_exclusive_scan_i32(const int32_t *counts, int64_t n, int32_t *out,
 /* Next-row components: per-row sortedness check and
  * per-row index sort (check_is_sorted / sort_sparse_indices_known_ncol,
  * src/misc.cpp:118-128, :261-298). */
+/* indptr[0] may be > 0 (a row-block view of a larger CSR that keeps absolute offsets into `indices`): only the entries
+ * [indptr[0], indptr[m]) are looked at.  One pass over the indices + one over indptr, nothing read twice. */
 int mxd_csr_rows_sorted(int m, const int32_t *indptr, const int32_t *indices,
                         int32_t *workspace4, int *flag_host, void *stream);
 /* sorts every row by column id (stable), in place; tmp_indices / tmp_values are

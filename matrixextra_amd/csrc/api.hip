@@ -5,6 +5,7 @@
 #include "mx_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
@@ -54,6 +55,9 @@ int set_error(const char *fmt, ...)
     return 1;
 }
 
+int spmm_auto_family(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor);
+int spmm_block(int family, bool from_auto, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+               const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, int npanels, hipStream_t st);
 int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
                 const void *v, int v_dtype, void *y, int algo, hipStream_t st);
 // xfer.hip: synchronous host <-> device copies, pipelined through pinned slots + a host copy pool when large
@@ -65,26 +69,55 @@ uint64_t host_hash(const void *p, size_t bytes, uint64_t seed);
 bool pin_host(const void *p, size_t bytes, bool all_devices = false);
 void unpin_host(const void *p);
 
-// MXGPU_TRACE=1: wall-clock phases of an export-level call on stderr
+// Wall-clock phases of the calling thread's last export-level SpMM call: always recorded (a handful of clock reads per
+// call), read with mx_last_call_phases(); MXGPU_TRACE=1 also prints them on stderr as they are passed.
+static thread_local char g_phases[512] = "";
 struct Trace {
     bool on;
     const char *what;
+    size_t used = 0;
     std::chrono::steady_clock::time_point t0, last;
     explicit Trace(const char *w) : on(getenv("MXGPU_TRACE") != nullptr), what(w)
     {
-        if (on) t0 = last = std::chrono::steady_clock::now();
+        t0 = last = std::chrono::steady_clock::now();
+        used = (size_t)snprintf(g_phases, sizeof(g_phases), "%s", w);
     }
     ~Trace() { mark("release"); }                   // declared before the device buffers: runs after their hipFree
+    void note(const char *key, const char *value)
+    {
+        if (used < sizeof(g_phases)) used += (size_t)snprintf(g_phases + used, sizeof(g_phases) - used, ";%s=%s", key, value);
+    }
     void mark(const char *phase)
     {
-        if (!on) return;
         const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[mxgpu] %s: %-10s %8.3f ms (total %8.3f)\n", what, phase,
-                std::chrono::duration<double, std::milli>(now - last).count(),
-                std::chrono::duration<double, std::milli>(now - t0).count());
+        const double dt = std::chrono::duration<double, std::milli>(now - last).count();
+        const double tot = std::chrono::duration<double, std::milli>(now - t0).count();
+        if (used < sizeof(g_phases)) used += (size_t)snprintf(g_phases + used, sizeof(g_phases) - used, ";%s=%.3f", phase, dt);
+        if (on) fprintf(stderr, "[mxgpu] %s: %-10s %8.3f ms (total %8.3f)\n", what, phase, dt, tot);
         last = now;
     }
 };
+
+// Device memory is kept between calls in three places: the CSR cache (and the plans hanging off its entries), the
+// per-thread export scratch and AUTO's per-thread plan.  When an allocation fails all of that is given back and the
+// allocation is tried once more (an export that fitted before the cache existed must still fit).
+static void release_kept_device_memory();
+static hipError_t malloc_with_relief(void **p, size_t n)
+{
+    hipError_t e = hipMalloc(p, n);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    release_kept_device_memory();
+    return hipMalloc(p, n);
+}
+void *scratch_buffer_relief(int slot, size_t bytes)
+{
+    void *q = mx::scratch_buffer(slot, bytes);
+    if (q) return q;
+    (void)hipGetLastError();
+    release_kept_device_memory();
+    return mx::scratch_buffer(slot, bytes);
+}
 
 // device buffer: owning (alloc / upload) or an alias of memory owned elsewhere (the CSR cache)
 struct DevBuf {
@@ -99,7 +132,7 @@ struct DevBuf {
     {
         bytes = n;
         if (n == 0) n = 16;                  // keep pointers non-null and 16-B aligned
-        MX_HIP(hipMalloc(&p, n));
+        MX_HIP(malloc_with_relief(&p, n));
         return 0;
     }
     void alias(void *ptr, size_t n) { p = ptr; bytes = n; own = false; }
@@ -129,10 +162,22 @@ static inline size_t dtype_bytes(int dt)
 // duration of a call, so eviction never pulls memory from under a running export.
 struct CsrDev {
     DevBuf p, j, x;
-    mx_spmv_plan *spmv_plan = nullptr;       // built when the operand is multiplied by a vector for the second time
+    mx_spmv_plan *spmv_plan = nullptr;       // built on request (MXGPU_SPMV_PLANNED=1) when the operand comes back for another product
     int spmv_plan_K = -1;
+    // SpMM plan of the whole matrix, built the first time the operand is found in the cache by a product that AUTO would
+    // plan: later products (and every block of a pipelined call) skip the 0.27 ms (cfg2) / 4 ms (cfg5) build.  Safe to keep:
+    // an entry is only ever found again when the hash of every byte of its three host arrays still matches.
+    mx_spmm_plan *spmm_plan = nullptr;
+    int spmm_plan_K = -1, spmm_plan_panels = 0;
+    bool spmm_plan_rejected = false;         // the plan would pad too much: AUTO's row-wave fallback, remembered
     std::mutex plan_mu;
-    ~CsrDev() { if (spmv_plan) mxd_spmv_plan_destroy(spmv_plan); }
+    void drop_plans()
+    {
+        if (spmv_plan) mxd_spmv_plan_destroy(spmv_plan);
+        if (spmm_plan) mxd_spmm_plan_destroy(spmm_plan);
+        spmv_plan = nullptr; spmm_plan = nullptr; spmm_plan_rejected = false;
+    }
+    ~CsrDev() { drop_plans(); }
     const void *hp = nullptr, *hj = nullptr, *hx = nullptr;
     int m = 0, device = 0;
     int64_t nnz = 0;
@@ -190,6 +235,19 @@ public:
         misses_++;
         return nullptr;
     }
+    // is there an entry for these three host vectors at all?  (a miss by address needs no fingerprint to be known as a miss)
+    bool has_address(const int32_t *hp, const int32_t *hj, const void *hx, int m, int64_t nnz, size_t vb)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu_);
+        for (auto &it : items_) {
+            const CsrDev &e = *it;
+            if (e.device == dev && e.hp == hp && e.hj == hj && e.hx == hx && e.m == m && e.nnz == nnz && e.vb == vb) return true;
+        }
+        return false;
+    }
+    void count_miss() { std::lock_guard<std::mutex> lk(mu_); misses_++; }
     void insert(const std::shared_ptr<CsrDev> &e)
     {
         std::lock_guard<std::mutex> lk(mu_);
@@ -232,7 +290,11 @@ public:
 private:
     CsrCache()
     {
+        // default: 8 GiB, but never more than a quarter of the device (a small or shared GPU keeps room for the operands)
         cap_ = (size_t)8192 << 20;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 4 < cap_) cap_ = total_b / 4;
+        else (void)hipGetLastError();
         if (const char *e = getenv("MXGPU_CSR_CACHE_MB")) cap_ = (size_t)(atoll(e) > 0 ? atoll(e) : 0) << 20;
     }
     std::mutex mu_;
@@ -241,6 +303,16 @@ private:
     uint64_t clock_ = 0;
     int64_t hits_ = 0, misses_ = 0;
 };
+
+// (not the export scratch: the failing allocation may belong to a pipelined call whose B already sits in it)
+void plan_auto_release();
+void *slab_pack_workspace(size_t bytes, bool release);
+static void release_kept_device_memory()
+{
+    CsrCache::get().invalidate(nullptr);
+    mx::plan_auto_release();
+    mx::slab_pack_workspace(0, true);
+}
 
 struct Csr {
     DevBuf p, j, x;                          // aliases of `hold`'s buffers
@@ -258,11 +330,17 @@ struct Csr {
         MX_REQUIRE(nnz >= 0 && indptr[0] >= 0, "CSR upload: negative index pointer");
         const size_t pb = sizeof(int32_t) * ((size_t)m + 1), jb = sizeof(int32_t) * (size_t)nnz, xb = value_bytes * (size_t)nnz;
         use_cache = use_cache && pb + jb + xb >= ((size_t)1 << 20) && CsrCache::get().enabled();
+        // The fingerprint reads every byte of the operand on the host team (cfg2: ~1.3 ms, cfg5 whole: ~40 ms).  It is needed
+        // at once only when the cache holds an entry for these addresses (is it still the same matrix?); for an operand the
+        // cache has never seen it is only the key of the entry to come and is computed later — by the pipelined exports
+        // while the GPU and the DMA engines are busy (fingerprint_now), otherwise in publish().
         uint64_t fp = 0;
         if (use_cache) {
-            fp = fingerprint_array(fingerprint_array(fingerprint_array(0xcbf29ce484222325ULL, indptr, pb), indices, jb),
-                                   value_bytes ? values : nullptr, xb);
-            hold = CsrCache::get().find(indptr, indices, value_bytes ? values : nullptr, m, nnz, value_bytes, fp);
+            if (CsrCache::get().has_address(indptr, indices, value_bytes ? values : nullptr, m, nnz, value_bytes)) {
+                fp = fingerprint_of(indptr, indices, value_bytes ? values : nullptr, pb, jb, xb);
+                have_fp = true;
+                hold = CsrCache::get().find(indptr, indices, value_bytes ? values : nullptr, m, nnz, value_bytes, fp);
+            } else CsrCache::get().count_miss();
         }
         if (hold) {
             resident = true;
@@ -289,11 +367,25 @@ struct Csr {
         publish();
         return 0;
     }
+    static uint64_t fingerprint_of(const int32_t *indptr, const int32_t *indices, const void *values, size_t pb, size_t jb, size_t xb)
+    {
+        return fingerprint_array(fingerprint_array(fingerprint_array(0xcbf29ce484222325ULL, indptr, pb), indices, jb), values, xb);
+    }
+    // the key of the entry to come, if it has not been computed yet (call where the host has time to spare)
+    void fingerprint_now()
+    {
+        if (resident || !cacheable || have_fp) return;
+        CsrDev &e = *hold;
+        e.fp = fingerprint_of((const int32_t *)e.hp, (const int32_t *)e.hj, e.hx, sizeof(int32_t) * ((size_t)e.m + 1),
+                              sizeof(int32_t) * (size_t)e.nnz, e.vb * (size_t)e.nnz);
+        have_fp = true;
+    }
     void publish()
     {
-        if (!resident && cacheable) CsrCache::get().insert(hold);
+        if (!resident && cacheable) { fingerprint_now(); CsrCache::get().insert(hold); }
         resident = true;
     }
+    bool have_fp = false;
     // uploads indptr[0..m], indices/values[0..indptr[m]) (or finds them in the cache); value_bytes 0 => no values
     int upload(const int32_t *indptr, const int32_t *indices, const void *values, int m, size_t value_bytes)
     {
@@ -435,6 +527,10 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
     mx::prefault_begin(C_host, c_bytes);
     std::vector<int> cut((size_t)nd + 1);
     partition_rows(indptr, m, nd, 12.0, (double)n * sizeof(real_t), cut.data());
+    // one kernel family for the whole product (see spmm_host); the alignment rules only look at the low bits of the pointers
+    const int family = algo == MX_SPMM_AUTO ? mx::spmm_auto_family(m, n, K_rows, dt, (const void *)(uintptr_t)256, ldb,
+                                                                   (const void *)(uintptr_t)256, colmajor ? (size_t)m : ldc,
+                                                                   colmajor ? 1 : 0) : algo;
     // host memory registered for every device; `gate` opens once the result is registered (downloads wait for it)
     Pin pinB, pinJ, pinX, pinC;
     // (large arrays as a whole, smaller ones by their interior pages; what cannot be registered goes up by plain copies)
@@ -468,7 +564,7 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
         const size_t ldc_k = colmajor ? (size_t)mk : ldc;
         bool ok = upload_through(pinB, dB.p, B_host, b_bytes, L.up);
         std::vector<int> bc((size_t)nblk + 1);
-        for (int b = 0; b <= nblk; b++) bc[b] = (int)((int64_t)mk * b / nblk);
+        for (int b = 0; b <= nblk; b++) bc[b] = b == nblk ? mk : (int)((int64_t)mk * b / nblk) & ~1023;   // whole generations of the planned kernel
         for (int b = 0; b < nblk && ok; b++) {
             const int64_t e0 = p_local[bc[b]], e1 = p_local[bc[b + 1]];
             if (e1 > e0) {
@@ -486,8 +582,8 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
             if (p_local[r0] == p_local[r1]) {
                 if (colmajor) (void)hipMemset2DAsync(dCb, ldc_k * sizeof(real_t), 0, (size_t)(r1 - r0) * sizeof(real_t), n, L.run);
                 else (void)hipMemsetAsync(dCb, 0, (size_t)(r1 - r0) * ldc_k * sizeof(real_t), L.run);
-            } else if (mxd_spmm_csr_dense_ex(r1 - r0, n, K_rows, dp.as<int32_t>() + r0, dj.as<int32_t>(), dx.as<double>(), dB.p,
-                                             ldb, dCb, ldc_k, dt, colmajor ? 1 : 0, algo, 0, npanels, 0, L.run)) {
+            } else if (mx::spmm_block(family, algo == MX_SPMM_AUTO, r1 - r0, n, K_rows, dp.as<int32_t>() + r0, dj.as<int32_t>(),
+                                      dx.as<double>(), dB.p, ldb, dCb, ldc_k, dt, colmajor ? 1 : 0, npanels, L.run)) {
                 failed("spmm");
                 return;
             }
@@ -577,7 +673,7 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
         if (L0.init(2 * (size_t)MAX_BLK + 2)) return 1;
         fence.l = &L0;
         // device B from the thread's grow-only scratch (no hipMalloc / hipFree of gigabytes per call)
-        dB = (real_t *)mx::scratch_buffer(mx::MX_SCRATCH_EXPORT_B, b_bytes);
+        dB = (real_t *)scratch_buffer_relief(mx::MX_SCRATCH_EXPORT_B, b_bytes);
         MX_REQUIRE(dB, "spmm export: cannot allocate the device operands");
         evB = L0.ev[2 * MAX_BLK];
         if (pinB.pin(B_host, b_bytes)) {
@@ -626,17 +722,49 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     if (shape == COLS) nblk = std::max(1, std::min(nblk, n / col_gran));
     static_assert(MAX_BLK == 16, "nblk above is capped at 16");
     Lanes &L = lanes();
-    real_t *dC = (real_t *)mx::scratch_buffer(mx::MX_SCRATCH_EXPORT_C, c_bytes);
+    real_t *dC = (real_t *)scratch_buffer_relief(mx::MX_SCRATCH_EXPORT_C, c_bytes);
     MX_REQUIRE(dC, "spmm export: cannot allocate the device operands");
     const int64_t nnz = A.nnz;
+    // The kernel family is chosen ONCE, for the whole product, and every block runs it (AUTO applied block by block took
+    // the row-wave kernel for cfg2's blocks — each below AUTO's size threshold — and would hand back other last bits cold
+    // than cached once cached calls use the matrix's plan).
+    const int family = algo == MX_SPMM_AUTO ? mx::spmm_auto_family(m, n, K_rows, dt, dB, ldb, dC, ldc, colmajor ? 1 : 0) : algo;
+    // A matrix that is found on the device again keeps a plan of ALL its rows on its cache entry: built once (here, when
+    // AUTO plans this product), used by every block of this call and by every later call.
+    mx_spmm_plan *plan = nullptr;
+    if (A.cache_hit && algo == MX_SPMM_AUTO && family == MX_SPMM_PLANNED) {
+        CsrDev &e = *A.hold;
+        std::lock_guard<std::mutex> lk(e.plan_mu);
+        if (e.spmm_plan && (e.spmm_plan_K != K_rows || e.spmm_plan_panels != npanels)) {
+            mxd_spmm_plan_destroy(e.spmm_plan);
+            e.spmm_plan = nullptr; e.spmm_plan_rejected = false;
+        }
+        if (!e.spmm_plan && !e.spmm_plan_rejected) {
+            int ready = 0;
+            if (mxd_spmm_plan_create_auto(m, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), npanels, L.run,
+                                          &e.spmm_plan, &ready)) {
+                e.spmm_plan = nullptr;                               // (no memory for a plan: the per-block path below)
+            } else if (!ready) {
+                mxd_spmm_plan_destroy(e.spmm_plan);
+                e.spmm_plan = nullptr; e.spmm_plan_rejected = true;
+            }
+            e.spmm_plan_K = K_rows; e.spmm_plan_panels = npanels;
+            tr.mark("plan");
+        }
+        plan = e.spmm_plan;
+    }
+    tr.note("csr", A.cache_hit ? (plan ? "cached+plan" : "cached") : "uploaded");
     if (!A.resident) {
         const bool direct_up = pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz) && pinX.pin(values, sizeof(double) * (size_t)nnz);
         if (!direct_up) { if (A.finish_upload()) return 1; }     // whole arrays through xfer_h2d; the blocks below then only compute
     }
-    // block b = rows [cut[b], cut[b+1]) (ROWS, ROWS_STRIDED) or columns (COLS)
+    // block b = rows [cut[b], cut[b+1]) (ROWS, ROWS_STRIDED; cut at multiples of 1024 rows = whole generations of the
+    // planned kernel: a block that ended inside an octet of 64 rows would leave a half-empty octet to its own plan, and the
+    // whole matrix's plan can only be run from an octet boundary) or columns (COLS)
     std::vector<int> cut((size_t)nblk + 1);
     for (int b = 0; b <= nblk; b++)
-        cut[b] = shape == COLS ? (b == nblk ? n : (int)((int64_t)(n / col_gran) * b / nblk) * col_gran) : (int)((int64_t)m * b / nblk);
+        cut[b] = shape == COLS ? (b == nblk ? n : (int)((int64_t)(n / col_gran) * b / nblk) * col_gran)
+                               : (b == nblk ? m : (int)((int64_t)m * b / nblk) & ~1023);
     const bool uploading = !A.resident;
     if (uploading) {
         for (int b = 0; b < nblk; b++) {                         // the whole upload is queued up front
@@ -667,64 +795,92 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     auto piece_ptr = [&](int b) { return (char *)C_host + hb[b]; };
     auto piece_bytes = [&](int b) { return hb[b + 1] - hb[b]; };
     if (incremental) { mx::prefault_wait(); mx::prefault_begin(piece_ptr(0), piece_bytes(0)); }
-    // ---- compute: everything is queued before the host waits for anything
+    // ---- One loop over the blocks: block b's product is queued, then its download behind it (first-touch by the host team
+    // -> register -> direct DMA).  Queueing a product can hold the host for a moment — a block's own plan is sized on the
+    // host, i.e. the call waits until the block's slice of the CSR has arrived — so the downloads are queued block by
+    // block too: when they were all queued after the last product, nothing came down before the whole upload had ended
+    // (cfg5 whole: 311 ms where upload and download could overlap).
     MX_HIP(hipStreamWaitEvent(L.run, evB, 0));
+    bool direct_down = true, c_ready = false;
     for (int b = 0; b < nblk; b++) {
         const int c0 = cut[b], c1 = cut[b + 1];
-        if (c1 == c0) continue;
-        if (uploading) MX_HIP(hipStreamWaitEvent(L.run, L.ev[b], 0));
-        int rc = 0;
-        if (shape == COLS) {
-            rc = mxd_spmm_csr_dense_ex(m, c1 - c0, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), dB + c0, ldb,
-                                       dC + (size_t)c0 * ldc, ldc, dt, 1, algo, 0, npanels, 0, L.run);
-        } else {
-            real_t *dCb = colmajor ? dC + c0 : dC + (size_t)c0 * ldc;
-            if (indptr[c0] == indptr[c1]) {                      // a block without entries: zeros (the kernels' early-out)
-                if (colmajor) MX_HIP(hipMemset2DAsync(dCb, ldc * sizeof(real_t), 0, (size_t)(c1 - c0) * sizeof(real_t), n, L.run));
-                else MX_HIP(hipMemsetAsync(dCb, 0, (size_t)(c1 - c0) * ldc * sizeof(real_t), L.run));
+        if (c1 > c0) {
+            if (uploading) MX_HIP(hipStreamWaitEvent(L.run, L.ev[b], 0));
+            int rc = 0;
+            if (shape == COLS) {
+                rc = plan ? mxd_spmm_plan_run_rows(plan, 0, m, c1 - c0, dB + c0, ldb, dC + (size_t)c0 * ldc, ldc, dt, 1, 0, -1, L.run)
+                          : mx::spmm_block(family, algo == MX_SPMM_AUTO, m, c1 - c0, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(),
+                                           A.x.as<double>(), dB + c0, ldb, dC + (size_t)c0 * ldc, ldc, dt, 1, npanels, L.run);
             } else {
-                rc = mxd_spmm_csr_dense_ex(c1 - c0, n, K_rows, A.p.as<int32_t>() + c0, A.j.as<int32_t>(), A.x.as<double>(), dB, ldb,
-                                           dCb, ldc, dt, colmajor ? 1 : 0, algo, 0, npanels, 0, L.run);
+                real_t *dCb = colmajor ? dC + c0 : dC + (size_t)c0 * ldc;
+                if (indptr[c0] == indptr[c1]) {                      // a block without entries: zeros (the kernels' early-out)
+                    if (colmajor) MX_HIP(hipMemset2DAsync(dCb, ldc * sizeof(real_t), 0, (size_t)(c1 - c0) * sizeof(real_t), n, L.run));
+                    else MX_HIP(hipMemsetAsync(dCb, 0, (size_t)(c1 - c0) * ldc * sizeof(real_t), L.run));
+                } else {
+                    rc = plan ? mxd_spmm_plan_run_rows(plan, c0, c1 - c0, n, dB, ldb, dCb, ldc, dt, colmajor ? 1 : 0, 0, -1, L.run)
+                              : mx::spmm_block(family, algo == MX_SPMM_AUTO, c1 - c0, n, K_rows, A.p.as<int32_t>() + c0,
+                                               A.j.as<int32_t>(), A.x.as<double>(), dB, ldb, dCb, ldc, dt, colmajor ? 1 : 0,
+                                               npanels, L.run);
+                }
             }
+            if (rc) return 1;
         }
-        if (rc) return 1;
         MX_HIP(hipEventRecord(L.ev[nblk + b], L.run));
-    }
-    tr.mark("queued");
-    // ---- download: first-touch (host team) -> register -> direct DMA, block by block where the blocks are contiguous
-    bool direct_down = true;
-    if (incremental) {
-        for (int b = 0; b < nblk && direct_down; b++) {
-            mx::prefault_wait();                                 // piece b's pages exist
+        if (b == 0) tr.mark("block 0");
+        if (!direct_down) continue;
+        if (incremental) {
+            mx::prefault_wait();                                     // piece b's pages exist
             if (b + 1 < nblk && piece_bytes(b + 1)) mx::prefault_begin(piece_ptr(b + 1), piece_bytes(b + 1));
             if (piece_bytes(b) == 0) continue;
-            if (!pinBlk[b].pin_pages(piece_ptr(b), piece_bytes(b))) { direct_down = false; break; }
+            if (!pinBlk[b].pin_pages(piece_ptr(b), piece_bytes(b))) { direct_down = false; continue; }
             MX_HIP(hipStreamWaitEvent(L.down, L.ev[nblk + b], 0));   // (blocks complete in order: piece b needs blocks <= b)
             MX_HIP(hipMemcpyAsync(piece_ptr(b), (const char *)dC + hb[b], piece_bytes(b), hipMemcpyDeviceToHost, L.down));
-        }
-    } else {
-        mx::prefault_wait();
-        tr.mark("touched C");
-        direct_down = pinC.pin(C_host, c_bytes);
-        tr.mark("pinned C");
-        for (int b = 0; b < nblk && direct_down; b++) {
-            const int r0 = cut[b], r1 = cut[b + 1];
-            if (r1 == r0) continue;
+        } else {
+            if (!c_ready) {                                          // the whole result: touched under the upload, registered once
+                mx::prefault_wait();
+                tr.mark("touched C");
+                direct_down = pinC.pin(C_host, c_bytes);
+                tr.mark("pinned C");
+                c_ready = true;
+                if (!direct_down) continue;
+            }
+            if (c1 == c0) continue;
             MX_HIP(hipStreamWaitEvent(L.down, L.ev[nblk + b], 0));
-            MX_HIP(hipMemcpy2DAsync(C_host + r0, ldc * sizeof(real_t), dC + r0, ldc * sizeof(real_t),
-                                    (size_t)(r1 - r0) * sizeof(real_t), n, hipMemcpyDeviceToHost, L.down));
+            MX_HIP(hipMemcpy2DAsync(C_host + c0, ldc * sizeof(real_t), dC + c0, ldc * sizeof(real_t),
+                                    (size_t)(c1 - c0) * sizeof(real_t), n, hipMemcpyDeviceToHost, L.down));
         }
     }
+    tr.mark("queued");
+    if (uploading) { A.fingerprint_now(); tr.mark("fingerprint"); }  // the cache key of a new operand: hashed while the queues drain
     MX_HIP(hipStreamSynchronize(L.run));
     if (uploading) { MX_HIP(hipStreamSynchronize(L.up)); A.publish(); }
     tr.mark("kernels");
     if (direct_down) MX_HIP(hipStreamSynchronize(L.down));
     else {                                                       // registration failed somewhere: staged copy of the whole result
+        mx::prefault_wait();
         L.drain();
         if (mx::xfer_d2h(C_host, dC, c_bytes)) return 1;
     }
     tr.mark("D2H C");
     return 0;
+}
+
+// run-time options (mx_set_option / mx_get_option); -1 = not set: the environment variable of the same meaning decides
+static std::atomic<int64_t> g_opt_spmv_planned{-1}, g_opt_spmv_algo{-1};
+static std::atomic<int64_t> g_spmv_planned_calls{0};
+static bool opt_spmv_planned()
+{
+    const int64_t v = g_opt_spmv_planned.load();
+    if (v >= 0) return v != 0;
+    static const bool env = [] { const char *e = getenv("MXGPU_SPMV_PLANNED"); return e && atoi(e) == 1; }();
+    return env;
+}
+static int opt_spmv_algo()
+{
+    const int64_t v = g_opt_spmv_algo.load();
+    if (v >= 0) return (int)v;
+    static const int env = [] { const char *e = getenv("MXGPU_SPMV_ALGO"); return e ? atoi(e) : (int)MX_SPMV_AUTO; }();
+    return env;
 }
 
 template <typename vec_t, typename out_t>
@@ -738,10 +894,15 @@ static int spmv_host(int m, const int32_t *indptr, const int32_t *indices, const
     DevBuf v, o;
     if (v.upload(y, sizeof(vec_t) * (size_t)len_y)) return 1;
     if (o.alloc(sizeof(out_t) * (size_t)m)) return 1;
-    // A matrix that comes back for another product (cache hit) is worth a plan: the planned kernel keeps v's panels in LDS
-    // instead of gathering v[j] from L2 (cfg3: 81 vs 165 us; the build costs about six one-shot products, once)
+    // OPT-IN (mx_set_option("spmv_planned", 1) or MXGPU_SPMV_PLANNED=1): a matrix that comes back for another product
+    // (cache hit) gets a plan — the planned kernel keeps v's panels in LDS instead of gathering v[j] from L2 (cfg3: 81 vs
+    // 165 us; the build costs about six one-shot products, once).  Not the default because the planned kernel regroups a
+    // row's sum by column panel and adds with LDS atomics: equal to the reference to 1e-12, but not bit for bit and not the
+    // same bits from run to run, and the float32 kind rounds once from an f64 sum where the reference accumulates in
+    // float (matmul.cpp:403) — the same `X %*% v` would return different last bits on its first and on later calls
+    // (ADVICE r2).  The default is the one-shot flat kernel on every call: bit for bit the reference's loop.
     bool planned = false;
-    if (A.cache_hit && A.nnz >= ((int64_t)1 << 22) && (len_y + 6143) / 6144 <= 64) {
+    if (opt_spmv_planned() && A.cache_hit && A.nnz >= ((int64_t)1 << 20) && (len_y + 6143) / 6144 <= 64) {
         std::lock_guard<std::mutex> lk(A.hold->plan_mu);
         if (A.hold->spmv_plan && A.hold->spmv_plan_K != len_y) { mxd_spmv_plan_destroy(A.hold->spmv_plan); A.hold->spmv_plan = nullptr; }
         if (!A.hold->spmv_plan) {
@@ -754,8 +915,9 @@ static int spmv_host(int m, const int32_t *indptr, const int32_t *indices, const
             planned = true;
         }
     }
+    g_spmv_planned_calls += planned ? 1 : 0;
     if (!planned && spmv_launch(m, len_y, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), v.p, v_dtype, o.p,
-                                MX_SPMV_AUTO, nullptr))
+                                opt_spmv_algo(), nullptr))
         return 1;
     if (mx::xfer_d2h(out, o.p, sizeof(out_t) * (size_t)m)) return 1;
     return 0;
@@ -808,6 +970,31 @@ int mx_device_name(char *buf, size_t buflen)
     hipDeviceProp_t prop;
     MX_HIP(hipGetDeviceProperties(&prop, dev));
     snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+int mx_set_option(const char *name, int64_t value)
+{
+    MX_REQUIRE(name, "mx_set_option: null name");
+    if (strcmp(name, "spmv_planned") == 0) { g_opt_spmv_planned = value; return 0; }
+    if (strcmp(name, "spmv_algo") == 0) {
+        MX_REQUIRE(value >= -1 && value <= MX_SPMV_FLAT, "mx_set_option: spmv_algo %lld", (long long)value);
+        g_opt_spmv_algo = value;
+        return 0;
+    }
+    return set_error("mx_set_option: unknown option '%s'", name);
+}
+int mx_get_option(const char *name, int64_t *value)
+{
+    MX_REQUIRE(name && value, "mx_get_option: null pointer");
+    if (strcmp(name, "spmv_planned") == 0) { *value = opt_spmv_planned() ? 1 : 0; return 0; }
+    if (strcmp(name, "spmv_algo") == 0) { *value = opt_spmv_algo(); return 0; }
+    if (strcmp(name, "spmv_planned_calls") == 0) { *value = g_spmv_planned_calls.load(); return 0; }   // read-only counter
+    return set_error("mx_get_option: unknown option '%s'", name);
+}
+int mx_last_call_phases(char *buf, size_t buflen)
+{
+    MX_REQUIRE(buf && buflen > 0, "mx_last_call_phases: no buffer");
+    snprintf(buf, buflen, "%s", mx::g_phases);
     return 0;
 }
 int mx_cache_configure(int64_t max_bytes) { CsrCache::get().configure(max_bytes); return 0; }

@@ -126,6 +126,113 @@ static int launch_gather_copy(int G, int r, const int32_t *indptr, const int32_t
     return 0;
 }
 
+// The whole gather in ONE launch (round 3): a workgroup sizes a tile of GF_TILE output rows, scans their lengths, finds
+// its place in the output with the decoupled look-back (as gather_count_kernel) and copies its rows — into arrays that
+// the caller sized for an ESTIMATE of the result (`capacity` entries).  new_indptr and the total are always complete
+// and exact; rows that would end beyond `capacity` are not copied, the caller sees total > capacity and runs
+// gather_copy_kernel into exactly sized arrays instead.  What this removes from a call: the second launch, and the host
+// round trip for nnz_out BETWEEN the two launches (the size is read back once, behind all the work).
+// Copy: G lanes per row, GF_ROWS rows per group and trip with all their loads in flight before the first store.
+constexpr int GF_TILE = GATHER_BLOCK;
+constexpr int GF_ROWS = 4;
+template <int G, typename VT, bool HAS_VALUES>
+__global__ __launch_bounds__(GATHER_BLOCK)
+void gather_fused_kernel(int r, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                         const VT *__restrict__ values, const int32_t *__restrict__ rows,
+                         int32_t *__restrict__ new_indptr, int32_t *__restrict__ new_indices, VT *__restrict__ new_values,
+                         long long capacity, unsigned long long *__restrict__ tile_state, unsigned *__restrict__ ticket,
+                         long long *__restrict__ total_out, int ntiles)
+{
+    __shared__ int s_tile;
+    __shared__ long long s_base;
+    __shared__ int wave_tot[GATHER_BLOCK / 64];
+    __shared__ int src_l[GF_TILE], len_l[GF_TILE];
+    __shared__ long long dst_l[GF_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int tile = s_tile;
+    const long long i = (long long)tile * GF_TILE + tid;
+    int src = 0, len = 0;
+    if (i < r) {
+        const int row = rows[i];
+        src = indptr[row];
+        len = indptr[row + 1] - src;
+    }
+    int incl = len;
+#pragma unroll
+    for (int o2 = 1; o2 < 64; o2 <<= 1) { const int up = __shfl_up(incl, o2, 64); if (lane >= o2) incl += up; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int wbase = 0, tile_total = 0;
+#pragma unroll
+    for (int w = 0; w < GATHER_BLOCK / 64; w++) { wbase += w < wave ? wave_tot[w] : 0; tile_total += wave_tot[w]; }
+    if (wave == 0) {
+        const long long excl = lookback_exclusive<4>(tile_state, tile, tile_total);
+        if (lane == 0) {
+            s_base = excl;
+            if (tile == ntiles - 1) {
+                *total_out = excl + tile_total;
+                new_indptr[r] = excl + tile_total <= (long long)INT_MAX ? (int32_t)(excl + tile_total) : INT_MAX;
+            }
+        }
+    }
+    __syncthreads();
+    const long long dst = s_base + wbase + incl - len;
+    if (i < r) new_indptr[i] = dst <= (long long)INT_MAX ? (int32_t)dst : INT_MAX;
+    src_l[tid] = src;
+    len_l[tid] = dst + len <= capacity ? len : 0;                      // beyond the caller's arrays: not copied
+    dst_l[tid] = dst;
+    __syncthreads();
+    constexpr int NG = GATHER_BLOCK / G;                              // lane groups per workgroup
+    const int lg = tid % G, grp = tid / G;
+    for (int r0 = grp * GF_ROWS; r0 < GF_TILE; r0 += NG * GF_ROWS) {
+        int s[GF_ROWS], n[GF_ROWS];
+        long long d[GF_ROWS];
+        int maxn = 0;
+#pragma unroll
+        for (int q = 0; q < GF_ROWS; q++) { s[q] = src_l[r0 + q]; n[q] = len_l[r0 + q]; d[q] = dst_l[r0 + q]; maxn = max(maxn, n[q]); }
+        for (int k = lg; k < maxn; k += G) {                          // (uniform per group: all four rows advance together)
+            int jv[GF_ROWS];
+            VT xv[GF_ROWS];
+#pragma unroll
+            for (int q = 0; q < GF_ROWS; q++) {
+                jv[q] = 0; xv[q] = VT();
+                if (k < n[q]) {
+                    jv[q] = indices[s[q] + k];
+                    if constexpr (HAS_VALUES) xv[q] = values[s[q] + k];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < GF_ROWS; q++) {
+                if (k < n[q]) {
+                    new_indices[d[q] + k] = jv[q];
+                    if constexpr (HAS_VALUES) new_values[d[q] + k] = xv[q];
+                }
+            }
+        }
+    }
+}
+
+template <typename VT, bool HAS_VALUES>
+static int launch_gather_fused(int G, int r, const int32_t *indptr, const int32_t *indices, const void *values,
+                               const int32_t *rows, int32_t *new_indptr, int32_t *new_indices, void *new_values,
+                               long long capacity, void *workspace, int ntiles, hipStream_t st)
+{
+#define MX_CASE(GG)                                                                                                   \
+    case GG:                                                                                                          \
+        hipLaunchKernelGGL((gather_fused_kernel<GG, VT, HAS_VALUES>), dim3((unsigned)ntiles), dim3(GATHER_BLOCK), 0, st, r,   \
+                           indptr, indices, (const VT *)values, rows, new_indptr, new_indices, (VT *)new_values, capacity,    \
+                           (unsigned long long *)((char *)workspace + 16), (unsigned *)((char *)workspace + 8),       \
+                           (long long *)workspace, ntiles);                                                           \
+        break;
+    switch (G) { MX_CASE(4) MX_CASE(8) MX_CASE(16) MX_CASE(32) MX_CASE(64)
+                 default: return set_error("gather: bad group %d", G); }
+#undef MX_CASE
+    MX_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- check_is_seq / check_is_rev_seq ---------------------------------------------------------
 // flag[0] starts at 0 and is set by any violating pair.
 __global__ __launch_bounds__(256)
@@ -139,86 +246,132 @@ void is_seq_kernel(const int32_t *__restrict__ idx, int64_t n, int step, int32_t
 
 // ---- per-row sortedness / sort -----------------------------------------------------------------
 // check_is_sorted over every row (misc.cpp:118-128, as sort_sparse_indices_known_ncol applies it row by row, :283): a
-// row is unsorted iff some entry is smaller than its predecessor IN THE SAME ROW.  Counted without knowing which row an
-// entry belongs to:   D = #{k >= 1 : indices[k] < indices[k-1]}  (one pure stream over the indices, 16 B per lane)
-//                     S = #{non-empty rows r with start s > 0 : indices[s] < indices[s-1]}  (one pass over indptr)
-// every descent that is not at a row start is inside a row, so all rows are sorted  <=>  D == S.  The first
-// `nb_entries` workgroups count D, the others S; nnz is read from indptr[m] on the device (no host round trip before
-// the launch).  (The element-parallel kernel this replaces searched indptr for every descent — 20 dependent loads — and
-// read 4 B per lane: 0.26 TB/s.)
-template <bool VEC>
-__global__ __launch_bounds__(256)
-void rows_sorted_count_kernel(int m, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                              unsigned *__restrict__ counters, int nb_entries)
+// row is unsorted iff some entry is smaller than its predecessor IN THE SAME ROW, i.e. iff some DESCENT
+// (indices[k] < indices[k-1]) sits at a position that is not the start of a row.  With
+//     D = #{descents},   S = #{non-empty rows whose first entry is a descent}
+// all rows are sorted  <=>  D == S.  Both are counted in ONE pass over the indices (round 3; rounds 1-2 counted S in a
+// second pass over indptr that re-read one 128-byte line of `indices` per row: 256 MB on top of the 408 MB of cfg4):
+// a workgroup owns a contiguous range of quads (4 entries = one 16-byte load per lane), streams it in sub-chunks of
+// RS_SUB_Q quads, leaves each quad's four descent bits in a byte of an LDS bitmap, and resolves the rows that start inside
+// the sub-chunk against that bitmap — the row pointers are the only other thing read (coalesced, once).  The rows of a
+// sub-chunk are found by a cursor that the workgroup carries along (rows start in ascending order); the first cursor
+// of a workgroup comes from a 64-ary search of indptr by one wavefront while the others already stream.
+// Entry positions are counted from a 16-byte aligned base (`shift` = elements between that base and indices[0]), so any
+// int32-aligned array takes the vector path; a quad that holds at least one valid entry lies inside one aligned 16-byte
+// granule of the array's pages, so partial quads at either end are loaded whole and masked.  nnz and the first entry
+// (indptr[0] > 0: a row-block view with absolute offsets) are read on the device — no host round trip before the launch.
+constexpr int RS_BLOCK = 256, RS_U = 4, RS_SUB_Q = RS_BLOCK * RS_U, RS_NB = 2048;
+
+__global__ __launch_bounds__(RS_BLOCK)
+void rows_sorted_tile_kernel(int m, const int32_t *__restrict__ indptr, const int32_t *__restrict__ idx_al, int shift,
+                             unsigned *__restrict__ partial)
 {
     typedef int i4 __attribute__((ext_vector_type(4)));
-    const long long nnz = indptr[m];
-    const int lane = lane_id();
-    unsigned cnt = 0;
-    const bool entry_part = (int)blockIdx.x < nb_entries;
-    if (entry_part) {
-        if constexpr (VEC) {
-            const long long nq = nnz >> 2;                                    // whole quads
-            constexpr int U = 4;                                              // quads per thread and trip: 4 loads in flight
-            const long long stride = (long long)nb_entries * 256;
-            for (long long q0 = (long long)blockIdx.x * 256 + threadIdx.x; q0 < nq; q0 += stride * U) {
-                i4 c[U];
-                int pv[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const long long q = q0 + u * stride;
-                    const long long qs = q < nq ? q : q0;                     // clamped: every load is issued
-                    c[u] = *reinterpret_cast<const i4 *>(indices + qs * 4);
-                    pv[u] = 0;
-                    if (lane == 0) pv[u] = indices[qs > 0 ? qs * 4 - 1 : 0];  // the wavefront's first quad: predecessor from memory
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const long long q = q0 + u * stride;
-                    const int up = __shfl_up(c[u][3], 1, 64);                 // lane - 1 holds quad q - 1 of the same trip
-                    if (q < nq) {
-                        const int prev = q > 0 ? (lane == 0 ? pv[u] : up) : c[u][0];
-                        cnt += (c[u][0] < prev) + (c[u][1] < c[u][0]) + (c[u][2] < c[u][1]) + (c[u][3] < c[u][2]);
-                    }
-                }
+    __shared__ unsigned char bits[2][RS_SUB_Q];
+    __shared__ int cur[3];
+    __shared__ unsigned wsum[2][RS_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p0 = indptr[0];
+    const long long lo = (long long)p0 + shift, hi = (long long)indptr[m] + shift;     // descents count at lo < k' < hi
+    const long long Q0 = lo >> 2, Q1 = (hi + 3) >> 2;
+    long long cq = (Q1 - Q0 + gridDim.x - 1) / gridDim.x;
+    cq = (cq + RS_SUB_Q - 1) / RS_SUB_Q * RS_SUB_Q;
+    const long long Qa = Q0 + (long long)blockIdx.x * cq, Qb = Qa + cq < Q1 ? Qa + cq : Q1;
+    unsigned D = 0, S = 0;
+    if (Qa < Qb) {                                                            // (uniform per workgroup)
+        if (wave == 0) {
+            // first row r in [0, m] with indptr[r] >= key: 64 probes per round
+            const long long key = 4 * Qa - shift;
+            int a = 0, b = m;                                                 // indptr[m] >= key because 4 Qa < hi
+            while (a < b) {
+                const int stride = (b - a + 63) >> 6;
+                const long long idx = (long long)a + (long long)lane * stride;
+                const bool lt = idx < b && (long long)indptr[idx] < key;
+                const int cnt = __popcll(__ballot(lt));                       // probes 0 .. cnt-1 are below the key
+                const long long nb = (long long)a + (long long)cnt * stride;  // the first probe that is not
+                if (cnt > 0) a = a + (cnt - 1) * stride + 1;
+                if (nb < b) b = (int)nb;
+                if (cnt == 0) b = a;
             }
-            if (blockIdx.x == 0 && threadIdx.x < (unsigned)(nnz & 3)) {       // the last partial quad
-                const long long k = (nq << 2) + threadIdx.x;
-                if (k > 0) cnt += indices[k] < indices[k - 1];
-            }
-        } else {
-            for (long long k = (long long)blockIdx.x * 256 + threadIdx.x + 1; k < nnz; k += (long long)nb_entries * 256)
-                cnt += indices[k] < indices[k - 1];
+            if (lane == 0) { cur[0] = a; cur[1] = m; cur[2] = m; }
         }
-    } else {
-        const long long nb_rows = gridDim.x - nb_entries;
-        constexpr int U = 4;                                                  // rows per thread and trip
-        const long long stride = nb_rows * 256;
-        for (long long r0 = (long long)(blockIdx.x - nb_entries) * 256 + threadIdx.x; r0 < m; r0 += stride * U) {
-            int s[U], e[U], a[U], b[U];
+        i4 c[RS_U];
+        int pv[RS_U];
+        long long Qs = Qa;
+        auto issue = [&](long long Qstart) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const long long r = r0 + u * stride < m ? r0 + u * stride : r0;
-                s[u] = indptr[r]; e[u] = indptr[r + 1];
+            for (int u = 0; u < RS_U; u++) {
+                const long long Q = Qstart + u * RS_BLOCK + tid;
+                c[u] = (i4){0, 0, 0, 0};
+                pv[u] = 0;
+                if (Q < Qb) {
+                    c[u] = *reinterpret_cast<const i4 *>(idx_al + Q * 4);
+                    if (lane == 0 && Q > 0) pv[u] = idx_al[Q * 4 - 1];       // the wavefront's first quad: predecessor from memory
+                }
             }
+        };
+        auto mark = [&](long long Qstart, int buf) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const bool ok = e[u] > s[u] && s[u] > 0;
-                a[u] = indices[ok ? s[u] : 0]; b[u] = indices[ok ? s[u] - 1 : 0];
+            for (int u = 0; u < RS_U; u++) {
+                const int qi = u * RS_BLOCK + tid;
+                const long long k = (Qstart + qi) * 4;
+                const int up = __shfl_up(c[u][3], 1, 64);
+                const int prev = lane == 0 ? pv[u] : up;
+                unsigned nib = 0;
+                nib |= (unsigned)(c[u][0] < prev && k > lo && k < hi);
+                nib |= (unsigned)(c[u][1] < c[u][0] && k + 1 > lo && k + 1 < hi) << 1;
+                nib |= (unsigned)(c[u][2] < c[u][1] && k + 2 > lo && k + 2 < hi) << 2;
+                nib |= (unsigned)(c[u][3] < c[u][2] && k + 3 > lo && k + 3 < hi) << 3;
+                if (Qstart + qi >= Qb) nib = 0;
+                bits[buf][qi] = (unsigned char)nib;
+                D += __popc(nib);
             }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (r0 + u * stride < m && e[u] > s[u] && s[u] > 0) cnt += a[u] < b[u];
+        };
+        issue(Qs);
+        mark(Qs, 0);
+        for (int it = 0;; it++) {
+            const long long Qn = Qs + RS_SUB_Q;
+            __syncthreads();                                                  // bitmap `it` and cursor `it` are complete
+            const int rc = cur[it % 3];
+            if (tid == 0) cur[(it + 2) % 3] = m;
+            const long long sbase = 4 * Qs - shift;                           // row start s lies in this sub-chunk iff 0 <= s - sbase < 4 RS_SUB_Q
+            // first round of row pointers, then the next sub-chunk's entries: both in flight together
+            long long row = (long long)rc + 64 * wave + lane;
+            int s = 0, e = 0;
+            if (row < m) { s = indptr[row]; e = indptr[row + 1]; }
+            if (Qn < Qb) issue(Qn);
+            for (;;) {
+                const bool in_m = row < m;
+                const long long off = (long long)s - sbase;
+                const bool exceed = !in_m || off >= 4 * RS_SUB_Q;
+                if (!exceed && e > s && s > p0) S += (bits[it & 1][off >> 2] >> (off & 3)) & 1u;
+                const unsigned long long ex = __ballot(exceed);
+                if (ex) {
+                    if (lane == 0) {
+                        const long long cand = row + __builtin_ctzll(ex);
+                        atomicMin(&cur[(it + 1) % 3], cand < m ? (int)cand : m);
+                    }
+                    break;
+                }
+                row += RS_BLOCK;
+                s = e = 0;
+                if (row < m) { s = indptr[row]; e = indptr[row + 1]; }
+            }
+            if (Qn >= Qb) break;
+            mark(Qn, (it + 1) & 1);
+            Qs = Qn;
         }
     }
-    // one plain store per workgroup, summed by rows_sorted_finish_kernel: same-address atomics serialise in L2 (~10 ns
-    // each; one atomicAdd per wavefront of a 3072-workgroup grid was 130 us of a 180 us kernel)
-    __shared__ unsigned wsum[4];
+    // one plain store per workgroup and count, summed by rows_sorted_finish_kernel: same-address atomics serialise in L2
+    // (~10 ns each; one atomicAdd per wavefront of a 3072-workgroup grid was 130 us of a 180 us kernel)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-    if (lane == 0) wsum[threadIdx.x >> 6] = cnt;
+    for (int off = 32; off > 0; off >>= 1) { D += __shfl_xor(D, off, 64); S += __shfl_xor(S, off, 64); }
+    if (lane == 0) { wsum[0][wave] = D; wsum[1][wave] = S; }
     __syncthreads();
-    if (threadIdx.x == 0) counters[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0) {
+        partial[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+        partial[gridDim.x + blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+    }
 }
 
 // out[0] = sum of the first nb_entries partial counts (D), out[1] = sum of the rest (S)
@@ -371,6 +524,40 @@ extern "C" int mxd_csr_gather_fill(int r, const int32_t *indptr, const int32_t *
     }
 }
 
+extern "C" int mxd_csr_gather_fused(int r, const int32_t *indptr, const int32_t *indices, const void *values,
+                                    const int32_t *rows_take, int32_t *new_indptr, int32_t *new_indices, void *new_values,
+                                    int value_dtype, int64_t capacity, double avg_row_len, void *workspace,
+                                    int64_t *nnz_out_host, void *stream)
+{
+    MX_REQUIRE(r >= 0 && capacity >= 0, "mxd_csr_gather_fused: negative size");
+    MX_REQUIRE(new_indptr && workspace && nnz_out_host, "mxd_csr_gather_fused: null pointer");
+    hipStream_t st = mx::as_stream(stream);
+    int64_t *total_dev = (int64_t *)workspace;
+    if (r == 0) {
+        MX_HIP(hipMemsetAsync(new_indptr, 0, sizeof(int32_t), st));
+        *nnz_out_host = 0;
+        return 0;
+    }
+    // workspace: [int64 total][uint32 ticket, pad][uint64 tile_state[ntiles]]  (fits mxd_gather_workspace_bytes(r): >= 4 r bytes)
+    const int ntiles = (int)mx::ceil_div(r, mx::GF_TILE);
+    MX_HIP(hipMemsetAsync(workspace, 0, 16 + (size_t)ntiles * 8, st));
+    const int G = mx::pick_group(avg_row_len > 0 ? avg_row_len : 32.0);
+    int rc;
+    switch (value_dtype) {
+        case MX_F64: rc = mx::launch_gather_fused<double, true>(G, r, indptr, indices, values, rows_take, new_indptr, new_indices,
+                                                                new_values, capacity, workspace, ntiles, st); break;
+        case MX_LGL: rc = mx::launch_gather_fused<int32_t, true>(G, r, indptr, indices, values, rows_take, new_indptr, new_indices,
+                                                                 new_values, capacity, workspace, ntiles, st); break;
+        case MX_NONE: rc = mx::launch_gather_fused<int32_t, false>(G, r, indptr, indices, nullptr, rows_take, new_indptr,
+                                                                   new_indices, nullptr, capacity, workspace, ntiles, st); break;
+        default: return mx::set_error("mxd_csr_gather_fused: unsupported value dtype %d", value_dtype);
+    }
+    if (rc) return rc;
+    if (mx::read_back_small(nnz_out_host, total_dev, sizeof(int64_t), st)) return 1;
+    MX_REQUIRE(*nnz_out_host <= (int64_t)INT_MAX, "result has %lld entries: exceeds R's int32 index range", (long long)*nnz_out_host);
+    return 0;
+}
+
 extern "C" int mxd_check_is_seq(const int32_t *idx, int64_t n, int reversed, int32_t *workspace4, int *flag_host,
                                 void *stream)
 {
@@ -395,18 +582,14 @@ extern "C" int mxd_csr_rows_sorted(int m, const int32_t *indptr, const int32_t *
     if (m <= 0) { *flag_host = 1; return 0; }
     MX_REQUIRE(indptr && workspace4, "mxd_csr_rows_sorted: null pointer");
     hipStream_t st = mx::as_stream(stream);
-    const int nb_entries = 2048, nb_rows = (int)std::min<int64_t>(512, mx::ceil_div(m, 256));
-    unsigned *partial = (unsigned *)mx::scratch_buffer(mx::MX_SCRATCH_PARTIALS, (size_t)(nb_entries + nb_rows) * sizeof(unsigned));
+    const int nb = mx::RS_NB;
+    unsigned *partial = (unsigned *)mx::scratch_buffer(mx::MX_SCRATCH_PARTIALS, (size_t)2 * nb * sizeof(unsigned));
     MX_REQUIRE(partial, "mxd_csr_rows_sorted: cannot allocate the partial counts");
-    if (((uintptr_t)indices & 15) == 0)
-        hipLaunchKernelGGL((mx::rows_sorted_count_kernel<true>), dim3(nb_entries + nb_rows), dim3(256), 0, st, m, indptr,
-                           indices, partial, nb_entries);
-    else
-        hipLaunchKernelGGL((mx::rows_sorted_count_kernel<false>), dim3(nb_entries + nb_rows), dim3(256), 0, st, m, indptr,
-                           indices, partial, nb_entries);
-    hipLaunchKernelGGL(mx::rows_sorted_finish_kernel, dim3(1), dim3(256), 0, st, partial, nb_entries + nb_rows, nb_entries,
-                       (unsigned *)workspace4);                              // [0] descents, [1] descents at row starts
-    MX_LAUNCH_CHECK();
+    MX_REQUIRE(((uintptr_t)indices & 3) == 0, "mxd_csr_rows_sorted: indices not int32-aligned");
+    const int shift = (int)(((uintptr_t)indices & 15) >> 2);                 // entries between the 16-byte aligned base and indices[0]
+    hipLaunchKernelGGL(mx::rows_sorted_tile_kernel, dim3(nb), dim3(mx::RS_BLOCK), 0, st, m, indptr, indices - shift, shift, partial);
+    hipLaunchKernelGGL(mx::rows_sorted_finish_kernel, dim3(1), dim3(256), 0, st, partial, 2 * nb, nb, (unsigned *)workspace4);
+    MX_LAUNCH_CHECK();                                                       // [0] descents, [1] descents at row starts
     uint32_t counts[2] = {0, 0};
     if (mx::read_back_small(counts, workspace4, sizeof(counts), st)) return 1;
     *flag_host = counts[0] == counts[1];

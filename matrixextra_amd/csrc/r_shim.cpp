@@ -444,11 +444,16 @@ SEXP _MatrixExtra_concat_csr_batch(SEXP objects, SEXP out)
             else Rf_error("Invalid vector type in argument %d.\n", k);     // rbind.cpp:131-135
         }
     }
+    // everything that can long-jump (a missing slot, a slot of the wrong type) happens BEFORE the device handle exists:
+    // R_do_slot / INTEGER() after a successful `begin` would leak it
+    SEXP op = R_do_slot(out, Rf_install("p")), oj = R_do_slot(out, Rf_install("j"));
+    SEXP ox = out_kind == 2 ? R_NilValue : R_do_slot(out, Rf_install("x"));
+    if (TYPEOF(op) != INTSXP || TYPEOF(oj) != INTSXP || (out_kind == 0 && TYPEOF(ox) != REALSXP) ||
+        (out_kind == 1 && TYPEOF(ox) != LGLSXP))
+        Rf_error("concat_csr_batch: the slots of `out` do not have the types of its class");
     mx_result *res = nullptr;
     mx_result_info info;
     if (mx_concat_csr_batch_begin(in, n_inputs, out_kind, &res, &info)) fail();
-    SEXP op = R_do_slot(out, Rf_install("p")), oj = R_do_slot(out, Rf_install("j"));
-    SEXP ox = out_kind == 2 ? R_NilValue : R_do_slot(out, Rf_install("x"));
     if ((int64_t)XLENGTH(op) < info.indptr_len || (int64_t)XLENGTH(oj) < info.nnz ||
         (out_kind != 2 && (int64_t)XLENGTH(ox) < info.values_len)) {
         mx_result_discard(res);

@@ -81,6 +81,52 @@ extern "C" int mxd_spmm_kernel_times(float *out_ms, int max_out, int *count)
 
 extern "C" const char *mxd_spmm_last_kernel(void) { return mx::g_last_spmm_kernel; }
 
+namespace mx {
+// AUTO's choice, in one place: PLANNED when B outgrows one XCD's L2, the operands meet the 16-byte rules and there is
+// enough work to fill the persistent grid (measured on MI355X, headline config, profiles/r01_*: row-wave 4.45 ms; one-panel
+// slab kernel on the slab-major copy of B 4.05 ms; planned panel sweep 1.74 ms + 0.27 ms to build the plan from plain CSR),
+// SLAB for K >= 2^25 (the plan's 32-bit slab offsets), else ROWWAVE.
+static int spmm_auto_algo(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor)
+{
+    const bool ok = dense_dtype == MX_F64 ? slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor)
+                                          : slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor);
+    const size_t b_bytes = (size_t)K * (size_t)n * (dense_dtype == MX_F64 ? 8 : 4);
+    const bool big = ok && b_bytes > ((size_t)8 << 20) && (long long)m * n >= (1LL << 24);
+    return big ? (K < (1 << 25) ? MX_SPMM_PLANNED : MX_SPMM_SLAB) : MX_SPMM_ROWWAVE;
+}
+int spmm_auto_family(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor)
+{
+    return spmm_auto_algo(m, n, K, dense_dtype, B, ldb, C, ldc, colmajor);
+}
+// One block (rows or columns) of a product whose kernel family was chosen for the WHOLE product (the export pipelines).
+// from_auto: the family is AUTO's choice — a planned block still falls back to the row-wave kernel when its plan would
+// pad too much, as AUTO does.
+int spmm_block(int family, bool from_auto, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+               const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, int npanels, hipStream_t st)
+{
+    if (family == MX_SPMM_PLANNED && from_auto) {
+        const bool ok = dense_dtype == MX_F64 ? slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor)
+                                              : slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor);
+        if (ok && K < (1 << 25)) {
+            bool ready = false;
+            if (plan_auto_build(m, K, indptr, indices, values, npanels, st, 1.55, &ready)) return 1;
+            if (ready) return plan_auto_run(n, B, ldb, C, ldc, dense_dtype, colmajor, st);
+        }
+        family = MX_SPMM_ROWWAVE;
+    }
+    return mxd_spmm_csr_dense_ex(m, n, K, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, family, 0, npanels, 0, st);
+}
+}  // namespace mx
+
+extern "C" int mxd_spmm_auto_algo(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
+                                  int colmajor_out, int *algo)
+{
+    MX_REQUIRE(algo, "mxd_spmm_auto_algo: null pointer");
+    MX_REQUIRE(dense_dtype == MX_F64 || dense_dtype == MX_F32, "mxd_spmm_auto_algo: unsupported dense dtype %d", dense_dtype);
+    *algo = mx::spmm_auto_algo(m, n, K, dense_dtype, B, ldb, C, ldc, colmajor_out);
+    return 0;
+}
+
 extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
                                      const int32_t *indptr, const int32_t *indices, const double *values,
                                      const void *B, size_t ldb, void *C, size_t ldc,
@@ -97,13 +143,9 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
         : mx::slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor_out);
     bool auto_pick_planned = false;
     if (algo == MX_SPMM_AUTO) {
-        // Measured on MI355X, headline config (profiles/r01_*): row-wave 4.45 ms; one-panel slab kernel on the
-        // slab-major copy of B 4.05 ms; planned panel sweep 1.74 ms + 0.33 ms to build the plan from plain CSR.
-        // AUTO = planned (plan rebuilt on every call: nothing is assumed about A between calls) when B outgrows
-        // one XCD's L2 and there is enough work to fill the persistent grid, else the row-wave kernel.
-        const size_t b_bytes = (size_t)K * (size_t)n * (dense_dtype == MX_F64 ? 8 : 4);
-        const bool big = ok && b_bytes > ((size_t)8 << 20) && (long long)m * n >= (1LL << 24);
-        algo = big ? (K < (1 << 25) ? MX_SPMM_PLANNED : MX_SPMM_SLAB) : MX_SPMM_ROWWAVE;
+        // AUTO rebuilds the plan on every call (nothing is assumed about A between calls); callers that multiply one
+        // matrix repeatedly keep a plan (mxd_spmm_plan_create_auto + mxd_spmm_plan_run)
+        algo = mx::spmm_auto_algo(m, n, K, dense_dtype, B, ldb, C, ldc, colmajor_out);
         auto_pick_planned = algo == MX_SPMM_PLANNED;
         if (algo == MX_SPMM_SLAB) { npanels = 1; if (wg_per_cu <= 0) wg_per_cu = 4; }
     }

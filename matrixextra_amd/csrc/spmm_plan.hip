@@ -856,13 +856,16 @@ static int plan_repack(int K, int n, const real_t *B, size_t ldb, hipStream_t st
     return 0;
 }
 
+// rows [row0, row0 + m) of the planned matrix (row0 a multiple of 64: whole octets); C points at the block's first row
 template <typename real_t>
-static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor,
-                    int wg_per_cu, int sync_mode, hipStream_t st)
+static int plan_run(const mx_spmm_plan *pl, int row0, int m, int n, const real_t *B, size_t ldb, real_t *C, size_t ldc,
+                    int colmajor, int wg_per_cu, int sync_mode, hipStream_t st)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
     constexpr int W = SLAB_GROUP * VEC;
-    const int m = pl->m, K = pl->K;
+    const int K = pl->K;
+    const int oct0 = row0 / PLAN_OCT_ROWS, noct = (int)ceil_div(m, PLAN_OCT_ROWS);
+    const int32_t *step_off = pl->step_off + (size_t)oct0 * pl->npanels;
     const int nslabs = (int)ceil_div(n, W);
     const int Kp = K + 1;
     real_t *Bp = nullptr;
@@ -888,7 +891,7 @@ static int plan_run(const mx_spmm_plan *pl, int n, const real_t *B, size_t ldb, 
     const bool shared = sizeof(real_t) == 4 && pl->ndealt > 0;
 #define MX_PLAN_LAUNCH2(CM, WV, SH)                                                                                          \
     hipLaunchKernelGGL((spmm_plan_kernel<real_t, CM, WV, SH>), dim3((unsigned)grid), dim3(WV * 64), 0, st, m, n, pl->npanels, \
-                       pl->step_off, pl->pcol, pl->pval, Bp, (size_t)Kp * W, C, ldc, nslabs, ngens, pl->noct, K,             \
+                       step_off, pl->pcol, pl->pval, Bp, (size_t)Kp * W, C, ldc, nslabs, ngens, noct, K,                     \
                        sync, sync_mode)
 #define MX_PLAN_LAUNCH(CM, WV)                                                                                               \
     do { if constexpr (sizeof(real_t) == 4) { if (shared) MX_PLAN_LAUNCH2(CM, WV, true); else MX_PLAN_LAUNCH2(CM, WV, false); } \
@@ -921,6 +924,24 @@ extern "C" int mxd_spmm_plan_create(int m, int K, const int32_t *indptr, const i
     return 0;
 }
 
+// the padding limit beyond which AUTO prefers the row-wave kernel (tools/skew_probe.py)
+#define MX_PLAN_AUTO_PAD_RATIO 1.55
+
+extern "C" int mxd_spmm_plan_create_auto(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+                                         int npanels, void *stream, mx_spmm_plan **plan_out, int *ready)
+{
+    MX_REQUIRE(plan_out && ready && m >= 0 && K >= 0, "mxd_spmm_plan_create_auto: bad arguments");
+    mx_spmm_plan *pl = *plan_out ? *plan_out : new (std::nothrow) mx_spmm_plan();
+    MX_REQUIRE(pl, "out of host memory");
+    if (mx::plan_build(pl, m, K, indptr, indices, values, npanels, mx::as_stream(stream), MX_PLAN_AUTO_PAD_RATIO)) {
+        if (!*plan_out) { mxd_spmm_plan_destroy(pl); }
+        return 1;
+    }
+    *plan_out = pl;
+    *ready = pl->ready ? 1 : 0;
+    return 0;
+}
+
 extern "C" int mxd_spmm_plan_destroy(mx_spmm_plan *pl)
 {
     if (!pl) return 0;
@@ -946,9 +967,19 @@ extern "C" int mxd_spmm_plan_info(const mx_spmm_plan *pl, int *npanels, int64_t 
 extern "C" int mxd_spmm_plan_run(const mx_spmm_plan *pl, int n, const void *B, size_t ldb, void *C, size_t ldc,
                                  int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream)
 {
+    MX_REQUIRE(pl, "mxd_spmm_plan_run: null plan");
+    return mxd_spmm_plan_run_rows(pl, 0, pl->m, n, B, ldb, C, ldc, dense_dtype, colmajor_out, wg_per_cu, sync_mode, stream);
+}
+
+extern "C" int mxd_spmm_plan_run_rows(const mx_spmm_plan *pl, int row0, int nrows, int n, const void *B, size_t ldb, void *C,
+                                      size_t ldc, int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream)
+{
     MX_REQUIRE(pl && n >= 0, "mxd_spmm_plan_run: bad arguments");
     MX_REQUIRE(pl->ready, "mxd_spmm_plan_run: the plan was sized but not built");
-    if (pl->m == 0 || n == 0) return 0;
+    MX_REQUIRE(row0 >= 0 && nrows >= 0 && row0 % mx::PLAN_OCT_ROWS == 0 && (long long)row0 + nrows <= pl->m,
+               "mxd_spmm_plan_run_rows: rows [%d, %d + %d) of a %d-row plan (the first row must be a multiple of 64)", row0, row0,
+               nrows, pl->m);
+    if (nrows == 0 || n == 0) return 0;
     MX_REQUIRE(B && C, "mxd_spmm_plan_run: null pointer");
     hipStream_t st = mx::as_stream(stream);
     if (sync_mode < 0) sync_mode = 1;       // panel meetings inside the CU's workgroup; 2 adds one XCD barrier per generation
@@ -956,12 +987,12 @@ extern "C" int mxd_spmm_plan_run(const mx_spmm_plan *pl, int n, const void *B, s
     if (dense_dtype == MX_F64) {
         MX_REQUIRE(mx::slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor_out),
                    "mxd_spmm_plan_run: operands do not meet the 16-byte alignment rules");
-        return mx::plan_run<double>(pl, n, (const double *)B, ldb, (double *)C, ldc, colmajor_out, wg_per_cu, sync_mode, st);
+        return mx::plan_run<double>(pl, row0, nrows, n, (const double *)B, ldb, (double *)C, ldc, colmajor_out, wg_per_cu, sync_mode, st);
     }
     if (dense_dtype == MX_F32) {
         MX_REQUIRE(mx::slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor_out),
                    "mxd_spmm_plan_run: operands do not meet the 16-byte alignment rules");
-        return mx::plan_run<float>(pl, n, (const float *)B, ldb, (float *)C, ldc, colmajor_out, wg_per_cu, sync_mode, st);
+        return mx::plan_run<float>(pl, row0, nrows, n, (const float *)B, ldb, (float *)C, ldc, colmajor_out, wg_per_cu, sync_mode, st);
     }
     return mx::set_error("mxd_spmm_plan_run: unsupported dense dtype %d", dense_dtype);
 }

@@ -103,8 +103,14 @@ void spmv_plan_kernel(int m, int K, int npanels, const int32_t *__restrict__ seg
     constexpr int PER = SP_PANEL / SP_THREADS;                        // panel elements staged per thread (6)
     __shared__ double acc[SP_RB + 8];                                 // + the padding's dummy row
     __shared__ double vpan[2][SP_PANEL];
+    // integer / logical vectors: one bit per row "an NA element took part" (the reference adds NA_REAL itself for such a
+    // term, matmul.cpp:406-411: the row's result is NA_real_, whereas a NaN that comes out of the arithmetic stays a NaN —
+    // R tells the two apart; the flag, not `sum != sum`, decides, as RowAcc does in spmv_rows.h)
+    __shared__ unsigned na_rows[(SP_RB + 8 + 31) / 32];
     const int tid = threadIdx.x, rb = blockIdx.x;
     for (int i = tid; i < SP_RB + 8; i += SP_THREADS) acc[i] = 0.0;
+    if constexpr (KIND == MX_I32 || KIND == MX_LGL)
+        for (int i = tid; i < (SP_RB + 8 + 31) / 32; i += SP_THREADS) na_rows[i] = 0u;
     const int32_t *__restrict__ so = seg_off + (size_t)rb * npanels;
     // panel 0 -> buffer 0
     double stage[PER];
@@ -136,7 +142,12 @@ void spmv_plan_kernel(int m, int K, int npanels, const int32_t *__restrict__ seg
             for (int q = 0; q < 4; q++) {
                 const double f = vp[c0[q] & ((1 << SP_COL_BITS) - 1)];
                 double t = av[q] * f;
-                if constexpr (KIND == MX_I32 || KIND == MX_LGL) t = __double_as_longlong(f) == (long long)MX_NA_REAL_BITS ? f : t;
+                if constexpr (KIND == MX_I32 || KIND == MX_LGL) {
+                    if (__double_as_longlong(f) == (long long)MX_NA_REAL_BITS) {
+                        t = 0.0;
+                        atomicOr(&na_rows[(c0[q] >> SP_COL_BITS) >> 5], 1u << ((c0[q] >> SP_COL_BITS) & 31));
+                    }
+                }
                 __hip_atomic_fetch_add(&acc[c0[q] >> SP_COL_BITS], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (two) {
@@ -144,7 +155,12 @@ void spmv_plan_kernel(int m, int K, int npanels, const int32_t *__restrict__ seg
                 for (int q = 0; q < 4; q++) {
                     const double f = vp[c1[q] & ((1 << SP_COL_BITS) - 1)];
                     double t = bv[q] * f;
-                    if constexpr (KIND == MX_I32 || KIND == MX_LGL) t = __double_as_longlong(f) == (long long)MX_NA_REAL_BITS ? f : t;
+                    if constexpr (KIND == MX_I32 || KIND == MX_LGL) {
+                        if (__double_as_longlong(f) == (long long)MX_NA_REAL_BITS) {
+                            t = 0.0;
+                            atomicOr(&na_rows[(c1[q] >> SP_COL_BITS) >> 5], 1u << ((c1[q] >> SP_COL_BITS) & 31));
+                        }
+                    }
                     __hip_atomic_fetch_add(&acc[c1[q] >> SP_COL_BITS], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -159,7 +175,7 @@ void spmv_plan_kernel(int m, int K, int npanels, const int32_t *__restrict__ seg
     for (int i = tid; i < SP_RB && r0 + i < m; i += SP_THREADS) {
         const double sum = acc[i];
         if constexpr (KIND == MX_F32) ((float *)y_)[r0 + i] = (float)sum;
-        else if constexpr (KIND == MX_I32 || KIND == MX_LGL) ((double *)y_)[r0 + i] = sum != sum ? na_real() : sum;
+        else if constexpr (KIND == MX_I32 || KIND == MX_LGL) ((double *)y_)[r0 + i] = (na_rows[i >> 5] >> (i & 31)) & 1u ? na_real() : sum;
         else ((double *)y_)[r0 + i] = sum;
     }
 }

@@ -37,16 +37,39 @@ class DeviceCSR:
     _sorted: bool | None = None
     _plan: object = None
     _plan_panels: int = -1
+    _plan_ready: bool = True
     _spmv_plan: object = None
+
+    def invalidate(self):
+        """Forget everything derived from the arrays (plans, the sortedness flag): call after changing indptr / indices /
+        values in place.  The arrays of a DeviceCSR are otherwise taken as immutable, like an R object's slots."""
+        lib = _lib.load()
+        if self._plan is not None:
+            lib.mxd_spmm_plan_destroy(self._plan)
+        self._plan, self._plan_panels, self._plan_ready, self._sorted = None, -1, True, None
+        self.drop_spmv_plan()
+
+    def auto_plan(self, npanels: int = 0):
+        """The plan AUTO products keep on the matrix (mxd_spmm_plan_create_auto: AUTO's padding limit applies); None when
+        the plan would pad too much — the caller then runs the row-wave kernel, as AUTO does."""
+        lib = _lib.load()
+        if self._plan is None or self._plan_panels != npanels:
+            handle = self._plan if self._plan is not None else C.c_void_p()
+            ready = C.c_int(0)
+            check(lib.mxd_spmm_plan_create_auto(C.c_int(self.m), C.c_int(self.K), _dp(self.indptr), _dp(self.indices),
+                                                _dp(self.values), C.c_int(npanels), _stream(), C.byref(handle),
+                                                C.byref(ready)))
+            self._plan, self._plan_panels, self._plan_ready = handle, npanels, bool(ready.value)
+        return self._plan if self._plan_ready else None
 
     def plan(self, npanels: int = 0, rebuild: bool = False):
         """Device-resident SpMM plan (mxd_spmm_plan_create); cached per DeviceCSR, buffers re-used on rebuild."""
         lib = _lib.load()
-        if self._plan is None or rebuild or self._plan_panels != npanels:
+        if self._plan is None or rebuild or self._plan_panels != npanels or not self._plan_ready:
             handle = self._plan if self._plan is not None else C.c_void_p()
             check(lib.mxd_spmm_plan_create(C.c_int(self.m), C.c_int(self.K), _dp(self.indptr), _dp(self.indices),
                                            _dp(self.values), C.c_int(npanels), _stream(), C.byref(handle)))
-            self._plan, self._plan_panels = handle, npanels
+            self._plan, self._plan_panels, self._plan_ready = handle, npanels, True
         return self._plan
 
     def plan_info(self):
@@ -102,11 +125,14 @@ class DeviceCSR:
 
 
 def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajor: bool = False,
-         algo: int = 0, npanels: int = 0, wg_per_cu: int = 0):
+         algo: int = 0, npanels: int = 0, wg_per_cu: int = 0, keep_plan: bool = True):
     """C = A @ B with B (K x n) row-major in HBM.  colmajor=False: C row-major (m x n) —
     gemm_csr_drm_as_drm layout; colmajor=True: C column-major (what tcrossprod_csr_dense returns to R),
     stored as a row-major (n x m) tensor and returned as its transposed view.
-    algo: 0 auto, 1 row-wave kernel, 2 slab/panel kernel (include/mxgpu.h mx_spmm_algo)."""
+    algo: 0 auto, 1 row-wave kernel, 2 slab/panel kernel (include/mxgpu.h mx_spmm_algo).
+    keep_plan (algo 0 only): when AUTO picks the planned kernel, the plan — a regrouping of A's entries that depends on A
+    alone — is built once and kept on the DeviceCSR (like rows_sorted()); keep_plan=False is the C-ABI's own AUTO, which
+    rebuilds the plan from plain CSR inside every call."""
     lib = _lib.load()
     assert B.is_cuda and B.dim() == 2 and B.stride(1) == 1 and B.shape[0] == A.K
     n = int(B.shape[1])
@@ -125,6 +151,17 @@ def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajo
     if A.nnz == 0:                       # reference early-out (matmul.cpp:128-129,160-161): all zeros
         out.zero_()
         return out.t() if colmajor else out
+    if algo == 0 and keep_plan and wg_per_cu == 0:
+        pick = C.c_int(0)
+        check(lib.mxd_spmm_auto_algo(C.c_int(A.m), C.c_int(n), C.c_int(A.K), C.c_int(dt), _dp(B), C.c_size_t(B.stride(0)),
+                                     _dp(out), C.c_size_t(ldc), C.c_int(1 if colmajor else 0), C.byref(pick)))
+        if pick.value == 3:
+            plan = A.auto_plan(npanels)
+            if plan is not None:
+                check(lib.mxd_spmm_plan_run(plan, C.c_int(n), _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),
+                                            C.c_int(dt), C.c_int(1 if colmajor else 0), C.c_int(0), C.c_int(-1), _stream()))
+                return out.t() if colmajor else out
+            algo = 1                                                 # too much padding: AUTO's row-wave fallback
     sorted_rows = A.rows_sorted() if algo != 1 else False
     check(lib.mxd_spmm_csr_dense_ex(C.c_int(A.m), C.c_int(n), C.c_int(A.K), _dp(A.indptr), _dp(A.indices),
                                     _dp(A.values), _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),
@@ -221,22 +258,39 @@ def csr_elemwise(op, A: DeviceCSR, B: DeviceCSR, two_pass: bool = True):
     return DeviceCSR(out_p, out_j, out_x, A.m, A.K, int(nnz_out.value))
 
 
-def csr_gather_rows(A: DeviceCSR, rows: torch.Tensor):
-    """A[rows, :] on device (copy_csr_rows).  rows int32, 0-based."""
+def csr_gather_rows(A: DeviceCSR, rows: torch.Tensor, one_launch: bool = True):
+    """A[rows, :] on device (copy_csr_rows).  rows int32, 0-based.
+    one_launch (default): mxd_csr_gather_fused into arrays sized for 1.25x the expected result (r mean row lengths) — one
+    kernel, the size read back once behind it; a selection that does not fit (very uneven rows) is copied again into
+    exactly sized arrays by the fill kernel.  one_launch=False: count -> (host round trip) -> fill."""
     lib = _lib.load()
     dev = A.indptr.device
     r = int(rows.numel())
     ws = torch.empty(lib.mxd_gather_workspace_bytes(r), dtype=torch.uint8, device=dev)
     new_p = torch.empty(r + 1, dtype=torch.int32, device=dev)
     nnz_out = C.c_int64(0)
-    check(lib.mxd_csr_gather_count(C.c_int(r), _dp(A.indptr), _dp(rows), _dp(new_p), _dp(ws),
-                                   C.byref(nnz_out), _stream()))
-    new_j = torch.empty(nnz_out.value, dtype=torch.int32, device=dev)
     if A.values is None:
-        vd, new_x = MX_NONE, None
+        vd, vdt = MX_NONE, None
     else:
-        vd = MX_F64 if A.values.dtype == torch.float64 else MX_LGL
-        new_x = torch.empty(nnz_out.value, dtype=A.values.dtype, device=dev)
+        vd, vdt = (MX_F64 if A.values.dtype == torch.float64 else MX_LGL), A.values.dtype
+    counted = False
+    if one_launch and A.m > 0 and r > 0:
+        avg = A.nnz / A.m
+        cap = min(int(1.25 * r * avg) + 1024, 2 ** 31 - 1)
+        new_j = torch.empty(cap, dtype=torch.int32, device=dev)
+        new_x = None if vdt is None else torch.empty(cap, dtype=vdt, device=dev)
+        check(lib.mxd_csr_gather_fused(C.c_int(r), _dp(A.indptr), _dp(A.indices), _dp(A.values), _dp(rows), _dp(new_p),
+                                       _dp(new_j), _dp(new_x), C.c_int(vd), C.c_int64(cap), C.c_double(avg), _dp(ws),
+                                       C.byref(nnz_out), _stream()))
+        n = int(nnz_out.value)
+        if n <= cap:
+            return DeviceCSR(new_p, new_j[:n], None if new_x is None else new_x[:n], r, A.K, n)
+        counted = True                                               # new_p is complete; only the copy has to be redone
+    if not counted:
+        check(lib.mxd_csr_gather_count(C.c_int(r), _dp(A.indptr), _dp(rows), _dp(new_p), _dp(ws),
+                                       C.byref(nnz_out), _stream()))
+    new_j = torch.empty(nnz_out.value, dtype=torch.int32, device=dev)
+    new_x = None if vdt is None else torch.empty(nnz_out.value, dtype=vdt, device=dev)
     check(lib.mxd_csr_gather_fill(C.c_int(r), _dp(A.indptr), _dp(A.indices), _dp(A.values), _dp(rows), _dp(new_p),
                                   _dp(new_j), _dp(new_x), C.c_int(vd), C.c_int64(nnz_out.value), _stream()))
     return DeviceCSR(new_p, new_j, new_x, r, A.K, int(nnz_out.value))

@@ -20,7 +20,6 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libmxoracle.so")
 
 NA_INTEGER = np.int32(-2147483648)
 NA_LOGICAL = NA_INTEGER
@@ -28,7 +27,8 @@ NA_REAL = np.frombuffer(np.uint64(0x7FF00000000007A2).tobytes(), dtype=np.float6
 
 
 def _cpu_stamp() -> str:
-    """md5 of this machine's CPU model + ISA flags (what `make` records next to a -march=native build)."""
+    """md5 of this machine's CPU model + ISA flags — the same digest oracle/Makefile computes (a -march=native build only
+    runs on the CPU model it was made on)."""
     import hashlib
     model = flags = ""
     try:
@@ -42,25 +42,35 @@ def _cpu_stamp() -> str:
                     break
     except OSError:
         pass
-    return hashlib.md5((model + flags).encode()).hexdigest()
+    return hashlib.md5((model + flags).encode()).hexdigest()[:12]
 
 
 def build(force: bool = False) -> str:
     """MXORACLE_SO=<path>: use that build as is (tools/sanitize.sh points it at an ASan + UBSan build).
-    The library is built -march=native: rebuild when it is missing, older than the source, or was made on another
-    CPU model (the prebuilt file travels from the build container to the GPU box)."""
+    Otherwise oracle/_build/libmxoracle-<cpu stamp>.so: one library per CPU model (the build container's file travels to
+    the GPU box, whose CPU differs — it is simply not the file that box asks for).  Built when missing or older than the
+    source, under an exclusive file lock and through a temporary name (make: `mv` into place), so that processes that
+    ask at the same time — pytest workers, the ranks of `bench.py --gpus N` — never load a half-written file."""
     if os.environ.get("MXORACLE_SO"):
         return os.environ["MXORACLE_SO"]
-    stamp = os.path.join(_HERE, "_build", "cpu_stamp")
-    try:
-        with open(stamp) as f:
-            same_cpu = f.read().strip() == _cpu_stamp()
-    except OSError:
-        same_cpu = False
-    if force or not same_cpu or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
-            os.path.join(_HERE, "mx_oracle.c")):
-        subprocess.check_call(["make", "-B", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
-    return _SO
+    import fcntl
+    bdir = os.path.join(_HERE, "_build")
+    so = os.path.join(bdir, f"libmxoracle-{_cpu_stamp()}.so")
+    src = os.path.join(_HERE, "mx_oracle.c")
+
+    def fresh():
+        return os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(src)
+    if force or not fresh():
+        os.makedirs(bdir, exist_ok=True)
+        with open(os.path.join(bdir, ".lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if force or not fresh():                              # (another process may have built it meanwhile)
+                    subprocess.check_call(["make", "-B", "-C", _HERE, f"OUT=_build/{os.path.basename(so)}"],
+                                          stdout=subprocess.DEVNULL)
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
+    return so
 
 
 _lib = None

@@ -126,3 +126,38 @@ def spmv_plan_device(p, j, x, vectors):
     finally:
         lib.mxd_spmv_plan_destroy(plan)
     return outs
+
+
+def rows_sorted_device(p, j, misalign=0):
+    """mxd_csr_rows_sorted on device copies; misalign = int32 elements by which the indices array is shifted off its
+    16-byte alignment (0..3).  p may start above 0 (a row-block view that keeps absolute offsets into j)."""
+    lib = _lib.load()
+    m = p.size - 1
+    dp = Dev(p.astype(np.int32))
+    jj = np.concatenate([np.full(misalign, -7, dtype=np.int32), j.astype(np.int32)]) if misalign else j.astype(np.int32)
+    dj = Dev(jj)
+    ws = Dev(nbytes=16)
+    flag = C.c_int(-1)
+    check(lib.mxd_csr_rows_sorted(C.c_int(m), dp.ptr, C.c_void_p(dj.ptr.value + 4 * misalign), ws.ptr, C.byref(flag), None))
+    return bool(flag.value)
+
+
+def gather_fused_device(p, j, x, rows, capacity, value_dtype):
+    """mxd_csr_gather_fused; returns (new_indptr, new_indices[:min(nnz, capacity)], new_values or None, nnz_out)"""
+    lib = _lib.load()
+    r = rows.size
+    dp, dj, dr = Dev(p.astype(np.int32)), Dev(j.astype(np.int32)), Dev(rows.astype(np.int32))
+    dx = None if x is None else Dev(x)
+    vb = 0 if x is None else x.dtype.itemsize
+    op, oj = Dev(nbytes=4 * (r + 1)), Dev(nbytes=4 * max(capacity, 1))
+    ox = None if x is None else Dev(nbytes=vb * max(capacity, 1))
+    check(lib.mx_dev_memset(oj.ptr, 0xFF, C.c_size_t(oj.nbytes), None))
+    ws = Dev(nbytes=int(lib.mxd_gather_workspace_bytes(C.c_int(r))))
+    nnz = C.c_int64(-1)
+    avg = float(p[-1] - p[0]) / max(p.size - 1, 1)
+    check(lib.mxd_csr_gather_fused(C.c_int(r), dp.ptr, dj.ptr, None if dx is None else dx.ptr, dr.ptr, op.ptr, oj.ptr,
+                                   None if ox is None else ox.ptr, C.c_int(value_dtype), C.c_int64(capacity), C.c_double(avg),
+                                   ws.ptr, C.byref(nnz), None))
+    n = int(min(nnz.value, capacity))
+    return (op.download(np.int32, (r + 1,)), oj.download(np.int32, (max(capacity, 1),))[:n],
+            None if ox is None else ox.download(x.dtype, (max(capacity, 1),))[:n], int(nnz.value))

@@ -214,28 +214,59 @@ def test_sharded_export_on_one_gpu(gpu):
         _lib.check(lib.mx_set_devices((C.c_int * 1)(99), 1))
 
 
-def test_export_spmv_uses_a_plan_for_a_cached_matrix(gpu):
-    """matmul_csr_dvec_* on a matrix that is still on the device from the previous call goes through the planned kernel
-    (v's panels in LDS): same answers (1e-12) as the one-shot kernel of the first call, all four kinds."""
+def _option(lib, name):
+    v = C.c_int64(0)
+    _lib.check(lib.mx_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+def test_export_spmv_is_bitwise_by_default_and_planned_on_request(gpu):
+    """matmul_csr_dvec_* by default runs the one-shot flat kernel on EVERY call — the same bits on the first and on later
+    calls, bit for bit the reference's loop (the planned kernel used to take over silently on a cache hit).
+    With mx_set_option("spmv_planned", 1) a matrix that is still on the device from the previous call goes through the
+    planned kernel (v's panels in LDS): same answers to 1e-12, all four kinds, NA rows exact."""
     lib = _lib.load()
     lib.mx_cache_invalidate(None)
     m, K = 300_000, 50_000
     p, j, x = synth.csr_fixed(m, K, 20, seed=6)                      # 6 M entries: above the planning threshold
     rng = np.random.default_rng(2)
     v = rng.normal(size=K)
-    first = G.matmul_csr_dvec_numeric(p, j, x, v)                    # miss: one-shot flat kernel, bitwise the oracle's loop
     ref = O.matmul_csr_dvec_numeric(p, j, x, v)
+    assert _option(lib, "spmv_planned") == 0
+    n0 = _option(lib, "spmv_planned_calls")
+    first = G.matmul_csr_dvec_numeric(p, j, x, v)                    # miss: one-shot flat kernel, bitwise the oracle's loop
+    again = G.matmul_csr_dvec_numeric(p, j, x, v)                    # hit: still the flat kernel
     np.testing.assert_array_equal(first, ref)
-    again = G.matmul_csr_dvec_numeric(p, j, x, v)                    # hit: plan built, planned kernel
-    np.testing.assert_allclose(again, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
-    v2 = rng.normal(size=K)
-    np.testing.assert_allclose(G.matmul_csr_dvec_numeric(p, j, x, v2), O.matmul_csr_dvec_numeric(p, j, x, v2), rtol=1e-12,
-                               atol=1e-12)
-    vi = rng.integers(-5, 6, size=K).astype(np.int32)
-    vi[::97] = -2147483648
-    gi, ri = G.matmul_csr_dvec_integer(p, j, x, vi), O.matmul_csr_dvec_integer(p, j, x, vi)
-    np.testing.assert_array_equal(np.isnan(gi), np.isnan(ri))
-    np.testing.assert_allclose(gi[~np.isnan(ri)], ri[~np.isnan(ri)], rtol=1e-12, atol=1e-12)
-    vf = v.astype(np.float32)
-    np.testing.assert_allclose(G.matmul_csr_dvec_float32(p, j, x, vf), O.matmul_csr_dvec_float32(p, j, x, vf), rtol=1e-5, atol=1e-5)
-    assert _cache_stats(lib)["hits"] >= 4
+    np.testing.assert_array_equal(again, ref)
+    assert _option(lib, "spmv_planned_calls") == n0 and _cache_stats(lib)["hits"] >= 1
+    _lib.check(lib.mx_set_option(b"spmv_planned", C.c_int64(1)))
+    try:
+        planned = G.matmul_csr_dvec_numeric(p, j, x, v)              # hit: plan built, planned kernel
+        assert _option(lib, "spmv_planned_calls") == n0 + 1
+        np.testing.assert_allclose(planned, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+        v2 = rng.normal(size=K)
+        np.testing.assert_allclose(G.matmul_csr_dvec_numeric(p, j, x, v2), O.matmul_csr_dvec_numeric(p, j, x, v2), rtol=1e-12,
+                                   atol=1e-12)
+        vi = rng.integers(-5, 6, size=K).astype(np.int32)
+        vi[::97] = -2147483648
+        gi, ri = G.matmul_csr_dvec_integer(p, j, x, vi), O.matmul_csr_dvec_integer(p, j, x, vi)
+        # NA rows carry R's NA_real_ payload exactly (low word 1954), not just "a NaN"
+        np.testing.assert_array_equal(np.isnan(gi), np.isnan(ri))
+        na_bits = np.uint64(0x7FF00000000007A2)
+        assert np.all(gi[np.isnan(ri)].view(np.uint64) == na_bits) and np.isnan(ri).sum() > 1000
+        np.testing.assert_allclose(gi[~np.isnan(ri)], ri[~np.isnan(ri)], rtol=1e-12, atol=1e-12)
+        # a NaN that comes out of the arithmetic (NaN value x finite integer) stays an ordinary NaN, it is not turned into NA
+        x2 = x.copy()
+        k = int(p[1234]) + 3
+        x2[k] = np.nan
+        vi2 = np.abs(vi) % 7 + 1
+        G.matmul_csr_dvec_integer(p, j, x2, vi2.astype(np.int32))            # miss (new values): flat
+        gn = G.matmul_csr_dvec_integer(p, j, x2, vi2.astype(np.int32))       # hit: planned
+        assert np.isnan(gn[1234]) and gn[1234:1235].view(np.uint64)[0] != na_bits and np.isnan(gn).sum() == 1
+        vf = v.astype(np.float32)
+        np.testing.assert_allclose(G.matmul_csr_dvec_float32(p, j, x, vf), O.matmul_csr_dvec_float32(p, j, x, vf), rtol=1e-5, atol=1e-5)
+        assert _option(lib, "spmv_planned_calls") >= n0 + 5
+    finally:
+        _lib.check(lib.mx_set_option(b"spmv_planned", C.c_int64(-1)))
+    with pytest.raises(_lib.MxError):
+        _lib.check(lib.mx_set_option(b"no_such_option", C.c_int64(1)))

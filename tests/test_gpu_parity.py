@@ -718,3 +718,120 @@ def test_csr_by_dvec_empty_inputs(gpu):
     assert G.logicaland_csr_by_dvec_internal(p, j, np.zeros(0, np.int32), np.ones(5, np.int32), 4).size == 0
     p0 = np.zeros(1, dtype=np.int32)
     assert G.multiply_csr_by_dvec_no_NAs_numeric(p0, j, x, np.ones(1), 0, 0, 0, 1, 0, 0, 1).size == 0
+
+
+# ----------------------------------------------------------------------------- round 3: one-stream sortedness, one-launch gather
+def _sorted_ref(p, j):
+    """numpy statement of check_is_sorted per row (misc.cpp:118-128): no descent inside a row"""
+    lo, hi = int(p[0]), int(p[-1])
+    if hi - lo < 2:
+        return True
+    d = np.zeros(hi, dtype=bool)
+    d[lo + 1:hi] = j[lo + 1:hi] < j[lo:hi - 1]
+    starts = p[:-1][(p[1:] > p[:-1])]
+    d[starts] = False
+    return not d.any()
+
+
+@pytest.mark.parametrize("mean_len,m", [(1.5, 400_000), (3, 600_000), (50, 300_000), (120, 400_000), (6000, 2500)])
+def test_rows_sorted_one_stream_kernel(gpu, mean_len, m):
+    """The sortedness check streams the indices once and resolves row starts against an LDS bitmap (gather.hip): sizes at which
+    a workgroup walks several sub-chunks (> 8.4 M entries), short rows (several rounds of row pointers per sub-chunk), long
+    rows (sub-chunks without a row start), empty rows, descents planted at sub-chunk / workgroup boundaries, an indices
+    array that is not 16-byte aligned, and a row-block view whose indptr[0] > 0."""
+    from devmem import rows_sorted_device
+    rng = np.random.default_rng(int(mean_len * 10) + m)
+    lens = rng.poisson(mean_len, size=m).astype(np.int64)
+    lens[rng.integers(0, m, size=m // 20)] = 0                          # empty rows, also runs of them
+    lens[m // 2:m // 2 + 50] = 0
+    p = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(lens, out=p[1:])
+    nnz = int(p[-1])
+    assert nnz < 2 ** 31
+    p = p.astype(np.int32)
+    K = 1 << 20
+    # sorted rows: ascending inside a row by construction (cumulative gaps), random across rows
+    gaps = rng.integers(1, 40, size=nnz).astype(np.int64)
+    c = np.cumsum(gaps)
+    row_of = np.repeat(np.arange(m), lens)
+    base = np.concatenate([[0], c])[p[:-1]][row_of]                    # cumulative value before the row's first entry
+    j = ((c - base) % K).astype(np.int32)
+    # (c - base) grows inside a row and rows are far shorter than K / 40 on average ... except the long-row case: sort those
+    if mean_len > 1000:
+        for r in range(m):
+            j[p[r]:p[r + 1]].sort()
+    assert _sorted_ref(p, j)
+    assert rows_sorted_device(p, j) is True
+    for mis in (1, 2, 3):
+        assert rows_sorted_device(p, j, misalign=mis) is True
+    # one descent INSIDE a row, at positions spread over the array incl. the first / last entries and multiples of the
+    # sub-chunk (4096 entries) and of a workgroup's chunk
+    nq = (nnz + 3) // 4
+    cq = -(-nq // 2048)                                                # quads per workgroup (gather.hip: RS_NB = 2048) ...
+    cq = -(-cq // 1024) * 1024                                         # ... in whole sub-chunks of RS_SUB_Q = 1024 quads
+    cand = {1, 2, nnz - 1, nnz // 2, 4096, 4095, 4097, 8192, 4 * cq, 4 * cq - 1, 4 * cq + 1, 12 * cq} | \
+        set(rng.integers(1, nnz, size=12).tolist())
+    tried = 0
+    for k in sorted(cand):
+        if not (0 < k < nnz):
+            continue
+        r = int(np.searchsorted(p, k, side="right") - 1)
+        if k == p[r]:                                                  # first entry of its row: move inside the row if it has one
+            if p[r + 1] - p[r] < 2:
+                continue
+            k += 1
+        jb = j.copy()
+        jb[k] = jb[k - 1] - 1 if jb[k - 1] > 0 else -1
+        if jb[k] < 0:
+            continue
+        assert not _sorted_ref(p, jb)
+        assert rows_sorted_device(p, jb, misalign=tried % 4) is False, f"descent at {k} (row {r}) not seen"
+        tried += 1
+    assert tried >= 8
+    # row-block views with absolute offsets: indptr[0] > 0; entries before the view are garbage that must not count
+    for r0 in (1, m // 3, m - 5):
+        jb = j.copy()
+        if p[r0] > 2:
+            jb[:p[r0]] = jb[:p[r0]][::-1]                              # descending garbage before the view
+        assert rows_sorted_device(p[r0:], jb) is True
+        if p[-1] - p[r0] > 4:
+            k = int(p[r0]) + 1
+            r = int(np.searchsorted(p, k, side="right") - 1)
+            if k > p[r]:
+                jb[k] = jb[k - 1] - 1
+                assert rows_sorted_device(p[r0:], jb) == _sorted_ref(p[r0:], jb)
+
+
+def test_gather_one_launch_kernel(gpu):
+    """mxd_csr_gather_fused against the oracle, bit for bit: capacity exact / generous / too small (then indptr and the
+    total must still be exact and everything that fits must have been copied), numeric / logical / pattern values,
+    rows of very uneven length, repeats, empty selections."""
+    from devmem import gather_fused_device
+    p, j, x = synth.csr_skewed(20_000, 5000, 25, seed=11, sigma=1.2)
+    xl = np.random.default_rng(3).choice(np.array([0, 1, NA], dtype=np.int32), size=x.size)
+    for r, seed in ((1, 1), (255, 2), (256, 3), (257, 4), (30_000, 5)):
+        rows = synth.rows_with_replacement(r, 20_000, seed=seed)
+        ref = O.copy_csr_rows_numeric(p, j, x, rows)
+        total = int(ref["indices"].size)
+        refp = ref["indptr"] if total else np.concatenate([[0], np.cumsum((p[1:] - p[:-1])[rows])]).astype(np.int32)
+        for cap in (total, total + 1000, max(total // 2, 0), 0):
+            for vals, dt, refv in ((x, _lib.MX_F64, ref["values"]), (xl, _lib.MX_LGL, None), (None, _lib.MX_NONE, None)):
+                gp, gj, gx, nnz = gather_fused_device(p, j, vals, rows, cap, dt)
+                assert nnz == total
+                np.testing.assert_array_equal(gp, refp)
+                if total == 0:
+                    continue
+                # rows that end within the capacity are copied completely
+                fits = refp[1:] <= cap
+                for t in np.nonzero(fits)[0][:: max(1, r // 300)]:
+                    rr = rows[t]
+                    np.testing.assert_array_equal(gj[refp[t]:refp[t + 1]], j[p[rr]:p[rr + 1]])
+                    if vals is not None:
+                        np.testing.assert_array_equal(gx[refp[t]:refp[t + 1]], vals[p[rr]:p[rr + 1]])
+                if cap >= total:
+                    np.testing.assert_array_equal(gj, ref["indices"])
+                    if refv is not None:
+                        np.testing.assert_array_equal(gx, refv)
+    # nothing selected / rows without entries
+    gp, gj, gx, nnz = gather_fused_device(p, j, x, np.zeros(0, dtype=np.int32), 10, _lib.MX_F64)
+    assert nnz == 0 and gp.tolist() == [0]

@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] WHOLE on one MI355X: dgRMatrix 8M x 200k, 64 nnz/row (nnz 512M, 6.1 GB of CSR, values f64) %*% dense
+200k x 256 FLOAT32 -> 8M x 256 f32 column-major (2.048e9 elements, 8.2 GB), through the export-level boundary
+(mx_tcrossprod_csr_dense_float32: src/matmul.cpp:316-343,361-375; alpha narrowed per nonzero :53-57; `(size_t)row*ldc`
+:138 is the 64-bit-offset hazard this size is about).
+
+  * operand: block r (rows r*1M .. (r+1)*1M) = synth.csr_fixed(1M, 200k, 64, seed = SEED_A + 1000*r), i.e. exactly the
+    row block rank r of `bench.py --gpus 8` multiplies;
+  * result: plain malloc, untouched (what R's allocVector hands over);
+  * runs: sharded with mx_set_devices([0]*8) (the 8-way path behind the boundary on the one GPU there is), unsharded cold
+    (CSR not on the device), unsharded with the CSR cached; then the same product at device level (one 8M-row launch);
+  * checks: mx_partition_rows' cuts == the bench's row blocks; f64 column checksum 1^T C == (A^T 1)^T B; 256-row blocks
+    against the oracle (f32 arithmetic) at rows 0, around the 2^31- and 2^32-byte marks of the column-major result, around
+    row 2^22 (the 2^32-byte mark of a row-major one) and at the end; linearity A(B1 + 2 B2) == A B1 + 2 A B2 on a row sample;
+    sharded == unsharded == device-level.
+
+Used by tests/test_gpu_cfg5_full.py and `bench.py --config cfg5-full`; as a script it prints one JSON object."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+M_BLOCK, NBLOCKS, K, NNZ_ROW, N = 1_000_000, 8, 200_000, 64, 256
+ALG_BYTES = 4 * (M_BLOCK * NBLOCKS + 1) + 12 * M_BLOCK * NBLOCKS * NNZ_ROW + 4 * K * N + 4 * M_BLOCK * NBLOCKS * N
+
+
+def build_operand(synth, nblocks=NBLOCKS, m_block=M_BLOCK, k=K, nnz_row=NNZ_ROW):
+    """the 8M x 200k CSR, block by block (block r == rank r's bench operand); also w = A^T 1 in f64 for the checksum"""
+    m, nnz = nblocks * m_block, nblocks * m_block * nnz_row
+    p = (np.arange(m + 1, dtype=np.int64) * nnz_row).astype(np.int32)
+    j = np.empty(nnz, dtype=np.int32)
+    x = np.empty(nnz, dtype=np.float64)
+    w = np.zeros(k)
+    for r in range(nblocks):
+        _, jb, xb = synth.csr_fixed(m_block, k, nnz_row, seed=synth.SEED_A + 1000 * r)
+        lo = r * m_block * nnz_row
+        j[lo:lo + jb.size] = jb
+        x[lo:lo + xb.size] = xb
+        w += np.bincount(jb, weights=xb, minlength=k)
+    return p, j, x, w
+
+
+def oracle_block(O, p, j, x, B, r0, rows):
+    n = B.shape[1]
+    lo, hi = int(p[r0]), int(p[r0 + rows])
+    ref = np.zeros(rows * n, dtype=np.float32)
+    O.gemm_csr_drm_as_drm(rows, n, (p[r0:r0 + rows + 1].astype(np.int64) - lo).astype(np.int32), j[lo:hi].copy(),
+                          x[lo:hi].copy(), B.reshape(-1), n, ref, n, O.max_threads(), True)
+    return ref.reshape(rows, n)
+
+
+def run(nblocks=NBLOCKS, m_block=M_BLOCK, device_level=True, verbose=False):
+    import matrixextra_amd  # noqa: F401
+    from matrixextra_amd import _lib, synth
+    from oracle import oracle as O
+    lib = _lib.load()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+
+    def say(*a):
+        if verbose:
+            print("[cfg5-full]", *a, file=sys.stderr, flush=True)
+
+    m, n = nblocks * m_block, N
+    avail_kb = next((int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")), 0)
+    need = 12 * m * NNZ_ROW + 2 * 4 * m * n + (4 << 30)
+    if avail_kb * 1024 < need:
+        raise RuntimeError(f"cfg5-full needs {need >> 30} GiB of host memory, {avail_kb >> 20} GiB available")
+    t0 = time.perf_counter()
+    p, j, x, w = build_operand(synth, nblocks, m_block)
+    nnz = int(p[-1])
+    B1 = synth.dense_normal(K, n, seed=synth.SEED_B, dtype=np.float32)
+    B2 = synth.dense_normal(K, n, seed=22, dtype=np.float32)
+    say(f"operands built in {time.perf_counter() - t0:.1f} s: m={m} nnz={nnz}")
+    res = {"dims": {"rows": m, "cols": K, "nnz_per_row": NNZ_ROW, "nnz": nnz, "dense_cols": n, "dense_dtype": "f32",
+                    "result_elements": m * n, "result_bytes": 4 * m * n},
+           "algorithmic_bytes": 4 * (m + 1) + 12 * nnz + 4 * K * n + 4 * m * n}
+
+    # ---- the row cuts sharding uses == the bench's row blocks (equal rows: every row costs the same)
+    cuts = (C.c_int * (nblocks + 1))()
+    _lib.check(lib.mx_partition_rows(C.c_void_p(p.ctypes.data), C.c_int(m), C.c_int(nblocks), C.c_int(n), C.c_int(4), cuts))
+    assert list(cuts) == [r * m_block for r in range(nblocks + 1)], list(cuts)
+    res["partition_rows_cuts_equal_bench_blocks"] = True
+
+    fn = lib.mx_tcrossprod_csr_dense_float32
+    c_bytes = 4 * m * n
+    phases = []                                                      # mx_last_call_phases of every export call, in order
+
+    def call(B):
+        """one export call into fresh malloc'ed memory; returns (seconds, pointer, (m, n) view)"""
+        q = libc.malloc(c_bytes)
+        assert q, "malloc failed"
+        t = time.perf_counter()
+        _lib.check(fn(C.c_void_p(p.ctypes.data), C.c_void_p(j.ctypes.data), C.c_void_p(x.ctypes.data), C.c_int(m),
+                      C.c_void_p(B.ctypes.data), C.c_int(n), C.c_int(K), C.c_int(1), C.c_void_p(q)))
+        dt = time.perf_counter() - t
+        buf = C.create_string_buffer(512)
+        lib.mx_last_call_phases(buf, C.c_size_t(512))
+        phases.append(buf.value.decode())
+        view = np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_float)), shape=(n, m)).T
+        return dt, q, view
+
+    # oracle blocks: rows around the byte marks of the result (element 2^29 / 2^30 of the column-major matrix = byte 2^31 /
+    # 2^32: column 67 / 134 at these rows), row 2^22, both ends
+    rows_chk = 256
+    marks = sorted({0, m - rows_chk} | {max(0, min(m - rows_chk, r - rows_chk // 2))
+                                        for r in ((1 << 29) % m, (1 << 30) % m, 1 << 22) if r < m})
+    refs = {r0: oracle_block(O, p, j, x, B1, r0, rows_chk) for r0 in marks}
+    scale = float(np.abs(x).sum() * np.abs(B1).max())
+    expect = w @ B1.astype(np.float64)
+
+    def check(out, what):
+        for r0, ref in refs.items():
+            np.testing.assert_allclose(out[r0:r0 + rows_chk], ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()),
+                                       err_msg=f"{what}: rows {r0}..{r0 + rows_chk}")
+        got = np.zeros(n)
+        for c0 in range(0, n, 32):                                   # f64 column sums, 1 GB of the result at a time
+            got[c0:c0 + 32] = out[:, c0:c0 + 32].sum(axis=0, dtype=np.float64)
+        err = float(np.max(np.abs(got - expect)))
+        assert err <= 1e-8 * scale, f"{what}: column checksum off by {err} (scale {scale})"
+        return err / scale
+    sample = np.arange(0, m, 997)
+
+    # ---- (1) sharded: the device listed nblocks times
+    lib.mx_cache_invalidate(None)
+    _lib.check(lib.mx_set_devices((C.c_int * nblocks)(*([0] * nblocks)), nblocks))
+    try:
+        t_sh, q_sh, out_sh = call(B1)
+        t_sh2, q2, _ = call(B1)
+        libc.free(q2)
+    finally:
+        _lib.check(lib.mx_set_devices(None, 0))
+    say(f"sharded x{nblocks}: {t_sh * 1e3:.1f} ms, again {t_sh2 * 1e3:.1f} ms")
+    res["sharded_checksum_rel_err"] = check(out_sh, "sharded")
+    res["export_sharded_ms"] = [round(t_sh * 1e3, 2), round(t_sh2 * 1e3, 2)]
+
+    # ---- (2) unsharded, cold then with the CSR cached
+    lib.mx_cache_invalidate(None)
+    t_cold, q_un, out_un = call(B1)
+    say(f"unsharded cold: {t_cold * 1e3:.1f} ms")
+    res["unsharded_checksum_rel_err"] = check(out_un, "unsharded")
+    res["sharded_equals_unsharded_bitwise"] = bool(all(np.array_equal(out_sh[:, c], out_un[:, c]) for c in range(n)))
+    if not res["sharded_equals_unsharded_bitwise"]:
+        for c in range(0, n, 17):
+            np.testing.assert_allclose(out_sh[:, c], out_un[:, c], rtol=1e-5, atol=1e-5 * float(np.abs(out_un[:, c]).max()))
+    libc.free(q_sh)
+    del out_sh
+    C1 = out_un[sample].astype(np.float64)
+    t_cached, q3, out3 = call(B1)
+    res["cached_checksum_rel_err"] = check(out3, "unsharded, CSR cached")
+    # (blocks are cut differently — row blocks cold, column blocks of the whole matrix's plan when cached —, so an octet of
+    # 64 rows can be laid out differently in the two plans: same sums in another order, f32 rounding apart)
+    res["cached_equals_cold_bitwise"] = bool(all(np.array_equal(out3[:, c], out_un[:, c]) for c in range(n)))
+    if not res["cached_equals_cold_bitwise"]:
+        for c in range(n):
+            np.testing.assert_allclose(out3[:, c], out_un[:, c], rtol=1e-5, atol=1e-5 * float(np.abs(out_un[:, c]).max()))
+    libc.free(q3)
+    del out3
+    say(f"unsharded cached: {t_cached * 1e3:.1f} ms")
+    res["export_unsharded_ms"] = {"cold": round(t_cold * 1e3, 2), "csr_cached": round(t_cached * 1e3, 2)}
+    res["export_phases_ms"] = {"sharded": phases[0], "sharded_again": phases[1], "cold": phases[2], "csr_cached": phases[3]}
+    # linearity on a row sample (every 997th row, all columns)
+    _, q4, out4 = call(B2)
+    C2 = out4[sample].astype(np.float64)
+    libc.free(q4)
+    del out4
+    _, q5, out5 = call((B1 + 2.0 * B2).astype(np.float32))
+    C12 = out5[sample].astype(np.float64)
+    libc.free(q5)
+    del out5
+    lin = float(np.max(np.abs(C12 - (C1 + 2.0 * C2))) / (np.abs(C1).max() + 2 * np.abs(C2).max()))
+    assert lin <= 2e-5, f"linearity: {lin}"
+    res["linearity_rel_err"] = lin
+
+    # ---- (3) device level: ONE launch over all 8M rows (plan for 512M entries, 8.2 GB column-major C in HBM)
+    if device_level:
+        import torch
+        from matrixextra_amd import device as D
+        lib.mx_cache_invalidate(None)
+        lib.mxd_release_workspaces()
+        A = D.DeviceCSR.from_host(p, j, x, K)
+        tB = torch.from_numpy(B1).cuda()
+        Cd = torch.empty((n, m), dtype=torch.float32, device="cuda")
+        Cd.fill_(float("nan"))
+        D.spmm(A, tB, out=Cd, colmajor=True)
+        torch.cuda.synchronize()
+        kernel = lib.mxd_spmm_last_kernel().decode()
+        host = torch.from_numpy(out_un.T)                            # (n, m) view of the malloc'ed result
+        same = all(bool(torch.equal(Cd[c0:c0 + 16].cpu(), host[c0:c0 + 16])) for c0 in range(0, n, 16))
+        if not same:
+            for c0 in range(0, n, 16):
+                a, b = Cd[c0:c0 + 16].cpu().numpy(), host[c0:c0 + 16].numpy()
+                np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5 * float(np.abs(b).max()))
+        res["device_level_equals_export_bitwise"] = bool(same)
+        steps = 5
+        lib.mxd_spmm_kernel_timing(1)
+        for _ in range(2):
+            D.spmm(A, tB, out=Cd, colmajor=True)
+        torch.cuda.synchronize()
+        lib.mxd_spmm_kernel_timing(0)
+        lib.mxd_spmm_kernel_timing(1)
+        t = time.perf_counter()
+        for _ in range(steps):
+            D.spmm(A, tB, out=Cd, colmajor=True)
+        torch.cuda.synchronize()
+        step = (time.perf_counter() - t) / steps
+        kt = (C.c_float * 64)()
+        kc = C.c_int(0)
+        _lib.check(lib.mxd_spmm_kernel_times(kt, 64, C.byref(kc)))
+        lib.mxd_spmm_kernel_timing(0)
+        k_ms = float(np.mean(kt[:kc.value])) if kc.value else step * 1e3
+        res["device_level"] = {"kernel": kernel, "ms_per_step": round(step * 1e3, 3), "kernel_avg_ms": round(k_ms, 3),
+                               "GFLOP/s": round(2.0 * nnz * n / step / 1e9, 1),
+                               "roofline": {"bound": "hbm", "achieved": round(res["algorithmic_bytes"] / (k_ms / 1e3) / 1e9, 1),
+                                            "peak": 8000.0, "unit": "GB/s",
+                                            "frac": round(res["algorithmic_bytes"] / (k_ms / 1e3) / 1e9 / 8000.0, 4),
+                                            "traffic": None},
+                               "plan": A.plan_info() if A._plan is not None else None}
+        say("device level:", res["device_level"])
+        del A, tB, Cd, host
+        torch.cuda.empty_cache()
+    libc.free(q_un)
+    lib.mx_cache_invalidate(None)
+    lib.mxd_release_workspaces()
+    res["GFLOP/s_export"] = {"sharded": round(2.0 * nnz * n / min(t_sh, t_sh2) / 1e9, 1),
+                             "cold": round(2.0 * nnz * n / t_cold / 1e9, 1), "csr_cached": round(2.0 * nnz * n / t_cached / 1e9, 1)}
+    res["oracle_blocks_at_rows"] = marks
+    return res
+
+
+if __name__ == "__main__":
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 else NBLOCKS
+    print(json.dumps(run(nblocks=nb, verbose=True)))

@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default=None, choices=sorted(WORKLOADS),
+    ap.add_argument("--config", default=None, choices=sorted(WORKLOADS) + ["cfg5-full"],
                     help="workload; default cfg2 at N = 1 (the metric's configuration), cfg5 for N > 1")
     ap.add_argument("--rows", type=int, default=None)
     ap.add_argument("--cols", type=int, default=None)
@@ -74,7 +74,7 @@ def parse():
     args.config_given = args.config is not None
     if args.config is None:
         args.config = "cfg2" if args.gpus == 1 else "cfg5"
-    w = WORKLOADS[args.config]
+    w = WORKLOADS["cfg5" if args.config == "cfg5-full" else args.config]
     args.custom = any(v is not None for v in (args.rows, args.cols, args.nnz_row, args.n, args.dtype))
     for k in ("rows", "cols", "nnz_row", "n", "dtype"):
         if getattr(args, k) is None:
@@ -643,6 +643,92 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
                 "(setup = B upload queued + cache look-up; block 0 = first product queued; touched C / pinned C = host pages of "
                 "the result exist / are registered; queued = all blocks and downloads queued; fingerprint = cache key of a new "
                 "operand hashed while the queues drain; kernels = compute queue empty; D2H C = download queue empty)"}
+
+    # ---- the skewed variant of the headline matrix (log-normal row lengths, sigma = 1, same mean, same B)
+    ps, js, xs = synth.csr_skewed_fast(m, K, 32, seed=synth.SEED_A, sigma=1.0)
+    As = D.DeviceCSR.from_host(ps, js, xs, K)
+    n_d = int(B.shape[1])
+    Cs = torch.empty((n_d, m), dtype=B.dtype, device="cuda")
+    lib.mxd_spmm_kernel_timing(0)
+    D.spmm(As, B, out=Cs, colmajor=True)
+    kname = lib.mxd_spmm_last_kernel().decode()
+    rows_chk = 2048
+    r0 = int(np.argmax(ps[1:] - ps[:-1]))                            # a block that contains the longest row
+    r0 = max(0, min(m - rows_chk, r0 - rows_chk // 2))
+    lo_, hi_ = int(ps[r0]), int(ps[r0 + rows_chk])
+    ref = np.zeros(rows_chk * n_d, dtype=B_host.dtype)
+    O.gemm_csr_drm_as_drm(rows_chk, n_d, (ps[r0:r0 + rows_chk + 1] - ps[r0]).astype(np.int32), js[lo_:hi_].copy(), xs[lo_:hi_].copy(),
+                          B_host.reshape(-1), n_d, ref, n_d, threads, True)
+    got = Cs[:, r0:r0 + rows_chk].t().cpu().numpy()
+    err = float(np.max(np.abs(got - ref.reshape(rows_chk, n_d))) / np.max(np.abs(ref)))
+    assert err <= 1e-10, f"skewed SpMM differs from the oracle: {err}"
+    lib.mxd_spmm_kernel_timing(1)
+    t = timeit(lambda: D.spmm(As, B, out=Cs, colmajor=True), reps=10)
+    kt = (C.c_float * 64)()
+    kc = C.c_int(0)
+    _lib.check(lib.mxd_spmm_kernel_times(kt, 64, C.byref(kc)))
+    lib.mxd_spmm_kernel_timing(0)
+    k_s = float(np.mean(kt[2:kc.value])) / 1e3 if kc.value > 2 else t
+    t_rw = timeit(lambda: D.spmm(As, B, out=Cs, colmajor=True, algo=1), reps=5)
+    byts = synth.spmm_algorithmic_bytes(m, K, n_d, As.nnz, B_host.dtype.itemsize)
+    res["spmm_cfg2_skewed"] = {
+        "ms": round(t * 1e3, 4), "GFLOP/s": round(2.0 * As.nnz * n_d / t / 1e9, 1), "kernel": kname, "nnz": As.nnz,
+        "row_lengths": {"mean": round(As.nnz / m, 2), "max": int((ps[1:] - ps[:-1]).max()), "empty_rows": int((ps[1:] == ps[:-1]).sum())},
+        "plan": As.plan_info() if As._plan is not None and As._plan_ready else None,
+        "roofline": roofline(byts, k_s, kernel_avg_ms=round(k_s * 1e3, 4), call_frac=round(byts / t / 1e9 / HBM_PEAK_GBS, 4)),
+        "row_wave_kernel_ms": round(t_rw * 1e3, 4),
+        "parity_max_err_over_max_abs_vs_oracle": err,
+        "note": "cfg2's shape with log-normal row lengths (sigma 1, mean 32, synth.csr_skewed_fast): octets whose bundles are "
+                "uneven take the plan's dealt layout; plan kept on the DeviceCSR as for `value`; roofline.frac is kernel-level"}
+    del As, Cs, ps, js, xs
+
+    # ---- the one workload the reference publishes a number for (vignette Rmd:247-251): dense 100 x 1e4 %*% CSC 1e4 x 1e4,
+    # density 0.05 -> matmul_dense_csc_numeric (matmul.cpp:188-235: gemm_csr_drm_as_drm with the CSC read as CSR of its transpose)
+    from matrixextra_amd import exports as G
+    mv, Kv, nv = 10_000, 10_000, 100
+    pv_, jv_, xv_ = synth.csr_fixed(mv, Kv, 500, seed=7)               # 5e6 entries: density 0.05 (columns of the CSC)
+    Xd = np.asfortranarray(synth.dense_normal(nv, Kv, seed=8))         # Y_dense, column-major 100 x 1e4
+    outv = G.matmul_dense_csc_numeric(Xd, pv_, jv_, xv_, 1)
+    refv = O.matmul_dense_csc(Xd, pv_, jv_, xv_, threads, True)
+    errv = float(np.max(np.abs(outv - refv)) / np.max(np.abs(refv)))
+    assert errv <= 1e-12, f"dense x CSC differs from the oracle: {errv}"
+    te = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        G.matmul_dense_csc_numeric(Xd, pv_, jv_, xv_, 1)
+        te.append(time.perf_counter() - t0)
+    Av = D.DeviceCSR.from_host(pv_, jv_, xv_, Kv)
+    Bv = torch.from_numpy(np.ascontiguousarray(Xd.T)).cuda()          # K x n row-major = X column-major
+    algos = {}
+    for name, kw in (("auto", dict(algo=0)), ("row_wave", dict(algo=1)), ("slab", dict(algo=2))):
+        D.spmm(Av, Bv, colmajor=False, **kw)
+        kn = lib.mxd_spmm_last_kernel().decode()
+        algos[name] = {"ms": round(timeit(lambda: D.spmm(Av, Bv, colmajor=False, **kw), reps=20) * 1e3, 4), "kernel": kn}
+    tpl = timeit(lambda: D.spmm_planned(Av, Bv, colmajor=False), reps=20)
+    algos["planned_kept_plan"] = {"ms": round(tpl * 1e3, 4), "kernel": "spmm_plan_kernel"}
+    tdev = algos["auto"]["ms"] / 1e3
+    bytv = synth.spmm_algorithmic_bytes(mv, Kv, nv, Av.nnz, 8)
+    ev = {"device_ms": algos["auto"]["ms"], "export_ms_median": round(float(np.median(te[2:])) * 1e3, 3),
+          "GFLOP/s_device": round(2.0 * Av.nnz * nv / tdev / 1e9, 1),
+          "GFLOP/s_export": round(2.0 * Av.nnz * nv / float(np.median(te[2:])) / 1e9, 1),
+          "kernels_ms": algos, "roofline": roofline(bytv, tdev),
+          "parity_max_err_over_max_abs_vs_oracle": errv,
+          "reference_published": {"ms": 72.74, "GFLOP/s": 13.7, "hardware": "unstated",
+                                  "source": "inst/doc/Introducing_MatrixExtra.html:668 (vignette Rmd:247-251) — context only"}}
+    if want_cpu:
+        tc = cpu_time(lambda: O.matmul_dense_csc(Xd, pv_, jv_, xv_, threads, False), 3)
+        tc1 = cpu_time(lambda: O.matmul_dense_csc(Xd, pv_, jv_, xv_, 1, False), 2)
+        ev["cpu_baseline"] = {"value": round(2.0 * Av.nnz * nv / tc / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+                              "ms": round(tc * 1e3, 2),
+                              "single_thread": {"value": round(2.0 * Av.nnz * nv / tc1 / 1e9, 3), "ms": round(tc1 * 1e3, 2), "cores": 1},
+                              "sample": "the whole product, matmul_dense_csc restated (gemm_csr_drm_as_drm, OpenMP dynamic), best of 3"}
+    res["vignette_dense_csc"] = ev
+    del Av, Bv
+
+    # ---- the vignette's usage loop through the export level (tools/vignette_loop.py; 60 iterations here, 200 in the GPU test)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import vignette_loop
+    res["vignette_lbfgs_loop"] = vignette_loop.run(iters=60)
     return res
 
 
@@ -668,8 +754,27 @@ def main():
     from matrixextra_amd import _lib, device as D, synth
     lib = _lib.load()                      # fails loudly if libmxgpu.so is missing
 
+    if args.config == "cfg5-full":
+        # BASELINE configs[4] WHOLE on this one GPU, through the export-level boundary (tools/cfg5_full.py: sharded over the
+        # device listed 8 times, unsharded cold / cached, and one device-level launch; parity checks inside)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import cfg5_full
+        stream = stream_copy_probe(torch, lib, _lib)
+        r = cfg5_full.run(verbose=True)
+        dl = r["device_level"]
+        dl["roofline"]["frac_of_stream_copy"] = round(dl["roofline"]["achieved"] / stream["GBps"], 4)
+        print(json.dumps({
+            "metric": "CSR x dense SpMM GFLOP/s (fp32 dense / f64 CSR values, 8M x 200k, 64 nnz/row, k=256, whole matrix on one GPU) "
+                      "+ achieved HBM BW% vs CPU ref",
+            "value": dl["GFLOP/s"], "unit": "GFLOP/s", "n_gpus": 1, "steps": 5, "warmup": 2, "ms_per_step": dl["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "dgRMatrix 8000000x200000 nnz/row=64 (CSR values f64) %*% dense 200000x256 f32 (BASELINE "
+                                   "configs[4], the whole matrix on ONE MI355X); C col-major", "parallelism": "single"},
+            "roofline": dl["roofline"], "stream_copy": stream, "cfg5_full": r, "device": _lib.device_name()}), flush=True)
+        return
     cfg = dict(name=args.config, rows=args.rows, cols=args.cols, nnz_row=args.nnz_row, n=args.n, dtype=args.dtype,
                label=WORKLOADS[args.config]["label"] if not args.custom else "custom shape")
+    stream = stream_copy_probe(torch, lib, _lib) if world == 1 or rank == 0 else None
     want_cpu = world == 1 and not FORCE_DIST and not args.no_cpu_baseline
     r = spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, args.steps, args.warmup, want_cpu, True)
     out = None
@@ -687,6 +792,7 @@ def main():
             "config": dict(workload=r.pop("workload"), parallelism=f"rowshard{world}" if world > 1 else "single",
                            **r.pop("dims")),
             "roofline": r.pop("roofline"),
+            "stream_copy": stream,
         }
         cpu = r.pop("cpu_baseline", None)
         out.update(r)

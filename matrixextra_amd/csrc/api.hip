@@ -1212,26 +1212,38 @@ int mx_copy_csr_rows_begin(const int32_t *indptr, int nrows, const int32_t *indi
     do {
         Csr A;
         if ((rc = A.upload(indptr, indices, values, nrows, vb))) break;
-        DevBuf rows, ws;
+        DevBuf rows;
         if ((rc = rows.upload(rows_take, sizeof(int32_t) * (size_t)n_take))) break;
-        if ((rc = ws.alloc(mxd_gather_workspace_bytes((int)n_take)))) break;
         if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)n_take + 1)))) break;
+        // ONE launch into arrays sized for 1.25x the expected result (n_take mean row lengths); a selection that does not fit
+        // (very uneven rows) is copied again into exactly sized arrays — new_indptr is exact either way
+        const double avg = nrows > 0 ? (double)A.nnz / (double)nrows : 0.0;
+        const int64_t cap = std::min<int64_t>((int64_t)(1.25 * avg * (double)n_take) + 1024, (int64_t)INT_MAX);
+        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)cap))) break;
+        if (has_values && (rc = res->values.alloc(vb * (size_t)cap))) break;
         int64_t nnz_out = 0;
-        if ((rc = mxd_csr_gather_count((int)n_take, A.p.as<int32_t>(), rows.as<int32_t>(), res->indptr.as<int32_t>(),
-                                       ws.p, &nnz_out, nullptr)))
+        if ((rc = mxd_csr_gather_fused((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, rows.as<int32_t>(),
+                                       res->indptr.as<int32_t>(), res->indices.as<int32_t>(), res->values.p,
+                                       has_values ? value_dtype : MX_NONE, cap, avg, nullptr, &nnz_out, nullptr)))
             break;
         if (nnz_out == 0) {          // slice.cpp:236-240: three EMPTY vectors (even the indptr)
+            if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
             res->info.indptr_len = 0;
             res->info.nnz = 0;
             res->info.values_len = 0;
             break;
         }
-        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
-        if (has_values && (rc = res->values.alloc(vb * (size_t)nnz_out))) break;
-        if ((rc = mxd_csr_gather_fill((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, rows.as<int32_t>(),
-                                      res->indptr.as<int32_t>(), res->indices.as<int32_t>(), res->values.p,
-                                      has_values ? value_dtype : MX_NONE, nnz_out, nullptr)))
-            break;
+        if (nnz_out > cap) {
+            if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
+            (void)hipFree(res->indices.p); res->indices.p = nullptr;
+            if (res->values.p) { (void)hipFree(res->values.p); res->values.p = nullptr; }
+            if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
+            if (has_values && (rc = res->values.alloc(vb * (size_t)nnz_out))) break;
+            if ((rc = mxd_csr_gather_fill((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, rows.as<int32_t>(),
+                                          res->indptr.as<int32_t>(), res->indices.as<int32_t>(), res->values.p,
+                                          has_values ? value_dtype : MX_NONE, nnz_out, nullptr)))
+                break;
+        }
         if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
         res->info.indptr_len = n_take + 1;
         res->info.nnz = nnz_out;

@@ -127,29 +127,34 @@ static int launch_gather_copy(int G, int r, const int32_t *indptr, const int32_t
 }
 
 // The whole gather in ONE launch (round 3): a workgroup sizes a tile of GF_TILE output rows, scans their lengths, finds
-// its place in the output with the decoupled look-back (as gather_count_kernel) and copies its rows — into arrays that
-// the caller sized for an ESTIMATE of the result (`capacity` entries).  new_indptr and the total are always complete
-// and exact; rows that would end beyond `capacity` are not copied, the caller sees total > capacity and runs
-// gather_copy_kernel into exactly sized arrays instead.  What this removes from a call: the second launch, and the host
-// round trip for nnz_out BETWEEN the two launches (the size is read back once, behind all the work).
-// Copy: G lanes per row, GF_ROWS rows per group and trip with all their loads in flight before the first store.
+// its place in the output with a decoupled look-back and copies its rows — into arrays that the caller sized for an
+// ESTIMATE of the result (`capacity` entries).  new_indptr and the total are always complete and exact; rows that would end
+// beyond `capacity` are not copied, the caller sees total > capacity and runs gather_copy_kernel into exactly sized
+// arrays instead.  What this removes from a call, measured at cfg3 (two launches: 64 us per call, 43 us of kernels):
+//   * the second launch and the host round trip for nnz_out BETWEEN the launches;
+//   * the state memset: the look-back words carry a generation (lookback_exclusive_gen) and the ticket counter runs on
+//     from launch to launch, so the library's state array is never cleared;
+//   * the wait for the size: the workgroup of the LAST tile stores the total straight into pinned host memory as soon as
+//     its look-back is through — the host has it while the copies are still running and returns (the copy completes in
+//     stream order, like every device-level call).
+// Copy: G lanes per row, GF_ROWS rows per group and trip with all their loads in flight before the first store; the
+// first trip's loads are issued BEFORE the look-back (they need no output position), so its latency hides the wait.
 constexpr int GF_TILE = GATHER_BLOCK;
-constexpr int GF_ROWS = 4;
+constexpr int GF_ROWS = 8;
 template <int G, typename VT, bool HAS_VALUES>
 __global__ __launch_bounds__(GATHER_BLOCK)
 void gather_fused_kernel(int r, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                          const VT *__restrict__ values, const int32_t *__restrict__ rows,
                          int32_t *__restrict__ new_indptr, int32_t *__restrict__ new_indices, VT *__restrict__ new_values,
                          long long capacity, unsigned long long *__restrict__ tile_state, unsigned *__restrict__ ticket,
-                         long long *__restrict__ total_out, int ntiles)
+                         unsigned ticket_base, unsigned gen, long long *__restrict__ total_out,
+                         unsigned long long *__restrict__ host_word, int ntiles)
 {
     __shared__ int s_tile;
     __shared__ long long s_base;
-    __shared__ int wave_tot[GATHER_BLOCK / 64];
-    __shared__ int src_l[GF_TILE], len_l[GF_TILE];
-    __shared__ long long dst_l[GF_TILE];
+    __shared__ int src_l[GF_TILE], len_l[GF_TILE], off_l[GF_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);
+    if (tid == 0) s_tile = (int)(atomicAdd(ticket, 1u) - ticket_base);
     __syncthreads();
     const int tile = s_tile;
     const long long i = (long long)tile * GF_TILE + tid;
@@ -159,50 +164,76 @@ void gather_fused_kernel(int r, const int32_t *__restrict__ indptr, const int32_
         src = indptr[row];
         len = indptr[row + 1] - src;
     }
-    int incl = len;
+    long long incl = len;                                             // (a tile of 256 rows can hold more than 2^31 entries)
 #pragma unroll
-    for (int o2 = 1; o2 < 64; o2 <<= 1) { const int up = __shfl_up(incl, o2, 64); if (lane >= o2) incl += up; }
-    if (lane == 63) wave_tot[wave] = incl;
+    for (int o2 = 1; o2 < 64; o2 <<= 1) { const long long up = __shfl_up(incl, o2, 64); if (lane >= o2) incl += up; }
+    __shared__ long long wave_tot64[GATHER_BLOCK / 64];
+    if (lane == 63) wave_tot64[wave] = incl;
+    src_l[tid] = src;
+    len_l[tid] = len;
     __syncthreads();
-    int wbase = 0, tile_total = 0;
+    long long wbase = 0, tile_total = 0;
 #pragma unroll
-    for (int w = 0; w < GATHER_BLOCK / 64; w++) { wbase += w < wave ? wave_tot[w] : 0; tile_total += wave_tot[w]; }
+    for (int w = 0; w < GATHER_BLOCK / 64; w++) { wbase += w < wave ? wave_tot64[w] : 0; tile_total += wave_tot64[w]; }
+    const long long my_off = wbase + incl - len;                      // my row's offset inside the tile
+    // the first trip's source loads: issued now, consumed behind the look-back
+    constexpr int NG = GATHER_BLOCK / G;                              // lane groups per workgroup
+    const int lg = tid % G, grp = tid / G;
+    int s[GF_ROWS], n[GF_ROWS], jv[GF_ROWS];
+    VT xv[GF_ROWS];
+    auto rows_of = [&](int r0) {
+#pragma unroll
+        for (int q = 0; q < GF_ROWS; q++) { s[q] = src_l[r0 + q]; n[q] = len_l[r0 + q]; }
+    };
+    auto load_at = [&](int k) {
+#pragma unroll
+        for (int q = 0; q < GF_ROWS; q++) {
+            jv[q] = 0; xv[q] = VT();
+            if (k < n[q]) {
+                jv[q] = indices[s[q] + k];
+                if constexpr (HAS_VALUES) xv[q] = values[s[q] + k];
+            }
+        }
+    };
+    if (grp * GF_ROWS < GF_TILE) {                                    // (G = 4: more lane groups than trips)
+        rows_of(grp * GF_ROWS);
+        load_at(lg);
+    }
     if (wave == 0) {
-        const long long excl = lookback_exclusive<4>(tile_state, tile, tile_total);
+        const long long excl = lookback_exclusive_gen<4>(tile_state, tile, tile_total, gen);
         if (lane == 0) {
             s_base = excl;
             if (tile == ntiles - 1) {
-                *total_out = excl + tile_total;
-                new_indptr[r] = excl + tile_total <= (long long)INT_MAX ? (int32_t)(excl + tile_total) : INT_MAX;
+                const long long total = excl + tile_total;
+                *total_out = total;
+                new_indptr[r] = total <= (long long)INT_MAX ? (int32_t)total : INT_MAX;
+                if (host_word)                                        // the size, straight to the waiting host
+                    __hip_atomic_store(host_word, lbg_pack(0, gen, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
     __syncthreads();
-    const long long dst = s_base + wbase + incl - len;
-    if (i < r) new_indptr[i] = dst <= (long long)INT_MAX ? (int32_t)dst : INT_MAX;
-    src_l[tid] = src;
-    len_l[tid] = dst + len <= capacity ? len : 0;                      // beyond the caller's arrays: not copied
-    dst_l[tid] = dst;
+    const long long base = s_base;
+    {
+        const long long dst = base + my_off;
+        if (i < r) new_indptr[i] = dst <= (long long)INT_MAX ? (int32_t)dst : INT_MAX;
+        // rows that end beyond the caller's arrays are not copied; offsets inside a tile fit int32 whenever they matter
+        off_l[tid] = dst + len <= capacity ? (int)my_off : -1;
+    }
     __syncthreads();
-    constexpr int NG = GATHER_BLOCK / G;                              // lane groups per workgroup
-    const int lg = tid % G, grp = tid / G;
     for (int r0 = grp * GF_ROWS; r0 < GF_TILE; r0 += NG * GF_ROWS) {
-        int s[GF_ROWS], n[GF_ROWS];
+        if (r0 != grp * GF_ROWS) rows_of(r0);
         long long d[GF_ROWS];
         int maxn = 0;
 #pragma unroll
-        for (int q = 0; q < GF_ROWS; q++) { s[q] = src_l[r0 + q]; n[q] = len_l[r0 + q]; d[q] = dst_l[r0 + q]; maxn = max(maxn, n[q]); }
-        for (int k = lg; k < maxn; k += G) {                          // (uniform per group: all four rows advance together)
-            int jv[GF_ROWS];
-            VT xv[GF_ROWS];
-#pragma unroll
-            for (int q = 0; q < GF_ROWS; q++) {
-                jv[q] = 0; xv[q] = VT();
-                if (k < n[q]) {
-                    jv[q] = indices[s[q] + k];
-                    if constexpr (HAS_VALUES) xv[q] = values[s[q] + k];
-                }
-            }
+        for (int q = 0; q < GF_ROWS; q++) {
+            const int o = off_l[r0 + q];
+            if (o < 0) n[q] = 0;
+            d[q] = base + o;
+            maxn = max(maxn, n[q]);
+        }
+        for (int k = lg; k < maxn; k += G) {                          // (uniform per group: all rows of the trip advance together)
+            if (r0 != grp * GF_ROWS || k != lg) load_at(k);
 #pragma unroll
             for (int q = 0; q < GF_ROWS; q++) {
                 if (k < n[q]) {
@@ -217,20 +248,54 @@ void gather_fused_kernel(int r, const int32_t *__restrict__ indptr, const int32_
 template <typename VT, bool HAS_VALUES>
 static int launch_gather_fused(int G, int r, const int32_t *indptr, const int32_t *indices, const void *values,
                                const int32_t *rows, int32_t *new_indptr, int32_t *new_indices, void *new_values,
-                               long long capacity, void *workspace, int ntiles, hipStream_t st)
+                               long long capacity, unsigned long long *state, unsigned *ticket, unsigned ticket_base, unsigned gen,
+                               long long *total_dev, unsigned long long *host_word, int ntiles, hipStream_t st)
 {
 #define MX_CASE(GG)                                                                                                   \
     case GG:                                                                                                          \
         hipLaunchKernelGGL((gather_fused_kernel<GG, VT, HAS_VALUES>), dim3((unsigned)ntiles), dim3(GATHER_BLOCK), 0, st, r,   \
                            indptr, indices, (const VT *)values, rows, new_indptr, new_indices, (VT *)new_values, capacity,    \
-                           (unsigned long long *)((char *)workspace + 16), (unsigned *)((char *)workspace + 8),       \
-                           (long long *)workspace, ntiles);                                                           \
+                           state, ticket, ticket_base, gen, total_dev, host_word, ntiles);                            \
         break;
     switch (G) { MX_CASE(4) MX_CASE(8) MX_CASE(16) MX_CASE(32) MX_CASE(64)
                  default: return set_error("gather: bad group %d", G); }
 #undef MX_CASE
     MX_LAUNCH_CHECK();
     return 0;
+}
+
+// The fused gather's state, per thread and device (one stream per thread and device at a time, like AUTO's plan): the
+// look-back words + ticket counter + total in device memory (zeroed when allocated, never cleared afterwards), one pinned
+// host word the last tile's workgroup stores the total into, and the launch counters that make the generation / ticket base.
+struct GatherState {
+    char *dev = nullptr;                     // [int64 total][uint32 ticket][pad][uint64 tile_state[cap_tiles]]
+    size_t cap_tiles = 0;
+    unsigned ticket_base = 0, gen = 0;
+    unsigned long long *host_word = nullptr;
+};
+static GatherState *gather_state(int ntiles, hipStream_t st)
+{
+    static thread_local GatherState gs[16];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) d = 0;
+    GatherState &g = gs[d];
+    if (!g.host_word) {
+        if (hipHostMalloc((void **)&g.host_word, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError();
+            g.host_word = nullptr;
+            return nullptr;
+        }
+        *g.host_word = 0;
+    }
+    if (g.cap_tiles < (size_t)ntiles) {
+        if (g.dev) { (void)hipStreamSynchronize(st); (void)hipFree(g.dev); g.dev = nullptr; g.cap_tiles = 0; }
+        const size_t want = (size_t)ntiles + (size_t)ntiles / 2 + 1024;
+        if (hipMalloc((void **)&g.dev, 16 + want * 8) != hipSuccess) { (void)hipGetLastError(); g.dev = nullptr; return nullptr; }
+        if (hipMemsetAsync(g.dev, 0, 16 + want * 8, st) != hipSuccess) return nullptr;
+        g.cap_tiles = want;
+        g.ticket_base = 0;                                            // a fresh ticket counter; generations run on
+    }
+    return &g;
 }
 
 // ---- check_is_seq / check_is_rev_seq ---------------------------------------------------------
@@ -529,32 +594,56 @@ extern "C" int mxd_csr_gather_fused(int r, const int32_t *indptr, const int32_t 
                                     int value_dtype, int64_t capacity, double avg_row_len, void *workspace,
                                     int64_t *nnz_out_host, void *stream)
 {
+    (void)workspace;                                                 // (kept in the signature; the state lives in the library)
     MX_REQUIRE(r >= 0 && capacity >= 0, "mxd_csr_gather_fused: negative size");
-    MX_REQUIRE(new_indptr && workspace && nnz_out_host, "mxd_csr_gather_fused: null pointer");
+    MX_REQUIRE(new_indptr && nnz_out_host, "mxd_csr_gather_fused: null pointer");
     hipStream_t st = mx::as_stream(stream);
-    int64_t *total_dev = (int64_t *)workspace;
     if (r == 0) {
         MX_HIP(hipMemsetAsync(new_indptr, 0, sizeof(int32_t), st));
         *nnz_out_host = 0;
         return 0;
     }
-    // workspace: [int64 total][uint32 ticket, pad][uint64 tile_state[ntiles]]  (fits mxd_gather_workspace_bytes(r): >= 4 r bytes)
     const int ntiles = (int)mx::ceil_div(r, mx::GF_TILE);
-    MX_HIP(hipMemsetAsync(workspace, 0, 16 + (size_t)ntiles * 8, st));
+    mx::GatherState *g = mx::gather_state(ntiles, st);
+    MX_REQUIRE(g, "mxd_csr_gather_fused: cannot allocate the look-back state");
+    g->gen = (g->gen + 1) & 0x3FFFFFFFu;
+    if (g->gen == 0) g->gen = 1;
+    const unsigned gen = g->gen, ticket_base = g->ticket_base;
+    long long *total_dev = (long long *)g->dev;
+    unsigned *ticket = (unsigned *)(g->dev + 8);
+    unsigned long long *state = (unsigned long long *)(g->dev + 16);
     const int G = mx::pick_group(avg_row_len > 0 ? avg_row_len : 32.0);
     int rc;
     switch (value_dtype) {
         case MX_F64: rc = mx::launch_gather_fused<double, true>(G, r, indptr, indices, values, rows_take, new_indptr, new_indices,
-                                                                new_values, capacity, workspace, ntiles, st); break;
+                                                                new_values, capacity, state, ticket, ticket_base, gen, total_dev,
+                                                                g->host_word, ntiles, st); break;
         case MX_LGL: rc = mx::launch_gather_fused<int32_t, true>(G, r, indptr, indices, values, rows_take, new_indptr, new_indices,
-                                                                 new_values, capacity, workspace, ntiles, st); break;
+                                                                 new_values, capacity, state, ticket, ticket_base, gen, total_dev,
+                                                                 g->host_word, ntiles, st); break;
         case MX_NONE: rc = mx::launch_gather_fused<int32_t, false>(G, r, indptr, indices, nullptr, rows_take, new_indptr,
-                                                                   new_indices, nullptr, capacity, workspace, ntiles, st); break;
+                                                                   new_indices, nullptr, capacity, state, ticket, ticket_base, gen,
+                                                                   total_dev, g->host_word, ntiles, st); break;
         default: return mx::set_error("mxd_csr_gather_fused: unsupported value dtype %d", value_dtype);
     }
     if (rc) return rc;
-    if (mx::read_back_small(nnz_out_host, total_dev, sizeof(int64_t), st)) return 1;
-    MX_REQUIRE(*nnz_out_host <= (int64_t)INT_MAX, "result has %lld entries: exceeds R's int32 index range", (long long)*nnz_out_host);
+    g->ticket_base = ticket_base + (unsigned)ntiles;                  // (the launch was accepted: its tiles will take their tickets)
+    // the size arrives in the pinned word while the copies still run: a short spin, then the ordinary wait for the stream
+    volatile unsigned long long *hw = g->host_word;
+    unsigned long long w = 0;
+    bool got = false;
+    for (int spin = 0; spin < 200000; spin++) {
+        w = *hw;
+        if (((w >> 32) & 0x3FFFFFFFu) == gen) { got = true; break; }
+    }
+    if (!got) {
+        MX_HIP(hipStreamSynchronize(st));
+        w = *hw;
+        MX_REQUIRE(((w >> 32) & 0x3FFFFFFFu) == gen, "mxd_csr_gather_fused: the kernel did not report its size");
+    }
+    const unsigned long long total = w & mx::LBG_VALUE;
+    MX_REQUIRE(total <= (unsigned long long)INT_MAX, "result has %llu or more entries: exceeds R's int32 index range", total);
+    *nnz_out_host = (int64_t)total;
     return 0;
 }
 

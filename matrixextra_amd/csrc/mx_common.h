@@ -154,6 +154,65 @@ __device__ __forceinline__ long long lookback_exclusive(unsigned long long *__re
     return excl;
 }
 
+// The same look-back over state words that carry a GENERATION: [63:62] flag, [61:32] generation (30 bits), [31:0] value
+// (saturating at 2^32 - 1).  A word of another generation reads as "not published yet", so the array is never cleared
+// between launches — the caller passes a generation it has not used on this array for the last 2^30 launches (the array
+// starts zeroed; generation 0 is never used).  Values are per-tile entry counts: results beyond R's int32 range saturate
+// and are reported as "too many" by the caller.
+constexpr unsigned long long LBG_VALUE = 0xFFFFFFFFULL;
+__device__ __forceinline__ unsigned long long lbg_pack(unsigned flag, unsigned gen, long long v)
+{
+    const unsigned long long sat = v > (long long)LBG_VALUE ? LBG_VALUE : (unsigned long long)v;
+    return ((unsigned long long)flag << 62) | ((unsigned long long)(gen & 0x3FFFFFFFu) << 32) | sat;
+}
+template <int LOOK>
+__device__ __forceinline__ long long lookback_exclusive_gen(unsigned long long *__restrict__ tile_state, int tile, long long tile_total,
+                                                            unsigned gen)
+{
+    const int lane = lane_id();
+    long long excl = 0;
+    if (tile == 0) {
+        if (lane == 0) __hip_atomic_store(&tile_state[0], lbg_pack(2, gen, tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&tile_state[tile], lbg_pack(1, gen, tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int look = tile - 1;
+    for (;;) {
+        unsigned long long st[LOOK];
+#pragma unroll
+        for (int u = 0; u < LOOK; u++) {
+            const int t = look - 64 * u - lane;
+            st[u] = lbg_pack(2, gen, 0);                              // before tile 0: an empty prefix
+            if (t >= 0) {
+                st[u] = __hip_atomic_load(&tile_state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (((st[u] >> 32) & 0x3FFFFFFFu) != (gen & 0x3FFFFFFFu)) st[u] = 0;   // another launch's word
+            }
+        }
+        bool done = false, stalled = false;
+#pragma unroll
+        for (int u = 0; u < LOOK; u++) {
+            if (done || stalled) continue;                            // uniform
+            const unsigned long long empty = __ballot((st[u] >> 62) == 0);
+            const unsigned long long pre = __ballot((st[u] >> 62) == 2);
+            const int first_empty = empty ? __builtin_ctzll(empty) : 64;
+            const int first_pre = pre ? __builtin_ctzll(pre) : 64;
+            const int upto = first_pre < first_empty ? first_pre + 1 : first_empty;
+            long long v = lane < upto ? (long long)(st[u] & LBG_VALUE) : 0;
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2, 64);
+            excl += v;
+            look -= upto;
+            if (first_pre < first_empty) done = true;
+            else if (upto < 64) stalled = true;
+        }
+        if (done) break;
+        if (stalled) __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane == 0)
+        __hip_atomic_store(&tile_state[tile], lbg_pack(2, gen, excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
 // first position in [first, first+count) whose value is >= key
 __device__ __forceinline__ int lower_bound_dev(const int32_t *__restrict__ first, int count, int key)
 {

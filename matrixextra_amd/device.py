@@ -266,8 +266,6 @@ def csr_gather_rows(A: DeviceCSR, rows: torch.Tensor, one_launch: bool = True):
     lib = _lib.load()
     dev = A.indptr.device
     r = int(rows.numel())
-    ws = torch.empty(lib.mxd_gather_workspace_bytes(r), dtype=torch.uint8, device=dev)
-    new_p = torch.empty(r + 1, dtype=torch.int32, device=dev)
     nnz_out = C.c_int64(0)
     if A.values is None:
         vd, vdt = MX_NONE, None
@@ -276,17 +274,24 @@ def csr_gather_rows(A: DeviceCSR, rows: torch.Tensor, one_launch: bool = True):
     counted = False
     if one_launch and A.m > 0 and r > 0:
         avg = A.nnz / A.m
-        cap = min(int(1.25 * r * avg) + 1024, 2 ** 31 - 1)
-        new_j = torch.empty(cap, dtype=torch.int32, device=dev)
-        new_x = None if vdt is None else torch.empty(cap, dtype=vdt, device=dev)
+        cap = min(int(1.25 * r * avg) + 1024, 2 ** 31 - 1) & ~3
+        # one allocation for the three result arrays (values first: 8-byte aligned), no workspace (the look-back state lives
+        # in the library): the call is short enough for every torch.empty to show
+        vb = 0 if vdt is None else (8 if vdt == torch.float64 else 4)
+        buf = torch.empty(cap * (vb + 4) + 4 * (r + 1), dtype=torch.uint8, device=dev)
+        new_x = None if vdt is None else buf[:cap * vb].view(vdt)
+        new_j = buf[cap * vb:cap * (vb + 4)].view(torch.int32)
+        new_p = buf[cap * (vb + 4):].view(torch.int32)
         check(lib.mxd_csr_gather_fused(C.c_int(r), _dp(A.indptr), _dp(A.indices), _dp(A.values), _dp(rows), _dp(new_p),
-                                       _dp(new_j), _dp(new_x), C.c_int(vd), C.c_int64(cap), C.c_double(avg), _dp(ws),
+                                       _dp(new_j), _dp(new_x), C.c_int(vd), C.c_int64(cap), C.c_double(avg), None,
                                        C.byref(nnz_out), _stream()))
         n = int(nnz_out.value)
         if n <= cap:
             return DeviceCSR(new_p, new_j[:n], None if new_x is None else new_x[:n], r, A.K, n)
         counted = True                                               # new_p is complete; only the copy has to be redone
     if not counted:
+        ws = torch.empty(lib.mxd_gather_workspace_bytes(r), dtype=torch.uint8, device=dev)
+        new_p = torch.empty(r + 1, dtype=torch.int32, device=dev)
         check(lib.mxd_csr_gather_count(C.c_int(r), _dp(A.indptr), _dp(rows), _dp(new_p), _dp(ws),
                                        C.byref(nnz_out), _stream()))
     new_j = torch.empty(nnz_out.value, dtype=torch.int32, device=dev)

@@ -75,6 +75,7 @@ def run(iters=200, m=72_309, K=20_958, mean_nnz=51, planned=True, check_iters=3,
     tp, tj, tx = Xt["indptr"], Xt["indices"], Xt["values"]
     yt = y[ix]
     mt = tp.size - 1
+    short_rows = (tp[1:] - tp[:-1]) <= 256
     res["train"] = {"rows": mt, "cols": Kc, "nnz": int(tp[-1])}
 
     lam, step = 1e-5, 2.0
@@ -101,7 +102,10 @@ def run(iters=200, m=72_309, K=20_958, mean_nnz=51, planned=True, check_iters=3,
                 if planned and it > 0:
                     worst_mv = max(worst_mv, float(np.max(np.abs(z - zo)) / max(np.max(np.abs(zo)), 1e-300)))
                 else:
-                    assert np.array_equal(z, zo), "SpMV (flat kernel) differs from the oracle's loop"
+                    # flat kernel: bit for bit the oracle's loop for rows of up to 256 entries (one thread adds them in
+                    # storage order); longer rows are summed by a wavefront (reassociated)
+                    assert np.array_equal(z[short_rows], zo[short_rows]), "SpMV (flat kernel) differs from the oracle's loop"
+                    np.testing.assert_allclose(z, zo, rtol=1e-12, atol=1e-12 * max(float(np.max(np.abs(zo))), 1e-300))
                 gvo = O.multiply_csr_by_dvec_no_NAs_numeric(tp, tj, tx, d, Kc, True, False, False, False, False, True)
                 assert np.array_equal(gv, gvo), "CSR * vector differs from the oracle"
             w = w - step * grad
@@ -125,7 +129,7 @@ def run(iters=200, m=72_309, K=20_958, mean_nnz=51, planned=True, check_iters=3,
         "csr_times_vector_ms": {"first": round(t_mul[0] * 1e3, 3), "median": round(float(np.median(t_mul[2:])) * 1e3, 3),
                                 "min": round(min(t_mul) * 1e3, 3)},
         "loop_s": round(sum(t_mv) + sum(t_mul), 4),
-        "parity": {"spmv_first_call": "bitwise (flat kernel)", "spmv_planned_max_rel_err": worst_mv,
+        "parity": {"spmv_first_call": "bitwise for rows of <= 256 entries, 1e-12 beyond (flat kernel)", "spmv_planned_max_rel_err": worst_mv,
                    "csr_times_vector": "bitwise", "final_coefficients_max_rel_err_vs_oracle_loop": coef_err},
         "reference_published": "4.01 s for the vignette's optim() run, hardware unstated (html:829) — context only"})
     assert coef_err <= 1e-9, f"coefficients after {iters} steps differ from the oracle loop: {coef_err}"

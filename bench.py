@@ -605,14 +605,21 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
                 out_[k] = v
         return out_
     _, q = call()                                  # first call of the process: allocates the library's grow-only device scratch
-    cold, cached, ph_cold, ph_cached = [], [], [], []
-    for k in range(10):
+    cold, cached, ph_cold, ph_cached, cold_rows = [], [], [], [], []
+    for k in range(13):
         libc.free(q)                              # (freeing the previous 1 GB result is not part of the next call)
-        if k < 5:
+        if k < 8:
             lib.mx_cache_invalidate(None)         # CSR not on the device: upload + compute + download
+        if 5 <= k < 8:                            # the other cold form (row blocks, whole result touched first), same process
+            os.environ["MXGPU_EXPORT_COLD_COLS"] = "0"
         t, q = call()
-        (cold if k < 5 else cached).append(t)
-        (ph_cold if k < 5 else ph_cached).append(phases())
+        os.environ.pop("MXGPU_EXPORT_COLD_COLS", None)
+        if k < 5:
+            cold.append(t); ph_cold.append(phases())
+        elif k < 8:
+            cold_rows.append(t)
+        else:
+            cached.append(t); ph_cached.append(phases())
     out = np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_double if f64 else C.c_float)), shape=(n_, m_)).T   # view; freed below
     n = out.shape[1]
     ref = np.zeros(2048 * n, dtype=B_host.dtype)
@@ -632,6 +639,7 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
     res["export_call_end_to_end"] = {
         "ms_cold": round(med(cold) * 1e3, 2), "ms_csr_cached": round(med(cached) * 1e3, 2),
         "ms_cold_all": [round(v * 1e3, 2) for v in cold], "ms_csr_cached_all": [round(v * 1e3, 2) for v in cached],
+        "ms_cold_row_block_form": [round(v * 1e3, 2) for v in cold_rows],
         "phases_ms_cold": phase_medians(ph_cold), "phases_ms_csr_cached": phase_medians(ph_cached),
         "csr_state_cached": ph_cached[-1].get("csr"),
         "GFLOP/s_cold": round(2 * nnz * n / med(cold) / 1e9, 1), "GFLOP/s_csr_cached": round(2 * nnz * n / med(cached) / 1e9, 1),

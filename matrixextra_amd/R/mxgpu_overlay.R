@@ -48,6 +48,15 @@
 
 mxgpu_enable <- function(shim_path, min_nnz = 0L) {
     dll <- dyn.load(shim_path)
+    ## options of the backend (include/mxgpu.h, mx_set_option / mx_set_devices), taken from R options at enable time:
+    ##   options(MatrixExtra.mxgpu_spmv_planned = TRUE)   `X %*% v` on a matrix still on the device may use the planned
+    ##                                                    kernel (faster; equal to 1e-12, not bit for bit: see mxgpu.h)
+    ##   options(MatrixExtra.mxgpu_devices = 0:7)         large CSR x dense products sharded by rows over these GPUs
+    if (isTRUE(getOption("MatrixExtra.mxgpu_spmv_planned", FALSE)))
+        .Call(getNativeSymbolInfo("_mxgpu_set_option", dll), "spmv_planned", 1L)
+    devs <- getOption("MatrixExtra.mxgpu_devices", NULL)
+    if (!is.null(devs))
+        .Call(getNativeSymbolInfo("_mxgpu_set_devices", dll), as.integer(devs))
     ns <- asNamespace("MatrixExtra")
     .mxgpu_state$saved <- list()
     for (fn in .mxgpu_hot_routines) {

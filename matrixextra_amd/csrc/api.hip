@@ -715,7 +715,16 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     //   ROWS_STRIDED (column-major C, CSR still on the host): row blocks, so that a block's slice of (indices, values) can
     //        go up while earlier blocks are multiplied and come down (rows of a column-major matrix are strided: the whole
     //        result is first-touched — under the upload — and registered before the first block comes down).
-    enum { ROWS, COLS, ROWS_STRIDED } shape = !colmajor ? ROWS : (A.resident ? COLS : ROWS_STRIDED);
+    // A column-major result whose CSR is still on the host takes COLS too when the upload is the shorter job: row blocks
+    // need ALL pages of the result touched and registered before the first block can come down (~7.75 ms per GB), column
+    // blocks need the whole CSR on the device before the first block can be multiplied (12 bytes per entry at ~55 GB/s).
+    // cfg2: 7.1 ms of upload against 7.9 ms of page preparation -> COLS (cold call 33.8 -> ~27 ms); cfg5 whole: 112 ms
+    // against 63 ms -> ROWS_STRIDED (upload and download overlap).
+    const double est_up_ms = 12.0 * (double)A.nnz / 55e6, est_prep_ms = (double)c_bytes * 7.75 / 1e9;
+    const char *cc_env = getenv("MXGPU_EXPORT_COLD_COLS");          // (read per call: bench.py times both forms in one process)
+    const int cold_cols_on = cc_env ? atoi(cc_env) : 1;
+    const bool cold_cols = colmajor && !A.resident && cold_cols_on && est_up_ms < est_prep_ms && n >= 2 * 8 * (16 / (int)sizeof(real_t));
+    enum { ROWS, COLS, ROWS_STRIDED } shape = !colmajor ? ROWS : (A.resident || cold_cols ? COLS : ROWS_STRIDED);
     constexpr int VEC = 16 / (int)sizeof(real_t);
     const int col_gran = 8 * VEC;                                    // column blocks in whole 128-byte slabs
     int nblk = (int)std::min<size_t>(16, std::max<size_t>(2, c_bytes / ((size_t)96 << 20)));
@@ -729,31 +738,7 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     // the row-wave kernel for cfg2's blocks — each below AUTO's size threshold — and would hand back other last bits cold
     // than cached once cached calls use the matrix's plan).
     const int family = algo == MX_SPMM_AUTO ? mx::spmm_auto_family(m, n, K_rows, dt, dB, ldb, dC, ldc, colmajor ? 1 : 0) : algo;
-    // A matrix that is found on the device again keeps a plan of ALL its rows on its cache entry: built once (here, when
-    // AUTO plans this product), used by every block of this call and by every later call.
     mx_spmm_plan *plan = nullptr;
-    if (A.cache_hit && algo == MX_SPMM_AUTO && family == MX_SPMM_PLANNED) {
-        CsrDev &e = *A.hold;
-        std::lock_guard<std::mutex> lk(e.plan_mu);
-        if (e.spmm_plan && (e.spmm_plan_K != K_rows || e.spmm_plan_panels != npanels)) {
-            mxd_spmm_plan_destroy(e.spmm_plan);
-            e.spmm_plan = nullptr; e.spmm_plan_rejected = false;
-        }
-        if (!e.spmm_plan && !e.spmm_plan_rejected) {
-            int ready = 0;
-            if (mxd_spmm_plan_create_auto(m, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), npanels, L.run,
-                                          &e.spmm_plan, &ready)) {
-                e.spmm_plan = nullptr;                               // (no memory for a plan: the per-block path below)
-            } else if (!ready) {
-                mxd_spmm_plan_destroy(e.spmm_plan);
-                e.spmm_plan = nullptr; e.spmm_plan_rejected = true;
-            }
-            e.spmm_plan_K = K_rows; e.spmm_plan_panels = npanels;
-            tr.mark("plan");
-        }
-        plan = e.spmm_plan;
-    }
-    tr.note("csr", A.cache_hit ? (plan ? "cached+plan" : "cached") : "uploaded");
     if (!A.resident) {
         const bool direct_up = pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz) && pinX.pin(values, sizeof(double) * (size_t)nnz);
         if (!direct_up) { if (A.finish_upload()) return 1; }     // whole arrays through xfer_h2d; the blocks below then only compute
@@ -766,7 +751,13 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
         cut[b] = shape == COLS ? (b == nblk ? n : (int)((int64_t)(n / col_gran) * b / nblk) * col_gran)
                                : (b == nblk ? m : (int)((int64_t)m * b / nblk) & ~1023);
     const bool uploading = !A.resident;
-    if (uploading) {
+    if (uploading && shape == COLS) {                            // the whole CSR in one piece; every block waits for it
+        if (nnz) {
+            MX_HIP(hipMemcpyAsync(A.j.as<int32_t>(), indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, L.up));
+            MX_HIP(hipMemcpyAsync(A.x.as<double>(), values, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, L.up));
+        }
+        MX_HIP(hipEventRecord(L.ev[0], L.up));
+    } else if (uploading) {
         for (int b = 0; b < nblk; b++) {                         // the whole upload is queued up front
             const int64_t e0 = indptr[cut[b]], e1 = indptr[cut[b + 1]];
             if (e1 > e0) {
@@ -795,17 +786,42 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     auto piece_ptr = [&](int b) { return (char *)C_host + hb[b]; };
     auto piece_bytes = [&](int b) { return hb[b + 1] - hb[b]; };
     if (incremental) { mx::prefault_wait(); mx::prefault_begin(piece_ptr(0), piece_bytes(0)); }
+    // A matrix that is found on the device again — or that goes up in one piece — keeps a plan of ALL its rows on its cache
+    // entry: built once (here, when AUTO plans this product), used by every block of this call and by every later call.
+    MX_HIP(hipStreamWaitEvent(L.run, evB, 0));
+    if ((A.cache_hit || shape == COLS) && algo == MX_SPMM_AUTO && family == MX_SPMM_PLANNED) {
+        CsrDev &e = *A.hold;
+        if (uploading) MX_HIP(hipStreamWaitEvent(L.run, L.ev[0], 0));   // (COLS: the one upload; the build then waits for it)
+        std::lock_guard<std::mutex> lk(e.plan_mu);
+        if (e.spmm_plan && (e.spmm_plan_K != K_rows || e.spmm_plan_panels != npanels)) {
+            mxd_spmm_plan_destroy(e.spmm_plan);
+            e.spmm_plan = nullptr; e.spmm_plan_rejected = false;
+        }
+        if (!e.spmm_plan && !e.spmm_plan_rejected) {
+            int ready = 0;
+            if (mxd_spmm_plan_create_auto(m, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), npanels, L.run,
+                                          &e.spmm_plan, &ready)) {
+                e.spmm_plan = nullptr;                               // (no memory for a plan: the per-block path below)
+            } else if (!ready) {
+                mxd_spmm_plan_destroy(e.spmm_plan);
+                e.spmm_plan = nullptr; e.spmm_plan_rejected = true;
+            }
+            e.spmm_plan_K = K_rows; e.spmm_plan_panels = npanels;
+            tr.mark("plan");
+        }
+        plan = e.spmm_plan;
+    }
+    tr.note("csr", A.cache_hit ? (plan ? "cached+plan" : "cached") : (shape == COLS ? "uploaded whole" : "uploaded by row blocks"));
     // ---- One loop over the blocks: block b's product is queued, then its download behind it (first-touch by the host team
     // -> register -> direct DMA).  Queueing a product can hold the host for a moment — a block's own plan is sized on the
     // host, i.e. the call waits until the block's slice of the CSR has arrived — so the downloads are queued block by
     // block too: when they were all queued after the last product, nothing came down before the whole upload had ended
     // (cfg5 whole: 311 ms where upload and download could overlap).
-    MX_HIP(hipStreamWaitEvent(L.run, evB, 0));
     bool direct_down = true, c_ready = false;
     for (int b = 0; b < nblk; b++) {
         const int c0 = cut[b], c1 = cut[b + 1];
         if (c1 > c0) {
-            if (uploading) MX_HIP(hipStreamWaitEvent(L.run, L.ev[b], 0));
+            if (uploading) MX_HIP(hipStreamWaitEvent(L.run, L.ev[shape == COLS ? 0 : b], 0));
             int rc = 0;
             if (shape == COLS) {
                 rc = plan ? mxd_spmm_plan_run_rows(plan, 0, m, c1 - c0, dB + c0, ldb, dC + (size_t)c0 * ldc, ldc, dt, 1, 0, -1, L.run)

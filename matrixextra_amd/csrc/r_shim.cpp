@@ -544,7 +544,26 @@ SEXP _MatrixExtra_sort_sparse_indices_logical_known_ncol(SEXP p_, SEXP j_, SEXP 
 SEXP _MatrixExtra_sort_sparse_indices_binary(SEXP p_, SEXP j_) { return sort_inplace(p_, j_, R_NilValue, MX_NONE); }
 
 #define MX_ENTRY(name, n) {"_MatrixExtra_" #name, (DL_FUNC)&_MatrixExtra_##name, n}
+// ---- control routines of the shim itself (not in MatrixExtra's table; the overlay calls them from mxgpu_enable) -------------
+// .Call("_mxgpu_set_option", "spmv_planned", 1L)  ->  mx_set_option   (include/mxgpu.h: run-time options)
+SEXP _mxgpu_set_option(SEXP name, SEXP value)
+{
+    if (TYPEOF(name) != STRSXP || XLENGTH(name) != 1) Rf_error("mxgpu_set_option: the option's name as one string");
+    if (mx_set_option(R_CHAR(STRING_ELT(name, 0)), (int64_t)Rf_asInteger(value))) fail();
+    return R_NilValue;
+}
+// .Call("_mxgpu_set_devices", c(0L, 1L, ...))  ->  mx_set_devices   (integer(0): the current device, unsharded)
+SEXP _mxgpu_set_devices(SEXP devices)
+{
+    Protect p;
+    devices = as_type(devices, INTSXP, p);
+    if (mx_set_devices(INTEGER(devices), (int)XLENGTH(devices))) fail();
+    return R_NilValue;
+}
+
 static const R_CallMethodDef mxgpu_call_entries[] = {
+    {"_mxgpu_set_option", (DL_FUNC)&_mxgpu_set_option, 2},
+    {"_mxgpu_set_devices", (DL_FUNC)&_mxgpu_set_devices, 1},
     MX_ENTRY(matmul_dense_csc_numeric, 5), MX_ENTRY(matmul_dense_csc_float32, 5),
     MX_ENTRY(tcrossprod_dense_csr_numeric, 6), MX_ENTRY(tcrossprod_dense_csr_float32, 6),
     MX_ENTRY(tcrossprod_csr_dense_numeric, 5), MX_ENTRY(tcrossprod_csr_dense_float32, 5),

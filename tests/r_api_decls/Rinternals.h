@@ -27,6 +27,8 @@ double *REAL(SEXP x);
 SEXP VECTOR_ELT(SEXP x, R_xlen_t i);
 SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v);
 void SET_STRING_ELT(SEXP x, R_xlen_t i, SEXP v);
+SEXP STRING_ELT(SEXP x, R_xlen_t i);
+const char *R_CHAR(SEXP x);
 SEXP Rf_protect(SEXP);
 void Rf_unprotect(int);
 #define PROTECT(s) Rf_protect(s)

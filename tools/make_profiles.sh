@@ -1,0 +1,34 @@
+#!/bin/bash
+# All rocprofv3 summaries of one round, on the GPU box:  bash tools/make_profiles.sh r03
+# Writes gpurun_out/profiles_<round>/<round>_*.{json,csv}; copy them into profiles/ afterwards (gpurun only brings
+# gpurun_out/ back).  Every --pmc pass runs on its own, never together with a trace domain (tools/profile.sh).
+set -u
+RND=$1
+R=$GRAFT_REPO_ROOT
+W=gpurun_out/prof_$RND
+O=$R/gpurun_out/profiles_$RND
+mkdir -p $O
+cd $R
+# (a) the headline command without the extras: kernel trace + FETCH / WRITE / L2 passes of the cfg2 sweep
+bash tools/profile.sh $W/cfg2 1 -- --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/log_cfg2.txt 2>&1
+python3 tools/prof_summary.py $W/cfg2 $O/${RND}_cfg2_spmm "spmm_plan_kernel" cfg2-default > /dev/null
+# (b) the default command (extras included): the kernels of SpMV / gather / merges / sortedness
+bash tools/profile.sh $W/extras 1 -- --steps 10 --warmup 3 --no-cpu-baseline > $O/log_extras.txt 2>&1
+python3 tools/prof_summary_multi.py $W/extras $O/${RND}_extras extras-default spmv_flat_kernel slice_rows_kernel spmv_plan_kernel \
+    gather_fused_kernel gather_count_kernel gather_copy_kernel "merge_count_kernel<64, false>" "merge_count_kernel<64, true>" \
+    "merge_fill_kernel<64, 0" "merge_fill_kernel<64, 1" "merge_fill_kernel<64, 2" rows_sorted_tile_kernel stream_copy_kernel \
+    "spmm_rowwave_kernel<double, 2, false" csr_by_dvec_kernel > /dev/null
+cp "$(ls -t $W/extras/trace/*/*_kernel_stats.csv | head -1)" $O/${RND}_extras_kernel_stats.csv
+# (c) configs[4]'s per-GPU shard on this GPU
+bash tools/profile.sh $W/cfg5 1 -- --config cfg5 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/log_cfg5.txt 2>&1
+python3 tools/prof_summary.py $W/cfg5 $O/${RND}_cfg5_shard "spmm_plan_kernel" cfg5-shard-default > /dev/null
+# (d) the bench lines themselves (un-profiled runs: profiled passes clock lower)
+python3 bench.py --steps 20 --warmup 5 > $O/${RND}_bench_n1.json 2> $O/log_bench.txt
+python3 bench.py --config cfg5 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/${RND}_cfg5_shard_bench_n1.json 2>> $O/log_bench.txt
+python3 bench.py --config cfg5-full > $O/${RND}_cfg5_full_bench.json 2> $O/log_cfg5_full.txt
+# (e) configs[4] whole: kernel trace of the same command
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$W/cfg5_full/trace -- python3 $R/bench.py --config cfg5-full > $O/log_cfg5_full_trace.txt 2>&1
+cd $R
+cp "$(ls -t $W/cfg5_full/trace/*/*_kernel_stats.csv | head -1)" $O/${RND}_cfg5_full_kernel_stats.csv
+ls -la $O

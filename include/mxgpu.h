@@ -123,7 +123,9 @@ typedef enum {
     MX_OP_MUL = 2,   /* multiply_csr_elemwise               operators.cpp:209 */
     MX_OP_OR  = 3,   /* logicalor_csr_elemwise(xor=false)   operators.cpp:556 */
     MX_OP_XOR = 4,   /* logicalor_csr_elemwise(xor=true)                      */
-    MX_OP_AND = 5    /* logicaland_csr_elemwise             operators.cpp:224 */
+    MX_OP_AND = 5,   /* logicaland_csr_elemwise             operators.cpp:224 */
+    MX_OP_FIRST = 6  /* device level only (count / fill pair): union of the patterns, f64 values, the FIRST operand's value
+                        where both hold a cell — the last step of the CSR (op) vector NA route, csrc/dvec_na.hip */
 } mx_merge_op;
 
 /* ========================================================================== */

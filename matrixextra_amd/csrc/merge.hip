@@ -173,6 +173,7 @@ __device__ __forceinline__ VT combine(VT a, VT b)
     else if constexpr (OP == MX_OP_MUL) return a * b;
     else if constexpr (OP == MX_OP_OR)  return r_logical_or(a, b);
     else if constexpr (OP == MX_OP_XOR) return r_logical_xor(a, b);
+    else if constexpr (OP == MX_OP_FIRST) return a;                 // union, the left operand's value where both hold the cell
     else return r_logical_and(a, b);
 }
 
@@ -555,6 +556,7 @@ int merge_fill_launch(int op, int G, int m, const int32_t *p1, const int32_t *j1
         case MX_OP_OR:  return merge_fill_op<MX_OP_OR, int32_t>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, st);
         case MX_OP_XOR: return merge_fill_op<MX_OP_XOR, int32_t>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, st);
         case MX_OP_AND: return merge_fill_op<MX_OP_AND, int32_t>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, st);
+        case MX_OP_FIRST: return merge_fill_op<MX_OP_FIRST, double>(G, m, p1, j1, x1, p2, j2, x2, po, jo, xo, st);
         default: return set_error("merge: unknown op %d", op);
     }
 }

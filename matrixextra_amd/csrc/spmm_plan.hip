@@ -360,6 +360,59 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
     }
 }
 
+// The order in which the sweep takes the octets (round 3).  A generation = the 16 octets one workgroup sweeps together, and
+// its wavefronts meet at every panel boundary: a generation lasts as long as its LONGEST octet.  With rows of very uneven
+// length (log-normal, sigma 1: octets of 64 rows differ by +-16 % in entries) the 16 neighbours of a generation differed by
+// 1.3x between the shortest and the longest.  sched[] lists the octets by descending length (a counting sort over 4096
+// length classes in one workgroup: ~20 us for 125 k octets), so that a generation's octets are equally long and the long
+// generations start first; position t of the schedule is swept by wavefront t % 16 of generation t / 16.  Equal lengths
+// (the headline matrix) keep the natural order.  Which octet a wavefront sweeps changes no bit of the result.
+constexpr int PLAN_SCHED_BINS = 4096;
+__global__ __launch_bounds__(1024)
+void plan_sched_kernel(int noct, const int32_t *__restrict__ steps, int32_t *__restrict__ sched, long long *__restrict__ reordered)
+{
+    __shared__ int bins[PLAN_SCHED_BINS];
+    __shared__ int smin, smax;
+    const int tid = threadIdx.x;
+    if (tid == 0) { smin = INT_MAX; smax = 0; }
+    for (int b = tid; b < PLAN_SCHED_BINS; b += 1024) bins[b] = 0;
+    __syncthreads();
+    int lo = INT_MAX, hi = 0;
+    for (int o = tid; o < noct; o += 1024) { const int v = steps[o]; lo = min(lo, v); hi = max(hi, v); }
+    atomicMin(&smin, lo);
+    atomicMax(&smax, hi);
+    __syncthreads();
+    const int vmin = smin, vmax = smax;
+    if (tid == 0) *reordered = vmax > vmin ? 1 : 0;                  // rides back to the host with the plan's size
+    if (vmax <= vmin) {                                              // all octets equally long: natural order
+        for (int o = tid; o < noct; o += 1024) sched[o] = o;
+        return;
+    }
+    // class 0 = the longest octets
+    const float scale = (float)(PLAN_SCHED_BINS - 1) / (float)(vmax - vmin);
+    auto cls = [&](int v) { return (int)((float)(vmax - v) * scale); };
+    for (int o = tid; o < noct; o += 1024) atomicAdd(&bins[cls(steps[o])], 1);
+    __syncthreads();
+    // exclusive scan of the 4096 class counts: 4 per thread
+    __shared__ int wsum[16];
+    int c[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { c[k] = bins[tid * 4 + k]; sum += c[k]; }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(incl, off, 64); if ((tid & 63) >= off) incl += up; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+    int run = base + incl - sum;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) { bins[tid * 4 + k] = run; run += c[k]; }
+    __syncthreads();
+    for (int o = tid; o < noct; o += 1024) sched[atomicAdd(&bins[cls(steps[o])], 1)] = o;
+}
+
 // Where the sweep's wavefronts meet (locality only, any value is correct): the 16 octets that one workgroup sweeps
 // together share the panel boundaries, as fractions of each octet's own length — the mean relative panel start over
 // the group.  With per-octet boundaries every meeting waited for the wavefront whose panel happened to be longest
@@ -368,17 +421,19 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
 __global__ __launch_bounds__(256)
 void plan_bounds_kernel(int noct, int npanels, const int32_t *__restrict__ oct_off, const int32_t *__restrict__ pstart,
                         int32_t *__restrict__ step_off, long long cap_slots,
-                        const long long *__restrict__ total_steps)
+                        const long long *__restrict__ total_steps, const int32_t *__restrict__ sched)
 {
     if (!plan_fits(*total_steps, cap_slots)) return;                             // the fill wrote nothing either
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nn = (long long)noct * npanels;
     if (t > nn) return;
     if (t == nn) { step_off[nn] = oct_off[noct]; return; }
-    const int oct = (int)(t / npanels), q = (int)(t % npanels);
-    const int o0 = (oct / PLAN_GEN_OCTS) * PLAN_GEN_OCTS, o1 = min(o0 + PLAN_GEN_OCTS, noct);
+    const int pos = (int)(t / npanels), q = (int)(t % npanels);                  // position in the schedule
+    const int oct = sched[pos];
+    const int o0 = (pos / PLAN_GEN_OCTS) * PLAN_GEN_OCTS, o1 = min(o0 + PLAN_GEN_OCTS, noct);
     long long sum = 0, len = 0;
-    for (int o = o0; o < o1; o++) {
+    for (int k = o0; k < o1; k++) {                                              // the octets swept together with this one
+        const int o = sched[k];
         sum += pstart[(size_t)o * (npanels + 1) + q];
         len += pstart[(size_t)o * (npanels + 1) + npanels];
     }
@@ -386,7 +441,7 @@ void plan_bounds_kernel(int noct, int npanels, const int32_t *__restrict__ oct_o
     const double frac = len > 0 ? (double)sum / (double)len : 0.0;
     int b = q == 0 ? 0 : (int)(frac * (double)mine);
     if (b > mine) b = mine;
-    step_off[t] = oct_off[oct] + b;
+    step_off[(size_t)oct * npanels + q] = oct_off[oct] + b;
 }
 
 // broadcast lane U of every 8-lane group: row_newbcast takes lane n of each 16-lane DPP row; bank_mask restricts the
@@ -473,7 +528,7 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                       const int32_t *__restrict__ pcol, const double *__restrict__ pval,
                       const real_t *__restrict__ Bp, size_t slab_stride,
                       real_t *__restrict__ C, size_t ldc, int nslabs, int ngens, int noct, int pad_col,
-                      unsigned *__restrict__ sync_ctr, int sync_mode)
+                      unsigned *__restrict__ sync_ctr, int sync_mode, const int32_t *__restrict__ sched)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
     constexpr int W = SLAB_GROUP * VEC;
@@ -498,6 +553,10 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
     // start with two exposed memory latencies (bounds, then the first chunk: ~3-4 us of a ~58 us generation).
     bool primed = false;                                            // wave-uniform
     int bounds_c = 0, send_c = 0;
+    // schedule look-ups run two generations ahead: a look-up consumed where it is issued would expose a load latency (and
+    // drain the B-line pipeline) once per generation
+    int oct_next_c = 0;                                             // next generation's octet (scalar, from the previous iteration)
+    int octnn_v = 0;                                                // the one after: requested a generation ago, still a vector register
     int rc[PLAN_CHUNK];
     double rv[PLAN_CHUNK];
 #pragma unroll
@@ -507,12 +566,26 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
         const bool have = item_raw < hi;
         const long long item = have ? item_raw : lo;
         const int slab = (int)(item / ngens), gen = (int)(item % ngens);
-        const int oct = gen * PLAN_WAVES + wave;
-        const bool oct_ok = have && oct < noct;
-        // this wavefront's octet of the next generation (if any)
-        const long long item_n = item_raw + nwg;
-        const int oct_n = (int)(item_n % ngens) * PLAN_WAVES + wave;
-        const bool octn_ok = it + 1 < niter && item_n < hi && oct_n < noct;
+        // position in the schedule -> octet (identity without a schedule); looked up one generation ahead
+        const int pos = gen * PLAN_WAVES + wave;
+        const bool oct_ok = have && pos < noct;
+        // this wavefront's octet of the next generation (if any), and of the one after
+        const long long item_n = item_raw + nwg, item_nn = item_n + nwg;
+        const int pos_n = (int)(item_n % ngens) * PLAN_WAVES + wave, pos_nn = (int)(item_nn % ngens) * PLAN_WAVES + wave;
+        const bool octn_ok = it + 1 < niter && item_n < hi && pos_n < noct;
+        const bool octnn_ok = it + 2 < niter && item_nn < hi && pos_nn < noct;
+        int oct = pos, oct_n = pos_n;
+        if (sched) {
+            if (it == 0) {                                           // the only look-ups that are waited for
+                const int a = oct_ok ? sched[pos] : 0, b = octn_ok ? sched[pos_n] : 0;
+                oct = __builtin_amdgcn_readfirstlane(a);
+                oct_n = __builtin_amdgcn_readfirstlane(b);
+            } else {
+                oct = oct_next_c;
+                oct_n = __builtin_amdgcn_readfirstlane(octnn_v);
+            }
+            oct_next_c = oct_n;
+        }
         // slab base is wave-uniform (scalar registers), the per-lane part is a 32-bit byte offset: one VALU op per
         // address.  A slab is K x 128 B < 4 GiB because K < 2^27... checked on the host (K * 128 < 2^32).
         const char *__restrict__ Bbase = reinterpret_cast<const char *>(Bp + (size_t)slab * slab_stride);
@@ -537,6 +610,7 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             // All panel boundaries of the octet come in with ONE load (lane p holds the start of the p-th panel) and
             // are picked out with v_readlane when the stream crosses a panel: a load at every boundary had to be
             // waited for with vmcnt(0), i.e. it drained the whole B-line pipeline once per panel.
+            if (sched && octnn_ok) octnn_v = sched[pos_nn];          // consumed at the start of the next generation
             int bounds = 0, send = 0;
             if (primed) {                                           // requested during the previous generation
                 bounds = bounds_c; send = send_c;
@@ -710,6 +784,8 @@ struct mx_spmm_plan {
     double *pval = nullptr;      size_t pval_cap = 0;
     unsigned char *layout = nullptr; size_t layout_cap = 0;    // [noct]: 0 bundle layout, 1 dealt layout
     int32_t *pstart = nullptr;     size_t pstart_cap = 0;     // [noct][P + 1]: relative panel starts, unpadded length
+    int32_t *sched = nullptr;      size_t sched_cap = 0;      // [noct]: the order the sweep takes the octets in
+    bool reordered = false;                                    // sched is not the identity (octets of unequal length)
     long long *rbdev = nullptr;                                // [total steps][nnz][dealt octets], read back in one copy
     long long ndealt = 0;                                      // octets in the dealt layout (rows shared by lane groups)
     void *scratch = nullptr;     size_t scratch_cap = 0;       // rowpre + steps + scan workspace (build only)
@@ -787,6 +863,7 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     if (grow((void **)&pl->step_off, &pl->step_off_cap, (nop + 1) * 4)) return 1;
     if (grow((void **)&pl->layout, &pl->layout_cap, (size_t)pl->noct)) return 1;
     if (grow((void **)&pl->pstart, &pl->pstart_cap, (size_t)pl->noct * (npanels + 1) * 4)) return 1;
+    if (grow((void **)&pl->sched, &pl->sched_cap, (size_t)pl->noct * 4)) return 1;
     int32_t *steps = (int32_t *)pl->scratch;
     int32_t *oct_off = (int32_t *)((char *)steps + steps_b);
     int32_t *bpo = (int32_t *)((char *)oct_off + octoff_b);
@@ -797,9 +874,11 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
                        steps, bpo, pl->noct, rb_dev + 1, pl->layout, pl->pstart, rb_dev + 2);
     MX_LAUNCH_CHECK();
     if (exclusive_scan_i32(steps, (int64_t)pl->noct, oct_off, (int64_t *)rb_dev, scan_ws, st)) return 1;
+    hipLaunchKernelGGL(plan_sched_kernel, dim3(1), dim3(1024), 0, st, pl->noct, steps, pl->sched, rb_dev + 3);
+    MX_LAUNCH_CHECK();
     PlanReadback *rb = plan_readback();
     MX_REQUIRE(rb, "spmm plan: cannot allocate the pinned read-back buffer");
-    MX_HIP(hipMemcpyAsync(rb->host, rb_dev, 3 * sizeof(long long), hipMemcpyDeviceToHost, st));
+    MX_HIP(hipMemcpyAsync(rb->host, rb_dev, 4 * sizeof(long long), hipMemcpyDeviceToHost, st));
     MX_HIP(hipEventRecord(rb->ev, st));
     // The host needs the plan's size to (re)allocate its arrays.  While it waits for the read-back the GPU would idle
     // (~25 us): when arrays from an earlier build exist, the fill is launched right away against their capacity — it
@@ -812,13 +891,14 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
                            values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->layout, pl->pstart,
                            rb_dev + 2, (long long)cap_slots, rb_dev);
         hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)ceil_div((long long)nop + 1, 256)), dim3(256), 0, st, pl->noct,
-                           npanels, oct_off, pl->pstart, pl->step_off, (long long)cap_slots, rb_dev);
+                           npanels, oct_off, pl->pstart, pl->step_off, (long long)cap_slots, rb_dev, pl->sched);
         MX_LAUNCH_CHECK();
     }
     MX_HIP(hipEventSynchronize(rb->ev));
     const long long total = rb->host[0];
     pl->nnz = (int32_t)rb->host[1];
     pl->ndealt = rb->host[2];
+    pl->reordered = rb->host[3] != 0;
     MX_REQUIRE(total >= 0 && total * 8 <= (long long)INT_MAX * 4LL, "spmm plan: too many steps (%lld)", total);
     MX_REQUIRE(total <= (long long)INT_MAX, "spmm plan: step offsets exceed int32");
     pl->total_steps = total;
@@ -834,7 +914,7 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
                            values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->layout, pl->pstart,
                            rb_dev + 2, (long long)slots, rb_dev);
         hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)ceil_div((long long)nop + 1, 256)), dim3(256), 0, st, pl->noct,
-                           npanels, oct_off, pl->pstart, pl->step_off, (long long)slots, rb_dev);
+                           npanels, oct_off, pl->pstart, pl->step_off, (long long)slots, rb_dev, pl->sched);
         MX_LAUNCH_CHECK();
     }
     pl->ready = true;
@@ -866,6 +946,9 @@ static int plan_run(const mx_spmm_plan *pl, int row0, int m, int n, const real_t
     const int K = pl->K;
     const int oct0 = row0 / PLAN_OCT_ROWS, noct = (int)ceil_div(m, PLAN_OCT_ROWS);
     const int32_t *step_off = pl->step_off + (size_t)oct0 * pl->npanels;
+    // the schedule (octets by descending length) covers the whole matrix: row ranges, and matrices whose octets are all
+    // equally long, are swept in natural order
+    const int32_t *sched = pl->reordered && row0 == 0 && m == pl->m ? pl->sched : nullptr;
     const int nslabs = (int)ceil_div(n, W);
     const int Kp = K + 1;
     real_t *Bp = nullptr;
@@ -892,7 +975,7 @@ static int plan_run(const mx_spmm_plan *pl, int row0, int m, int n, const real_t
 #define MX_PLAN_LAUNCH2(CM, WV, SH)                                                                                          \
     hipLaunchKernelGGL((spmm_plan_kernel<real_t, CM, WV, SH>), dim3((unsigned)grid), dim3(WV * 64), 0, st, m, n, pl->npanels, \
                        step_off, pl->pcol, pl->pval, Bp, (size_t)Kp * W, C, ldc, nslabs, ngens, noct, K,                     \
-                       sync, sync_mode)
+                       sync, sync_mode, sched)
 #define MX_PLAN_LAUNCH(CM, WV)                                                                                               \
     do { if constexpr (sizeof(real_t) == 4) { if (shared) MX_PLAN_LAUNCH2(CM, WV, true); else MX_PLAN_LAUNCH2(CM, WV, false); } \
          else MX_PLAN_LAUNCH2(CM, WV, false); } while (0)
@@ -951,6 +1034,7 @@ extern "C" int mxd_spmm_plan_destroy(mx_spmm_plan *pl)
     if (pl->scratch) (void)hipFree(pl->scratch);
     if (pl->layout) (void)hipFree(pl->layout);
     if (pl->pstart) (void)hipFree(pl->pstart);
+    if (pl->sched) (void)hipFree(pl->sched);
     if (pl->rbdev) (void)hipFree(pl->rbdev);
     delete pl;
     return 0;

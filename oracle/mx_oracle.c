@@ -685,3 +685,198 @@ void mxo_csr_by_dvec(int nrows, int ncols, const int *indptr, const int *indices
         }
     }
 }
+
+/* ---- CSR (op) dense vector when the vector holds NA / NaN, zeros under a division or power, negatives under a power or
+ * infinities under a product: the STRUCTURE-CHANGING route multiply_csr_by_dvec_with_NAs (operators.cpp:2258-2856).
+ * The reference's three length branches are kept as written:
+ *   A  :2316-2518  len <= nrows and len divides nrows: a row whose vector element is special becomes a FULL row;
+ *   B  :2520-2572  len >= nrows * ncols ("full dense"): special cells that the matrix does not hold are collected;
+ *   C  :2574-2637  any other length: special vector elements x their repeats, same collection;
+ * B and C then share the row loop :2700-2843 (copy the row with the plain operation, append the collected cells with
+ * their fill value, sort the row if needed).  Quirks kept because the result is what R gets:
+ *   - in B / C a cell whose vector element is NA_real_ is filled with NaN and one whose element is a plain NaN (or an
+ *     infinity under a product) with NA_real_ (:2544-2563, :2817-2833) — the other way round from branch A (:2352);
+ *   - the operation is always `value op element` (X on the left), X_is_LHS only decides an error (:2274-2275);
+ *   - no special cell found: the reference returns its INPUT indptr / indices and the values of the no-NAs routine
+ *     (:2639-2647): status 1 here.
+ * Rows must be sorted by column (the R caller sorts first, R/operators.R:1112-1114).
+ * Output: malloc'ed arrays in *res (free with mxo_free_dvec_na); status 0 ok, 1 aliased structure (indptr / indices NULL),
+ * 2 too many entries for int32 (:2650-2656), 3 internal error (:2274-2289). */
+typedef struct { int *indptr; int *indices; double *values; size_t nnz; int status; } mxo_dvec_na_result;
+
+typedef struct { int *p; size_t n, cap; } ivec_t;
+typedef struct { double *p; size_t n, cap; } dvec_t;
+static void ivec_push(ivec_t *v, int x)
+{
+    if (v->n == v->cap) { v->cap = v->cap ? 2 * v->cap : 1024; v->p = (int *)realloc(v->p, v->cap * sizeof(int)); }
+    v->p[v->n++] = x;
+}
+static void dvec_push(dvec_t *v, double x)
+{
+    if (v->n == v->cap) { v->cap = v->cap ? 2 * v->cap : 1024; v->p = (double *)realloc(v->p, v->cap * sizeof(double)); }
+    v->p[v->n++] = x;
+}
+static int is_na_real(double x)                                   /* R's ISNA: a NaN whose low word is 1954 */
+{
+    union { double d; uint64_t u; } w;
+    w.d = x;
+    return isnan(x) && (uint32_t)(w.u & 0xFFFFFFFFu) == 1954u;
+}
+static double dvec_na_op(int op, double x, double d)              /* the plain operation of the row loop :2708-2788 */
+{
+    switch (op) {
+        case 0: return x * d;
+        case 2: return x / d;
+        case 3: return r_modulus_o(x, d);
+        case 4: return r_intdiv_o(x, d);
+        default: return r_pow_o(x, d);
+    }
+}
+/* argsort_buffer_NAs :2202-2222: the (row, col) pairs ordered by row (the order inside a row is left to the row sort) */
+typedef struct { int row, col; } cell_t;
+static int cell_by_row(const void *a, const void *b) { return ((const cell_t *)a)->row - ((const cell_t *)b)->row; }
+typedef struct { cell_t *p; size_t n, cap; } cells_t;
+static void cells_push(cells_t *v, int row, int col)
+{
+    if (v->n == v->cap) { v->cap = v->cap ? 2 * v->cap : 1024; v->p = (cell_t *)realloc(v->p, v->cap * sizeof(cell_t)); }
+    v->p[v->n].row = row; v->p[v->n].col = col; v->n++;
+}
+typedef struct { int j; double x; } ent_t;
+static int ent_by_col(const void *a, const void *b) { return ((const ent_t *)a)->j - ((const ent_t *)b)->j; }
+
+void mxo_free_dvec_na(mxo_dvec_na_result *res)
+{
+    free(res->indptr); free(res->indices); free(res->values);
+    res->indptr = res->indices = NULL; res->values = NULL;
+}
+
+void mxo_csr_by_dvec_with_NAs(int nrows, int ncols, const int *indptr, const int *indices, const double *values,
+                              const double *dvec, size_t len, int op /* 0 multiply, 1 powerto, 2 divide, 3 divrest, 4 intdiv */,
+                              int x_is_lhs, mxo_dvec_na_result *res)
+{
+    memset(res, 0, sizeof(*res));
+    const int multiply = op == 0, powerto = op == 1, divide = op == 2, divrest = op == 3, intdiv = op == 4;
+    if (((powerto || divide || divrest) && !x_is_lhs) || op < 0 || op > 4) { res->status = 3; return; }     /* :2274-2289 */
+    const int is_div = divide || divrest || intdiv;
+    const unsigned long long cells = (unsigned long long)nrows * (unsigned long long)ncols;
+    ivec_t jo = {0, 0, 0};
+    dvec_t xo = {0, 0, 0};
+    int *po = (int *)calloc((size_t)nrows + 1, sizeof(int));
+
+    if (len <= (size_t)nrows && ((size_t)nrows % len) == 0) {
+        /* ---- branch A :2316-2518 */
+        for (int row = 0; row < nrows; row++) {
+            const double val = dvec[(size_t)row % len];
+            int full = 0;                                           /* 1: the row becomes 0 .. ncols-1 */
+            double fill = 0.0;
+            int overwrite = 0;                                      /* existing entries written over the fill */
+            if (multiply) {
+                if (isnan(val) || isinf(val)) { full = 1; fill = is_na_real(val) ? na_real() : NAN; overwrite = isinf(val); }
+            } else if (divide || divrest || intdiv) {
+                if (val == 0) { full = 1; fill = NAN; overwrite = 1; }
+                else if (isnan(val)) { full = 1; fill = val; }
+            } else {                                                /* powerto :2472-2510 */
+                if (isnan(val)) { full = 1; fill = val; overwrite = 1; }
+                else if (val <= 0) { full = 1; fill = val == 0 ? 1. : HUGE_VAL; overwrite = 1; }
+            }
+            if (!full) {
+                for (int ix = indptr[row]; ix < indptr[row + 1]; ix++) { ivec_push(&jo, indices[ix]); dvec_push(&xo, dvec_na_op(op, values[ix], val)); }
+            } else {
+                const size_t at = xo.n;
+                for (int col = 0; col < ncols; col++) { ivec_push(&jo, col); dvec_push(&xo, fill); }
+                if (overwrite)
+                    for (int ix = indptr[row]; ix < indptr[row + 1]; ix++) xo.p[at + (size_t)indices[ix]] = dvec_na_op(op, values[ix], val);
+            }
+            if (jo.n > (size_t)INT_MAX) { res->status = 2; break; } /* (the reference's int indptr would wrap here) */
+            po[row + 1] = (int)jo.n;
+        }
+        if (res->status) { free(po); free(jo.p); free(xo.p); return; }
+        res->indptr = po; res->indices = jo.p; res->values = xo.p; res->nnz = jo.n;
+        return;
+    }
+
+    /* ---- branches B / C: collect the special cells the matrix does not hold, by fill value */
+    cells_t na = {0, 0, 0}, nan_ = {0, 0, 0}, ones = {0, 0, 0}, inf = {0, 0, 0};
+    const int fulldense = (unsigned long long)len >= cells;
+#define MXO_SPECIAL(d) (isnan(d) || ((is_div || powerto) && (d) == 0) || (powerto && (d) < 0) || (multiply && isinf(d)))
+#define MXO_COLLECT(row, col, d)                                                                                   \
+    do {                                                                                                           \
+        int add_el = indptr[row] == indptr[(row) + 1] || (int)(col) < indices[indptr[row]] ||                      \
+                     (int)(col) > indices[indptr[(row) + 1] - 1];                                                  \
+        if (!add_el) {                                                                                             \
+            const int *r_ = lower_bound_int(indices + indptr[row], indices + indptr[(row) + 1], (int)(col));       \
+            add_el = r_ >= indices + indptr[(row) + 1] || *r_ != (int)(col);                                       \
+        }                                                                                                          \
+        if (add_el) {                                                                                              \
+            if ((is_div && (d) == 0) || is_na_real(d)) cells_push(&nan_, (int)(row), (int)(col));                  \
+            else if (powerto && (d) == 0) cells_push(&ones, (int)(row), (int)(col));                               \
+            else if (powerto && (d) < 0) cells_push(&inf, (int)(row), (int)(col));                                 \
+            else cells_push(&na, (int)(row), (int)(col));                                                          \
+        }                                                                                                          \
+    } while (0)
+    if (fulldense) {                                                /* :2520-2572 */
+        for (size_t row = 0; row < (size_t)nrows; row++)
+            for (size_t col = 0; col < (size_t)ncols; col++) {
+                const double d = dvec[row + col * (size_t)nrows];
+                if (MXO_SPECIAL(d)) MXO_COLLECT(row, col, d);
+            }
+    } else {                                                        /* :2592-2637 */
+        const unsigned long long n_repeats = (cells + len - 1) / len;
+        for (size_t ix = 0; ix < len; ix++) {
+            const double d = dvec[ix];
+            if (!MXO_SPECIAL(d)) continue;
+            for (unsigned long long rep = 0; rep < n_repeats; rep++) {
+                const unsigned long long ix_this = ix + rep * len;
+                if (ix_this >= cells) break;
+                const size_t row = (size_t)(ix_this % (unsigned long long)nrows), col = (size_t)(ix_this / (unsigned long long)nrows);
+                MXO_COLLECT(row, col, d);
+            }
+        }
+    }
+#undef MXO_COLLECT
+#undef MXO_SPECIAL
+    if (!na.n && !nan_.n && !ones.n && !inf.n) {                    /* :2639-2647: structure untouched */
+        res->status = 1;
+        res->nnz = (size_t)indptr[nrows];
+        res->values = (double *)malloc(sizeof(double) * (res->nnz ? res->nnz : 1));
+        mxo_csr_by_dvec(nrows, ncols, indptr, indices, values, dvec, len, op, x_is_lhs, res->values);
+        free(po); free(na.p); free(nan_.p); free(ones.p); free(inf.p);
+        return;
+    }
+    if ((unsigned long long)na.n + nan_.n + ones.n + inf.n + (unsigned long long)indptr[nrows] >= (unsigned long long)INT_MAX) {
+        res->status = 2;                                            /* :2650-2656 */
+        free(po); free(na.p); free(nan_.p); free(ones.p); free(inf.p);
+        return;
+    }
+    qsort(na.p, na.n, sizeof(cell_t), cell_by_row);
+    qsort(nan_.p, nan_.n, sizeof(cell_t), cell_by_row);
+    qsort(ones.p, ones.n, sizeof(cell_t), cell_by_row);
+    qsort(inf.p, inf.n, sizeof(cell_t), cell_by_row);
+    size_t c_na = 0, c_nan = 0, c_one = 0, c_inf = 0;               /* cursors of add_missing_indices_in_loop :2224-2253 */
+    ent_t *rowbuf = NULL;
+    size_t rowcap = 0;
+    for (int row = 0; row < nrows; row++) {                         /* :2700-2843 */
+        const size_t at = jo.n;
+        for (int ix = indptr[row]; ix < indptr[row + 1]; ix++) {
+            const double d = fulldense ? dvec[(size_t)row + (size_t)indices[ix] * (size_t)nrows]
+                                       : dvec[(size_t)(((unsigned long long)row + (unsigned long long)indices[ix] * (unsigned long long)nrows) % (unsigned long long)len)];
+            ivec_push(&jo, indices[ix]);
+            dvec_push(&xo, dvec_na_op(op, values[ix], d));
+        }
+        int added = 0;
+        for (; c_na < na.n && na.p[c_na].row == row; c_na++) { ivec_push(&jo, na.p[c_na].col); dvec_push(&xo, na_real()); added = 1; }
+        for (; c_nan < nan_.n && nan_.p[c_nan].row == row; c_nan++) { ivec_push(&jo, nan_.p[c_nan].col); dvec_push(&xo, NAN); added = 1; }
+        for (; c_one < ones.n && ones.p[c_one].row == row; c_one++) { ivec_push(&jo, ones.p[c_one].col); dvec_push(&xo, 1.); added = 1; }
+        for (; c_inf < inf.n && inf.p[c_inf].row == row; c_inf++) { ivec_push(&jo, inf.p[c_inf].col); dvec_push(&xo, HUGE_VAL); added = 1; }
+        if (added) {                                                /* sort the row by column (:2835-2851) */
+            const size_t n_this = jo.n - at;
+            if (n_this > rowcap) { rowcap = 2 * n_this; rowbuf = (ent_t *)realloc(rowbuf, rowcap * sizeof(ent_t)); }
+            for (size_t k = 0; k < n_this; k++) { rowbuf[k].j = jo.p[at + k]; rowbuf[k].x = xo.p[at + k]; }
+            qsort(rowbuf, n_this, sizeof(ent_t), ent_by_col);
+            for (size_t k = 0; k < n_this; k++) { jo.p[at + k] = rowbuf[k].j; xo.p[at + k] = rowbuf[k].x; }
+        }
+        po[row + 1] = (int)jo.n;
+    }
+    free(rowbuf); free(na.p); free(nan_.p); free(ones.p); free(inf.p);
+    res->indptr = po; res->indices = jo.p; res->values = xo.p; res->nnz = jo.n;
+}

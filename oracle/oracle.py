@@ -651,3 +651,33 @@ def multiply_csr_by_dvec_no_NAs_numeric(p, j, x, dvec, ncols, multiply, powerto,
 def logicaland_csr_by_dvec_internal(p, j, x, dvec, ncols):
     """src/operators.cpp:2177-2200"""
     return _csr_by_dvec(p, j, x, dvec, ncols, 5, True)
+
+
+class _DvecNaResult(C.Structure):
+    _fields_ = [("indptr", C.POINTER(C.c_int)), ("indices", C.POINTER(C.c_int)), ("values", C.POINTER(C.c_double)),
+                ("nnz", C.c_size_t), ("status", C.c_int)]
+
+
+def multiply_csr_by_dvec_with_NAs(p, j, x, dvec, ncols, multiply, powerto, divide, divrest, intdiv, X_is_LHS):
+    """src/operators.cpp:2258-2856 (R/RcppExports.R: multiply_csr_by_dvec_with_NAs): the structure-changing route of
+    `CSR op vector` when the vector holds NA / NaN, zeros under / %% %/% ^, negatives under ^ or infinities under *.
+    Returns dict(indptr, indices, values, alias_structure); raises ValueError for the reference's two error exits."""
+    p, j = _i32(p), _i32(j)
+    xv, dv = _f64(x), _f64(dvec).reshape(-1)
+    op = 0 if multiply else 1 if powerto else 2 if divide else 3 if divrest else 4 if intdiv else -1
+    res = _DvecNaResult()
+    lib().mxo_csr_by_dvec_with_NAs(C.c_int(p.size - 1), C.c_int(int(ncols)), _p(p), _p(j), _p(xv), _p(dv), C.c_size_t(dv.size),
+                                   C.c_int(op), C.c_int(1 if X_is_LHS else 0), C.byref(res))
+    try:
+        if res.status == 3:
+            raise ValueError("Unexpected error.")
+        if res.status == 2:
+            raise ValueError("Error: the resulting matrix would have too many entries for a sparse CSR representation (int overflow).")
+        n = int(res.nnz)
+        vals = np.ctypeslib.as_array(res.values, shape=(max(n, 1),))[:n].copy()
+        if res.status == 1:                                          # the reference hands back its input indptr / indices
+            return dict(indptr=p, indices=j, values=vals, alias_structure=True)
+        return dict(indptr=np.ctypeslib.as_array(res.indptr, shape=(p.size,)).copy(),
+                    indices=np.ctypeslib.as_array(res.indices, shape=(max(n, 1),))[:n].copy(), values=vals, alias_structure=False)
+    finally:
+        lib().mxo_free_dvec_na(C.byref(res))

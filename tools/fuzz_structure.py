@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
 import numpy as np
 from conftest import rand_csr
-from devmem import merge_fused_device, spmv_device
+from devmem import gather_fused_device, merge_fused_device, rows_sorted_device, spmv_device, spmv_plan_device
 from matrixextra_amd import _lib
 from matrixextra_amd import exports as G
 from oracle import oracle as O
@@ -94,8 +94,37 @@ while time.time() < t_end:
                 gp, gj, gx = merge_fused_device(op, l1[0] if lg else p1, l1[1] if lg else j1, l1[2] if lg else x1,
                                                 l2[0] if lg else p2, l2[1] if lg else j2, l2[2] if lg else x2)
                 same_list(dict(indptr=gp, indices=gj, values=gx), ref, what)
+        if rows.size:                                                 # the one-launch gather (device level): any capacity
+            total = int((p1[1:] - p1[:-1])[rows].sum())
+            cap = int(rng.choice([total, total + 5, max(total // 2, 0), 0, 3 * total + 1]))
+            kind = int(rng.integers(3))
+            vals, dt = ((x1, _lib.MX_F64), (l1[2] if l1[1].size == j1.size else None, _lib.MX_LGL), (None, _lib.MX_NONE))[kind]
+            if vals is None:
+                dt = _lib.MX_NONE
+            what = f"gather fused cap={cap} total={total} kind={kind}"; trace("  start", what)
+            ref = O.copy_csr_rows_numeric(p1, j1, x1, rows)
+            gp, gj, gx, nnz = gather_fused_device(p1, j1, vals, rows, cap, dt)
+            assert nnz == total, what
+            refp = np.concatenate([[0], np.cumsum((p1[1:] - p1[:-1])[rows])]).astype(np.int32)
+            same(gp, refp, what + "/indptr")
+            if cap >= total and total:
+                same(gj, ref["indices"], what + "/indices")
+                if dt == _lib.MX_F64:
+                    same(gx, ref["values"], what + "/values")
+            elif total:                                               # everything that ends within the capacity is there
+                for t in np.nonzero(refp[1:] <= cap)[0][:50]:
+                    rr = rows[t]
+                    same(gj[refp[t]:refp[t + 1]], j1[p1[rr]:p1[rr + 1]], what + "/row")
         what = "sorted check"; trace("  start", what)
         assert G.check_indices_are_sorted(p1, j1) == O.check_indices_are_sorted(p1, j1)
+        if m > 2:                                                     # device level: unaligned indices, row-block views (indptr[0] > 0)
+            r0 = int(rng.integers(0, m - 1))
+            mis = int(rng.integers(0, 4))
+            what = f"sorted check view r0={r0} misalign={mis}"; trace("  start", what)
+            pu0, ju0, _ = rand_csr(m, K, d2, seed=s2 + 2, sorted_cols=bool(rng.integers(2)))
+            lo_, hi_ = int(pu0[r0]), int(pu0[-1])
+            ref_sorted = all(np.all(np.diff(ju0[pu0[r]:pu0[r + 1]]) >= 0) for r in range(r0, m)) if hi_ > lo_ else True
+            assert rows_sorted_device(pu0[r0:], ju0, misalign=mis) == ref_sorted, what
         what = "sort"; trace("  start", what)
         pu, ju, xu = rand_csr(m, K, d2, seed=s2 + 1, sorted_cols=False)
         assert G.check_indices_are_sorted(pu, ju) == O.check_indices_are_sorted(pu, ju)
@@ -114,6 +143,20 @@ while time.time() < t_end:
                 got = spmv_device(pu, ju, xu, v, _lib.MX_F64, algo)
                 same(got[short], ref[short], what)
                 np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+        if pu[-1] >= 1 and K <= 64 * 6144:                            # planned SpMV, all kinds incl. NA elements
+            vi = rng.integers(-3, 4, size=K).astype(np.int32)
+            vi[rng.random(K) < 0.1] = NA
+            what = "spmv plan"; trace("  start", what)
+            outs = spmv_plan_device(pu, ju, xu, [(v, _lib.MX_F64), (vi, _lib.MX_I32), (vi, _lib.MX_LGL), (v.astype(np.float32), _lib.MX_F32)])
+            refs = [O.matmul_csr_dvec_numeric(pu, ju, xu, v), O.matmul_csr_dvec_integer(pu, ju, xu, vi),
+                    O.matmul_csr_dvec_logical(pu, ju, xu, vi), O.matmul_csr_dvec_float32(pu, ju, xu, v.astype(np.float32))]
+            for got, ref, tol in zip(outs, refs, (1e-12, 1e-12, 1e-12, 1e-5)):
+                # R's NA_real_ = a NaN whose low word is 1954 (arithmetic may set the quiet bit: ISNA looks at the low word only)
+                na_g = np.isnan(got) & ((got.view(np.uint64) & np.uint64(0xFFFFFFFF)) == 1954) if got.dtype == np.float64 else np.isnan(got)
+                na_r = np.isnan(ref) & ((ref.view(np.uint64) & np.uint64(0xFFFFFFFF)) == 1954) if ref.dtype == np.float64 else np.isnan(ref)
+                assert np.array_equal(na_g, na_r), what + " NA rows"
+                ok = ~np.isnan(ref)
+                np.testing.assert_allclose(got[ok], ref[ok], rtol=tol, atol=tol * max(1.0, float(np.max(np.abs(ref[ok]), initial=0.0))))
         what = "dvec mul"; trace("  start", what)
         ln = int(rng.choice([1, m, m * K, max(1, m // 2), 7]))
         dv = rng.uniform(0.5, 2.0, size=ln).round(3)

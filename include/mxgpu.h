@@ -380,6 +380,19 @@ int mxd_csr_by_dvec(int m, int ncols, int64_t nnz, const int32_t *indptr, const 
                     const void *values, const void *dvec, int64_t dvec_len, int op, int x_is_lhs,
                     void *values_out, void *stream);
 
+/* The structure-changing route of CSR (op) dense vector (multiply_csr_by_dvec_with_NAs, src/operators.cpp:2258-2856): the
+ * vector holds NA / NaN, zeros under / %% %/% ^, negatives under ^ or infinities under *, and every cell it makes special
+ * becomes an explicit entry.  op MX_DV_MULTIPLY .. MX_DV_INTDIV, always `value op element`; rows sorted by column (the R
+ * caller sorts first).  The result arrays are allocated by the library (free them with mx_dev_free): *out_indptr[m+1],
+ * *out_indices / *out_values[*nnz_out].  *structure_unchanged = 1: no cell was added (lengths that neither divide nrows nor
+ * cover the matrix only: the reference then returns its INPUT indptr / indices) — only *out_values[nnz] is set.
+ * Synchronises `stream` (three sizes come back to the host).  See csrc/dvec_na.hip for how the result is put together
+ * (values kernel + a CSR of the special cells + the MX_OP_FIRST union merge) and for the reference's quirks that are kept. */
+int mxd_csr_by_dvec_with_NAs(int m, int ncols, int64_t nnz, const int32_t *indptr, const int32_t *indices,
+                             const double *values, const double *dvec, int64_t dvec_len, int op,
+                             int32_t **out_indptr, int32_t **out_indices, double **out_values,
+                             int64_t *nnz_out, int *structure_unchanged, void *stream);
+
 /* check_is_seq / check_is_rev_seq (src/slice.cpp:25-47) on a device vector.
  * *flag_host receives 0/1 after an internal stream sync. */
 int mxd_check_is_seq(const int32_t *idx, int64_t n, int reversed, int32_t *workspace4,
@@ -520,12 +533,19 @@ int mx_matmul_csr_svec(const int32_t *X_indptr, const int32_t *X_indices, const 
 int mx_multiply_csr_by_dense_elemwise(const int32_t *indptr, const int32_t *indices, const void *values, int nrows,
                                       const void *dense_mat, int64_t ncols, int kind, void *values_out);
 /* multiply_csr_by_dvec_no_NAs_numeric  src/operators.cpp:2142-2175: exactly one of the five flags is set (as the R
- * caller passes them, R/operators.R:1134-1137); values_out f64[nnz].  The structure-changing NA route
- * (multiply_csr_by_dvec_with_NAs, :2258-) is not provided. */
+ * caller passes them, R/operators.R:1134-1137); values_out f64[nnz]. */
 int mx_multiply_csr_by_dvec_no_NAs_numeric(const int32_t *indptr, const int32_t *indices, const double *values,
                                            int nrows, const double *dvec, int64_t dvec_len, int ncols, int multiply,
                                            int powerto, int divide, int divrest, int intdiv, int X_is_LHS,
                                            double *values_out);
+/* multiply_csr_by_dvec_with_NAs  src/operators.cpp:2258-2856 (RcppExports.cpp CallEntries: 11 arguments): the
+ * structure-changing route, same flags.  info.alias_structure = 1 when the reference would hand back its input indptr /
+ * indices (finish then fills only the values); errors as the reference's ("Unexpected error." for ^ / %% with the matrix
+ * on the right, the int-overflow message). */
+int mx_multiply_csr_by_dvec_with_NAs_begin(const int32_t *indptr, const int32_t *indices, const double *values, int nrows,
+                                           const double *dvec, int64_t dvec_len, int ncols, int multiply, int powerto,
+                                           int divide, int divrest, int intdiv, int X_is_LHS,
+                                           mx_result **res, mx_result_info *info);
 /* logicaland_csr_by_dvec_internal  src/operators.cpp:2177-2200: R logicals (int32), values_out int32[nnz] */
 int mx_logicaland_csr_by_dvec_internal(const int32_t *indptr, const int32_t *indices, const int32_t *values,
                                        int nrows, const int32_t *dvec, int64_t dvec_len, int ncols,

@@ -33,7 +33,7 @@
     "reverse_rows_numeric", "reverse_rows_logical", "reverse_rows_binary",
     "reverse_columns_inplace_numeric", "reverse_columns_inplace_logical", "reverse_columns_inplace_binary",
     ## rank 4: values-only CSR (op) vector, CSR x sparse vector, CSR (.) dense
-    "multiply_csr_by_dvec_no_NAs_numeric", "logicaland_csr_by_dvec_internal",
+    "multiply_csr_by_dvec_no_NAs_numeric", "logicaland_csr_by_dvec_internal", "multiply_csr_by_dvec_with_NAs",
     "matmul_csr_svec_numeric", "matmul_csr_svec_integer", "matmul_csr_svec_logical", "matmul_csr_svec_binary",
     "matmul_csr_svec_float32",
     "multiply_csr_by_dense_elemwise_double", "multiply_csr_by_dense_elemwise_float32",

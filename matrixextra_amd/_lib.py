@@ -38,7 +38,7 @@ def declared_symbols() -> list[str]:
     with open(HEADER_PATH) as f:
         text = f.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mxd?_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(mxd?_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def load() -> C.CDLL:

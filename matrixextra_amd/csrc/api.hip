@@ -464,7 +464,7 @@ struct Pin {
     bool pin_inside(const void *ptr, size_t nbytes)
     {
         const uintptr_t a = ((uintptr_t)ptr + 4095) & ~(uintptr_t)4095, b = ((uintptr_t)ptr + nbytes) & ~(uintptr_t)4095;
-        ok = b > a && b - a >= ((size_t)4 << 20) && mx::pin_host((const void *)a, b - a, true);
+        ok = nbytes > ((size_t)32 << 20) && b > a && mx::pin_host((const void *)a, b - a, true);   // (> 32 MiB: never a piece of the brk heap, see xfer.hip)
         p = (const void *)a; bytes = b - a;
         return ok;
     }
@@ -1521,6 +1521,54 @@ int mx_multiply_csr_by_dvec_no_NAs_numeric(const int32_t *indptr, const int32_t 
     else if (intdiv) op = MX_DV_INTDIV;
     else return set_error("Internal error. Please file an issue in GitHub.");        // throw_internal_err()
     return csr_by_dvec_export(indptr, indices, values, nrows, dvec, dvec_len, ncols, op, X_is_LHS, values_out);
+}
+
+int mx_multiply_csr_by_dvec_with_NAs_begin(const int32_t *indptr, const int32_t *indices, const double *values, int nrows,
+                                           const double *dvec, int64_t dvec_len, int ncols, int multiply, int powerto,
+                                           int divide, int divrest, int intdiv, int X_is_LHS, mx_result **res_out,
+                                           mx_result_info *info)
+{
+    MX_REQUIRE(res_out && info, "mx_multiply_csr_by_dvec_with_NAs_begin: null output pointer");
+    MX_REQUIRE(nrows >= 0 && ncols >= 0 && dvec_len > 0 && indptr && dvec, "mx_multiply_csr_by_dvec_with_NAs_begin: bad arguments");
+    *res_out = nullptr;
+    // operators.cpp:2274-2289: ^ / %% need the matrix on the left; the flags' precedence
+    if ((powerto || divide || divrest) && !X_is_LHS) return set_error("Internal error. Please file an issue in GitHub.");
+    int op;
+    if (multiply) op = MX_DV_MULTIPLY;
+    else if (powerto) op = MX_DV_POWERTO;
+    else if (divide) op = MX_DV_DIVIDE;
+    else if (divrest) op = MX_DV_DIVREST;
+    else if (intdiv) op = MX_DV_INTDIV;
+    else return set_error("Internal error. Please file an issue in GitHub.");
+    mx_result *res = new (std::nothrow) mx_result();
+    MX_REQUIRE(res, "out of host memory");
+    res->info.values_dtype = MX_F64;
+    int rc = 0;
+    do {
+        Csr A;
+        if ((rc = A.upload(indptr, indices, values, nrows, sizeof(double)))) break;
+        DevBuf dv;
+        if ((rc = dv.upload(dvec, sizeof(double) * (size_t)dvec_len))) break;
+        int32_t *op_ = nullptr, *oj = nullptr;
+        double *ox = nullptr;
+        int64_t nnz_out = 0;
+        int unchanged = 0;
+        if ((rc = mxd_csr_by_dvec_with_NAs(nrows, ncols, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(),
+                                           dv.as<double>(), dvec_len, op, &op_, &oj, &ox, &nnz_out, &unchanged, nullptr)))
+            break;
+        // the result arrays were allocated by the device-level call: the handle owns them from here
+        res->indptr.p = op_; res->indptr.bytes = sizeof(int32_t) * ((size_t)nrows + 1);
+        res->indices.p = oj; res->indices.bytes = sizeof(int32_t) * (size_t)nnz_out;
+        res->values.p = ox;  res->values.bytes = sizeof(double) * (size_t)nnz_out;
+        res->info.alias_structure = unchanged;
+        res->info.indptr_len = (int64_t)nrows + 1;
+        res->info.nnz = nnz_out;
+        res->info.values_len = nnz_out;
+    } while (0);
+    if (rc) { delete res; return rc; }
+    *info = res->info;
+    *res_out = res;
+    return 0;
 }
 
 int mx_logicaland_csr_by_dvec_internal(const int32_t *indptr, const int32_t *indices, const int32_t *values,

@@ -376,6 +376,22 @@ SEXP _MatrixExtra_multiply_csr_by_dvec_no_NAs_numeric(SEXP p_, SEXP j_, SEXP x_,
         fail();
     return out;
 }
+// multiply_csr_by_dvec_with_NAs (src/operators.cpp:2258-2856): list(indptr =, indices =, values =); when no cell is added
+// the INPUT indptr / indices objects are returned, as the reference does (:2639-2647)
+SEXP _MatrixExtra_multiply_csr_by_dvec_with_NAs(SEXP p_, SEXP j_, SEXP x_, SEXP dvec, SEXP ncols, SEXP multiply, SEXP powerto,
+                                                SEXP divide, SEXP divrest, SEXP intdiv, SEXP X_is_LHS)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p); x_ = as_type(x_, REALSXP, p); dvec = as_type(dvec, REALSXP, p);
+    mx_result *res = nullptr;
+    mx_result_info info;
+    if (mx_multiply_csr_by_dvec_with_NAs_begin(INTEGER(p_), INTEGER(j_), REAL(x_), (int)XLENGTH(p_) - 1, REAL(dvec),
+                                               (int64_t)XLENGTH(dvec), Rf_asInteger(ncols), Rf_asLogical(multiply),
+                                               Rf_asLogical(powerto), Rf_asLogical(divide), Rf_asLogical(divrest),
+                                               Rf_asLogical(intdiv), Rf_asLogical(X_is_LHS), &res, &info))
+        fail();
+    return finish_guarded(res, info, p_, j_);
+}
 SEXP _MatrixExtra_logicaland_csr_by_dvec_internal(SEXP p_, SEXP j_, SEXP x_, SEXP dvec, SEXP ncols)
 {
     Protect p;
@@ -580,6 +596,7 @@ static const R_CallMethodDef mxgpu_call_entries[] = {
     MX_ENTRY(reverse_columns_inplace_numeric, 4), MX_ENTRY(reverse_columns_inplace_logical, 4),
     MX_ENTRY(reverse_columns_inplace_binary, 4),
     MX_ENTRY(multiply_csr_by_dvec_no_NAs_numeric, 11), MX_ENTRY(logicaland_csr_by_dvec_internal, 5),
+    MX_ENTRY(multiply_csr_by_dvec_with_NAs, 11),
     MX_ENTRY(cbind_csr_numeric, 6), MX_ENTRY(cbind_csr_logical, 6), MX_ENTRY(cbind_csr_binary, 4),
     MX_ENTRY(concat_csr_batch, 2),
     MX_ENTRY(matmul_csr_svec_numeric, 6), MX_ENTRY(matmul_csr_svec_integer, 6), MX_ENTRY(matmul_csr_svec_logical, 6),

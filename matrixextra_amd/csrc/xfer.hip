@@ -28,6 +28,13 @@ using Pool = HostPool;
 constexpr int XF_SLOTS = 3;
 constexpr size_t XF_CHUNK = (size_t)8 << 20;
 constexpr size_t XF_MIN = (size_t)16 << 20;           // below this a plain hipMemcpy is as good
+// Caller memory is only REGISTERED when it is a mapping of its own: glibc never serves more than 32 MiB
+// (DEFAULT_MMAP_THRESHOLD_MAX) from the shared brk heap, and its threshold climbs to that value as large blocks are freed —
+// a 16-32 MiB vector can therefore sit in the heap, whose pages are trimmed and re-grown behind the runtime's back.
+// Round 3's longer fuzz loops (more and larger host arrays per case) ended twice in "Memory access fault by GPU" at a
+// brk-heap address, some calls after such a vector had been registered and unregistered; every operation alone ran clean
+// for 10-20 k cases.  Buffers of 16-32 MiB take the staged pipeline (pinned slots + host copy team) instead.
+constexpr size_t XF_REG_MIN = ((size_t)32 << 20) + 4096;
 
 int xfer_mode()
 {
@@ -187,6 +194,7 @@ struct Interior { char *p = nullptr; size_t bytes = 0; };
 static Interior pin_interior(const void *ptr, size_t bytes)
 {
     Interior in;
+    if (bytes < XF_REG_MIN) return in;                             // possibly a piece of the brk heap: never registered
     const uintptr_t a = ((uintptr_t)ptr + 4095) & ~(uintptr_t)4095, b = ((uintptr_t)ptr + bytes) & ~(uintptr_t)4095;
     if (b <= a || b - a < XF_MIN / 2) return in;
     if (!pin_host((const void *)a, b - a)) return in;

@@ -525,6 +525,22 @@ def multiply_csr_by_dvec_no_NAs_numeric(indptr, indices, values, dvec, ncols, mu
     return out
 
 
+def multiply_csr_by_dvec_with_NAs(indptr, indices, values, dvec, ncols, multiply, powerto, divide, divrest, intdiv, X_is_LHS):
+    """src/operators.cpp:2258-2856: the structure-changing route of `CSR op vector` (NA / NaN in the vector, zeros under
+    / %% %/% ^, negatives under ^, infinities under *).  Returns dict(indptr, indices, values); when no cell is added the
+    INPUT indptr / indices objects come back, as in the reference (:2639-2647)."""
+    p, j = _i32(indptr), _i32(indices)
+    xv = np.ascontiguousarray(values, dtype=np.float64)
+    dv = np.ascontiguousarray(dvec, dtype=np.float64).reshape(-1)
+    res = C.c_void_p()
+    info = ResultInfo()
+    check(_lib.load().mx_multiply_csr_by_dvec_with_NAs_begin(
+        ptr(p), ptr(j), ptr(xv), C.c_int(p.size - 1), ptr(dv), C.c_int64(dv.size), C.c_int(int(ncols)),
+        C.c_int(bool(multiply)), C.c_int(bool(powerto)), C.c_int(bool(divide)), C.c_int(bool(divrest)), C.c_int(bool(intdiv)),
+        C.c_int(bool(X_is_LHS)), C.byref(res), C.byref(info)))
+    return _finish(res, info, alias_from=(indptr, indices))
+
+
 def logicaland_csr_by_dvec_internal(indptr, indices, values, dvec, ncols):
     """src/operators.cpp:2177-2200 (R/RcppExports.R:484-486): R logicals in, R logicals out."""
     p, j = _i32(indptr), _i32(indices)

@@ -8,7 +8,7 @@ import warnings
 import numpy as np
 
 from . import exports
-from .matrices import (RsparseMatrix, as_csr_matrix, check_valid_matrix, dgRMatrix, lgRMatrix, ngRMatrix,
+from .matrices import (NA_REAL, RsparseMatrix, as_csr_matrix, check_valid_matrix, dgRMatrix, lgRMatrix, ngRMatrix,
                        options, sort_sparse_indices, stop)
 
 
@@ -113,9 +113,10 @@ def _as_logical(v):
 
 def multiply_csr_by_dvec_elemwise_internal(e1, e2, logical=False, X_is_LHS=True, op="*"):
     """R/operators.R:950-1153 for RsparseMatrix `e1`: `e1 op e2` (or `e2 op e1` when X_is_LHS is false) with a dense
-    vector (or a same-shape dense matrix read as a vector), R's recycling, values-only result.  The routes the
-    reference sends through multiply_csr_by_dvec_with_NAs or through a CsparseMatrix (vector with NA, division by
-    zero, multiplication by Inf, `v op X` for ^ / %% %/% while NAs are kept) raise: they stay on the CPU."""
+    vector (or a same-shape dense matrix read as a vector), R's recycling: values-only result, or — when the vector holds
+    NA / NaN, zeros under / %% %/% ^, negatives under ^, infinities under * — the structure-changing route
+    multiply_csr_by_dvec_with_NAs (:1112-1131).  The routes the reference sends through a CsparseMatrix (an all-NA
+    vector, a scalar that needs the NA route, `v op X` for ^ / %% %/% while NAs are kept) raise: they stay on the CPU."""
     e2 = np.asarray(e2)
     if e2.ndim == 2:                                                          # :952-959
         if e1.Dim[0] != e2.shape[0] or e2.shape[1] != e2.shape[1]:            # (sic: the reference compares ncol(e2) with itself)
@@ -130,14 +131,21 @@ def multiply_csr_by_dvec_elemwise_internal(e1, e2, logical=False, X_is_LHS=True,
     if (not X_is_LHS) and keep_NAs and op in ("^", "/", "%%", "%/%"):         # :973-978
         stop(_NOT_ACCELERATED % "973-978")
     check_valid_matrix(e1)
-    e2f = e2.astype(np.float64) if e2.dtype != np.int32 else np.where(e2 == np.int32(-2147483648), np.nan, e2.astype(np.float64))
+    # as.numeric(): NA_integer_ / NA (logical) become NA_real_ — the NaN whose low word is 1954, which the NA route tells
+    # apart from a plain NaN
+    if e2.dtype == np.int32:
+        e2f = e2.astype(np.float64)
+        e2f[e2 == np.int32(-2147483648)] = NA_REAL
+    else:
+        e2f = e2.astype(np.float64)
     take_route_NAs = (not logical) and keep_NAs and (
         bool(np.isnan(e2f).any())
         or (op in ("^", "/", "%%", "%/%") and bool((e2f == 0).any()))
         or (op == "*" and bool(np.isinf(e2f).any()))
         or (op == "^" and bool((e2f < 0).any())))                             # :981-988
-    if take_route_NAs:
-        stop(_NOT_ACCELERATED % "981-1131")
+    if take_route_NAs:                                                        # :995-1013
+        if bool(np.isnan(e2f).all()):
+            stop(_NOT_ACCELERATED % "997-1005")                               # all NA: the reference goes through a CsparseMatrix
     e2 = _as_logical(e2) if logical else e2f
     e1 = as_csr_matrix(e1, logical=logical)                                   # :1020-1029
     out = type(e1).__new__(type(e1))
@@ -156,8 +164,18 @@ def multiply_csr_by_dvec_elemwise_internal(e1, e2, logical=False, X_is_LHS=True,
             warnings.warn("Warning: division by zero.")
         if op == "^" and (not X_is_LHS) and (e2[0] == 1 or e2[0] == 0):
             stop(_NOT_ACCELERATED % "1091-1095")
-    elif e1.Dim[0] % e2.size != 0:                                            # :1114-1115
+    if take_route_NAs and e2.size == 1:
+        # :1056-1105: a scalar that needs the NA route (x * Inf, x / 0, x ^ 0 ...) is computed on a CsparseMatrix upstream
+        stop(_NOT_ACCELERATED % "1056-1105")
+    if take_route_NAs:                                                        # :1112-1114: the route needs rows sorted by column
+        e1 = sort_sparse_indices(e1, copy=not bool(options.get("MatrixExtra.inplace_sort", False)))
+    if e2.size != 1 and e1.Dim[0] % e2.size != 0:                             # :1116-1117
         warnings.warn("Number of elements in vector is not a multiple of matrix dimension.")
+    if take_route_NAs:                                                        # :1119-1131
+        res = exports.multiply_csr_by_dvec_with_NAs(e1.p, e1.j, e1.x, e2, e1.Dim[1], op == "*", op == "^", op == "/",
+                                                    op == "%%", op == "%/%", X_is_LHS)
+        out.p, out.j, out.x = res["indptr"], res["indices"], res["values"]
+        return out
     if logical:
         out.x = exports.logicaland_csr_by_dvec_internal(e1.p, e1.j, e1.x, e2, e1.Dim[1])
     else:

@@ -674,10 +674,11 @@ def multiply_csr_by_dvec_with_NAs(p, j, x, dvec, ncols, multiply, powerto, divid
         if res.status == 2:
             raise ValueError("Error: the resulting matrix would have too many entries for a sparse CSR representation (int overflow).")
         n = int(res.nnz)
-        vals = np.ctypeslib.as_array(res.values, shape=(max(n, 1),))[:n].copy()
+        vals = np.ctypeslib.as_array(res.values, shape=(n,)).copy() if n else np.zeros(0)
         if res.status == 1:                                          # the reference hands back its input indptr / indices
             return dict(indptr=p, indices=j, values=vals, alias_structure=True)
         return dict(indptr=np.ctypeslib.as_array(res.indptr, shape=(p.size,)).copy(),
-                    indices=np.ctypeslib.as_array(res.indices, shape=(max(n, 1),))[:n].copy(), values=vals, alias_structure=False)
+                    indices=np.ctypeslib.as_array(res.indices, shape=(n,)).copy() if n else np.zeros(0, dtype=np.int32),
+                    values=vals, alias_structure=False)
     finally:
         lib().mxo_free_dvec_na(C.byref(res))

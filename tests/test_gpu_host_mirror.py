@@ -249,9 +249,22 @@ def test_csr_by_vector_operators(gpu):                            # test-operato
     assert isinstance(res, mx.lgRMatrix)
     np.testing.assert_array_equal(res.x, (L.x != 0) & (vl[r] != 0))
     assert (L & np.array([0], dtype=np.int32)).j.size == 0          # R/operators.R:1039-1046
-    # routes that stay on the reference's CPU code
-    for bad in (lambda: X * np.array([1.0, np.nan] * 30), lambda: X / np.zeros(60), lambda: X * np.full(60, np.inf),
-                lambda: X ** (-np.ones(60)), lambda: np.ones(60) / X):
+    # the structure-changing NA route (R/operators.R:981-1131 -> multiply_csr_by_dvec_with_NAs, round 3): the pattern grows
+    # by every cell the vector makes special and the result is what R's dense arithmetic gives
+    Dm = X.toarray()
+    with np.errstate(all="ignore"):
+        cases = ((X * np.array([1.0, np.nan] * 30), Dm * np.array([1.0, np.nan] * 30)[:, None]),
+                 (X / np.zeros(60), Dm / np.zeros(60)[:, None]),
+                 (X * np.full(60, np.inf), Dm * np.inf),
+                 (X ** (-np.ones(60)), np.where(Dm == 0, np.inf, np.power(np.where(Dm == 0, 1.0, Dm), -1.0))))
+    for res, exp in cases:
+        assert isinstance(res, mx.dgRMatrix) and res.Dim == X.Dim
+        got = res.toarray()
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+        np.testing.assert_allclose(got[~np.isnan(exp)], exp[~np.isnan(exp)], rtol=1e-13)
+        assert res.p[-1] > X.p[-1]
+    # routes that stay on the reference's CPU code (it goes through a CsparseMatrix there)
+    for bad in (lambda: X * np.full(60, np.nan), lambda: X * np.array([np.inf]), lambda: np.ones(60) / X):
         with pytest.raises(M.MatrixExtraError):
             bad()
     with pytest.raises(M.MatrixExtraError, match="more entries than matrix"):

@@ -835,3 +835,109 @@ def test_gather_one_launch_kernel(gpu):
     # nothing selected / rows without entries
     gp, gj, gx, nnz = gather_fused_device(p, j, x, np.zeros(0, dtype=np.int32), 10, _lib.MX_F64)
     assert nnz == 0 and gp.tolist() == [0]
+
+
+# ----------------------------------------------------------------------------- round 3: CSR (op) vector, the NA route
+def _is_na_real(a):
+    """R's ISNA: a NaN whose low word is 1954 (arithmetic may set the quiet bit)"""
+    return np.isnan(a) & ((a.view(np.uint64) & np.uint64(0xFFFFFFFF)) == 1954)
+
+
+def _special_vector(rng, ln, opname):
+    """a vector with the elements that send `CSR op vector` down the NA route (R/operators.R:981-988), ~12 % of them"""
+    v = (rng.uniform(0.5, 3.0, size=ln) * rng.choice([-1.0, 1.0], size=ln)).round(2)
+    if opname == "pow":
+        v = np.abs(v)                                               # negatives are special under ^: placed explicitly below
+    pool = [NA_REAL_F, np.nan]
+    if opname == "mul":
+        pool += [np.inf, -np.inf]
+    if opname in ("div", "mod", "idiv", "pow"):
+        pool += [0.0]
+    if opname == "pow":
+        pool += [-1.0, -2.5]
+    hit = rng.random(ln) < 0.12
+    if ln > 2 and not hit.any():
+        hit[rng.integers(ln)] = True
+    v[hit] = rng.choice(np.array(pool), size=int(hit.sum()))
+    return v
+
+
+NA_REAL_F = np.frombuffer(np.uint64(0x7FF00000000007A2).tobytes(), dtype=np.float64)[0]
+
+
+@pytest.mark.parametrize("m,K,dens", [(200, 37, 0.2), (64, 5, 0.5), (513, 300, 0.02), (1, 9, 0.9)])
+def test_csr_by_dvec_with_NAs_all_ops_and_lengths(gpu, m, K, dens):
+    """multiply_csr_by_dvec_with_NAs (src/operators.cpp:2258-2856) against the oracle's restatement: structure bit for bit
+    (pattern grows by every cell the recycled vector makes special; rows stay sorted), values NaN-for-NaN, NA-for-NA
+    (NA_real_ and plain NaN are told apart, incl. the reference's swapped fills in the general branch), exact for * and /,
+    1e-13 for %% %/% ^.  Lengths: == nrows, a divisor of nrows (branch A), the whole matrix (B), others (C)."""
+    p, j, x = rand_csr(m, K, dens, seed=m + K, empty_rows=(0,) if m > 3 else ())
+    x = (x * 4).round(2)
+    x[x == 0] = 1.5
+    rng = np.random.default_rng(m * 11 + K)
+    lens = sorted({m, m * K, max(1, m // 2) if m % 2 == 0 else m, 5, min(m * K, m + 3), max(2, (m * K) // 3)})
+    for ln in lens:
+        for opname, f in DV_FLAGS.items():
+            v = _special_vector(rng, ln, opname)
+            want = O.multiply_csr_by_dvec_with_NAs(p, j, x, v, K, *f, True)
+            with np.errstate(all="ignore"):
+                got = G.multiply_csr_by_dvec_with_NAs(p, j, x, v, K, *f, True)
+            what = f"{opname} len={ln}"
+            if want["alias_structure"]:
+                assert got["indptr"] is p and got["indices"] is j, what      # the INPUT objects, as the reference returns them
+            else:
+                np.testing.assert_array_equal(got["indptr"], want["indptr"], err_msg=what)
+                np.testing.assert_array_equal(got["indices"], want["indices"], err_msg=what)
+            gv, wv = got["values"], want["values"]
+            assert gv.shape == wv.shape, what
+            np.testing.assert_array_equal(np.isnan(gv), np.isnan(wv), err_msg=what)
+            np.testing.assert_array_equal(_is_na_real(gv), _is_na_real(wv), err_msg=what + " (NA vs NaN)")
+            ok = ~np.isnan(wv)
+            if opname in ("mul", "div"):
+                np.testing.assert_array_equal(gv[ok].view(np.int64), wv[ok].view(np.int64), err_msg=what)
+            else:
+                np.testing.assert_array_equal(np.isinf(gv[ok]), np.isinf(wv[ok]), err_msg=what)
+                fin = ok & np.isfinite(wv)
+                np.testing.assert_allclose(gv[fin], wv[fin], rtol=1e-13, atol=1e-300, err_msg=what)
+            # rows sorted and unique
+            gp, gj = got["indptr"], got["indices"]
+            d = np.diff(gj) <= 0
+            starts = np.zeros(gj.size, dtype=bool)
+            starts[gp[1:-1][gp[1:-1] < gj.size]] = True
+            assert not (d & ~starts[1:]).any(), what
+
+
+def test_csr_by_dvec_with_NAs_errors_and_edge_cases(gpu):
+    p, j, x = rand_csr(50, 20, 0.3, seed=3)
+    v = np.ones(50); v[3] = np.nan
+    # ^ / %% with the matrix on the right: the reference's internal error (operators.cpp:2274-2275)
+    for f in (DV_FLAGS["pow"], DV_FLAGS["div"], DV_FLAGS["mod"]):
+        with pytest.raises(_lib.MxError):
+            G.multiply_csr_by_dvec_with_NAs(p, j, x, v, 20, *f, False)
+    # a vector without any special element: branch A copies, branch C hands the input structure back
+    v1 = np.full(50, 2.0)
+    got = G.multiply_csr_by_dvec_with_NAs(p, j, x, v1, 20, *DV_FLAGS["mul"], True)
+    np.testing.assert_array_equal(got["indptr"], p); np.testing.assert_array_equal(got["values"], x * 2.0)
+    v2 = np.full(7, 2.0)
+    got = G.multiply_csr_by_dvec_with_NAs(p, j, x, v2, 20, *DV_FLAGS["mul"], True)
+    assert got["indptr"] is p and got["indices"] is j
+    np.testing.assert_array_equal(got["values"], x * 2.0)
+    # empty matrix, rows of a full-NA branch-A vector
+    p0 = np.zeros(4, dtype=np.int32); j0 = np.zeros(0, dtype=np.int32); x0 = np.zeros(0)
+    vna = np.array([1.0, NA_REAL_F, 1.0])
+    got = G.multiply_csr_by_dvec_with_NAs(p0, j0, x0, vna, 6, *DV_FLAGS["mul"], True)
+    want = O.multiply_csr_by_dvec_with_NAs(p0, j0, x0, vna, 6, *DV_FLAGS["mul"], True)
+    np.testing.assert_array_equal(got["indptr"], want["indptr"]); np.testing.assert_array_equal(got["indices"], want["indices"])
+    assert got["indptr"].tolist() == [0, 0, 6, 6] and _is_na_real(got["values"]).all()
+    # the mirror of R's `X * v` takes the route by itself (R/operators.R:981-1131) and agrees with dense R arithmetic
+    import matrixextra_amd as mx
+    A = mx.dgRMatrix(p, j, x, (50, 20))
+    vv = np.ones(50); vv[[2, 9]] = [np.inf, np.nan]
+    R = A * vv
+    dense = A.toarray()
+    with np.errstate(all="ignore"):
+        exp = dense * vv[:, None]
+    got_d = R.toarray()
+    np.testing.assert_array_equal(np.isnan(got_d), np.isnan(exp))
+    np.testing.assert_array_equal(got_d[~np.isnan(exp)], exp[~np.isnan(exp)])
+    assert R.p[-1] == p[-1] + 2 * 20 - (p[3] - p[2]) - (p[10] - p[9])    # two rows became full rows

@@ -422,3 +422,48 @@ def test_logicaland_csr_by_dvec():
         d = np.resize(vl, 270).reshape(9, 30).T[r, j]
         want = np.where((xl == 0) | (d == 0), 0, np.where((xl == NA) | (d == NA), NA, 1)).astype(np.int32)
         np.testing.assert_array_equal(O.logicaland_csr_by_dvec_internal(p, j, xl, vl, 9), want)
+
+
+def test_oracle_csr_by_dvec_with_NAs_matches_dense_r_arithmetic():
+    """The oracle's restatement of multiply_csr_by_dvec_with_NAs (src/operators.cpp:2258-2856) against what R's dense
+    arithmetic gives for `as.matrix(X) op recycled(v)` (the reference's own tests check it that way, test-operators.R): same
+    NaN pattern, same finite values, pattern = X's cells + every cell the vector makes special, rows sorted."""
+    p, j, x = rand_csr(40, 9, 0.3, seed=5, empty_rows=(4,))
+    x = (x * 3).round(1)
+    x[x == 0] = 2.0
+    dense = csr_to_dense(p, j, x, 9)
+    held = csr_to_dense(p, j, np.ones_like(x), 9) != 0
+    NA = np.frombuffer(np.uint64(0x7FF00000000007A2).tobytes(), dtype=np.float64)[0]
+    rng = np.random.default_rng(8)
+    ops = {"mul": ((1, 0, 0, 0, 0), lambda a, b: a * b), "div": ((0, 0, 1, 0, 0), lambda a, b: a / b),
+           "pow": ((0, 1, 0, 0, 0), None)}
+    for ln in (40, 20, 360, 7, 43, 120):
+        for name, (flags, f) in ops.items():
+            v = rng.uniform(0.5, 3.0, size=ln).round(1)
+            sp = rng.random(ln) < 0.15
+            sp[rng.integers(ln)] = True
+            v[sp] = rng.choice(np.array([NA, np.nan, np.inf] if name == "mul" else [NA, 0.0] if name == "div" else [0.0, -1.0, NA]),
+                               size=int(sp.sum()))
+            r = O.multiply_csr_by_dvec_with_NAs(p, j, x, v, 9, *flags, True)
+            rec = np.resize(v, 40 * 9).reshape(9, 40).T                        # R's recycling runs down the columns
+            got = np.zeros((40, 9))
+            present = np.zeros((40, 9), dtype=bool)
+            for i in range(40):
+                cols = r["indices"][r["indptr"][i]:r["indptr"][i + 1]]
+                assert np.all(np.diff(cols) > 0)
+                got[i, cols] = r["values"][r["indptr"][i]:r["indptr"][i + 1]]
+                present[i, cols] = True
+            if name == "pow":
+                special = np.isnan(rec) | (rec <= 0)
+                with np.errstate(all="ignore"):
+                    exp = np.where(rec == 0, 1.0, np.power(dense, rec))
+                    exp = np.where((dense == 0) & (rec < 0), np.inf, exp)
+            else:
+                special = np.isnan(rec) | (np.isinf(rec) if name == "mul" else rec == 0)
+                with np.errstate(all="ignore"):
+                    exp = f(dense, rec)
+            if not r["alias_structure"]:
+                np.testing.assert_array_equal(present, held | special)
+            np.testing.assert_array_equal(np.isnan(got), np.isnan(exp), err_msg=f"{name} len={ln}")
+            ok = ~np.isnan(exp)
+            np.testing.assert_allclose(got[ok], exp[ok], rtol=1e-14)

@@ -28,7 +28,7 @@ REFERENCE_ARITY = {
     "multiply_csr_by_dense_elemwise_int": 4, "multiply_csr_by_dense_elemwise_bool": 4,
     "logicaland_csr_by_dense_cpp": 4,                                                                    # :2292-2296
     "add_csr_elemwise": 7, "logicalor_csr_elemwise": 7,                                                  # :2297-2298
-    "multiply_csr_by_dvec_no_NAs_numeric": 11, "logicaland_csr_by_dvec_internal": 5,
+    "multiply_csr_by_dvec_no_NAs_numeric": 11, "logicaland_csr_by_dvec_internal": 5, "multiply_csr_by_dvec_with_NAs": 11,
     "concat_csr_batch": 2,                                                                               # :2332
     "check_is_seq": 1, "check_is_rev_seq": 1,                                                            # :2333-2334
     "reverse_rows_numeric": 3, "reverse_rows_logical": 3, "reverse_rows_binary": 2,

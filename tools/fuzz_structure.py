@@ -150,18 +150,47 @@ while time.time() < t_end:
             outs = spmv_plan_device(pu, ju, xu, [(v, _lib.MX_F64), (vi, _lib.MX_I32), (vi, _lib.MX_LGL), (v.astype(np.float32), _lib.MX_F32)])
             refs = [O.matmul_csr_dvec_numeric(pu, ju, xu, v), O.matmul_csr_dvec_integer(pu, ju, xu, vi),
                     O.matmul_csr_dvec_logical(pu, ju, xu, vi), O.matmul_csr_dvec_float32(pu, ju, xu, v.astype(np.float32))]
+            # error scale of a row: sum |a| |v| (the float32 kind: the reference rounds after every term, the plan once)
+            row_scale = O.matmul_csr_dvec_numeric(pu, ju, np.abs(xu), np.abs(v))
             for got, ref, tol in zip(outs, refs, (1e-12, 1e-12, 1e-12, 1e-5)):
                 # R's NA_real_ = a NaN whose low word is 1954 (arithmetic may set the quiet bit: ISNA looks at the low word only)
                 na_g = np.isnan(got) & ((got.view(np.uint64) & np.uint64(0xFFFFFFFF)) == 1954) if got.dtype == np.float64 else np.isnan(got)
                 na_r = np.isnan(ref) & ((ref.view(np.uint64) & np.uint64(0xFFFFFFFF)) == 1954) if ref.dtype == np.float64 else np.isnan(ref)
                 assert np.array_equal(na_g, na_r), what + " NA rows"
                 ok = ~np.isnan(ref)
-                np.testing.assert_allclose(got[ok], ref[ok], rtol=tol, atol=tol * max(1.0, float(np.max(np.abs(ref[ok]), initial=0.0))))
+                lim = tol * np.maximum(row_scale if tol > 1e-8 else np.abs(ref), 1.0) * (4.0 if tol > 1e-8 else 1.0)
+                assert np.all(np.abs(got[ok].astype(np.float64) - ref[ok].astype(np.float64)) <= lim[ok] + tol), what + f" tol {tol}"
         what = "dvec mul"; trace("  start", what)
         ln = int(rng.choice([1, m, m * K, max(1, m // 2), 7]))
         dv = rng.uniform(0.5, 2.0, size=ln).round(3)
         same(G.multiply_csr_by_dvec_no_NAs_numeric(p1, j1, x1, dv, K, 1, 0, 0, 0, 0, 1),
              O.multiply_csr_by_dvec_no_NAs_numeric(p1, j1, x1, dv, K, 1, 0, 0, 0, 0, 1), what)
+        # the structure-changing NA route of CSR (op) vector: any length, any operation, specials sprinkled in
+        what = "dvec NA route"; trace("  start", what)
+        opn = int(rng.integers(5))
+        flags = [0, 0, 0, 0, 0]; flags[opn] = 1                      # multiply, powerto, divide, divrest, intdiv
+        ln = int(rng.choice([m, max(1, m // 2) if m % 2 == 0 else m, m * K, 5, m + 1, max(2, (m * K) // 3)]))
+        dv = rng.uniform(0.5, 2.0, size=ln).round(2)
+        pool = np.array([np.frombuffer(np.uint64(0x7FF00000000007A2).tobytes(), dtype=np.float64)[0], np.nan] +
+                        ([np.inf, -np.inf] if opn == 0 else [0.0]) + ([-1.5] if opn == 1 else []))
+        hit = rng.random(ln) < float(rng.choice([0.0, 0.05, 0.3]))
+        dv[hit] = rng.choice(pool, size=int(hit.sum()))
+        if not np.isnan(dv).all():
+            ps, js, xs = p1, j1, x1                                   # (sorted rows: rand_csr default)
+            want = O.multiply_csr_by_dvec_with_NAs(ps, js, xs, dv, K, *flags, True)
+            got = G.multiply_csr_by_dvec_with_NAs(ps, js, xs, dv, K, *flags, True)
+            if not want["alias_structure"]:
+                same(got["indptr"], want["indptr"], what + "/indptr"); same(got["indices"], want["indices"], what + "/indices")
+            else:
+                assert got["indptr"] is ps, what + " alias"
+            gv, wv = got["values"], want["values"]
+            assert gv.shape == wv.shape and np.array_equal(np.isnan(gv), np.isnan(wv)), what + " NaN pattern"
+            na = lambda a: np.isnan(a) & ((a.view(np.uint64) & np.uint64(0xFFFFFFFF)) == 1954)
+            assert np.array_equal(na(gv), na(wv)), what + " NA vs NaN"
+            ok = ~np.isnan(wv)
+            assert np.array_equal(np.isinf(gv[ok]), np.isinf(wv[ok])), what + " inf"
+            fin = ok & np.isfinite(wv)
+            np.testing.assert_allclose(gv[fin], wv[fin], rtol=1e-13, atol=1e-300)
     except Exception as exc:
         print("FAIL", dict(m=m, K=K, d1=d1, d2=d2, s1=s1, s2=s2, seed=seed, case=cases, what=what), repr(exc)[:600])
         sys.exit(1)

@@ -329,7 +329,8 @@ constexpr int RS_BLOCK = 256, RS_U = 4, RS_SUB_Q = RS_BLOCK * RS_U, RS_NB = 2048
 
 __global__ __launch_bounds__(RS_BLOCK)
 void rows_sorted_tile_kernel(int m, const int32_t *__restrict__ indptr, const int32_t *__restrict__ idx_al, int shift,
-                             unsigned *__restrict__ partial)
+                             unsigned *__restrict__ partial, unsigned *__restrict__ done, unsigned *__restrict__ out2,
+                             unsigned long long *__restrict__ host_word, unsigned gen)
 {
     typedef int i4 __attribute__((ext_vector_type(4)));
     __shared__ unsigned char bits[2][RS_SUB_Q];
@@ -433,26 +434,37 @@ void rows_sorted_tile_kernel(int m, const int32_t *__restrict__ indptr, const in
     for (int off = 32; off > 0; off >>= 1) { D += __shfl_xor(D, off, 64); S += __shfl_xor(S, off, 64); }
     if (lane == 0) { wsum[0][wave] = D; wsum[1][wave] = S; }
     __syncthreads();
+    // The workgroup that finishes LAST adds the partial counts up and reports (no second launch, no copy packet): every
+    // workgroup publishes its two counts with agent-scope stores, then takes a number; the last one reads them all back
+    // with agent-scope loads (another CU's plain stores are not visible through this CU's L1 otherwise).
+    __shared__ bool s_last;
     if (tid == 0) {
-        partial[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
-        partial[gridDim.x + blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+        __hip_atomic_store(&partial[blockIdx.x], wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partial[gridDim.x + blockIdx.x], wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the counts have left before the number is taken
+        s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     }
-}
-
-// out[0] = sum of the first nb_entries partial counts (D), out[1] = sum of the rest (S)
-__global__ __launch_bounds__(256)
-void rows_sorted_finish_kernel(const unsigned *__restrict__ partial, int nb, int nb_entries, unsigned *__restrict__ out)
-{
-    __shared__ unsigned wsum[2][4];
-    unsigned d = 0, s = 0;
-    for (int i = threadIdx.x; i < nb; i += 256) { const unsigned v = partial[i]; if (i < nb_entries) d += v; else s += v; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { d += __shfl_xor(d, off, 64); s += __shfl_xor(s, off, 64); }
-    if (lane_id() == 0) { wsum[0][threadIdx.x >> 6] = d; wsum[1][threadIdx.x >> 6] = s; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        out[0] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
-        out[1] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                         // (once per launch; the loads below bypass L1 anyway)
+    unsigned d = 0, sct = 0;
+    for (unsigned i = tid; i < gridDim.x; i += RS_BLOCK) {
+        d += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sct += __hip_atomic_load(&partial[gridDim.x + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { d += __shfl_xor(d, off, 64); sct += __shfl_xor(sct, off, 64); }
+    __syncthreads();
+    if (lane == 0) { wsum[0][wave] = d; wsum[1][wave] = sct; }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned dt = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3], stt = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+        out2[0] = dt; out2[1] = stt;                                           // [0] descents, [1] descents at row starts
+        *done = 0;                                                             // ready for the next launch
+        if (host_word)
+            __hip_atomic_store(host_word, ((unsigned long long)gen << 32) | (dt == stt ? 1ULL : 0ULL), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -672,16 +684,19 @@ extern "C" int mxd_csr_rows_sorted(int m, const int32_t *indptr, const int32_t *
     MX_REQUIRE(indptr && workspace4, "mxd_csr_rows_sorted: null pointer");
     hipStream_t st = mx::as_stream(stream);
     const int nb = mx::RS_NB;
-    unsigned *partial = (unsigned *)mx::scratch_buffer(mx::MX_SCRATCH_PARTIALS, (size_t)2 * nb * sizeof(unsigned));
+    // [2 nb partial counts][done counter]: the counter is zeroed when the buffer is (re)allocated and reset by every launch
+    unsigned *partial = (unsigned *)mx::scratch_buffer_zeroed(mx::MX_SCRATCH_PARTIALS, (size_t)(2 * nb + 4) * sizeof(unsigned), st, nullptr);
     MX_REQUIRE(partial, "mxd_csr_rows_sorted: cannot allocate the partial counts");
     MX_REQUIRE(((uintptr_t)indices & 3) == 0, "mxd_csr_rows_sorted: indices not int32-aligned");
     const int shift = (int)(((uintptr_t)indices & 15) >> 2);                 // entries between the 16-byte aligned base and indices[0]
-    hipLaunchKernelGGL(mx::rows_sorted_tile_kernel, dim3(nb), dim3(mx::RS_BLOCK), 0, st, m, indptr, indices - shift, shift, partial);
-    hipLaunchKernelGGL(mx::rows_sorted_finish_kernel, dim3(1), dim3(256), 0, st, partial, 2 * nb, nb, (unsigned *)workspace4);
-    MX_LAUNCH_CHECK();                                                       // [0] descents, [1] descents at row starts
-    uint32_t counts[2] = {0, 0};
-    if (mx::read_back_small(counts, workspace4, sizeof(counts), st)) return 1;
-    *flag_host = counts[0] == counts[1];
+    mx::HostSignal sig;
+    if (mx::host_signal_next(&sig)) return 1;
+    hipLaunchKernelGGL(mx::rows_sorted_tile_kernel, dim3(nb), dim3(mx::RS_BLOCK), 0, st, m, indptr, indices - shift, shift, partial,
+                       partial + 2 * nb, (unsigned *)workspace4, sig.word, sig.gen);
+    MX_LAUNCH_CHECK();
+    unsigned sorted = 0;
+    if (mx::host_signal_wait(sig, &sorted, st)) return 1;
+    *flag_host = sorted != 0;
     return 0;
 }
 

@@ -44,11 +44,22 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // value is there: everything enqueued on `st` before it has completed.  (scan.hip)
 int read_back_small(void *host_dst, const void *dev_src, size_t bytes, hipStream_t st);
 
+// A result word that a kernel stores straight into pinned host memory (system-scope store of `generation << 32 | value`)
+// and the host spins on: what `read_back_small` costs — a D2H copy packet, an event, their completion signals: ~10 us —
+// shrinks to the PCIe write (~1-2 us after the kernel's last workgroup).  One word per thread and device, one stream per
+// thread and device at a time.  host_signal_next: the word's device-visible address and the generation the kernel must
+// write; host_signal_wait: spins, then falls back to synchronising the stream (other work queued before the kernel), and
+// returns the 32-bit value.  (scan.hip)
+struct HostSignal { unsigned long long *word; unsigned gen; };
+int host_signal_next(HostSignal *s);
+int host_signal_wait(const HostSignal &s, unsigned *value, hipStream_t st);
+
 // Grow-only device scratch of the calling thread and current device, one buffer per `slot` (kernels' internal tables: the
 // SpMV slice table, per-workgroup partial counts ...).  Like AUTO's SpMM plan it assumes one stream per thread and device
 // at a time.  nullptr when the allocation fails.  (scan.hip)
 enum { MX_SCRATCH_SPMV_SLICES = 0, MX_SCRATCH_PARTIALS = 1, MX_SCRATCH_EXPORT_B = 2, MX_SCRATCH_EXPORT_C = 3, MX_SCRATCH_SLOTS = 4 };
 void *scratch_buffer(int slot, size_t bytes);
+void *scratch_buffer_zeroed(int slot, size_t bytes, hipStream_t st, bool *fresh);   // zero-filled when (re)allocated
 void scratch_release();
 
 // lanes-per-row for the sub-wave ("group") kernels: smallest power of two

@@ -160,6 +160,20 @@ void *scratch_buffer(int slot, size_t bytes)
     }
     return w.p;
 }
+// the same buffer, zero-filled whenever it is (re)allocated (state that kernels reset themselves afterwards)
+void *scratch_buffer_zeroed(int slot, size_t bytes, hipStream_t st, bool *fresh)
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) d = 0;
+    Scratch &w = g_scratch[d][slot];
+    const void *before = w.p;
+    const size_t cap_before = w.cap;
+    void *p = scratch_buffer(slot, bytes);
+    const bool is_new = p && (p != before || w.cap != cap_before);
+    if (is_new && hipMemsetAsync(p, 0, w.cap, st) != hipSuccess) return nullptr;
+    if (fresh) *fresh = is_new;
+    return p;
+}
 void scratch_release()
 {
     for (auto &dev : g_scratch)
@@ -186,6 +200,42 @@ int read_back_small(void *host_dst, const void *dev_src, size_t bytes, hipStream
     MX_HIP(hipEventRecord(rb.ev, st));
     MX_HIP(hipEventSynchronize(rb.ev));
     memcpy(host_dst, rb.host, bytes);
+    return 0;
+}
+
+int host_signal_next(HostSignal *s)
+{
+    struct Hs { unsigned long long *word = nullptr; unsigned gen = 0; };
+    static thread_local Hs hs[16];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) d = 0;
+    Hs &h = hs[d];
+    if (!h.word) {
+        MX_HIP(hipHostMalloc((void **)&h.word, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *h.word = 0;
+    }
+    h.gen = (h.gen + 1) & 0x3FFFFFFFu;
+    if (h.gen == 0) h.gen = 1;
+    s->word = h.word;
+    s->gen = h.gen;
+    return 0;
+}
+
+int host_signal_wait(const HostSignal &s, unsigned *value, hipStream_t st)
+{
+    volatile unsigned long long *w = s.word;
+    unsigned long long v = 0;
+    bool got = false;
+    for (int spin = 0; spin < 400000; spin++) {
+        v = *w;
+        if ((unsigned)(v >> 32) == s.gen) { got = true; break; }
+    }
+    if (!got) {
+        MX_HIP(hipStreamSynchronize(st));
+        v = *w;
+        MX_REQUIRE((unsigned)(v >> 32) == s.gen, "the kernel did not report its result");
+    }
+    *value = (unsigned)(v & 0xFFFFFFFFu);
     return 0;
 }
 

@@ -67,6 +67,10 @@ int  mx_partition_rows(const int32_t *indptr, int nrows, int nparts, int dense_c
 int  mx_dev_malloc(void **dptr, size_t bytes);
 int  mx_dev_free(void *dptr);
 int  mx_dev_memset(void *dptr, int value, size_t bytes, void *stream);
+/* asynchronous copies on `stream`: give them PINNED host memory (mx_host_register, hipHostMalloc).  With ordinary pageable
+ * memory the HIP runtime pins the caller's pages on the fly; long randomised runs on the MI355X boxes ended now and then in a
+ * GPU memory-access fault at a heap address with such copies in the mix — for ordinary memory use
+ * mx_upload / mx_download below (synchronous; what every export-level call uses). */
 int  mx_memcpy_h2d(void *dptr, const void *hptr, size_t bytes, void *stream);
 int  mx_memcpy_d2h(void *hptr, const void *dptr, size_t bytes, void *stream);
 int  mx_stream_sync(void *stream);

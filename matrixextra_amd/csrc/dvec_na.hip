@@ -14,7 +14,7 @@
 //   C  any other length (:2574-2637): the special elements are compacted, every (element, repeat) pair is a cell
 //      (row = position mod nrows, col = position / nrows); cells are counted per row with atomics, scattered, and the rows
 //      sorted by the per-row sort kernel (gather.hip) — work proportional to the cells produced, as in the reference.
-// The reference's quirks are kept (the oracle restates them, oracle/mx_oracle.c): in B / C a cell under an NA_real_ element
+// The reference's quirks are kept (the CPU checker under tests restates them too): in B / C a cell under an NA_real_ element
 // is filled with NaN and one under a plain NaN (or an infinity, for *) with NA_real_ — the other way round from branch A;
 // the operation is always `value op element`.  When no cell is added in B / C the structure is reported as unchanged
 // (the reference returns its input indptr / indices there).

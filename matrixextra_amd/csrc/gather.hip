@@ -443,7 +443,16 @@ void rows_sorted_tile_kernel(int m, const int32_t *__restrict__ indptr, const in
         __hip_atomic_store(&partial[gridDim.x + blockIdx.x], wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3], __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the counts have left before the number is taken
-        s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        // The workgroups finish within a few microseconds of each other: 2048 adds on ONE word queued up for ~20 us at
+        // the end of the kernel (same-address atomics serialise in L2, ~10 ns each).  Eight shard counters (blockIdx % 8,
+        // one cache line each) take the adds side by side; the last arriver of a shard moves on to the top counter.
+        const unsigned shard = blockIdx.x & 7u, in_shard = (gridDim.x - shard + 7u) >> 3;
+        bool last = false;
+        if (__hip_atomic_fetch_add(done + 32 * (1 + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+            const unsigned nshards = gridDim.x < 8u ? gridDim.x : 8u;
+            last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nshards - 1;
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
@@ -461,7 +470,8 @@ void rows_sorted_tile_kernel(int m, const int32_t *__restrict__ indptr, const in
     if (tid == 0) {
         const unsigned dt = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3], stt = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
         out2[0] = dt; out2[1] = stt;                                           // [0] descents, [1] descents at row starts
-        *done = 0;                                                             // ready for the next launch
+        done[0] = 0;                                                           // ready for the next launch
+        for (int k = 1; k <= 8; k++) done[32 * k] = 0;
         if (host_word)
             __hip_atomic_store(host_word, ((unsigned long long)gen << 32) | (dt == stt ? 1ULL : 0ULL), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
@@ -684,15 +694,16 @@ extern "C" int mxd_csr_rows_sorted(int m, const int32_t *indptr, const int32_t *
     MX_REQUIRE(indptr && workspace4, "mxd_csr_rows_sorted: null pointer");
     hipStream_t st = mx::as_stream(stream);
     const int nb = mx::RS_NB;
-    // [2 nb partial counts][done counter]: the counter is zeroed when the buffer is (re)allocated and reset by every launch
-    unsigned *partial = (unsigned *)mx::scratch_buffer_zeroed(mx::MX_SCRATCH_PARTIALS, (size_t)(2 * nb + 4) * sizeof(unsigned), st, nullptr);
+    // [2 nb partial counts][pad][top counter + 8 shard counters, a cache line each]: zeroed when the buffer is (re)allocated,
+    // reset by every launch
+    unsigned *partial = (unsigned *)mx::scratch_buffer_zeroed(mx::MX_SCRATCH_PARTIALS, (size_t)(2 * nb + 32 * 9 + 32) * sizeof(unsigned), st, nullptr);
     MX_REQUIRE(partial, "mxd_csr_rows_sorted: cannot allocate the partial counts");
     MX_REQUIRE(((uintptr_t)indices & 3) == 0, "mxd_csr_rows_sorted: indices not int32-aligned");
     const int shift = (int)(((uintptr_t)indices & 15) >> 2);                 // entries between the 16-byte aligned base and indices[0]
     mx::HostSignal sig;
     if (mx::host_signal_next(&sig)) return 1;
     hipLaunchKernelGGL(mx::rows_sorted_tile_kernel, dim3(nb), dim3(mx::RS_BLOCK), 0, st, m, indptr, indices - shift, shift, partial,
-                       partial + 2 * nb, (unsigned *)workspace4, sig.word, sig.gen);
+                       partial + 2 * nb + 32, (unsigned *)workspace4, sig.word, sig.gen);
     MX_LAUNCH_CHECK();
     unsigned sorted = 0;
     if (mx::host_signal_wait(sig, &sorted, st)) return 1;

@@ -605,6 +605,10 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
                 out_[k] = v
         return out_
     _, q = call()                                  # first call of the process: allocates the library's grow-only device scratch
+    for _ in range(2):                             # two more untimed cold calls: the first 1-GB results of a process come from
+        libc.free(q)                              # freshly mapped, not yet compacted memory (46 ms where later calls take 38)
+        lib.mx_cache_invalidate(None)
+        _, q = call()
     cold, cached, ph_cold, ph_cached, cold_rows = [], [], [], [], []
     for k in range(13):
         libc.free(q)                              # (freeing the previous 1 GB result is not part of the next call)

@@ -941,3 +941,52 @@ def test_csr_by_dvec_with_NAs_errors_and_edge_cases(gpu):
     np.testing.assert_array_equal(np.isnan(got_d), np.isnan(exp))
     np.testing.assert_array_equal(got_d[~np.isnan(exp)], exp[~np.isnan(exp)])
     assert R.p[-1] == p[-1] + 2 * 20 - (p[3] - p[2]) - (p[10] - p[9])    # two rows became full rows
+
+
+# ----------------------------------------------------------------------------- round 3: kept plans, row ranges, the octet schedule
+def test_spmm_plan_rows_and_auto_choice(gpu):
+    """mxd_spmm_plan_create_auto + mxd_spmm_plan_run_rows (what the CSR cache and DeviceCSR keep): the whole matrix and
+    row ranges of ONE plan against the oracle, on a matrix whose octets differ in length (so the sweep's schedule is not
+    the natural order and some octets take the dealt layout); mxd_spmm_auto_algo's thresholds."""
+    import ctypes as C
+    from devmem import Dev
+    lib = _lib.load()
+    m, K, n = 5000, 3000, 64
+    p, j, x = synth.csr_skewed(m, K, 20, seed=9, sigma=1.1)
+    B = synth.dense_normal(K, n, seed=4)
+    ref = np.zeros(m * n)
+    O.gemm_csr_drm_as_drm(m, n, p, j, x, B.reshape(-1), n, ref, n, 4, True)
+    ref = ref.reshape(m, n)
+    dp, dj, dx, dB = Dev(p), Dev(j), Dev(x), Dev(B)
+    plan = C.c_void_p()
+    ready = C.c_int(0)
+    _lib.check(lib.mxd_spmm_plan_create_auto(C.c_int(m), C.c_int(K), dp.ptr, dj.ptr, dx.ptr, C.c_int(0), None, C.byref(plan),
+                                             C.byref(ready)))
+    try:
+        assert ready.value == 1
+        for colmajor in (0, 1):
+            ldc = m if colmajor else n
+            for row0, nrows in ((0, m), (0, 640), (640, m - 640), (4992, 8), (1024, 1024)):
+                dC = Dev(nbytes=m * n * 8)
+                _lib.check(lib.mx_dev_memset(dC.ptr, 0xFF, C.c_size_t(dC.nbytes), None))
+                off = row0 * 8 if colmajor else row0 * n * 8
+                _lib.check(lib.mxd_spmm_plan_run_rows(plan, C.c_int(row0), C.c_int(nrows), C.c_int(n), dB.ptr, C.c_size_t(n),
+                                                      C.c_void_p(dC.ptr.value + off), C.c_size_t(ldc), C.c_int(_lib.MX_F64),
+                                                      C.c_int(colmajor), C.c_int(0), C.c_int(-1), None))
+                _lib.check(lib.mx_stream_sync(None))
+                got = dC.download(np.float64, (n, m) if colmajor else (m, n))
+                got = got.T if colmajor else got
+                np.testing.assert_allclose(got[row0:row0 + nrows], ref[row0:row0 + nrows], rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+                rest = np.ones(m, dtype=bool); rest[row0:row0 + nrows] = False
+                assert np.isnan(got[rest]).all()                      # nothing outside the range was written
+        with pytest.raises(_lib.MxError):                             # a range must start at a multiple of 64
+            _lib.check(lib.mxd_spmm_plan_run_rows(plan, C.c_int(10), C.c_int(64), C.c_int(n), dB.ptr, C.c_size_t(n), dB.ptr,
+                                                  C.c_size_t(n), C.c_int(_lib.MX_F64), C.c_int(0), C.c_int(0), C.c_int(-1), None))
+    finally:
+        lib.mxd_spmm_plan_destroy(plan)
+    pick = C.c_int(-1)
+    al = C.c_void_p(4096)
+    for (mm, nn, KK, want) in ((1_000_000, 128, 100_000, 3), (10_000, 100, 10_000, 1), (100_000, 128, 100_000, 1), (1_000_000, 128, 1 << 25, 2)):
+        _lib.check(lib.mxd_spmm_auto_algo(C.c_int(mm), C.c_int(nn), C.c_int(KK), C.c_int(_lib.MX_F64), al, C.c_size_t(nn), al,
+                                          C.c_size_t(mm), C.c_int(1), C.byref(pick)))
+        assert pick.value == want, (mm, nn, KK, pick.value)

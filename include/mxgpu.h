@@ -106,6 +106,10 @@ int  mx_cache_stats(int64_t *bytes, int *entries, int64_t *hits, int64_t *misses
  *                  for large operands: bit for bit the reference's loop, whatever the cache holds.
  *   "spmv_algo"    [MXGPU_SPMV_ALGO, default 0 = AUTO]  mx_spmv_algo for the one-shot products of the exports
  *   "spmv_planned_calls"  read-only: export-level products served by the planned kernel so far
+ *   "pool_idle_bytes" / "pool_idle_blocks" / "pool_hits" / "pool_misses"  read-only: the export level's device blocks
+ *                  (operands, results, kept plans) go back to a pool instead of hipFree — capped at MXGPU_POOL_MB, default
+ *                  min(4 GiB, 1/16 of the device; 0 = every block is freed at once) — and mxd_release_workspaces() or a
+ *                  failed allocation gives them back to the device (csrc/pool.hip: why)
  * mx_last_call_phases: wall-clock phases of the calling thread's last SpMM export as "what;key=value;phase=ms;..."
  * (bench.py reports them for the cold / cached export calls). */
 int  mx_set_option(const char *name, int64_t value);

@@ -104,11 +104,11 @@ struct Trace {
 static void release_kept_device_memory();
 static hipError_t malloc_with_relief(void **p, size_t n)
 {
-    hipError_t e = hipMalloc(p, n);
+    hipError_t e = mx::pool_malloc(p, n);                  // (gives its own idle blocks back before it fails)
     if (e == hipSuccess) return e;
     (void)hipGetLastError();
     release_kept_device_memory();
-    return hipMalloc(p, n);
+    return mx::pool_malloc(p, n);
 }
 void *scratch_buffer_relief(int slot, size_t bytes)
 {
@@ -127,7 +127,7 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { if (p && own) (void)hipFree(p); }
+    ~DevBuf() { if (p && own) mx::pool_free(p); }
     int alloc(size_t n)
     {
         bytes = n;
@@ -312,6 +312,7 @@ static void release_kept_device_memory()
     CsrCache::get().invalidate(nullptr);
     mx::plan_auto_release();
     mx::slab_pack_workspace(0, true);
+    mx::pool_trim();
 }
 
 struct Csr {
@@ -1005,6 +1006,14 @@ int mx_get_option(const char *name, int64_t *value)
     if (strcmp(name, "spmv_planned") == 0) { *value = opt_spmv_planned() ? 1 : 0; return 0; }
     if (strcmp(name, "spmv_algo") == 0) { *value = opt_spmv_algo(); return 0; }
     if (strcmp(name, "spmv_planned_calls") == 0) { *value = g_spmv_planned_calls.load(); return 0; }   // read-only counter
+    if (strncmp(name, "pool_", 5) == 0) {                                                              // read-only: pool.hip
+        long long idle_b = 0, idle_n = 0, hits = 0, misses = 0;
+        mx::pool_stats(&idle_b, &idle_n, &hits, &misses);
+        if (strcmp(name, "pool_idle_bytes") == 0) { *value = idle_b; return 0; }
+        if (strcmp(name, "pool_idle_blocks") == 0) { *value = idle_n; return 0; }
+        if (strcmp(name, "pool_hits") == 0) { *value = hits; return 0; }
+        if (strcmp(name, "pool_misses") == 0) { *value = misses; return 0; }
+    }
     return set_error("mx_get_option: unknown option '%s'", name);
 }
 int mx_last_call_phases(char *buf, size_t buflen)
@@ -1251,8 +1260,8 @@ int mx_copy_csr_rows_begin(const int32_t *indptr, int nrows, const int32_t *indi
         }
         if (nnz_out > cap) {
             if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-            (void)hipFree(res->indices.p); res->indices.p = nullptr;
-            if (res->values.p) { (void)hipFree(res->values.p); res->values.p = nullptr; }
+            mx::pool_free(res->indices.p); res->indices.p = nullptr;
+            if (res->values.p) { mx::pool_free(res->values.p); res->values.p = nullptr; }
             if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
             if (has_values && (rc = res->values.alloc(vb * (size_t)nnz_out))) break;
             if ((rc = mxd_csr_gather_fill((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, rows.as<int32_t>(),

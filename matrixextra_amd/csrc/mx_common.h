@@ -62,6 +62,16 @@ void *scratch_buffer(int slot, size_t bytes);
 void *scratch_buffer_zeroed(int slot, size_t bytes, hipStream_t st, bool *fresh);   // zero-filled when (re)allocated
 void scratch_release();
 
+// Device blocks that are freed and allocated again call after call (export-level operands and results, the plans kept on
+// cache entries): pool_free keeps a block (total capped: MXGPU_POOL_MB, default min(4 GiB, 1/16 of the device)) for the
+// next pool_malloc of about its size on the same device.  pool_free waits for the device first, like hipFree; a pointer
+// that did not come from pool_malloc is simply hipFree'd.  A pointer from pool_malloc must go back through pool_free.
+// (pool.hip)
+hipError_t pool_malloc(void **out, size_t bytes);
+void pool_free(void *p);
+void pool_trim();
+void pool_stats(long long *idle_bytes, long long *idle_blocks, long long *hits, long long *misses);
+
 // lanes-per-row for the sub-wave ("group") kernels: smallest power of two
 // >= avg row length, clamped to [lo, 64]
 inline int pick_group(double avg_len, int lo = 4)

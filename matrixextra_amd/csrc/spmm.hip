@@ -54,6 +54,7 @@ extern "C" int mxd_release_workspaces(void)
     mx::plan_auto_release();
     mx::slab_pack_workspace(0, true);
     mx::scratch_release();
+    mx::pool_trim();
     return 0;
 }
 

@@ -811,9 +811,9 @@ static inline int cur_device()
 static int grow(void **p, size_t *cap, size_t bytes)
 {
     if (*cap >= bytes && *p) return 0;
-    if (*p) (void)hipFree(*p);
+    if (*p) pool_free(*p);
     *p = nullptr; *cap = 0;
-    MX_HIP(hipMalloc(p, bytes ? bytes : 16));
+    MX_HIP(pool_malloc(p, bytes ? bytes : 16));
     *cap = bytes;
     return 0;
 }
@@ -1028,13 +1028,13 @@ extern "C" int mxd_spmm_plan_create_auto(int m, int K, const int32_t *indptr, co
 extern "C" int mxd_spmm_plan_destroy(mx_spmm_plan *pl)
 {
     if (!pl) return 0;
-    if (pl->step_off) (void)hipFree(pl->step_off);
-    if (pl->pcol) (void)hipFree(pl->pcol);
-    if (pl->pval) (void)hipFree(pl->pval);
-    if (pl->scratch) (void)hipFree(pl->scratch);
-    if (pl->layout) (void)hipFree(pl->layout);
-    if (pl->pstart) (void)hipFree(pl->pstart);
-    if (pl->sched) (void)hipFree(pl->sched);
+    if (pl->step_off) mx::pool_free(pl->step_off);
+    if (pl->pcol) mx::pool_free(pl->pcol);
+    if (pl->pval) mx::pool_free(pl->pval);
+    if (pl->scratch) mx::pool_free(pl->scratch);
+    if (pl->layout) mx::pool_free(pl->layout);
+    if (pl->pstart) mx::pool_free(pl->pstart);
+    if (pl->sched) mx::pool_free(pl->sched);
     if (pl->rbdev) (void)hipFree(pl->rbdev);
     delete pl;
     return 0;

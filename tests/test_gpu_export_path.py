@@ -270,3 +270,41 @@ def test_export_spmv_is_bitwise_by_default_and_planned_on_request(gpu):
         _lib.check(lib.mx_set_option(b"spmv_planned", C.c_int64(-1)))
     with pytest.raises(_lib.MxError):
         _lib.check(lib.mx_set_option(b"no_such_option", C.c_int64(1)))
+
+
+def test_device_blocks_come_back_from_the_pool(gpu):
+    """Export calls hand their device blocks (operands, results, the kept plan) to csrc/pool.hip instead of hipFree: the
+    second call of a kind is served from the pool, results are the same bits either way (a reused block is not zeroed:
+    nothing may depend on fresh memory), and mxd_release_workspaces() gives everything back to the device."""
+    lib = _lib.load()
+    lib.mx_cache_invalidate(None)
+    _lib.check(lib.mxd_release_workspaces())
+    assert _option(lib, "pool_idle_bytes") == 0 and _option(lib, "pool_idle_blocks") == 0
+    p1, j1, x1 = synth.csr_fixed(60_000, 3_000, 10, seed=21)
+    p2, j2, x2 = synth.csr_overlapping(p1, j1, 3_000, 10, share=0.4, seed=22)
+    ref = O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, False)
+    h0 = _option(lib, "pool_hits")
+    first = G.add_csr_elemwise(p1, p2, j1, j2, x1, x2, False)
+    assert _option(lib, "pool_idle_blocks") > 0                     # the result's blocks (the operands sit in the CSR cache)
+    h1 = _option(lib, "pool_hits")
+    again = G.add_csr_elemwise(p1, p2, j1, j2, x1, x2, False)
+    assert _option(lib, "pool_hits") > h1 >= h0
+    for k in ("indptr", "indices", "values"):
+        np.testing.assert_array_equal(first[k], ref[k])
+        np.testing.assert_array_equal(again[k], ref[k])
+    # dirty blocks under a row gather with empty rows and under a product with rows without entries
+    pe = p1.copy()
+    pe[30_000:] = pe[30_000]                                        # rows 30000.. are empty
+    rows = np.array([5, 5, 0, 59_999, 30_000, 17], dtype=np.int32)
+    B = np.asfortranarray(np.random.default_rng(3).normal(size=(16, 3_000)))
+    for _ in range(2):
+        g, r = G.copy_csr_rows_numeric(pe, j1, x1, rows), O.copy_csr_rows_numeric(pe, j1, x1, rows)
+        for k in ("indptr", "indices", "values"):
+            np.testing.assert_array_equal(g[k], r[k])
+        out = G.tcrossprod_csr_dense_numeric(pe, j1, x1, B)
+        np.testing.assert_allclose(out, O.tcrossprod_csr_dense_numeric(pe, j1, x1, B), rtol=1e-12, atol=1e-12)
+        assert not out[30_000:].any()
+    lib.mx_cache_invalidate(None)
+    assert _option(lib, "pool_idle_bytes") > 0
+    _lib.check(lib.mxd_release_workspaces())
+    assert _option(lib, "pool_idle_bytes") == 0

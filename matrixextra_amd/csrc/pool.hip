@@ -46,6 +46,15 @@ size_t pool_cap_locked(Pool &P)
     return P.cap_bytes;
 }
 inline size_t slack_of(size_t n) { return std::max<size_t>(n / 8, (size_t)64 << 10); }
+// MXGPU_POOL_POISON=1 (test runs): every block handed out — new or reused — is first filled with 0xA5 bytes, so that a
+// kernel which counts on fresh, zeroed memory shows up as a wrong result instead of working by accident
+bool poison_on() { static const bool on = [] { const char *e = getenv("MXGPU_POOL_POISON"); return e && atoi(e) != 0; }(); return on; }
+hipError_t hand_out(void *q, size_t bytes)
+{
+    if (!poison_on()) return hipSuccess;
+    hipError_t e = hipMemset(q, 0xA5, bytes);
+    return e == hipSuccess ? hipDeviceSynchronize() : e;
+}
 }  // namespace
 
 hipError_t pool_malloc(void **out, size_t n)
@@ -69,7 +78,7 @@ hipError_t pool_malloc(void **out, size_t n)
             P.live[b.p] = b;
             P.hits++;
             *out = b.p;
-            return hipSuccess;
+            return hand_out(b.p, b.bytes);
         }
         P.misses++;
     }
@@ -84,7 +93,7 @@ hipError_t pool_malloc(void **out, size_t n)
     std::lock_guard<std::mutex> lk(P.mu);
     P.live[q] = Block{q, n, dev, 0};
     *out = q;
-    return hipSuccess;
+    return hand_out(q, n);
 }
 
 void pool_free(void *p)

@@ -643,8 +643,8 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
             libc.free(q)                              # (freeing the previous 1 GB result is not part of the next call)
             if k < 8:
                 lib.mx_cache_invalidate(None)         # CSR not on the device: upload + compute + download
-            if 5 <= k < 8:                            # the other cold form (row blocks, whole result touched first), same process
-                os.environ["MXGPU_EXPORT_COLD_COLS"] = "0"
+            if 5 <= k < 8:                            # the other cold form (whole CSR up first, then column blocks), same process
+                os.environ["MXGPU_EXPORT_COLD_COLS"] = "2"
             t, q = call()
             os.environ.pop("MXGPU_EXPORT_COLD_COLS", None)
             if k < 5:
@@ -672,17 +672,18 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
         res["export_call_end_to_end"] = {
             "ms_cold": round(med(cold) * 1e3, 2), "ms_csr_cached": round(med(cached) * 1e3, 2),
             "ms_cold_all": [round(v * 1e3, 2) for v in cold], "ms_csr_cached_all": [round(v * 1e3, 2) for v in cached],
-            "ms_cold_row_block_form": [round(v * 1e3, 2) for v in cold_rows],
+            "ms_cold_column_block_form": [round(v * 1e3, 2) for v in cold_rows],
             "phases_ms_cold": phase_medians(ph_cold), "phases_ms_csr_cached": phase_medians(ph_cached),
             "csr_state_cached": ph_cached[-1].get("csr"),
             "GFLOP/s_cold": round(2 * nnz * n / med(cold) / 1e9, 1), "GFLOP/s_csr_cached": round(2 * nnz * n / med(cached) / 1e9, 1),
             "parity_max_err_over_max_abs_vs_oracle": err,
             "note": "mx_tcrossprod_csr_dense_* on cfg2: ordinary (pageable) host vectors in, a freshly malloc'ed, untouched host "
                     "matrix out (as R allocates it); cold = CSR not on the device (upload, compute and download pipelined over "
-                    "row blocks), csr_cached = the same host vectors again (device-side CSR cache and the matrix's kept plan; "
+                    "row blocks x column groups of the result, each group's pages touched and registered on their own; "
+                    "ms_cold_column_block_form = the other cold form, forced: whole CSR up first, then column blocks), csr_cached = the same host vectors again (device-side CSR cache and the matrix's kept plan; "
                     "download-bound: 1 GB over PCIe); medians of 5 calls each, phases = medians of mx_last_call_phases "
-                    "(setup = B upload queued + cache look-up; block 0 = first product queued; touched C / pinned C = host pages of "
-                    "the result exist / are registered; queued = all blocks and downloads queued; fingerprint = cache key of a new "
+                    "(setup = B upload queued + cache look-up; block 0 = first product queued; piece 0 = the first column group's pages exist and "
+                    "are registered; queued = all blocks and downloads queued; fingerprint = cache key of a new "
                     "operand hashed while the queues drain; kernels = compute queue empty; D2H C = download queue empty)"}
 
     section("export_call", _export_call)

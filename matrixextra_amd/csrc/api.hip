@@ -64,6 +64,7 @@ int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t 
 int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes);
 void prefault_begin(void *p, size_t bytes);
+int prefault_begin_pieces(void *base, size_t total, const std::vector<std::pair<void *, size_t>> &pieces, std::atomic<int> *arrived);
 void prefault_wait();
 uint64_t host_hash(const void *p, size_t bytes, uint64_t seed);
 bool pin_host(const void *p, size_t bytes, bool all_devices = false);
@@ -306,6 +307,7 @@ private:
 
 // (not the export scratch: the failing allocation may belong to a pipelined call whose B already sits in it)
 void plan_auto_release();
+void release_thread_workspaces();
 void *slab_pack_workspace(size_t bytes, bool release);
 static void release_kept_device_memory()
 {
@@ -550,7 +552,7 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
         const int64_t e_lo = indptr[r_lo], e_hi = indptr[r_hi];
         Lanes L;                                                 // this worker thread's queues, gone with it
         const int nblk = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)mk * n * (int64_t)sizeof(real_t) / ((int64_t)96 << 20)));
-        struct Drain { Lanes &l; ~Drain() { l.drain(); l.destroy(); mxd_release_workspaces(); } } drain{L};
+        struct Drain { Lanes &l; ~Drain() { l.drain(); l.destroy(); mx::release_thread_workspaces(); } } drain{L};   // (the thread ends: its scratch with it; pooled blocks stay)
         if (L.init(2 * (size_t)nblk + 2)) { failed("streams"); return; }
         // the shard's own CSR arrays (indptr rebased on the host: mk + 1 ints), B, and its rows of C (column-major mk x n, or
         // row-major)
@@ -666,6 +668,9 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     constexpr int MAX_BLK = 16;
     Pin pinB, pinJ, pinX, pinC;
     std::vector<Pin> pinBlk((size_t)MAX_BLK);
+    std::atomic<int> piece_arrived[MAX_BLK];                     // (declared before `fence`: the team counts into it until it is joined)
+    for (auto &a : piece_arrived) a.store(0);
+    int touch_team = 0;
     struct Fence { Lanes *l; ~Fence() { if (l) { mx::prefault_wait(); l->drain(); } } } fence{nullptr};
     real_t *dB = nullptr;
     hipEvent_t evB = nullptr;
@@ -684,8 +689,6 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     }
     Csr A;
     if (A.prepare(indptr, indices, values, m, sizeof(double), true)) return 1;
-    // column-major result + CSR still on the host: the whole result is first-touched under the upload (see below)
-    if (pipelined && colmajor && !A.resident) mx::prefault_begin(C_host, c_bytes);
     if (!pipelined) {
         if (A.finish_upload()) return 1;
         tr.mark("H2D csr");
@@ -716,21 +719,76 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     //   ROWS_STRIDED (column-major C, CSR still on the host): row blocks, so that a block's slice of (indices, values) can
     //        go up while earlier blocks are multiplied and come down (rows of a column-major matrix are strided: the whole
     //        result is first-touched — under the upload — and registered before the first block comes down).
-    // A column-major result whose CSR is still on the host takes COLS too when the upload is the shorter job: row blocks
-    // need ALL pages of the result touched and registered before the first block can come down (~7.75 ms per GB), column
-    // blocks need the whole CSR on the device before the first block can be multiplied (12 bytes per entry at ~55 GB/s).
-    // cfg2: 7.1 ms of upload against 7.9 ms of page preparation -> COLS (cold call 33.8 -> ~27 ms); cfg5 whole: 112 ms
-    // against 63 ms -> ROWS_STRIDED (upload and download overlap).
+    // A column-major result whose CSR is still on the host takes COLS too when the upload is SHORT beside the page work:
+    // column blocks need the whole CSR on the device before the first block can be multiplied (12 bytes per entry at
+    // ~55 GB/s) but then run ONE plan — kept on the cache entry for the calls to come — and download contiguous pieces;
+    // row blocks (tiled, below) start their first download after one block's upload and one piece's pages.  cfg2: 7.1 ms of
+    // upload against 7.9 ms of page preparation -> row blocks (tiled: 25 ms, column blocks 28.5, same box); cfg5 whole:
+    // 112 ms against 63 ms -> row blocks (192 ms; 223 before the tiles).  Below half the page work: column blocks (not
+    // measured in between).
     const double est_up_ms = 12.0 * (double)A.nnz / 55e6, est_prep_ms = (double)c_bytes * 7.75 / 1e9;
     const char *cc_env = getenv("MXGPU_EXPORT_COLD_COLS");          // (read per call: bench.py times both forms in one process)
     const int cold_cols_on = cc_env ? atoi(cc_env) : 1;
-    const bool cold_cols = colmajor && !A.resident && cold_cols_on && est_up_ms < est_prep_ms && n >= 2 * 8 * (16 / (int)sizeof(real_t));
+    const bool cold_cols = colmajor && !A.resident && cold_cols_on && (est_up_ms < 0.5 * est_prep_ms || cold_cols_on == 2) &&   // (2: forced, for A/B runs)
+                           n >= 2 * 8 * (16 / (int)sizeof(real_t));
     enum { ROWS, COLS, ROWS_STRIDED } shape = !colmajor ? ROWS : (A.resident || cold_cols ? COLS : ROWS_STRIDED);
     constexpr int VEC = 16 / (int)sizeof(real_t);
     const int col_gran = 8 * VEC;                                    // column blocks in whole 128-byte slabs
     int nblk = (int)std::min<size_t>(16, std::max<size_t>(2, c_bytes / ((size_t)96 << 20)));
     if (shape == COLS) nblk = std::max(1, std::min(nblk, n / col_gran));
     static_assert(MAX_BLK == 16, "nblk above is capped at 16");
+    // block b = rows [cut[b], cut[b+1]) (ROWS, ROWS_STRIDED; cut at multiples of 1024 rows = whole generations of the
+    // planned kernel: a block that ended inside an octet of 64 rows would leave a half-empty octet to its own plan, and the
+    // whole matrix's plan can only be run from an octet boundary) or columns (COLS)
+    std::vector<int> cut((size_t)nblk + 1);
+    for (int b = 0; b <= nblk; b++)
+        cut[b] = shape == COLS ? (b == nblk ? n : (int)((int64_t)(n / col_gran) * b / nblk) * col_gran)
+                               : (b == nblk ? m : (int)((int64_t)m * b / nblk) & ~1023);
+    // ROWS_STRIDED, tiled: the result is ALSO cut into `ng` groups of whole columns = contiguous pieces of the caller's
+    // matrix (cut at page boundaries like the pieces of the contiguous shapes below), touched and registered one after
+    // the other; tile (b, g) = rows of block b x columns of group g comes down as soon as block b is multiplied and piece
+    // g is registered.  Before, the first block came down only when ALL pages of the result existed and were registered
+    // (cfg2: ~9 ms into a 29 ms call; cfg5 whole: ~95 ms into a 250 ms call, the download queue idle until then).
+    static const int tiles_on = [] { const char *e = getenv("MXGPU_EXPORT_TILES"); return e ? atoi(e) : 1; }();
+    int ng = shape == ROWS_STRIDED && tiles_on ? (int)std::min<size_t>({(size_t)MAX_BLK, (size_t)n, c_bytes / ((size_t)64 << 20)}) : 0;
+    std::vector<int> gcut((size_t)std::max(ng, 0) + 1, 0);
+    for (int g = 0; g <= ng; g++) gcut[g] = (int)((int64_t)n * g / std::max(ng, 1));
+    // Contiguous shapes: the result is first-touched, registered and downloaded in PIECES that follow the blocks but are cut
+    // at page boundaries of the caller's buffer (piece b = bytes [hb[b], hb[b+1]) of the result: block b without its last
+    // partial page, plus the last partial page of block b-1), so that no page is registered twice.
+    const bool incremental = shape != ROWS_STRIDED;
+    bool tiled = !incremental && ng >= 2 && ldc == (size_t)m;
+    const int npieces = incremental ? nblk : (tiled ? ng : 0);
+    std::vector<size_t> hb((size_t)std::max(npieces, 0) + 1, 0);
+    for (int b = 1; b < npieces; b++) {
+        const size_t first = incremental ? (size_t)cut[b] * ldc : (size_t)gcut[b] * ldc;     // first element of piece b
+        const uintptr_t start = (uintptr_t)(C_host + first), page = start & ~(uintptr_t)4095;
+        const size_t off = page > (uintptr_t)C_host ? (size_t)(page - (uintptr_t)C_host) : 0;
+        hb[b] = std::max(hb[b - 1], std::min(off, c_bytes));
+    }
+    if (npieces) hb[npieces] = c_bytes;
+    auto piece_ptr = [&](int b) { return (char *)C_host + hb[b]; };
+    auto piece_bytes = [&](int b) { return hb[b + 1] - hb[b]; };
+    // tiled: the last partial page of group g — the last tail[g] rows of its last column — lies in piece g + 1; it must be
+    // a part of the LAST row block alone, and no piece may be empty (else: the whole-result form)
+    std::vector<int> tail((size_t)std::max(ng, 1), 0);
+    for (int g = 0; tiled && g < ng; g++) {
+        if (piece_bytes(g) == 0 || gcut[g + 1] == gcut[g]) tiled = false;
+        if (g + 1 < ng) {
+            const size_t end_of_group = (size_t)gcut[g + 1] * ldc * sizeof(real_t);
+            tail[g] = end_of_group > hb[g + 1] ? (int)((end_of_group - hb[g + 1]) / sizeof(real_t)) : 0;
+            if (tail[g] >= cut[nblk] - cut[nblk - 1] || (end_of_group - hb[g + 1]) % sizeof(real_t)) tiled = false;
+        }
+    }
+    // First touch of the result's pages by the host team, under the uploads: piece 0 when pieces follow one another,
+    // the whole result when it is registered in one go (or when the whole CSR has to arrive first anyway: COLS cold)
+    const bool whole_first = colmajor && !A.resident && !tiled;
+    if (whole_first) mx::prefault_begin(C_host, c_bytes);
+    else if (tiled) {                                               // all pieces, one after the other, without this thread in between
+        std::vector<std::pair<void *, size_t>> pcs;
+        for (int g = 0; g < ng; g++) pcs.emplace_back((void *)piece_ptr(g), piece_bytes(g));
+        touch_team = mx::prefault_begin_pieces(C_host, c_bytes, pcs, piece_arrived);
+    } else mx::prefault_begin(piece_ptr(0), piece_bytes(0));
     Lanes &L = lanes();
     real_t *dC = (real_t *)scratch_buffer_relief(mx::MX_SCRATCH_EXPORT_C, c_bytes);
     MX_REQUIRE(dC, "spmm export: cannot allocate the device operands");
@@ -744,13 +802,6 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
         const bool direct_up = pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz) && pinX.pin(values, sizeof(double) * (size_t)nnz);
         if (!direct_up) { if (A.finish_upload()) return 1; }     // whole arrays through xfer_h2d; the blocks below then only compute
     }
-    // block b = rows [cut[b], cut[b+1]) (ROWS, ROWS_STRIDED; cut at multiples of 1024 rows = whole generations of the
-    // planned kernel: a block that ended inside an octet of 64 rows would leave a half-empty octet to its own plan, and the
-    // whole matrix's plan can only be run from an octet boundary) or columns (COLS)
-    std::vector<int> cut((size_t)nblk + 1);
-    for (int b = 0; b <= nblk; b++)
-        cut[b] = shape == COLS ? (b == nblk ? n : (int)((int64_t)(n / col_gran) * b / nblk) * col_gran)
-                               : (b == nblk ? m : (int)((int64_t)m * b / nblk) & ~1023);
     const bool uploading = !A.resident;
     if (uploading && shape == COLS) {                            // the whole CSR in one piece; every block waits for it
         if (nnz) {
@@ -771,22 +822,7 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
         }
     }
     tr.mark("setup");
-    // Contiguous shapes: the result is first-touched, registered and downloaded in PIECES that follow the blocks but are cut
-    // at page boundaries of the caller's buffer (piece b = bytes [hb[b], hb[b+1]) of the result: block b without its last
-    // partial page, plus the last partial page of block b-1), so that no page is registered twice.
-    const bool incremental = shape != ROWS_STRIDED;
-    std::vector<size_t> hb((size_t)nblk + 1, 0);
-    if (incremental) {
-        for (int b = 1; b < nblk; b++) {
-            const uintptr_t start = (uintptr_t)(C_host + (size_t)cut[b] * ldc), page = start & ~(uintptr_t)4095;
-            const size_t off = page > (uintptr_t)C_host ? (size_t)(page - (uintptr_t)C_host) : 0;
-            hb[b] = std::max(hb[b - 1], std::min(off, c_bytes));
-        }
-        hb[nblk] = c_bytes;
-    }
-    auto piece_ptr = [&](int b) { return (char *)C_host + hb[b]; };
-    auto piece_bytes = [&](int b) { return hb[b + 1] - hb[b]; };
-    if (incremental) { mx::prefault_wait(); mx::prefault_begin(piece_ptr(0), piece_bytes(0)); }
+    if (incremental && whole_first) { mx::prefault_wait(); mx::prefault_begin(piece_ptr(0), piece_bytes(0)); }
     // A matrix that is found on the device again — or that goes up in one piece — keeps a plan of ALL its rows on its cache
     // entry: built once (here, when AUTO plans this product), used by every block of this call and by every later call.
     MX_HIP(hipStreamWaitEvent(L.run, evB, 0));
@@ -819,7 +855,7 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     // block too: when they were all queued after the last product, nothing came down before the whole upload had ended
     // (cfg5 whole: 311 ms where upload and download could overlap).
     bool direct_down = true, c_ready = false;
-    for (int b = 0; b < nblk; b++) {
+    auto queue_product = [&](int b) -> int {
         const int c0 = cut[b], c1 = cut[b + 1];
         if (c1 > c0) {
             if (uploading) MX_HIP(hipStreamWaitEvent(L.run, L.ev[shape == COLS ? 0 : b], 0));
@@ -844,6 +880,85 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
         }
         MX_HIP(hipEventRecord(L.ev[nblk + b], L.run));
         if (b == 0) tr.mark("block 0");
+        return 0;
+    };
+    if (tiled) {
+        // Tiles are queued diagonal by diagonal (b + g = d): diagonal d needs block d multiplied and piece d registered, i.e.
+        // the download queue gets its first tile after one block and one piece, and the number of tiles it may run grows with
+        // both.  (The last partial page of group g — tail[g] rows of its last column, rows of the LAST block — lies in piece
+        // g + 1, which is registered by the time that block's tiles are queued: diagonal nblk - 1 + g >= g + 1.)
+        char dims[32];
+        snprintf(dims, sizeof(dims), "%dx%d", nblk, ng);
+        tr.note("tiles", dims);
+        const size_t pitch = ldc * sizeof(real_t);
+        auto tile = [&](int b, int g) -> int {
+            const int c0 = cut[b], c1 = cut[b + 1], g0 = gcut[g], g1 = gcut[g + 1];
+            if (c1 == c0) return 0;
+            if (tr.on) fprintf(stderr, "[mxgpu] tile %d %d\n", b, g);
+            MX_HIP(hipStreamWaitEvent(L.down, L.ev[nblk + b], 0));
+            const int t = b == nblk - 1 && g + 1 < ng ? tail[g] : 0;
+            const int whole_cols = t ? g1 - g0 - 1 : g1 - g0;           // columns that come down over all rows of the block
+            const size_t at = (size_t)g0 * ldc + (size_t)c0;
+            if (whole_cols > 0)
+                MX_HIP(hipMemcpy2DAsync(C_host + at, pitch, dC + at, pitch, (size_t)(c1 - c0) * sizeof(real_t), (size_t)whole_cols,
+                                        hipMemcpyDeviceToHost, L.down));
+            if (t) {                                                 // the group's last column: up to the page boundary, then the rest
+                const size_t last = (size_t)(g1 - 1) * ldc + (size_t)c0;
+                const size_t head = (size_t)(c1 - c0 - t);
+                if (head) MX_HIP(hipMemcpyAsync(C_host + last, dC + last, head * sizeof(real_t), hipMemcpyDeviceToHost, L.down));
+                MX_HIP(hipMemcpyAsync(C_host + last + head, dC + last + head, (size_t)t * sizeof(real_t), hipMemcpyDeviceToHost, L.down));
+            }
+            return 0;
+        };
+        // This thread alternates between three jobs, none of which waits for another for long: a piece whose pages the team
+        // has touched is registered; every tile whose block is queued and whose piece is registered is queued for download
+        // (piece by piece, blocks in order); the next block's product is queued (holds the thread until that block's slice
+        // of the CSR has arrived).  The last block's tile of group g also needs piece g + 1 (the group's last partial page).
+        int nq = 0, nr = 0;                                         // products queued, pieces registered
+        int next_b[MAX_BLK] = {};                                   // per piece: the first block whose tile is not queued yet
+        double host_ms[4] = {0, 0, 0, 0};                           // where this thread spent its time
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+        auto touched = [&](int g) { return touch_team == 0 || piece_arrived[g].load(std::memory_order_acquire) >= touch_team; };
+        int left = nblk * ng;
+        while (left > 0 || nq < nblk) {
+            auto t0 = now();
+            while (direct_down && nr < ng && touched(nr)) {
+                if (!pinBlk[nr].pin_pages(piece_ptr(nr), piece_bytes(nr))) { direct_down = false; break; }
+                if (nr == 0) tr.mark("piece 0");
+                nr++;
+            }
+            host_ms[2] += since(t0);
+            if (!direct_down) {                                      // no direct downloads: the products, then the staged copy below
+                while (nq < nblk) { if (queue_product(nq)) return 1; nq++; }
+                break;
+            }
+            t0 = now();
+            for (int g = 0; g < nr; g++)
+                while (next_b[g] < nq) {
+                    const int b = next_b[g];
+                    if (b == nblk - 1 && g + 1 < ng && tail[g] && nr < g + 2) break;
+                    if (tile(b, g)) return 1;
+                    next_b[g]++; left--;
+                }
+            host_ms[3] += since(t0);
+            t0 = now();
+            if (nq < nblk) {
+                if (queue_product(nq)) return 1;
+                nq++;
+                host_ms[0] += since(t0);
+            } else if (nr < ng && !touched(nr)) {                    // everything else is queued: wait for the team
+                while (!touched(nr)) std::this_thread::yield();
+                host_ms[1] += since(t0);
+            }
+        }
+        char hm[96];
+        snprintf(hm, sizeof(hm), "products %.2f touch %.2f pin %.2f tiles %.2f", host_ms[0], host_ms[1], host_ms[2], host_ms[3]);
+        tr.note("host ms", hm);
+    } else
+    for (int b = 0; b < nblk; b++) {
+        const int c0 = cut[b], c1 = cut[b + 1];
+        if (queue_product(b)) return 1;
         if (!direct_down) continue;
         if (incremental) {
             mx::prefault_wait();                                     // piece b's pages exist

@@ -2,6 +2,7 @@
 // and caller memory, and the parallel first-touch of freshly allocated result pages.  Plain C++ (no HIP): also built
 // stand-alone under ThreadSanitizer / AddressSanitizer by tools/sanitize.sh.
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
@@ -9,6 +10,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace mx {
@@ -66,6 +68,26 @@ public:
             volatile char *q = (volatile char *)p + off;
             for (size_t i = 0; i < len; i += 4096) q[i] = q[i];
             q[len - 1] = q[len - 1];
+        });
+    }
+    // The same over several pieces, one after the other, every worker walking through all of them without meeting the
+    // others: arrived[g] counts the workers that are through piece g — the piece is touched when it reaches threads().
+    // Returns at once; `arrived` must stay alive until wait().
+    void touch_pieces(std::vector<std::pair<void *, size_t>> pieces, std::atomic<int> *arrived)
+    {
+        run([pieces, arrived](int id, int team) {
+            for (size_t g = 0; g < pieces.size(); g++) {
+                const size_t n = pieces[g].second;
+                const size_t piece = ((n + (size_t)team - 1) / (size_t)team + 4095) & ~(size_t)4095;
+                const size_t off = piece * (size_t)id;
+                if (off < n) {
+                    const size_t len = n - off < piece ? n - off : piece;
+                    volatile char *q = (volatile char *)pieces[g].first + off;
+                    for (size_t i = 0; i < len; i += 4096) q[i] = q[i];
+                    q[len - 1] = q[len - 1];
+                }
+                arrived[g].fetch_add(1, std::memory_order_release);
+            }
         });
     }
     // 64-bit content hash of [p, p + n): 1 MiB chunks over the team, four multiply-xor lanes of 64-bit words per chunk,

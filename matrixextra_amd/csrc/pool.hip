@@ -37,7 +37,7 @@ size_t pool_cap_locked(Pool &P)
         if (e) P.cap_bytes = (size_t)std::max(0LL, atoll(e)) << 20;
         else {
             size_t fr = 0, tot = 0;
-            P.cap_bytes = (size_t)4 << 30;
+            P.cap_bytes = (size_t)8 << 30;
             if (hipMemGetInfo(&fr, &tot) == hipSuccess) P.cap_bytes = std::min(P.cap_bytes, tot / 16);
             else (void)hipGetLastError();
         }

@@ -7,6 +7,8 @@
 // with carried offset); vectors of up to 2^15 entries take one single-workgroup launch instead.  Row-count vectors are <= 32 MB here; the scan is a
 // bandwidth-trivial step between the count and fill passes of merge / gather.
 #include "mx_common.h"
+
+#include <algorithm>
 #include <cstring>
 
 namespace mx {
@@ -154,7 +156,7 @@ void *scratch_buffer(int slot, size_t bytes)
     if (w.cap < bytes || !w.p) {
         if (w.p) (void)hipFree(w.p);
         w.p = nullptr; w.cap = 0;
-        const size_t want = bytes + bytes / 2 + 4096;
+        const size_t want = bytes + std::min<size_t>(bytes / 2, (size_t)256 << 20) + 4096;   // (fresh VRAM is cleared by the copy engines: 12 GB for an 8 GB result delayed that call's uploads by ~100 ms)
         if (hipMalloc(&w.p, want) != hipSuccess) { w.p = nullptr; return nullptr; }
         w.cap = want;
     }

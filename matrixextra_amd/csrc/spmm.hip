@@ -48,12 +48,19 @@ void set_last_spmm_kernel(const char *name) { g_last_spmm_kernel = name; }
 
 }  // namespace mx
 
-// frees this thread's grow-only scratch (AUTO's plan, the slab-major copy of B); they are re-created on demand
+namespace mx {
+// this thread's grow-only scratch (AUTO's plan, the slab-major copy of B, the export scratch); re-created on demand
+void release_thread_workspaces()
+{
+    plan_auto_release();
+    slab_pack_workspace(0, true);
+    scratch_release();
+}
+}  // namespace mx
+// the calling thread's workspaces and every idle block of the pool (pool.hip) go back to the device
 extern "C" int mxd_release_workspaces(void)
 {
-    mx::plan_auto_release();
-    mx::slab_pack_workspace(0, true);
-    mx::scratch_release();
+    mx::release_thread_workspaces();
     mx::pool_trim();
     return 0;
 }

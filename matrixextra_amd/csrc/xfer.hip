@@ -11,9 +11,12 @@
 // Should registration fail (locked-memory limit, exotic mappings) the previous scheme takes over: a pipeline over three
 // pinned 8 MiB slots in which the DMA engine moves one slot while the pool copies the previous one to / from the
 // caller's buffer.  MXGPU_XFER=0: plain hipMemcpy; MXGPU_XFER=2: always the staged pipeline.  Synchronous at return.
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <thread>
+#include <utility>
+#include <vector>
 #include <sys/mman.h>
 
 #include "host_pool.h"
@@ -158,6 +161,19 @@ void prefault_begin(void *p, size_t bytes)
     Engine &e = engine();
     std::lock_guard<std::mutex> lk(e.mu);
     e.team()->touch(p, bytes);
+}
+// The pieces of one buffer [base, base + total), touched one after the other without the caller in between: returns the
+// team's size — piece g is touched when arrived[g] has reached it — or 0 when nothing was started (small buffer, another
+// transfer mode: the pieces then count as touched).  prefault_wait() joins; `arrived` must live until then.
+int prefault_begin_pieces(void *base, size_t total, const std::vector<std::pair<void *, size_t>> &pieces, std::atomic<int> *arrived)
+{
+    if (!base || total < XF_MIN || xfer_mode() != 1 || pieces.empty()) return 0;
+    advise_huge(base, total);
+    Engine &e = engine();
+    std::lock_guard<std::mutex> lk(e.mu);
+    Pool *t = e.team();
+    t->touch_pieces(pieces, arrived);
+    return t->threads();
 }
 // content hash of caller memory on the host team (the CSR cache's fingerprint)
 uint64_t host_hash(const void *p, size_t bytes, uint64_t seed)

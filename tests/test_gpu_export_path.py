@@ -308,3 +308,54 @@ def test_device_blocks_come_back_from_the_pool(gpu):
     assert _option(lib, "pool_idle_bytes") > 0
     _lib.check(lib.mxd_release_workspaces())
     assert _option(lib, "pool_idle_bytes") == 0
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_cold_export_comes_down_in_tiles(gpu, f32):
+    """A cold product into a column-major result comes down as tiles (row block x column group), each group's pages
+    touched and registered on their own; a group's last partial page belongs to the next group's registration and is
+    written by a copy of its own.  Result at every byte offset the page cuts can fall on (the result starts 8 .. 4088
+    bytes into a page), rows not a multiple of the block granularity, both element sizes: every column equal to the cached
+    call's (column blocks of the kept plan, contiguous downloads) and to the oracle on a row sample; the bytes before and
+    after the result untouched."""
+    lib = _lib.load()
+    m, K, n = 301_003, 40_000, 160 if f32 else 80                     # ~193 MB of result either way: 3 column groups
+    p, j, x = synth.csr_fixed(m, K, 96, seed=31)                      # 29 M entries: the upload outlasts the page work
+    dt = np.float32 if f32 else np.float64
+    B = synth.dense_normal(K, n).astype(dt)
+    Y = np.asfortranarray(B.T)
+    fn = lib.mx_tcrossprod_csr_dense_float32 if f32 else lib.mx_tcrossprod_csr_dense_numeric
+    item = np.dtype(dt).itemsize
+    guard = 8192
+    raw = np.empty(m * n * item + 3 * guard, dtype=np.uint8)
+    page0 = (-raw.ctypes.data) % 4096
+    rows = np.r_[0:300, m // 2:m // 2 + 300, m - 300:m]
+    ref = None
+    for off in (8, 2048 + 24, 4088):
+        raw[:] = 0x5A
+        start = page0 + off
+        out = raw[start:start + m * n * item].view(dt).reshape(n, m).T      # column-major m x n, `off` bytes into a page
+        lib.mx_cache_invalidate(None)
+        _lib.check(fn(_lib.ptr(p), _lib.ptr(j), _lib.ptr(x), C.c_int(m), _lib.ptr(Y), C.c_int(n), C.c_int(K), C.c_int(1),
+                      C.c_void_p(out.ctypes.data)))
+        buf = C.create_string_buffer(512)
+        lib.mx_last_call_phases(buf, C.c_size_t(512))
+        assert b"tiles=" in buf.value, buf.value                      # the tiled form ran
+        assert (raw[:start] == 0x5A).all() and (raw[start + m * n * item:] == 0x5A).all()
+        if ref is None:
+            ref = out.copy()
+            dense = np.zeros((rows.size, n))
+            for k, r in enumerate(rows):
+                dense[k] = x[p[r]:p[r + 1]] @ B[j[p[r]:p[r + 1]]].astype(np.float64)
+            np.testing.assert_allclose(out[rows], dense, rtol=2e-5 if f32 else 1e-12, atol=2e-4 if f32 else 1e-11)
+        else:
+            assert np.array_equal(out, ref)
+    cached = np.empty((m, n), dtype=dt, order="F")
+    _lib.check(fn(_lib.ptr(p), _lib.ptr(j), _lib.ptr(x), C.c_int(m), _lib.ptr(Y), C.c_int(n), C.c_int(K), C.c_int(1),
+                  C.c_void_p(cached.ctypes.data)))
+    lib.mx_last_call_phases(buf, C.c_size_t(512))
+    assert b"csr=cached" in buf.value, buf.value
+    if not np.array_equal(cached, ref):                               # (the last, partial octet of 64 rows may be laid out differently)
+        np.testing.assert_allclose(cached, ref, rtol=1e-5 if f32 else 1e-13, atol=1e-4 if f32 else 1e-11)
+        assert np.array_equal(cached[: m - m % 1024], ref[: m - m % 1024])
+    lib.mx_cache_invalidate(None)

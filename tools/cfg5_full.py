@@ -145,8 +145,17 @@ def run(nblocks=NBLOCKS, m_block=M_BLOCK, device_level=True, verbose=False):
     res["sharded_checksum_rel_err"] = check(out_sh, "sharded")
     res["export_sharded_ms"] = [round(t_sh * 1e3, 2), round(t_sh2 * 1e3, 2)]
 
-    # ---- (2) unsharded, cold then with the CSR cached
+    # ---- (2) unsharded: the first such call of the process (its thread allocates the export scratch — 8.4 GB of fresh VRAM,
+    # which the copy engines clear under that call's uploads), cold again, then with the CSR cached.  Each cold call starts
+    # on a quiet device: what the leg before hipFree'd beyond the block pool's cap is scrubbed for the next ~200 ms
+    # (DESIGN §5.2).
     lib.mx_cache_invalidate(None)
+    time.sleep(0.5)
+    t_first, q_first, _ = call(B1)
+    libc.free(q_first)
+    say(f"unsharded, first call of the process: {t_first * 1e3:.1f} ms")
+    lib.mx_cache_invalidate(None)
+    time.sleep(0.5)
     t_cold, q_un, out_un = call(B1)
     say(f"unsharded cold: {t_cold * 1e3:.1f} ms")
     res["unsharded_checksum_rel_err"] = check(out_un, "unsharded")
@@ -168,8 +177,10 @@ def run(nblocks=NBLOCKS, m_block=M_BLOCK, device_level=True, verbose=False):
     libc.free(q3)
     del out3
     say(f"unsharded cached: {t_cached * 1e3:.1f} ms")
-    res["export_unsharded_ms"] = {"cold": round(t_cold * 1e3, 2), "csr_cached": round(t_cached * 1e3, 2)}
-    res["export_phases_ms"] = {"sharded": phases[0], "sharded_again": phases[1], "cold": phases[2], "csr_cached": phases[3]}
+    res["export_unsharded_ms"] = {"cold_first_call_of_the_process": round(t_first * 1e3, 2), "cold": round(t_cold * 1e3, 2),
+                                  "csr_cached": round(t_cached * 1e3, 2)}
+    res["export_phases_ms"] = {"sharded": phases[0], "sharded_again": phases[1], "cold_first_call_of_the_process": phases[2],
+                               "cold": phases[3], "csr_cached": phases[4]}
     # linearity on a row sample (every 997th row, all columns)
     _, q4, out4 = call(B2)
     C2 = out4[sample].astype(np.float64)

@@ -18,19 +18,21 @@ libc = C.CDLL(None)
 libc.malloc.restype = C.c_void_p
 libc.malloc.argtypes = [C.c_size_t]
 libc.free.argtypes = [C.c_void_p]
-m, K, n = 1_000_000, 100_000, 128
-p, j, x = synth.csr_fixed(m, K, 32)
-Y = np.asfortranarray(synth.dense_normal(K, n).T)
+m, K, n = int(os.environ.get("PROBE_M", 1_000_000)), int(os.environ.get("PROBE_K", 100_000)), int(os.environ.get("PROBE_N", 128))
+F32 = os.environ.get("PROBE_F32") == "1"                           # cfg5's kind: float32 dense, f64 CSR values
+ITEM = 4 if F32 else 8
+p, j, x = synth.csr_fixed(m, K, int(os.environ.get("PROBE_NNZ_ROW", 32)))
+Y = np.asfortranarray(synth.dense_normal(K, n).T.astype(np.float32 if F32 else np.float64))
 lib = _lib.load()
-fn = lib.mx_tcrossprod_csr_dense_numeric
+fn = lib.mx_tcrossprod_csr_dense_float32 if F32 else lib.mx_tcrossprod_csr_dense_numeric
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 
 
-kept = libc.malloc(8 * m * n) if REUSE else None
+kept = libc.malloc(ITEM * m * n) if REUSE else None
 
 
 def call():
-    out = kept if REUSE else libc.malloc(8 * m * n)
+    out = kept if REUSE else libc.malloc(ITEM * m * n)
     t0 = time.perf_counter()
     _lib.check(fn(p.ctypes.data, j.ctypes.data, x.ctypes.data, m, Y.ctypes.data, n, K, 1, out))
     t = time.perf_counter() - t0
@@ -47,7 +49,7 @@ for _ in range(3):
 ts = {"1": [], "0": []}
 for i in range(2 * calls):
     form = ORDER[i % len(ORDER)]
-    os.environ["MXGPU_EXPORT_COLD_COLS"] = form
+    os.environ["MXGPU_EXPORT_COLD_COLS"] = "2" if form == "1" else "0"   # 2 = column blocks forced, 0 = row blocks
     t0 = time.perf_counter()
     lib.mx_cache_invalidate(None)
     t_inv = (time.perf_counter() - t0) * 1e3

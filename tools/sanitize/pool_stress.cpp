@@ -3,6 +3,7 @@
 #include "../../matrixextra_amd/csrc/host_pool.h"
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 int main()
@@ -22,6 +23,27 @@ int main()
         pool.touch(fresh.data(), n);                             // touching keeps the contents
         pool.wait();
         if (memcmp(fresh.data(), src.data(), n) != 0) { printf("touch changed the data in round %d\n", round); return 1; }
+    }
+    // pieces touched one after the other without the caller in between: the counters reach the team size in order,
+    // a reader that has seen piece g complete may write to it while later pieces are still being touched
+    for (int round = 0; round < 10; round++) {
+        std::vector<unsigned char> buf(src.begin(), src.begin() + ((size_t)30 << 20) + 4096 * 3 + 17 * (size_t)round);
+        std::vector<std::pair<void *, size_t>> pieces;
+        const size_t np = 7, step = (buf.size() / np) & ~(size_t)4095;
+        for (size_t g = 0; g < np; g++)
+            pieces.emplace_back((void *)(buf.data() + g * step), g + 1 < np ? step : buf.size() - g * step);
+        std::atomic<int> arrived[7];
+        for (auto &a : arrived) a.store(0);
+        pool.touch_pieces(pieces, arrived);
+        for (size_t g = 0; g < np; g++) {
+            while (arrived[g].load(std::memory_order_acquire) < pool.threads()) std::this_thread::yield();
+            for (size_t h = 0; h < g; h++)
+                if (arrived[h].load() != pool.threads()) { printf("piece %zu complete before piece %zu\n", g, h); return 1; }
+            memset(pieces[g].first, 0xEE, pieces[g].second);      // (the consumer's write: the DMA in the real thing)
+        }
+        pool.wait();
+        for (size_t i = 0; i < buf.size(); i++)
+            if (buf[i] != 0xEE) { printf("touch_pieces wrote over the consumer at %zu\n", i); return 1; }
     }
     // content hash: the same for the same bytes whatever the team size, different after ONE byte changes anywhere
     {

@@ -36,7 +36,8 @@ def _roundtrip(nbytes, seed):
 
 def test_transfer_engine_moves_large_buffers_both_ways(gpu):
     # >= 64 MiB each way (above the 16 MiB threshold: register + direct DMA), odd sizes, and just below the threshold
-    for nbytes, seed in ((96 << 20, 1), ((64 << 20) + 12345, 2), ((16 << 20) - 1, 3), (300 << 20, 4)):
+    for nbytes, seed in ((96 << 20, 1), ((64 << 20) + 12345, 2), ((16 << 20) - 1, 3), (300 << 20, 4),
+                         ((1 << 30) + 4099, 6)):                      # (from 192 MiB: touched, registered and copied piece by piece)
         _roundtrip(nbytes, seed)
 
 

@@ -482,7 +482,7 @@ static bool upload_through(const Pin &pin, void *dst, const void *src, size_t nb
     const char *s0 = (const char *)src, *s1 = s0 + nbytes;
     const char *r0 = pin.ok ? std::max(s0, (const char *)pin.p) : s1;
     const char *r1 = pin.ok ? std::min(s1, (const char *)pin.p + pin.bytes) : s1;
-    if (r1 <= r0) return hipMemcpy(dst, src, nbytes, hipMemcpyHostToDevice) == hipSuccess;
+    if (r1 <= r0) return mx::xfer_h2d(dst, src, nbytes) == 0;               // (nothing registered: the engine's staged / registered copy)
     bool ok = hipMemcpyAsync((char *)dst + (r0 - s0), r0, (size_t)(r1 - r0), hipMemcpyHostToDevice, st) == hipSuccess;
     if (ok && r0 > s0) ok = hipMemcpy(dst, s0, (size_t)(r0 - s0), hipMemcpyHostToDevice) == hipSuccess;
     if (ok && s1 > r1) ok = hipMemcpy((char *)dst + (r1 - s0), r1, (size_t)(s1 - r1), hipMemcpyHostToDevice) == hipSuccess;

@@ -31,7 +31,14 @@ using Pool = HostPool;
 
 constexpr int XF_SLOTS = 3;
 constexpr size_t XF_CHUNK = (size_t)8 << 20;
-constexpr size_t XF_MIN = (size_t)16 << 20;           // below this a plain hipMemcpy is as good
+constexpr size_t XF_MIN = (size_t)16 << 20;           // below this: no team first-touch, no registration
+// Caller memory of XF_STAGE_MIN .. XF_REG_MIN bytes never reaches the runtime as a copy operand: a plain hipMemcpy of
+// pageable memory of that size makes the runtime pin the caller's pages on the fly (and remember the mapping), and for
+// memory of the brk heap that ended in "Memory access fault by GPU" at a heap address some calls later — again with
+// tools/fuzz_export_tiles.py, whose cases allocate and free 1-13 MB index-pointer arrays between gigabyte results.  Such
+// buffers go through the engine's own pinned slots (host copy by the team, DMA out of / into the slot); smaller ones are
+// staged by the runtime itself.
+constexpr size_t XF_STAGE_MIN = (size_t)64 << 10;
 // Caller memory is only REGISTERED when it is a mapping of its own: glibc never serves more than 32 MiB
 // (DEFAULT_MMAP_THRESHOLD_MAX) from the shared brk heap, and its threshold climbs to that value as large blocks are freed —
 // a 16-32 MiB vector can therefore sit in the heap, whose pages are trimmed and re-grown behind the runtime's back.
@@ -102,14 +109,19 @@ Engine &engine()
     return *e;
 }
 
+// (smaller chunks for mid-sized transfers — bytes / 4, so that DMA and host copy overlap there too — were measured and are
+// slower: every chunk wakes the team once; the vignette's 14.8 MB result 0.79 ms per call against 0.65)
+inline size_t chunk_for(size_t) { return XF_CHUNK; }
+
 int staged_d2h(Engine &e, void *dst_host, const void *src_dev, size_t bytes)
 {
     MX_HIP(hipStreamSynchronize(nullptr));
-    const size_t nch = (bytes + XF_CHUNK - 1) / XF_CHUNK;
-    auto len_of = [&](size_t c) { return c + 1 < nch ? XF_CHUNK : bytes - c * XF_CHUNK; };
+    const size_t CH = chunk_for(bytes);
+    const size_t nch = (bytes + CH - 1) / CH;
+    auto len_of = [&](size_t c) { return c + 1 < nch ? CH : bytes - c * CH; };
     auto issue = [&](size_t c) -> int {
         const int s = (int)(c % XF_SLOTS);
-        MX_HIP(hipMemcpyAsync(e.slot[s], (const char *)src_dev + c * XF_CHUNK, len_of(c), hipMemcpyDeviceToHost, e.st));
+        MX_HIP(hipMemcpyAsync(e.slot[s], (const char *)src_dev + c * CH, len_of(c), hipMemcpyDeviceToHost, e.st));
         MX_HIP(hipEventRecord(e.ev[s], e.st));
         return 0;
     };
@@ -118,20 +130,21 @@ int staged_d2h(Engine &e, void *dst_host, const void *src_dev, size_t bytes)
     for (size_t c = 0; c < nch; c++) {
         if (c + XF_SLOTS - 1 < nch && issue(c + XF_SLOTS - 1)) return 1;      // its slot was drained one iteration ago
         MX_HIP(hipEventSynchronize(e.ev[c % XF_SLOTS]));
-        e.pool->copy((char *)dst_host + c * XF_CHUNK, e.slot[c % XF_SLOTS], len_of(c));
+        e.pool->copy((char *)dst_host + c * CH, e.slot[c % XF_SLOTS], len_of(c));
     }
     return 0;
 }
 
 int staged_h2d(Engine &e, void *dst_dev, const void *src_host, size_t bytes)
 {
-    const size_t nch = (bytes + XF_CHUNK - 1) / XF_CHUNK;
+    const size_t CH = chunk_for(bytes);
+    const size_t nch = (bytes + CH - 1) / CH;
     for (size_t c = 0; c < nch; c++) {
         const int s = (int)(c % XF_SLOTS);
-        const size_t len = c + 1 < nch ? XF_CHUNK : bytes - c * XF_CHUNK;
+        const size_t len = c + 1 < nch ? CH : bytes - c * CH;
         if (c >= (size_t)XF_SLOTS) MX_HIP(hipEventSynchronize(e.ev[s]));      // the DMA out of this slot has finished
-        e.pool->copy(e.slot[s], (const char *)src_host + c * XF_CHUNK, len);
-        MX_HIP(hipMemcpyAsync((char *)dst_dev + c * XF_CHUNK, e.slot[s], len, hipMemcpyHostToDevice, e.st));
+        e.pool->copy(e.slot[s], (const char *)src_host + c * CH, len);
+        MX_HIP(hipMemcpyAsync((char *)dst_dev + c * CH, e.slot[s], len, hipMemcpyHostToDevice, e.st));
         MX_HIP(hipEventRecord(e.ev[s], e.st));
     }
     MX_HIP(hipStreamSynchronize(e.st));
@@ -229,8 +242,13 @@ static Interior pin_interior(const void *ptr, size_t bytes)
 int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes)
 {
     if (bytes == 0) return 0;
-    if (bytes < XF_MIN || xfer_mode() == 0) { MX_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); return 0; }
+    if (bytes < XF_STAGE_MIN || xfer_mode() == 0) { MX_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); return 0; }
     Engine &e = engine();
+    if (bytes < XF_MIN) {
+        std::lock_guard<std::mutex> lk(e.mu);
+        if (!e.init()) { MX_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); return 0; }
+        return staged_d2h(e, dst_host, src_dev, bytes);
+    }
     if (xfer_mode() == 1 && bytes >= XF_PIECES_MIN) {
         // Large destinations piece by piece: the team walks through the pieces on its own (touch_pieces), this thread
         // registers piece g when the last worker is through it and queues its DMA — the copy of piece g runs under the
@@ -307,7 +325,13 @@ int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes)
 int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes)
 {
     if (bytes == 0) return 0;
-    if (bytes < XF_MIN || xfer_mode() == 0) { MX_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return 0; }
+    if (bytes < XF_STAGE_MIN || xfer_mode() == 0) { MX_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return 0; }
+    if (bytes < XF_MIN) {
+        Engine &e = engine();
+        std::lock_guard<std::mutex> lk(e.mu);
+        if (!e.init()) { MX_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return 0; }
+        return staged_h2d(e, dst_dev, src_host, bytes);
+    }
     if (xfer_mode() == 1) {   // (piece by piece like the downloads: measured, no gain — registering touched memory is ~0.3 ms per GB)
         const Interior in = pin_interior(src_host, bytes);
         if (in.p) {

@@ -826,9 +826,8 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     // A matrix that is found on the device again — or that goes up in one piece — keeps a plan of ALL its rows on its cache
     // entry: built once (here, when AUTO plans this product), used by every block of this call and by every later call.
     MX_HIP(hipStreamWaitEvent(L.run, evB, 0));
-    if ((A.cache_hit || shape == COLS) && algo == MX_SPMM_AUTO && family == MX_SPMM_PLANNED) {
+    auto ensure_plan = [&](const char *phase) -> mx_spmm_plan * {
         CsrDev &e = *A.hold;
-        if (uploading) MX_HIP(hipStreamWaitEvent(L.run, L.ev[0], 0));   // (COLS: the one upload; the build then waits for it)
         std::lock_guard<std::mutex> lk(e.plan_mu);
         if (e.spmm_plan && (e.spmm_plan_K != K_rows || e.spmm_plan_panels != npanels)) {
             mxd_spmm_plan_destroy(e.spmm_plan);
@@ -844,9 +843,14 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
                 e.spmm_plan = nullptr; e.spmm_plan_rejected = true;
             }
             e.spmm_plan_K = K_rows; e.spmm_plan_panels = npanels;
-            tr.mark("plan");
+            tr.mark(phase);
         }
-        plan = e.spmm_plan;
+        return e.spmm_plan;
+    };
+    const bool plans = algo == MX_SPMM_AUTO && family == MX_SPMM_PLANNED;
+    if ((A.cache_hit || shape == COLS) && plans) {
+        if (uploading) MX_HIP(hipStreamWaitEvent(L.run, L.ev[0], 0));   // (COLS: the one upload; the build then waits for it)
+        plan = ensure_plan("plan");
     }
     tr.note("csr", A.cache_hit ? (plan ? "cached+plan" : "cached") : (shape == COLS ? "uploaded whole" : "uploaded by row blocks"));
     // ---- One loop over the blocks: block b's product is queued, then its download behind it (first-touch by the host team
@@ -987,6 +991,10 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     MX_HIP(hipStreamSynchronize(L.run));
     if (uploading) { MX_HIP(hipStreamSynchronize(L.up)); A.publish(); }
     tr.mark("kernels");
+    // A cold call by row blocks ran one plan per block; the plan of ALL rows, which the next call with this matrix will
+    // want (column blocks), is built now — the compute queue is idle, the downloads are still draining — instead of on
+    // that call's critical path (cfg2: 2 ms, cfg5 whole: 5 ms).
+    if (uploading && shape != COLS && plans && A.cacheable && direct_down) (void)ensure_plan("plan for later");
     if (direct_down) MX_HIP(hipStreamSynchronize(L.down));
     else {                                                       // registration failed somewhere: staged copy of the whole result
         mx::prefault_wait();

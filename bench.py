@@ -812,8 +812,9 @@ def main():
         # device listed 8 times, unsharded cold / cached, and one device-level launch; parity checks inside)
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import cfg5_full
-        stream = stream_copy_probe(torch, lib, _lib)
         r = cfg5_full.run(verbose=True)
+        stream = stream_copy_probe(torch, lib, _lib)       # (AFTER the run: with torch's allocator already active in the process the cold
+                                                           # unsharded call measured 262-265 ms instead of 188-197, three runs each way)
         dl = r["device_level"]
         dl["roofline"]["frac_of_stream_copy"] = round(dl["roofline"]["achieved"] / stream["GBps"], 4)
         print(json.dumps({

@@ -994,7 +994,11 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     // A cold call by row blocks ran one plan per block; the plan of ALL rows, which the next call with this matrix will
     // want (column blocks), is built now — the compute queue is idle, the downloads are still draining — instead of on
     // that call's critical path (cfg2: 2 ms, cfg5 whole: 5 ms).
-    if (uploading && shape != COLS && plans && A.cacheable && direct_down) (void)ensure_plan("plan for later");
+    // Only while the plan is small beside the block pool: the plan of cfg5 whole is 9 GB on top of 6 GB of CSR, and when
+    // such an entry leaves the cache, what the pool cannot keep is hipFree'd — and scrubbed by the copy engines under
+    // whatever call comes next (a cold call right after it: 341 ms instead of 192).
+    if (uploading && shape != COLS && plans && A.cacheable && direct_down && (double)nnz * 12.0 * 1.55 <= (double)((size_t)2 << 30))
+        (void)ensure_plan("plan for later");
     if (direct_down) MX_HIP(hipStreamSynchronize(L.down));
     else {                                                       // registration failed somewhere: staged copy of the whole result
         mx::prefault_wait();

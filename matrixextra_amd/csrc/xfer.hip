@@ -109,8 +109,9 @@ Engine &engine()
     return *e;
 }
 
-// (smaller chunks for mid-sized transfers — bytes / 4, so that DMA and host copy overlap there too — were measured and are
-// slower: every chunk wakes the team once; the vignette's 14.8 MB result 0.79 ms per call against 0.65)
+// (smaller chunks for mid-sized transfers — bytes / 4 or / 8, so that DMA and host copy overlap there too — were measured and
+// are slower, also with a team that polls before it sleeps: what a chunk costs is its copy call, event and wait, ~30 us;
+// 8 MiB down: 0.26 ms in one chunk, 0.39 ms in eight; a plain hipMemcpy — the runtime pins the caller's pages — 0.16 ms)
 inline size_t chunk_for(size_t) { return XF_CHUNK; }
 
 int staged_d2h(Engine &e, void *dst_host, const void *src_dev, size_t bytes)

@@ -360,3 +360,31 @@ def test_cold_export_comes_down_in_tiles(gpu, f32):
         np.testing.assert_allclose(cached, ref, rtol=1e-5 if f32 else 1e-13, atol=1e-4 if f32 else 1e-11)
         assert np.array_equal(cached[: m - m % 1024], ref[: m - m % 1024])
     lib.mx_cache_invalidate(None)
+
+
+def test_pool_switched_off_and_poisoned(gpu):
+    """MXGPU_POOL_MB=0: every block goes straight back to the device (the behaviour before the pool);
+    MXGPU_POOL_POISON=1: every block handed out is filled with 0xA5 first.  Both read once per process: a child."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import ctypes as C, numpy as np\n"
+        "from matrixextra_amd import _lib, synth, exports as G\n"
+        "from oracle import oracle as O\n"
+        "lib = _lib.load()\n"
+        "p1, j1, x1 = synth.csr_fixed(50_000, 4_000, 12, seed=3)\n"
+        "p2, j2, x2 = synth.csr_overlapping(p1, j1, 4_000, 12, share=0.5, seed=4)\n"
+        "for _ in range(3):\n"
+        "    g = G.add_csr_elemwise(p1, p2, j1, j2, x1, x2, True); r = O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, True)\n"
+        "    assert all(np.array_equal(g[k], r[k]) for k in ('indptr', 'indices', 'values'))\n"
+        "    rows = np.array([7, 7, 0, 49_999], dtype=np.int32)\n"
+        "    g = G.copy_csr_rows_numeric(p1, j1, x1, rows); r = O.copy_csr_rows_numeric(p1, j1, x1, rows)\n"
+        "    assert all(np.array_equal(g[k], r[k]) for k in ('indptr', 'indices', 'values'))\n"
+        "    v = np.random.default_rng(1).normal(size=4_000)\n"
+        "    assert np.allclose(G.matmul_csr_dvec_numeric(p1, j1, x1, v), O.matmul_csr_dvec_numeric(p1, j1, x1, v), rtol=1e-12, atol=1e-12)\n"
+        "n = C.c_int64(-1); _lib.check(lib.mx_get_option(b'pool_idle_bytes', C.byref(n)))\n"
+        "print('idle', n.value)\n") % ROOT
+    for env, want_zero in ((dict(MXGPU_POOL_MB="0"), True), (dict(MXGPU_POOL_POISON="1"), False)):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        idle = int(r.stdout.strip().split()[-1])
+        assert (idle == 0) if want_zero else (idle > 0), (env, idle)

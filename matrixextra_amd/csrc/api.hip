@@ -717,8 +717,10 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     //   COLS (column-major C, CSR already on the device): column blocks of B / C, same incremental scheme — the download
     //        starts as soon as the first block is computed (~0.5 ms into the call);
     //   ROWS_STRIDED (column-major C, CSR still on the host): row blocks, so that a block's slice of (indices, values) can
-    //        go up while earlier blocks are multiplied and come down (rows of a column-major matrix are strided: the whole
-    //        result is first-touched — under the upload — and registered before the first block comes down).
+    //        go up while earlier blocks are multiplied and come down.  Rows of a column-major matrix are strided: the result
+    //        is ALSO cut into groups of whole columns (contiguous pieces, touched and registered one after the other) and
+    //        comes down in tiles, row block x column group — see `tiled` below; without tiles (MXGPU_EXPORT_TILES=0, tiny
+    //        geometries) the whole result is first-touched and registered before the first block comes down.
     // A column-major result whose CSR is still on the host takes COLS too when the upload is SHORT beside the page work:
     // column blocks need the whole CSR on the device before the first block can be multiplied (12 bytes per entry at
     // ~55 GB/s) but then run ONE plan — kept on the cache entry for the calls to come — and download contiguous pieces;

@@ -417,6 +417,26 @@ size_t mxd_scan_workspace_bytes(int64_t n);
 int mxd_exclusive_scan_i32(const int32_t *counts, int64_t n, int32_t *out,
                            int64_t *total_dev, void *workspace, void *stream);
 
+/* What follows a merge and what precedes it in the R callers (widened after SURVEY §8f's four ranks):
+ *   remove_zero_valued_csr<>  src/misc.cpp:553-664 (R `remove_zeros`, R/utils.R:286-312): the explicit zeros A - B leaves
+ *     behind (operators.cpp:477-495) leave the matrix, with remove_NAs the missing values too.  value_dtype MX_F64 or
+ *     MX_LGL.  Predicates exactly the reference's: zeros are +-0.0 / FALSE, NaN and NA are "true" and stay unless
+ *     remove_NAs; for R logicals with remove_NAs only the NAs leave — the zeros stay (misc.cpp:636-647), kept as it is.
+ *     count: out_indptr[m+1], *nnz_out_host, *dirty_host = is there anything the reference's first scan would have found
+ *     (misc.cpp:562-584; 0: it returns its INPUT vectors); fill: ordered compaction.  `nnz` (< 0 unknown) only picks the
+ *     lanes per row.  workspace: mxd_csr_drop_workspace_bytes(m).
+ *   check_valid_csr_matrix  src/misc.cpp:970-1016 (R `check_sparse_matrix`, R/utils.R:448): *code_host = 0 valid,
+ *     1 "Matrix has negative indices.", 2 "Matrix has invalid column indices.", 4 "Matrix has missing values in the index
+ *     pointer.", 5 "Matrix index pointer is not monotonicaly increasing." — the reference's order of checks (its third one,
+ *     NA among the indices, cannot fire: NA_INTEGER is negative).  nnz = length of `indices`; flags_dev: 4 ints of scratch. */
+size_t mxd_csr_drop_workspace_bytes(int m);
+int mxd_csr_drop_count(int m, int64_t nnz, const int32_t *indptr, const void *values, int value_dtype, int remove_NAs,
+                       int32_t *out_indptr, void *workspace, int64_t *nnz_out_host, int *dirty_host, void *stream);
+int mxd_csr_drop_fill(int m, int64_t nnz, const int32_t *indptr, const int32_t *indices, const void *values, int value_dtype,
+                      int remove_NAs, const int32_t *out_indptr, int32_t *out_indices, void *out_values, void *stream);
+int mxd_csr_check_valid(int m, int ncols, int64_t nnz, const int32_t *indptr, const int32_t *indices, int *flags_dev,
+                        int *code_host, void *stream);
+
 /* Next-row components: per-row sortedness check and
  * per-row index sort (check_is_sorted / sort_sparse_indices_known_ncol,
  * src/misc.cpp:118-128, :261-298). */
@@ -493,7 +513,8 @@ typedef struct {
     int     values_dtype;  /* MX_F64 / MX_LGL / MX_NONE                         */
     int     alias_structure; /* 1: reference returns the INPUT indptr1/indices1
                                 objects themselves (operators.cpp:127-131,:390-394);
-                                finish then fills only values                   */
+                                finish then fills only values.  2 (remove_zero_valued_csr
+                                only): all three input vectors come back            */
 } mx_result_info;
 
 /* add_csr_elemwise / logicalor_csr_elemwise / multiply_csr_elemwise /
@@ -574,6 +595,15 @@ typedef struct {
 } mx_rbind_input;
 int mx_concat_csr_batch_begin(const mx_rbind_input *objects, int n_inputs, int out_kind,
                               mx_result **res, mx_result_info *info);
+/* remove_zero_valued_csr_{numeric,logical}  src/misc.cpp:667-698 (RcppExports.cpp CallEntries: 4 arguments each).
+ * info.alias_structure = 2 when nothing has to leave: the reference returns its three INPUT vectors
+ * (misc.cpp:586-590) — discard the handle and do the same. */
+int mx_remove_zero_valued_csr_begin(const int32_t *indptr, const int32_t *indices, const void *values, int value_dtype,
+                                    int nrows, int remove_NAs, mx_result **res, mx_result_info *info);
+/* check_valid_csr_matrix  src/misc.cpp:970-1016: *code as mxd_csr_check_valid; message = the reference's text for it
+ * ("" when valid), a static string. */
+int mx_check_valid_csr_matrix(const int32_t *indptr, const int32_t *indices, int64_t n_indices, int nrows, int ncols,
+                              int *code, const char **message);
 int mx_result_finish(mx_result *res, int32_t *out_indptr, int32_t *out_indices, void *out_values);
 int mx_result_discard(mx_result *res);
 

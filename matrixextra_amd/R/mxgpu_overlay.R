@@ -43,7 +43,9 @@
     ## rank 1: sortedness check and in-place sort (run before every CSR (+) CSR, R/operators.R:58,64,748,754)
     "check_indices_are_unsorted",
     "sort_sparse_indices_numeric", "sort_sparse_indices_logical", "sort_sparse_indices_numeric_known_ncol",
-    "sort_sparse_indices_logical_known_ncol", "sort_sparse_indices_binary"
+    "sort_sparse_indices_logical_known_ncol", "sort_sparse_indices_binary",
+    ## what follows a merge (`remove_zeros`, R/utils.R:286-312) and what `check_sparse_matrix` asks (R/utils.R:448)
+    "remove_zero_valued_csr_numeric", "remove_zero_valued_csr_logical", "check_valid_csr_matrix"
 )
 
 mxgpu_enable <- function(shim_path, min_nnz = 0L) {

@@ -12,8 +12,8 @@ No CPU fallback anywhere: without libmxgpu.so and a GPU every compute call raise
 """
 from . import _lib  # noqa: F401
 from .matrices import (DenseMatrix, MatrixExtraError, NA_INTEGER, NA_LOGICAL, NA_REAL, RsparseMatrix,  # noqa: F401
-                       as_csr_matrix, check_valid_matrix, dgCMatrix, dgRMatrix, float32, from_scipy,
-                       lgRMatrix, ngRMatrix, options, sort_sparse_indices)
+                       as_csr_matrix, check_sparse_matrix, check_valid_matrix, dgCMatrix, dgRMatrix, float32, from_scipy,
+                       lgRMatrix, ngRMatrix, options, remove_sparse_zeros, sort_sparse_indices)
 from .matmul import RLogical, crossprod, tcrossprod  # noqa: F401  (`%*%` is the @ operator)
 from .operators import (add_csr_matrices, logicalor_csr_matrices, multiply_csr_by_csr,  # noqa: F401
                         xor_csr_matrices)

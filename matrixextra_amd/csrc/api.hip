@@ -1808,6 +1808,73 @@ int mx_concat_csr_batch_begin(const mx_rbind_input *objs, int n_inputs, int out_
     return 0;
 }
 
+int mx_remove_zero_valued_csr_begin(const int32_t *indptr, const int32_t *indices, const void *values, int value_dtype,
+                                    int nrows, int remove_NAs, mx_result **res_out, mx_result_info *info)
+{
+    MX_REQUIRE(res_out && info, "mx_remove_zero_valued_csr_begin: null output pointer");
+    MX_REQUIRE(nrows >= 0 && indptr, "mx_remove_zero_valued_csr_begin: bad arguments");
+    MX_REQUIRE(value_dtype == MX_F64 || value_dtype == MX_LGL, "mx_remove_zero_valued_csr_begin: values must be f64 or R logical");
+    *res_out = nullptr;
+    mx_result *res = new (std::nothrow) mx_result();
+    MX_REQUIRE(res, "out of host memory");
+    res->info.values_dtype = value_dtype;
+    const size_t vb = dtype_bytes(value_dtype);
+    int rc = 0;
+    do {
+        Csr A;
+        if ((rc = A.upload(indptr, indices, values, nrows, vb))) break;
+        DevBuf ws;
+        if ((rc = ws.alloc(mxd_csr_drop_workspace_bytes(nrows)))) break;
+        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
+        int64_t nnz_out = 0;
+        int dirty = 0;
+        if ((rc = mxd_csr_drop_count(nrows, A.nnz, A.p.as<int32_t>(), A.x.p, value_dtype, remove_NAs, res->indptr.as<int32_t>(),
+                                     ws.p, &nnz_out, &dirty, nullptr)))
+            break;
+        res->info.indptr_len = (int64_t)nrows + 1;
+        if (!dirty) {                                                // misc.cpp:586-590: the input vectors themselves
+            res->info.alias_structure = 2;
+            res->info.nnz = A.nnz;
+            res->info.values_len = A.nnz;
+            break;
+        }
+        res->info.nnz = nnz_out;
+        res->info.values_len = nnz_out;
+        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
+        if ((rc = res->values.alloc(vb * (size_t)nnz_out))) break;
+        if ((rc = mxd_csr_drop_fill(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, value_dtype, remove_NAs,
+                                    res->indptr.as<int32_t>(), res->indices.as<int32_t>(), res->values.p, nullptr)))
+            break;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
+    } while (0);
+    if (rc) { delete res; return rc; }
+    *info = res->info;
+    *res_out = res;
+    return 0;
+}
+
+int mx_check_valid_csr_matrix(const int32_t *indptr, const int32_t *indices, int64_t n_indices, int nrows, int ncols,
+                              int *code, const char **message)
+{
+    MX_REQUIRE(code && indptr && nrows >= 0 && n_indices >= 0, "mx_check_valid_csr_matrix: bad arguments");
+    // (not through the CSR cache: an invalid index pointer is exactly what this routine is asked about)
+    DevBuf p, j, flags;
+    if (p.upload(indptr, sizeof(int32_t) * ((size_t)nrows + 1))) return 1;
+    if (j.upload(indices, sizeof(int32_t) * (size_t)n_indices)) return 1;
+    if (flags.alloc(16)) return 1;
+    if (mxd_csr_check_valid(nrows, ncols, n_indices, p.as<int32_t>(), j.as<int32_t>(), flags.as<int>(), code, nullptr)) return 1;
+    if (message) {
+        switch (*code) {
+            case 1: *message = "Matrix has negative indices."; break;
+            case 2: *message = "Matrix has invalid column indices."; break;
+            case 4: *message = "Matrix has missing values in the index pointer."; break;
+            case 5: *message = "Matrix index pointer is not monotonicaly increasing."; break;
+            default: *message = ""; break;
+        }
+    }
+    return 0;
+}
+
 int mx_result_finish(mx_result *res, int32_t *out_indptr, int32_t *out_indices, void *out_values)
 {
     MX_REQUIRE(res, "mx_result_finish: null handle");

@@ -559,6 +559,46 @@ SEXP _MatrixExtra_sort_sparse_indices_numeric_known_ncol(SEXP p_, SEXP j_, SEXP 
 SEXP _MatrixExtra_sort_sparse_indices_logical_known_ncol(SEXP p_, SEXP j_, SEXP x_, SEXP ncol) { (void)ncol; return sort_inplace(p_, j_, x_, MX_LGL); }
 SEXP _MatrixExtra_sort_sparse_indices_binary(SEXP p_, SEXP j_) { return sort_inplace(p_, j_, R_NilValue, MX_NONE); }
 
+// ---- remove_zero_valued_csr_{numeric,logical} (misc.cpp:667-698), check_valid_csr_matrix (misc.cpp:970-1016) ------------
+static SEXP remove_zero_valued(SEXP p_, SEXP j_, SEXP x_, SEXP remove_NAs, int dtype)
+{
+    Protect p;
+    SEXP pi = as_type(p_, INTSXP, p), ji = as_type(j_, INTSXP, p);
+    SEXP xi = as_type(x_, dtype == MX_F64 ? REALSXP : LGLSXP, p);
+    const void *v = dtype == MX_F64 ? (const void *)REAL(xi) : (const void *)LOGICAL(xi);
+    mx_result *res = nullptr;
+    mx_result_info info;
+    if (mx_remove_zero_valued_csr_begin(INTEGER(pi), INTEGER(ji), v, dtype, (int)XLENGTH(pi) - 1, Rf_asLogical(remove_NAs) ? 1 : 0,
+                                        &res, &info))
+        fail();
+    if (info.alias_structure == 2) {                       // nothing to remove: the caller's three vectors (misc.cpp:586-590)
+        mx_result_discard(res);
+        return named_list3(p_, j_, x_, p);
+    }
+    info.values_dtype = dtype;
+    return finish_guarded(res, info, R_NilValue, R_NilValue);
+}
+SEXP _MatrixExtra_remove_zero_valued_csr_numeric(SEXP p_, SEXP j_, SEXP x_, SEXP remove_NAs) { return remove_zero_valued(p_, j_, x_, remove_NAs, MX_F64); }
+SEXP _MatrixExtra_remove_zero_valued_csr_logical(SEXP p_, SEXP j_, SEXP x_, SEXP remove_NAs) { return remove_zero_valued(p_, j_, x_, remove_NAs, MX_LGL); }
+SEXP _MatrixExtra_check_valid_csr_matrix(SEXP p_, SEXP j_, SEXP nrows, SEXP ncols)
+{
+    Protect p;
+    p_ = as_type(p_, INTSXP, p); j_ = as_type(j_, INTSXP, p);
+    int code = 0;
+    const char *msg = "";
+    if (mx_check_valid_csr_matrix(INTEGER(p_), INTEGER(j_), (int64_t)XLENGTH(j_), Rf_asInteger(nrows), Rf_asInteger(ncols), &code, &msg))
+        fail();
+    if (!code) return p(Rf_allocVector(VECSXP, 0));        // Rcpp::List()
+    SEXP out = p(Rf_allocVector(VECSXP, 1));
+    SEXP err = p(Rf_allocVector(STRSXP, 1));
+    SET_STRING_ELT(err, 0, Rf_mkChar(msg));
+    SET_VECTOR_ELT(out, 0, err);
+    SEXP nm = p(Rf_allocVector(STRSXP, 1));
+    SET_STRING_ELT(nm, 0, Rf_mkChar("err"));
+    Rf_setAttrib(out, R_NamesSymbol, nm);
+    return out;
+}
+
 #define MX_ENTRY(name, n) {"_MatrixExtra_" #name, (DL_FUNC)&_MatrixExtra_##name, n}
 // ---- control routines of the shim itself (not in MatrixExtra's table; the overlay calls them from mxgpu_enable) -------------
 // .Call("_mxgpu_set_option", "spmv_planned", 1L)  ->  mx_set_option   (include/mxgpu.h: run-time options)
@@ -608,6 +648,8 @@ static const R_CallMethodDef mxgpu_call_entries[] = {
     MX_ENTRY(sort_sparse_indices_numeric, 3), MX_ENTRY(sort_sparse_indices_logical, 3),
     MX_ENTRY(sort_sparse_indices_numeric_known_ncol, 4), MX_ENTRY(sort_sparse_indices_logical_known_ncol, 4),
     MX_ENTRY(sort_sparse_indices_binary, 2),
+    MX_ENTRY(remove_zero_valued_csr_numeric, 4), MX_ENTRY(remove_zero_valued_csr_logical, 4),
+    MX_ENTRY(check_valid_csr_matrix, 4),
     {NULL, NULL, 0}
 };
 

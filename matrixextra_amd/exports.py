@@ -550,3 +550,38 @@ def logicaland_csr_by_dvec_internal(indptr, indices, values, dvec, ncols):
     check(_lib.load().mx_logicaland_csr_by_dvec_internal(ptr(p), ptr(j), ptr(xv), C.c_int(p.size - 1), ptr(dv),
                                                          C.c_int64(dv.size), C.c_int(int(ncols)), ptr(out)))
     return out
+
+
+def _remove_zero_valued_csr(indptr, indices, values, remove_NAs, value_dtype, vdt):
+    lib = _lib.load()
+    p, j = _i32(indptr), _i32(indices)
+    v = np.ascontiguousarray(values, dtype=vdt)
+    res = C.c_void_p()
+    info = ResultInfo()
+    check(lib.mx_remove_zero_valued_csr_begin(ptr(p), ptr(j), ptr(v), C.c_int(value_dtype), C.c_int(p.size - 1),
+                                              C.c_int(1 if remove_NAs else 0), C.byref(res), C.byref(info)))
+    if info.alias_structure == 2:          # nothing to remove: the INPUT objects themselves (misc.cpp:586-590)
+        check(lib.mx_result_discard(res))
+        return dict(indptr=indptr, indices=indices, values=values)
+    return _finish(res, info)
+
+
+def remove_zero_valued_csr_numeric(indptr, indices, values, remove_NAs):
+    """R/RcppExports.R `remove_zero_valued_csr_numeric` -> src/misc.cpp:667-682."""
+    return _remove_zero_valued_csr(indptr, indices, values, remove_NAs, MX_F64, np.float64)
+
+
+def remove_zero_valued_csr_logical(indptr, indices, values, remove_NAs):
+    """R/RcppExports.R `remove_zero_valued_csr_logical` -> src/misc.cpp:684-698."""
+    return _remove_zero_valued_csr(indptr, indices, values, remove_NAs, MX_LGL, np.int32)
+
+
+def check_valid_csr_matrix(indptr, indices, nrows, ncols):
+    """R/RcppExports.R `check_valid_csr_matrix` -> src/misc.cpp:970-1016: dict(err=...) or an empty dict."""
+    lib = _lib.load()
+    p, j = _i32(indptr), _i32(indices)
+    code = C.c_int(0)
+    msg = C.c_char_p()
+    check(lib.mx_check_valid_csr_matrix(ptr(p), ptr(j), C.c_int64(j.size), C.c_int(int(nrows)), C.c_int(int(ncols)),
+                                        C.byref(code), C.byref(msg)))
+    return dict(err=msg.value.decode()) if code.value else dict()

@@ -337,3 +337,47 @@ def sort_sparse_indices(X, copy=False):
         X = type(X)(X.p, X.j.copy(), None if X.x is None else X.x.copy(), X.Dim, list(X.Dimnames))
     exports.sort_sparse_indices_inplace(X.p, X.j, X.x)
     return X
+
+
+def remove_sparse_zeros(X, na_rm=False):
+    """remove_sparse_zeros (R/utils.R:263-330), RsparseMatrix / CsparseMatrix branches: entries stored with the value
+    zero (what `A - B` leaves where entries cancel) leave the representation, with na_rm the missing values too;
+    src/misc.cpp:553-698 on the device.  Pattern matrices come back as they are.  The object is modified like the
+    reference's (`attributes(X) <-` builds a new S4 object there: here a new object of the same class)."""
+    from . import exports
+    if isinstance(X, ngRMatrix):
+        return X
+    if isinstance(X, dgRMatrix):
+        res = exports.remove_zero_valued_csr_numeric(X.p, X.j, X.x, na_rm)
+    elif isinstance(X, lgRMatrix):
+        res = exports.remove_zero_valued_csr_logical(X.p, X.j, X.x, na_rm)
+    elif isinstance(X, dgCMatrix):
+        res = exports.remove_zero_valued_csr_numeric(X.p, X.i, X.x, na_rm)
+        return dgCMatrix(res["indptr"], res["indices"], res["values"], X.Dim, list(X.Dimnames))
+    else:
+        stop("Method is only applicable to sparse matrices and vectors.")
+    return type(X)(res["indptr"], res["indices"], res["values"], X.Dim, list(X.Dimnames))
+
+
+def check_sparse_matrix(X, sort=True, remove_zeros=True):
+    """check_sparse_matrix (R/utils.R:439-489), RsparseMatrix / CsparseMatrix branches: check_valid_matrix, then
+    check_valid_csr_matrix (src/misc.cpp:970-1016) on the device — its message becomes the error —, then zeros removed and
+    indices sorted (on a copy when nothing was removed, as the reference does)."""
+    from . import exports
+    check_valid_matrix(X)
+    if isinstance(X, RsparseMatrix):
+        res = exports.check_valid_csr_matrix(X.p, X.j, X.nrow(), X.ncol())
+    elif isinstance(X, dgCMatrix):
+        res = exports.check_valid_csr_matrix(X.p, X.i, X.nrow(), X.ncol())
+    else:
+        stop("Function is only applicable to sparse matrices and sparse vectors.")
+    if len(res):
+        stop(res["err"])
+    idx = (lambda M: M.j if isinstance(M, RsparseMatrix) else M.i)
+    nnz_before = idx(X).size
+    if remove_zeros:
+        X = remove_sparse_zeros(X)
+    nnz_after = idx(X).size
+    if sort and isinstance(X, RsparseMatrix):
+        X = sort_sparse_indices(X, copy=nnz_before == nnz_after)
+    return X

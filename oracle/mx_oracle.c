@@ -880,3 +880,59 @@ void mxo_csr_by_dvec_with_NAs(int nrows, int ncols, const int *indptr, const int
     free(rowbuf); free(na.p); free(nan_.p); free(ones.p); free(inf.p);
     res->indptr = po; res->indices = jo.p; res->values = xo.p; res->nnz = jo.n;
 }
+
+
+/* remove_zero_valued_csr<>  src/misc.cpp:553-664.  kind 0: numeric (double), 1: R logical (int).  Returns -1 when the
+ * reference's first scan finds nothing to remove (it then hands back its INPUT vectors, :586-590), else the number of
+ * entries written to indices_new / values_new (capacity: nnz) with indptr_new[0..nrows] filled.  For R logicals with
+ * remove_NAs the copy loop only drops the NAs — zeros stay (:636-647) — restated as it is. */
+long long mxo_remove_zero_valued_csr(int nrows, const int *indptr, const int *indices, const void *values, int kind,
+                                     int remove_NAs, int *indptr_new, int *indices_new, void *values_new)
+{
+    const double *xd = (const double *)values;
+    const int *xl = (const int *)values;
+    const long long nnz = indptr[nrows];
+    int dirty = 0;
+    for (long long i = 0; i < nnz && !dirty; i++) {
+        if (kind == 0) dirty = !remove_NAs ? !xd[i] : (!xd[i] || xd[i] != xd[i]);
+        else dirty = !remove_NAs ? !xl[i] : (!xl[i] || xl[i] == INT_MIN);
+    }
+    if (!dirty) return -1;
+    int curr = 0;
+    indptr_new[0] = 0;
+    for (int row = 0; row < nrows; row++) {
+        for (int ix = indptr[row]; ix < indptr[row + 1]; ix++) {
+            int keep;
+            if (kind == 0) keep = !remove_NAs ? (xd[ix] != 0) : (xd[ix] != 0 && xd[ix] == xd[ix]);
+            else keep = !remove_NAs ? (xl[ix] != 0) : (xl[ix] != INT_MIN);
+            if (keep) {
+                indices_new[curr] = indices[ix];
+                if (kind == 0) ((double *)values_new)[curr] = xd[ix];
+                else ((int *)values_new)[curr] = xl[ix];
+                curr++;
+            }
+        }
+        indptr_new[row + 1] = curr;
+    }
+    return curr;
+}
+
+/* check_valid_csr_matrix  src/misc.cpp:970-1016: 0 valid, 1 negative index, 2 index >= ncols, 3 NA among the indices
+ * (unreachable: NA_INTEGER is negative), 4 NA in the index pointer, 5 index pointer decreases.  (The reference dereferences
+ * min_element of an EMPTY index vector; here an empty one passes the index checks.) */
+int mxo_check_valid_csr_matrix(const int *indptr, const int *indices, long long n_indices, int nrows, int ncols)
+{
+    if (n_indices > 0) {
+        int imin = indices[0], imax = indices[0];
+        for (long long i = 1; i < n_indices; i++) {
+            if (indices[i] < imin) imin = indices[i];
+            if (indices[i] > imax) imax = indices[i];
+        }
+        if (imin < 0) return 1;
+        if (imax >= ncols) return 2;
+        for (long long i = 0; i < n_indices; i++) if (indices[i] == INT_MIN) return 3;
+    }
+    for (int i = 0; i <= nrows; i++) if (indptr[i] == INT_MIN) return 4;
+    for (int i = 0; i < nrows; i++) if (indptr[i] > indptr[i + 1]) return 5;
+    return 0;
+}

@@ -682,3 +682,41 @@ def multiply_csr_by_dvec_with_NAs(p, j, x, dvec, ncols, multiply, powerto, divid
                     values=vals, alias_structure=False)
     finally:
         lib().mxo_free_dvec_na(C.byref(res))
+
+
+def _remove_zero_valued_csr(indptr, indices, values, remove_NAs, kind):
+    p, j = _i32(indptr), _i32(indices)
+    vdt = np.float64 if kind == 0 else np.int32
+    v = np.ascontiguousarray(values, dtype=vdt)
+    n = p.size - 1
+    npz = np.zeros(n + 1, dtype=np.int32)
+    nj = np.empty(j.size, dtype=np.int32)
+    nv = np.empty(j.size, dtype=vdt)
+    fn = lib().mxo_remove_zero_valued_csr
+    fn.restype = C.c_longlong
+    k = fn(C.c_int(n), _p(p), _p(j), _p(v), C.c_int(kind), C.c_int(1 if remove_NAs else 0), _p(npz), _p(nj), _p(nv))
+    if k < 0:   # misc.cpp:586-590: the INPUT vectors themselves
+        return dict(indptr=indptr, indices=indices, values=values)
+    return dict(indptr=npz, indices=nj[:k].copy(), values=nv[:k].copy())
+
+
+def remove_zero_valued_csr_numeric(indptr, indices, values, remove_NAs):
+    """src/misc.cpp:667-682"""
+    return _remove_zero_valued_csr(indptr, indices, values, remove_NAs, 0)
+
+
+def remove_zero_valued_csr_logical(indptr, indices, values, remove_NAs):
+    """src/misc.cpp:684-698"""
+    return _remove_zero_valued_csr(indptr, indices, values, remove_NAs, 1)
+
+
+_VALID_CSR_MESSAGES = {1: "Matrix has negative indices.", 2: "Matrix has invalid column indices.",
+                       3: "Matrix has indices with missing values.", 4: "Matrix has missing values in the index pointer.",
+                       5: "Matrix index pointer is not monotonicaly increasing."}
+
+
+def check_valid_csr_matrix(indptr, indices, nrows, ncols):
+    """src/misc.cpp:970-1016: list(err=...) or an empty list"""
+    p, j = _i32(indptr), _i32(indices)
+    code = lib().mxo_check_valid_csr_matrix(_p(p), _p(j), C.c_longlong(j.size), C.c_int(nrows), C.c_int(ncols))
+    return dict(err=_VALID_CSR_MESSAGES[code]) if code else dict()

@@ -124,6 +124,19 @@ put("sort_kat", p=np.array([0, 1, 4, 5, 6], np.int32), j=np.array([4, 2, 1, 4, 1
     x=np.array([-0.91, 0.14, -0.12, -0.12, 1.1, 0.66]), j_sorted=np.array([4, 1, 2, 4, 1, 0], np.int32),
     x_sorted=np.array([-0.91, -0.12, 0.14, -0.12, 1.1, 0.66]))
 
+# ---- remove_zero_valued_csr (what remove_zeros runs after A - B) and check_valid_csr_matrix codes
+p, j, x = rand_csr(25, 9, 0.4, seed=91, empty_rows=(2, 24))
+rng = np.random.default_rng(92)
+x = x.copy(); x[rng.random(x.size) < 0.3] = 0.0; x[3] = -0.0; x[rng.random(x.size) < 0.15] = np.nan
+xl = rng.choice(np.array([0, 1, NA], dtype=np.int32), size=x.size)
+put("dropzeros", p=p, j=j, x=x, xl=xl)
+for rm in (0, 1):
+    lst("dropzeros", f"numeric_{rm}", O.remove_zero_valued_csr_numeric(p, j, x, bool(rm)))
+    lst("dropzeros", f"logical_{rm}", O.remove_zero_valued_csr_logical(p, j, xl, bool(rm)))
+    keep = (x != 0) & (~np.isnan(x) if rm else True)                 # the numeric predicate, restated with masks
+    np.testing.assert_array_equal(out[f"dropzeros/numeric_{rm}_indices"], j[keep])
+    np.testing.assert_array_equal(out[f"dropzeros/numeric_{rm}_values"], x[keep])
+
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hotpath_golden.npz")
 np.savez_compressed(path, **out)
 print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} bytes")

@@ -98,7 +98,16 @@ def run_all(M, exact_spmm):
         eq(M.logicaland_csr_by_dvec_internal(p, j, xl, vl, 7), g(c, "and_" + vname))
 
 
+def run_dropzeros(M):
+    c = "dropzeros"
+    p, j, x, xl = g(c, "p"), g(c, "j"), g(c, "x"), g(c, "xl")
+    for rm in (0, 1):
+        eq_list(M.remove_zero_valued_csr_numeric(p, j, x, bool(rm)), c, f"numeric_{rm}")
+        eq_list(M.remove_zero_valued_csr_logical(p, j, xl, bool(rm)), c, f"logical_{rm}")
+
+
 def test_oracle_reproduces_golden():
+    run_dropzeros(O)
     run_all(O, exact_spmm=True)
     c = "sort_kat"
     js, xs = O.sort_sparse_indices(g(c, "p"), g(c, "j"), g(c, "x"))
@@ -109,6 +118,7 @@ def test_oracle_reproduces_golden():
 def test_hip_reproduces_golden(gpu):
     from matrixextra_amd import exports
     run_all(exports, exact_spmm=False)
+    run_dropzeros(exports)
     c = "sort_kat"
     j, x = g(c, "j").copy(), g(c, "x").copy()
     exports.sort_sparse_indices_inplace(g(c, "p"), j, x)

@@ -270,3 +270,56 @@ def test_csr_by_vector_operators(gpu):                            # test-operato
     with pytest.raises(M.MatrixExtraError, match="more entries than matrix"):
         X * np.ones(60 * 17 + 1)
     assert (X * np.zeros(0)).size == 0                              # R/operators.R:961-966
+
+
+def to_dense(X):
+    """as.matrix(X): stored entries summed into a dense array (NaN where a stored value is missing)"""
+    out = np.zeros(X.Dim)
+    for r in range(X.Dim[0]):
+        for k in range(X.p[r], X.p[r + 1]):
+            out[r, X.j[k]] += X.x[k]
+    return out
+
+
+def test_removing_zeros(gpu):                                     # tests/testthat/test-utilities.R:6-30
+    rng = np.random.default_rng(1)
+    D = np.round(rng.normal(size=(10, 5)), 2) * (rng.random((10, 5)) < 0.75)
+    X = mx.as_csr_matrix(sp.csr_matrix(D))
+    x = X.x.copy()
+    x[4:8] = 0.0
+    X = mx.dgRMatrix(X.p, X.j, x, X.Dim)
+    dense = to_dense(X)
+    Xr = mx.remove_sparse_zeros(X)
+    np.testing.assert_array_equal(to_dense(Xr), dense)
+    assert (Xr.x == 0).sum() == 0 and Xr.j.size == X.j.size - 4
+    x[7:10] = np.nan
+    X = mx.dgRMatrix(X.p, X.j, x, X.Dim)
+    Xr = mx.remove_sparse_zeros(X, na_rm=True)
+    want = to_dense(X)
+    want[np.isnan(want)] = 0
+    np.testing.assert_array_equal(to_dense(Xr), want)
+    assert not np.isnan(Xr.x).any()
+    assert np.isnan(mx.remove_sparse_zeros(X).x).sum() == 3        # without na.rm the missing values stay
+    P = mx.ngRMatrix(X.p, X.j, None, X.Dim)
+    assert mx.remove_sparse_zeros(P) is P
+
+
+def test_checking_indices(gpu):                                   # tests/testthat/test-utilities.R:51-80
+    def fresh(p=(0, 1, 4, 5, 6), j=(4, 2, 1, 4, 1, 0)):
+        return mx.dgRMatrix(list(p), list(j), [-0.91, 0.14, -0.12, -0.12, 1.1, 0.66], (4, 5))
+    X = fresh()
+    Xc = mx.check_sparse_matrix(X)
+    assert Xc.j.tolist() == [4, 1, 2, 4, 1, 0] and X.j.tolist() == [4, 2, 1, 4, 1, 0]
+    for p in ((0, 1, 4, 5, 100), (0, 5, 4, 5, 6), (0, 1, -2147483648, 5, 6), (0, -1, 4, 5, 6)):
+        with pytest.raises(mx.MatrixExtraError):
+            mx.check_sparse_matrix(fresh(p=p))
+    with pytest.raises(mx.MatrixExtraError, match="invalid column indices"):
+        mx.check_sparse_matrix(fresh(j=(4, 1, 2, 4, 1, 10)))
+    with pytest.raises(mx.MatrixExtraError, match="negative indices"):
+        mx.check_sparse_matrix(fresh(j=(4, 1, 2, 4, -1, 0)))
+    with pytest.raises(mx.MatrixExtraError, match="not monotonicaly increasing"):
+        mx.check_sparse_matrix(fresh(p=(0, 5, 4, 5, 6)))
+    mx.check_sparse_matrix(fresh())
+    Z = mx.dgRMatrix([0, 2, 3], [3, 0, 1], [0.0, 2.0, 0.0], (2, 4))  # zeros leave first, then the sort (in place: nnz changed)
+    Zc = mx.check_sparse_matrix(Z)
+    assert Zc.j.tolist() == [0] and Zc.x.tolist() == [2.0] and Zc.p.tolist() == [0, 1, 1]

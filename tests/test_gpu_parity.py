@@ -990,3 +990,70 @@ def test_spmm_plan_rows_and_auto_choice(gpu):
         _lib.check(lib.mxd_spmm_auto_algo(C.c_int(mm), C.c_int(nn), C.c_int(KK), C.c_int(_lib.MX_F64), al, C.c_size_t(nn), al,
                                           C.c_size_t(mm), C.c_int(1), C.byref(pick)))
         assert pick.value == want, (mm, nn, KK, pick.value)
+
+
+@pytest.mark.parametrize("m,K,dens", [(1, 1, 1.0), (37, 5, 0.6), (700, 300, 0.05), (5000, 64, 0.9), (20000, 4000, 0.004)])
+def test_remove_zero_valued_csr(gpu, m, K, dens):
+    """remove_zero_valued_csr_{numeric,logical} (src/misc.cpp:553-698) — what `remove_zeros` runs after A - B has left
+    explicit zeros behind: structure and values bit for bit the oracle's, for every lanes-per-row choice (row lengths from
+    0.3 to 58 entries on average), with -0.0, NaN, NA_real_ (payload kept), and the reference's quirk for R logicals with
+    remove_NAs (the zeros stay).  Nothing to remove: the INPUT objects come back."""
+    rng = np.random.default_rng(m + K)
+    p, j, x = rand_csr(m, K, dens, seed=m, empty_rows=(0,) if m > 30 else ())
+    if x.size == 0:
+        return
+    x = x.copy()
+    x[rng.random(x.size) < 0.3] = 0.0
+    x[rng.random(x.size) < 0.05] = -0.0
+    x[rng.random(x.size) < 0.1] = np.nan
+    na_real = np.array([0x7FF00000000007A2], dtype=np.uint64).view(np.float64)[0]
+    x[rng.random(x.size) < 0.05] = na_real
+    xl = rng.choice(np.array([0, 1, NA], dtype=np.int32), size=x.size, p=[0.3, 0.5, 0.2])
+    for rm in (False, True):
+        assert_list_equal(G.remove_zero_valued_csr_numeric(p, j, x, rm), O.remove_zero_valued_csr_numeric(p, j, x, rm))
+        assert_list_equal(G.remove_zero_valued_csr_logical(p, j, xl, rm), O.remove_zero_valued_csr_logical(p, j, xl, rm))
+    ones = np.ones(x.size)
+    r = G.remove_zero_valued_csr_numeric(p, j, ones, True)
+    assert r["indptr"] is p and r["indices"] is j and r["values"] is ones
+    only_nan = ones.copy(); only_nan[x.size // 2] = np.nan
+    assert G.remove_zero_valued_csr_numeric(p, j, only_nan, False)["values"] is only_nan
+    assert_list_equal(G.remove_zero_valued_csr_numeric(p, j, only_nan, True), O.remove_zero_valued_csr_numeric(p, j, only_nan, True))
+    lz = np.ones(x.size, dtype=np.int32); lz[0] = 0                  # zeros trigger the rebuild but stay
+    g = G.remove_zero_valued_csr_logical(p, j, lz, True)
+    assert g["values"] is not lz
+    assert_list_equal(g, O.remove_zero_valued_csr_logical(p, j, lz, True))
+    allz = np.zeros(x.size)                                          # everything leaves: empty indices / values, indptr of zeros
+    assert_list_equal(G.remove_zero_valued_csr_numeric(p, j, allz, False), O.remove_zero_valued_csr_numeric(p, j, allz, False))
+
+
+def test_remove_zeros_after_a_subtraction(gpu):
+    """the caller's sequence: X - Y keeps cancelled entries as explicit zeros (operators.cpp:477-495), remove_zeros drops them"""
+    p1, j1, x1 = rand_csr(3000, 500, 0.05, seed=1)
+    d = G.add_csr_elemwise(p1, p1.copy(), j1, j1.copy(), x1, x1.copy(), True)      # X - X: every entry an explicit zero
+    assert d["indices"].size == j1.size and not d["values"].any()
+    z = G.remove_zero_valued_csr_numeric(d["indptr"], d["indices"], d["values"], False)
+    assert z["indices"].size == 0 and z["values"].size == 0 and not z["indptr"].any() and z["indptr"].size == p1.size
+
+
+def test_check_valid_csr_matrix(gpu):
+    """check_valid_csr_matrix (src/misc.cpp:970-1016): the reference's messages in the reference's order of checks"""
+    p, j, _ = rand_csr(4000, 900, 0.02, seed=3)
+    cases = [(p, j, 4000, 900), (p, j, 4000, int(j.max()))]
+    jn = j.copy(); jn[j.size // 2] = -1
+    cases.append((p, jn, 4000, 900))
+    jna = j.copy(); jna[-1] = NA
+    cases.append((p, jna, 4000, 900))
+    pn = p.copy(); pn[1234] = NA
+    cases.append((pn, j, 4000, 900))
+    pd = p.copy(); pd[2000] = pd[2001] + 1
+    cases.append((pd, j, 4000, 900))
+    jb = j.copy(); jb[0] = 5000
+    cases.append((pd, jb, 4000, 900))
+    cases.append((np.zeros(1, dtype=np.int32), np.zeros(0, dtype=np.int32), 0, 0))
+    cases.append((np.zeros(6, dtype=np.int32), np.zeros(0, dtype=np.int32), 5, 3))
+    seen = set()
+    for args in cases:
+        g, o = G.check_valid_csr_matrix(*args), O.check_valid_csr_matrix(*args)
+        assert g == o, (g, o)
+        seen.add(g.get("err", ""))
+    assert len(seen) == 5

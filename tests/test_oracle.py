@@ -467,3 +467,66 @@ def test_oracle_csr_by_dvec_with_NAs_matches_dense_r_arithmetic():
             np.testing.assert_array_equal(np.isnan(got), np.isnan(exp), err_msg=f"{name} len={ln}")
             ok = ~np.isnan(exp)
             np.testing.assert_allclose(got[ok], exp[ok], rtol=1e-14)
+
+
+def _drop_reference(p, j, x, remove_NAs, logical):
+    """remove_zero_valued_csr restated with numpy masks (src/misc.cpp:553-664), incl. its first scan and its quirk"""
+    NA = np.int32(-2147483648)
+    if logical:
+        dirty = (x == 0) | ((x == NA) if remove_NAs else False)
+        keep = (x != NA) if remove_NAs else (x != 0)             # (with remove_NAs the zeros STAY: misc.cpp:636-647)
+    else:
+        dirty = (x == 0) | (np.isnan(x) if remove_NAs else False)
+        keep = (x != 0) & (~np.isnan(x) if remove_NAs else True)
+    if not np.any(dirty):
+        return None
+    rows = np.repeat(np.arange(p.size - 1), np.diff(p))
+    counts = np.bincount(rows[keep], minlength=p.size - 1)
+    return np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), j[keep], x[keep]
+
+
+def test_remove_zero_valued_csr_follows_the_reference_loop():
+    NA = -2147483648
+    for seed in range(6):
+        p, j, x = rand_csr(60, 40, 0.2, seed=seed, empty_rows=(3, 59))
+        x = x.copy()
+        rng = np.random.default_rng(seed)
+        x[rng.random(x.size) < 0.2] = 0.0
+        x[rng.random(x.size) < 0.05] = -0.0
+        x[rng.random(x.size) < 0.1] = np.nan
+        xl = rng.choice(np.array([0, 1, NA], dtype=np.int32), size=x.size)
+        for rm in (False, True):
+            for vals, logical, fn in ((x, False, O.remove_zero_valued_csr_numeric), (xl, True, O.remove_zero_valued_csr_logical)):
+                got = fn(p, j, vals, rm)
+                want = _drop_reference(p, j, vals, rm, logical)
+                assert want is not None
+                np.testing.assert_array_equal(got["indptr"], want[0])
+                np.testing.assert_array_equal(got["indices"], want[1])
+                np.testing.assert_array_equal(got["values"], want[2])        # (NaN == NaN for assert_array_equal)
+    # nothing to remove: the INPUT objects themselves (misc.cpp:586-590)
+    p, j, x = rand_csr(20, 10, 0.3, seed=9)
+    r = O.remove_zero_valued_csr_numeric(p, j, x, True)
+    assert r["indptr"] is p and r["indices"] is j and r["values"] is x
+    xn = x.copy(); xn[0] = np.nan
+    assert O.remove_zero_valued_csr_numeric(p, j, xn, False)["values"] is xn     # a NaN alone is nothing to remove ...
+    assert O.remove_zero_valued_csr_numeric(p, j, xn, True)["values"].size == x.size - 1   # ... unless NAs are to leave
+    # R logicals, remove_NAs: zeros trigger the rebuild but stay
+    xl = np.ones(x.size, dtype=np.int32); xl[1] = 0
+    r = O.remove_zero_valued_csr_logical(p, j, xl, True)
+    assert r["values"] is not xl and np.array_equal(r["values"], xl) and np.array_equal(r["indptr"], p)
+
+
+def test_check_valid_csr_matrix_messages_in_the_reference_order():
+    p, j, _ = rand_csr(30, 12, 0.3, seed=2)
+    assert O.check_valid_csr_matrix(p, j, 30, 12) == {}
+    assert O.check_valid_csr_matrix(p, j, 30, int(j.max()))["err"] == "Matrix has invalid column indices."
+    jn = j.copy(); jn[5] = -1
+    assert O.check_valid_csr_matrix(p, jn, 30, 12)["err"] == "Matrix has negative indices."
+    jn[5] = -2147483648                                              # NA among the indices is "negative" first
+    assert O.check_valid_csr_matrix(p, jn, 30, 12)["err"] == "Matrix has negative indices."
+    pn = p.copy(); pn[7] = -2147483648
+    assert O.check_valid_csr_matrix(pn, j, 30, 12)["err"] == "Matrix has missing values in the index pointer."
+    pd = p.copy(); pd[10] = pd[11] + 1
+    assert O.check_valid_csr_matrix(pd, j, 30, 12)["err"] == "Matrix index pointer is not monotonicaly increasing."
+    jb = j.copy(); jb[0] = 99                                        # both wrong: the index check comes first
+    assert O.check_valid_csr_matrix(pd, jb, 30, 12)["err"] == "Matrix has invalid column indices."

@@ -63,6 +63,17 @@ while time.time() < t_end:
         for sub in (False, True):
             what = f"add sub={sub}"; trace("  start", what)
             same_list(G.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub), O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub), what)
+        if "dropzeros" not in SKIP:                                  # what remove_zeros runs after the subtraction above
+            d = O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, True)
+            dv = d["values"].copy()
+            if dv.size and rng.random() < 0.5:
+                dv[rng.random(dv.size) < 0.2] = np.nan
+            for rm in (False, True):
+                what = f"remove zeros na.rm={rm}"; trace("  start", what)
+                same_list(G.remove_zero_valued_csr_numeric(d["indptr"], d["indices"], dv, rm),
+                          O.remove_zero_valued_csr_numeric(d["indptr"], d["indices"], dv, rm), what)
+            what = "check valid"; trace("  start", what)
+            assert G.check_valid_csr_matrix(p1, j1, m, K) == O.check_valid_csr_matrix(p1, j1, m, K) == {}, what
         what = "mul"; trace("  start", what)
         same_list(G.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2), O.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2), what)
         l1 = rand_csr(m, K, d1, seed=s1, dtype="l")

@@ -594,6 +594,25 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
         byts = 4 * (m4 + 1) + 4 * A1.nnz
         res["rows_sorted_check_cfg4"] = {"ms": round(t * 1e3, 4),
                                          "roofline": roofline(byts, t, **committed_kernels_traffic([("rows_sorted_tile_kernel", 1)], t * 1e3))}
+        # what remove_zeros runs after a subtraction has left explicit zeros behind (R/utils.R:263-330 -> misc.cpp:553-664):
+        # the first operand with 30 % of its values zeroed
+        gen = torch.Generator(device="cuda"); gen.manual_seed(11)
+        xz = torch.where(torch.rand(x1.numel(), device="cuda", generator=gen) < 0.3, torch.zeros_like(x1), x1)
+        Az = D.DeviceCSR(p1, j1, xz, m4, K4, A1.nnz)
+        Rz = D.csr_drop_zeros(Az)
+        t = timeit(lambda: D.csr_drop_zeros(Az), reps=5)
+        byts = 2 * 4 * (m4 + 1) + 12 * Az.nnz + 12 * Rz.nnz
+        oz = O.remove_zero_valued_csr_numeric(hp1, hj1, xz[: hp1[-1]].cpu().numpy(), False)
+        n_s = int(oz["indptr"][-1])
+        assert np.array_equal(Rz.indptr[: rs + 1].cpu().numpy(), oz["indptr"]) and \
+            np.array_equal(Rz.indices[:n_s].cpu().numpy(), oz["indices"]) and \
+            np.array_equal(Rz.values[:n_s].cpu().numpy(), oz["values"]), "remove_zero_valued_csr differs from the oracle"
+        res["drop_zeros_cfg4"] = {"ms": round(t * 1e3, 4), "nnz_in": Az.nnz, "nnz_out": Rz.nnz,
+                                  "roofline": roofline(byts, t),
+                                  "kernels": "drop_count_kernel + scan + drop_fill_kernel (values read twice: the count's 8 B per "
+                                             "entry are overhead, not algorithmic bytes)",
+                                  "parity": f"bit-exact vs oracle on the first {rs} rows (indptr, indices, values)"}
+        del Az, Rz, xz, oz
         del A1, A2, p1, j1, x1, p2, j2, x2
         torch.cuda.empty_cache()
 

@@ -57,7 +57,10 @@ void drop_count_kernel(int m, const int32_t *__restrict__ indptr, const VT *__re
 #pragma unroll
     for (int s = G / 2; s > 0; s >>= 1) kept += __shfl_xor(kept, s, MX_WAVE);
     if (row < m && lg == 0) counts[row] = kept;
-    if (__ballot(d) != 0ull && lane_id() == 0) atomicOr(dirty, 1u);
+    // (one flag for the whole grid: same-address atomics serialise at ~10 ns each, and 2M wavefronts setting it cost 20 ms
+    // at cfg4 size — a wavefront first looks whether somebody else has already done it)
+    if (__ballot(d) != 0ull && lane_id() == 0 && __hip_atomic_load(dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        atomicOr(dirty, 1u);
 }
 
 template <int G, int MODE, typename VT>
@@ -133,6 +136,16 @@ static int launch_drop_fill(int G, int m, const int32_t *indptr, const int32_t *
     return 0;
 }
 
+// lanes per row (MXGPU_DROP_G: A/B runs)
+static int drop_group(int m, int64_t nnz)
+{
+    static const int forced = [] { const char *e = getenv("MXGPU_DROP_G"); return e ? atoi(e) : 0; }();
+    if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
+    // half the lanes the mean row length would fill: two rounds per row keep more rows — more independent loads — in a
+    // wavefront (cfg4 size, 50 per row: 0.86 ms with 32 lanes, 1.11 with 64; 12 per row: 0.31 with 8, 0.38 with 16)
+    return nnz < 0 ? 16 : std::max(4, pick_group((double)nnz / (double)(m > 0 ? m : 1)) / 2);
+}
+
 // ---- check_valid_csr_matrix -------------------------------------------------------------------------------------
 // out[0] = min index, out[1] = max index, out[2] = NA in the index pointer, out[3] = index pointer decreases somewhere
 __global__ __launch_bounds__(256)
@@ -189,7 +202,7 @@ extern "C" int mxd_csr_drop_count(int m, int64_t nnz, const int32_t *indptr, con
     MX_HIP(hipMemsetAsync(workspace, 0, 16, st));
     if (m == 0) MX_HIP(hipMemsetAsync(out_indptr, 0, sizeof(int32_t), st));
     else {
-        const int G = nnz < 0 ? 32 : mx::pick_group((double)nnz / (double)m);
+        const int G = mx::drop_group(m, nnz);
         int rc;
         if (value_dtype == MX_F64)
             rc = remove_NAs ? mx::launch_drop_count<1, double>(G, m, indptr, values, counts, dirty, st)
@@ -217,7 +230,7 @@ extern "C" int mxd_csr_drop_fill(int m, int64_t nnz, const int32_t *indptr, cons
     MX_REQUIRE(value_dtype == MX_F64 || value_dtype == MX_LGL, "mxd_csr_drop_fill: values must be f64 or R logical");
     if (m == 0) return 0;
     hipStream_t st = mx::as_stream(stream);
-    const int G = nnz < 0 ? 32 : mx::pick_group((double)nnz / (double)m);
+    const int G = mx::drop_group(m, nnz);
     if (value_dtype == MX_F64)
         return remove_NAs ? mx::launch_drop_fill<1, double>(G, m, indptr, indices, values, out_indptr, out_indices, out_values, st)
                           : mx::launch_drop_fill<0, double>(G, m, indptr, indices, values, out_indptr, out_indices, out_values, st);

@@ -258,6 +258,27 @@ def csr_elemwise(op, A: DeviceCSR, B: DeviceCSR, two_pass: bool = True):
     return DeviceCSR(out_p, out_j, out_x, A.m, A.K, int(nnz_out.value))
 
 
+def csr_drop_zeros(A: DeviceCSR, remove_NAs: bool = False):
+    """remove_zero_valued_csr on a device-resident matrix (src/misc.cpp:553-664): count -> scan -> (host round trip for
+    nnz) -> ordered compaction.  Returns A itself when the reference's first scan would find nothing to remove."""
+    lib = _lib.load()
+    dev = A.indptr.device
+    vd = MX_F64 if A.values.dtype == torch.float64 else MX_LGL
+    lib.mxd_csr_drop_workspace_bytes.restype = C.c_size_t
+    ws = torch.empty(lib.mxd_csr_drop_workspace_bytes(C.c_int(A.m)), dtype=torch.uint8, device=dev)
+    out_p = torch.empty(A.m + 1, dtype=torch.int32, device=dev)
+    nnz_out, dirty = C.c_int64(0), C.c_int(0)
+    check(lib.mxd_csr_drop_count(C.c_int(A.m), C.c_int64(A.nnz), _dp(A.indptr), _dp(A.values), C.c_int(vd),
+                                 C.c_int(1 if remove_NAs else 0), _dp(out_p), _dp(ws), C.byref(nnz_out), C.byref(dirty), _stream()))
+    if not dirty.value:
+        return A
+    out_j = torch.empty(nnz_out.value, dtype=torch.int32, device=dev)
+    out_x = torch.empty(nnz_out.value, dtype=A.values.dtype, device=dev)
+    check(lib.mxd_csr_drop_fill(C.c_int(A.m), C.c_int64(A.nnz), _dp(A.indptr), _dp(A.indices), _dp(A.values), C.c_int(vd),
+                                C.c_int(1 if remove_NAs else 0), _dp(out_p), _dp(out_j), _dp(out_x), _stream()))
+    return DeviceCSR(out_p, out_j, out_x, A.m, A.K, int(nnz_out.value))
+
+
 def csr_gather_rows(A: DeviceCSR, rows: torch.Tensor, one_launch: bool = True):
     """A[rows, :] on device (copy_csr_rows).  rows int32, 0-based.
     one_launch (default): mxd_csr_gather_fused into arrays sized for 1.25x the expected result (r mean row lengths) — one

@@ -170,11 +170,18 @@ void csr_valid_kernel(int m, int64_t nnz, const int32_t *__restrict__ indptr, co
         hi = max(hi, __shfl_xor(hi, s, MX_WAVE));
     }
     const bool any_na = __ballot(na) != 0ull, any_dec = __ballot(dec) != 0ull;
-    if (lane_id() == 0) {
+    // one set of atomics per workgroup (same-address atomics serialise: ~10 ns each)
+    __shared__ int s_lo[4], s_hi[4], s_fl[4];
+    const int w = threadIdx.x / MX_WAVE;
+    if (lane_id() == 0) { s_lo[w] = lo; s_hi[w] = hi; s_fl[w] = (any_na ? 1 : 0) | (any_dec ? 2 : 0); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int fl = 0;
+        for (int k = 0; k < 4; k++) { lo = min(lo, s_lo[k]); hi = max(hi, s_hi[k]); fl |= s_fl[k]; }
         if (lo != INT_MAX) atomicMin(out + 0, lo);
         if (hi != INT_MIN) atomicMax(out + 1, hi);
-        if (any_na) atomicOr(out + 2, 1);
-        if (any_dec) atomicOr(out + 3, 1);
+        if (fl & 1) atomicOr(out + 2, 1);
+        if (fl & 2) atomicOr(out + 3, 1);
     }
 }
 
@@ -248,7 +255,7 @@ extern "C" int mxd_csr_check_valid(int m, int ncols, int64_t nnz, const int32_t 
     hipStream_t st = mx::as_stream(stream);
     hipLaunchKernelGGL(mx::csr_valid_init_kernel, dim3(1), dim3(1), 0, st, flags_dev);
     const long long work = (long long)std::max<int64_t>(nnz, (int64_t)m + 1);
-    const unsigned grid = (unsigned)std::min<long long>(4096, std::max<long long>(1, mx::ceil_div(work, (long long)(256 * 8))));
+    const unsigned grid = (unsigned)std::min<long long>(2048, std::max<long long>(1, mx::ceil_div(work, (long long)(256 * 8))));
     hipLaunchKernelGGL(mx::csr_valid_kernel, dim3(grid), dim3(256), 0, st, m, nnz, indptr, indices, flags_dev);
     MX_LAUNCH_CHECK();
     int f[4];

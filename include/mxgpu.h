@@ -557,6 +557,11 @@ int mx_reverse_columns_inplace(const int32_t *indptr, int nrows, int32_t *indice
 int mx_matmul_csr_svec(const int32_t *X_indptr, const int32_t *X_indices, const double *X_values, int nrows_X,
                        const int32_t *y_indices_base1, int64_t ny, const void *y_values, int kind, int nthreads,
                        double *out);
+/* matmul_rowvec_by_csc / matmul_rowvec_by_cscbin  src/matmul.cpp:643-684 (float32 row vector %*% CsparseMatrix,
+ * R/matmul.R:243-259,350-365,411-425): out[ncols_Y] float32, accumulated in float like the reference; values NULL = the
+ * pattern kind (every stored entry counts as 1). */
+int mx_matmul_rowvec_by_csc(const float *rowvec, int len, const int32_t *indptr, const int32_t *indices, const double *values,
+                            int ncols_Y, float *out);
 /* multiply_csr_by_dense_elemwise_{double,float32,int,bool} + logicaland_csr_by_dense_cpp  src/operators.cpp:289-334:
  * dense_mat column-major nrows x ncols; values_out has nnz entries (f64, or int32 for kind 4). */
 int mx_multiply_csr_by_dense_elemwise(const int32_t *indptr, const int32_t *indices, const void *values, int nrows,

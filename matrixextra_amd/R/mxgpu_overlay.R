@@ -45,7 +45,9 @@
     "sort_sparse_indices_numeric", "sort_sparse_indices_logical", "sort_sparse_indices_numeric_known_ncol",
     "sort_sparse_indices_logical_known_ncol", "sort_sparse_indices_binary",
     ## what follows a merge (`remove_zeros`, R/utils.R:286-312) and what `check_sparse_matrix` asks (R/utils.R:448)
-    "remove_zero_valued_csr_numeric", "remove_zero_valued_csr_logical", "check_valid_csr_matrix"
+    "remove_zero_valued_csr_numeric", "remove_zero_valued_csr_logical", "check_valid_csr_matrix",
+    ## float32 row vector %*% CsparseMatrix (R/matmul.R:243-259, 350-365, 411-425)
+    "matmul_rowvec_by_csc", "matmul_rowvec_by_cscbin"
 )
 
 mxgpu_enable <- function(shim_path, min_nnz = 0L) {

@@ -1260,6 +1260,19 @@ int mx_matmul_csr_dvec_float32(const int32_t *p, const int32_t *j, const double 
     return spmv_host<float, float>(nrows_X, p, j, x, y, len_y, MX_F32, out);
 }
 
+// matmul_rowvec_by_csc / _cscbin (matmul.cpp:643-684): float32 row vector x CSC.  Column `col` of the result is
+// sum over the column's entries of values[ix] * rowvec[indices[ix]], accumulated in float — term by term the arithmetic of
+// matmul_csr_dvec's float32 kind (matmul.cpp:403) on the CSC arrays read as the CSR arrays of the transpose.  The pattern
+// kind has no values: every stored entry counts as 1 (float + float is what (float)(double + 1.0 * double) rounds to).
+int mx_matmul_rowvec_by_csc(const float *rowvec, int len, const int32_t *indptr, const int32_t *indices, const double *values,
+                            int ncols_Y, float *out)
+{
+    MX_REQUIRE(ncols_Y >= 0 && indptr && (len == 0 || rowvec), "mx_matmul_rowvec_by_csc: bad arguments");
+    if (values) return spmv_host<float, float>(ncols_Y, indptr, indices, values, rowvec, len, MX_F32, out);
+    std::vector<double> ones((size_t)std::max(indptr[ncols_Y], 1), 1.0);
+    return spmv_host<float, float>(ncols_Y, indptr, indices, ones.data(), rowvec, len, MX_F32, out);
+}
+
 // ---- CSR (+) CSR -------------------------------------------------------------------------------
 int mx_csr_elemwise_begin(int op, int nrows, const int32_t *indptr1, const int32_t *indptr2,
                           const int32_t *indices1, const int32_t *indices2, const void *values1,

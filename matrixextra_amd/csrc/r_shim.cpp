@@ -559,6 +559,21 @@ SEXP _MatrixExtra_sort_sparse_indices_numeric_known_ncol(SEXP p_, SEXP j_, SEXP 
 SEXP _MatrixExtra_sort_sparse_indices_logical_known_ncol(SEXP p_, SEXP j_, SEXP x_, SEXP ncol) { (void)ncol; return sort_inplace(p_, j_, x_, MX_LGL); }
 SEXP _MatrixExtra_sort_sparse_indices_binary(SEXP p_, SEXP j_) { return sort_inplace(p_, j_, R_NilValue, MX_NONE); }
 
+// ---- matmul_rowvec_by_csc / _cscbin (matmul.cpp:643-684): float32 row vector x CSC -> IntegerMatrix(1, ncols) of float bits
+static SEXP rowvec_by_csc(SEXP rowvec, SEXP p_, SEXP i_, SEXP x_)
+{
+    Protect p;
+    rowvec = as_type(rowvec, INTSXP, p); p_ = as_type(p_, INTSXP, p); i_ = as_type(i_, INTSXP, p);
+    const double *x = nullptr;
+    if (x_ != R_NilValue) { x_ = as_type(x_, REALSXP, p); x = REAL(x_); }
+    const int ncols = (int)XLENGTH(p_) - 1;
+    SEXP out = p(Rf_allocMatrix(INTSXP, 1, ncols));
+    if (mx_matmul_rowvec_by_csc(f32(rowvec), (int)XLENGTH(rowvec), INTEGER(p_), INTEGER(i_), x, ncols, f32w(out))) fail();
+    return out;
+}
+SEXP _MatrixExtra_matmul_rowvec_by_csc(SEXP rowvec, SEXP p_, SEXP i_, SEXP x_) { return rowvec_by_csc(rowvec, p_, i_, x_); }
+SEXP _MatrixExtra_matmul_rowvec_by_cscbin(SEXP rowvec, SEXP p_, SEXP i_) { return rowvec_by_csc(rowvec, p_, i_, R_NilValue); }
+
 // ---- remove_zero_valued_csr_{numeric,logical} (misc.cpp:667-698), check_valid_csr_matrix (misc.cpp:970-1016) ------------
 static SEXP remove_zero_valued(SEXP p_, SEXP j_, SEXP x_, SEXP remove_NAs, int dtype)
 {
@@ -650,6 +665,7 @@ static const R_CallMethodDef mxgpu_call_entries[] = {
     MX_ENTRY(sort_sparse_indices_binary, 2),
     MX_ENTRY(remove_zero_valued_csr_numeric, 4), MX_ENTRY(remove_zero_valued_csr_logical, 4),
     MX_ENTRY(check_valid_csr_matrix, 4),
+    MX_ENTRY(matmul_rowvec_by_csc, 4), MX_ENTRY(matmul_rowvec_by_cscbin, 3),
     {NULL, NULL, 0}
 };
 

@@ -585,3 +585,19 @@ def check_valid_csr_matrix(indptr, indices, nrows, ncols):
     check(lib.mx_check_valid_csr_matrix(ptr(p), ptr(j), C.c_int64(j.size), C.c_int(int(nrows)), C.c_int(int(ncols)),
                                         C.byref(code), C.byref(msg)))
     return dict(err=msg.value.decode()) if code.value else dict()
+
+
+def matmul_rowvec_by_csc(rowvec, indptr, indices, values):
+    """R/RcppExports.R `matmul_rowvec_by_csc` -> src/matmul.cpp:643-663: float32 row vector x CSC, (1, ncols) float32."""
+    lib = _lib.load()
+    r = np.ascontiguousarray(rowvec, dtype=np.float32).reshape(-1)
+    p, j = _i32(indptr), _i32(indices)
+    v = None if values is None else _f64(values)
+    out = np.zeros((1, p.size - 1), dtype=np.float32)
+    check(lib.mx_matmul_rowvec_by_csc(ptr(r), C.c_int(r.size), ptr(p), ptr(j), ptr(v), C.c_int(p.size - 1), ptr(out)))
+    return out
+
+
+def matmul_rowvec_by_cscbin(rowvec, indptr, indices):
+    """R/RcppExports.R `matmul_rowvec_by_cscbin` -> src/matmul.cpp:665-684 (pattern matrix: every stored entry is 1)."""
+    return matmul_rowvec_by_csc(rowvec, indptr, indices, None)

@@ -111,6 +111,13 @@ def gemm_dense_csc(x, y):
 
 def gemm_f32_csc(x, y):
     """float32 %*% CsparseMatrix — R/matmul.R:202-279."""
+    if x.is_vector:                       # R/matmul.R:209-262: a float32 VECTOR is a row vector unless y has one row
+        check_valid_matrix(y)
+        if y.nrow() == 1:                 # (outer product -> dgCMatrix, matmul_colvec_by_scolvecascsr_f32: stays on the CPU)
+            stop("float32 vector %*% one-row CsparseMatrix is not on the GPU path.")
+        if y.nrow() != x.Data.size:
+            stop("(row) vector-Matrix multiplication dimensions do not match.")
+        return float32(exports.matmul_rowvec_by_csc(x.Data, y.p, y.i, y.x))
     check_dimensions_match(x, y, matmult=True)
     check_valid_matrix(y)
     res = float32(exports.matmul_dense_csc_float32(x.Data, y.p, y.i, y.x, _nthreads()))

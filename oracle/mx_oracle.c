@@ -936,3 +936,18 @@ int mxo_check_valid_csr_matrix(const int *indptr, const int *indices, long long 
     for (int i = 0; i < nrows; i++) if (indptr[i] > indptr[i + 1]) return 5;
     return 0;
 }
+
+
+/* matmul_rowvec_by_csc / matmul_rowvec_by_cscbin  src/matmul.cpp:643-684: out[col] += values[ix] * rowvec[indices[ix]] with
+ * `out` a float — every term is added in double and rounded to float at once; values NULL: out[col] += rowvec[indices[ix]]. */
+void mxo_matmul_rowvec_by_csc(const float *rowvec, const int *indptr, const int *indices, const double *values, int ncols,
+                              float *out)
+{
+    for (int col = 0; col < ncols; col++) {
+        out[col] = 0;
+        for (int ix = indptr[col]; ix < indptr[col + 1]; ix++) {
+            if (values) out[col] += values[ix] * rowvec[indices[ix]];
+            else out[col] += rowvec[indices[ix]];
+        }
+    }
+}

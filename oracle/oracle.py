@@ -720,3 +720,18 @@ def check_valid_csr_matrix(indptr, indices, nrows, ncols):
     p, j = _i32(indptr), _i32(indices)
     code = lib().mxo_check_valid_csr_matrix(_p(p), _p(j), C.c_longlong(j.size), C.c_int(nrows), C.c_int(ncols))
     return dict(err=_VALID_CSR_MESSAGES[code]) if code else dict()
+
+
+def matmul_rowvec_by_csc(rowvec, indptr, indices, values):
+    """src/matmul.cpp:643-663"""
+    r = np.ascontiguousarray(rowvec, dtype=np.float32).reshape(-1)
+    p, j = _i32(indptr), _i32(indices)
+    v = None if values is None else _f64(values)
+    out = np.zeros((1, p.size - 1), dtype=np.float32)
+    lib().mxo_matmul_rowvec_by_csc(_p(r), _p(p), _p(j), _p(v) if v is not None else None, C.c_int(p.size - 1), _p(out))
+    return out
+
+
+def matmul_rowvec_by_cscbin(rowvec, indptr, indices):
+    """src/matmul.cpp:665-684"""
+    return matmul_rowvec_by_csc(rowvec, indptr, indices, None)

@@ -323,3 +323,14 @@ def test_checking_indices(gpu):                                   # tests/testth
     Z = mx.dgRMatrix([0, 2, 3], [3, 0, 1], [0.0, 2.0, 0.0], (2, 4))  # zeros leave first, then the sort (in place: nnz changed)
     Zc = mx.check_sparse_matrix(Z)
     assert Zc.j.tolist() == [0] and Zc.x.tolist() == [2.0] and Zc.p.tolist() == [0, 1, 1]
+
+
+def test_float32_vector_times_csc(gpu):                           # R/matmul.R:243-259 (float32 row vector %*% CsparseMatrix)
+    As = rsparse(30, 12, 0.3, seed=4)[1].tocsc()
+    Y = mx.dgCMatrix(As.indptr, As.indices, As.data, As.shape)
+    v = np.random.default_rng(5).normal(size=30).astype(np.float32)
+    res = mx.float32(v) @ Y
+    assert isinstance(res, mx.float32) and res.Data.shape == (1, 12)
+    np.testing.assert_allclose(res.Data[0], v.astype(np.float64) @ As.toarray(), rtol=1e-5, atol=1e-5)
+    with pytest.raises(mx.MatrixExtraError, match="dimensions do not match"):
+        mx.float32(v[:7]) @ Y

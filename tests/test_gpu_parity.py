@@ -1057,3 +1057,19 @@ def test_check_valid_csr_matrix(gpu):
         assert g == o, (g, o)
         seen.add(g.get("err", ""))
     assert len(seen) == 5
+
+
+@pytest.mark.parametrize("ncols,nrows,dens", [(1, 1, 1.0), (300, 200, 0.1), (5000, 4000, 0.02), (70000, 3000, 0.01)])
+def test_matmul_rowvec_by_csc(gpu, ncols, nrows, dens):
+    """matmul_rowvec_by_csc / _cscbin (src/matmul.cpp:643-684): float32 row vector x CSC, accumulated in float.  Against the
+    oracle's loop to float tolerance (the lane-group kernel adds a column's terms in another order) and, for the flat
+    kernel's sizes, bit for bit."""
+    p, j, x = rand_csr(ncols, nrows, dens, seed=ncols, empty_rows=(0,) if ncols > 10 else ())
+    v = np.random.default_rng(ncols + 1).normal(size=nrows).astype(np.float32)
+    for got, want in ((G.matmul_rowvec_by_csc(v, p, j, x), O.matmul_rowvec_by_csc(v, p, j, x)),
+                      (G.matmul_rowvec_by_cscbin(v, p, j), O.matmul_rowvec_by_cscbin(v, p, j))):
+        assert got.shape == want.shape == (1, ncols) and got.dtype == np.float32
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * scale)
+        if j.size >= (1 << 20):                                      # AUTO takes the flat kernel: the reference's order of additions
+            np.testing.assert_array_equal(got, want)

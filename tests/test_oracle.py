@@ -530,3 +530,17 @@ def test_check_valid_csr_matrix_messages_in_the_reference_order():
     assert O.check_valid_csr_matrix(pd, j, 30, 12)["err"] == "Matrix index pointer is not monotonicaly increasing."
     jb = j.copy(); jb[0] = 99                                        # both wrong: the index check comes first
     assert O.check_valid_csr_matrix(pd, jb, 30, 12)["err"] == "Matrix has invalid column indices."
+
+
+def test_matmul_rowvec_by_csc_against_dense():
+    """src/matmul.cpp:643-684: float32 row vector x CSC (the CSC arrays of Y = the CSR arrays of t(Y))"""
+    p, j, x = rand_csr(40, 25, 0.3, seed=5, empty_rows=(7,))         # 40 columns of Y, 25 rows
+    v = np.random.default_rng(6).normal(size=25).astype(np.float32)
+    Yt = csr_to_dense(p, j, x, 25)                                   # t(Y): 40 x 25
+    got = O.matmul_rowvec_by_csc(v, p, j, x)
+    assert got.shape == (1, 40) and got.dtype == np.float32
+    np.testing.assert_allclose(got[0], Yt @ v.astype(np.float64), rtol=2e-6, atol=2e-6)
+    np.testing.assert_array_equal(got[0], O.matmul_csr_dvec_float32(p, j, x, v))       # the same float accumulation (matmul.cpp:403)
+    gb = O.matmul_rowvec_by_cscbin(v, p, j)
+    np.testing.assert_allclose(gb[0], (Yt != 0) @ v.astype(np.float64), rtol=2e-6, atol=2e-6)
+    np.testing.assert_array_equal(gb, O.matmul_rowvec_by_csc(v, p, j, np.ones(j.size)))

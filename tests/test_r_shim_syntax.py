@@ -37,6 +37,7 @@ REFERENCE_ARITY = {
     "copy_csr_rows_col_seq_numeric": 6, "copy_csr_rows_col_seq_logical": 6, "copy_csr_rows_col_seq_binary": 5,
     "copy_csr_arbitrary_numeric": 5, "copy_csr_arbitrary_logical": 5, "copy_csr_arbitrary_binary": 4,
     "remove_zero_valued_csr_numeric": 4, "remove_zero_valued_csr_logical": 4, "check_valid_csr_matrix": 4,
+    "matmul_rowvec_by_csc": 4, "matmul_rowvec_by_cscbin": 3,                                             # :2248-2249
 }
 
 

@@ -608,7 +608,8 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
             np.array_equal(Rz.indices[:n_s].cpu().numpy(), oz["indices"]) and \
             np.array_equal(Rz.values[:n_s].cpu().numpy(), oz["values"]), "remove_zero_valued_csr differs from the oracle"
         res["drop_zeros_cfg4"] = {"ms": round(t * 1e3, 4), "nnz_in": Az.nnz, "nnz_out": Rz.nnz,
-                                  "roofline": roofline(byts, t),
+                                  "roofline": roofline(byts, t, **committed_kernels_traffic(
+                                      [("drop_count_kernel<32, 0, double>", 1), ("drop_fill_kernel<32, 0, double>", 1)], t * 1e3)),
                                   "kernels": "drop_count_kernel + scan + drop_fill_kernel (values read twice: the count's 8 B per "
                                              "entry are overhead, not algorithmic bytes)",
                                   "parity": f"bit-exact vs oracle on the first {rs} rows (indptr, indices, values)"}

@@ -17,7 +17,7 @@ bash tools/profile.sh $W/extras 1 -- --steps 10 --warmup 3 --no-cpu-baseline > $
 python3 tools/prof_summary_multi.py $W/extras $O/${RND}_extras extras-default spmv_flat_kernel slice_rows_kernel spmv_plan_kernel \
     gather_fused_kernel gather_count_kernel gather_copy_kernel "merge_count_kernel<64, false>" "merge_count_kernel<64, true>" \
     "merge_fill_kernel<64, 0" "merge_fill_kernel<64, 1" "merge_fill_kernel<64, 2" rows_sorted_tile_kernel stream_copy_kernel \
-    "spmm_rowwave_kernel<double, 2, false" csr_by_dvec_kernel > /dev/null
+    "spmm_rowwave_kernel<double, 2, false" csr_by_dvec_kernel "drop_count_kernel<32, 0, double>" "drop_fill_kernel<32, 0, double>" > /dev/null
 cp "$(ls -t $W/extras/trace/*/*_kernel_stats.csv | head -1)" $O/${RND}_extras_kernel_stats.csv
 # (c) configs[4]'s per-GPU shard on this GPU
 bash tools/profile.sh $W/cfg5 1 -- --config cfg5 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/log_cfg5.txt 2>&1

@@ -37,32 +37,53 @@ template <int MODE, typename VT> __device__ __forceinline__ bool dz_dirty(VT v)
     else return v == 0 || v == MX_NA_INT;
 }
 
+// A lane group counts DZ_ROWS rows at a time: the loads of all of them are issued before any is looked at (a row of 50
+// doubles is two loads per lane: one row per group left the memory pipeline mostly empty — 0.39 ms for 0.8 GB).
+constexpr int DZ_ROWS = 4;
 template <int G, int MODE, typename VT>
 __global__ __launch_bounds__(DZ_BLOCK)
 void drop_count_kernel(int m, const int32_t *__restrict__ indptr, const VT *__restrict__ values, int32_t *__restrict__ counts,
                        unsigned *__restrict__ dirty)
 {
     const int lg = threadIdx.x % G;
-    const long long row = (long long)blockIdx.x * (DZ_BLOCK / G) + threadIdx.x / G;
-    int kept = 0;
+    const long long row0 = ((long long)blockIdx.x * (DZ_BLOCK / G) + threadIdx.x / G) * DZ_ROWS;
+    int s[DZ_ROWS], n[DZ_ROWS], kept[DZ_ROWS];
+    int maxn = 0;
+#pragma unroll
+    for (int q = 0; q < DZ_ROWS; q++) {
+        const long long row = row0 + q;
+        s[q] = row < m ? indptr[row] : 0;
+        n[q] = row < m ? indptr[row + 1] - s[q] : 0;
+        kept[q] = 0;
+        maxn = max(maxn, n[q]);
+    }
     bool d = false;
-    if (row < m) {
-        const int e = indptr[row + 1];
-        for (int k = indptr[row] + lg; k < e; k += G) {
-            const VT v = values[k];
-            kept += dz_keep<MODE, VT>(v) ? 1 : 0;
-            d |= dz_dirty<MODE, VT>(v);
+    for (int k = lg; k < maxn; k += G) {
+        VT v[DZ_ROWS];
+#pragma unroll
+        for (int q = 0; q < DZ_ROWS; q++) v[q] = k < n[q] ? values[s[q] + k] : VT(1);     // (1: kept and clean, not counted below)
+#pragma unroll
+        for (int q = 0; q < DZ_ROWS; q++) {
+            if (k < n[q]) {
+                kept[q] += dz_keep<MODE, VT>(v[q]) ? 1 : 0;
+                d |= dz_dirty<MODE, VT>(v[q]);
+            }
         }
     }
 #pragma unroll
-    for (int s = G / 2; s > 0; s >>= 1) kept += __shfl_xor(kept, s, MX_WAVE);
-    if (row < m && lg == 0) counts[row] = kept;
+    for (int q = 0; q < DZ_ROWS; q++) {
+#pragma unroll
+        for (int sft = G / 2; sft > 0; sft >>= 1) kept[q] += __shfl_xor(kept[q], sft, MX_WAVE);
+        if (lg == 0 && row0 + q < m) counts[row0 + q] = kept[q];
+    }
     // (one flag for the whole grid: same-address atomics serialise at ~10 ns each, and 2M wavefronts setting it cost 20 ms
     // at cfg4 size — a wavefront first looks whether somebody else has already done it)
     if (__ballot(d) != 0ull && lane_id() == 0 && __hip_atomic_load(dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
         atomicOr(dirty, 1u);
 }
 
+// (the fill with DZ_ROWS rows per group in flight like the count was measured too: slower, 0.91 against 0.73 ms per call —
+// four rows' worth of scattered stores per round; it stays at one row per group)
 template <int G, int MODE, typename VT>
 __global__ __launch_bounds__(DZ_BLOCK)
 void drop_fill_kernel(int m, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const VT *__restrict__ values,
@@ -101,7 +122,7 @@ static int launch_drop_count(int G, int m, const int32_t *indptr, const void *va
 {
     const VT *x = (const VT *)values;
 #define MX_DZ_COUNT(GG)                                                                                                      \
-    hipLaunchKernelGGL((drop_count_kernel<GG, MODE, VT>), dim3((unsigned)ceil_div((long long)m, DZ_BLOCK / GG)), dim3(DZ_BLOCK), 0, \
+    hipLaunchKernelGGL((drop_count_kernel<GG, MODE, VT>), dim3((unsigned)ceil_div((long long)m, (DZ_BLOCK / GG) * DZ_ROWS)), dim3(DZ_BLOCK), 0, \
                        st, m, indptr, x, counts, dirty)
     switch (G) {
         case 4: MX_DZ_COUNT(4); break;

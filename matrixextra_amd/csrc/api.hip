@@ -3,6 +3,7 @@
 // device, running the HIP kernels and bringing the result back.  There is no
 // CPU fallback: without a usable GPU every call fails with an error.
 #include "mx_common.h"
+#include "tile_geometry.h"
 
 #include <algorithm>
 #include <atomic>
@@ -752,36 +753,28 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     // g is registered.  Before, the first block came down only when ALL pages of the result existed and were registered
     // (cfg2: ~9 ms into a 29 ms call; cfg5 whole: ~95 ms into a 250 ms call, the download queue idle until then).
     static const int tiles_on = [] { const char *e = getenv("MXGPU_EXPORT_TILES"); return e ? atoi(e) : 1; }();
-    int ng = shape == ROWS_STRIDED && tiles_on ? (int)std::min<size_t>({(size_t)MAX_BLK, (size_t)n, c_bytes / ((size_t)64 << 20)}) : 0;
-    std::vector<int> gcut((size_t)std::max(ng, 0) + 1, 0);
-    for (int g = 0; g <= ng; g++) gcut[g] = (int)((int64_t)n * g / std::max(ng, 1));
+    // (the cuts: csrc/tile_geometry.h — page-aligned pieces, the groups' last partial pages; property-tested on the CPU)
+    mx::TileGeometry tg;
+    if (shape == ROWS_STRIDED && tiles_on)
+        tg = mx::tile_geometry((uintptr_t)C_host, sizeof(real_t), m, n, ldc, MAX_BLK, (size_t)64 << 20, cut[nblk] - cut[nblk - 1]);
+    const bool tiled = tg.ok;
+    const int ng = tiled ? tg.ng : 0;
+    const std::vector<int> &gcut = tg.gcut, &tail = tg.tail;
     // Contiguous shapes: the result is first-touched, registered and downloaded in PIECES that follow the blocks but are cut
     // at page boundaries of the caller's buffer (piece b = bytes [hb[b], hb[b+1]) of the result: block b without its last
     // partial page, plus the last partial page of block b-1), so that no page is registered twice.
     const bool incremental = shape != ROWS_STRIDED;
-    bool tiled = !incremental && ng >= 2 && ldc == (size_t)m;
-    const int npieces = incremental ? nblk : (tiled ? ng : 0);
+    const int npieces = incremental ? nblk : ng;
     std::vector<size_t> hb((size_t)std::max(npieces, 0) + 1, 0);
-    for (int b = 1; b < npieces; b++) {
-        const size_t first = incremental ? (size_t)cut[b] * ldc : (size_t)gcut[b] * ldc;     // first element of piece b
-        const uintptr_t start = (uintptr_t)(C_host + first), page = start & ~(uintptr_t)4095;
+    if (tiled) hb = tg.hb;
+    for (int b = 1; incremental && b < npieces; b++) {
+        const uintptr_t start = (uintptr_t)(C_host + (size_t)cut[b] * ldc), page = start & ~(uintptr_t)4095;   // first element of piece b
         const size_t off = page > (uintptr_t)C_host ? (size_t)(page - (uintptr_t)C_host) : 0;
         hb[b] = std::max(hb[b - 1], std::min(off, c_bytes));
     }
-    if (npieces) hb[npieces] = c_bytes;
+    if (incremental && npieces) hb[npieces] = c_bytes;
     auto piece_ptr = [&](int b) { return (char *)C_host + hb[b]; };
     auto piece_bytes = [&](int b) { return hb[b + 1] - hb[b]; };
-    // tiled: the last partial page of group g — the last tail[g] rows of its last column — lies in piece g + 1; it must be
-    // a part of the LAST row block alone, and no piece may be empty (else: the whole-result form)
-    std::vector<int> tail((size_t)std::max(ng, 1), 0);
-    for (int g = 0; tiled && g < ng; g++) {
-        if (piece_bytes(g) == 0 || gcut[g + 1] == gcut[g]) tiled = false;
-        if (g + 1 < ng) {
-            const size_t end_of_group = (size_t)gcut[g + 1] * ldc * sizeof(real_t);
-            tail[g] = end_of_group > hb[g + 1] ? (int)((end_of_group - hb[g + 1]) / sizeof(real_t)) : 0;
-            if (tail[g] >= cut[nblk] - cut[nblk - 1] || (end_of_group - hb[g + 1]) % sizeof(real_t)) tiled = false;
-        }
-    }
     // First touch of the result's pages by the host team, under the uploads: piece 0 when pieces follow one another,
     // the whole result when it is registered in one go (or when the whole CSR has to arrive first anyway: COLS cold)
     const bool whole_first = colmajor && !A.resident && !tiled;

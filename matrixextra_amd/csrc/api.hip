@@ -1135,6 +1135,10 @@ int mx_get_option(const char *name, int64_t *value)
         if (strcmp(name, "pool_idle_blocks") == 0) { *value = idle_n; return 0; }
         if (strcmp(name, "pool_hits") == 0) { *value = hits; return 0; }
         if (strcmp(name, "pool_misses") == 0) { *value = misses; return 0; }
+        long long live_b = 0, live_n = 0;
+        mx::pool_live(&live_b, &live_n);
+        if (strcmp(name, "pool_live_bytes") == 0) { *value = live_b; return 0; }
+        if (strcmp(name, "pool_live_blocks") == 0) { *value = live_n; return 0; }
     }
     return set_error("mx_get_option: unknown option '%s'", name);
 }

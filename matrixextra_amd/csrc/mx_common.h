@@ -71,6 +71,7 @@ hipError_t pool_malloc(void **out, size_t bytes);
 void pool_free(void *p);
 void pool_trim();
 void pool_stats(long long *idle_bytes, long long *idle_blocks, long long *hits, long long *misses);
+void pool_live(long long *live_bytes, long long *live_blocks);       // handed out by pool_malloc, not yet back
 
 // lanes-per-row for the sub-wave ("group") kernels: smallest power of two
 // >= avg row length, clamped to [lo, 64]

@@ -144,6 +144,16 @@ void pool_trim()
     for (const Block &o : out) (void)hipFree(o.p);
 }
 
+void pool_live(long long *live_bytes, long long *live_blocks)
+{
+    Pool &P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    long long b = 0;
+    for (const auto &kv : P.live) b += (long long)kv.second.bytes;
+    if (live_bytes) *live_bytes = b;
+    if (live_blocks) *live_blocks = (long long)P.live.size();
+}
+
 void pool_stats(long long *idle_bytes, long long *idle_blocks, long long *hits, long long *misses)
 {
     Pool &P = pool();

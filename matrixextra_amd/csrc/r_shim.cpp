@@ -110,6 +110,10 @@ SEXP elemwise(int op, SEXP p1, SEXP p2, SEXP j1, SEXP j2, SEXP x1, SEXP x2, SEXP
     p1 = as_type(p1, INTSXP, p); p2 = as_type(p2, INTSXP, p);
     j1 = as_type(j1, INTSXP, p); j2 = as_type(j2, INTSXP, p);
     x1 = as_type(x1, vt, p);     x2 = as_type(x2, vt, p);
+    // the R callers check the dimensions (R/operators.R:45,716); a direct .Call with unequal row counts would read past
+    // the shorter index pointer — refuse it here instead
+    if (XLENGTH(p1) != XLENGTH(p2) || XLENGTH(p1) < 1)
+        Rf_error("Matrices must have the same dimensions in order to add/substract/multiply them.");
     const void *v1 = vt == REALSXP ? (const void *)REAL(x1) : (const void *)LOGICAL(x1);
     const void *v2 = vt == REALSXP ? (const void *)REAL(x2) : (const void *)LOGICAL(x2);
     mx_result *res = nullptr;

@@ -1,0 +1,80 @@
+"""CPU half of the `.Call` shim execution test: the shim + the mock R runtime (tests/r_mock/) build and load, the table the
+shim registers through R_registerRoutines is the reference's (names + arities, src/RcppExports.cpp:2200-2363), the mock's
+collector really reports a missing PROTECT, and — on a box without a GPU — a routine called by name ends in an R error
+raised by Rf_error(mx_last_error()) with the protect stack balanced.  The GPU half is tests/test_gpu_r_shim_exec.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "r_mock"))
+import rmock  # noqa: E402
+from test_r_shim_syntax import REFERENCE_ARITY  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def R():
+    rmock.build()
+    return rmock.runtime()
+
+
+def test_shim_registers_the_reference_table(R):
+    t = R.routines()
+    ours = {k[len("_MatrixExtra_"):]: v for k, v in t.items() if k.startswith("_MatrixExtra_")}
+    assert ours == REFERENCE_ARITY
+    assert set(t) - {"_MatrixExtra_" + k for k in ours} == {"_mxgpu_set_option", "_mxgpu_set_devices"}
+    assert R.L.rmock_dynamic_symbols() == 0
+
+
+def test_arity_is_checked_like_r_does_for_registered_routines(R):
+    with pytest.raises(LookupError, match=r"Incorrect number of arguments \(0\), expecting 1"):
+        R.call("check_is_seq")
+    with pytest.raises(LookupError, match="not in DLL"):
+        R.call("not_a_routine")
+
+
+def test_collector_reports_a_missing_protect_and_accepts_a_correct_routine(R):
+    R.L.rmock_selftest_missing_protect.restype = __import__("ctypes").c_long
+    assert R.L.rmock_selftest_missing_protect(1) == 0
+    assert R.L.rmock_selftest_missing_protect(0) > 0
+    assert b"garbage-collected" in R.L.rmock_violation_msg()
+    R.L.rmock_clear_violations()
+
+
+def test_coercions_follow_r(R):
+    """what Rcpp's input_parameter<> relies on: NA_integer_ <-> NA_real_, logical NA kept, dims survive as.double()"""
+    L = R.L
+    L.Rf_coerceVector.restype = __import__("ctypes").c_void_p
+    L.Rf_coerceVector.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_uint]
+    s = R.matrix(np.array([[1, rmock.NA_INTEGER], [3, 4]], dtype=np.int32), "integer")
+    d = L.Rf_coerceVector(s, rmock.REALSXP)
+    L.rmock_hold(d)
+    v = R.view(d)
+    assert v.shape == (2, 2) and np.isnan(v[0, 1]) and v[1, 0] == 3.0
+    assert v.view(np.uint64)[0, 1] & 0xFFFFFFFF == 1954                      # R's NA_real_ payload
+    back = L.Rf_coerceVector(d, rmock.INTSXP)
+    L.rmock_hold(back)
+    assert R.view(back).tolist() == [[1, rmock.NA_INTEGER], [3, 4]]
+    lg = L.Rf_coerceVector(R.real([0.0, 2.5, np.nan]), rmock.LGLSXP)
+    L.rmock_hold(lg)
+    assert R.view(lg).tolist() == [0, 1, rmock.NA_INTEGER]
+
+
+def test_library_error_longjumps_to_the_trampoline_on_a_box_without_gpu(R):
+    from matrixextra_amd import _lib
+    try:
+        have_gpu = _lib.device_count() > 0
+    except _lib.MxError:
+        have_gpu = False
+    if have_gpu:
+        pytest.skip("a GPU is present: the error path is covered by tests/test_gpu_r_shim_exec.py")
+    p, j, x = R.integer([0, 1, 2]), R.integer([0, 1]), R.real([1.0, 2.0])
+    with pytest.raises(rmock.RError) as e:                                    # no device -> status != 0 -> Rf_error
+        R.call("tcrossprod_csr_dense_numeric", p, j, x, R.matrix(np.ones((3, 2))), R.integer([1]))
+    assert str(e.value)                                                       # mx_last_error()'s text
+    assert R.L.rmock_protect_depth() == 0 and R.L.rmock_preserved_count() == 0
+    with pytest.raises(rmock.RError):
+        R.call("add_csr_elemwise", p, p, j, j, x, R.real([3.0, 4.0]), R.logical([0]))
+    assert R.L.rmock_protect_depth() == 0
+    R.check_clean()

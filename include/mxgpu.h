@@ -173,13 +173,29 @@ int mxd_spmm_csr_dense(int m, int n,
  * for matrices with very uneven row lengths some rows are shared by several lane groups and folded with LDS atomics,
  * so the last bits of those rows can differ from run to run.  Callers that need run-to-run bitwise reproducibility
  * pass MX_SPMM_ROWWAVE (the exports: MXGPU_SPMM_ALGO=1).
- * npanels <= 0 / wg_per_cu <= 0 pick defaults. */
-typedef enum { MX_SPMM_AUTO = 0, MX_SPMM_ROWWAVE = 1, MX_SPMM_SLAB = 2, MX_SPMM_PLANNED = 3 } mx_spmm_algo;
+ * npanels <= 0 / wg_per_cu <= 0 pick defaults.
+ *   algo MX_SPMM_ROWSPLIT: short-and-fat products (few rows and / or long rows, narrow B — the reference's published
+ *                          dense x CSC workload): one wavefront per row SEGMENT, G = 8 .. 64 lanes per row of B, partial
+ *                          sums met in LDS in a fixed order (reproducible; bitwise the storage-order FMA chain when a row
+ *                          is one segment, B's rows fill the wavefront and C is row-major, else a reassociation: 1e-12).
+ *                          When B outgrows an XCD's L2 the product runs as `npanels` launches over column panels of
+ *                          ~2.5 MB of B (rows sorted by column are cut at the panel bounds by a cursor kernel; a row that is
+ *                          not sorted is taken whole by the first launch — always correct).  npanels = column panels
+ *                          (1 .. 32), wg_per_cu = segments per row (1, 2, 4, 8); <= 0: chosen from the shape and the mean
+ *                          row length
+ * mxd_spmm_csr_dense_ex2: the same with nnz = the number of entries of A (indptr[m] - indptr[0]) when the caller knows it;
+ * -1 = unknown (ROWSPLIT then reads indptr[m] from the device: one 4-byte copy and a stream sync). */
+typedef enum { MX_SPMM_AUTO = 0, MX_SPMM_ROWWAVE = 1, MX_SPMM_SLAB = 2, MX_SPMM_PLANNED = 3, MX_SPMM_ROWSPLIT = 4 } mx_spmm_algo;
 int mxd_spmm_csr_dense_ex(int m, int n, int K,
                           const int32_t *indptr, const int32_t *indices, const double *values,
                           const void *B, size_t ldb, void *C, size_t ldc,
                           int dense_dtype, int colmajor_out, int algo, int rows_sorted,
                           int npanels, int wg_per_cu, void *stream);
+int mxd_spmm_csr_dense_ex2(int m, int n, int K, int64_t nnz,
+                           const int32_t *indptr, const int32_t *indices, const double *values,
+                           const void *B, size_t ldb, void *C, size_t ldc,
+                           int dense_dtype, int colmajor_out, int algo, int rows_sorted,
+                           int npanels, int wg_per_cu, void *stream);
 
 /* Planned SpMM (v3): a device-resident regrouping of A's entries by (row bundle, column panel), wave-interleaved,
  * so that the panel-sweep kernel reads every entry once, coalesced, while B's current slab-panel stays in L2.
@@ -206,6 +222,14 @@ int mxd_spmm_plan_run_rows(const mx_spmm_plan *plan, int row0, int nrows, int n,
  * keep AUTO's decision AND the plan across products with one matrix (matrixextra_amd/device.py DeviceCSR, the CSR cache). */
 int mxd_spmm_auto_algo(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
                        int colmajor_out, int *algo);
+/* ... with the entry count (-1 = unknown: the rule above) and whether the caller keeps a plan across products: a cost model of
+ * the row-split kernel and the planned sweep fitted to a map of 228 shapes (tools/auto_map.py, profiles/r04_auto_map.json;
+ * csrc/spmm.hip spmm_auto_cost) chooses between MX_SPMM_ROWSPLIT, _PLANNED and, for one-slab products of very short rows,
+ * _SLAB; products below 2^22 multiply-adds stay on MX_SPMM_ROWWAVE.  mxd_spmm_auto_cost: the model's two estimates. */
+int mxd_spmm_auto_algo2(int m, int n, int K, int64_t nnz /* -1 = unknown */, int keep_plan, int dense_dtype, const void *B,
+                        size_t ldb, const void *C, size_t ldc, int colmajor_out, int *algo);
+int mxd_spmm_auto_cost(int m, int n, int K, int64_t nnz, int keep_plan, int dense_dtype, double *rowsplit_us, double *planned_us,
+                       int *panels);
 int mxd_spmm_plan_create_auto(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
                               int npanels, void *stream, mx_spmm_plan **plan, int *ready);
 

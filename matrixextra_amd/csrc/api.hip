@@ -56,8 +56,8 @@ int set_error(const char *fmt, ...)
     return 1;
 }
 
-int spmm_auto_family(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor);
-int spmm_block(int family, bool from_auto, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+int spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor);
+int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
                const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, int npanels, hipStream_t st);
 int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
                 const void *v, int v_dtype, void *y, int algo, hipStream_t st);
@@ -532,7 +532,7 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
     std::vector<int> cut((size_t)nd + 1);
     partition_rows(indptr, m, nd, 12.0, (double)n * sizeof(real_t), cut.data());
     // one kernel family for the whole product (see spmm_host); the alignment rules only look at the low bits of the pointers
-    const int family = algo == MX_SPMM_AUTO ? mx::spmm_auto_family(m, n, K_rows, dt, (const void *)(uintptr_t)256, ldb,
+    const int family = algo == MX_SPMM_AUTO ? mx::spmm_auto_family(m, n, K_rows, nnz, dt, (const void *)(uintptr_t)256, ldb,
                                                                    (const void *)(uintptr_t)256, colmajor ? (size_t)m : ldc,
                                                                    colmajor ? 1 : 0) : algo;
     // host memory registered for every device; `gate` opens once the result is registered (downloads wait for it)
@@ -586,7 +586,8 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
             if (p_local[r0] == p_local[r1]) {
                 if (colmajor) (void)hipMemset2DAsync(dCb, ldc_k * sizeof(real_t), 0, (size_t)(r1 - r0) * sizeof(real_t), n, L.run);
                 else (void)hipMemsetAsync(dCb, 0, (size_t)(r1 - r0) * ldc_k * sizeof(real_t), L.run);
-            } else if (mx::spmm_block(family, algo == MX_SPMM_AUTO, r1 - r0, n, K_rows, dp.as<int32_t>() + r0, dj.as<int32_t>(),
+            } else if (mx::spmm_block(family, algo == MX_SPMM_AUTO, r1 - r0, n, K_rows, (int64_t)p_local[r1] - p_local[r0],
+                                      dp.as<int32_t>() + r0, dj.as<int32_t>(),
                                       dx.as<double>(), dB.p, ldb, dCb, ldc_k, dt, colmajor ? 1 : 0, npanels, L.run)) {
                 failed("spmm");
                 return;
@@ -704,8 +705,8 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
             if (flag.alloc(16)) return 1;
             if (mxd_csr_rows_sorted(m, A.p.as<int32_t>(), A.j.as<int32_t>(), flag.as<int32_t>(), &sorted, nullptr)) return 1;
         }
-        if (mxd_spmm_csr_dense_ex(m, n, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), B.p, ldb, C.p, ldc,
-                                  dt, colmajor ? 1 : 0, algo, sorted, npanels, 0, nullptr)) return 1;
+        if (mxd_spmm_csr_dense_ex2(m, n, K_rows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), B.p, ldb, C.p, ldc,
+                                   dt, colmajor ? 1 : 0, algo, sorted, npanels, 0, nullptr)) return 1;
         if (tr.on) { MX_HIP(hipDeviceSynchronize()); tr.mark("kernels"); }
         const int rc = mx::xfer_d2h(C_host, C.p, c_bytes);
         tr.mark("D2H C");
@@ -791,7 +792,7 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     // The kernel family is chosen ONCE, for the whole product, and every block runs it (AUTO applied block by block took
     // the row-wave kernel for cfg2's blocks — each below AUTO's size threshold — and would hand back other last bits cold
     // than cached once cached calls use the matrix's plan).
-    const int family = algo == MX_SPMM_AUTO ? mx::spmm_auto_family(m, n, K_rows, dt, dB, ldb, dC, ldc, colmajor ? 1 : 0) : algo;
+    const int family = algo == MX_SPMM_AUTO ? mx::spmm_auto_family(m, n, K_rows, nnz, dt, dB, ldb, dC, ldc, colmajor ? 1 : 0) : algo;
     mx_spmm_plan *plan = nullptr;
     if (!A.resident) {
         const bool direct_up = pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz) && pinX.pin(values, sizeof(double) * (size_t)nnz);
@@ -861,7 +862,7 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
             int rc = 0;
             if (shape == COLS) {
                 rc = plan ? mxd_spmm_plan_run_rows(plan, 0, m, c1 - c0, dB + c0, ldb, dC + (size_t)c0 * ldc, ldc, dt, 1, 0, -1, L.run)
-                          : mx::spmm_block(family, algo == MX_SPMM_AUTO, m, c1 - c0, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(),
+                          : mx::spmm_block(family, algo == MX_SPMM_AUTO, m, c1 - c0, K_rows, nnz, A.p.as<int32_t>(), A.j.as<int32_t>(),
                                            A.x.as<double>(), dB + c0, ldb, dC + (size_t)c0 * ldc, ldc, dt, 1, npanels, L.run);
             } else {
                 real_t *dCb = colmajor ? dC + c0 : dC + (size_t)c0 * ldc;
@@ -870,7 +871,8 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
                     else MX_HIP(hipMemsetAsync(dCb, 0, (size_t)(c1 - c0) * ldc * sizeof(real_t), L.run));
                 } else {
                     rc = plan ? mxd_spmm_plan_run_rows(plan, c0, c1 - c0, n, dB, ldb, dCb, ldc, dt, colmajor ? 1 : 0, 0, -1, L.run)
-                              : mx::spmm_block(family, algo == MX_SPMM_AUTO, c1 - c0, n, K_rows, A.p.as<int32_t>() + c0,
+                              : mx::spmm_block(family, algo == MX_SPMM_AUTO, c1 - c0, n, K_rows, (int64_t)indptr[c1] - indptr[c0],
+                                               A.p.as<int32_t>() + c0,
                                                A.j.as<int32_t>(), A.x.as<double>(), dB, ldb, dCb, ldc, dt, colmajor ? 1 : 0,
                                                npanels, L.run);
                 }

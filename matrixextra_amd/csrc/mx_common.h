@@ -57,7 +57,8 @@ int host_signal_wait(const HostSignal &s, unsigned *value, hipStream_t st);
 // Grow-only device scratch of the calling thread and current device, one buffer per `slot` (kernels' internal tables: the
 // SpMV slice table, per-workgroup partial counts ...).  Like AUTO's SpMM plan it assumes one stream per thread and device
 // at a time.  nullptr when the allocation fails.  (scan.hip)
-enum { MX_SCRATCH_SPMV_SLICES = 0, MX_SCRATCH_PARTIALS = 1, MX_SCRATCH_EXPORT_B = 2, MX_SCRATCH_EXPORT_C = 3, MX_SCRATCH_SLOTS = 4 };
+enum { MX_SCRATCH_SPMV_SLICES = 0, MX_SCRATCH_PARTIALS = 1, MX_SCRATCH_EXPORT_B = 2, MX_SCRATCH_EXPORT_C = 3, MX_SCRATCH_ROWSPLIT = 4,
+       MX_SCRATCH_SLOTS = 5 };
 void *scratch_buffer(int slot, size_t bytes);
 void *scratch_buffer_zeroed(int slot, size_t bytes, hipStream_t st, bool *fresh);   // zero-filled when (re)allocated
 void scratch_release();

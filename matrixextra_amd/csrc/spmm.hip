@@ -6,6 +6,8 @@
 // Three kernels, one measured progression: spmm_rowwave.hip (v1, any operands), spmm_slab.hip (v2,
 // opt-in), spmm_plan.hip (v3, what AUTO runs when B outgrows an XCD's L2).
 #include "spmm_common.h"
+#include <algorithm>
+#include <cmath>
 
 namespace mx {
 
@@ -90,28 +92,106 @@ extern "C" int mxd_spmm_kernel_times(float *out_ms, int max_out, int *count)
 extern "C" const char *mxd_spmm_last_kernel(void) { return mx::g_last_spmm_kernel; }
 
 namespace mx {
-// AUTO's choice, in one place: PLANNED when B outgrows one XCD's L2, the operands meet the 16-byte rules and there is
-// enough work to fill the persistent grid (measured on MI355X, headline config, profiles/r01_*: row-wave 4.45 ms; one-panel
-// slab kernel on the slab-major copy of B 4.05 ms; planned panel sweep 1.74 ms + 0.27 ms to build the plan from plain CSR),
-// SLAB for K >= 2^25 (the plan's 32-bit slab offsets), else ROWWAVE.
-static int spmm_auto_algo(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor)
+// AUTO's choice, in one place.  Rounds 1-3 had one rule (PLANNED when B outgrows an XCD's L2 and m * n >= 2^24, else
+// ROWWAVE) read off the headline configuration; round 4 mapped every kernel over 228 shapes between the benchmarks
+// (tools/auto_map.py -> profiles/r04_auto_map.json) and replaced it by a small cost model of the two kernels that
+// matter there — the row-split kernel (column panels by launches) and the planned panel sweep — in the quantities that
+// bound them on MI355X:
+//   * both gather nnz rows of B through the CUs' L1s; what they read from is an XCD's L2 (4 MiB) when the panel of B they
+//     work on fits it (~26 TB/s of line reads measured in the row-split kernel; 23 TB/s in the planned sweep with one
+//     panel, 18 TB/s with several), the Infinity Cache otherwise (~8.5 TB/s); a uniformly gathered panel of T bytes
+//     hits L2 with probability 4 MiB / T (guide: "Indexed rows: gather into LDS");
+//   * the row-split kernel pays ~0.35 ns per (row, panel, column pass) — one wavefront each — and a few us per launch;
+//     the planned kernel ~0.01 ns per (row, slab, panel), ~40 us of fixed cost per run, and, when the plan is not kept,
+//     ~36 us + 6 ps per entry to build it; it needs m / 64 octets x slabs >> 1024 workgroups: below 32k rows it is never
+//     chosen (at m = 1e4 the row-split kernel won 38 of 40 points, the other two within 18 %).
+// keep_plan: the caller keeps the plan across products (DeviceCSR, the exports' CSR cache) — the build is not charged.
+// Callers that do not know nnz get the old rule.  Products below 2^22 multiply-adds are launch-bound whatever runs and
+// stay on the row-wave kernel, whose sums are the reference's storage-order FMA chain bit for bit.
+struct AutoCost { double rowsplit_us, planned_us; int panels; };
+static AutoCost spmm_auto_cost(int m, int n, int K, int64_t nnz, int sz, bool keep_plan)
+{
+    const double avg = m > 0 ? (double)nnz / m : 0.0;
+    const int W = 64 * (16 / sz);
+    const double passes = (double)((n + W - 1) / W);
+    const int cols_per_line = 128 / sz;
+    const double slabs = (double)((n + cols_per_line - 1) / cols_per_line);
+    const double b_bytes = (double)K * n * sz;
+    auto rate = [](double panel_bytes, double l2_rate, double mall_rate) {     // bytes per us
+        const double hit = panel_bytes <= 3.5e6 ? 1.0 : (4.0 * 1048576.0) / panel_bytes;
+        return 1e6 / (hit / l2_rate + (1.0 - hit) / mall_rate);
+    };
+    AutoCost c;
+    c.panels = rowsplit_panels(n, K, sz, avg);
+    const double lanes_rate = n * sz <= 128 ? 17.0 : 26.0;                     // (8-lane groups: 17 TB/s measured)
+    c.rowsplit_us = (double)nnz * n * sz / rate(b_bytes / c.panels, lanes_rate, 8.5) + 0.35e-3 * m * c.panels * passes +
+                    4.0 * c.panels + 4.0;
+    const double plan_panels = std::max(1.0, std::ceil((double)K * 128.0 / 2.5e6));
+    const double sweep_rate = plan_panels > 1.0 ? 18.0 : 23.0;
+    c.planned_us = (double)nnz * slabs * 128.0 / rate((double)K * 128.0 / plan_panels, sweep_rate, 8.5) +
+                   0.01e-3 * m * slabs * plan_panels + 40.0 + (keep_plan ? 0.0 : 36.0 + 6e-6 * (double)nnz);
+    return c;
+}
+static int spmm_auto_algo(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
+                          int colmajor, bool keep_plan)
 {
     const bool ok = dense_dtype == MX_F64 ? slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor)
                                           : slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor);
-    const size_t b_bytes = (size_t)K * (size_t)n * (dense_dtype == MX_F64 ? 8 : 4);
+    const int sz = dense_dtype == MX_F64 ? 8 : 4;
+    const size_t b_bytes = (size_t)K * (size_t)n * sz;
     const bool big = ok && b_bytes > ((size_t)8 << 20) && (long long)m * n >= (1LL << 24);
-    return big ? (K < (1 << 25) ? MX_SPMM_PLANNED : MX_SPMM_SLAB) : MX_SPMM_ROWWAVE;
+    if (nnz < 0) return big ? (K < (1 << 25) ? MX_SPMM_PLANNED : MX_SPMM_SLAB) : MX_SPMM_ROWWAVE;     // rounds 1-3
+    if (nnz * (long long)n < (1LL << 22)) return MX_SPMM_ROWWAVE;
+    if (!ok || m < 32768) return MX_SPMM_ROWSPLIT;
+    if (K >= (1 << 25)) return big ? MX_SPMM_SLAB : MX_SPMM_ROWSPLIT;           // (the plan's 32-bit slab offsets)
+    // one 128-byte slab, a handful of entries per row, a slab-panel of B that fits L2: 8 lanes per row and 8 rows per
+    // wavefront (the slab kernel's shape) beat one wavefront per row and a plan that costs more than the product
+    // (m = 1e6, 8 entries per row, n = 16: slab 0.096 ms, planned rebuilt 0.164, row-split 0.296; plan kept 0.064)
+    if (!keep_plan && n * sz <= 128 && nnz <= 16LL * m && (double)K * 128.0 <= 2.5e6) return MX_SPMM_SLAB;
+    const AutoCost c = spmm_auto_cost(m, n, K, nnz, sz, keep_plan);
+    return c.planned_us < c.rowsplit_us ? MX_SPMM_PLANNED : MX_SPMM_ROWSPLIT;
 }
-int spmm_auto_family(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor)
+int spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
+                     int colmajor)
 {
-    return spmm_auto_algo(m, n, K, dense_dtype, B, ldb, C, ldc, colmajor);
+    return spmm_auto_algo(m, n, K, nnz, dense_dtype, B, ldb, C, ldc, colmajor, false);
+}
+// entries of a device-resident CSR whose count the caller did not pass: indptr[m] (one 4-byte copy, synchronises `st`)
+static int device_nnz(const int32_t *indptr, int m, hipStream_t st, int64_t *nnz)
+{
+    int32_t last = 0, first = 0;
+    MX_HIP(hipMemcpyAsync(&last, indptr + m, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MX_HIP(hipMemcpyAsync(&first, indptr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MX_HIP(hipStreamSynchronize(st));
+    *nnz = (int64_t)last - first;
+    return 0;
+}
+static int run_rowsplit(int m, int n, int K, int64_t nnz, int segments, int panels, int rows_sorted_hint, const int32_t *indptr,
+                        const int32_t *indices, const double *values, const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype,
+                        int colmajor, hipStream_t st)
+{
+    (void)rows_sorted_hint;                    // (the cursor kernel checks every row itself)
+    const int sz = dense_dtype == MX_F64 ? 8 : 4;
+    if (segments <= 0 || panels <= 0) {
+        if (nnz < 0 && device_nnz(indptr, m, st, &nnz)) return 1;
+        const double avg = m > 0 ? (double)nnz / m : 0.0;
+        if (panels <= 0) panels = rowsplit_panels(n, K, sz, avg);
+        if (segments <= 0) segments = rowsplit_segments(m, n, sz, avg / panels);
+    }
+    set_last_spmm_kernel("spmm_rowsplit_kernel");
+    if (dense_dtype == MX_F64)
+        return rowsplit_spmm<double>(m, n, K, segments, panels, indptr, indices, values, (const double *)B, ldb, (double *)C, ldc, colmajor, st);
+    return rowsplit_spmm<float>(m, n, K, segments, panels, indptr, indices, values, (const float *)B, ldb, (float *)C, ldc, colmajor, st);
 }
 // One block (rows or columns) of a product whose kernel family was chosen for the WHOLE product (the export pipelines).
 // from_auto: the family is AUTO's choice — a planned block still falls back to the row-wave kernel when its plan would
 // pad too much, as AUTO does.
-int spmm_block(int family, bool from_auto, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
-               const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, int npanels, hipStream_t st)
+int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices,
+               const double *values, const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, int npanels,
+               hipStream_t st)
 {
+    if (family == MX_SPMM_ROWSPLIT)
+        return run_rowsplit(m, n, K, nnz, 0, from_auto ? 0 : npanels, 0, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, st);
     if (family == MX_SPMM_PLANNED && from_auto) {
         const bool ok = dense_dtype == MX_F64 ? slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor)
                                               : slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor);
@@ -120,19 +200,35 @@ int spmm_block(int family, bool from_auto, int m, int n, int K, const int32_t *i
             if (plan_auto_build(m, K, indptr, indices, values, npanels, st, 1.55, &ready)) return 1;
             if (ready) return plan_auto_run(n, B, ldb, C, ldc, dense_dtype, colmajor, st);
         }
-        family = MX_SPMM_ROWWAVE;
+        family = nnz >= 0 ? MX_SPMM_ROWSPLIT : MX_SPMM_ROWWAVE;       // (very uneven rows: the plan would pad too much)
+        if (family == MX_SPMM_ROWSPLIT)
+            return run_rowsplit(m, n, K, nnz, 0, 0, 0, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, st);
     }
-    return mxd_spmm_csr_dense_ex(m, n, K, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, family, 0, npanels, 0, st);
+    return mxd_spmm_csr_dense_ex2(m, n, K, nnz, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, family, 0, npanels, 0, st);
 }
 }  // namespace mx
 
-extern "C" int mxd_spmm_auto_algo(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
-                                  int colmajor_out, int *algo)
+extern "C" int mxd_spmm_auto_algo2(int m, int n, int K, int64_t nnz, int keep_plan, int dense_dtype, const void *B, size_t ldb,
+                                   const void *C, size_t ldc, int colmajor_out, int *algo)
 {
     MX_REQUIRE(algo, "mxd_spmm_auto_algo: null pointer");
     MX_REQUIRE(dense_dtype == MX_F64 || dense_dtype == MX_F32, "mxd_spmm_auto_algo: unsupported dense dtype %d", dense_dtype);
-    *algo = mx::spmm_auto_algo(m, n, K, dense_dtype, B, ldb, C, ldc, colmajor_out);
+    *algo = mx::spmm_auto_algo(m, n, K, nnz, dense_dtype, B, ldb, C, ldc, colmajor_out, keep_plan != 0);
     return 0;
+}
+// the model's two estimates (microseconds) and the row-split kernel's panel count, for tools/auto_map.py
+extern "C" int mxd_spmm_auto_cost(int m, int n, int K, int64_t nnz, int keep_plan, int dense_dtype, double *rowsplit_us, double *planned_us,
+                                  int *panels)
+{
+    MX_REQUIRE(nnz >= 0 && rowsplit_us && planned_us && panels, "mxd_spmm_auto_cost: nnz and three result pointers are required");
+    const mx::AutoCost c = mx::spmm_auto_cost(m, n, K, nnz, dense_dtype == MX_F64 ? 8 : 4, keep_plan != 0);
+    *rowsplit_us = c.rowsplit_us; *planned_us = c.planned_us; *panels = c.panels;
+    return 0;
+}
+extern "C" int mxd_spmm_auto_algo(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
+                                  int colmajor_out, int *algo)
+{
+    return mxd_spmm_auto_algo2(m, n, K, -1, 0, dense_dtype, B, ldb, C, ldc, colmajor_out, algo);
 }
 
 extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
@@ -140,6 +236,16 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
                                      const void *B, size_t ldb, void *C, size_t ldc,
                                      int dense_dtype, int colmajor_out, int algo, int rows_sorted,
                                      int npanels, int wg_per_cu, void *stream)
+{
+    return mxd_spmm_csr_dense_ex2(m, n, K, -1, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor_out, algo, rows_sorted,
+                                  npanels, wg_per_cu, stream);
+}
+
+extern "C" int mxd_spmm_csr_dense_ex2(int m, int n, int K, int64_t nnz,
+                                      const int32_t *indptr, const int32_t *indices, const double *values,
+                                      const void *B, size_t ldb, void *C, size_t ldc,
+                                      int dense_dtype, int colmajor_out, int algo, int rows_sorted,
+                                      int npanels, int wg_per_cu, void *stream)
 {
     MX_REQUIRE(m >= 0 && n >= 0 && K >= 0, "mxd_spmm_csr_dense_ex: negative dimension");
     if (m == 0 || n == 0) return 0;
@@ -153,10 +259,14 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
     if (algo == MX_SPMM_AUTO) {
         // AUTO rebuilds the plan on every call (nothing is assumed about A between calls); callers that multiply one
         // matrix repeatedly keep a plan (mxd_spmm_plan_create_auto + mxd_spmm_plan_run)
-        algo = mx::spmm_auto_algo(m, n, K, dense_dtype, B, ldb, C, ldc, colmajor_out);
+        algo = mx::spmm_auto_algo(m, n, K, nnz, dense_dtype, B, ldb, C, ldc, colmajor_out, false);
         auto_pick_planned = algo == MX_SPMM_PLANNED;
         if (algo == MX_SPMM_SLAB) { npanels = 1; if (wg_per_cu <= 0) wg_per_cu = 4; }
+        if (algo == MX_SPMM_ROWSPLIT) { npanels = 0; wg_per_cu = 0; }   // (column panels / segments per row: AUTO picks both)
     }
+    if (algo == MX_SPMM_ROWSPLIT)
+        return mx::run_rowsplit(m, n, K, nnz, wg_per_cu, npanels, rows_sorted, indptr, indices, values, B, ldb, C, ldc, dense_dtype,
+                                colmajor_out, st);
     if (algo == MX_SPMM_PLANNED) {
         MX_REQUIRE(ok, "mxd_spmm_csr_dense_ex: operands do not meet the planned kernel's 16-byte alignment rules");
         // Measured with log-normal row lengths (tools/skew_probe.py): up to ~1.55x the CSR the planned sweep still
@@ -165,6 +275,8 @@ extern "C" int mxd_spmm_csr_dense_ex(int m, int n, int K,
         bool ready = false;          // the plan's buffers are re-used from call to call (grow-only, per thread)
         if (mx::plan_auto_build(m, K, indptr, indices, values, npanels, st, auto_pick_planned ? 1.55 : 0.0, &ready)) return 1;
         if (ready) return mx::plan_auto_run(n, B, ldb, C, ldc, dense_dtype, colmajor_out, stream);
+        if (nnz >= 0)                                                // (very uneven rows: the plan would pad too much)
+            return mx::run_rowsplit(m, n, K, nnz, 0, 0, 0, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor_out, st);
         algo = MX_SPMM_ROWWAVE;
     }
     if (algo == MX_SPMM_SLAB) {

@@ -100,6 +100,14 @@ template <typename real_t>
 int rowwave_spmm(int m, int n, const int32_t *indptr, const int32_t *indices, const double *values,
                  const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream);
 
+// ---- spmm_rowsplit.hip: S segments per row (1, 2, 4 or 8), one wavefront per segment, G lanes per row of B
+// and P column panels of B (one launch each)
+template <typename real_t>
+int rowsplit_spmm(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
+                  const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream);
+int rowsplit_segments(int m, int n, int dense_bytes, double avg_len);
+int rowsplit_panels(int n, int K, int dense_bytes, double avg_len);
+
 // ---- spmm_slab.hip
 int pick_panels(int K, size_t l2_budget);
 void *slab_pack_workspace(size_t bytes, bool release = false);     // grow-only per-device scratch for the packed B

@@ -1,0 +1,314 @@
+// spmm_rowsplit.hip — CSR x dense SpMM for gfx950 (MI355X): the kernel for SHORT-AND-FAT products (few rows and / or
+// long rows, narrow dense operands), the shape of the one workload the reference publishes a number for: dense 100 x 1e4
+// %*% CSC 1e4 x 1e4, density .05 (vignettes/Introducing_MatrixExtra.Rmd:247-251 -> matmul_dense_csc_numeric ->
+// gemm_csr_drm_as_drm, src/matmul.cpp:118-142, :188-235) — 1e4 rows of ~500 entries against a 100-column B.
+//
+// Why another kernel: the row-wave kernel (spmm_rowwave.hip) gives 8 consecutive rows to one wavefront and 64 * VEC output
+// columns to its 64 lanes.  With m = 1e4 that is 313 workgroups for 256 CUs — one or two wavefronts per SIMD, every one of
+// them a serial chain of 4,000 dependent-latency B-row reads — with n = 16 or 64 most of the lanes of every read are idle,
+// and the whole of B (8 MB there) is gathered by every XCD through a 4 MiB L2: half of the line reads come from the
+// Infinity Cache (measured: 0.343 ms = 11.7 TB/s of line reads; an L2-resident gather runs at 20-28 TB/s).
+// The planned sweep (spmm_plan.hip) needs m / 8 octets to fill its persistent grid.  Here:
+//
+//   * the unit of work is one SEGMENT of one row: a workgroup is 8 wavefronts = 8 / S rows x S segments per row
+//     (S in {1, 2, 4, 8}, chosen on the host so that the launch has a few wavefronts for every slot of the machine while
+//     a segment keeps >= 64 entries);
+//   * inside a wavefront, G lanes (G = 8 .. 64, G * VEC >= the columns of the pass) own one row of B, so one load
+//     instruction covers 64 / G entries; the segment's (j, a) are loaded coalesced, 64 entries at a time, and handed to
+//     the groups by ds_bpermute (G < 64) or v_readlane into SGPRs (G = 64: no per-entry address arithmetic);
+//   * COLUMN PANELS by launches: when B outgrows an XCD's L2, [0, K) is cut into P ranges of ~2.5 MB of B and the product
+//     runs as P launches, launch p taking from every row the entries whose column lies in panel p and continuing the sums
+//     left in C by launch p - 1 — so that at any moment every wavefront of the machine gathers from the same few MB.  Rows
+//     sorted by column (what R's CSR / CSC classes hold) have their panel bounds found once by a cursor kernel (one
+//     wavefront per row: sortedness check + P binary searches); a row that is NOT sorted is simply taken whole by launch 0
+//     — always correct, no host round trip;
+//   * partial sums meet in LDS: groups inside a wave by a butterfly, segments of a row in a fixed order when the tile is
+//     written out — run-to-run reproducible, no atomics.  S = 1 and G = 64 with row-major C is the reference's
+//     storage-order FMA chain bit for bit, panels included (the chain continues from the value stored in C); everything
+//     else reassociates (<= 1e-12 relative, the bar of the planned kernel);
+//   * both layouts of C: row-major rows straight from the tile, column-major as 8 / S-row segments per column (C is small
+//     wherever this kernel is chosen).
+//
+// Roofline: HBM-bound by the contract's algorithmic bytes; what limits it in practice is the L2 -> L1 gather
+// of nnz * n * s bytes (4 GB for the vignette product), reported as `l2_to_l1_gather` in bench.py.
+#include "spmm_common.h"
+
+namespace mx {
+
+constexpr int RS_WAVES = 8;        // wavefronts per workgroup
+constexpr int RS_UNROLL = 8;       // B-row reads in flight per wavefront (G = 64)
+constexpr int RS_MAX_PANELS = 32;
+
+// G = 64: one chunk of <= 64 entries, lane k holds (jv, av) of entry k — the row-wave kernel's inner loop
+template <typename real_t, int VEC>
+__device__ __forceinline__ void rs_chunk(int cnt, int jv, double av, const real_t *__restrict__ B, size_t ldb, unsigned col,
+                                         real_t (&acc)[VEC])
+{
+    int k = 0;
+    for (; k + RS_UNROLL <= cnt; k += RS_UNROLL) {
+        real_t b[RS_UNROLL][VEC];
+#pragma unroll
+        for (int u = 0; u < RS_UNROLL; u++) {
+            const int j = __builtin_amdgcn_readlane(jv, k + u);
+            vload<real_t, VEC>(b[u], B + (size_t)j * ldb + col);
+        }
+#pragma unroll
+        for (int u = 0; u < RS_UNROLL; u++) {
+            const real_t a = (real_t)readlane_f64(av, k + u);       // narrowed per entry for f32 (matmul.cpp:53-57)
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] = mx_fma(a, b[u][v], acc[v]);
+        }
+    }
+    for (; k < cnt; k++) {
+        const int j = __builtin_amdgcn_readlane(jv, k);
+        const real_t a = (real_t)readlane_f64(av, k);
+        real_t b[VEC];
+        vload<real_t, VEC>(b, B + (size_t)j * ldb + col);
+#pragma unroll
+        for (int v = 0; v < VEC; v++) acc[v] = mx_fma(a, b[v], acc[v]);
+    }
+}
+
+__device__ __forceinline__ double bperm_f64(double v, int src_lane)
+{
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_ds_bpermute(src_lane << 2, u.i[0]);
+    u.i[1] = __builtin_amdgcn_ds_bpermute(src_lane << 2, u.i[1]);
+    return u.d;
+}
+
+// G < 64: one chunk of <= 64 entries, lane k holds entry k; group g = lane / G takes entries g, g + NG, ... — one load
+// instruction reads NG rows of B, 16 bytes per lane.  U instructions are in flight; entries past `cnt` re-read entry 0's
+// row (valid memory) and are dropped by a select, never by arithmetic (0 * Inf would poison the sum).
+template <typename real_t, int VEC, int G>
+__device__ __forceinline__ void rs_chunk_groups(int cnt, int jv, double av, const real_t *__restrict__ B, size_t ldb, unsigned col,
+                                                int g, real_t (&acc)[VEC])
+{
+    constexpr int NG = MX_WAVE / G;
+    constexpr int U = G >= 32 ? 8 : 4;
+    for (int t = 0; t * NG < cnt; t += U) {
+        int jj[U];
+        real_t bb[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = (t + u) * NG + g;
+            jj[u] = __builtin_amdgcn_ds_bpermute((k < cnt ? k : 0) << 2, jv);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) vload<real_t, VEC>(bb[u], B + (size_t)jj[u] * ldb + col);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = (t + u) * NG + g;
+            const real_t x = (real_t)bperm_f64(av, k < cnt ? k : 0);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] = k < cnt ? mx_fma(x, bb[u][v], acc[v]) : acc[v];
+        }
+    }
+}
+
+// lo / hi: per-row entry ranges of this launch (a column panel), nullptr = the whole row; accumulate: C holds the sums of
+// the earlier panels
+template <typename real_t, int VEC, int G, bool COLMAJOR>
+__global__ __launch_bounds__(RS_WAVES * MX_WAVE)
+void spmm_rowsplit_kernel(int m, int n, int S,
+                          const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                          const double *__restrict__ values,
+                          const int32_t *__restrict__ lo, const int32_t *__restrict__ hi, int accumulate,
+                          const real_t *__restrict__ B, size_t ldb,
+                          real_t *__restrict__ C, size_t ldc)
+{
+    constexpr int W = G * VEC;                // output columns per pass
+    constexpr int LS = W + 1;                 // odd LDS row stride (elements)
+    __shared__ real_t tile[RS_WAVES * LS];
+
+    const int lane = lane_id();
+    const int wave = uniform(threadIdx.x / MX_WAVE);
+    const int RW = RS_WAVES / S;              // rows per workgroup
+    const int row0 = blockIdx.x * RW;
+    const int row = row0 + wave / S;
+    const int seg = wave % S;
+    const int c0 = blockIdx.y * W;
+    const int lg = lane % G;
+    const int col = c0 + lg * VEC;
+    const bool active = col < n;
+    const unsigned lcol = active ? (unsigned)col : (unsigned)(n - VEC);     // clamped, valid column for idle lanes
+    const bool direct = !COLMAJOR && S == 1;  // one wavefront = one whole row of row-major C: no tile
+
+    real_t acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) acc[v] = 0;
+
+    if (row < m) {
+        const int s = uniform(lo ? lo[row] : indptr[row]);
+        const int e = uniform(hi ? hi[row] : indptr[row + 1]);
+        int a = s, b = e;
+        if (S > 1) {                           // whole 64-entry chunks per segment; the row's tail goes to the last busy one
+            const int L = (((e - s + S - 1) / S + MX_WAVE - 1) / MX_WAVE) * MX_WAVE;
+            a = min(e, s + seg * L);
+            b = min(e, a + L);
+        }
+        // the storage-order chain goes on from what the earlier panels left in C
+        if (direct && accumulate && active && lane < G) vload<real_t, VEC>(acc, C + (size_t)row * ldc + col);
+        int jv = 0;
+        double av = 0.0;
+        if (a + lane < b) { jv = indices[a + lane]; av = values[a + lane]; }
+        for (int k0 = a; k0 < b; k0 += MX_WAVE) {
+            int jn = 0;
+            double an = 0.0;                    // the next chunk's (j, a) are in flight while this one streams B
+            if (k0 + MX_WAVE + lane < b) { jn = indices[k0 + MX_WAVE + lane]; an = values[k0 + MX_WAVE + lane]; }
+            if constexpr (G == MX_WAVE) rs_chunk<real_t, VEC>(min(MX_WAVE, b - k0), jv, av, B, ldb, lcol, acc);
+            else rs_chunk_groups<real_t, VEC, G>(min(MX_WAVE, b - k0), jv, av, B, ldb, lcol, lane / G, acc);
+            jv = jn; av = an;
+        }
+    }
+    if constexpr (G < MX_WAVE) {               // the groups' partial sums: butterfly over the group index
+        // (with `accumulate` only group 0 started from C's value, the others from zero)
+#pragma unroll
+        for (int off = G; off < MX_WAVE; off <<= 1) {
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] += __shfl_xor(acc[v], off, MX_WAVE);
+        }
+    }
+
+    if (direct) {
+        if (row < m && active && lane < G) vstore<real_t, VEC>(C + (size_t)row * ldc + col, acc);
+        return;
+    }
+    if (lane < G) {
+        real_t *t = tile + wave * LS + lg * VEC;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) t[v] = acc[v];
+    }
+    __syncthreads();
+    const int ncols = min(W, n - c0);
+    const int total = RW * ncols;
+    for (int idx = threadIdx.x; idx < total; idx += RS_WAVES * MX_WAVE) {
+        // column-major: consecutive threads take consecutive rows of one column; row-major: consecutive columns of one row
+        const int r = COLMAJOR ? idx % RW : idx / ncols;
+        const int c = COLMAJOR ? idx / RW : idx % ncols;
+        if (row0 + r >= m) continue;
+        real_t *dst = COLMAJOR ? C + (size_t)(c0 + c) * ldc + row0 + r : C + (size_t)(row0 + r) * ldc + c0 + c;
+        real_t sum = tile[(r * S) * LS + c];
+        if (accumulate) sum = *dst + sum;
+        for (int q = 1; q < S; q++) sum += tile[(r * S + q) * LS + c];       // segments in order
+        *dst = sum;
+    }
+}
+
+// cursors[p * m + row], p = 0 .. P: where panel p's entries of `row` begin (panel p = columns [p * panel_cols, (p + 1) *
+// panel_cols)).  One wavefront per row: is the row sorted by column? (the same test as check_is_sorted, src/misc.cpp:118-128)
+// — then lanes 1 .. P - 1 each find one bound by binary search; otherwise panel 0 takes the whole row.
+__global__ __launch_bounds__(RS_WAVES * MX_WAVE)
+void rowsplit_cursors_kernel(int m, int P, int panel_cols, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                             int32_t *__restrict__ cursors)
+{
+    const int lane = lane_id();
+    const int row = blockIdx.x * RS_WAVES + uniform(threadIdx.x / MX_WAVE);
+    if (row >= m) return;
+    const int s = uniform(indptr[row]), e = uniform(indptr[row + 1]);
+    bool bad = false;
+    for (int k = s + lane; k + 1 < e; k += MX_WAVE) bad |= indices[k] > indices[k + 1];
+    const bool sorted = __ballot(bad) == 0;
+    for (int p = lane; p <= P; p += MX_WAVE) {
+        int at = e;
+        if (p == 0) at = s;
+        else if (p < P && sorted) at = s + lower_bound_dev(indices + s, e - s, p * panel_cols);
+        cursors[(size_t)p * m + row] = at;
+    }
+}
+
+template <typename real_t, int VEC, int G, bool COLMAJOR>
+static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
+                           const real_t *B, size_t ldb, real_t *C, size_t ldc, hipStream_t stream)
+{
+    constexpr int W = G * VEC;
+    dim3 grid((unsigned)ceil_div(m, RS_WAVES / S), (unsigned)ceil_div(n, W));
+    if (P <= 1) {
+        kt_begin(stream);
+        hipLaunchKernelGGL((spmm_rowsplit_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
+                           m, n, S, indptr, indices, values, (const int32_t *)nullptr, (const int32_t *)nullptr, 0, B, ldb, C, ldc);
+        kt_end(stream);
+        MX_LAUNCH_CHECK();
+        return 0;
+    }
+    // grow-only per-thread scratch, like AUTO's plan: launches that use it must follow each other on one stream
+    int32_t *cur = (int32_t *)scratch_buffer(MX_SCRATCH_ROWSPLIT, (size_t)(P + 1) * (size_t)m * sizeof(int32_t));
+    if (!cur) return set_error("rowsplit_spmm: cannot allocate %zu bytes of panel cursors", (size_t)(P + 1) * (size_t)m * sizeof(int32_t));
+    const int panel_cols = (int)ceil_div(K, P);
+    kt_begin(stream);
+    hipLaunchKernelGGL(rowsplit_cursors_kernel, dim3((unsigned)ceil_div(m, RS_WAVES)), dim3(RS_WAVES * MX_WAVE), 0, stream,
+                       m, P, panel_cols, indptr, indices, cur);
+    for (int p = 0; p < P; p++)
+        hipLaunchKernelGGL((spmm_rowsplit_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
+                           m, n, S, indptr, indices, values, cur + (size_t)p * m, cur + (size_t)(p + 1) * m, p > 0 ? 1 : 0, B, ldb, C, ldc);
+    kt_end(stream);
+    MX_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename real_t, int VEC, bool COLMAJOR>
+static int pick_group_rowsplit(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
+                               const real_t *B, size_t ldb, real_t *C, size_t ldc, hipStream_t st)
+{
+    if constexpr (VEC > 1) {
+        if (n <= 8 * VEC) return launch_rowsplit<real_t, VEC, 8, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, st);
+        if (n <= 16 * VEC) return launch_rowsplit<real_t, VEC, 16, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, st);
+        if (n <= 32 * VEC) return launch_rowsplit<real_t, VEC, 32, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, st);
+    }
+    return launch_rowsplit<real_t, VEC, 64, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, st);
+}
+
+// Column panels (tools/auto_map.py, profiles/r04_auto_map.json): none while an XCD's L2 still holds most of B (5 MB: 80 %
+// of the reads hit, and three launches of a third of each row were SLOWER: 0.156 vs 0.122 ms at m = 1e4, 500 entries per
+// row, n = 64); from 7 MB on, ~2.5 MB of B per panel (the budget of the planned kernel's panels) as long as a row keeps
+// enough entries per panel to pay for a wavefront of its own: 32 when 32 or 64 lanes own a row of B (m = 1e5, K = 1e4,
+// 128 per row, n = 128: 4 panels 0.576 ms, one 0.971), 64 / 96 with 16- / 8-lane groups, whose load instruction covers 4 / 8
+// entries (n = 16, 32 per panel: 2.36 vs 1.75 ms at m = 1e6)
+int rowsplit_panels(int n, int K, int dense_bytes, double avg_len)
+{
+    const double b_bytes = (double)K * n * dense_bytes;
+    if (b_bytes < 7e6) return 1;
+    int P = (int)((b_bytes + 2.5e6 - 1) / 2.5e6);
+    const int row_bytes = n * dense_bytes;
+    const double per_panel = row_bytes <= 128 ? 96.0 : (row_bytes <= 256 ? 64.0 : 32.0);
+    const int by_len = (int)(avg_len / per_panel);
+    if (P > by_len) P = by_len;
+    if (P > RS_MAX_PANELS) P = RS_MAX_PANELS;
+    return P < 1 ? 1 : P;
+}
+
+// segments per row: enough wavefronts for a few rounds of the machine (256 CUs x 32 slots), while a segment keeps at
+// least one full chunk of 64 entries on average (avg_len: entries of a row that ONE launch sees)
+int rowsplit_segments(int m, int n, int dense_bytes, double avg_len)
+{
+    const int W = 64 * (16 / dense_bytes);
+    const long long passes = (n + W - 1) / W;
+    int S = 1;
+    while (S < RS_WAVES && (long long)m * S * passes < 4LL * 8192 && avg_len / (2 * S) >= 64.0) S <<= 1;
+    return S;
+}
+
+template <typename real_t>
+int rowsplit_spmm(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
+                  const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream)
+{
+    constexpr int VECMAX = 16 / (int)sizeof(real_t);
+    if (S != 1 && S != 2 && S != 4 && S != 8) return set_error("rowsplit_spmm: segments per row must be 1, 2, 4 or 8 (got %d)", S);
+    if (P < 1 || P > RS_MAX_PANELS) return set_error("rowsplit_spmm: 1 .. %d column panels (got %d)", RS_MAX_PANELS, P);
+    // widest per-lane access the operands allow (16 B when the rows of B are 16-B aligned); row-major C is read / written
+    // by vector accesses only on the S = 1 path, which needs its rows aligned as well
+    const bool b_vec = (n % VECMAX == 0) && (ldb % VECMAX == 0) && ((uintptr_t)B % 16 == 0);
+    const bool c_vec = colmajor || S > 1 || ((ldc % VECMAX == 0) && ((uintptr_t)C % 16 == 0));
+    if (b_vec && c_vec)
+        return colmajor ? pick_group_rowsplit<real_t, VECMAX, true>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, stream)
+                        : pick_group_rowsplit<real_t, VECMAX, false>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, stream);
+    return colmajor ? pick_group_rowsplit<real_t, 1, true>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, stream)
+                    : pick_group_rowsplit<real_t, 1, false>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, stream);
+}
+template int rowsplit_spmm<double>(int, int, int, int, int, const int32_t *, const int32_t *, const double *, const double *, size_t,
+                                   double *, size_t, int, hipStream_t);
+template int rowsplit_spmm<float>(int, int, int, int, int, const int32_t *, const int32_t *, const double *, const float *, size_t,
+                                  float *, size_t, int, hipStream_t);
+
+}  // namespace mx

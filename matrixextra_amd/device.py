@@ -129,7 +129,8 @@ def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajo
     """C = A @ B with B (K x n) row-major in HBM.  colmajor=False: C row-major (m x n) —
     gemm_csr_drm_as_drm layout; colmajor=True: C column-major (what tcrossprod_csr_dense returns to R),
     stored as a row-major (n x m) tensor and returned as its transposed view.
-    algo: 0 auto, 1 row-wave kernel, 2 slab/panel kernel (include/mxgpu.h mx_spmm_algo).
+    algo: 0 auto, 1 row-wave kernel, 2 slab/panel kernel, 3 planned (rebuilt per call), 4 row-split kernel — npanels is
+    then the number of segments per row, 0 = chosen from the shape (include/mxgpu.h mx_spmm_algo).
     keep_plan (algo 0 only): when AUTO picks the planned kernel, the plan — a regrouping of A's entries that depends on A
     alone — is built once and kept on the DeviceCSR (like rows_sorted()); keep_plan=False is the C-ABI's own AUTO, which
     rebuilds the plan from plain CSR inside every call."""
@@ -153,20 +154,23 @@ def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajo
         return out.t() if colmajor else out
     if algo == 0 and keep_plan and wg_per_cu == 0:
         pick = C.c_int(0)
-        check(lib.mxd_spmm_auto_algo(C.c_int(A.m), C.c_int(n), C.c_int(A.K), C.c_int(dt), _dp(B), C.c_size_t(B.stride(0)),
-                                     _dp(out), C.c_size_t(ldc), C.c_int(1 if colmajor else 0), C.byref(pick)))
+        check(lib.mxd_spmm_auto_algo2(C.c_int(A.m), C.c_int(n), C.c_int(A.K), C.c_int64(A.nnz), C.c_int(1), C.c_int(dt), _dp(B),
+                                      C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc), C.c_int(1 if colmajor else 0),
+                                      C.byref(pick)))
         if pick.value == 3:
             plan = A.auto_plan(npanels)
             if plan is not None:
                 check(lib.mxd_spmm_plan_run(plan, C.c_int(n), _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),
                                             C.c_int(dt), C.c_int(1 if colmajor else 0), C.c_int(0), C.c_int(-1), _stream()))
                 return out.t() if colmajor else out
-            algo = 1                                                 # too much padding: AUTO's row-wave fallback
-    sorted_rows = A.rows_sorted() if algo != 1 else False
-    check(lib.mxd_spmm_csr_dense_ex(C.c_int(A.m), C.c_int(n), C.c_int(A.K), _dp(A.indptr), _dp(A.indices),
-                                    _dp(A.values), _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),
-                                    C.c_int(dt), C.c_int(1 if colmajor else 0), C.c_int(algo),
-                                    C.c_int(int(sorted_rows)), C.c_int(npanels), C.c_int(wg_per_cu), _stream()))
+            algo = 4                                                 # too much padding: AUTO's fallback (row-split kernel)
+        elif pick.value != 3:
+            algo = pick.value                                        # the choice made WITH a kept plan in mind stands
+    sorted_rows = A.rows_sorted() if algo == 2 else False              # only the slab kernel's panels need it
+    check(lib.mxd_spmm_csr_dense_ex2(C.c_int(A.m), C.c_int(n), C.c_int(A.K), C.c_int64(A.nnz), _dp(A.indptr), _dp(A.indices),
+                                     _dp(A.values), _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),
+                                     C.c_int(dt), C.c_int(1 if colmajor else 0), C.c_int(algo),
+                                     C.c_int(int(sorted_rows)), C.c_int(npanels), C.c_int(wg_per_cu), _stream()))
     return out.t() if colmajor else out
 
 

@@ -1,0 +1,159 @@
+"""AUTO regime map: every SpMM kernel family timed over a grid of shapes between the benchmarks, so that
+MX_SPMM_AUTO's rule (csrc/spmm.hip spmm_auto_algo) is what the measurements say and not a guess.
+
+  python tools/auto_map.py [--quick] [--out profiles/r04_auto_map.json]
+
+Grid: m in {1e4, 1e5, 1e6} x entries/row in {8, 32, 128, 500} x n in {16, 64, 100, 128, 256} x K in {1e4, 1e5}, f64, both
+layouts of C (column-major = tcrossprod_csr_dense, what R's `%*%` takes; row-major = dense x CSC / dense x t(CSR)), plus a
+few f32 points; shapes with more than 1.3e8 entries or a result above 2 GiB are skipped.  Per shape: the row-wave kernel,
+the row-split kernel (AUTO's segment count), the slab kernel, the planned kernel with the plan kept / rebuilt per call, and
+AUTO both ways (plan kept on the matrix = what the exports do for a cached operand; C-ABI AUTO = plan rebuilt).  Device
+time per product from HIP events around 10 launches after 2 warm-ups, operands resident.
+
+Also: SpMV kernels (lane-group / flat / tile / AUTO) over m x entries/row, and the gather's lane-group width is left to
+bench.py's gather leg (one shape).  Writes one JSON document."""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from matrixextra_amd import _lib, device as D, synth  # noqa: E402
+
+
+def timeit(fn, reps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def spmm_point(m, K, npr, n, colmajor, dtype, lib):
+    p, j, x = synth.device_csr_fixed(m, K, npr, seed=11)
+    A = D.DeviceCSR(p, j, x, m, K, int(j.numel()))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    B = torch.randn((K, n), dtype=dtype, device="cuda", generator=g)
+    out = torch.empty((n, m) if colmajor else (m, n), dtype=dtype, device="cuda")
+    ms, kern = {}, {}
+
+    def run(name, fn):
+        try:
+            fn()
+            kern[name] = lib.mxd_spmm_last_kernel().decode()
+            ms[name] = round(timeit(fn), 5)
+        except _lib.MxError as e:                                 # operands a kernel does not take (alignment rules)
+            ms[name] = None
+            kern[name] = "n/a: " + str(e)[:60]
+
+    run("rowwave", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=1))
+    run("rowsplit", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=4))
+    run("rowsplit_one_panel", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=4, npanels=1))
+    run("slab", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=2))
+    run("planned_kept", lambda: D.spmm_planned(A, B, out=out, colmajor=colmajor))
+    run("planned_rebuilt", lambda: D.spmm_planned(A, B, out=out, colmajor=colmajor, rebuild_plan=True))
+    A.invalidate()
+    run("auto_kept_plan", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=0, keep_plan=True))
+    pick = C.c_int(0)
+    _lib.check(lib.mxd_spmm_auto_algo2(C.c_int(m), C.c_int(n), C.c_int(K), C.c_int64(A.nnz), C.c_int(0), C.c_int(0 if dtype == torch.float64 else 1),
+                                       C.c_void_p(B.data_ptr()), C.c_size_t(n), C.c_void_p(out.data_ptr()),
+                                       C.c_size_t(m if colmajor else n), C.c_int(int(colmajor)), C.byref(pick)))
+    A.invalidate()
+    run("auto_one_shot", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=0, keep_plan=False))
+    one_shot = {k: v for k, v in ms.items() if v is not None and k in ("rowwave", "rowsplit", "slab", "planned_rebuilt")}
+    kept = {k: v for k, v in ms.items() if v is not None and k in ("rowwave", "rowsplit", "slab", "planned_kept")}
+    best1, bestk = min(one_shot, key=one_shot.get), min(kept, key=kept.get)
+    rec = {"m": m, "K": K, "per_row": npr, "n": n, "layout": "col" if colmajor else "row", "dtype": "f64" if dtype == torch.float64 else "f32",
+           "ms": ms, "auto_family": {0: "auto", 1: "rowwave", 2: "slab", 3: "planned", 4: "rowsplit"}[pick.value],
+           "best_one_shot": best1, "best_kept": bestk,
+           "auto_one_shot_over_best": round(ms["auto_one_shot"] / one_shot[best1], 3),
+           "auto_kept_over_best": round(ms["auto_kept_plan"] / kept[bestk], 3)}
+    del A, B, out, p, j, x
+    return rec
+
+
+def spmv_point(m, K, npr, lib):
+    p, j, x = synth.device_csr_fixed(m, K, npr, seed=13)
+    A = D.DeviceCSR(p, j, x, m, K, int(j.numel()))
+    v = torch.randn(K, dtype=torch.float64, device="cuda")
+    y = torch.empty(m, dtype=torch.float64, device="cuda")
+    ms = {}
+    for name, algo in (("auto", 0), ("group", 1), ("tile", 2), ("flat", 3)):
+        try:
+            ms[name] = round(timeit(lambda: D.spmv(A, v, out=y, algo=algo), reps=20), 5)
+        except _lib.MxError:
+            ms[name] = None
+    ms["planned_kept"] = round(timeit(lambda: D.spmv_planned(A, v, out=y), reps=20), 5)
+    cand = {k: t for k, t in ms.items() if t is not None and k in ("group", "tile", "flat")}
+    best = min(cand, key=cand.get)
+    return {"m": m, "K": K, "per_row": npr, "ms": ms, "best_one_shot": best, "auto_over_best": round(ms["auto"] / cand[best], 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true", help="the reduced grid of tests/test_gpu_auto_map.py")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "auto_map.json"))
+    ap.add_argument("--no-spmv", action="store_true")
+    args = ap.parse_args()
+    lib = _lib.load()
+    t0 = time.time()
+    doc = {"device": _lib.device_name(), "spmm": [], "spmv": [], "skipped": []}
+    ms_, nprs, ns, Ks = (10_000, 100_000, 1_000_000), (8, 32, 128, 500), (16, 64, 100, 128, 256), (10_000, 100_000)
+    if args.quick:
+        ms_, nprs, ns, Ks = (10_000, 100_000), (32, 500), (16, 100, 128), (10_000, 100_000)
+    for m in ms_:
+        for npr in nprs:
+            for K in Ks:
+                if m * npr > 130_000_000:
+                    doc["skipped"].append({"m": m, "per_row": npr, "K": K, "why": "more than 1.3e8 entries"})
+                    continue
+                for n in ns:
+                    if m * n * 8 > 2 << 30:
+                        doc["skipped"].append({"m": m, "per_row": npr, "K": K, "n": n, "why": "result above 2 GiB"})
+                        continue
+                    for colmajor in (True, False):
+                        doc["spmm"].append(spmm_point(m, K, npr, n, colmajor, torch.float64, lib))
+                torch.cuda.empty_cache()
+            print(f"[auto_map] m={m} per_row={npr} done at {time.time() - t0:.0f}s", file=sys.stderr, flush=True)
+    for (m, K, npr, n) in ((10_000, 10_000, 500, 100), (100_000, 100_000, 32, 256), (1_000_000, 100_000, 32, 256), (10_000, 100_000, 128, 64)):
+        if args.quick and m > 100_000:
+            continue
+        for colmajor in (True, False):
+            doc["spmm"].append(spmm_point(m, K, npr, n, colmajor, torch.float32, lib))
+    if not args.no_spmv:
+        for m in ms_:
+            for npr in nprs:
+                if m * npr > 130_000_000:
+                    continue
+                doc["spmv"].append(spmv_point(m, 100_000, npr, lib))
+    w1 = max(doc["spmm"], key=lambda r: r["auto_one_shot_over_best"])
+    wk = max(doc["spmm"], key=lambda r: r["auto_kept_over_best"])
+    doc["summary"] = {
+        "points": len(doc["spmm"]), "seconds": round(time.time() - t0, 1),
+        "auto_one_shot_worst_over_best": {"ratio": w1["auto_one_shot_over_best"], "at": {k: w1[k] for k in ("m", "K", "per_row", "n", "layout", "dtype")}},
+        "auto_kept_worst_over_best": {"ratio": wk["auto_kept_over_best"], "at": {k: wk[k] for k in ("m", "K", "per_row", "n", "layout", "dtype")}},
+        "points_above_1.25_one_shot": sum(r["auto_one_shot_over_best"] > 1.25 for r in doc["spmm"]),
+        "points_above_1.25_kept": sum(r["auto_kept_over_best"] > 1.25 for r in doc["spmm"]),
+        "spmv_worst_over_best": max((r["auto_over_best"] for r in doc["spmv"]), default=None)}
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        json.dump(doc, f, indent=1)
+    print(json.dumps(doc["summary"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -98,13 +98,14 @@ namespace mx {
 // matter there — the row-split kernel (column panels by launches) and the planned panel sweep — in the quantities that
 // bound them on MI355X:
 //   * both gather nnz rows of B through the CUs' L1s; what they read from is an XCD's L2 (4 MiB) when the panel of B they
-//     work on fits it (~26 TB/s of line reads measured in the row-split kernel; 23 TB/s in the planned sweep with one
-//     panel, 18 TB/s with several), the Infinity Cache otherwise (~8.5 TB/s); a uniformly gathered panel of T bytes
-//     hits L2 with probability 4 MiB / T (guide: "Indexed rows: gather into LDS");
-//   * the row-split kernel pays ~0.35 ns per (row, panel, column pass) — one wavefront each — and a few us per launch;
-//     the planned kernel ~0.01 ns per (row, slab, panel), ~40 us of fixed cost per run, and, when the plan is not kept,
-//     ~36 us + 6 ps per entry to build it; it needs m / 64 octets x slabs >> 1024 workgroups: below 32k rows it is never
-//     chosen (at m = 1e4 the row-split kernel won 38 of 40 points, the other two within 18 %).
+//     work on fits it (~28 TB/s of line reads measured in the row-split kernel, 17 with 8-lane groups; 23.5 TB/s in the
+//     planned sweep with one panel, 19 TB/s with several), the Infinity Cache otherwise (~8.5 TB/s); a uniformly gathered
+//     panel of T bytes hits L2 with probability 4 MiB / T (guide: "Indexed rows: gather into LDS");
+//   * the row-split kernel pays ~0.2 ns per (row, panel, column pass) — one wavefront each — and a few us per launch;
+//     the planned kernel ~0.01 ns per (row, slab, panel), ~15 us of fixed cost per run, and, when the plan is not kept,
+//     ~36 us + 6 ps per entry to build it; its persistent grid fills with (octet of 64 rows, slab) pairs — rate x
+//     pairs / (pairs + 2400) — and below 32k rows it is never chosen (at m = 1e4 the row-split kernel won 38 of 40
+//     points, the other two within 18 %).
 // keep_plan: the caller keeps the plan across products (DeviceCSR, the exports' CSR cache) — the build is not charged.
 // Callers that do not know nnz get the old rule.  Products below 2^22 multiply-adds are launch-bound whatever runs and
 // stay on the row-wave kernel, whose sums are the reference's storage-order FMA chain bit for bit.
@@ -123,13 +124,21 @@ static AutoCost spmm_auto_cost(int m, int n, int K, int64_t nnz, int sz, bool ke
     };
     AutoCost c;
     c.panels = rowsplit_panels(n, K, sz, avg);
-    const double lanes_rate = n * sz <= 128 ? 17.0 : 26.0;                     // (8-lane groups: 17 TB/s measured)
-    c.rowsplit_us = (double)nnz * n * sz / rate(b_bytes / c.panels, lanes_rate, 8.5) + 0.35e-3 * m * c.panels * passes +
-                    4.0 * c.panels + 4.0;
+    const bool one_line = n * sz <= 128;                                       // 8-lane groups: 17 TB/s measured, and a
+    const double lanes_rate = one_line ? 17.0 : 28.0;                          // wavefront per row costs half as much
+    // every launch after the first reads and rewrites C: free while C lives in the Infinity Cache (m = 1e5, n = 128: 0.1 GB),
+    // HBM traffic at ~5 TB/s beyond (m = 1e6: 4 panels = 7 x 1 GB more: 7.4 ms measured where one panel's model said 5.5)
+    const double c_bytes = (double)m * n * sz;
+    const double c_traffic_us = c_bytes > 128e6 ? (2.0 * c.panels - 2.0) * c_bytes / 5e6 : 0.0;
+    c.rowsplit_us = (double)nnz * n * sz / rate(b_bytes / c.panels, lanes_rate, 8.5) + 0.2e-3 * m * c.panels * passes +
+                    4.0 * c.panels + 4.0 + c_traffic_us;
     const double plan_panels = std::max(1.0, std::ceil((double)K * 128.0 / 2.5e6));
-    const double sweep_rate = plan_panels > 1.0 ? 18.0 : 23.0;
-    c.planned_us = (double)nnz * slabs * 128.0 / rate((double)K * 128.0 / plan_panels, sweep_rate, 8.5) +
-                   0.01e-3 * m * slabs * plan_panels + 40.0 + (keep_plan ? 0.0 : 36.0 + 6e-6 * (double)nnz);
+    // the sweep's persistent grid fills with the number of (octet of 64 rows, slab) pairs: 1,563 of them (m = 1e5, one slab)
+    // ran at 9 TB/s, 6,250 at 17.7, 12,500 at 19, 125,000 at 23.8
+    const double pairs = std::ceil(m / 64.0) * slabs, fill = pairs / (pairs + 2400.0);
+    const double sweep_rate = (plan_panels > 1.0 ? 19.0 : 23.5) * fill;
+    c.planned_us = (double)nnz * slabs * 128.0 / rate((double)K * 128.0 / plan_panels, sweep_rate, 8.5 * fill) +
+                   0.01e-3 * m * slabs * plan_panels + 15.0 + (keep_plan ? 0.0 : 36.0 + 6e-6 * (double)nnz);
     return c;
 }
 static int spmm_auto_algo(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,

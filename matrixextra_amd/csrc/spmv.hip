@@ -167,8 +167,12 @@ int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t 
     if (algo == MX_SPMV_FLAT && !flat_ok)
         return set_error("spmv: the flat kernel needs the exact nnz (>= 4) and 16-byte aligned index / value arrays");
     // AUTO: the flat kernel once there are enough entries to fill the chip (measured on MI355X: 1M x 100k, 32 / row:
-    // flat vs lane-group in DESIGN.md §4.3); small products stay on the lane-group kernel
-    if (algo == MX_SPMV_FLAT || (algo == MX_SPMV_AUTO && flat_ok && nnz >= ((int64_t)1 << 20)))
+    // flat vs lane-group in DESIGN.md §4.3); small products stay on the lane-group kernel.  Rounds 1-3 switched at 2^20
+    // entries whatever the shape; round 4's map (tools/auto_map.py, K = 1e5) shows the flat kernel 1.6-1.9x behind for FEW
+    // rows (1e4 x 128 / row: lane-group 0.009 ms, flat 0.016; 1e4 x 500: 0.029 / 0.047) and within 1.2x either way from 1e5
+    // rows on (1e5 x 32: 0.020 / 0.024; 1e5 x 500: 0.328 / 0.276; 1e6 x 32: 0.190 / 0.164) — where it stays, because its
+    // sums are the reference's loop bit for bit
+    if (algo == MX_SPMV_FLAT || (algo == MX_SPMV_AUTO && flat_ok && nnz >= ((int64_t)1 << 20) && m >= 32768))
         return spmv_flat_launch(m, nnz, indptr, indices, values, v, v_dtype, y, st);
     const int G = nnz < 0 ? 32 : pick_group((double)nnz / (double)(m > 0 ? m : 1));
     switch (v_dtype) {

@@ -1,0 +1,35 @@
+"""MX_SPMM_AUTO stays close to the best kernel between the benchmarks: a reduced grid of
+tools/auto_map.py — the reference's published dense x CSC shape (vignettes/Introducing_MatrixExtra.Rmd:247-251), the
+headline shape, and the mid-size shapes where rounds 1-3's rule was up to 2x off — each kernel family timed on the device,
+AUTO (plan rebuilt per call, and plan kept on the matrix) within 25 % of the best of them.  The full map (228 shapes) is
+profiles/r04_auto_map.json; this test allows 35 % + 10 us for the noise of a single short timing run."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POINTS = [  # m, K, entries / row, n, column-major C
+    (10_000, 10_000, 500, 100, False),        # the vignette's product (matmul_dense_csc_numeric)
+    (10_000, 100_000, 32, 64, True),
+    (100_000, 10_000, 128, 16, True),         # one slab, long rows: planned was chosen (2.2x off) before the fill term
+    (100_000, 10_000, 128, 128, True),        # row-split with 4 column panels beats the kept plan
+    (100_000, 100_000, 32, 128, True),        # round 3's rule ran the row-wave kernel here: 1.75x off
+    (100_000, 100_000, 500, 100, False),
+    (1_000_000, 100_000, 32, 128, True),      # BASELINE configs[1]
+]
+
+
+@pytest.mark.parametrize("m,K,per_row,n,colmajor", POINTS)
+def test_auto_within_25pct_of_best(gpu, m, K, per_row, n, colmajor):
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import auto_map
+    rec = auto_map.spmm_point(m, K, per_row, n, colmajor, torch.float64, gpu.load())
+    ms = rec["ms"]
+    best1 = min(ms[k] for k in ("rowwave", "rowsplit", "slab", "planned_rebuilt") if ms[k] is not None)
+    bestk = min(ms[k] for k in ("rowwave", "rowsplit", "slab", "planned_kept") if ms[k] is not None)
+    assert ms["auto_one_shot"] <= 1.35 * best1 + 0.010, rec
+    assert ms["auto_kept_plan"] <= 1.35 * bestk + 0.010, rec
+    torch.cuda.empty_cache()

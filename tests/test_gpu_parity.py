@@ -1071,5 +1071,12 @@ def test_matmul_rowvec_by_csc(gpu, ncols, nrows, dens):
         assert got.shape == want.shape == (1, ncols) and got.dtype == np.float32
         scale = max(1.0, float(np.abs(want).max()))
         np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * scale)
-        if j.size >= (1 << 20):                                      # AUTO takes the flat kernel: the reference's order of additions
-            np.testing.assert_array_equal(got, want)
+    if j.size >= (1 << 20):      # the flat kernel (AUTO from 2^24 entries on; here by option): the reference's order of additions
+        import ctypes as C
+        lib = _lib.load()
+        _lib.check(lib.mx_set_option(b"spmv_algo", C.c_int64(3)))
+        try:
+            np.testing.assert_array_equal(G.matmul_rowvec_by_csc(v, p, j, x), O.matmul_rowvec_by_csc(v, p, j, x))
+            np.testing.assert_array_equal(G.matmul_rowvec_by_cscbin(v, p, j), O.matmul_rowvec_by_cscbin(v, p, j))
+        finally:
+            _lib.check(lib.mx_set_option(b"spmv_algo", C.c_int64(0)))

@@ -55,30 +55,40 @@ def spmm_point(m, K, npr, n, colmajor, dtype, lib):
         try:
             fn()
             kern[name] = lib.mxd_spmm_last_kernel().decode()
-            ms[name] = round(timeit(fn), 5)
+            ms[name] = round(min(timeit(fn), timeit(fn, warm=0)), 5)     # best of two rounds of 10
         except _lib.MxError as e:                                 # operands a kernel does not take (alignment rules)
             ms[name] = None
             kern[name] = "n/a: " + str(e)[:60]
 
+    dt = 0 if dtype == torch.float64 else 1
+    pick, pick_kept = C.c_int(0), C.c_int(0)
+    for keep, dst in ((0, pick), (1, pick_kept)):
+        _lib.check(lib.mxd_spmm_auto_algo2(C.c_int(m), C.c_int(n), C.c_int(K), C.c_int64(A.nnz), C.c_int(keep), C.c_int(dt),
+                                           C.c_void_p(B.data_ptr()), C.c_size_t(n), C.c_void_p(out.data_ptr()),
+                                           C.c_size_t(m if colmajor else n), C.c_int(int(colmajor)), C.byref(dst)))
+    model = {}
+    for keep in (0, 1):
+        a, b, P = C.c_double(), C.c_double(), C.c_int()
+        _lib.check(lib.mxd_spmm_auto_cost(C.c_int(m), C.c_int(n), C.c_int(K), C.c_int64(A.nnz), C.c_int(keep), C.c_int(dt), C.byref(a),
+                                          C.byref(b), C.byref(P)))
+        model["kept" if keep else "one_shot"] = {"rowsplit_ms": round(a.value / 1e3, 4), "planned_ms": round(b.value / 1e3, 4), "panels": P.value}
+    # AUTO first: nothing has been freed yet (a plan that goes back to the pool / the driver makes the next launches slower
+    # for a while — pool.hip — and showed up as 1.3-2.4x "AUTO over best" artefacts in the first version of this map)
+    run("auto_one_shot", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=0, keep_plan=False))
+    run("auto_kept_plan", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=0, keep_plan=True))
     run("rowwave", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=1))
     run("rowsplit", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=4))
     run("rowsplit_one_panel", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=4, npanels=1))
     run("slab", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=2))
     run("planned_kept", lambda: D.spmm_planned(A, B, out=out, colmajor=colmajor))
     run("planned_rebuilt", lambda: D.spmm_planned(A, B, out=out, colmajor=colmajor, rebuild_plan=True))
-    A.invalidate()
-    run("auto_kept_plan", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=0, keep_plan=True))
-    pick = C.c_int(0)
-    _lib.check(lib.mxd_spmm_auto_algo2(C.c_int(m), C.c_int(n), C.c_int(K), C.c_int64(A.nnz), C.c_int(0), C.c_int(0 if dtype == torch.float64 else 1),
-                                       C.c_void_p(B.data_ptr()), C.c_size_t(n), C.c_void_p(out.data_ptr()),
-                                       C.c_size_t(m if colmajor else n), C.c_int(int(colmajor)), C.byref(pick)))
-    A.invalidate()
-    run("auto_one_shot", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=0, keep_plan=False))
     one_shot = {k: v for k, v in ms.items() if v is not None and k in ("rowwave", "rowsplit", "slab", "planned_rebuilt")}
     kept = {k: v for k, v in ms.items() if v is not None and k in ("rowwave", "rowsplit", "slab", "planned_kept")}
     best1, bestk = min(one_shot, key=one_shot.get), min(kept, key=kept.get)
     rec = {"m": m, "K": K, "per_row": npr, "n": n, "layout": "col" if colmajor else "row", "dtype": "f64" if dtype == torch.float64 else "f32",
            "ms": ms, "auto_family": {0: "auto", 1: "rowwave", 2: "slab", 3: "planned", 4: "rowsplit"}[pick.value],
+           "auto_family_kept_plan": {0: "auto", 1: "rowwave", 2: "slab", 3: "planned", 4: "rowsplit"}[pick_kept.value],
+           "model": model, "kernels": {k: kern[k] for k in ("auto_one_shot", "auto_kept_plan")},
            "best_one_shot": best1, "best_kept": bestk,
            "auto_one_shot_over_best": round(ms["auto_one_shot"] / one_shot[best1], 3),
            "auto_kept_over_best": round(ms["auto_kept_plan"] / kept[bestk], 3)}
@@ -142,8 +152,15 @@ def main():
                 doc["spmv"].append(spmv_point(m, 100_000, npr, lib))
     w1 = max(doc["spmm"], key=lambda r: r["auto_one_shot_over_best"])
     wk = max(doc["spmm"], key=lambda r: r["auto_kept_over_best"])
+    # products of a few microseconds are timed through Python's ~10 us per call (the same kernel measures 0.011 and 0.021 ms
+    # in two legs of one point): the ratios that say something about the CHOICE are those of products above 50 us
+    long1 = [r for r in doc["spmm"] if min(v for k, v in r["ms"].items() if v is not None) >= 0.05]
     doc["summary"] = {
         "points": len(doc["spmm"]), "seconds": round(time.time() - t0, 1),
+        "points_above_50us": len(long1),
+        "above_50us_auto_one_shot_worst_over_best": max((r["auto_one_shot_over_best"] for r in long1), default=None),
+        "above_50us_auto_kept_worst_over_best": max((r["auto_kept_over_best"] for r in long1), default=None),
+        "above_50us_points_above_1.25": [sum(r["auto_one_shot_over_best"] > 1.25 for r in long1), sum(r["auto_kept_over_best"] > 1.25 for r in long1)],
         "auto_one_shot_worst_over_best": {"ratio": w1["auto_one_shot_over_best"], "at": {k: w1[k] for k in ("m", "K", "per_row", "n", "layout", "dtype")}},
         "auto_kept_worst_over_best": {"ratio": wk["auto_kept_over_best"], "at": {k: wk[k] for k in ("m", "K", "per_row", "n", "layout", "dtype")}},
         "points_above_1.25_one_shot": sum(r["auto_one_shot_over_best"] > 1.25 for r in doc["spmm"]),

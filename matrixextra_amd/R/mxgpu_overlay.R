@@ -50,7 +50,19 @@
     "matmul_rowvec_by_csc", "matmul_rowvec_by_cscbin"
 )
 
-mxgpu_enable <- function(shim_path, min_nnz = 0L) {
+## From which operand size on a call goes to the GPU (the length of the longest vector passed: the entry count, or the
+## dense operand).  Measured on an MI355X box against MatrixExtra's algorithm on the host's cores (tools/small_calls.py,
+## profiles/r04_small_calls.json: host arrays in, host arrays out): one call costs 29-50 us at the reference's own test
+## sizes (100 x 50) whatever it does, so products and CSR (+) CSR win from ~5e4 entries on, `X %*% v` (8 bytes of result per
+## row against 12 bytes per entry over PCIe) from ~1e6, and `X[rows, ]` — a memcpy on the host — only from ~1e7.
+.mxgpu_default_min_len <- function(fn) {
+    if (startsWith(fn, "matmul_csr_dvec_") || startsWith(fn, "matmul_csr_svec_") || startsWith(fn, "matmul_rowvec_by_")) return(1000000L)
+    if (startsWith(fn, "copy_csr_") || startsWith(fn, "reverse_") || startsWith(fn, "cbind_") || fn == "concat_csr_batch") return(10000000L)
+    50000L
+}
+
+## min_nnz: NULL = the measured defaults above; 0 = every call goes to the GPU; a number = that threshold for every routine
+mxgpu_enable <- function(shim_path, min_nnz = NULL) {
     dll <- dyn.load(shim_path)
     ## options of the backend (include/mxgpu.h, mx_set_option / mx_set_devices), taken from R options at enable time:
     ##   options(MatrixExtra.mxgpu_spmv_planned = TRUE)   `X %*% v` on a matrix still on the device may use the planned
@@ -68,10 +80,11 @@ mxgpu_enable <- function(shim_path, min_nnz = 0L) {
         .mxgpu_state$saved[[fn]] <- cpu_fun
         native <- getNativeSymbolInfo(paste0("_MatrixExtra_", fn), dll)
         gpu_fun <- local({
-            native <- native; cpu_fun <- cpu_fun; min_nnz <- min_nnz
+            native <- native; cpu_fun <- cpu_fun
+            min_nnz <- if (is.null(min_nnz)) .mxgpu_default_min_len(fn) else as.integer(min_nnz)
             function(...) {
-                ## tiny operands are cheaper on the host than a PCIe round trip: optional size gate on the
-                ## length of the first index vector passed (0 = always use the GPU)
+                ## small operands are cheaper on the host than a PCIe round trip: size gate on the length of the
+                ## longest vector passed (0 = always use the GPU)
                 args <- list(...)
                 if (min_nnz > 0L) {
                     lens <- vapply(args, length, integer(1L))

@@ -518,6 +518,63 @@ static void partition_rows(const int32_t *indptr, int m, int nparts, double w_en
     cuts[nparts] = m;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// SMALL CALLS.  The reference's own tests multiply 100 x 50 matrices (tests/testthat/test-matmul.R:108-114)
+// and slice 1000 x 500 ones (test-slice.R:6-16); the machinery above is built for results of a gigabyte and cost such a call
+// 76-175 us (tools/small_calls.py, round 4: four or six synchronous pageable copies, five pooled blocks each freed behind a
+// device synchronisation, a cache look-up).  A call whose operands and result fit SMALL_LIMIT goes another way: every
+// input is packed into ONE pinned block (a host memcpy of a few microseconds), goes up in ONE asynchronous copy on the
+// thread's own stream, the kernels run on the device twin of that block (inputs, results and workspaces at the same
+// offsets), the results come back in ONE copy, and the call synchronises ONCE.  No pool, no cache, no registration, no
+// fingerprint.  The same kernels compute; nothing is computed on the host.  MXGPU_SMALL_CALLS=0 switches the path off.
+constexpr size_t SMALL_LIMIT = (size_t)512 << 10;                // inputs + results of a call that takes the small path
+constexpr size_t SMALL_STAGE = (size_t)4 << 20;                  // the block: inputs, results, kernel workspaces
+struct SmallStage {
+    char *h = nullptr, *d = nullptr;
+    hipStream_t st = nullptr;
+    size_t top = 0;
+    bool tried = false;
+    bool init()
+    {
+        if (tried) return h != nullptr;
+        tried = true;
+        if (hipHostMalloc((void **)&h, SMALL_STAGE, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h = nullptr; return false; }
+        if (hipMalloc((void **)&d, SMALL_STAGE) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostFree(h);
+            if (d) (void)hipFree(d);
+            h = d = nullptr;
+            return false;
+        }
+        return true;
+    }
+    // offsets are the same on both sides; 256-byte aligned (16-byte rules of the kernels, whole cache lines)
+    size_t take(size_t n) { const size_t at = top; top = (top + (n ? n : 16) + 255) & ~(size_t)255; return at; }
+    size_t put(const void *src, size_t n) { const size_t at = take(n); if (n) memcpy(h + at, src, n); return at; }
+    bool fits() const { return top <= SMALL_STAGE; }
+    template <typename T> T *dev(size_t off) const { return reinterpret_cast<T *>(d + off); }
+    int up(size_t bytes) { MX_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st)); return 0; }
+    int down_and_wait(size_t from, size_t to)
+    {
+        if (to > from) MX_HIP(hipMemcpyAsync(h + from, d + from, to - from, hipMemcpyDeviceToHost, st));
+        MX_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+};
+static SmallStage *small_stage()
+{
+    static const bool on = [] { const char *e = getenv("MXGPU_SMALL_CALLS"); return !e || atoi(e) != 0; }();
+    if (!on) return nullptr;
+    static thread_local SmallStage stages[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
+    SmallStage &s = stages[dev];
+    if (!s.init()) return nullptr;
+    s.top = 0;
+    return &s;
+}
+static std::atomic<long long> g_small_calls{0};                  // mx_get_option("small_calls")
+
 template <typename real_t>
 static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_rows, const int32_t *indptr,
                            const int32_t *indices, const double *values, const real_t *B_host, size_t ldb, real_t *C_host,
@@ -655,6 +712,22 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     int algo = MX_SPMM_AUTO, npanels = 0;
     if (const char *e = getenv("MXGPU_SPMM_ALGO")) algo = atoi(e);
     if (const char *e = getenv("MXGPU_SPMM_PANELS")) npanels = atoi(e);
+    {   // small call: one block up, the product, one block down, one wait (see SmallStage)
+        const int64_t nnz_s = (int64_t)indptr[m] - indptr[0];
+        const size_t csr_bytes = 4 * ((size_t)m + 1) + 12 * (size_t)nnz_s;
+        SmallStage *S = indptr[0] == 0 && csr_bytes + b_bytes + c_bytes <= SMALL_LIMIT && algo != MX_SPMM_SLAB ? small_stage() : nullptr;
+        if (S) {
+            const size_t op = S->put(indptr, 4 * ((size_t)m + 1)), oj = S->put(indices, 4 * (size_t)nnz_s), ox = S->put(values, 8 * (size_t)nnz_s);
+            const size_t ob = S->put(B_host, b_bytes), in_end = S->top, oc = S->take(c_bytes), out_end = S->top;
+            if (S->up(in_end)) return 1;
+            if (mxd_spmm_csr_dense_ex2(m, n, K_rows, nnz_s, S->dev<int32_t>(op), S->dev<int32_t>(oj), S->dev<double>(ox), S->dev<real_t>(ob), ldb,
+                                       S->dev<real_t>(oc), ldc, dt, colmajor ? 1 : 0, algo, 0, npanels, 0, S->st)) return 1;
+            if (S->down_and_wait(oc, out_end)) return 1;
+            memcpy(C_host, S->h + oc, c_bytes);
+            g_small_calls++;
+            return 0;
+        }
+    }
     static const int pipeline_on = [] { const char *e = getenv("MXGPU_EXPORT_PIPELINE"); return e ? atoi(e) : 1; }();
     const bool pipelined = pipeline_on && c_bytes >= ((size_t)64 << 20) && m >= 4096 && algo != MX_SPMM_SLAB;
     if (pipelined) {
@@ -1030,6 +1103,22 @@ static int spmv_host(int m, const int32_t *indptr, const int32_t *indices, const
 {
     MX_REQUIRE(m >= 0 && len_y >= 0, "negative dimension");
     if (m == 0) return 0;
+    {   // small call (see SmallStage)
+        const int64_t nnz_s = (int64_t)indptr[m] - indptr[0];
+        const size_t in_bytes = 4 * ((size_t)m + 1) + 12 * (size_t)nnz_s + sizeof(vec_t) * (size_t)len_y, out_bytes = sizeof(out_t) * (size_t)m;
+        SmallStage *S = indptr[0] == 0 && in_bytes + out_bytes <= SMALL_LIMIT ? small_stage() : nullptr;
+        if (S) {
+            const size_t op = S->put(indptr, 4 * ((size_t)m + 1)), oj = S->put(indices, 4 * (size_t)nnz_s), ox = S->put(values, 8 * (size_t)nnz_s);
+            const size_t ov = S->put(y, sizeof(vec_t) * (size_t)len_y), in_end = S->top, oo = S->take(out_bytes), out_end = S->top;
+            if (S->up(in_end)) return 1;
+            if (spmv_launch(m, len_y, nnz_s, S->dev<int32_t>(op), S->dev<int32_t>(oj), S->dev<double>(ox), S->dev<void>(ov), v_dtype,
+                            S->dev<void>(oo), opt_spmv_algo(), S->st)) return 1;
+            if (S->down_and_wait(oo, out_end)) return 1;
+            memcpy(out, S->h + oo, out_bytes);
+            g_small_calls++;
+            return 0;
+        }
+    }
     Csr A;
     if (A.upload(indptr, indices, values, m, sizeof(double))) return 1;
     DevBuf v, o;
@@ -1070,6 +1159,11 @@ static int spmv_host(int m, const int32_t *indptr, const int32_t *indices, const
 struct mx_result {
     mx::DevBuf indptr, indices, values;
     mx_result_info info;
+    // a small call's result is already on the host when `begin` returns (one copy down with the sizes): the three arrays,
+    // back to back, owned by the handle (the staging block belongs to the thread and is reused by its next call)
+    std::vector<char> host;
+    size_t host_indices = 0, host_values = 0;
+    bool on_host = false;
 };
 
 using namespace mx;
@@ -1130,6 +1224,7 @@ int mx_get_option(const char *name, int64_t *value)
     if (strcmp(name, "spmv_planned") == 0) { *value = opt_spmv_planned() ? 1 : 0; return 0; }
     if (strcmp(name, "spmv_algo") == 0) { *value = opt_spmv_algo(); return 0; }
     if (strcmp(name, "spmv_planned_calls") == 0) { *value = g_spmv_planned_calls.load(); return 0; }   // read-only counter
+    if (strcmp(name, "small_calls") == 0) { *value = g_small_calls.load(); return 0; }                  // read-only: calls served by the small path
     if (strncmp(name, "pool_", 5) == 0) {                                                              // read-only: pool.hip
         long long idle_b = 0, idle_n = 0, hits = 0, misses = 0;
         mx::pool_stats(&idle_b, &idle_n, &hits, &misses);
@@ -1315,6 +1410,42 @@ int mx_csr_elemwise_begin(int op, int nrows, const int32_t *indptr1, const int32
             if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
             break;
         }
+        {   // small call (see SmallStage): count -> scan -> fill into arrays sized for the upper bound of the result, all
+            // three arrays down in one copy, the size read from the result's own index pointer
+            const bool isect_s = op == MX_OP_MUL || op == MX_OP_AND;
+            const int64_t bound_s = isect_s ? (nnz1 < nnz2 ? nnz1 : nnz2) : nnz1 + nnz2;
+            const size_t pb = 4 * ((size_t)nrows + 1);
+            const size_t in_bytes = 2 * pb + (4 + vb) * (size_t)(nnz1 + nnz2), out_bytes = pb + (4 + vb) * (size_t)bound_s;
+            SmallStage *S = nrows > 0 && indptr1[0] == 0 && indptr2[0] == 0 && indptr1[nrows] == nnz1 && indptr2[nrows] == nnz2 &&
+                            in_bytes + out_bytes <= SMALL_LIMIT ? small_stage() : nullptr;
+            if (S) {
+                const size_t p1 = S->put(indptr1, pb), j1 = S->put(indices1, 4 * (size_t)nnz1), x1 = S->put(values1, vb * (size_t)nnz1);
+                const size_t p2 = S->put(indptr2, pb), j2 = S->put(indices2, 4 * (size_t)nnz2), x2 = S->put(values2, vb * (size_t)nnz2);
+                const size_t in_end = S->top, po = S->take(pb), jo = S->take(4 * (size_t)bound_s), xo = S->take(vb * (size_t)bound_s), out_end = S->top;
+                const size_t ws = S->take(mxd_merge_workspace_bytes(nrows));
+                if (S->fits()) {
+                    if ((rc = S->up(in_end))) break;
+                    if ((rc = mxd_csr_merge_count(op, nrows, S->dev<int32_t>(p1), S->dev<int32_t>(j1), nnz1, S->dev<int32_t>(p2), S->dev<int32_t>(j2),
+                                                  nnz2, S->dev<int32_t>(po), S->dev<void>(ws), nullptr, S->st))) break;
+                    if ((rc = mxd_csr_merge_fill(op, nrows, S->dev<int32_t>(p1), S->dev<int32_t>(j1), S->dev<void>(x1), nnz1, S->dev<int32_t>(p2),
+                                                 S->dev<int32_t>(j2), S->dev<void>(x2), nnz2, S->dev<int32_t>(po), S->dev<int32_t>(jo),
+                                                 S->dev<void>(xo), S->st))) break;
+                    if ((rc = S->down_and_wait(po, out_end))) break;
+                    const int64_t nnz_s = ((const int32_t *)(S->h + po))[nrows];
+                    res->host.resize(pb + (4 + vb) * (size_t)nnz_s);
+                    res->host_indices = pb; res->host_values = pb + 4 * (size_t)nnz_s;
+                    memcpy(res->host.data(), S->h + po, pb);
+                    memcpy(res->host.data() + res->host_indices, S->h + jo, 4 * (size_t)nnz_s);
+                    memcpy(res->host.data() + res->host_values, S->h + xo, vb * (size_t)nnz_s);
+                    res->on_host = true;
+                    res->info.indptr_len = (int64_t)nrows + 1;
+                    res->info.nnz = nnz_s;
+                    res->info.values_len = nnz_s;
+                    g_small_calls++;
+                    break;
+                }
+            }
+        }
         Csr A, B;
         if ((rc = A.upload(indptr1, indices1, values1, nrows, vb))) break;
         if ((rc = B.upload(indptr2, indices2, values2, nrows, vb))) break;
@@ -1376,6 +1507,55 @@ int mx_copy_csr_rows_begin(const int32_t *indptr, int nrows, const int32_t *indi
     res->info.alias_structure = 0;
     int rc = 0;
     do {
+        {   // small call (see SmallStage): the one-launch gather into whatever room the block has left; its size arrives
+            // in the pinned word, then exactly the result comes down
+            const int64_t nnz_in = nrows > 0 ? (int64_t)indptr[nrows] - indptr[0] : 0;
+            const size_t pb = 4 * ((size_t)nrows + 1), in_bytes = pb + (4 + vb) * (size_t)nnz_in + 4 * (size_t)n_take, npb = 4 * ((size_t)n_take + 1);
+            SmallStage *S = nrows > 0 && n_take > 0 && indptr[0] == 0 && in_bytes + npb < SMALL_LIMIT ? small_stage() : nullptr;
+            if (S) {
+                const int64_t cap = (int64_t)((SMALL_LIMIT - in_bytes - npb) / (4 + vb)) & ~(int64_t)3;
+                const size_t p0 = S->put(indptr, pb), j0 = S->put(indices, 4 * (size_t)nnz_in), x0 = S->put(values, vb * (size_t)nnz_in);
+                const size_t r0 = S->put(rows_take, 4 * (size_t)n_take), in_end = S->top;
+                const size_t po = S->take(npb), jo = S->take(4 * (size_t)cap), xo = S->take(vb * (size_t)cap);
+                if (S->fits() && cap > 0) {
+                    if ((rc = S->up(in_end))) break;
+                    int64_t nnz_s = 0;
+                    if ((rc = mxd_csr_gather_fused((int)n_take, S->dev<int32_t>(p0), S->dev<int32_t>(j0), vb ? S->dev<void>(x0) : nullptr,
+                                                   S->dev<int32_t>(r0), S->dev<int32_t>(po), S->dev<int32_t>(jo), vb ? S->dev<void>(xo) : nullptr,
+                                                   has_values ? value_dtype : MX_NONE, cap, (double)nnz_in / (double)nrows, nullptr, &nnz_s,
+                                                   S->st))) break;
+                    if (nnz_s <= cap) {
+                        if (nnz_s == 0) {            // slice.cpp:236-240: three EMPTY vectors (even the indptr)
+                            if ((rc = S->down_and_wait(0, 0))) break;
+                            res->on_host = true;
+                            res->info.indptr_len = 0; res->info.nnz = 0; res->info.values_len = 0;
+                            g_small_calls++;
+                            break;
+                        }
+                        // three pieces of exactly the result's size, one wait
+                        if (hipMemcpyAsync(S->h + po, S->d + po, npb, hipMemcpyDeviceToHost, S->st) != hipSuccess ||
+                            hipMemcpyAsync(S->h + jo, S->d + jo, 4 * (size_t)nnz_s, hipMemcpyDeviceToHost, S->st) != hipSuccess ||
+                            (vb && hipMemcpyAsync(S->h + xo, S->d + xo, vb * (size_t)nnz_s, hipMemcpyDeviceToHost, S->st) != hipSuccess)) {
+                            rc = set_error("small gather: D2H copy failed"); break;
+                        }
+                        if ((rc = S->down_and_wait(0, 0))) break;
+                        res->host.resize(npb + (4 + vb) * (size_t)nnz_s);
+                        res->host_indices = npb; res->host_values = npb + 4 * (size_t)nnz_s;
+                        memcpy(res->host.data(), S->h + po, npb);
+                        memcpy(res->host.data() + res->host_indices, S->h + jo, 4 * (size_t)nnz_s);
+                        if (vb) memcpy(res->host.data() + res->host_values, S->h + xo, vb * (size_t)nnz_s);
+                        res->on_host = true;
+                        res->info.indptr_len = n_take + 1;
+                        res->info.nnz = nnz_s;
+                        res->info.values_len = has_values ? nnz_s : 0;
+                        if (!has_values) res->info.values_dtype = MX_NONE;
+                        g_small_calls++;
+                        break;
+                    }
+                    if (hipStreamSynchronize(S->st) != hipSuccess) { rc = set_error("stream sync failed"); break; }   // does not fit: the regular path
+                }
+            }
+        }
         Csr A;
         if ((rc = A.upload(indptr, indices, values, nrows, vb))) break;
         DevBuf rows;
@@ -1891,6 +2071,15 @@ int mx_result_finish(mx_result *res, int32_t *out_indptr, int32_t *out_indices, 
 {
     MX_REQUIRE(res, "mx_result_finish: null handle");
     int rc = 0;
+    if (res->on_host) {                                           // a small call: plain copies out of the handle
+        const mx_result_info &inf = res->info;
+        const size_t vbh = dtype_bytes(inf.values_dtype);
+        if (inf.indptr_len > 0 && out_indptr) memcpy(out_indptr, res->host.data(), sizeof(int32_t) * (size_t)inf.indptr_len);
+        if (inf.nnz > 0 && out_indices) memcpy(out_indices, res->host.data() + res->host_indices, sizeof(int32_t) * (size_t)inf.nnz);
+        if (vbh && inf.values_len > 0 && out_values) memcpy(out_values, res->host.data() + res->host_values, vbh * (size_t)inf.values_len);
+        delete res;
+        return 0;
+    }
     do {
         const mx_result_info &inf = res->info;
         if (!inf.alias_structure) {

@@ -272,6 +272,8 @@ struct GatherState {
     size_t cap_tiles = 0;
     unsigned ticket_base = 0, gen = 0;
     unsigned long long *host_word = nullptr;
+    hipStream_t last_stream = nullptr;       // the stream of the previous launch (a caller that switches streams)
+    bool launched = false;
 };
 static GatherState *gather_state(int ntiles, hipStream_t st)
 {
@@ -628,6 +630,14 @@ extern "C" int mxd_csr_gather_fused(int r, const int32_t *indptr, const int32_t 
     const int ntiles = (int)mx::ceil_div(r, mx::GF_TILE);
     mx::GatherState *g = mx::gather_state(ntiles, st);
     MX_REQUIRE(g, "mxd_csr_gather_fused: cannot allocate the look-back state");
+    // One launch at a time uses the state.  A call returns only after the LAST tile (in ticket order) has published the
+    // total — every ticket of that launch is then taken and every state word written, so the next launch's tickets
+    // (ticket_base + ...) and generation cannot mix with it even while its copy phase still runs.  The one exit that
+    // returns earlier is an error; and a caller may come back on ANOTHER stream (a torch stream switch): wait for the
+    // previous stream then, so that the state is never shared by two launches in flight.
+    if (g->launched && g->last_stream != st) MX_HIP(hipStreamSynchronize(g->last_stream));
+    g->last_stream = st;
+    g->launched = true;
     g->gen = (g->gen + 1) & 0x3FFFFFFFu;
     if (g->gen == 0) g->gen = 1;
     const unsigned gen = g->gen, ticket_base = g->ticket_base;

@@ -522,14 +522,20 @@ def test_r_allocation_failure_longjumps_with_the_device_handle_released(R, gpu, 
     ("cannot allocate vector of size ...").  The handle must be discarded by the R_ExecWithCleanup handler: the count of
     device blocks handed out (mx_get_option("pool_live_blocks")) is what it was, the protect stack is balanced, nothing is
     left on the R_PreserveObject list (rmock.call asserts the last two)."""
-    p, j, x, p2, j2, x2 = (mats[k] for k in ("p", "j", "x", "p2", "j2", "x2"))
+    # operands of ~1 MB each: the regular path, whose results wait in pooled device blocks between begin and finish (the
+    # small path of calls under 512 KiB keeps its result in the handle itself and is covered by the second half below)
+    p, j, x = rand_csr(4000, 3000, 0.007, seed=21)
+    p2, j2, x2 = rand_csr(4000, 3000, 0.007, seed=22)
+    assert 12 * j.size + 12 * j2.size > (1 << 20)
     sp, sj, sx, sp2, sj2, sx2 = R.integer(p), R.integer(j), R.real(x), R.integer(p2), R.integer(j2), R.real(x2)
     rows = R.integer(np.array([4, 4, 9], dtype=np.int32))
     call(R, "add_csr_elemwise", sp, sp2, sj, sj2, sx, sx2, R.logical([0]))           # warm: cache entries, scratch
     call(R, "copy_csr_rows_numeric", sp, sj, sx, rows)
     base = _live_blocks(gpu)
     hit = 0
-    for name, args in (("add_csr_elemwise", (sp, sp2, sj, sj2, sx, sx2, R.logical([0]))), ("copy_csr_rows_numeric", (sp, sj, sx, rows))):
+    small = tuple(R.integer(mats[k]) if k[0] in "pj" else R.real(mats[k]) for k in ("p", "p2", "j", "j2", "x", "x2"))
+    for name, args in (("add_csr_elemwise", (sp, sp2, sj, sj2, sx, sx2, R.logical([0]))), ("copy_csr_rows_numeric", (sp, sj, sx, rows)),
+                       ("add_csr_elemwise", small + (R.logical([0]),)), ("copy_csr_rows_numeric", (small[0], small[2], small[4], rows))):
         for k in range(8):                                        # the k-th R allocation of the call fails
             R.L.rmock_fail_alloc_at(k)
             try:

@@ -99,39 +99,49 @@ class PipelinedRowShardedSpMM:
     Two gathered buffers alternate; `step(B)` computes this rank's block straight into its slot of the next buffer and
     starts the all-gather asynchronously (RCCL on its own stream; on xGMI the exchange is ~10x longer than the product,
     so hiding the product behind it is all there is to gain).  A buffer is handed out again only after its previous
-    all-gather has completed.  `finish()` waits for everything and returns the most recent full C.
-    Equal row blocks only (the block is computed in place inside the gathered buffer)."""
+    all-gather has completed.  `finish()` waits for everything and returns the most recent gathered buffer.
+
+    Row blocks may be RAGGED (nnz_balanced_row_blocks of any matrix, any world size): the gathered buffer then has one
+    SLOT of max(rows) rows per rank — rank r's block is the first rows[r] rows of slot r — so that the exchange stays ONE
+    in-place all-gather of equal pieces (the padding rows, at most the imbalance of the cut, travel with it).  With equal
+    blocks the slots are the blocks and the buffer IS C; otherwise `block(buf, r)` is rank r's rows and `assemble(buf)`
+    the contiguous C (a copy)."""
 
     def __init__(self, sharded: RowShardedSpMM, n: int, dtype, device):
-        assert sharded.equal, "PipelinedRowShardedSpMM needs equal row blocks"
         self.s = sharded
-        m_total = sum(sharded.rows)
-        self.bufs = [torch.empty((m_total, n), dtype=dtype, device=device) for _ in range(2)]
+        self.slot = sharded.max_rows
+        self.bufs = [torch.empty((sharded.world * self.slot, n), dtype=dtype, device=device) for _ in range(2)]
         self.pending = [None, None]
         self.k = 0
+
+    def block(self, buf: torch.Tensor, r: int) -> torch.Tensor:
+        return buf[r * self.slot: r * self.slot + self.s.rows[r]]
+
+    def assemble(self, buf: torch.Tensor) -> torch.Tensor:
+        return buf if self.s.equal else torch.cat([self.block(buf, r) for r in range(self.s.world)], dim=0)
 
     def _wait(self, i):
         w = self.pending[i]
         if w is not None:
             w.wait()                     # NCCL: the current stream waits, the host does not; gloo: blocks the host
             if not self.bufs[i].is_cuda:
-                _copy_back(self.bufs[i], self._chunks[i], self.s.rows)
+                _copy_back(self.bufs[i], self._chunks[i], [self.slot] * self.s.world)
             self.pending[i] = None
 
     def step(self, B: torch.Tensor) -> int:
         i = self.k % 2
         self._wait(i)
         out = self.bufs[i]
-        r0, r1 = self.s.row_blocks[self.s.rank]
-        mine = out[r0:r1]
-        self.s.spmm_local(self.s.local_A, B, mine)
+        rk = self.s.rank
+        mine = out[rk * self.slot:(rk + 1) * self.slot]              # my whole slot travels
+        self.s.spmm_local(self.s.local_A, B, mine[: self.s.rows[rk]])
         if self.s.world > 1 or ALWAYS_COLLECTIVE:
             if out.is_cuda:
                 self.pending[i] = dist.all_gather_into_tensor(out, mine, group=self.s.group, async_op=True)
             else:
                 if not hasattr(self, "_chunks"):
                     self._chunks = [None, None]
-                self._chunks[i] = list(torch.split(out, self.s.rows, dim=0))
+                self._chunks[i] = list(torch.split(out, self.slot, dim=0))
                 self.pending[i] = dist.all_gather(self._chunks[i], mine.clone(), group=self.s.group, async_op=True)
         self.k += 1
         return i

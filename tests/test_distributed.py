@@ -54,16 +54,20 @@ def _worker(rank, world, port, m, K, n, balanced, q):
         full = np.zeros(m * n)
         O.gemm_csr_drm_as_drm(m, n, p, j, x, B.reshape(-1), n, full, n, 1, False)
         ok = np.array_equal(C, full.reshape(m, n))
-        if balanced:
-            # a stream of products with the all-gather of one running under the next: every product must come out right
-            pipe = MD.PipelinedRowShardedSpMM(op, n, torch.float64, "cpu")
-            for k in range(5):
-                Bk = torch.from_numpy(B * 2.0 ** k)                  # powers of two: the products scale exactly
-                i = pipe.step(Bk)
-                if k >= 1:                                           # the other buffer holds product k - 1 once waited for
-                    pipe._wait(1 - i)
-                    ok = ok and np.array_equal(pipe.bufs[1 - i].numpy(), full.reshape(m, n) * 2.0 ** (k - 1))
-            ok = ok and np.array_equal(pipe.finish().numpy(), full.reshape(m, n) * 2.0 ** 4)
+        # a stream of products with the all-gather of one running under the next: every product must come out right —
+        # equal blocks (the gathered buffer IS C) and ragged ones (one slot of max(rows) rows per rank, assembled on request)
+        pipe = MD.PipelinedRowShardedSpMM(op, n, torch.float64, "cpu")
+        assert pipe.bufs[0].shape[0] == world * max(b - a for a, b in blocks)
+        for k in range(5):
+            Bk = torch.from_numpy(B * 2.0 ** k)                  # powers of two: the products scale exactly
+            i = pipe.step(Bk)
+            if k >= 1:                                           # the other buffer holds product k - 1 once waited for
+                pipe._wait(1 - i)
+                ok = ok and np.array_equal(pipe.assemble(pipe.bufs[1 - i]).numpy(), full.reshape(m, n) * 2.0 ** (k - 1))
+        last = pipe.finish()
+        ok = ok and np.array_equal(pipe.assemble(last).numpy(), full.reshape(m, n) * 2.0 ** 4)
+        for rk, (a, b) in enumerate(blocks):                     # every rank's rows sit at the start of its slot
+            ok = ok and np.array_equal(pipe.block(last, rk).numpy(), full.reshape(m, n)[a:b] * 2.0 ** 4)
         q.put((rank, bool(ok), blocks))
     finally:
         dist.destroy_process_group()

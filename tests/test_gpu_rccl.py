@@ -37,3 +37,17 @@ def test_bench_distributed_path_one_rank(gpu, overlap):
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert "allgather" in d and d["allgather"]["bytes_received_per_gpu"] == 0      # (world - 1) blocks arrive
     assert d["parity_max_err_over_max_abs_vs_oracle"] <= 2e-5
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_path_one_rank(gpu):
+    """--scaling strong: --rows is the WHOLE matrix (64 device-drawn row chunks, the same matrix whatever N is), cut into
+    nnz-balanced row blocks; the line says so and carries what the driver needs to check "N ranks" (world size, the
+    number of ranks seen by an RCCL all-reduce of ones, the row blocks)."""
+    d = run_bench({"MXGPU_BENCH_OVERLAP": "1"}, "--scaling", "strong", "--rows", "131072", "--cols", "30000", "--nnz-row", "24", "--n", "128",
+                  "--dtype", "f32")
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["value"] > 0
+    dd = d["distributed"]
+    assert dd["world_size"] == 1 and dd["ranks_in_an_rccl_all_reduce_of_ones"] == 1 and dd["backend"] == "nccl"
+    assert dd["rows_total"] == 131072 and sum(dd["row_blocks"]) == 131072
+    assert d["parity_max_err_over_max_abs_vs_oracle"] <= 2e-5

@@ -16,6 +16,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import prof_common as PC  # noqa: E402
+
 
 def pmc(dirname, kernel_sub):
     acc = collections.defaultdict(list)
@@ -45,12 +48,27 @@ def main():
                         r["MinNs"], r["MaxNs"]])
     counters, counts = pmc(src, ksub)
     out = {"kernel_substring": ksub, "workload": sys.argv[4] if len(sys.argv) > 4 else "cfg2-default",
+           "source_blobs": PC.source_blobs(),       # bench.py quotes the counters only while the kernel's files still hash to these
            "counters_avg_per_launch": counters, "launches_sampled": counts}
     k = [r for r in rows if ksub in r["Name"]]
     if k:
         out["kernel"] = k[0]["Name"][:200]
         out["avg_ns"] = float(k[0]["AverageNs"])
         out["calls"] = int(k[0]["Calls"])
+    # the launches of ONE grid size (one workload) when the command ran the kernel on several: the group with the most time
+    traces = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")), key=os.path.getmtime, reverse=True)
+    if traces:
+        groups, _ = PC.dispatch_groups(traces[0], [ksub])
+        g = groups[ksub]
+        if g:
+            main_g = max(g, key=lambda q: sum(g[q]))
+            out["grid_size"] = main_g
+            out["avg_ns"] = sum(g[main_g]) / len(g[main_g])
+            out["calls"] = len(g[main_g])
+            cg = PC.counter_groups(src, [ksub])[ksub].get(main_g, {})
+            if cg:
+                counters = {n: sum(v) / len(v) for n, v in cg.items()}
+                out["counters_avg_per_launch"] = counters
     if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
         fetch = counters["FETCH_SIZE"] * 1024.0
         write = counters["WRITE_SIZE"] * 1024.0

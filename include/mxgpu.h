@@ -108,7 +108,7 @@ int  mx_cache_stats(int64_t *bytes, int *entries, int64_t *hits, int64_t *misses
  *   "spmv_planned_calls"  read-only: export-level products served by the planned kernel so far
  *   "pool_idle_bytes" / "pool_idle_blocks" / "pool_hits" / "pool_misses"  read-only: the export level's device blocks
  *                  (operands, results, kept plans) go back to a pool instead of hipFree — capped at MXGPU_POOL_MB, default
- *                  min(8 GiB, 1/16 of the device; 0 = every block is freed at once) — and mxd_release_workspaces() or a
+ *                  min(32 GiB, 1/8 of the device; 0 = every block is freed at once) — and mxd_release_workspaces() or a
  *                  failed allocation gives them back to the device (csrc/pool.hip: why)
  *   "small_calls"  read-only: export-level calls served by the small path — operands + result within 512 KiB (SpMM, SpMV,
  *                  CSR (+) CSR, X[rows, ]): every input packed into one pinned block, one copy up, the same kernels, one copy

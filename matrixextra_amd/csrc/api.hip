@@ -12,6 +12,8 @@
 #include <cstring>
 #include <memory>
 #include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -460,7 +462,7 @@ struct Pin {
         return ok;
     }
     // a page-aligned piece of a buffer that is registered piece by piece (the pieces must not share pages)
-    bool pin_pages(const void *ptr, size_t nbytes) { ok = mx::pin_host(ptr, nbytes, false); p = ptr; bytes = nbytes; return ok; }
+    bool pin_pages(const void *ptr, size_t nbytes, bool all_devices = false) { ok = mx::pin_host(ptr, nbytes, all_devices); p = ptr; bytes = nbytes; return ok; }
     // the whole pages INSIDE a buffer of any size, for every device: what the coordinating thread of a sharded call
     // registers once for an input that all its workers read.  (The workers must not register such a buffer themselves:
     // while one of them unregisters its range another one's hipMemcpy may have just found that range in the runtime's
@@ -575,6 +577,64 @@ static SmallStage *small_stage()
 }
 static std::atomic<long long> g_small_calls{0};                  // mx_get_option("small_calls")
 
+// The shards of a sharded export run on PERSISTENT worker threads, one per entry of the device list, kept between calls
+// with what a thread keeps (its streams and events, AUTO's plan buffers, the library's per-thread scratch).  Rounds 2-3
+// started fresh threads for every call and let them release everything at exit: each call then began with ~2 GB of
+// hipMalloc per shard (serialised in the driver: 20 ms per shard, 190 ms at the head of configs[4] on the first call) and
+// ended with as much hipFree, which the copy engines scrub under whatever comes next (round 4 timeline).
+// mx_set_devices gives the workers' memory back (their threads stay).
+struct ShardPool {
+    struct W {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<void()> job;
+        bool has = false, done = true;
+    };
+    std::vector<std::unique_ptr<W>> ws;
+    std::mutex call_mu;                                          // one sharded call at a time uses the workers
+    void ensure(size_t n)
+    {
+        while (ws.size() < n) {
+            ws.emplace_back(new W());
+            W *w = ws.back().get();
+            w->th = std::thread([w] {
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(w->mu);
+                    w->cv.wait(lk, [&] { return w->has; });
+                    std::function<void()> j = std::move(w->job);
+                    w->has = false;
+                    lk.unlock();
+                    j();
+                    lk.lock();
+                    w->done = true;
+                    w->cv.notify_all();
+                }
+            });
+            w->th.detach();                                      // (lives as long as the process; blocked on its condition variable between calls)
+        }
+    }
+    void start(size_t k, std::function<void()> j)
+    {
+        W &w = *ws[k];
+        { std::lock_guard<std::mutex> lk(w.mu); w.job = std::move(j); w.has = true; w.done = false; }
+        w.cv.notify_all();
+    }
+    void wait(size_t k)
+    {
+        W &w = *ws[k];
+        std::unique_lock<std::mutex> lk(w.mu);
+        w.cv.wait(lk, [&] { return w.done; });
+    }
+    void release_memory()                                        // every worker gives its per-thread device memory back
+    {
+        std::lock_guard<std::mutex> lk(call_mu);
+        for (size_t k = 0; k < ws.size(); k++) start(k, [] { lanes().drain(); mx::release_thread_workspaces(); });
+        for (size_t k = 0; k < ws.size(); k++) wait(k);
+    }
+};
+static ShardPool &shard_pool() { static ShardPool *p = new ShardPool(); return *p; }   // (never destroyed: its threads outlive static teardown)
+
 template <typename real_t>
 static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_rows, const int32_t *indptr,
                            const int32_t *indices, const double *values, const real_t *B_host, size_t ldb, real_t *C_host,
@@ -585,7 +645,32 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
     const int64_t nnz = indptr[m];
     const int dt = sizeof(real_t) == 8 ? MX_F64 : MX_F32;
     Trace tr("spmm export (sharded)");
-    mx::prefault_begin(C_host, c_bytes);
+    // The caller's result is first-touched and registered PIECE BY PIECE (page-aligned cuts of ~96 MiB), and a shard
+    // downloads what lies in a piece as soon as that piece is registered.  Round 3 touched and registered the whole result
+    // before the first byte came down: on one GPU listed 8 times, configs[4] whole took 369-467 ms against 189 ms
+    // unsharded — 77 ms of page work at the head of every shard's download.  A "unit" is what is
+    // contiguous in the caller's matrix — a column of a column-major C, a row of a row-major one; a unit comes down with
+    // the first piece that completes it, so no copy ever touches an unregistered page and no page is registered twice.
+    constexpr int MAX_PIECES = 32;
+    const size_t unit_bytes = (colmajor ? (size_t)m : ldc) * sizeof(real_t);
+    const int64_t n_units = colmajor ? n : m;
+    int np = (int)std::min<size_t>(MAX_PIECES, std::max<size_t>(1, c_bytes / ((size_t)96 << 20)));
+    std::vector<size_t> piece_off(1, 0);
+    for (int g = 1; g < np; g++) {
+        const uintptr_t cutp = ((uintptr_t)C_host + c_bytes / (size_t)np * (size_t)g) & ~(uintptr_t)4095;
+        if (cutp > (uintptr_t)C_host + piece_off.back() && cutp < (uintptr_t)C_host + c_bytes) piece_off.push_back(cutp - (uintptr_t)C_host);
+    }
+    piece_off.push_back(c_bytes);
+    np = (int)piece_off.size() - 1;
+    std::vector<int64_t> ucut((size_t)np + 1, 0);                   // units [ucut[g], ucut[g + 1]) become complete with piece g
+    for (int g = 1; g < np; g++) ucut[g] = std::min<int64_t>(n_units, (int64_t)(piece_off[g] / unit_bytes));
+    ucut[np] = n_units;
+    std::vector<std::pair<void *, size_t>> pcs;
+    for (int g = 0; g < np; g++) pcs.emplace_back((void *)((char *)C_host + piece_off[g]), piece_off[g + 1] - piece_off[g]);
+    std::atomic<int> piece_arrived[MAX_PIECES];
+    for (auto &a : piece_arrived) a.store(0);
+    const int touch_team = mx::prefault_begin_pieces(C_host, c_bytes, pcs, piece_arrived);
+    struct JoinTeam { ~JoinTeam() { mx::prefault_wait(); } } join_team;   // (the team counts into piece_arrived until it is joined)
     std::vector<int> cut((size_t)nd + 1);
     partition_rows(indptr, m, nd, 12.0, (double)n * sizeof(real_t), cut.data());
     // one kernel family for the whole product (see spmm_host); the alignment rules only look at the low bits of the pointers
@@ -593,37 +678,84 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
                                                                    (const void *)(uintptr_t)256, colmajor ? (size_t)m : ldc,
                                                                    colmajor ? 1 : 0) : algo;
     // host memory registered for every device; `gate` opens once the result is registered (downloads wait for it)
-    Pin pinB, pinJ, pinX, pinC;
+    Pin pinB, pinJ, pinX;
+    std::vector<Pin> pinC((size_t)np);
     // (large arrays as a whole, smaller ones by their interior pages; what cannot be registered goes up by plain copies)
     if (!pinB.pin(B_host, b_bytes, true)) pinB.pin_inside(B_host, b_bytes);
     if (!pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz, true)) pinJ.pin_inside(indices, sizeof(int32_t) * (size_t)nnz);
     if (!pinX.pin(values, sizeof(double) * (size_t)nnz, true)) pinX.pin_inside(values, sizeof(double) * (size_t)nnz);
     std::mutex gate_mu;
     std::condition_variable gate_cv;
-    int gate = 0;                                                // 0 closed, 1 result registered, -1 registration failed
+    int gate = 0;                                                // pieces registered so far; -1: a registration failed
     std::vector<std::string> errors((size_t)nd);
+    // B goes up ONCE per distinct device (a device may be listed several times — its shards share the GPU): the first shard
+    // of a device to get there uploads it, the others wait for that upload's event
+    struct SharedB { std::once_flag once; DevBuf buf; hipEvent_t ev = nullptr; bool ok = false; };
+    std::vector<int> distinct;
+    std::vector<int> dev_slot((size_t)nd);
+    for (int k = 0; k < nd; k++) {
+        size_t at = std::find(distinct.begin(), distinct.end(), devs[k]) - distinct.begin();
+        if (at == distinct.size()) distinct.push_back(devs[k]);
+        dev_slot[k] = (int)at;
+    }
+    std::vector<std::unique_ptr<SharedB>> shared_b;
+    for (size_t q = 0; q < distinct.size(); q++) shared_b.emplace_back(new SharedB());
+    // every shard first allocates and copies its (small) index pointer, THEN all of them start their bulk uploads: a 4 MB
+    // copy queued behind the other shards' gigabytes waited up to 160 ms for its turn on the copy engines
+    int n_active = 0;
+    for (int k = 0; k < nd; k++) n_active += cut[k + 1] > cut[k];
+    std::mutex start_mu;
+    std::condition_variable start_cv;
+    int arrived_shards = 0;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto at_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     auto shard = [&](int k) {
         auto failed = [&](const char *what) { errors[k] = std::string(what) + ": " + mx_last_error(); };
+        auto note = [&](const char *what) { if (tr.on) fprintf(stderr, "[mxgpu] shard %d %-18s at %8.2f ms\n", k, what, at_ms()); };
+        note("start");
         if (hipSetDevice(devs[k]) != hipSuccess) { errors[k] = "hipSetDevice failed"; return; }
         const int r_lo = cut[k], r_hi = cut[k + 1], mk = r_hi - r_lo;
         if (mk == 0) return;
         const int64_t e_lo = indptr[r_lo], e_hi = indptr[r_hi];
-        Lanes L;                                                 // this worker thread's queues, gone with it
+        Lanes &L = lanes();                                      // this worker thread's queues: kept, like the thread
         const int nblk = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)mk * n * (int64_t)sizeof(real_t) / ((int64_t)96 << 20)));
-        struct Drain { Lanes &l; ~Drain() { l.drain(); l.destroy(); mx::release_thread_workspaces(); } } drain{L};   // (the thread ends: its scratch with it; pooled blocks stay)
+        struct Drain { Lanes &l; ~Drain() { l.drain(); } } drain{L};   // (every exit: nothing of this call is left in the queues)
         if (L.init(2 * (size_t)nblk + 2)) { failed("streams"); return; }
         // the shard's own CSR arrays (indptr rebased on the host: mk + 1 ints), B, and its rows of C (column-major mk x n, or
         // row-major)
-        DevBuf dp, dj, dx, dB, dC;
+        DevBuf dp, dj, dx, dC;
+        struct Arrive {                                          // counted once on every path (a failing shard must not hold the others)
+            std::mutex &mu; std::condition_variable &cv; int &count; bool done = false;
+            void now() { if (!done) { { std::lock_guard<std::mutex> lk(mu); count++; } cv.notify_all(); done = true; } }
+            ~Arrive() { now(); }
+        } arrive{start_mu, start_cv, arrived_shards};
         std::vector<int32_t> p_local((size_t)mk + 1);
         for (int r = 0; r <= mk; r++) p_local[r] = (int32_t)(indptr[r_lo + r] - e_lo);
-        if (dp.upload(p_local.data(), sizeof(int32_t) * ((size_t)mk + 1)) || dj.alloc(sizeof(int32_t) * (size_t)(e_hi - e_lo)) ||
-            dx.alloc(sizeof(double) * (size_t)(e_hi - e_lo)) || dB.alloc(b_bytes) || dC.alloc(sizeof(real_t) * (size_t)mk * n)) {
+        // (a plain copy: the transfer engine of xfer.hip is one per process and busy first-touching the result right now —
+        // going through it cost every shard ~18 ms, one after the other)
+        if (dp.alloc(sizeof(int32_t) * ((size_t)mk + 1)) ||
+            hipMemcpy(dp.p, p_local.data(), sizeof(int32_t) * ((size_t)mk + 1), hipMemcpyHostToDevice) != hipSuccess || dj.alloc(sizeof(int32_t) * (size_t)(e_hi - e_lo)) ||
+            dx.alloc(sizeof(double) * (size_t)(e_hi - e_lo)) || dC.alloc(sizeof(real_t) * (size_t)mk * n)) {
             failed("device allocation");
             return;
         }
         const size_t ldc_k = colmajor ? (size_t)mk : ldc;
-        bool ok = upload_through(pinB, dB.p, B_host, b_bytes, L.up);
+        note("allocated");
+        arrive.now();
+        {
+            std::unique_lock<std::mutex> lk(start_mu);
+            start_cv.wait(lk, [&] { return arrived_shards >= n_active; });
+        }
+        SharedB &sb = *shared_b[(size_t)dev_slot[k]];
+        std::call_once(sb.once, [&] {
+            if (sb.buf.alloc(b_bytes) || hipEventCreateWithFlags(&sb.ev, hipEventDisableTiming) != hipSuccess) return;
+            sb.ok = upload_through(pinB, sb.buf.p, B_host, b_bytes, L.up) && hipEventRecord(sb.ev, L.up) == hipSuccess;
+        });
+        if (!sb.ok) { failed("upload of B"); return; }
+        (void)hipStreamWaitEvent(L.run, sb.ev, 0);
+        DevBuf dB;
+        dB.alias(sb.buf.p, b_bytes);
+        bool ok = true;
         std::vector<int> bc((size_t)nblk + 1);
         for (int b = 0; b <= nblk; b++) bc[b] = b == nblk ? mk : (int)((int64_t)mk * b / nblk) & ~1023;   // whole generations of the planned kernel
         for (int b = 0; b < nblk && ok; b++) {
@@ -635,6 +767,53 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
             ok = ok && hipEventRecord(L.ev[b], L.up) == hipSuccess;
         }
         if (!ok) { errors[k] = "upload failed"; return; }
+        note("uploads queued");
+        // downloads of block b for piece g: queued as soon as BOTH exist — right behind the block's product for the pieces
+        // registered by then (queueing a product can hold this thread until the block's CSR slice has arrived: the plan is
+        // sized on the host), the rest when their pieces open.  issued[b] = pieces already queued for block b.
+        std::vector<int> issued((size_t)nblk, 0);
+        auto copy_run = [&](size_t off, const char *src, size_t bytes) {   // one contiguous run, cut at the piece boundaries it crosses
+            while (bytes && ok) {
+                size_t seg = bytes;
+                for (int q = 1; q < np; q++)
+                    if (piece_off[q] > off && piece_off[q] < off + bytes) { seg = piece_off[q] - off; break; }
+                ok = hipMemcpyAsync((char *)C_host + off, src, seg, hipMemcpyDeviceToHost, L.down) == hipSuccess;
+                off += seg; src += seg; bytes -= seg;
+            }
+        };
+        auto download = [&](int b, int g) {
+            const int r0 = bc[b], r1 = bc[b + 1];
+            const int64_t u0 = ucut[g], u1 = ucut[g + 1];
+            if (r1 == r0 || u1 <= u0) return;
+            if (colmajor) {                                      // rows of block b x columns [u0, u1)
+                int64_t uf = u0;                                 // columns whose run starts before this piece: one by one
+                while (uf < u1 && ((size_t)uf * ldc + r_lo + r0) * sizeof(real_t) < piece_off[g]) {
+                    copy_run(((size_t)uf * ldc + r_lo + r0) * sizeof(real_t), (const char *)(dC.as<real_t>() + (size_t)uf * ldc_k + r0),
+                             (size_t)(r1 - r0) * sizeof(real_t));
+                    uf++;
+                }
+                if (ok && uf < u1)
+                    ok = hipMemcpy2DAsync(C_host + (size_t)uf * ldc + r_lo + r0, ldc * sizeof(real_t),
+                                          dC.as<real_t>() + (size_t)uf * ldc_k + r0, ldc_k * sizeof(real_t),
+                                          (size_t)(r1 - r0) * sizeof(real_t), (size_t)(u1 - uf), hipMemcpyDeviceToHost, L.down) == hipSuccess;
+            } else {                                             // the rows of block b among rows [u0, u1)
+                const int64_t a0 = std::max<int64_t>(u0, (int64_t)r_lo + r0), a1 = std::min<int64_t>(u1, (int64_t)r_lo + r1);
+                if (a1 > a0)
+                    copy_run((size_t)a0 * ldc * sizeof(real_t), (const char *)(dC.as<real_t>() + (size_t)(a0 - r_lo) * ldc_k),
+                             (size_t)(a1 - a0) * ldc * sizeof(real_t));
+            }
+        };
+        auto download_open_pieces = [&](int upto_block) {        // non-blocking: whatever is registered by now
+            int open;
+            { std::lock_guard<std::mutex> lk(gate_mu); open = gate; }
+            if (open <= 0) return;
+            for (int b = 0; b <= upto_block && ok; b++) {
+                if (issued[b] >= open) continue;
+                (void)hipStreamWaitEvent(L.down, L.ev[nblk + b], 0);
+                for (int g = issued[b]; g < open && ok; g++) download(b, g);
+                issued[b] = open;
+            }
+        };
         for (int b = 0; b < nblk; b++) {
             const int r0 = bc[b], r1 = bc[b + 1];
             if (r1 == r0) continue;
@@ -650,38 +829,51 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
                 return;
             }
             (void)hipEventRecord(L.ev[nblk + b], L.run);
+            download_open_pieces(b);
         }
-        {                                                        // downloads need the result registered
-            std::unique_lock<std::mutex> lk(gate_mu);
-            gate_cv.wait(lk, [&] { return gate != 0; });
-            if (gate < 0) { errors[k] = "result not registered"; return; }
-        }
-        for (int b = 0; b < nblk && ok; b++) {
-            const int r0 = bc[b], r1 = bc[b + 1];
-            if (r1 == r0) continue;
-            (void)hipStreamWaitEvent(L.down, L.ev[nblk + b], 0);
-            if (colmajor)
-                ok = hipMemcpy2DAsync(C_host + r_lo + r0, ldc * sizeof(real_t), dC.as<real_t>() + r0, ldc_k * sizeof(real_t),
-                                      (size_t)(r1 - r0) * sizeof(real_t), n, hipMemcpyDeviceToHost, L.down) == hipSuccess;
-            else
-                ok = hipMemcpyAsync(C_host + (size_t)(r_lo + r0) * ldc, dC.as<real_t>() + (size_t)r0 * ldc_k,
-                                    (size_t)(r1 - r0) * ldc * sizeof(real_t), hipMemcpyDeviceToHost, L.down) == hipSuccess;
+        note("products queued");
+        for (int g = 0; g < np && ok; g++) {                     // the pieces that were not open yet: wait for each, queue what is left
+            {
+                std::unique_lock<std::mutex> lk(gate_mu);
+                gate_cv.wait(lk, [&] { return gate < 0 || gate > g; });
+                if (gate < 0) { errors[k] = "result not registered"; return; }
+            }
+            for (int b = 0; b < nblk && ok; b++) {
+                if (issued[b] > g || bc[b + 1] == bc[b]) continue;
+                (void)hipStreamWaitEvent(L.down, L.ev[nblk + b], 0);
+                download(b, g);
+                issued[b] = g + 1;
+            }
         }
         if (!ok) { errors[k] = "download failed"; return; }
+        note("downloads queued");
         L.drain();
+        note("drained");
     };
     int dev0 = 0;
     (void)hipGetDevice(&dev0);
-    std::vector<std::thread> workers;
-    for (int k = 0; k < nd; k++) workers.emplace_back(shard, k);
-    mx::prefault_wait();
-    const bool c_ok = pinC.pin(C_host, c_bytes, true);
-    {
-        std::lock_guard<std::mutex> lk(gate_mu);
-        gate = c_ok ? 1 : -1;
+    ShardPool &SP = shard_pool();
+    std::lock_guard<std::mutex> one_call(SP.call_mu);
+    SP.ensure((size_t)nd);
+    for (int k = 0; k < nd; k++) SP.start((size_t)k, [&shard, k] { shard(k); });
+    bool c_ok = true;
+    for (int g = 0; g < np && c_ok; g++) {                       // this thread: register each piece when the team has touched it
+        while (touch_team && piece_arrived[g].load(std::memory_order_acquire) < touch_team) std::this_thread::yield();
+        const double t_touched = at_ms();
+        c_ok = pinC[g].pin_pages((char *)C_host + piece_off[g], piece_off[g + 1] - piece_off[g], true);
+        if (tr.on) fprintf(stderr, "[mxgpu] piece %d/%d touched at %8.2f ms, registered at %8.2f ms\n", g, np, t_touched, at_ms());
+        {
+            std::lock_guard<std::mutex> lk(gate_mu);
+            gate = c_ok ? g + 1 : -1;
+        }
+        gate_cv.notify_all();
     }
-    gate_cv.notify_all();
-    for (auto &w : workers) w.join();
+    for (int k = 0; k < nd; k++) SP.wait((size_t)k);
+    for (size_t q = 0; q < distinct.size(); q++) {               // the shared copies of B go back to the pool of their device
+        (void)hipSetDevice(distinct[q]);
+        if (shared_b[q]->ev) (void)hipEventDestroy(shared_b[q]->ev);
+        shared_b[q].reset();
+    }
     (void)hipSetDevice(dev0);
     tr.mark("shards");
     MX_REQUIRE(c_ok, "sharded spmm export: cannot register the result for direct DMA");
@@ -1188,8 +1380,11 @@ int mx_set_devices(const int *devices, int n)
     MX_HIP(hipGetDeviceCount(&count));
     for (int k = 0; k < n; k++) MX_REQUIRE(devices[k] >= 0 && devices[k] < count, "mx_set_devices: no device %d", devices[k]);
     if (n == 1) MX_HIP(hipSetDevice(devices[0]));                 // one device: it becomes the calling thread's current device
-    std::lock_guard<std::mutex> lk(g_devices_mu);
-    g_devices.assign(devices, devices + n);
+    {
+        std::lock_guard<std::mutex> lk(g_devices_mu);
+        g_devices.assign(devices, devices + n);
+    }
+    shard_pool().release_memory();                                // the shard workers of the previous list give their buffers back
     return 0;
 }
 int mx_partition_rows(const int32_t *indptr, int nrows, int nparts, int dense_cols, int dense_bytes, int *cuts)

@@ -64,7 +64,7 @@ void *scratch_buffer_zeroed(int slot, size_t bytes, hipStream_t st, bool *fresh)
 void scratch_release();
 
 // Device blocks that are freed and allocated again call after call (export-level operands and results, the plans kept on
-// cache entries): pool_free keeps a block (total capped: MXGPU_POOL_MB, default min(8 GiB, 1/16 of the device)) for the
+// cache entries): pool_free keeps a block (total capped: MXGPU_POOL_MB, default min(32 GiB, 1/8 of the device)) for the
 // next pool_malloc of about its size on the same device.  pool_free waits for the device first, like hipFree; a pointer
 // that did not come from pool_malloc is simply hipFree'd.  A pointer from pool_malloc must go back through pool_free.
 // (pool.hip)

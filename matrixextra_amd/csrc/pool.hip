@@ -28,7 +28,7 @@ struct Pool {
     bool cap_known = false;
 };
 Pool &pool() { static Pool *p = new Pool(); return *p; }         // (never destroyed: frees may come after static teardown)
-constexpr size_t POOL_MAX_BLOCKS = 96;
+constexpr size_t POOL_MAX_BLOCKS = 160;
 
 size_t pool_cap_locked(Pool &P)
 {
@@ -36,9 +36,12 @@ size_t pool_cap_locked(Pool &P)
         const char *e = getenv("MXGPU_POOL_MB");
         if (e) P.cap_bytes = (size_t)std::max(0LL, atoll(e)) << 20;
         else {
+            // (round 4: 32 GiB / an eighth of the device; rounds 2-3 kept 8 GiB / a sixteenth, which a sharded export of
+            // configs[4] — 8 shards x 2 GB of operands and result — overran on every call: half of its blocks were
+            // hipFree'd and hipMalloc'ed again, 190 ms of driver work at the head of the next call)
             size_t fr = 0, tot = 0;
-            P.cap_bytes = (size_t)8 << 30;
-            if (hipMemGetInfo(&fr, &tot) == hipSuccess) P.cap_bytes = std::min(P.cap_bytes, tot / 16);
+            P.cap_bytes = (size_t)32 << 30;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess) P.cap_bytes = std::min(P.cap_bytes, tot / 8);
             else (void)hipGetLastError();
         }
         P.cap_known = true;

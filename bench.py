@@ -554,7 +554,13 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
     libc.free.argtypes = [C.c_void_p]
 
     def section(name, fn):
-        """one leg of the extras: a failure is recorded in the line, the other legs (and the headline) still report"""
+        """one leg of the extras: a failure is recorded in the line, the other legs (and the headline) still report.
+        MXGPU_BENCH_EXTRAS_SKIP / _ONLY (comma-separated leg names): tools/make_profiles.sh profiles legs that launch the same
+        kernel on different workloads in separate runs"""
+        skip = [q for q in os.environ.get("MXGPU_BENCH_EXTRAS_SKIP", "").split(",") if q]
+        only = [q for q in os.environ.get("MXGPU_BENCH_EXTRAS_ONLY", "").split(",") if q]
+        if name in skip or (only and name not in only):
+            return
         try:
             fn()
         except Exception as exc:                         # noqa: BLE001 - anything: the JSON line must still come out
@@ -860,13 +866,22 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
         tdev = algos["auto"]["ms"] / 1e3
         bytv = synth.spmm_algorithmic_bytes(mv, Kv, nv, Av.nnz, 8)
         gbv = Av.nnz * nv * 8
+        vig_traffic = {}
+        if algos["auto"]["kernel"] == "spmm_rowsplit_kernel":        # AUTO's launches: the cursor kernel + one launch per column panel
+            import ctypes as C
+            ca, cb, cp = C.c_double(), C.c_double(), C.c_int()
+            _lib.check(lib.mxd_spmm_auto_cost(C.c_int(mv), C.c_int(nv), C.c_int(Kv), C.c_int64(Av.nnz), C.c_int(0), C.c_int(0), C.byref(ca),
+                                              C.byref(cb), C.byref(cp)))
+            ks = [("spmm_rowsplit_kernel<double, 2, 64, false", cp.value)] + ([("rowsplit_cursors_kernel", 1)] if cp.value > 1 else [])
+            vig_traffic = committed_kernels_traffic(ks, tdev * 1e3)
+            vig_traffic["column_panels"] = cp.value
         ev = {"device_ms": algos["auto"]["ms"], "export_ms_median": round(float(np.median(te[2:])) * 1e3, 3),
               # what bounds it: every entry gathers one 800-byte row of B (8 MB, twice an XCD's L2) through the CUs' L1s
               "l2_to_l1_gather": {"bytes_per_launch": int(gbv), "achieved_GBps": round(gbv / tdev / 1e9, 0),
                                   "guide_ceiling_GBps": [16000, 22000], "bare_gather_GBps_round2": 28000},
               "GFLOP/s_device": round(2.0 * Av.nnz * nv / tdev / 1e9, 1),
               "GFLOP/s_export": round(2.0 * Av.nnz * nv / float(np.median(te[2:])) / 1e9, 1),
-              "kernels_ms": algos, "roofline": roofline(bytv, tdev),
+              "kernels_ms": algos, "roofline": roofline(bytv, tdev, **vig_traffic),
               "parity_max_err_over_max_abs_vs_oracle": errv,
               "reference_published": {"ms": 72.74, "GFLOP/s": 13.7, "hardware": "unstated",
                                       "source": "inst/doc/Introducing_MatrixExtra.html:668 (vignette Rmd:247-251) — context only"}}

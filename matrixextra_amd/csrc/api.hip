@@ -175,13 +175,23 @@ struct CsrDev {
     int spmm_plan_K = -1, spmm_plan_panels = 0;
     bool spmm_plan_rejected = false;         // the plan would pad too much: AUTO's row-wave fallback, remembered
     std::mutex plan_mu;
+    // recorded on the builder's stream right after a plan's build kernels were queued: a user on ANOTHER stream (another
+    // thread that finds the entry while the build is still running) makes its stream wait for it
+    hipEvent_t plan_built = nullptr;
+    void mark_plan_built(hipStream_t st)
+    {
+        if (!plan_built && hipEventCreateWithFlags(&plan_built, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); plan_built = nullptr; }
+        if (plan_built) (void)hipEventRecord(plan_built, st);
+        else (void)hipStreamSynchronize(st);                   // (no event to be had: the plan is complete before anyone can see it)
+    }
+    void wait_plan_built(hipStream_t st) { if (plan_built) (void)hipStreamWaitEvent(st, plan_built, 0); }
     void drop_plans()
     {
         if (spmv_plan) mxd_spmv_plan_destroy(spmv_plan);
         if (spmm_plan) mxd_spmm_plan_destroy(spmm_plan);
         spmv_plan = nullptr; spmm_plan = nullptr; spmm_plan_rejected = false;
     }
-    ~CsrDev() { drop_plans(); }
+    ~CsrDev() { drop_plans(); if (plan_built) (void)hipEventDestroy(plan_built); }
     const void *hp = nullptr, *hj = nullptr, *hx = nullptr;
     int m = 0, device = 0;
     int64_t nnz = 0;
@@ -1104,8 +1114,10 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
                 e.spmm_plan = nullptr; e.spmm_plan_rejected = true;
             }
             e.spmm_plan_K = K_rows; e.spmm_plan_panels = npanels;
+            if (e.spmm_plan) e.mark_plan_built(L.run);
             tr.mark(phase);
         }
+        if (e.spmm_plan) e.wait_plan_built(L.run);                   // (a no-op on the stream that built it)
         return e.spmm_plan;
     };
     const bool plans = algo == MX_SPMM_AUTO && family == MX_SPMM_PLANNED;
@@ -1331,8 +1343,10 @@ static int spmv_host(int m, const int32_t *indptr, const int32_t *indices, const
             if (mxd_spmv_plan_create(m, len_y, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), nullptr, &A.hold->spmv_plan))
                 A.hold->spmv_plan = nullptr;                              // (no memory for a plan: the one-shot kernel below)
             A.hold->spmv_plan_K = len_y;
+            if (A.hold->spmv_plan) A.hold->mark_plan_built(nullptr);
         }
         if (A.hold->spmv_plan) {
+            A.hold->wait_plan_built(nullptr);
             if (mxd_spmv_plan_run(A.hold->spmv_plan, v.p, v_dtype, o.p, nullptr)) return 1;
             planned = true;
         }
@@ -2058,6 +2072,12 @@ int mx_multiply_csr_by_dvec_with_NAs_begin(const int32_t *indptr, const int32_t 
     *res_out = nullptr;
     // operators.cpp:2274-2289: ^ / %% need the matrix on the left; the flags' precedence
     if ((powerto || divide || divrest) && !X_is_LHS) return set_error("Internal error. Please file an issue in GitHub.");
+    // %/% with the vector on the left: the reference's unchanged-structure exit would compute `dvec %/% x`
+    // (operators.cpp:2639-2649 -> multiply_csr_by_dvec_no_NAs(..., X_is_LHS)) while the structure-changing exits ignore the
+    // flag; the R side never asks for it (R/operators.R:973 always passes TRUE here).  Refused rather than answered two ways
+    // (ADVICE r3).
+    if (intdiv && !multiply && !X_is_LHS)
+        return set_error("multiply_csr_by_dvec_with_NAs: %%/%% with the vector on the left-hand side is not supported");
     int op;
     if (multiply) op = MX_DV_MULTIPLY;
     else if (powerto) op = MX_DV_POWERTO;

@@ -38,6 +38,8 @@ class DeviceCSR:
     _plan: object = None
     _plan_panels: int = -1
     _plan_ready: bool = True
+    _plan_limited: bool = False            # the kept plan was built under AUTO's padding limit (auto_plan) / without one (plan)
+    _plan_key: tuple = ()                  # (data_ptr, _version) of the three tensors when the kept plan / flags were derived
     _spmv_plan: object = None
 
     def invalidate(self):
@@ -46,30 +48,44 @@ class DeviceCSR:
         lib = _lib.load()
         if self._plan is not None:
             lib.mxd_spmm_plan_destroy(self._plan)
-        self._plan, self._plan_panels, self._plan_ready, self._sorted = None, -1, True, None
+        self._plan, self._plan_panels, self._plan_ready, self._sorted, self._plan_limited = None, -1, True, None, False
         self.drop_spmv_plan()
+
+    def _key(self):
+        """what the kept plans depend on: the tensors' storage and torch's in-place version counters — an `A.values.mul_(2)`
+        or an assignment of another tensor changes it (a kept plan must not outlive the arrays it regroups)"""
+        return tuple((t.data_ptr(), t._version) for t in (self.indptr, self.indices, self.values) if t is not None)
+
+    def _check_unchanged(self):
+        k = self._key()
+        if self._plan_key and self._plan_key != k:
+            self.invalidate()
+        self._plan_key = k
 
     def auto_plan(self, npanels: int = 0):
         """The plan AUTO products keep on the matrix (mxd_spmm_plan_create_auto: AUTO's padding limit applies); None when
-        the plan would pad too much — the caller then runs the row-wave kernel, as AUTO does."""
+        the plan would pad too much — the caller then runs the row-split kernel, as AUTO does.  A plan kept by plan()
+        (no limit) is rebuilt under the limit first; a matrix whose tensors changed since the plan was built gets a new one."""
         lib = _lib.load()
-        if self._plan is None or self._plan_panels != npanels:
+        self._check_unchanged()
+        if self._plan is None or self._plan_panels != npanels or not self._plan_limited:
             handle = self._plan if self._plan is not None else C.c_void_p()
             ready = C.c_int(0)
             check(lib.mxd_spmm_plan_create_auto(C.c_int(self.m), C.c_int(self.K), _dp(self.indptr), _dp(self.indices),
                                                 _dp(self.values), C.c_int(npanels), _stream(), C.byref(handle),
                                                 C.byref(ready)))
-            self._plan, self._plan_panels, self._plan_ready = handle, npanels, bool(ready.value)
+            self._plan, self._plan_panels, self._plan_ready, self._plan_limited = handle, npanels, bool(ready.value), True
         return self._plan if self._plan_ready else None
 
     def plan(self, npanels: int = 0, rebuild: bool = False):
         """Device-resident SpMM plan (mxd_spmm_plan_create); cached per DeviceCSR, buffers re-used on rebuild."""
         lib = _lib.load()
+        self._check_unchanged()
         if self._plan is None or rebuild or self._plan_panels != npanels or not self._plan_ready:
             handle = self._plan if self._plan is not None else C.c_void_p()
             check(lib.mxd_spmm_plan_create(C.c_int(self.m), C.c_int(self.K), _dp(self.indptr), _dp(self.indices),
                                            _dp(self.values), C.c_int(npanels), _stream(), C.byref(handle)))
-            self._plan, self._plan_panels, self._plan_ready = handle, npanels, True
+            self._plan, self._plan_panels, self._plan_ready, self._plan_limited = handle, npanels, True, False
         return self._plan
 
     def plan_info(self):
@@ -80,6 +96,7 @@ class DeviceCSR:
 
     def spmv_plan(self):
         """Planned-SpMV plan (mxd_spmv_plan_create): built on first use, cached on the DeviceCSR."""
+        self._check_unchanged()
         if self._spmv_plan is None:
             handle = C.c_void_p()
             check(_lib.load().mxd_spmv_plan_create(C.c_int(self.m), C.c_int(self.K), _dp(self.indptr), _dp(self.indices),
@@ -103,6 +120,7 @@ class DeviceCSR:
 
     def rows_sorted(self) -> bool:
         """check_is_sorted per row on the device (src/misc.cpp:118-128); cached."""
+        self._check_unchanged()
         if self._sorted is None:
             lib = _lib.load()
             ws = torch.empty(4, dtype=torch.int32, device=self.indptr.device)

@@ -123,7 +123,7 @@ static AutoCost spmm_auto_cost(int m, int n, int K, int64_t nnz, int sz, bool ke
         return 1e6 / (hit / l2_rate + (1.0 - hit) / mall_rate);
     };
     AutoCost c;
-    c.panels = rowsplit_panels(n, K, sz, avg);
+    c.panels = rowsplit_panels(m, n, K, sz, avg);
     const bool one_line = n * sz <= 128;                                       // 8-lane groups: 17 TB/s measured, and a
     const double lanes_rate = one_line ? 17.0 : 28.0;                          // wavefront per row costs half as much
     // every launch after the first reads and rewrites C: free while C lives in the Infinity Cache (m = 1e5, n = 128: 0.1 GB),
@@ -184,7 +184,7 @@ static int run_rowsplit(int m, int n, int K, int64_t nnz, int segments, int pane
     if (segments <= 0 || panels <= 0) {
         if (nnz < 0 && device_nnz(indptr, m, st, &nnz)) return 1;
         const double avg = m > 0 ? (double)nnz / m : 0.0;
-        if (panels <= 0) panels = rowsplit_panels(n, K, sz, avg);
+        if (panels <= 0) panels = rowsplit_panels(m, n, K, sz, avg);
         if (segments <= 0) segments = rowsplit_segments(m, n, sz, avg / panels);
     }
     set_last_spmm_kernel("spmm_rowsplit_kernel");

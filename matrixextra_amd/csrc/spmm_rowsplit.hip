@@ -261,15 +261,18 @@ static int pick_group_rowsplit(int m, int n, int K, int S, int P, const int32_t 
 
 // Column panels (tools/auto_map.py, profiles/r04_auto_map.json): none while an XCD's L2 still holds most of B (5 MB: 80 %
 // of the reads hit, and three launches of a third of each row were SLOWER: 0.156 vs 0.122 ms at m = 1e4, 500 entries per
-// row, n = 64); from 7 MB on, ~2.5 MB of B per panel (the budget of the planned kernel's panels) as long as a row keeps
+// row, n = 64); from 7 MB on, ~3 MB of B per panel (vignette shape, 8 MB: 3 panels 0.182 ms, 4: 0.189, 1: 0.193) as long as a row keeps
 // enough entries per panel to pay for a wavefront of its own: 32 when 32 or 64 lanes own a row of B (m = 1e5, K = 1e4,
 // 128 per row, n = 128: 4 panels 0.576 ms, one 0.971), 64 / 96 with 16- / 8-lane groups, whose load instruction covers 4 / 8
 // entries (n = 16, 32 per panel: 2.36 vs 1.75 ms at m = 1e6)
-int rowsplit_panels(int n, int K, int dense_bytes, double avg_len)
+int rowsplit_panels(int m, int n, int K, int dense_bytes, double avg_len)
 {
     const double b_bytes = (double)K * n * dense_bytes;
     if (b_bytes < 7e6) return 1;
-    int P = (int)((b_bytes + 2.5e6 - 1) / 2.5e6);
+    // a few thousand rows are ONE round of the machine: wavefronts that start together walk their (sorted) rows together
+    // and share the lines they gather without any panel (m = 500, 2000 entries per row: one panel 0.042 ms, three 0.061)
+    if ((long long)m * ((n * dense_bytes + 1023) / 1024) < 4096) return 1;
+    int P = (int)((b_bytes + 3e6 - 1) / 3e6);
     const int row_bytes = n * dense_bytes;
     const double per_panel = row_bytes <= 128 ? 96.0 : (row_bytes <= 256 ? 64.0 : 32.0);
     const int by_len = (int)(avg_len / per_panel);
@@ -278,14 +281,16 @@ int rowsplit_panels(int n, int K, int dense_bytes, double avg_len)
     return P < 1 ? 1 : P;
 }
 
-// segments per row: enough wavefronts for a few rounds of the machine (256 CUs x 32 slots), while a segment keeps at
-// least one full chunk of 64 entries on average (avg_len: entries of a row that ONE launch sees)
+// Segments per row: only when the rows alone cannot fill HALF the machine's wavefront slots (256 CUs x 32), and only while
+// a segment keeps a full chunk of 64 entries.  Splitting costs the LDS combine and the direct store path: measured on the
+// vignette's shape (m = 1e4, 500 per row, n = 100, one panel) S = 1 / 2 / 4 / 8 = 0.193 / 0.220 / 0.282 / 0.285 ms — one
+// wavefront per row wins as soon as there are ~4k rows (tools/rowsplit_sweep.py; round 4's first rule split up to 32k rows)
 int rowsplit_segments(int m, int n, int dense_bytes, double avg_len)
 {
     const int W = 64 * (16 / dense_bytes);
     const long long passes = (n + W - 1) / W;
     int S = 1;
-    while (S < RS_WAVES && (long long)m * S * passes < 4LL * 8192 && avg_len / (2 * S) >= 64.0) S <<= 1;
+    while (S < RS_WAVES && (long long)m * S * passes < 3000 && avg_len / (2 * S) >= 64.0) S <<= 1;
     return S;
 }
 

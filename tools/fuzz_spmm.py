@@ -42,12 +42,26 @@ while time.time() < t_end:
         np.add.at(ref, np.repeat(np.arange(m), lens), x[:, None] * B[j].astype(np.float64))
     colmajor = bool(rng.random() < 0.5)
     tol = 1e-11 if dtype == np.float64 else 5e-4
-    which = rng.choice(["planned", "auto", "rowwave"], p=[0.7, 0.15, 0.15])
+    which = rng.choice(["planned", "auto", "rowwave", "rowsplit"], p=[0.45, 0.1, 0.1, 0.35])
+    if which == "rowsplit" and rng.random() < 0.5 and nnz:          # half of the row-split cases: rows sorted by column (the panel cursors' case)
+        for r in range(m):
+            j[p[r]:p[r + 1]].sort()
+        ref = np.zeros((m, n))
+        np.add.at(ref, np.repeat(np.arange(m), lens), x[:, None] * B[j].astype(np.float64))
     npanels = int(rng.choice([0, 1, 2, 3, 8, 13]))
     try:
         if which == "planned":
             got = spmm_planned_device(p.astype(np.int32), j, x, B, colmajor, npanels=npanels,
                                       wg_per_cu=int(rng.choice([0, 1, 2, 4])), sync_mode=int(rng.choice([-1, 0, 1, 2])))
+        elif which == "rowsplit":                                     # segments x column panels, any operands (odd n: the scalar path)
+            if rng.random() < 0.3:
+                n_odd = int(rng.choice([1, 3, 7, 33, 101]))
+                B = rng.normal(size=(K, n_odd)).round(3).astype(dtype)
+                ref = np.zeros((m, n_odd))
+                if nnz:
+                    np.add.at(ref, np.repeat(np.arange(m), lens), x[:, None] * B[j].astype(np.float64))
+            got = spmm_device(p.astype(np.int32), j, x, B, colmajor, 4, 0, npanels=int(rng.choice([0, 1, 2, 3, 7, 32])),
+                              wg_per_cu=int(rng.choice([0, 1, 2, 4, 8])))
         else:
             got = spmm_device(p.astype(np.int32), j, x, B, colmajor, 0 if which == "auto" else 1, 0)
         np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * 100)

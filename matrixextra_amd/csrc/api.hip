@@ -573,11 +573,24 @@ struct SmallStage {
         return 0;
     }
 };
+static thread_local SmallStage g_small_stages[16];
+// the calling thread's staging blocks go back (mxd_release_workspaces); they come back on the next small call
+void small_stage_release()
+{
+    for (SmallStage &st : g_small_stages) {
+        if (!st.h) { st.tried = false; continue; }
+        (void)hipStreamSynchronize(st.st);
+        (void)hipStreamDestroy(st.st);
+        (void)hipHostFree(st.h);
+        (void)hipFree(st.d);
+        st = SmallStage();
+    }
+}
 static SmallStage *small_stage()
 {
     static const bool on = [] { const char *e = getenv("MXGPU_SMALL_CALLS"); return !e || atoi(e) != 0; }();
     if (!on) return nullptr;
-    static thread_local SmallStage stages[16];
+    SmallStage *stages = g_small_stages;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
     SmallStage &s = stages[dev];

@@ -273,6 +273,7 @@ struct GatherState {
     unsigned ticket_base = 0, gen = 0;
     unsigned long long *host_word = nullptr;
     hipStream_t last_stream = nullptr;       // the stream of the previous launch (a caller that switches streams)
+    hipEvent_t last_done = nullptr;          // recorded behind the previous launch (an event outlives its stream)
     bool launched = false;
 };
 static GatherState *gather_state(int ntiles, hipStream_t st)
@@ -635,7 +636,13 @@ extern "C" int mxd_csr_gather_fused(int r, const int32_t *indptr, const int32_t 
     // (ticket_base + ...) and generation cannot mix with it even while its copy phase still runs.  The one exit that
     // returns earlier is an error; and a caller may come back on ANOTHER stream (a torch stream switch): wait for the
     // previous stream then, so that the state is never shared by two launches in flight.
-    if (g->launched && g->last_stream != st) MX_HIP(hipStreamSynchronize(g->last_stream));
+    // (through an EVENT: the previous stream may be gone by now — the small-call path's stream is destroyed by
+    // mxd_release_workspaces — and synchronising a destroyed stream is a crash, an event recorded on it is not)
+    if (!g->last_done && hipEventCreateWithFlags(&g->last_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g->last_done = nullptr; }
+    if (g->launched && g->last_stream != st) {
+        if (g->last_done) MX_HIP(hipStreamWaitEvent(st, g->last_done, 0));
+        else MX_HIP(hipDeviceSynchronize());
+    }
     g->last_stream = st;
     g->launched = true;
     g->gen = (g->gen + 1) & 0x3FFFFFFFu;
@@ -659,6 +666,7 @@ extern "C" int mxd_csr_gather_fused(int r, const int32_t *indptr, const int32_t 
         default: return mx::set_error("mxd_csr_gather_fused: unsupported value dtype %d", value_dtype);
     }
     if (rc) return rc;
+    if (g->last_done) (void)hipEventRecord(g->last_done, st);
     g->ticket_base = ticket_base + (unsigned)ntiles;                  // (the launch was accepted: its tiles will take their tickets)
     // the size arrives in the pinned word while the copies still run: a short spin, then the ordinary wait for the stream
     volatile unsigned long long *hw = g->host_word;

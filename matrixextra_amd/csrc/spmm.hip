@@ -3,8 +3,9 @@
 // Replaces the two OpenMP loops of the reference:
 //   gemm_csr_drm_as_drm  src/matmul.cpp:118-142  (C row-major)
 //   gemm_csr_drm_as_dcm  src/matmul.cpp:150-185  (C column-major, what R needs)
-// Three kernels, one measured progression: spmm_rowwave.hip (v1, any operands), spmm_slab.hip (v2,
-// opt-in), spmm_plan.hip (v3, what AUTO runs when B outgrows an XCD's L2).
+// Four kernels: spmm_rowwave.hip (v1, any operands: tiny products), spmm_slab.hip (v2: one-slab
+// products of very short rows), spmm_plan.hip (v3: many rows against a wide B), spmm_rowsplit.hip (round 4: few or long
+// rows, narrow B); AUTO chooses with a cost model fitted to a map of 228 shapes (spmm_auto_cost below).
 #include "spmm_common.h"
 #include <algorithm>
 #include <cmath>
@@ -51,12 +52,15 @@ void set_last_spmm_kernel(const char *name) { g_last_spmm_kernel = name; }
 }  // namespace mx
 
 namespace mx {
-// this thread's grow-only scratch (AUTO's plan, the slab-major copy of B, the export scratch); re-created on demand
+void small_stage_release();                  // api.hip: the small-call staging blocks (pinned host + device twin)
+// this thread's grow-only scratch (AUTO's plan, the slab-major copy of B, the export scratch, the small-call blocks);
+// re-created on demand
 void release_thread_workspaces()
 {
     plan_auto_release();
     slab_pack_workspace(0, true);
     scratch_release();
+    small_stage_release();
 }
 }  // namespace mx
 // the calling thread's workspaces and every idle block of the pool (pool.hip) go back to the device

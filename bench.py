@@ -172,8 +172,8 @@ def committed_kernels_traffic(kernels, call_ms):
     from the NEWEST round's multi-kernel PMC summary (profiles/rNN_extras_pmc.json, tools/prof_summary_multi.py: per
     kernel the launches of one workload).  `kernels` = [(name in the summary, launches per call)].  Refused (traffic
     null + `traffic_refused`) when a kernel is missing, when a kernel's source files no longer hash to what the summary
-    recorded, or when the kernels' summed duration in that profile does not fit the call just timed (more than 5 % above
-    it, or under 60 % of it)."""
+    recorded, or when the kernels' summed duration in that profile does not fit the call just timed (more than 30 % above
+    it, or under half of it)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import prof_common as PC
     why = "no multi-kernel summary of the newest round"
@@ -191,7 +191,9 @@ def committed_kernels_traffic(kernels, call_ms):
             why = f"{os.path.relpath(f, ROOT)}: {bad[0][1]}"
             continue
         ns = sum(ks[k]["avg_ns"] * c for k, c in kernels)
-        if not (0.6 * call_ms <= ns / 1e6 <= 1.05 * call_ms):
+        # (the source hashes above are what tells a stale profile; this window only catches a summary of another workload —
+        # kernels of a few microseconds run up to ~20 % slower under the profiler than inside the timed loop)
+        if not (0.5 * call_ms <= ns / 1e6 <= 1.3 * call_ms):
             why = f"{os.path.relpath(f, ROOT)}: kernels {ns / 1e6:.4f} ms there, the call {call_ms:.4f} ms in this run"
             continue
         return {"traffic": int(sum(ks[k]["total_corrected"] * c for k, c in kernels)),

@@ -279,3 +279,57 @@ def test_kernels_at_the_int32_limit(gpu):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "maxnnz_probe.py")], cwd=root, capture_output=True,
                        text=True, timeout=1500)
     assert r.returncode == 0 and "max nnz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_published_workload_full_size(gpu):
+    """The one workload the reference publishes a number for, at its size (vignettes/Introducing_MatrixExtra.Rmd:247-251):
+    dense 100 x 1e4 %*% CSC 1e4 x 1e4, density .05, through the export (matmul_dense_csc_numeric, src/matmul.cpp:188-235) —
+    AUTO = the row-split kernel with column panels — against the WHOLE oracle product (60 ms on the host), 1e-12; and the
+    same kernel at device level for every panel count, bit for bit the storage-order FMA chain (row-major C, one segment)."""
+    from matrixextra_amd import device as D, exports as G
+    m, K, n = 10_000, 10_000, 100
+    p, j, x = synth.csr_fixed(m, K, 500, seed=7)
+    X = np.asfortranarray(synth.dense_normal(n, K, seed=8))            # Y_dense, column-major 100 x 1e4
+    got = G.matmul_dense_csc_numeric(X, p, j, x, 1)
+    assert _lib.load().mxd_spmm_last_kernel() == b"spmm_rowsplit_kernel"
+    ref = O.matmul_dense_csc(X, p, j, x, O.max_threads(), True)        # FMA chain in storage order
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * float(np.abs(ref).max()))
+    A = D.DeviceCSR.from_host(p, j, x, K)
+    B = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()             # K x n row-major
+    for P in (1, 3, 4, 7):
+        C = D.spmm(A, B, colmajor=False, algo=4, npanels=P, wg_per_cu=1).cpu().numpy()     # m x n = t(result)
+        np.testing.assert_array_equal(C, ref.T)
+
+
+def test_rowsplit_panels_mid_size_properties(gpu):
+    """100k x 10k, 128 per row, n = 128, column-major C (the shape where four column panels beat the kept plan):
+    column checksum and linearity over the whole product, sampled rows against the oracle."""
+    from matrixextra_amd import device as D
+    m, K, n = 100_000, 10_000, 128
+    p, j, x = synth.csr_fixed(m, K, 128, seed=3)
+    A = D.DeviceCSR.from_host(p, j, x, K)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    B1 = torch.randn((K, n), dtype=torch.float64, device="cuda", generator=g)
+    B2 = torch.randn((K, n), dtype=torch.float64, device="cuda", generator=g)
+
+    def prod(Bt):
+        out = D.spmm(A, Bt, colmajor=True)                             # AUTO
+        return out.clone()
+    C1 = prod(B1)
+    assert _lib.load().mxd_spmm_last_kernel() == b"spmm_rowsplit_kernel"
+    colsum_A = np.zeros(K)
+    np.add.at(colsum_A, j, x)
+    expect = torch.from_numpy(colsum_A).cuda() @ B1
+    scale = float(expect.abs().max())
+    assert float((C1.sum(dim=0) - expect).abs().max()) <= 1e-9 * scale
+    C12 = prod(B1 + 2.0 * B2)
+    C2 = prod(B2)
+    assert float((C12 - (C1 + 2.0 * C2)).abs().max()) <= 1e-10 * float(C12.abs().max())
+    rows = 256
+    for r0 in (0, m - rows):
+        ref = np.zeros(rows * n)
+        lo, hi = int(p[r0]), int(p[r0 + rows])
+        O.gemm_csr_drm_as_drm(rows, n, (p[r0:r0 + rows + 1] - p[r0]).astype(np.int32), j[lo:hi].copy(), x[lo:hi].copy(),
+                              B1.cpu().numpy().reshape(-1), n, ref, n, 1, True)
+        np.testing.assert_allclose(C1[r0:r0 + rows].cpu().numpy(), ref.reshape(rows, n), rtol=1e-12, atol=1e-11)

@@ -62,6 +62,8 @@ enum { MX_SCRATCH_SPMV_SLICES = 0, MX_SCRATCH_PARTIALS = 1, MX_SCRATCH_EXPORT_B 
 void *scratch_buffer(int slot, size_t bytes);
 void *scratch_buffer_zeroed(int slot, size_t bytes, hipStream_t st, bool *fresh);   // zero-filled when (re)allocated
 void scratch_release();
+void scratch_acquire(int slot, hipStream_t st);     // before queueing work that uses the slot: waits for the previous user when the stream changed
+void scratch_done(int slot, hipStream_t st);        // after queueing it
 
 // Device blocks that are freed and allocated again call after call (export-level operands and results, the plans kept on
 // cache entries): pool_free keeps a block (total capped: MXGPU_POOL_MB, default min(32 GiB, 1/8 of the device)) for the

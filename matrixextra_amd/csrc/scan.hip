@@ -145,8 +145,39 @@ void scan_single_kernel(const int32_t *__restrict__ counts, int64_t n, int32_t *
 }
 
 namespace {
-struct Scratch { void *p = nullptr; size_t cap = 0; };
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;               // recorded behind the last user (scratch_done); an event outlives its stream
+    hipStream_t last = nullptr;
+    bool used = false;
+};
 thread_local Scratch g_scratch[16][MX_SCRATCH_SLOTS];
+Scratch &scratch_slot(int slot)
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) d = 0;
+    return g_scratch[d][slot];
+}
+}
+// A scratch slot is per thread and device, but a thread may come back on ANOTHER stream while the previous user's kernels
+// are still queued (a torch stream switch; ADVICE r3 found this for the gather's look-back state): scratch_acquire makes
+// `st` wait for the previous user when the stream changed, scratch_done marks the end of this user's work on `st`.
+void scratch_acquire(int slot, hipStream_t st)
+{
+    Scratch &w = scratch_slot(slot);
+    if (w.used && w.last != st) {
+        if (w.done) (void)hipStreamWaitEvent(st, w.done, 0);
+        else (void)hipDeviceSynchronize();
+    }
+}
+void scratch_done(int slot, hipStream_t st)
+{
+    Scratch &w = scratch_slot(slot);
+    if (!w.done && hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); w.done = nullptr; }
+    if (w.done) (void)hipEventRecord(w.done, st);
+    w.last = st;
+    w.used = true;
 }
 void *scratch_buffer(int slot, size_t bytes)
 {
@@ -179,7 +210,7 @@ void *scratch_buffer_zeroed(int slot, size_t bytes, hipStream_t st, bool *fresh)
 void scratch_release()
 {
     for (auto &dev : g_scratch)
-        for (auto &w : dev) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.cap = 0; }
+        for (auto &w : dev) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.cap = 0; }     // (hipFree waits for the device: nobody uses it any more)
 }
 
 int read_back_small(void *host_dst, const void *dev_src, size_t bytes, hipStream_t st)

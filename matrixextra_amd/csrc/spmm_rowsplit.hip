@@ -232,8 +232,9 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
         MX_LAUNCH_CHECK();
         return 0;
     }
-    // grow-only per-thread scratch, like AUTO's plan: launches that use it must follow each other on one stream
+    // grow-only per-thread scratch; a caller that comes back on another stream waits for the previous product (scratch_acquire)
     int32_t *cur = (int32_t *)scratch_buffer(MX_SCRATCH_ROWSPLIT, (size_t)(P + 1) * (size_t)m * sizeof(int32_t));
+    scratch_acquire(MX_SCRATCH_ROWSPLIT, stream);
     if (!cur) return set_error("rowsplit_spmm: cannot allocate %zu bytes of panel cursors", (size_t)(P + 1) * (size_t)m * sizeof(int32_t));
     const int panel_cols = (int)ceil_div(K, P);
     kt_begin(stream);
@@ -242,6 +243,7 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
     for (int p = 0; p < P; p++)
         hipLaunchKernelGGL((spmm_rowsplit_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
                            m, n, S, indptr, indices, values, cur + (size_t)p * m, cur + (size_t)(p + 1) * m, p > 0 ? 1 : 0, B, ldb, C, ldc);
+    scratch_done(MX_SCRATCH_ROWSPLIT, stream);
     kt_end(stream);
     MX_LAUNCH_CHECK();
     return 0;

@@ -140,6 +140,7 @@ int spmv_flat_launch(int m, int64_t nnz, const int32_t *indptr, const int32_t *i
     const unsigned grid = (unsigned)(nnz / FL_TARGET + 1);            // slices cover the starts 0 .. nnz (trailing empty rows)
     int32_t *slice_rows = (int32_t *)scratch_buffer(MX_SCRATCH_SPMV_SLICES, ((size_t)grid + 1) * sizeof(int32_t));
     MX_REQUIRE(slice_rows, "spmv: cannot allocate the slice table");
+    scratch_acquire(MX_SCRATCH_SPMV_SLICES, st);                     // (a caller that switched streams waits for the previous product)
     hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)ceil_div((int64_t)m + 1, 256)), dim3(256), 0, st, m, indptr,
                        slice_rows, (int)grid);
 #define MX_FL(KIND)                                                                                         \
@@ -153,6 +154,7 @@ int spmv_flat_launch(int m, int64_t nnz, const int32_t *indptr, const int32_t *i
         default: return set_error("spmv: unsupported vector dtype %d", v_dtype);
     }
 #undef MX_FL
+    scratch_done(MX_SCRATCH_SPMV_SLICES, st);
     MX_LAUNCH_CHECK();
     return 0;
 }

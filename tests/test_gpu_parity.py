@@ -1080,3 +1080,40 @@ def test_matmul_rowvec_by_csc(gpu, ncols, nrows, dens):
             np.testing.assert_array_equal(G.matmul_rowvec_by_cscbin(v, p, j), O.matmul_rowvec_by_cscbin(v, p, j))
         finally:
             _lib.check(lib.mx_set_option(b"spmv_algo", C.c_int64(0)))
+
+
+def test_per_thread_scratch_survives_a_stream_switch(gpu):
+    """One thread, two torch streams, products queued back to back without a host wait in between: the library's per-thread
+    scratch (SpMV slice table, the row-split kernel's panel cursors, the gather's look-back state) is shared by both
+    launches — the second stream must wait for the first user (csrc/scan.hip scratch_acquire / scratch_done)."""
+    import torch
+    from matrixextra_amd import device as D
+    m, K = 200_000, 20_000
+    p, j, x = synth.csr_fixed(m, K, 64, seed=31)
+    p2, j2, x2 = synth.csr_fixed(30_000, K, 300, seed=32)
+    A, A2 = D.DeviceCSR.from_host(p, j, x, K), D.DeviceCSR.from_host(p2, j2, x2, K)
+    v = torch.from_numpy(synth.dense_normal(K, 1, seed=33).reshape(-1)).cuda()
+    B = torch.from_numpy(synth.dense_normal(K, 128, seed=34)).cuda()
+    rows = torch.from_numpy(synth.rows_with_replacement(50_000, m)).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ref_y = D.spmv(A, v, algo=3).clone()
+    ref_y2 = D.spmv(A2, v, algo=3).clone()
+    ref_C = D.spmm(A2, B, colmajor=False, algo=4, npanels=4).clone()
+    ref_g = D.csr_gather_rows(A, rows)
+    ref_g2 = D.csr_gather_rows(A2, rows[:20_000] % 30_000)
+    torch.cuda.synchronize()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            y1 = D.spmv(A, v, algo=3)
+            C1 = D.spmm(A2, B, colmajor=False, algo=4, npanels=4)
+            g1 = D.csr_gather_rows(A, rows)
+        with torch.cuda.stream(s2):
+            y2 = D.spmv(A2, v, algo=3)
+            C2 = D.spmm(A2, B, colmajor=False, algo=4, npanels=2)
+            g2 = D.csr_gather_rows(A2, rows[:20_000] % 30_000)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, ref_y) and torch.equal(y2, ref_y2)
+        assert torch.equal(C1, ref_C) and torch.equal(C2, ref_C)
+        assert torch.equal(g1.indices, ref_g.indices) and torch.equal(g1.indptr, ref_g.indptr)
+        assert torch.equal(g2.indices, ref_g2.indices) and torch.equal(g2.values, ref_g2.values)

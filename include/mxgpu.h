@@ -341,8 +341,10 @@ int mxd_csr_gather_fill(int r, const int32_t *indptr, const int32_t *indices, co
  * `capacity` entries.  new_indptr[r+1] and *nnz_out_host (read back once, behind all the work) are always exact; when
  * *nnz_out_host > capacity the entries beyond the capacity were not copied — allocate exactly and call mxd_csr_gather_fill
  * with the new_indptr this call produced.  avg_row_len (mean entries of a source row, <= 0 unknown) picks the lanes per row.
- * `workspace` is unused (may be NULL): the look-back state is kept by the library per thread and device (one stream per
- * thread and device at a time); its words carry a launch generation, so nothing is cleared between calls.  The size reaches
+ * `workspace` is unused (may be NULL): the look-back state is kept by the library per thread and device; its words carry a
+ * launch generation, so nothing is cleared between calls.  A thread may use any stream and switch streams between calls:
+ * what the library keeps per thread (this state, the SpMV slice table, the row-split kernel's cursors, AUTO's plan, the
+ * packed copy of B) is handed from one stream to the next through an event recorded behind its last user.  The size reaches
  * the host through a pinned word the kernel writes as soon as the last tile knows it: the call returns while the copies may
  * still be running on `stream` (stream order covers every later use of the outputs on the device). */
 int mxd_csr_gather_fused(int r, const int32_t *indptr, const int32_t *indices, const void *values,

@@ -952,6 +952,7 @@ static int plan_run(const mx_spmm_plan *pl, int row0, int m, int n, const real_t
     const int nslabs = (int)ceil_div(n, W);
     const int Kp = K + 1;
     real_t *Bp = nullptr;
+    scratch_acquire(MX_SCRATCH_PACKED_B, st);                        // the packed copy of B is per thread: wait for a sweep on another stream
     if (plan_repack<real_t>(K, n, B, ldb, st, &Bp)) return 1;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -987,6 +988,7 @@ static int plan_run(const mx_spmm_plan *pl, int row0, int m, int n, const real_t
 #undef MX_PLAN_LAUNCH
 #undef MX_PLAN_LAUNCH2
     kt_end(st);
+    scratch_done(MX_SCRATCH_PACKED_B, st);
     MX_LAUNCH_CHECK();
     return 0;
 }
@@ -1090,6 +1092,9 @@ int plan_auto_build(int m, int K, const int32_t *indptr, const int32_t *indices,
     mx_spmm_plan *&pl = g_auto_plan[cur_device()];
     if (!pl) pl = new (std::nothrow) mx_spmm_plan();
     MX_REQUIRE(pl, "out of host memory");
+    // the plan's buffers are reused call after call: a caller that comes back on another stream waits for the sweep that
+    // still reads them (scan.hip scratch_acquire / scratch_done)
+    scratch_acquire(MX_SCRATCH_AUTO_PLAN, st);
     if (plan_build(pl, m, K, indptr, indices, values, npanels, st, max_pad_ratio)) return 1;
     *ready = pl->ready;
     return 0;
@@ -1097,7 +1102,9 @@ int plan_auto_build(int m, int K, const int32_t *indptr, const int32_t *indices,
 
 int plan_auto_run(int n, const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, void *stream)
 {
-    return mxd_spmm_plan_run(g_auto_plan[cur_device()], n, B, ldb, C, ldc, dense_dtype, colmajor, 0, -1, stream);
+    const int rc = mxd_spmm_plan_run(g_auto_plan[cur_device()], n, B, ldb, C, ldc, dense_dtype, colmajor, 0, -1, stream);
+    scratch_done(MX_SCRATCH_AUTO_PLAN, as_stream(stream));
+    return rc;
 }
 
 void plan_auto_release()

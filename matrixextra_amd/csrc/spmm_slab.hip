@@ -307,6 +307,7 @@ static int launch_spmm_slab_rpg(int m, int n, int K, const int32_t *indptr, cons
         const size_t bytes = (size_t)nslabs * (size_t)K * W * sizeof(real_t);
         real_t *Bp = (real_t *)slab_pack_workspace(bytes);
         if (Bp) {
+            scratch_acquire(MX_SCRATCH_PACKED_B, stream);
             if (launch_repack<real_t>(K, K, n, B, ldb, Bp, stream)) return 1;
             B = Bp; ldb = W; slab_stride = (size_t)K * W;
         }
@@ -321,6 +322,7 @@ static int launch_spmm_slab_rpg(int m, int n, int K, const int32_t *indptr, cons
                            m, n, indptr, indices, values, B, ldb, C, ldc, npanels, panel_cols, nslabs, nrowblocks,
                            c_vec_ok, sync, sync_mode, slab_stride);
     kt_end(stream);
+    scratch_done(MX_SCRATCH_PACKED_B, stream);
     MX_LAUNCH_CHECK();
     return 0;
 }

@@ -1102,6 +1102,11 @@ def test_per_thread_scratch_survives_a_stream_switch(gpu):
     ref_C = D.spmm(A2, B, colmajor=False, algo=4, npanels=4).clone()
     ref_g = D.csr_gather_rows(A, rows)
     ref_g2 = D.csr_gather_rows(A2, rows[:20_000] % 30_000)
+    # the planned kernel: a kept plan per matrix, but ONE per-thread packed copy of B shared by both sweeps; and the C-ABI's
+    # own AUTO (keep_plan=False), whose plan buffers are per thread too
+    Bs = [B, B * 2.0]
+    ref_P = [D.spmm_planned(A, Bs[k], colmajor=True).clone() for k in (0, 1)]
+    ref_Q = D.spmm(A, B, colmajor=True, algo=0, keep_plan=False).clone()
     torch.cuda.synchronize()
     for _ in range(5):
         with torch.cuda.stream(s1):
@@ -1112,7 +1117,15 @@ def test_per_thread_scratch_survives_a_stream_switch(gpu):
             y2 = D.spmv(A2, v, algo=3)
             C2 = D.spmm(A2, B, colmajor=False, algo=4, npanels=2)
             g2 = D.csr_gather_rows(A2, rows[:20_000] % 30_000)
+        with torch.cuda.stream(s1):
+            P1 = D.spmm_planned(A, Bs[0], colmajor=True)
+            Q1 = D.spmm(A, B, colmajor=True, algo=0, keep_plan=False)
+        with torch.cuda.stream(s2):
+            P2 = D.spmm_planned(A, Bs[1], colmajor=True)
+            Q2 = D.spmm(A, B, colmajor=True, algo=0, keep_plan=False)
         torch.cuda.synchronize()
+        assert torch.equal(P1, ref_P[0]) and torch.equal(P2, ref_P[1])
+        assert torch.allclose(Q1, ref_Q, rtol=1e-12, atol=1e-12) and torch.allclose(Q2, ref_Q, rtol=1e-12, atol=1e-12)
         assert torch.equal(y1, ref_y) and torch.equal(y2, ref_y2)
         assert torch.equal(C1, ref_C) and torch.equal(C2, ref_C)
         assert torch.equal(g1.indices, ref_g.indices) and torch.equal(g1.indptr, ref_g.indptr)

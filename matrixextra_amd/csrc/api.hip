@@ -713,7 +713,11 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
     std::vector<std::string> errors((size_t)nd);
     // B goes up ONCE per distinct device (a device may be listed several times — its shards share the GPU): the first shard
     // of a device to get there uploads it, the others wait for that upload's event
-    struct SharedB { std::once_flag once; DevBuf buf; hipEvent_t ev = nullptr; bool ok = false; };
+    // turn: the shards of ONE device take turns for their upload + product phase (they share that device's link: eight
+    // concurrent upload streams moved 19 GB/s where one moves 33-55; MXGPU_SHARD_TURNS=0 lets them run together).  The
+    // downloads of a shard that has had its turn keep running under the next shard's uploads (PCIe is full duplex).
+    struct SharedB { std::once_flag once; DevBuf buf; hipEvent_t ev = nullptr; bool ok = false; std::mutex turn; };
+    static const bool shard_turns = [] { const char *e = getenv("MXGPU_SHARD_TURNS"); return !e || atoi(e) != 0; }();
     std::vector<int> distinct;
     std::vector<int> dev_slot((size_t)nd);
     for (int k = 0; k < nd; k++) {
@@ -736,9 +740,14 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
         auto failed = [&](const char *what) { errors[k] = std::string(what) + ": " + mx_last_error(); };
         auto note = [&](const char *what) { if (tr.on) fprintf(stderr, "[mxgpu] shard %d %-18s at %8.2f ms\n", k, what, at_ms()); };
         note("start");
-        if (hipSetDevice(devs[k]) != hipSuccess) { errors[k] = "hipSetDevice failed"; return; }
         const int r_lo = cut[k], r_hi = cut[k + 1], mk = r_hi - r_lo;
         if (mk == 0) return;
+        struct Arrive {                                          // counted once on EVERY path of a shard that has rows (a failing
+            std::mutex &mu; std::condition_variable &cv; int &count; bool done = false;      // shard must not hold the others)
+            void now() { if (!done) { { std::lock_guard<std::mutex> lk(mu); count++; } cv.notify_all(); done = true; } }
+            ~Arrive() { now(); }
+        } arrive{start_mu, start_cv, arrived_shards};
+        if (hipSetDevice(devs[k]) != hipSuccess) { errors[k] = "hipSetDevice failed"; return; }
         const int64_t e_lo = indptr[r_lo], e_hi = indptr[r_hi];
         Lanes &L = lanes();                                      // this worker thread's queues: kept, like the thread
         const int nblk = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)mk * n * (int64_t)sizeof(real_t) / ((int64_t)96 << 20)));
@@ -747,11 +756,6 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
         // the shard's own CSR arrays (indptr rebased on the host: mk + 1 ints), B, and its rows of C (column-major mk x n, or
         // row-major)
         DevBuf dp, dj, dx, dC;
-        struct Arrive {                                          // counted once on every path (a failing shard must not hold the others)
-            std::mutex &mu; std::condition_variable &cv; int &count; bool done = false;
-            void now() { if (!done) { { std::lock_guard<std::mutex> lk(mu); count++; } cv.notify_all(); done = true; } }
-            ~Arrive() { now(); }
-        } arrive{start_mu, start_cv, arrived_shards};
         std::vector<int32_t> p_local((size_t)mk + 1);
         for (int r = 0; r <= mk; r++) p_local[r] = (int32_t)(indptr[r_lo + r] - e_lo);
         // (a plain copy: the transfer engine of xfer.hip is one per process and busy first-touching the result right now —
@@ -779,6 +783,9 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
         DevBuf dB;
         dB.alias(sb.buf.p, b_bytes);
         bool ok = true;
+        std::unique_lock<std::mutex> my_turn(sb.turn, std::defer_lock);
+        if (shard_turns) my_turn.lock();
+        note("turn");
         std::vector<int> bc((size_t)nblk + 1);
         for (int b = 0; b <= nblk; b++) bc[b] = b == nblk ? mk : (int)((int64_t)mk * b / nblk) & ~1023;   // whole generations of the planned kernel
         for (int b = 0; b < nblk && ok; b++) {
@@ -854,6 +861,7 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
             (void)hipEventRecord(L.ev[nblk + b], L.run);
             download_open_pieces(b);
         }
+        if (my_turn.owns_lock()) my_turn.unlock();
         note("products queued");
         for (int g = 0; g < np && ok; g++) {                     // the pieces that were not open yet: wait for each, queue what is left
             {

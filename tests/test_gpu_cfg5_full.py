@@ -26,10 +26,10 @@ def test_cfg5_whole_matrix_through_the_boundary(gpu):
     assert r["sharded_equals_unsharded_bitwise"]                          # row cuts at multiples of 1024 rows: the same plan generations
     # 8 shards on ONE GPU (the second call: its workers, their streams and plan buffers exist): round 3 measured 2.0-2.5x the
     # unsharded cold call (369-467 ms vs 189); round 4 — pieces of the result registered as they are touched, downloads queued
-    # behind each block's product, persistent workers, B once per device — 1.7-1.8x (315-335 ms vs 187-197).  What is left is
-    # PCIe throughput under 8 concurrent upload / download streams, not fixed cost; the bound below only guards
-    # against falling back to round 3's figures.
-    assert r["export_sharded_ms"][1] <= 2.1 * r["export_unsharded_ms"]["cold"], (r["export_sharded_ms"], r["export_unsharded_ms"])
+    # behind each block's product, persistent workers, B once per device, the shards of one device taking turns on its link —
+    # 1.4x (267 ms vs 192).  What is left is the duplex rate of the one link all eight share and the last shard's download
+    # tail; the bound below guards against falling back.
+    assert r["export_sharded_ms"][1] <= 1.7 * r["export_unsharded_ms"]["cold"], (r["export_sharded_ms"], r["export_unsharded_ms"])
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "cfg5_full_test.json"), "w") as f:

@@ -906,6 +906,32 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
         res["vignette_lbfgs_loop"] = vignette_loop.run(iters=60)
     section("vignette_loop", _vignette_loop)
 
+    # ---- what ONE export call costs for small operands (tools/small_calls.py has the full table): the
+    # reference's own test size and a 1e5-entry matrix, p50 of the four hot-path exports beside the CPU restatement
+    def _export_small_calls():
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import small_calls
+        pts = {"test_matmul_R_100x50": small_calls.point("test_matmul_R_100x50", 100, 50, 20, 20, 30),
+               "nnz_1e5": small_calls.point("nnz_1e5", 5000, 10_000, 20, 32, 1500)}
+        res["export_small_calls"] = {
+            name: {leg: {"gpu_p50_us": v["gpu"]["p50_us"], "cpu_1_thread_p50_us": v["cpu_1_thread"]["p50_us"], "gpu_over_cpu": v["gpu_over_cpu"]}
+                   for leg, v in pt.items() if leg != "shape"} | {"shape": pt["shape"]}
+            for name, pt in pts.items()}
+        res["export_small_calls"]["note"] = ("host arrays in, host arrays out through ctypes; operands + result within 512 KiB take the small "
+                                             "path (one pinned block up, same kernels, one block down, one sync); full table and crossovers: "
+                                             "profiles/r04_small_calls.json")
+    section("export_small_calls", _export_small_calls)
+
+    # ---- AUTO's regime map is measured by tools/auto_map.py (4 minutes): its committed summary rides along
+    def _auto_map_summary():
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import prof_common as PC
+        files = PC.newest_round("auto_map.json")
+        if files:
+            doc = json.load(open(files[-1]))
+            res["auto_map"] = dict(doc["summary"], source=os.path.relpath(files[-1], ROOT), measured="offline, by tools/auto_map.py on an MI355X box")
+    section("auto_map", _auto_map_summary)
+
     return res
 
 

@@ -113,11 +113,38 @@ def spmv_point(m, K, npr, lib):
     return {"m": m, "K": K, "per_row": npr, "ms": ms, "best_one_shot": best, "auto_over_best": round(ms["auto"] / cand[best], 3)}
 
 
+def gather_point(m, K, npr, r, lib):
+    """X[rows, ]: the one-launch gather with every lane-group width (the width follows the row-length hint: 4 .. 64 lanes
+    per row) against the width AUTO derives from the matrix's mean row length"""
+    p, j, x = synth.device_csr_fixed(m, K, npr, seed=17)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    rows = torch.randint(0, m, (r,), dtype=torch.int32, device="cuda", generator=g)
+    cap = r * npr
+    new_p = torch.empty(r + 1, dtype=torch.int32, device="cuda")
+    new_j = torch.empty(cap, dtype=torch.int32, device="cuda")
+    new_x = torch.empty(cap, dtype=torch.float64, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nnz_out = C.c_int64(0)
+
+    def run(hint):
+        _lib.check(lib.mxd_csr_gather_fused(C.c_int(r), C.c_void_p(p.data_ptr()), C.c_void_p(j.data_ptr()), C.c_void_p(x.data_ptr()),
+                                            C.c_void_p(rows.data_ptr()), C.c_void_p(new_p.data_ptr()), C.c_void_p(new_j.data_ptr()),
+                                            C.c_void_p(new_x.data_ptr()), C.c_int(_lib.MX_F64), C.c_int64(cap), C.c_double(hint), None,
+                                            C.byref(nnz_out), st))
+    ms = {"auto": round(min(timeit(lambda: run(float(npr)), reps=20), timeit(lambda: run(float(npr)), reps=20, warm=0)), 5)}
+    for G in (4, 8, 16, 32, 64):
+        ms[f"lanes_{G}"] = round(min(timeit(lambda: run(float(G)), reps=20), timeit(lambda: run(float(G)), reps=20, warm=0)), 5)
+    best = min((k for k in ms if k != "auto"), key=ms.get)
+    return {"m": m, "per_row": npr, "rows_taken": r, "ms": ms, "best": best, "auto_over_best": round(ms["auto"] / ms[best], 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="the reduced grid of tests/test_gpu_auto_map.py")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "auto_map.json"))
-    ap.add_argument("--no-spmv", action="store_true")
+    ap.add_argument("--no-spmv", action="store_true", help="SpMM only (no SpMV / gather legs)")
+    ap.add_argument("--only-gather", action="store_true")
     args = ap.parse_args()
     lib = _lib.load()
     t0 = time.time()
@@ -125,6 +152,8 @@ def main():
     ms_, nprs, ns, Ks = (10_000, 100_000, 1_000_000), (8, 32, 128, 500), (16, 64, 100, 128, 256), (10_000, 100_000)
     if args.quick:
         ms_, nprs, ns, Ks = (10_000, 100_000), (32, 500), (16, 100, 128), (10_000, 100_000)
+    if args.only_gather:
+        ms_ = ()
     for m in ms_:
         for npr in nprs:
             for K in Ks:
@@ -150,6 +179,13 @@ def main():
                 if m * npr > 130_000_000:
                     continue
                 doc["spmv"].append(spmv_point(m, 100_000, npr, lib))
+    doc["gather"] = []
+    if not args.no_spmv:
+        for npr in (4, 8, 32, 128, 500):
+            for r in (10_000, 200_000, 1_000_000):
+                if r * npr > 130_000_000:
+                    continue
+                doc["gather"].append(gather_point(1_000_000, 100_000, npr, r, lib))
     w1 = max(doc["spmm"], key=lambda r: r["auto_one_shot_over_best"])
     wk = max(doc["spmm"], key=lambda r: r["auto_kept_over_best"])
     # products of a few microseconds are timed through Python's ~10 us per call (the same kernel measures 0.011 and 0.021 ms
@@ -165,7 +201,8 @@ def main():
         "auto_kept_worst_over_best": {"ratio": wk["auto_kept_over_best"], "at": {k: wk[k] for k in ("m", "K", "per_row", "n", "layout", "dtype")}},
         "points_above_1.25_one_shot": sum(r["auto_one_shot_over_best"] > 1.25 for r in doc["spmm"]),
         "points_above_1.25_kept": sum(r["auto_kept_over_best"] > 1.25 for r in doc["spmm"]),
-        "spmv_worst_over_best": max((r["auto_over_best"] for r in doc["spmv"]), default=None)}
+        "spmv_worst_over_best": max((r["auto_over_best"] for r in doc["spmv"]), default=None),
+        "gather_worst_over_best": max((r["auto_over_best"] for r in doc["gather"]), default=None)}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(doc, f, indent=1)

@@ -262,7 +262,7 @@ int mxd_spmv_csr_dvec(int m, int64_t nnz /* lanes-per-row hint, -1 = unknown */,
  *   MX_SPMV_TILE  : one 1024-thread workgroup per ~24 k entries, v swept through LDS in 16 k-column panels instead of
  *                   gathered; same summation as FLAT (additionally needs 16-B aligned v and K <= 24 * 16384).  Wins when
  *                   v fits one panel or the rows are very uneven; see DESIGN.md §4.3
- *   MX_SPMV_AUTO  : FLAT when it applies and nnz >= 2^20, else GROUP */
+ *   MX_SPMV_AUTO  : FLAT when it applies, nnz >= 2^22 and there are at least 32k rows (round 4's map), else GROUP */
 typedef enum { MX_SPMV_AUTO = 0, MX_SPMV_GROUP = 1, MX_SPMV_TILE = 2, MX_SPMV_FLAT = 3 } mx_spmv_algo;
 int mxd_spmv_csr_dvec_ex(int m, int K, int64_t nnz,
                          const int32_t *indptr, const int32_t *indices, const double *values,

@@ -63,6 +63,7 @@ int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, con
                const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, int npanels, hipStream_t st);
 int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
                 const void *v, int v_dtype, void *y, int algo, hipStream_t st);
+bool spmv_flat_ok(int m, int64_t nnz, const int32_t *indices, const double *values);
 // xfer.hip: synchronous host <-> device copies, pipelined through pinned slots + a host copy pool when large
 int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes);
@@ -1314,6 +1315,14 @@ static bool opt_spmv_planned()
     static const bool env = [] { const char *e = getenv("MXGPU_SPMV_PLANNED"); return e && atoi(e) == 1; }();
     return env;
 }
+// The exports prefer the FLAT kernel from 2^20 entries / 32k rows on: its sums are the reference's loop bit for bit
+// (matmul.cpp:401-416), which is worth more at this level — where a call is bound by PCIe, not by the kernel — than the
+// 20-45 % the lane-group kernel saves on the device between 2^20 and 2^22 entries (there the device-level AUTO takes it).
+static int export_spmv_algo(int algo, int m, int64_t nnz, const int32_t *dj, const double *dx)
+{
+    if (algo == MX_SPMV_AUTO && nnz >= ((int64_t)1 << 20) && m >= 32768 && mx::spmv_flat_ok(m, nnz, dj, dx)) return MX_SPMV_FLAT;
+    return algo;
+}
 static int opt_spmv_algo()
 {
     const int64_t v = g_opt_spmv_algo.load();
@@ -1374,7 +1383,7 @@ static int spmv_host(int m, const int32_t *indptr, const int32_t *indices, const
     }
     g_spmv_planned_calls += planned ? 1 : 0;
     if (!planned && spmv_launch(m, len_y, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), v.p, v_dtype, o.p,
-                                opt_spmv_algo(), nullptr))
+                                export_spmv_algo(opt_spmv_algo(), m, A.nnz, A.j.as<int32_t>(), A.x.as<double>()), nullptr))
         return 1;
     if (mx::xfer_d2h(out, o.p, sizeof(out_t) * (size_t)m)) return 1;
     return 0;

@@ -172,7 +172,8 @@ int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t 
     // rows (1e4 x 128 / row: lane-group 0.009 ms, flat 0.016; 1e4 x 500: 0.029 / 0.047) and within 1.2x either way from 1e5
     // rows on (1e5 x 32: 0.020 / 0.024; 1e5 x 500: 0.328 / 0.276; 1e6 x 32: 0.190 / 0.164) — where it stays, because its
     // sums are the reference's loop bit for bit
-    if (algo == MX_SPMV_FLAT || (algo == MX_SPMV_AUTO && flat_ok && nnz >= ((int64_t)1 << 20) && m >= 32768))
+    // (and from 2^22 entries: at 1e5 x 32 — 3.2 M entries — the lane-group kernel took 0.020 ms, the flat one 0.024-0.029)
+    if (algo == MX_SPMV_FLAT || (algo == MX_SPMV_AUTO && flat_ok && nnz >= ((int64_t)1 << 22) && m >= 32768))
         return spmv_flat_launch(m, nnz, indptr, indices, values, v, v_dtype, y, st);
     const int G = nnz < 0 ? 32 : pick_group((double)nnz / (double)(m > 0 ? m : 1));
     switch (v_dtype) {

@@ -849,6 +849,9 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
             const int r0 = bc[b], r1 = bc[b + 1];
             if (r1 == r0) continue;
             (void)hipStreamWaitEvent(L.run, L.ev[b], 0);
+            // the link is free for the next shard of this device once this shard's LAST upload has arrived — its last
+            // product (plan sizing on the host, the sweep) and its downloads do not need the upload direction any more
+            if (b == nblk - 1 && my_turn.owns_lock()) { (void)hipEventSynchronize(L.ev[b]); my_turn.unlock(); }
             real_t *dCb = colmajor ? dC.as<real_t>() + r0 : dC.as<real_t>() + (size_t)r0 * ldc_k;
             if (p_local[r0] == p_local[r1]) {
                 if (colmajor) (void)hipMemset2DAsync(dCb, ldc_k * sizeof(real_t), 0, (size_t)(r1 - r0) * sizeof(real_t), n, L.run);

@@ -3,6 +3,7 @@ shim registers through R_registerRoutines is the reference's (names + arities, s
 collector really reports a missing PROTECT, and — on a box without a GPU — a routine called by name ends in an R error
 raised by Rf_error(mx_last_error()) with the protect stack balanced.  The GPU half is tests/test_gpu_r_shim_exec.py."""
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -59,6 +60,38 @@ def test_coercions_follow_r(R):
     lg = L.Rf_coerceVector(R.real([0.0, 2.5, np.nan]), rmock.LGLSXP)
     L.rmock_hold(lg)
     assert R.view(lg).tolist() == [0, 1, rmock.NA_INTEGER]
+
+
+def test_shim_and_mock_under_asan(tmp_path):
+    """tests/r_mock/driver_asan.c: the shim + the mock built with AddressSanitizer + UBSan and every registered routine
+    called by name from plain C — well-formed arguments, index vectors / scalars as doubles (the coercion paths), the
+    collector on every allocation, an R allocation failure injected at every position.  Without a GPU every call ends in
+    the library's error, i.e. what runs under the sanitizers is the marshalling up to the C-ABI call and the Rf_error exit
+    (GPU AddressSanitizer is not available on the pool; with a GPU the same calls also run the result marshalling)."""
+    from matrixextra_amd import _lib
+    try:
+        if _lib.device_count() > 0:              # the driver's arguments are only well-formed enough for the refusal path
+            pytest.skip("a GPU is present: the marshalling of results is covered by tests/test_gpu_r_shim_exec.py")
+    except _lib.MxError:
+        pass
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "r_mock")
+    root = os.path.dirname(os.path.dirname(here))
+    inc = ["-I", os.path.join(root, "tests", "r_api_decls"), "-I", os.path.join(root, "include")]
+    san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-Wno-cast-function-type"]
+    objs = []
+    for cc, std, src in (("gcc", "-std=gnu11", os.path.join(here, "rmock.c")), ("gcc", "-std=gnu11", os.path.join(here, "driver_asan.c")),
+                         ("g++", "-std=c++17", os.path.join(root, "matrixextra_amd", "csrc", "r_shim.cpp"))):
+        obj = str(tmp_path / (os.path.basename(src) + ".o"))
+        r = subprocess.run([cc, std, *san, *inc, "-c", src, "-o", obj], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        objs.append(obj)
+    libdir = os.path.join(root, "matrixextra_amd")
+    exe = str(tmp_path / "driver")
+    r = subprocess.run(["g++", "-fsanitize=address,undefined", *objs, "-L", libdir, "-lmxgpu", f"-Wl,-rpath,{libdir}", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"), timeout=600)
+    assert r.returncode == 0 and "rmock driver ok" in r.stdout, (r.stdout + r.stderr)[-4000:]
 
 
 def test_library_error_longjumps_to_the_trampoline_on_a_box_without_gpu(R):

@@ -45,6 +45,37 @@ __device__ __forceinline__ void rs_chunk(int cnt, int jv, double av, const real_
                                          real_t (&acc)[VEC])
 {
     int k = 0;
+    if (cnt == MX_WAVE) {
+        // a full chunk: two register sets, the loads of one batch issued before the FMAs of the batch before it — 8 to 16
+        // B-row reads in flight all the way through the chunk instead of draining to zero at every batch (same FMA order)
+        real_t b0[RS_UNROLL][VEC], b1[RS_UNROLL][VEC];
+#pragma unroll
+        for (int u = 0; u < RS_UNROLL; u++) vload<real_t, VEC>(b0[u], B + (size_t)__builtin_amdgcn_readlane(jv, u) * ldb + col);
+#pragma unroll
+        for (int kk = 0; kk < MX_WAVE; kk += 2 * RS_UNROLL) {
+#pragma unroll
+            for (int u = 0; u < RS_UNROLL; u++)
+                vload<real_t, VEC>(b1[u], B + (size_t)__builtin_amdgcn_readlane(jv, kk + RS_UNROLL + u) * ldb + col);
+#pragma unroll
+            for (int u = 0; u < RS_UNROLL; u++) {
+                const real_t a = (real_t)readlane_f64(av, kk + u);
+#pragma unroll
+                for (int v = 0; v < VEC; v++) acc[v] = mx_fma(a, b0[u][v], acc[v]);
+            }
+            if (kk + 2 * RS_UNROLL < MX_WAVE) {
+#pragma unroll
+                for (int u = 0; u < RS_UNROLL; u++)
+                    vload<real_t, VEC>(b0[u], B + (size_t)__builtin_amdgcn_readlane(jv, kk + 2 * RS_UNROLL + u) * ldb + col);
+            }
+#pragma unroll
+            for (int u = 0; u < RS_UNROLL; u++) {
+                const real_t a = (real_t)readlane_f64(av, kk + RS_UNROLL + u);
+#pragma unroll
+                for (int v = 0; v < VEC; v++) acc[v] = mx_fma(a, b1[u][v], acc[v]);
+            }
+        }
+        return;
+    }
     for (; k + RS_UNROLL <= cnt; k += RS_UNROLL) {
         real_t b[RS_UNROLL][VEC];
 #pragma unroll

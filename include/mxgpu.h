@@ -173,9 +173,13 @@ int mxd_spmm_csr_dense(int m, int n,
  *                          work to fill the chip, else ROWWAVE
  * Determinism: ROWWAVE and SLAB add a row's terms in CSR storage order (bitwise equal to a CPU loop with fused multiply-
  * add, and reproducible).  PLANNED adds per-panel partial sums in panel order (a regrouping: equal to 1e-12 for f64);
- * for matrices with very uneven row lengths some rows are shared by several lane groups and folded with LDS atomics,
- * so the last bits of those rows can differ from run to run.  Callers that need run-to-run bitwise reproducibility
- * pass MX_SPMM_ROWWAVE (the exports: MXGPU_SPMM_ALGO=1).
+ * for matrices with very uneven row lengths some rows are shared by several lane groups of the ONE wavefront that owns
+ * the rows' octet and folded with LDS atomics.  No other wavefront ever touches those sums, a wavefront's LDS
+ * instructions execute in program order and the plan build is deterministic, so what is left open is only the order in
+ * which the LDS unit serves lanes of one instruction that hit the same address — fixed on gfx950 as measured: bitwise
+ * equal results over 320 runs with plan rebuilds and other kernels in between (tools/repro_probe.py; pinned by
+ * tests/test_gpu_fullsize.py::test_planned_kernel_same_bits_run_to_run_on_skewed_rows), but not a promise of the ISA
+ * manual.  Callers that want the guarantee by construction pass MX_SPMM_ROWWAVE (the exports: MXGPU_SPMM_ALGO=1).
  * npanels <= 0 / wg_per_cu <= 0 pick defaults.
  *   algo MX_SPMM_ROWSPLIT: short-and-fat products (few rows and / or long rows, narrow B — the reference's published
  *                          dense x CSC workload): one wavefront per row SEGMENT, G = 8 .. 64 lanes per row of B, partial

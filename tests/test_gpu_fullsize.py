@@ -333,3 +333,25 @@ def test_rowsplit_panels_mid_size_properties(gpu):
         O.gemm_csr_drm_as_drm(rows, n, (p[r0:r0 + rows + 1] - p[r0]).astype(np.int32), j[lo:hi].copy(), x[lo:hi].copy(),
                               B1.cpu().numpy().reshape(-1), n, ref, n, 1, True)
         np.testing.assert_allclose(C1[r0:r0 + rows].cpu().numpy(), ref.reshape(rows, n), rtol=1e-12, atol=1e-11)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_planned_kernel_same_bits_run_to_run_on_skewed_rows(gpu, dtype):
+    """Log-normal row lengths put octets in the plan's dealt layout: long rows are shared by several lane groups of the
+    wavefront that owns the octet and folded with LDS atomics (spmm_plan.hip).  Only that one wavefront touches the sums,
+    so the result is the same bits on every run — with the plan kept, with the plan rebuilt, with other kernels running
+    in between (include/mxgpu.h, 'Determinism')."""
+    from matrixextra_amd import device as D
+    m, K, n = 400_000, 100_000, 128
+    p, j, x = synth.csr_skewed_fast(m, K, 24, seed=21, sigma=1.3)
+    A = D.DeviceCSR.from_host(p, j, x, K)
+    B = torch.randn((K, n), dtype=dtype, device="cuda")
+    bits = torch.int64 if dtype == torch.float64 else torch.int32
+    for colmajor in (False, True):
+        ref = D.spmm_planned(A, B, colmajor=colmajor).clone()
+        assert A.plan_info()["padded_entries"] < 1.25 * A.nnz          # dealt octets (the bundle layout pads ~1.8x here)
+        for r in range(12):
+            if r % 3 == 0:
+                _ = torch.randn((2048, 2048), device="cuda") @ torch.randn((2048, 2048), device="cuda")
+            got = D.spmm_planned(A, B, colmajor=colmajor, rebuild_plan=(r % 2 == 1))
+            assert torch.equal(got.view(bits), ref.view(bits))

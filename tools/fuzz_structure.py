@@ -44,6 +44,24 @@ def same_list(g, o, what):
             same(g[k], o[k], f"{what}/{k}")
 
 
+def footprint():
+    """(live device blocks of the library's pool, live bytes, idle bytes, device bytes in use on the GPU, host RSS): what a
+    leak in the exports' begin / finish / error paths would move"""
+    import ctypes, psutil, torch
+    lib = _lib.load()
+    assert lib.mx_cache_invalidate(None) == 0          # the CSR cache holds device copies by design (cap: MXGPU_CSR_CACHE_MB)
+    out = []
+    for name in (b"pool_live_blocks", b"pool_live_bytes", b"pool_idle_bytes"):
+        v = ctypes.c_int64(0)
+        assert lib.mx_get_option(name, ctypes.byref(v)) == 0
+        out.append(int(v.value))
+    free, total = torch.cuda.mem_get_info()
+    return out + [int(total - free), psutil.Process().memory_info().rss]
+
+
+BASE_AT = 300
+TRACK = bool(os.environ.get("FUZZ_TRACK"))
+base = None
 SKIP = set(filter(None, os.environ.get("FUZZ_SKIP", "").split(",")))     # gatherfused, sortedview, spmvplan, naroute (bisecting)
 t_end = time.time() + budget
 cases = 0
@@ -207,4 +225,15 @@ while time.time() < t_end:
         print("FAIL", dict(m=m, K=K, d1=d1, d2=d2, s1=s1, s2=s2, seed=seed, case=cases, what=what), repr(exc)[:600])
         sys.exit(1)
     cases += 1
+    if cases == BASE_AT:
+        base = footprint()
+    elif TRACK and cases % 500 == 0:
+        print("  footprint at case", cases, footprint(), flush=True)
+if base is not None:
+    end = footprint()
+    print("footprint after %d cases [live blocks, live bytes, idle bytes, device bytes in use, host RSS]: %s" % (BASE_AT, base))
+    print("footprint after %d cases: %s" % (cases, end))
+    assert end[0] == base[0] and end[1] == base[1], "device blocks still held by finished calls: a leak"
+    assert end[3] - base[3] <= 256 << 20, "device memory in use grew by more than the pool can explain"
+    assert end[4] - base[4] <= 512 << 20, "host RSS grew by more than 512 MB over the run"
 print(f"fuzz OK: {cases} cases in {budget:.0f} s (seed {seed})")

@@ -32,7 +32,10 @@ cp "$(ls -t $W/vignette/trace/*/*_kernel_stats.csv | head -1)" $O/${RND}_vignett
 # (c) configs[4]'s per-GPU shard on this GPU
 bash tools/profile.sh $W/cfg5 1 -- --config cfg5 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/log_cfg5.txt 2>&1
 python3 tools/prof_summary.py $W/cfg5 $O/${RND}_cfg5_shard "spmm_plan_kernel" cfg5-shard-default > /dev/null
-# (d) the bench lines themselves (un-profiled runs: profiled passes clock lower)
+# (d) the bench lines themselves (un-profiled runs: profiled passes clock lower).  The summaries just made go into this
+# copy's profiles/ first, so that the lines quote THIS build's counters (bench.py refuses summaries whose kernel sources
+# hash differently from the tree it runs in)
+cp $O/${RND}_*.json $O/${RND}_*.csv $R/profiles/
 python3 bench.py --steps 20 --warmup 5 > $O/${RND}_bench_n1.json 2> $O/log_bench.txt
 python3 bench.py --config cfg5 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/${RND}_cfg5_shard_bench_n1.json 2>> $O/log_bench.txt
 python3 bench.py --config cfg5-full > $O/${RND}_cfg5_full_bench.json 2> $O/log_cfg5_full.txt

@@ -921,7 +921,7 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
             name: {leg: {"gpu_p50_us": v["gpu"]["p50_us"], "cpu_1_thread_p50_us": v["cpu_1_thread"]["p50_us"], "gpu_over_cpu": v["gpu_over_cpu"]}
                    for leg, v in pt.items() if leg != "shape"} | {"shape": pt["shape"]}
             for name, pt in pts.items()}
-        res["export_small_calls"]["note"] = ("host arrays in, host arrays out through ctypes; operands + result within 512 KiB take the small "
+        res["export_small_calls"]["note"] = ("host arrays in, host arrays out through ctypes; operands + result within ~2 MiB (SpMM 6, merges 3: the measured crossovers against the regular path) take the small "
                                              "path (one pinned block up, same kernels, one block down, one sync); full table and crossovers: "
                                              "profiles/r04_small_calls.json")
     section("export_small_calls", _export_small_calls)

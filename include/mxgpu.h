@@ -110,8 +110,9 @@ int  mx_cache_stats(int64_t *bytes, int *entries, int64_t *hits, int64_t *misses
  *                  (operands, results, kept plans) go back to a pool instead of hipFree — capped at MXGPU_POOL_MB, default
  *                  min(32 GiB, 1/8 of the device; 0 = every block is freed at once) — and mxd_release_workspaces() or a
  *                  failed allocation gives them back to the device (csrc/pool.hip: why)
- *   "small_calls"  read-only: export-level calls served by the small path — operands + result within 512 KiB (SpMM, SpMV,
- *                  CSR (+) CSR, X[rows, ]): every input packed into one pinned block, one copy up, the same kernels, one copy
+ *   "small_calls"  read-only: export-level calls served by the small path — operands + result within ~2 MiB (SpMM 6 MiB,
+ *                  merges 3 MiB: the measured crossovers against the regular path; MXGPU_SMALL_LIMIT_KB scales them) for SpMM,
+ *                  SpMV, CSR (+) CSR, X[rows, ]: every input packed into one pinned block, one copy up, the same kernels, one copy
  *                  down, one synchronisation; no pool, no cache (MXGPU_SMALL_CALLS=0 switches it off)
  *   "pool_live_bytes" / "pool_live_blocks"  read-only: blocks handed out and not yet returned (operands in the CSR cache,
  *                  kept plans, thread scratch, results between begin and finish / discard) — a leaked mx_result shows here

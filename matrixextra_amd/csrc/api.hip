@@ -540,8 +540,17 @@ static void partition_rows(const int32_t *indptr, int m, int nparts, double w_en
 // thread's own stream, the kernels run on the device twin of that block (inputs, results and workspaces at the same
 // offsets), the results come back in ONE copy, and the call synchronises ONCE.  No pool, no cache, no registration, no
 // fingerprint.  The same kernels compute; nothing is computed on the host.  MXGPU_SMALL_CALLS=0 switches the path off.
-constexpr size_t SMALL_LIMIT = (size_t)512 << 10;                // inputs + results of a call that takes the small path
-constexpr size_t SMALL_STAGE = (size_t)4 << 20;                  // the block: inputs, results, kernel workspaces
+// inputs + results of a call that takes the small path, and the block: inputs, results, kernel workspaces.  Where the path
+// stops paying against the regular one was measured per export (tools/small_limit_probe.py, MXGPU_SMALL_LIMIT_KB = 16 against
+// 65536: the packing memcpy is one host thread, the regular path's fixed cost ~110-250 us): SpMV and the row gather up to
+// ~2 MiB of operands + result, the merges ~3 MiB (operands + the result's upper bound), SpMM ~6-8 MiB.
+static const size_t SMALL_LIMIT = [] {
+    const char *e = getenv("MXGPU_SMALL_LIMIT_KB");
+    const long kb = e ? atol(e) : 2048;
+    return (size_t)(kb < 16 ? 16 : (kb > (64 << 10) ? (64 << 10) : kb)) << 10;
+}();
+static const size_t SMALL_LIMIT_SPMM = SMALL_LIMIT * 3, SMALL_LIMIT_MERGE = SMALL_LIMIT + SMALL_LIMIT / 2;
+static const size_t SMALL_STAGE = SMALL_LIMIT * 6;
 struct SmallStage {
     char *h = nullptr, *d = nullptr;
     hipStream_t st = nullptr;
@@ -942,7 +951,7 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     {   // small call: one block up, the product, one block down, one wait (see SmallStage)
         const int64_t nnz_s = (int64_t)indptr[m] - indptr[0];
         const size_t csr_bytes = 4 * ((size_t)m + 1) + 12 * (size_t)nnz_s;
-        SmallStage *S = indptr[0] == 0 && csr_bytes + b_bytes + c_bytes <= SMALL_LIMIT && algo != MX_SPMM_SLAB ? small_stage() : nullptr;
+        SmallStage *S = indptr[0] == 0 && csr_bytes + b_bytes + c_bytes <= SMALL_LIMIT_SPMM && algo != MX_SPMM_SLAB ? small_stage() : nullptr;
         if (S) {
             const size_t op = S->put(indptr, 4 * ((size_t)m + 1)), oj = S->put(indices, 4 * (size_t)nnz_s), ox = S->put(values, 8 * (size_t)nnz_s);
             const size_t ob = S->put(B_host, b_bytes), in_end = S->top, oc = S->take(c_bytes), out_end = S->top;
@@ -1659,7 +1668,7 @@ int mx_csr_elemwise_begin(int op, int nrows, const int32_t *indptr1, const int32
             const size_t pb = 4 * ((size_t)nrows + 1);
             const size_t in_bytes = 2 * pb + (4 + vb) * (size_t)(nnz1 + nnz2), out_bytes = pb + (4 + vb) * (size_t)bound_s;
             SmallStage *S = nrows > 0 && indptr1[0] == 0 && indptr2[0] == 0 && indptr1[nrows] == nnz1 && indptr2[nrows] == nnz2 &&
-                            in_bytes + out_bytes <= SMALL_LIMIT ? small_stage() : nullptr;
+                            in_bytes + out_bytes <= SMALL_LIMIT_MERGE ? small_stage() : nullptr;
             if (S) {
                 const size_t p1 = S->put(indptr1, pb), j1 = S->put(indices1, 4 * (size_t)nnz1), x1 = S->put(values1, vb * (size_t)nnz1);
                 const size_t p2 = S->put(indptr2, pb), j2 = S->put(indices2, 4 * (size_t)nnz2), x2 = S->put(values2, vb * (size_t)nnz2);

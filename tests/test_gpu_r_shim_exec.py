@@ -522,11 +522,11 @@ def test_r_allocation_failure_longjumps_with_the_device_handle_released(R, gpu, 
     ("cannot allocate vector of size ...").  The handle must be discarded by the R_ExecWithCleanup handler: the count of
     device blocks handed out (mx_get_option("pool_live_blocks")) is what it was, the protect stack is balanced, nothing is
     left on the R_PreserveObject list (rmock.call asserts the last two)."""
-    # operands of ~1 MB each: the regular path, whose results wait in pooled device blocks between begin and finish (the
-    # small path of calls under 512 KiB keeps its result in the handle itself and is covered by the second half below)
-    p, j, x = rand_csr(4000, 3000, 0.007, seed=21)
-    p2, j2, x2 = rand_csr(4000, 3000, 0.007, seed=22)
-    assert 12 * j.size + 12 * j2.size > (1 << 20)
+    # operands of ~3 MB each: the regular path, whose results wait in pooled device blocks between begin and finish (the
+    # small path of calls under ~2 MiB keeps its result in the handle itself and is covered by the second half below)
+    p, j, x = rand_csr(8000, 3000, 0.011, seed=21)
+    p2, j2, x2 = rand_csr(8000, 3000, 0.011, seed=22)
+    assert min(12 * j.size, 12 * j2.size) > (5 << 19)
     sp, sj, sx, sp2, sj2, sx2 = R.integer(p), R.integer(j), R.real(x), R.integer(p2), R.integer(j2), R.real(x2)
     rows = R.integer(np.array([4, 4, 9], dtype=np.int32))
     call(R, "add_csr_elemwise", sp, sp2, sj, sj2, sx, sx2, R.logical([0]))           # warm: cache entries, scratch

@@ -1,4 +1,4 @@
-"""The small-call path of the exports (csrc/api.hip SmallStage: operands + result within 512 KiB go up in one pinned block,
+"""The small-call path of the exports (csrc/api.hip SmallStage: operands + result within ~2 MiB (SpMM 6, merges 3) go up in one pinned block,
 the SAME kernels run, the result comes down in one copy, one synchronisation): the reference's own test sizes
 (tests/testthat/test-matmul.R:108-114: 100 x 50 density .4 times 50 x 20; test-slice.R:6-16: 1000 x 500) take it —
 mx_get_option("small_calls") counts — and return what the regular path returns: bit for bit for every structure / value
@@ -103,16 +103,16 @@ def test_small_row_gathers_take_the_small_path_or_fall_back(gpu):
 
 def test_operands_above_the_limit_take_the_regular_path(gpu):
     lib = gpu.load()
-    p, j, x = rand_csr(3000, 4000, 0.005, seed=2)            # ~60k entries: 720 KB of CSR
-    assert 12 * j.size > (512 << 10)
+    p, j, x = rand_csr(6000, 4000, 0.009, seed=2)            # ~216k entries: 2.6 MB of CSR (SpMV's limit: 2 MiB)
+    assert 12 * j.size > (2 << 20)
     v = np.random.default_rng(0).normal(size=4000)
     c0 = _count(lib)
     g = G.matmul_csr_dvec_numeric(p, j, x, v, 1)
     assert _count(lib) == c0
     np.testing.assert_allclose(g, O.matmul_csr_dvec_numeric(p, j, x, v), rtol=1e-12, atol=1e-12)
     # just under the limit: the block's offsets are 256-byte aligned, the last result element must still arrive
-    p2, j2, x2 = rand_csr(2000, 3000, 0.006, seed=4)
-    assert 12 * j2.size + 8 * 5000 < (512 << 10)
+    p2, j2, x2 = rand_csr(5000, 3000, 0.011, seed=4)
+    assert (2 << 20) - (96 << 10) < 12 * j2.size + 4 * 5001 + 8 * 3000 + 8 * 5000 < (2 << 20)
     g2 = G.matmul_csr_dvec_numeric(p2, j2, x2, v[:3000], 1)
     assert _count(lib) == c0 + 1
     np.testing.assert_allclose(g2, O.matmul_csr_dvec_numeric(p2, j2, x2, v[:3000]), rtol=1e-12, atol=1e-12)

@@ -25,3 +25,12 @@ def test_structure_fuzz_short(gpu):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "fuzz OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_r_shim_fuzz_short(gpu):
+    """tools/fuzz_r_shim.py: edge shapes through the `.Call` shim by routine name on the mock R runtime (gctorture on)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_r_shim.py"), "6", "31"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "shim fuzz OK" in r.stdout

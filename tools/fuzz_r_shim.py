@@ -148,6 +148,57 @@ while time.time() < t_end:
             assert R.view(R.call(what, sr)).tolist() == [int(O.check_is_seq(rows))], what
             what = "check_is_rev_seq"
             assert R.view(R.call(what, sr)).tolist() == [int(O.check_is_rev_seq(rows))], what
+        # ---- the widened rows: column slices, reversals, cbind, sparse vector, dense elemwise, sort, drop zeros
+        if m:
+            rows = rng.integers(0, m, size=int(rng.choice([1, 3, m + 2]))).astype(np.int32)
+            sr = R.integer(rows)
+            c0 = int(rng.integers(0, K)); c1 = int(rng.integers(c0, K))
+            cols, index1 = (np.arange(c0, c1 + 1, dtype=np.int32), False) if rng.random() < 0.5 else (np.arange(c1, c0 - 1, -1, dtype=np.int32), False)
+            sc, si = R.integer(cols), R.logical([int(index1)])
+            what = "copy_csr_rows_col_seq_numeric"
+            eq_list(R.call(what, sp, sj, sx, sr, sc, si), O.copy_csr_rows_col_seq_numeric(p, j, x, rows, cols, index1), what)
+            what = "copy_csr_rows_col_seq_binary"
+            eq_list(R.call(what, sp, sj, sr, sc, si), O.copy_csr_rows_col_seq_binary(p, j, rows, cols, index1), what)
+            acols = rng.integers(0, K, size=int(rng.choice([1, 2, K + 3]))).astype(np.int32)
+            what = "copy_csr_arbitrary_numeric"
+            eq_list(R.call(what, sp, sj, sx, sr, R.integer(acols)), O.copy_csr_arbitrary_numeric(p, j, x, rows, acols), what)
+            what = "copy_csr_arbitrary_logical"
+            eq_list(R.call(what, sp, sj, sxl, sr, R.integer(acols)), O.copy_csr_arbitrary_logical(p, j, xl, rows, acols), what)
+            what = "reverse_rows_numeric"
+            eq_list(R.call(what, sp, sj, sx), O.reverse_rows_numeric(p, j, x), what)
+            what = "reverse_columns_inplace_numeric"
+            jj, vv = j.copy(), x.copy()
+            O.reverse_columns_inplace(p, jj, vv, K)
+            tj, tv = R.integer(j), R.real(x)
+            assert R.call(what, sp, tj, tv, R.integer([K])) is None, what
+            eq(R.view(tj), jj, what); eq(R.view(tv), vv, what)
+            what = "cbind_csr_numeric"
+            pb, jb, xb = rand_csr(m, 5, float(rng.choice([0.0, 0.4])), seed=s + 2)
+            jbs = (jb + K).astype(np.int32)
+            eq_list(R.call(what, sp, sj, sx, R.integer(pb), R.integer(jbs), R.real(xb)), O.cbind_csr_numeric(p, j, x, pb, jbs, xb), what)
+            what = "matmul_csr_svec_numeric"
+            ny = int(rng.integers(0, K + 1))
+            yi = (np.sort(rng.permutation(K)[:ny]) + 1).astype(np.int32)
+            yv = rng.normal(size=ny)
+            if ny:
+                close(R.view(R.call(what, sp, sj, R.real(xf), R.integer(yi), R.real(yv), one)), O.matmul_csr_svec_numeric(p, j, xf, yi, yv), what, 1e-11)
+            what = "multiply_csr_by_dense_elemwise_double"
+            Dm = rng.normal(size=(m, K))
+            eq(R.view(R.call(what, sp, sj, sx, R.matrix(Dm))), O.multiply_csr_by_dense_elemwise_double(p, j, x, Dm), what)
+            what = "sort_sparse_indices_numeric"
+            pu, ju, xu = rand_csr(m, K, d, seed=s + 3, sorted_cols=False)
+            wj, wv = O.sort_sparse_indices(pu, ju, xu)
+            tj, tv = R.integer(ju), R.real(xu)
+            assert R.call(what, R.integer(pu), tj, tv) is None, what
+            eq(R.view(tj), wj, what); eq(R.view(tv), wv, what)
+            what = "check_indices_are_unsorted"
+            assert R.view(R.call(what, R.integer(pu), R.integer(ju))).tolist() == [int(O.check_indices_are_sorted(pu, ju))], what
+            what = "remove_zero_valued_csr_numeric"
+            xz = x.copy()
+            if xz.size:
+                xz[rng.random(xz.size) < 0.3] = 0.0
+            na = bool(rng.integers(2))
+            eq_list(R.call(what, sp, sj, R.real(xz), R.logical([int(na)])), O.remove_zero_valued_csr_numeric(p, j, xz, na), what)
         R.check_clean()
         for o in made:
             R_L.rmock_release(o)

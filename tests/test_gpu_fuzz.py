@@ -34,3 +34,12 @@ def test_r_shim_fuzz_short(gpu):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "shim fuzz OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sharded_export_fuzz_short(gpu):
+    """tools/fuzz_sharded.py: random geometry of the sharded export (this GPU listed 1 .. 8 times) against the unsharded call"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_sharded.py"), "8", "41"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "sharded fuzz OK" in r.stdout

@@ -134,7 +134,10 @@ static AutoCost spmm_auto_cost(int m, int n, int K, int64_t nnz, int sz, bool ke
     // HBM traffic at ~5 TB/s beyond (m = 1e6: 4 panels = 7 x 1 GB more: 7.4 ms measured where one panel's model said 5.5)
     const double c_bytes = (double)m * n * sz;
     const double c_traffic_us = c_bytes > 128e6 ? (2.0 * c.panels - 2.0) * c_bytes / 5e6 : 0.0;
-    c.rowsplit_us = (double)nnz * n * sz / rate(b_bytes / c.panels, lanes_rate, 8.5) + 0.2e-3 * m * c.panels * passes +
+    // the row-group form carries 64 / G rows per wavefront: that much less per-row cost
+    const int vec = 16 / sz;
+    const double rows_per_wave = rowsplit_segments(m, n, sz, avg / c.panels) == 0 ? (n <= 8 * vec ? 8.0 : (n <= 16 * vec ? 4.0 : 2.0)) : 1.0;
+    c.rowsplit_us = (double)nnz * n * sz / rate(b_bytes / c.panels, lanes_rate, 8.5) + 0.2e-3 * m * c.panels * passes / rows_per_wave +
                     4.0 * c.panels + 4.0 + c_traffic_us;
     const double plan_panels = std::max(1.0, std::ceil((double)K * 128.0 / 2.5e6));
     // the sweep's persistent grid fills with the number of (octet of 64 rows, slab) pairs: 1,563 of them (m = 1e5, one slab)
@@ -160,7 +163,9 @@ static int spmm_auto_algo(int m, int n, int K, int64_t nnz, int dense_dtype, con
     // one 128-byte slab, a handful of entries per row, a slab-panel of B that fits L2: 8 lanes per row and 8 rows per
     // wavefront (the slab kernel's shape) beat one wavefront per row and a plan that costs more than the product
     // (m = 1e6, 8 entries per row, n = 16: slab 0.096 ms, planned rebuilt 0.164, row-split 0.296; plan kept 0.064)
-    if (!keep_plan && n * sz <= 128 && nnz <= 16LL * m && (double)K * 128.0 <= 2.5e6) return MX_SPMM_SLAB;
+    // — unless the row-split kernel's row-group form applies (round 4, later: 0.061 ms there, and bit for bit the reference's sums)
+    if (!keep_plan && n * sz <= 128 && nnz <= 16LL * m && (double)K * 128.0 <= 2.5e6 &&
+        rowsplit_segments(m, n, sz, (double)nnz / m) != 0) return MX_SPMM_SLAB;
     const AutoCost c = spmm_auto_cost(m, n, K, nnz, sz, keep_plan);
     return c.planned_us < c.rowsplit_us ? MX_SPMM_PLANNED : MX_SPMM_ROWSPLIT;
 }
@@ -185,12 +190,14 @@ static int run_rowsplit(int m, int n, int K, int64_t nnz, int segments, int pane
 {
     (void)rows_sorted_hint;                    // (the cursor kernel checks every row itself)
     const int sz = dense_dtype == MX_F64 ? 8 : 4;
-    if (segments <= 0 || panels <= 0) {
+    // segments: 1 / 2 / 4 / 8 wavefronts per row, -1 = the row-group form (several rows per wavefront), 0 = chosen here
+    if (segments == 0 || panels <= 0) {
         if (nnz < 0 && device_nnz(indptr, m, st, &nnz)) return 1;
         const double avg = m > 0 ? (double)nnz / m : 0.0;
         if (panels <= 0) panels = rowsplit_panels(m, n, K, sz, avg);
-        if (segments <= 0) segments = rowsplit_segments(m, n, sz, avg / panels);
+        if (segments == 0) segments = rowsplit_segments(m, n, sz, avg / panels);
     }
+    if (segments < 0) segments = 0;           // rowsplit_spmm's code for the row-group form
     set_last_spmm_kernel("spmm_rowsplit_kernel");
     if (dense_dtype == MX_F64)
         return rowsplit_spmm<double>(m, n, K, segments, panels, indptr, indices, values, (const double *)B, ldb, (double *)C, ldc, colmajor, st);

@@ -227,6 +227,108 @@ void spmm_rowsplit_kernel(int m, int n, int S,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// ROW GROUPS: the form for MANY SHORT rows against a narrow B (m = 1e6, 8-32 entries per row, n = 16-64: sparse features
+// times a small weight matrix).  One wavefront per row is then 1e6 wavefronts of a few instructions each, most lanes idle
+// in the (j, a) load and a butterfly at the end (0.28-0.36 ms where the bytes ask for 0.10-0.15).  Here the G lanes that own
+// a row of B also own ONE ROW OF A: a wavefront carries 64 / G rows at once, group g walks its own row G entries at a time
+// (lane l of the group loads entry k0 + l, every entry is handed round the group by ds_bpermute), one load instruction
+// reads one row of B for each of the 64 / G rows, U of them in flight.  A row's terms are added by its own group in
+// storage order: bit for bit the reference's FMA chain (src/matmul.cpp:118-142), column panels included for row-major C.
+// Row-major C: each group stores its G * 16 bytes; column-major C: the workgroup's 8 * 64 / G rows go through an LDS tile
+// and leave as column segments of that many consecutive rows.
+template <typename real_t, int VEC, int G, bool COLMAJOR>
+__global__ __launch_bounds__(RS_WAVES * MX_WAVE)
+void spmm_rowgroup_kernel(int m, int n,
+                          const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                          const double *__restrict__ values,
+                          const int32_t *__restrict__ lo, const int32_t *__restrict__ hi, int accumulate,
+                          const real_t *__restrict__ B, size_t ldb,
+                          real_t *__restrict__ C, size_t ldc)
+{
+    static_assert(G < MX_WAVE, "one row per wavefront is the row-split form");
+    constexpr int NG = MX_WAVE / G;           // rows per wavefront
+    constexpr int RW = RS_WAVES * NG;         // rows per workgroup
+    constexpr int W = G * VEC;                // output columns per pass
+    constexpr int LS = W + 1;
+    constexpr int U = G < 8 ? G : 8;          // B-row reads in flight per lane
+    __shared__ real_t tile[COLMAJOR ? RW * LS : 1];
+
+    const int lane = lane_id();
+    const int wave = uniform(threadIdx.x / MX_WAVE);
+    const int g = lane / G, lg = lane % G, gbase = g * G;
+    const int row0 = blockIdx.x * RW;
+    const int row = row0 + wave * NG + g;
+    const int c0 = blockIdx.y * W;
+    const int col = c0 + lg * VEC;
+    const bool active = col < n;
+    const unsigned lcol = active ? (unsigned)col : (unsigned)(n - VEC);
+
+    real_t acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) acc[v] = 0;
+    int s = 0, e = 0;
+    if (row < m) {
+        s = lo ? lo[row] : indptr[row];
+        e = hi ? hi[row] : indptr[row + 1];
+        if (!COLMAJOR && accumulate && active) vload<real_t, VEC>(acc, C + (size_t)row * ldc + col);
+    }
+    // the wavefront runs as long as its longest row (wave-uniform trip count, full EXEC for the permutes); a group whose
+    // row has ended re-reads row 0 of B (valid memory, in cache) and drops the products by a select
+    int len = e - s;
+#pragma unroll
+    for (int off = G; off < MX_WAVE; off <<= 1) len = max(len, __shfl_xor(len, off, MX_WAVE));
+    const int longest = uniform(__shfl(len, 0, MX_WAVE));
+    const int trips = (longest + G - 1) / G;
+    int jv = 0;
+    double av = 0.0;
+    if (s + lg < e) { jv = indices[s + lg]; av = values[s + lg]; }
+    for (int t = 0; t < trips; t++) {
+        const int k0 = s + t * G;
+        int jn = 0;
+        double an = 0.0;                        // the next G entries of the row are in flight while these stream B
+        if (k0 + G + lg < e) { jn = indices[k0 + G + lg]; an = values[k0 + G + lg]; }
+        const int cnt = min(G, max(e - k0, 0));
+        const int most = longest - t * G;       // wave-uniform: entries the longest row still has in this trip
+#pragma unroll
+        for (int q = 0; q < G; q += U) {
+            if (q >= most) break;               // (rows shorter than the group: no batch of reads that nobody needs)
+            int jj[U];
+            real_t bb[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; u++) jj[u] = __builtin_amdgcn_ds_bpermute((gbase + (q + u < cnt ? q + u : 0)) << 2, jv);
+#pragma unroll
+            for (int u = 0; u < U; u++) vload<real_t, VEC>(bb[u], B + (size_t)jj[u] * ldb + lcol);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const real_t x = (real_t)bperm_f64(av, gbase + (q + u < cnt ? q + u : 0));   // narrowed per entry for f32
+#pragma unroll
+                for (int v = 0; v < VEC; v++) acc[v] = q + u < cnt ? mx_fma(x, bb[u][v], acc[v]) : acc[v];
+            }
+        }
+        jv = jn; av = an;
+    }
+
+    if constexpr (!COLMAJOR) {
+        if (row < m && active) vstore<real_t, VEC>(C + (size_t)row * ldc + col, acc);
+    } else {
+        real_t *tl = tile + (wave * NG + g) * LS + lg * VEC;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) tl[v] = acc[v];
+        __syncthreads();
+        const int ncols = min(W, n - c0);
+        const int total = RW * ncols;
+        for (int idx = threadIdx.x; idx < total; idx += RS_WAVES * MX_WAVE) {
+            const int r = idx % RW, c = idx / RW;               // consecutive threads: consecutive rows of one column
+            if (row0 + r >= m) continue;
+            real_t *dst = C + (size_t)(c0 + c) * ldc + row0 + r;
+            real_t sum = tile[r * LS + c];
+            if (accumulate) sum = *dst + sum;
+            *dst = sum;
+        }
+    }
+}
+
 // cursors[p * m + row], p = 0 .. P: where panel p's entries of `row` begin (panel p = columns [p * panel_cols, (p + 1) *
 // panel_cols)).  One wavefront per row: is the row sorted by column? (the same test as check_is_sorted, src/misc.cpp:118-128)
 // — then lanes 1 .. P - 1 each find one bound by binary search; otherwise panel 0 takes the whole row.
@@ -249,16 +351,33 @@ void rowsplit_cursors_kernel(int m, int P, int panel_cols, const int32_t *__rest
     }
 }
 
+// S = 0: the row-group form (several rows per wavefront, G < 64)
+template <typename real_t, int VEC, int G, bool COLMAJOR>
+static void launch_one(int m, int n, int S, dim3 grid, const int32_t *indptr, const int32_t *indices, const double *values,
+                       const int32_t *lo, const int32_t *hi, int accumulate, const real_t *B, size_t ldb, real_t *C, size_t ldc,
+                       hipStream_t stream)
+{
+    if constexpr (G < MX_WAVE) {
+        if (S == 0) {
+            hipLaunchKernelGGL((spmm_rowgroup_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
+                               m, n, indptr, indices, values, lo, hi, accumulate, B, ldb, C, ldc);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((spmm_rowsplit_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
+                       m, n, S, indptr, indices, values, lo, hi, accumulate, B, ldb, C, ldc);
+}
+
 template <typename real_t, int VEC, int G, bool COLMAJOR>
 static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
                            const real_t *B, size_t ldb, real_t *C, size_t ldc, hipStream_t stream)
 {
     constexpr int W = G * VEC;
-    dim3 grid((unsigned)ceil_div(m, RS_WAVES / S), (unsigned)ceil_div(n, W));
+    if (S == 0 && G == MX_WAVE) S = 1;                      // rows of B that fill the wavefront: one row per wavefront anyway
+    dim3 grid((unsigned)ceil_div(m, S == 0 ? RS_WAVES * (MX_WAVE / G) : RS_WAVES / S), (unsigned)ceil_div(n, W));
     if (P <= 1) {
         kt_begin(stream);
-        hipLaunchKernelGGL((spmm_rowsplit_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
-                           m, n, S, indptr, indices, values, (const int32_t *)nullptr, (const int32_t *)nullptr, 0, B, ldb, C, ldc);
+        launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, grid, indptr, indices, values, nullptr, nullptr, 0, B, ldb, C, ldc, stream);
         kt_end(stream);
         MX_LAUNCH_CHECK();
         return 0;
@@ -272,8 +391,8 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
     hipLaunchKernelGGL(rowsplit_cursors_kernel, dim3((unsigned)ceil_div(m, RS_WAVES)), dim3(RS_WAVES * MX_WAVE), 0, stream,
                        m, P, panel_cols, indptr, indices, cur);
     for (int p = 0; p < P; p++)
-        hipLaunchKernelGGL((spmm_rowsplit_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
-                           m, n, S, indptr, indices, values, cur + (size_t)p * m, cur + (size_t)(p + 1) * m, p > 0 ? 1 : 0, B, ldb, C, ldc);
+        launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, grid, indptr, indices, values, cur + (size_t)p * m, cur + (size_t)(p + 1) * m,
+                                             p > 0 ? 1 : 0, B, ldb, C, ldc, stream);
     scratch_done(MX_SCRATCH_ROWSPLIT, stream);
     kt_end(stream);
     MX_LAUNCH_CHECK();
@@ -318,8 +437,21 @@ int rowsplit_panels(int m, int n, int K, int dense_bytes, double avg_len)
 // a segment keeps a full chunk of 64 entries.  Splitting costs the LDS combine and the direct store path: measured on the
 // vignette's shape (m = 1e4, 500 per row, n = 100, one panel) S = 1 / 2 / 4 / 8 = 0.193 / 0.220 / 0.282 / 0.285 ms — one
 // wavefront per row wins as soon as there are ~4k rows (tools/rowsplit_sweep.py; round 4's first rule split up to 32k rows)
+//
+// 0 = the ROW-GROUP form (several rows per wavefront) for many short rows against a narrow B — measured against one
+// wavefront per row at m = 1e6, K = 1e4 (tools/rowgroup_probe.py, ms, f64): n = 16 (8 lanes per row), 8 / 16 / 32 / 48 / 64
+// entries per row: 0.061 / 0.148 / 0.267 / 0.439 / 0.564 against 0.301 / 0.346 / 0.345 / 0.491 / 0.520; n = 32 (16 lanes),
+// 8 / 32 / 48: 0.164 / 0.454 / 0.702 against 0.334 / 0.478 / 0.663; n = 64 (32 lanes), 8 / 16 / 32 / 64: 0.348 / 0.549 /
+// 0.891 / 1.695 against 0.520 / 0.585 / 0.889 / 1.627 — i.e. up to 56 / 40 / 24 entries per row with 8 / 16 / 32 lanes,
+// and only when the rows still fill the machine's wavefront slots at 64 / G rows per wavefront.
 int rowsplit_segments(int m, int n, int dense_bytes, double avg_len)
 {
+    {
+        const int vec = 16 / dense_bytes;
+        const int G = n <= 8 * vec ? 8 : (n <= 16 * vec ? 16 : (n <= 32 * vec ? 32 : 64));
+        const double limit = G == 8 ? 56.0 : (G == 16 ? 40.0 : 24.0);
+        if (G < 64 && n % vec == 0 && avg_len <= limit && (long long)m * G >= 8192LL * 64) return 0;
+    }
     const int W = 64 * (16 / dense_bytes);
     const long long passes = (n + W - 1) / W;
     int S = 1;
@@ -332,12 +464,14 @@ int rowsplit_spmm(int m, int n, int K, int S, int P, const int32_t *indptr, cons
                   const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream)
 {
     constexpr int VECMAX = 16 / (int)sizeof(real_t);
-    if (S != 1 && S != 2 && S != 4 && S != 8) return set_error("rowsplit_spmm: segments per row must be 1, 2, 4 or 8 (got %d)", S);
+    if (S != 0 && S != 1 && S != 2 && S != 4 && S != 8)
+        return set_error("rowsplit_spmm: segments per row must be 1, 2, 4 or 8, or 0 for the row-group form (got %d)", S);
     if (P < 1 || P > RS_MAX_PANELS) return set_error("rowsplit_spmm: 1 .. %d column panels (got %d)", RS_MAX_PANELS, P);
     // widest per-lane access the operands allow (16 B when the rows of B are 16-B aligned); row-major C is read / written
     // by vector accesses only on the S = 1 path, which needs its rows aligned as well
     const bool b_vec = (n % VECMAX == 0) && (ldb % VECMAX == 0) && ((uintptr_t)B % 16 == 0);
     const bool c_vec = colmajor || S > 1 || ((ldc % VECMAX == 0) && ((uintptr_t)C % 16 == 0));
+    if (S == 0 && !(b_vec && c_vec)) S = 1;                 // (the row-group form needs the 16-byte accesses)
     if (b_vec && c_vec)
         return colmajor ? pick_group_rowsplit<real_t, VECMAX, true>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, stream)
                         : pick_group_rowsplit<real_t, VECMAX, false>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, stream);

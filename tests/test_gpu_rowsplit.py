@@ -168,3 +168,75 @@ def test_auto_takes_the_rowsplit_kernel_for_the_published_workload(gpu):
     assert lib.mxd_spmm_last_kernel() == b"spmm_rowsplit_kernel"
     ref = O.matmul_dense_csc(X, pc, ic, xc, O.max_threads(), False)
     np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------------------ the row-group form
+ROWGROUPS = -1          # wg_per_cu = -1: G lanes own one row of A, 64 / G rows per wavefront (spmm_rowgroup_kernel)
+GROUP_SHAPES = [        # m, K, n, density — n <= 32 * VEC so that G < 64 (f64: n <= 64, f32: n <= 128)
+    (1000, 300, 16, 0.03), (1000, 300, 16, 0.3), (517, 90, 8, 0.2), (64, 700, 32, 0.05), (65, 40, 64, 0.5), (7, 64, 2, 1.0),
+    (1, 50, 16, 0.5), (513, 1000, 48, 0.02), (200, 30, 24, 0.4), (129, 2000, 64, 0.01),
+]
+
+
+@pytest.mark.parametrize("colmajor", [False, True])
+@pytest.mark.parametrize("m,K,n,dens", GROUP_SHAPES)
+def test_rowgroup_form_is_the_storage_order_fma_chain_f64(gpu, m, K, n, dens, colmajor):
+    """every row is summed by its own lane group in storage order: bit for bit gemm_csr_drm_as_drm's chain with fused
+    multiply-add (src/matmul.cpp:118-142) — unsorted rows, duplicate column ids, empty rows, rows longer than a group,
+    Inf / NaN in A (entries past a row's end are dropped by a select, never multiplied in)"""
+    p, j, x = rand_csr(m, K, dens, seed=3 * m + n, sorted_cols=False, empty_rows=(0, m // 2, m - 1) if m > 4 else ())
+    if x.size > 10:
+        x[1], x[x.size // 2], x[-2] = np.inf, np.nan, -np.inf
+    if j.size > 6:
+        j[3] = j[2]                                              # a repeated column id (may cross a row boundary: harmless)
+    B = np.random.default_rng(n).normal(size=(K, n))
+    got = _run(p, j, x, B, colmajor, ROWGROUPS)
+    ref = _oracle(p, j, x, B, True)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    np.testing.assert_array_equal(got[ok], ref[ok])
+    np.testing.assert_array_equal(np.nan_to_num(got), np.nan_to_num(_run(p, j, x, B, colmajor, ROWGROUPS)))
+
+
+@pytest.mark.parametrize("colmajor", [False, True])
+@pytest.mark.parametrize("m,K,n,dens", GROUP_SHAPES[:8] + [(300, 500, 128, 0.05), (90, 200, 96, 0.2)])
+def test_rowgroup_form_f32(gpu, m, K, n, dens, colmajor):
+    p, j, x = rand_csr(m, K, dens, seed=m + 7 * n, sorted_cols=True, empty_rows=(0,) if m > 4 else ())
+    B = np.random.default_rng(n).normal(size=(K, n)).astype(np.float32)
+    got = _run(p, j, x, B, colmajor, ROWGROUPS)
+    assert got.dtype == np.float32
+    if n % 4 == 0:                      # 16-byte rows of B: the row-group kernel itself — the f32 chain with alpha narrowed per entry
+        np.testing.assert_array_equal(got, _oracle(p, j, x, B, True))
+    else:                               # otherwise the call falls back to one wavefront per row (scalar accesses)
+        np.testing.assert_allclose(got, _oracle(p, j, x, B, False), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("P", [2, 5])
+@pytest.mark.parametrize("colmajor", [False, True])
+def test_rowgroup_form_with_column_panels(gpu, colmajor, P):
+    """forced panels: launch p continues from what launch p - 1 left in C — for row-major C the chain itself (bitwise)"""
+    m, K, n = 700, 3000, 16
+    p, j, x = rand_csr(m, K, 0.02, seed=4, sorted_cols=True, empty_rows=(0, 5))
+    B = np.random.default_rng(2).normal(size=(K, n))
+    got = _run(p, j, x, B, colmajor, ROWGROUPS, P)
+    if not colmajor:
+        np.testing.assert_array_equal(got, _oracle(p, j, x, B, True))
+    else:
+        np.testing.assert_allclose(got, _oracle(p, j, x, B, False), rtol=1e-12, atol=1e-12)
+
+
+def test_auto_takes_the_rowgroup_form_for_many_short_rows(gpu):
+    """m = 2e5 rows of 12 entries against a 16-column B: AUTO -> row-split family -> the row-group form; the result is the
+    storage-order chain bit for bit, whatever form the heuristic took"""
+    import torch
+    from matrixextra_amd import device as D
+    m, K, n = 200_000, 5000, 16
+    p, j, x = synth.csr_fixed(m, K, 12, seed=8)
+    A = D.DeviceCSR.from_host(p, j, x, K)
+    B = synth.dense_normal(K, n, seed=9)
+    got = D.spmm(A, torch.from_numpy(B).cuda(), keep_plan=False).cpu().numpy()
+    assert _lib.load().mxd_spmm_last_kernel().decode() == "spmm_rowsplit_kernel"
+    rows = np.r_[0:300, m - 300:m]
+    pp = np.concatenate([[0], np.cumsum(np.diff(p)[rows])]).astype(np.int32)
+    sel = np.concatenate([np.arange(p[r], p[r + 1]) for r in rows])
+    np.testing.assert_array_equal(got[rows], _oracle(pp, j[sel], x[sel], B, True))

@@ -61,7 +61,7 @@ while time.time() < t_end:
                 if nnz:
                     np.add.at(ref, np.repeat(np.arange(m), lens), x[:, None] * B[j].astype(np.float64))
             got = spmm_device(p.astype(np.int32), j, x, B, colmajor, 4, 0, npanels=int(rng.choice([0, 1, 2, 3, 7, 32])),
-                              wg_per_cu=int(rng.choice([0, 1, 2, 4, 8])))
+                              wg_per_cu=int(rng.choice([0, 1, 2, 4, 8, -1, -1])))   # -1: the row-group form
         else:
             got = spmm_device(p.astype(np.int32), j, x, B, colmajor, 0 if which == "auto" else 1, 0)
         np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * 100)

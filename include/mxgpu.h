@@ -189,8 +189,13 @@ int mxd_spmm_csr_dense(int m, int n,
  *                          When B outgrows an XCD's L2 the product runs as `npanels` launches over column panels of
  *                          ~2.5 MB of B (rows sorted by column are cut at the panel bounds by a cursor kernel; a row that is
  *                          not sorted is taken whole by the first launch — always correct).  npanels = column panels
- *                          (1 .. 32), wg_per_cu = segments per row (1, 2, 4, 8); <= 0: chosen from the shape and the mean
- *                          row length
+ *                          (1 .. 32), wg_per_cu = segments per row (1, 2, 4, 8); 0: chosen from the shape and the mean
+ *                          row length.  wg_per_cu = -1: the ROW-GROUP form for many short rows against a narrow B (rows of
+ *                          B of at most 512 bytes): the G lanes that own a row of B own one row of A, a wavefront carries
+ *                          64 / G rows, every row is summed by its own group in storage order — bit for bit the reference's
+ *                          FMA chain in both layouts; what wg_per_cu = 0 picks up to 56 / 40 / 24 entries per row with
+ *                          8 / 16 / 32 lanes per row (falls back to one wavefront per row when B's rows are not 16-byte
+ *                          aligned or fill the wavefront)
  * mxd_spmm_csr_dense_ex2: the same with nnz = the number of entries of A (indptr[m] - indptr[0]) when the caller knows it;
  * -1 = unknown (ROWSPLIT then reads indptr[m] from the device: one 4-byte copy and a stream sync). */
 typedef enum { MX_SPMM_AUTO = 0, MX_SPMM_ROWWAVE = 1, MX_SPMM_SLAB = 2, MX_SPMM_PLANNED = 3, MX_SPMM_ROWSPLIT = 4 } mx_spmm_algo;
@@ -231,7 +236,7 @@ int mxd_spmm_plan_run_rows(const mx_spmm_plan *plan, int row0, int nrows, int n,
 int mxd_spmm_auto_algo(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
                        int colmajor_out, int *algo);
 /* ... with the entry count (-1 = unknown: the rule above) and whether the caller keeps a plan across products: a cost model of
- * the row-split kernel and the planned sweep fitted to a map of 228 shapes (tools/auto_map.py, profiles/r04_auto_map.json;
+ * the row-split kernel and the planned sweep fitted to a map of 272 shapes (tools/auto_map.py, profiles/r04_auto_map.json;
  * csrc/spmm.hip spmm_auto_cost) chooses between MX_SPMM_ROWSPLIT, _PLANNED and, for one-slab products of very short rows,
  * _SLAB; products below 2^22 multiply-adds stay on MX_SPMM_ROWWAVE.  mxd_spmm_auto_cost: the model's two estimates. */
 int mxd_spmm_auto_algo2(int m, int n, int K, int64_t nnz /* -1 = unknown */, int keep_plan, int dense_dtype, const void *B,

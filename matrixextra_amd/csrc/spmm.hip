@@ -97,7 +97,7 @@ extern "C" const char *mxd_spmm_last_kernel(void) { return mx::g_last_spmm_kerne
 
 namespace mx {
 // AUTO's choice, in one place.  Rounds 1-3 had one rule (PLANNED when B outgrows an XCD's L2 and m * n >= 2^24, else
-// ROWWAVE) read off the headline configuration; round 4 mapped every kernel over 228 shapes between the benchmarks
+// ROWWAVE) read off the headline configuration; round 4 mapped every kernel over 228 (later 272) shapes between the benchmarks
 // (tools/auto_map.py -> profiles/r04_auto_map.json) and replaced it by a small cost model of the two kernels that
 // matter there — the row-split kernel (column panels by launches) and the planned panel sweep — in the quantities that
 // bound them on MI355X:
@@ -105,8 +105,10 @@ namespace mx {
 //     work on fits it (~28 TB/s of line reads measured in the row-split kernel, 17 with 8-lane groups; 23.5 TB/s in the
 //     planned sweep with one panel, 19 TB/s with several), the Infinity Cache otherwise (~8.5 TB/s); a uniformly gathered
 //     panel of T bytes hits L2 with probability 4 MiB / T (guide: "Indexed rows: gather into LDS");
-//   * the row-split kernel pays ~0.2 ns per (row, panel, column pass) — one wavefront each — and a few us per launch;
-//     the planned kernel ~0.01 ns per (row, slab, panel), ~15 us of fixed cost per run, and, when the plan is not kept,
+//   * the row-split kernel pays ~0.2 ns per (row, panel, column pass) — one wavefront each; its row-group form, several
+//     rows per wavefront, 0 - 0.15 ns — and ~6 us per launch (rowsplit_est_us, spmm_rowsplit.hip, which also decides
+//     between the panels its sizes suggest and none);
+//     the planned kernel ~0.005 ns per (row, slab, panel), ~15 us of fixed cost per run, and, when the plan is not kept,
 //     ~36 us + 6 ps per entry to build it; its persistent grid fills with (octet of 64 rows, slab) pairs — rate x
 //     pairs / (pairs + 2400) — and below 32k rows it is never chosen (at m = 1e4 the row-split kernel won 38 of 40
 //     points, the other two within 18 %).
@@ -117,35 +119,22 @@ struct AutoCost { double rowsplit_us, planned_us; int panels; };
 static AutoCost spmm_auto_cost(int m, int n, int K, int64_t nnz, int sz, bool keep_plan)
 {
     const double avg = m > 0 ? (double)nnz / m : 0.0;
-    const int W = 64 * (16 / sz);
-    const double passes = (double)((n + W - 1) / W);
     const int cols_per_line = 128 / sz;
     const double slabs = (double)((n + cols_per_line - 1) / cols_per_line);
-    const double b_bytes = (double)K * n * sz;
     auto rate = [](double panel_bytes, double l2_rate, double mall_rate) {     // bytes per us
         const double hit = panel_bytes <= 3.5e6 ? 1.0 : (4.0 * 1048576.0) / panel_bytes;
         return 1e6 / (hit / l2_rate + (1.0 - hit) / mall_rate);
     };
     AutoCost c;
     c.panels = rowsplit_panels(m, n, K, sz, avg);
-    const bool one_line = n * sz <= 128;                                       // 8-lane groups: 17 TB/s measured, and a
-    const double lanes_rate = one_line ? 17.0 : 28.0;                          // wavefront per row costs half as much
-    // every launch after the first reads and rewrites C: free while C lives in the Infinity Cache (m = 1e5, n = 128: 0.1 GB),
-    // HBM traffic at ~5 TB/s beyond (m = 1e6: 4 panels = 7 x 1 GB more: 7.4 ms measured where one panel's model said 5.5)
-    const double c_bytes = (double)m * n * sz;
-    const double c_traffic_us = c_bytes > 128e6 ? (2.0 * c.panels - 2.0) * c_bytes / 5e6 : 0.0;
-    // the row-group form carries 64 / G rows per wavefront: that much less per-row cost
-    const int vec = 16 / sz;
-    const double rows_per_wave = rowsplit_segments(m, n, sz, avg / c.panels) == 0 ? (n <= 8 * vec ? 8.0 : (n <= 16 * vec ? 4.0 : 2.0)) : 1.0;
-    c.rowsplit_us = (double)nnz * n * sz / rate(b_bytes / c.panels, lanes_rate, 8.5) + 0.2e-3 * m * c.panels * passes / rows_per_wave +
-                    4.0 * c.panels + 4.0 + c_traffic_us;
+    c.rowsplit_us = rowsplit_est_us(m, n, K, sz, avg, c.panels);        // (spmm_rowsplit.hip: the model next to the heuristics it prices)
     const double plan_panels = std::max(1.0, std::ceil((double)K * 128.0 / 2.5e6));
     // the sweep's persistent grid fills with the number of (octet of 64 rows, slab) pairs: 1,563 of them (m = 1e5, one slab)
     // ran at 9 TB/s, 6,250 at 17.7, 12,500 at 19, 125,000 at 23.8
     const double pairs = std::ceil(m / 64.0) * slabs, fill = pairs / (pairs + 2400.0);
     const double sweep_rate = (plan_panels > 1.0 ? 19.0 : 23.5) * fill;
     c.planned_us = (double)nnz * slabs * 128.0 / rate((double)K * 128.0 / plan_panels, sweep_rate, 8.5 * fill) +
-                   0.01e-3 * m * slabs * plan_panels + 15.0 + (keep_plan ? 0.0 : 36.0 + 6e-6 * (double)nnz);
+                   0.005e-3 * m * slabs * plan_panels + 15.0 + (keep_plan ? 0.0 : 36.0 + 6e-6 * (double)nnz);
     return c;
 }
 static int spmm_auto_algo(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,

@@ -106,6 +106,7 @@ template <typename real_t>
 int rowsplit_spmm(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
                   const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream);
 int rowsplit_segments(int m, int n, int dense_bytes, double avg_len);
+double rowsplit_est_us(int m, int n, int K, int dense_bytes, double avg_len, int P);
 int rowsplit_panels(int m, int n, int K, int dense_bytes, double avg_len);
 
 // ---- spmm_slab.hip

@@ -27,7 +27,9 @@
 //     storage-order FMA chain bit for bit, panels included (the chain continues from the value stored in C); everything
 //     else reassociates (<= 1e-12 relative, the bar of the planned kernel);
 //   * both layouts of C: row-major rows straight from the tile, column-major as 8 / S-row segments per column (C is small
-//     wherever this kernel is chosen).
+//     wherever this kernel is chosen);
+//   * a second form, ROW GROUPS (spmm_rowgroup_kernel below), for the opposite corner — many SHORT rows against a narrow B:
+//     several rows per wavefront, each summed by its own lane group in storage order.
 //
 // Roofline: HBM-bound by the contract's algorithmic bytes; what limits it in practice is the L2 -> L1 gather
 // of nnz * n * s bytes (4 GB for the vignette product), reported as `l2_to_l1_gather` in bench.py.
@@ -417,7 +419,7 @@ static int pick_group_rowsplit(int m, int n, int K, int S, int P, const int32_t 
 // enough entries per panel to pay for a wavefront of its own: 32 when 32 or 64 lanes own a row of B (m = 1e5, K = 1e4,
 // 128 per row, n = 128: 4 panels 0.576 ms, one 0.971), 64 / 96 with 16- / 8-lane groups, whose load instruction covers 4 / 8
 // entries (n = 16, 32 per panel: 2.36 vs 1.75 ms at m = 1e6)
-int rowsplit_panels(int m, int n, int K, int dense_bytes, double avg_len)
+static int rowsplit_panels_by_size(int m, int n, int K, int dense_bytes, double avg_len)
 {
     const double b_bytes = (double)K * n * dense_bytes;
     if (b_bytes < 7e6) return 1;
@@ -431,6 +433,39 @@ int rowsplit_panels(int m, int n, int K, int dense_bytes, double avg_len)
     if (P > by_len) P = by_len;
     if (P > RS_MAX_PANELS) P = RS_MAX_PANELS;
     return P < 1 ? 1 : P;
+}
+
+// What the kernel costs with P column panels, microseconds (the model AUTO compares with the planned sweep's, csrc/spmm.hip;
+// constants fitted to tools/auto_map.py's map, profiles/r04_auto_map.json): the gather of nnz * n * s bytes at the L2 -> L1
+// rate of the lane-group width for the share of a panel an XCD's L2 holds and at the Infinity Cache's for the rest, a cost
+// per (row, panel, pass) wavefront, ~6 us per launch, and — when C outgrows the Infinity Cache — the re-read and re-write
+// of C by every launch after the first.
+double rowsplit_est_us(int m, int n, int K, int dense_bytes, double avg_len, int P)
+{
+    const int sz = dense_bytes, vec = 16 / sz;
+    const double nnz = avg_len * m, b_bytes = (double)K * n * sz, c_bytes = (double)m * n * sz;
+    const double passes = (double)((n + 64 * vec - 1) / (64 * vec));
+    const int G = n <= 8 * vec ? 8 : (n <= 16 * vec ? 16 : (n <= 32 * vec ? 32 : 64));
+    double l2_rate = n * sz <= 128 ? 17.0 : 28.0, mall_rate = 8.5;                // TB/s: 8-lane groups read one line per row of B
+    double row_us = 0.2e-3 * passes;                                              // one wavefront per (row, panel, pass)
+    if (rowsplit_segments(m, n, sz, avg_len / P) == 0) {                          // the row-group form (tools/rowgroup_probe.py)
+        l2_rate = G == 8 ? 18.0 : 21.0;
+        mall_rate = 6.5;
+        row_us = G == 8 ? 0.0 : (G == 16 ? 0.07e-3 : 0.15e-3);
+    }
+    const double panel_bytes = b_bytes / P;
+    const double hit = panel_bytes <= 3.5e6 ? 1.0 : (4.0 * 1048576.0) / panel_bytes;
+    const double rate = 1e6 / (hit / l2_rate + (1.0 - hit) / mall_rate);          // bytes per microsecond
+    const double c_traffic_us = c_bytes > 128e6 ? (2.0 * P - 2.0) * c_bytes / 5e6 : 0.0;
+    return nnz * n * sz / rate + row_us * m * P + 6.0 * P + 4.0 + c_traffic_us;
+}
+// the panel count the sizes suggest, or none at all when the model says that the launches cost more than the locality buys
+// (m = 1e4, K = 1e5, 500 per row, n = 16: five panels 0.078 ms, one 0.059; n = 100: fifteen 0.350, one 0.491)
+int rowsplit_panels(int m, int n, int K, int dense_bytes, double avg_len)
+{
+    const int P = rowsplit_panels_by_size(m, n, K, dense_bytes, avg_len);
+    if (P <= 1) return 1;
+    return rowsplit_est_us(m, n, K, dense_bytes, avg_len, P) < rowsplit_est_us(m, n, K, dense_bytes, avg_len, 1) ? P : 1;
 }
 
 // Segments per row: only when the rows alone cannot fill HALF the machine's wavefront slots (256 CUs x 32), and only while

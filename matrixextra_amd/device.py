@@ -148,7 +148,8 @@ def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajo
     gemm_csr_drm_as_drm layout; colmajor=True: C column-major (what tcrossprod_csr_dense returns to R),
     stored as a row-major (n x m) tensor and returned as its transposed view.
     algo: 0 auto, 1 row-wave kernel, 2 slab/panel kernel, 3 planned (rebuilt per call), 4 row-split kernel — npanels is
-    then the number of segments per row, 0 = chosen from the shape (include/mxgpu.h mx_spmm_algo).
+    then its number of column panels and wg_per_cu the segments per row (1, 2, 4, 8; -1 = the row-group form: several
+    rows per wavefront), 0 = chosen from the shape (include/mxgpu.h mx_spmm_algo).
     keep_plan (algo 0 only): when AUTO picks the planned kernel, the plan — a regrouping of A's entries that depends on A
     alone — is built once and kept on the DeviceCSR (like rows_sorted()); keep_plan=False is the C-ABI's own AUTO, which
     rebuilds the plan from plain CSR inside every call."""

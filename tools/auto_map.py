@@ -79,11 +79,17 @@ def spmm_point(m, K, npr, n, colmajor, dtype, lib):
     run("rowwave", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=1))
     run("rowsplit", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=4))
     run("rowsplit_one_panel", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=4, npanels=1))
+    # the two forms of the row-split kernel forced (one panel): one wavefront per row / several rows per wavefront — the
+    # `rowsplit` leg above runs whichever rowsplit_segments() picks, these show whether it picked right
+    run("rowsplit_wave_per_row", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=4, npanels=1, wg_per_cu=1))
+    if n * B.element_size() <= 512:
+        run("rowsplit_row_groups", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=4, npanels=1, wg_per_cu=-1))
     run("slab", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=2))
     run("planned_kept", lambda: D.spmm_planned(A, B, out=out, colmajor=colmajor))
     run("planned_rebuilt", lambda: D.spmm_planned(A, B, out=out, colmajor=colmajor, rebuild_plan=True))
-    one_shot = {k: v for k, v in ms.items() if v is not None and k in ("rowwave", "rowsplit", "slab", "planned_rebuilt")}
-    kept = {k: v for k, v in ms.items() if v is not None and k in ("rowwave", "rowsplit", "slab", "planned_kept")}
+    forms = ("rowsplit", "rowsplit_one_panel", "rowsplit_wave_per_row", "rowsplit_row_groups")
+    one_shot = {k: v for k, v in ms.items() if v is not None and k in ("rowwave", "slab", "planned_rebuilt") + forms}
+    kept = {k: v for k, v in ms.items() if v is not None and k in ("rowwave", "slab", "planned_kept") + forms}
     best1, bestk = min(one_shot, key=one_shot.get), min(kept, key=kept.get)
     rec = {"m": m, "K": K, "per_row": npr, "n": n, "layout": "col" if colmajor else "row", "dtype": "f64" if dtype == torch.float64 else "f32",
            "ms": ms, "auto_family": {0: "auto", 1: "rowwave", 2: "slab", 3: "planned", 4: "rowsplit"}[pick.value],
@@ -149,7 +155,7 @@ def main():
     lib = _lib.load()
     t0 = time.time()
     doc = {"device": _lib.device_name(), "spmm": [], "spmv": [], "skipped": []}
-    ms_, nprs, ns, Ks = (10_000, 100_000, 1_000_000), (8, 32, 128, 500), (16, 64, 100, 128, 256), (10_000, 100_000)
+    ms_, nprs, ns, Ks = (10_000, 100_000, 1_000_000), (8, 32, 128, 500), (16, 32, 64, 100, 128, 256), (10_000, 100_000)
     if args.quick:
         ms_, nprs, ns, Ks = (10_000, 100_000), (32, 500), (16, 100, 128), (10_000, 100_000)
     if args.only_gather:

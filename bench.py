@@ -903,6 +903,46 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
 
     section("vignette_dense_csc", _vignette_dense_csc)
 
+    # ---- many short rows against a narrow B (sparse features x a small weight matrix): the row-split kernel's row-group form
+    # (csrc/spmm_rowsplit.hip spmm_rowgroup_kernel) — gemm_csr_drm_as_drm (matmul.cpp:118-142), rows summed in storage order
+    def _spmm_short_rows():
+        ms_, Ks_, npr_, ns_ = 1_000_000, 10_000, 8, 16
+        pq, jq, xq = synth.device_csr_fixed(ms_, Ks_, npr_, seed=31)
+        Aq = D.DeviceCSR(pq, jq, xq, ms_, Ks_, int(jq.numel()))
+        Bq_host = synth.dense_normal(Ks_, ns_, seed=32)
+        Bq = torch.from_numpy(Bq_host).cuda()
+        outq = torch.empty((ms_, ns_), dtype=torch.float64, device="cuda")
+        legs = {}
+        for name, kw in (("auto", dict(algo=0, keep_plan=False)), ("row_groups", dict(algo=4, npanels=1, wg_per_cu=-1)),
+                         ("wave_per_row", dict(algo=4, npanels=1, wg_per_cu=1)), ("row_wave", dict(algo=1)), ("slab", dict(algo=2))):
+            f = lambda: D.spmm(Aq, Bq, out=outq, colmajor=False, **kw)
+            f()
+            kn = lib.mxd_spmm_last_kernel().decode()
+            timeit(f, reps=100)
+            legs[name] = {"ms": round(min(timeit(f, reps=20) for _ in range(2)) * 1e3, 4), "kernel": kn}
+        legs["planned_kept_plan"] = {"ms": round(timeit(lambda: D.spmm_planned(Aq, Bq, out=outq, colmajor=False), reps=20) * 1e3, 4),
+                                     "kernel": "spmm_plan_kernel"}
+        got = D.spmm(Aq, Bq, colmajor=False, keep_plan=False)
+        rows = np.r_[0:256, ms_ - 256:ms_]
+        ph = pq.cpu().numpy(); jh = jq.cpu().numpy(); xh = xq.cpu().numpy()
+        sel = np.concatenate([np.arange(ph[r], ph[r + 1]) for r in rows])
+        pp = np.concatenate([[0], np.cumsum(np.diff(ph)[rows])]).astype(np.int32)
+        ref = O.tcrossprod_csr_dense(pp, jh[sel], xh[sel], np.asfortranarray(Bq_host.T), 1, True)
+        bitwise = bool(np.array_equal(got[torch.from_numpy(rows).cuda()].cpu().numpy(), ref))
+        assert bitwise, "row-group product differs from the storage-order FMA chain"
+        t = legs["auto"]["ms"] / 1e3
+        byts = synth.spmm_algorithmic_bytes(ms_, Ks_, ns_, Aq.nnz, 8)
+        res["spmm_short_rows_narrow_B"] = {
+            "workload": f"CSR {ms_}x{Ks_}, {npr_} entries/row, %*% dense {Ks_}x{ns_} f64, C row-major (device level, operands resident)",
+            "ms": legs["auto"]["ms"], "GFLOP/s": round(2.0 * Aq.nnz * ns_ / t / 1e9, 1), "kernels_ms": legs,
+            "roofline": roofline(byts, t), "l2_to_l1_gather": {"bytes_per_launch": int(Aq.nnz) * 128, "achieved_GBps": round(Aq.nnz * 128 / t / 1e9, 1)},
+            "parity": "bit for bit the oracle's storage-order FMA chain on 512 sampled rows",
+            "note": "AUTO (plan rebuilt per call, i.e. a one-shot product) = the row-split family's row-group form: 8 lanes own a row of A "
+                    "and a 128-byte row of B, 8 rows per wavefront; before it AUTO ran the slab kernel here and one wavefront per "
+                    "row for longer rows"}
+        del Aq, Bq, outq
+    section("spmm_short_rows", _spmm_short_rows)
+
     # ---- the vignette's usage loop through the export level (tools/vignette_loop.py; 60 iterations here, 200 in the GPU test)
     def _vignette_loop():
         sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -187,7 +187,8 @@ static int run_rowsplit(int m, int n, int K, int64_t nnz, int segments, int pane
         if (segments == 0) segments = rowsplit_segments(m, n, sz, avg / panels);
     }
     if (segments < 0) segments = 0;           // rowsplit_spmm's code for the row-group form
-    set_last_spmm_kernel("spmm_rowsplit_kernel");
+    const int vec = 16 / sz;
+    set_last_spmm_kernel(segments == 0 && n <= 32 * vec && n % vec == 0 ? "spmm_rowgroup_kernel" : "spmm_rowsplit_kernel");
     if (dense_dtype == MX_F64)
         return rowsplit_spmm<double>(m, n, K, segments, panels, indptr, indices, values, (const double *)B, ldb, (double *)C, ldc, colmajor, st);
     return rowsplit_spmm<float>(m, n, K, segments, panels, indptr, indices, values, (const float *)B, ldb, (float *)C, ldc, colmajor, st);

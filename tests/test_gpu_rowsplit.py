@@ -235,7 +235,7 @@ def test_auto_takes_the_rowgroup_form_for_many_short_rows(gpu):
     A = D.DeviceCSR.from_host(p, j, x, K)
     B = synth.dense_normal(K, n, seed=9)
     got = D.spmm(A, torch.from_numpy(B).cuda(), keep_plan=False).cpu().numpy()
-    assert _lib.load().mxd_spmm_last_kernel().decode() == "spmm_rowsplit_kernel"
+    assert _lib.load().mxd_spmm_last_kernel().decode() == "spmm_rowgroup_kernel"
     rows = np.r_[0:300, m - 300:m]
     pp = np.concatenate([[0], np.cumsum(np.diff(p)[rows])]).astype(np.int32)
     sel = np.concatenate([np.arange(p[r], p[r + 1]) for r in rows])

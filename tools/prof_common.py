@@ -21,7 +21,7 @@ CSRC = os.path.join(ROOT, "matrixextra_amd", "csrc")
 KERNEL_SOURCES = [
     ("spmm_plan_kernel", ["spmm_plan.hip"]), ("plan_", ["spmm_plan.hip"]), ("repack", ["spmm_slab.hip"]),
     ("spmm_rowwave_kernel", ["spmm_rowwave.hip"]), ("spmm_rowsplit_kernel", ["spmm_rowsplit.hip"]),
-    ("rowsplit_cursors_kernel", ["spmm_rowsplit.hip"]), ("spmm_slab_kernel", ["spmm_slab.hip"]),
+    ("rowsplit_cursors_kernel", ["spmm_rowsplit.hip"]), ("spmm_rowgroup_kernel", ["spmm_rowsplit.hip"]), ("spmm_slab_kernel", ["spmm_slab.hip"]),
     ("spmv_flat_kernel", ["spmv_flat.hip", "spmv_rows.h"]), ("slice_rows_kernel", ["spmv_flat.hip"]),
     ("spmv_plan_kernel", ["spmv_plan.hip"]), ("spmv_tile", ["spmv_tile.hip", "spmv_rows.h"]), ("spmv_kernel", ["spmv.hip", "spmv_rows.h"]),
     ("gather_", ["gather.hip"]), ("rows_sorted", ["gather.hip"]), ("sort_rows", ["gather.hip"]), ("is_seq", ["gather.hip"]),

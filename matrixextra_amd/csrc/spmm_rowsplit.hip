@@ -111,6 +111,12 @@ __device__ __forceinline__ double bperm_f64(double v, int src_lane)
     return u.d;
 }
 
+__device__ __forceinline__ double bperm_real(double v, int src_lane) { return bperm_f64(v, src_lane); }
+__device__ __forceinline__ float bperm_real(float v, int src_lane)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+
 // G < 64: one chunk of <= 64 entries, lane k holds entry k; group g = lane / G takes entries g, g + NG, ... — one load
 // instruction reads NG rows of B, 16 bytes per lane.  U instructions are in flight; entries past `cnt` re-read entry 0's
 // row (valid memory) and are dropped by a select, never by arithmetic (0 * Inf would poison the sum).
@@ -282,14 +288,16 @@ void spmm_rowgroup_kernel(int m, int n,
     for (int off = G; off < MX_WAVE; off <<= 1) len = max(len, __shfl_xor(len, off, MX_WAVE));
     const int longest = uniform(__shfl(len, 0, MX_WAVE));
     const int trips = (longest + G - 1) / G;
+    // (the f32 kind narrows a value once, where it is loaded — matmul.cpp:53-57 narrows per entry: the same number — and
+    // hands 4 bytes round the group instead of 8)
     int jv = 0;
-    double av = 0.0;
-    if (s + lg < e) { jv = indices[s + lg]; av = values[s + lg]; }
+    real_t av = 0;
+    if (s + lg < e) { jv = indices[s + lg]; av = (real_t)values[s + lg]; }
     for (int t = 0; t < trips; t++) {
         const int k0 = s + t * G;
         int jn = 0;
-        double an = 0.0;                        // the next G entries of the row are in flight while these stream B
-        if (k0 + G + lg < e) { jn = indices[k0 + G + lg]; an = values[k0 + G + lg]; }
+        real_t an = 0;                          // the next G entries of the row are in flight while these stream B
+        if (k0 + G + lg < e) { jn = indices[k0 + G + lg]; an = (real_t)values[k0 + G + lg]; }
         const int cnt = min(G, max(e - k0, 0));
         const int most = longest - t * G;       // wave-uniform: entries the longest row still has in this trip
 #pragma unroll
@@ -303,7 +311,7 @@ void spmm_rowgroup_kernel(int m, int n,
             for (int u = 0; u < U; u++) vload<real_t, VEC>(bb[u], B + (size_t)jj[u] * ldb + lcol);
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const real_t x = (real_t)bperm_f64(av, gbase + (q + u < cnt ? q + u : 0));   // narrowed per entry for f32
+                const real_t x = bperm_real(av, gbase + (q + u < cnt ? q + u : 0));
 #pragma unroll
                 for (int v = 0; v < VEC; v++) acc[v] = q + u < cnt ? mx_fma(x, bb[u][v], acc[v]) : acc[v];
             }

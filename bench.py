@@ -176,7 +176,7 @@ def committed_kernels_traffic(kernels, call_ms):
     it, or under half of it)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import prof_common as PC
-    why = "no multi-kernel summary of the newest round"
+    whys = []
     for f in PC.newest_round("*extras_pmc.json"):
         try:
             doc = json.load(open(f))
@@ -184,21 +184,21 @@ def committed_kernels_traffic(kernels, call_ms):
         except Exception:
             continue
         if any(k not in ks or ks[k].get("avg_ns") is None or "total_corrected" not in ks[k] for k, _ in kernels):
-            why = f"{os.path.relpath(f, ROOT)}: a kernel of this call is not in the summary"
+            whys.append(f"{os.path.relpath(f, ROOT)}: a kernel of this call is not in the summary")
             continue
         bad = [r for r in (PC.kernel_unchanged(ks[k]["kernel"], doc.get("source_blobs")) for k, _ in kernels) if not r[0]]
         if bad:
-            why = f"{os.path.relpath(f, ROOT)}: {bad[0][1]}"
+            whys.append(f"{os.path.relpath(f, ROOT)}: {bad[0][1]}")
             continue
         ns = sum(ks[k]["avg_ns"] * c for k, c in kernels)
         # (the source hashes above are what tells a stale profile; this window only catches a summary of another workload —
         # kernels of a few microseconds run up to ~20 % slower under the profiler than inside the timed loop)
         if not (0.5 * call_ms <= ns / 1e6 <= 1.3 * call_ms):
-            why = f"{os.path.relpath(f, ROOT)}: kernels {ns / 1e6:.4f} ms there, the call {call_ms:.4f} ms in this run"
+            whys.append(f"{os.path.relpath(f, ROOT)}: kernels {ns / 1e6:.4f} ms there, the call {call_ms:.4f} ms in this run")
             continue
         return {"traffic": int(sum(ks[k]["total_corrected"] * c for k, c in kernels)),
                 "traffic_source": os.path.relpath(f, ROOT), "traffic_kernels_ms": round(ns / 1e6, 4)}
-    return {"traffic_refused": why}
+    return {"traffic_refused": "; ".join(whys) if whys else "no multi-kernel summary of the newest round"}
 
 
 STREAM = {"GBps": None}          # measured once per run (stream_copy_probe): the box's own float4-copy rate

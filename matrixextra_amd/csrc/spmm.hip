@@ -122,7 +122,7 @@ static AutoCost spmm_auto_cost(int m, int n, int K, int64_t nnz, int sz, bool ke
     const int cols_per_line = 128 / sz;
     const double slabs = (double)((n + cols_per_line - 1) / cols_per_line);
     auto rate = [](double panel_bytes, double l2_rate, double mall_rate) {     // bytes per us
-        const double hit = panel_bytes <= 3.5e6 ? 1.0 : (4.0 * 1048576.0) / panel_bytes;
+        const double hit = panel_bytes <= 4.0 * 1048576.0 ? 1.0 : (4.0 * 1048576.0) / panel_bytes;
         return 1e6 / (hit / l2_rate + (1.0 - hit) / mall_rate);
     };
     AutoCost c;

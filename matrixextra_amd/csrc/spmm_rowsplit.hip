@@ -462,7 +462,7 @@ double rowsplit_est_us(int m, int n, int K, int dense_bytes, double avg_len, int
         row_us = G == 8 ? 0.0 : (G == 16 ? 0.07e-3 : 0.15e-3);
     }
     const double panel_bytes = b_bytes / P;
-    const double hit = panel_bytes <= 3.5e6 ? 1.0 : (4.0 * 1048576.0) / panel_bytes;
+    const double hit = panel_bytes <= 4.0 * 1048576.0 ? 1.0 : (4.0 * 1048576.0) / panel_bytes;
     const double rate = 1e6 / (hit / l2_rate + (1.0 - hit) / mall_rate);          // bytes per microsecond
     const double c_traffic_us = c_bytes > 128e6 ? (2.0 * P - 2.0) * c_bytes / 5e6 : 0.0;
     return nnz * n * sz / rate + row_us * m * P + 6.0 * P + 4.0 + c_traffic_us;

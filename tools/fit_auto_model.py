@@ -5,7 +5,8 @@ best measured candidate.  How round 4's constants (6 us per panel launch, the ro
 panel) of the planned sweep) were found without a GPU run per try.   python tools/fit_auto_model.py [map.json]"""
 import json, math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d=json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_auto_map.json")))
+_args = [a for a in sys.argv[1:] if not a.startswith("-")] if __name__ == "__main__" else []
+d=json.load(open(_args[0] if _args else os.path.join(ROOT, "profiles", "r04_auto_map.json")))
 pts=d['spmm']
 def G_of(n,sz):
     vec=16//sz
@@ -30,7 +31,7 @@ def cost(m,n,K,nnz,sz,keep,P):
     avg=nnz/m; W=64*(16//sz); passes=(n+W-1)//W
     cpl=128//sz; slabs=(n+cpl-1)//cpl; b=K*n*sz
     def rate(pb,l2,mall):
-        hit=1.0 if pb<=3.5e6 else 4*1048576.0/pb
+        hit=min(1.0,4*1048576.0/pb)
         return 1e6/(hit/l2+(1-hit)/mall)
     pn=panels(m,n,K,sz,avg,P)
     one_line=n*sz<=128
@@ -81,7 +82,7 @@ def cost2(m,n,K,nnz,sz,keep,P):
     avg=nnz/m; W=64*(16//sz); passes=(n+W-1)//W
     cpl=128//sz; slabs=(n+cpl-1)//cpl; b=K*n*sz
     def rate(pb,l2,mall):
-        hit=1.0 if pb<=P['full'] else min(1.0,P['H']/pb)
+        hit=min(1.0,P['H']/pb)
         return 1e6/(hit/l2+(1-hit)/mall)
     G=G_of(n,sz); one_line=n*sz<=128
     cb=m*n*sz
@@ -103,7 +104,7 @@ def cost2(m,n,K,nnz,sz,keep,P):
     pairs=math.ceil(m/64.0)*slabs; fill=pairs/(pairs+P['fillk'])
     sw=(19.0 if pp>1 else 23.5)*fill
     def prate(pb,l2,mall):
-        hit=1.0 if pb<=3.5e6 else 4*1048576.0/pb
+        hit=min(1.0,4*1048576.0/pb)
         return 1e6/(hit/l2+(1-hit)/mall)
     pl=nnz*slabs*128.0/prate(K*128.0/pp,sw,8.5*fill)+P['prow']*m*slabs*pp+15.0+(0.0 if keep else 36.0+6e-6*nnz)
     return rs,pl,pn,S

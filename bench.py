@@ -3,17 +3,21 @@
 
 Workloads (config.workload):
   cfg2  BASELINE configs[1] — dgRMatrix 1M x 100k, 32 nnz/row (nnz 32M), f64, %*% dense 100k x 128.  The metric's
-        configuration: default at N = 1.
-  cfg5  BASELINE configs[4] per GPU — 1M x 200k row block, 64 nnz/row (nnz 64M, CSR values f64), f32 dense 200k x 256
-        (8 such blocks = the 8M x 200k matrix).  Default for N > 1; also timed briefly at N = 1 (`cfg5_shard`).
+        configuration: the default for EVERY N.  At N > 1 it is the same matrix (same seed, same bytes) cut into N
+        nnz-balanced row blocks (strong scaling): `python bench.py --gpus 1/2/4/8` is one curve.
+  cfg5  BASELINE configs[4] — 8M x 200k, 64 nnz/row (CSR values f64), f32 dense 200k x 256.  At N > 1 the whole matrix,
+        strong-scaled, rides on the same line as `extras.cfg5_strong`; at N = 1 one GPU's 1M-row block is timed briefly
+        (`extras.cfg5_shard`) and `--config cfg5-full` runs the whole matrix on one GPU.
 One "step" = one SpMM over the rank's whole matrix, inputs resident in HBM.  `value` (--algo 0): the plan AUTO uses — a
 regrouping of the CSR's entries that depends on the matrix alone — is kept on the DeviceCSR and built once per matrix
 (untimed, like rows_sorted()); `plan.rebuild_every_step` in the line is the same loop with the plan rebuilt from plain CSR
 inside every step (--algo 4 times that form as `value`).
 N GPUs (one rank per GPU; `python bench.py --gpus N` starts torch.distributed.run itself when it was not started by
-it): every rank owns a row block (weak scaling), B replicated, blocks of C exchanged with one RCCL all-gather so that
-every rank holds the full C.  value = total GFLOP/s over all ranks, 2*nnz*n flops per rank-step, max-over-ranks time,
-all-gather included.
+it): every rank owns one nnz-balanced row block of the matrix, B replicated, blocks of C exchanged with one RCCL
+all-gather so that every rank holds the full C.  value = total GFLOP/s of the whole product (2*nnz*n flops per step,
+max-over-ranks time, all-gather included); `compute_only_gflops` = the same flops over the slowest rank's local product;
+`cpu_baseline` (rank 0's host cores, a bounded sample) and rank 0's `roofline` are carried at every N.
+`--scaling weak` is the other experiment: every rank owns a --rows row block (the matrix grows with N).
 
 At N = 1 the line also carries (`extras`) configs[2] (SpMV + gather of 200k rows), configs[3] (CSR + CSR, CSR * CSR
 on 2M x 2M, nnz 1e8 each) and one export-level call from host memory, each with its own roofline and CPU baseline.
@@ -37,6 +41,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SETUP_CALLS = 12               # untimed products before the warm-up: workspace allocation + clock ramp (see main)
 
+FORCE_DIST = os.environ.get("MXGPU_BENCH_FORCE_DIST") == "1"
+
 WORKLOADS = {
     "cfg2": dict(rows=1_000_000, cols=100_000, nnz_row=32, n=128, dtype="f64",
                  label="BASELINE configs[1]"),
@@ -51,7 +57,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default=None, choices=sorted(WORKLOADS) + ["cfg5-full"],
-                    help="workload; default cfg2 at N = 1 (the metric's configuration), cfg5 for N > 1")
+                    help="workload; default cfg2 (the metric's configuration) for every N")
     ap.add_argument("--rows", type=int, default=None)
     ap.add_argument("--cols", type=int, default=None)
     ap.add_argument("--nnz-row", type=int, default=None)
@@ -65,9 +71,11 @@ def parse():
     ap.add_argument("--sync", type=int, default=-1, help="planned kernel: 0 no barrier, 1 per row block, 2 per panel")
     ap.add_argument("--panels", type=int, default=0)
     ap.add_argument("--wg-per-cu", type=int, default=0)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = every rank owns a --rows row block (default); strong = --rows is the WHOLE matrix "
-                         "(default configs[4]'s 8M rows), cut into N nnz-balanced row blocks")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1: strong (default) = --rows is the WHOLE matrix (cfg2: the N = 1 matrix itself; cfg5: configs[4]'s "
+                         "8M rows), cut into N nnz-balanced row blocks; weak = every rank owns a --rows row block")
+    ap.add_argument("--cfg5-strong-rows", type=int, default=8_000_000,
+                    help="rows of the configs[4] matrix of `extras.cfg5_strong` (N > 1; a multiple of 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the SpMM CPU baseline sample")
     ap.add_argument("--no-extras", action="store_true",
@@ -76,7 +84,9 @@ def parse():
     args = ap.parse_args()
     args.config_given = args.config is not None
     if args.config is None:
-        args.config = "cfg2" if args.gpus == 1 else "cfg5"
+        args.config = "cfg2"
+    if args.scaling is None:
+        args.scaling = "strong" if (args.gpus > 1 or FORCE_DIST) else "weak"      # (one GPU: nothing to scale; reported as weak)
     w = WORKLOADS["cfg5" if args.config == "cfg5-full" else args.config]
     args.custom = any(v is not None for v in (args.rows, args.cols, args.nnz_row, args.n, args.dtype))
     for k in ("rows", "cols", "nnz_row", "n", "dtype"):
@@ -132,9 +142,6 @@ def cpu_baseline_spmm(args, p, j, x, B_host, dtype):
                               "sample": f"first {rows_one} rows, best of 3"},
             "sample": f"first {rows_all} of {m} rows of the same CSR x the same dense {B_host.shape[0]}x{n} "
                       f"({dtype}), gemm_csr_drm_as_dcm restated with OpenMP schedule(dynamic), -march=native, best of 3"}
-
-
-FORCE_DIST = os.environ.get("MXGPU_BENCH_FORCE_DIST") == "1"
 
 
 def committed_traffic(kernel_sub, workload_tag, kernel_avg_ms):
@@ -292,9 +299,18 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
         blocks = MDs.nnz_balanced_row_blocks(np.arange(m_total + 1, dtype=np.int64) * nnz_row, world)
         r0g, r1g = blocks[rank]
         m = r1g - r0g
-        dp, dj, dx = strong_rows(synth, torch, m_total, K, nnz_row, r0g, r1g)
-        A = D.DeviceCSR(dp, dj, dx, m, K, int(dj.numel()))
-        p = j = x = None
+        host_whole = cfg["name"] == "cfg2" and not args.custom
+        if host_whole:
+            # the metric's matrix: the SAME bytes as the N = 1 run (synth.csr_fixed, seed A = 1), drawn by every rank and cut
+            pw, jw, xw = synth.csr_fixed(m_total, K, nnz_row, seed=synth.SEED_A)
+            p, j, x = MDs.shard_csr(pw, jw, xw, r0g, r1g)
+            A = D.DeviceCSR.from_host(p, j, x, K)
+            last_rows = MDs.shard_csr(pw, jw, xw, m_total - 2048, m_total) if rank == 0 else None
+            del pw, jw, xw
+        else:
+            dp, dj, dx = strong_rows(synth, torch, m_total, K, nnz_row, r0g, r1g)
+            A = D.DeviceCSR(dp, dj, dx, m, K, int(dj.numel()))
+            p = j = x = None
     else:
         # synthetic inputs: seeds A=1 (+1000*rank for the other row blocks), B=2
         m_total = world * m
@@ -398,11 +414,15 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
     flops_all_step = 2.0 * m_total * nnz_row * n if strong else world * flops_rank_step
     alg_bytes = synth.spmm_algorithmic_bytes(m, K, n, nnz, s_dense)
     nranks_seen = None
+    slowest_local_ms = float(step_ms.mean())
     if dist_on:
         # how many ranks really took part: an RCCL all-reduce of ones (beside dist.get_world_size(), for the driver's check)
         ones = torch.ones(1, dtype=torch.float32, device="cuda")
         dist.all_reduce(ones)
         nranks_seen = int(round(float(ones.item())))
+        tl = torch.tensor([slowest_local_ms], dtype=torch.float64, device="cuda")     # the slowest rank's local product
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        slowest_local_ms = float(tl.item())
     if rank != 0:
         return None
 
@@ -421,7 +441,7 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
         # normalised max error: |got - ref| / max|ref| over the checked block (element-wise relative error is
         # meaningless for entries that cancel to ~0); NaN (unwritten / half-gathered data) propagates
         return float(np.max(np.abs(got.astype(np.float64) - ref)) / np.max(np.abs(ref)))
-    if strong:                                        # my block's first rows, read back from the device
+    if strong and p is None:                          # my block's first rows, read back from the device
         e = rows_chk * nnz_row
         p = (np.arange(rows_chk + 1, dtype=np.int64) * nnz_row).astype(np.int32)
         j, x = A.indices[:e].cpu().numpy(), A.values[:e].cpu().numpy()
@@ -433,7 +453,9 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
         # every gathered buffer, my own block AND the last rank's block (regenerated here from its seed): data that
         # never arrived, or arrived from an unfinished product, shows up as NaN or as a wrong value
         ml = blocks[-1][1] - blocks[-1][0]              # the last rank's block: its last rows_chk rows
-        if strong:
+        if strong and host_whole:
+            refl = oracle_rows(*last_rows, 0)
+        elif strong:
             _, jl_d, xl_d = strong_rows(synth, torch, m_total, K, nnz_row, m_total - rows_chk, m_total)
             pl = (np.arange(rows_chk + 1, dtype=np.int64) * nnz_row).astype(np.int32)
             refl = oracle_rows(pl, jl_d.cpu().numpy(), xl_d.cpu().numpy(), 0)
@@ -462,9 +484,9 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
     res = {
         "value": round(flops_all_step * steps / elapsed / 1e9, 2),
         "ms_per_step": round(elapsed / steps * 1e3, 4),
-        "workload": f"dgRMatrix {m}x{K} nnz/row={nnz_row} (CSR values f64) %*% dense {K}x{n} {dtype} "
+        "workload": f"dgRMatrix {m_total if strong else m}x{K} nnz/row={nnz_row} (CSR values f64) %*% dense {K}x{n} {dtype} "
                     f"({cfg['label']}); C {'col' if colmajor else 'row'}-major"
-                    + ((f"; the WHOLE matrix has {m_total} rows, cut into {world} nnz-balanced row blocks (this rank: {m}) + RCCL "
+                    + ((f"; the WHOLE matrix, cut into {world} nnz-balanced row blocks (rank 0: {m} rows), one per GPU, + RCCL "
                         f"all-gather of C" if strong else f"; one such row block per GPU + RCCL all-gather of C ({world}x{m} rows)")
                        + (", gather of step k under the product of step k+1" if pipe is not None else "")
                        if dist_on else ""),
@@ -490,6 +512,9 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
         res["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                               "ranks_in_an_rccl_all_reduce_of_ones": nranks_seen, "scaling": args.scaling,
                               "row_blocks": [b - a for a, b in blocks], "rows_total": m_total}
+        # the same flops over the slowest rank's local product alone (no exchange): what the GPUs do; `value` is what the job does
+        res["compute_only_gflops"] = round(flops_all_step / (slowest_local_ms / 1e3) / 1e9, 2)
+        res["roofline"]["scope"] = "rank 0's row block, its dominant kernel only (value is the whole job, all-gather included)"
     if kernel_name == "spmm_plan_kernel" and args.algo in (0, 4):
         res["plan"] = {"value_is": "plan kept on the DeviceCSR: built once per matrix in the untimed setup calls, every timed "
                                    "step = repack of B + the sweep" if args.algo == 0 else
@@ -515,8 +540,14 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
         dt = (time.perf_counter() - t1) / steps
         res["plan"]["kept_plan" if other_keeps else "rebuild_every_step"] = {
             "ms_per_step": round(dt * 1e3, 4), "GFLOP/s": round(flops_rank_step / dt / 1e9, 1)}
-    if want_cpu and not strong:
-        res["cpu_baseline"] = cpu_baseline_spmm(args, p, j, x, B_host, dtype)
+    if want_cpu:
+        if p is None:            # a device-drawn block: the CPU sample is its first rows, read back
+            rs = min(m, 60_000)
+            e = rs * nnz_row
+            p_c = (np.arange(rs + 1, dtype=np.int64) * nnz_row).astype(np.int32)
+            res["cpu_baseline"] = cpu_baseline_spmm(args, p_c, A.indices[:e].cpu().numpy(), A.values[:e].cpu().numpy(), B_host, dtype)
+        else:
+            res["cpu_baseline"] = cpu_baseline_spmm(args, p, j, x, B_host, dtype)
     res["_host"] = (p, j, x, A, B, B_host)          # handed to the extras; removed before printing
     return res
 
@@ -1023,15 +1054,21 @@ def main():
     cfg = dict(name=args.config, rows=args.rows, cols=args.cols, nnz_row=args.nnz_row, n=args.n, dtype=args.dtype,
                label=WORKLOADS[args.config]["label"] if not args.custom else "custom shape")
     stream = stream_copy_probe(torch, lib, _lib) if world == 1 or rank == 0 else None
-    want_cpu = world == 1 and not FORCE_DIST and not args.no_cpu_baseline
+    want_cpu = not args.no_cpu_baseline                      # (rank 0's host cores; a shorter sample beside N > 1 ranks)
+    if world > 1 or FORCE_DIST:
+        args.cpu_seconds = min(args.cpu_seconds, 8.0)
     r = spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, args.steps, args.warmup, want_cpu, True)
     out = None
     if rank == 0:
         host = r.pop("_host")
+        dist_line = world > 1 or FORCE_DIST
         what = {"cfg2": "fp64, 1M x 100k, 32 nnz/row, k=128", "cfg5": "fp32 dense / f64 CSR values, 1M x 200k per GPU, "
                 "64 nnz/row, k=256"}[args.config] if not args.custom else "custom shape"
-        if args.scaling == "strong" and (world > 1 or FORCE_DIST):
-            what = what.replace("1M x 200k per GPU", "8M x 200k over all GPUs") if not args.custom else "custom shape, rows over all GPUs"
+        if args.scaling == "strong" and dist_line:
+            what = (what.replace("1M x 200k per GPU", "8M x 200k over all GPUs") + f", the whole matrix row-sharded over {world} GPU(s) + "
+                    "RCCL all-gather of C") if not args.custom else "custom shape, rows over all GPUs"
+        elif dist_line:
+            what = what.replace("1M x 100k", "1M x 100k per GPU") if not args.custom else "custom shape, rows per GPU"
         out = {
             "metric": f"CSR x dense SpMM GFLOP/s ({what}; AUTO's plan kept per matrix — one_shot_* = plan rebuilt inside every step) "
                       f"+ achieved HBM BW% vs CPU ref",
@@ -1066,6 +1103,30 @@ def main():
                 out["extras"]["cfg5_shard"] = r5
             except Exception as exc:                         # noqa: BLE001 - the headline line still has to come out
                 out["extras"].setdefault("errors", {})["cfg5_shard"] = repr(exc)[:400]
+    if (world > 1 or FORCE_DIST) and not args.no_extras and not args.custom and args.config == "cfg2" and args.algo == 0 \
+            and args.scaling == "strong":
+        # BASELINE configs[4] on the same line: the 8M x 200k f32 product, strong-scaled over the same ranks (every rank takes
+        # part: the leg holds collectives).  A failure here must not cost the headline line — and must not leave ranks
+        # waiting for each other: every rank first learns whether all of them got through the set-up.
+        c5 = dict(WORKLOADS["cfg5"], name="cfg5", rows=args.cfg5_strong_rows,
+                  label="BASELINE configs[4], the whole matrix" if args.cfg5_strong_rows == 8_000_000 else "configs[4]'s shape, fewer rows")
+        try:
+            torch.cuda.empty_cache()
+            # bytes this rank will hold: its block of A (+ AUTO's plan, ~1.6x), B, two gathered C buffers, generator scratch
+            blk_nnz = c5["rows"] // world * c5["nnz_row"] * 1.05
+            need = blk_nnz * 12 * 3.5 + c5["cols"] * c5["n"] * 4 + 2.0 * c5["rows"] * c5["n"] * 4 * 1.02 + (2 << 30)
+            ok = torch.tensor([1.0 if torch.cuda.mem_get_info()[0] > need else 0.0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                raise RuntimeError(f"skipped: a rank has less than {need / 2**30:.1f} GiB of device memory free")
+            r5 = spmm_leg(args, torch, dist, D, synth, lib, _lib, c5, world, rank, max(3, args.steps // 4), 1, False, False)
+            if rank == 0:
+                r5.pop("_host")
+                r5["dtype"] = "f32"
+                out.setdefault("extras", {})["cfg5_strong"] = r5
+        except Exception as exc:                             # noqa: BLE001
+            if rank == 0:
+                out.setdefault("extras", {}).setdefault("errors", {})["cfg5_strong"] = repr(exc)[:400]
     if world > 1 or FORCE_DIST:
         # The JSON line must be the LAST line on stdout.  RCCL writes its version banner through C stdio, which — stdout
         # being a pipe — sits in the C buffer until the process exits, i.e. lands AFTER a line printed from Python.  So:

@@ -198,7 +198,8 @@ int mxd_spmm_csr_dense(int m, int n,
  *                          aligned or fill the wavefront)
  * mxd_spmm_csr_dense_ex2: the same with nnz = the number of entries of A (indptr[m] - indptr[0]) when the caller knows it;
  * -1 = unknown (ROWSPLIT then reads indptr[m] from the device: one 4-byte copy and a stream sync). */
-typedef enum { MX_SPMM_AUTO = 0, MX_SPMM_ROWWAVE = 1, MX_SPMM_SLAB = 2, MX_SPMM_PLANNED = 3, MX_SPMM_ROWSPLIT = 4 } mx_spmm_algo;
+typedef enum { MX_SPMM_AUTO = 0, MX_SPMM_ROWWAVE = 1, MX_SPMM_SLAB = 2, MX_SPMM_PLANNED = 3, MX_SPMM_ROWSPLIT = 4,
+               MX_SPMM_TILE = 5 } mx_spmm_algo;
 int mxd_spmm_csr_dense_ex(int m, int n, int K,
                           const int32_t *indptr, const int32_t *indices, const double *values,
                           const void *B, size_t ldb, void *C, size_t ldc,

@@ -60,7 +60,8 @@ int host_signal_wait(const HostSignal &s, unsigned *value, hipStream_t st);
 enum { MX_SCRATCH_SPMV_SLICES = 0, MX_SCRATCH_PARTIALS = 1, MX_SCRATCH_EXPORT_B = 2, MX_SCRATCH_EXPORT_C = 3, MX_SCRATCH_ROWSPLIT = 4,
        MX_SCRATCH_AUTO_PLAN = 5,      // no buffer of its own: orders the users of AUTO's per-thread plan (spmm_plan.hip) across streams
        MX_SCRATCH_PACKED_B = 6,       // likewise for the per-thread slab-major copy of B (spmm_slab.hip slab_pack_workspace)
-       MX_SCRATCH_SLOTS = 7 };
+       MX_SCRATCH_TILE_FLAGS = 7,     // per-row "not sorted by column" flags of the tile kernel (spmm_tile.hip)
+       MX_SCRATCH_SLOTS = 8 };
 void *scratch_buffer(int slot, size_t bytes);
 void *scratch_buffer_zeroed(int slot, size_t bytes, hipStream_t st, bool *fresh);   // zero-filled when (re)allocated
 void scratch_release();

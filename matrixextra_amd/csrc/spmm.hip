@@ -277,6 +277,14 @@ extern "C" int mxd_spmm_csr_dense_ex2(int m, int n, int K, int64_t nnz,
     if (algo == MX_SPMM_ROWSPLIT)
         return mx::run_rowsplit(m, n, K, nnz, wg_per_cu, npanels, rows_sorted, indptr, indices, values, B, ldb, C, ldc, dense_dtype,
                                 colmajor_out, st);
+    if (algo == MX_SPMM_TILE) {
+        mx::set_last_spmm_kernel("spmm_tile_kernel");
+        if (dense_dtype == MX_F64)
+            return mx::tile_spmm<double>(m, n, K, wg_per_cu, npanels, rows_sorted, indptr, indices, values, (const double *)B, ldb,
+                                         (double *)C, ldc, colmajor_out, st);
+        return mx::tile_spmm<float>(m, n, K, wg_per_cu, npanels, rows_sorted, indptr, indices, values, (const float *)B, ldb,
+                                    (float *)C, ldc, colmajor_out, st);
+    }
     if (algo == MX_SPMM_PLANNED) {
         MX_REQUIRE(ok, "mxd_spmm_csr_dense_ex: operands do not meet the planned kernel's 16-byte alignment rules");
         // Measured with log-normal row lengths (tools/skew_probe.py): up to ~1.55x the CSR the planned sweep still

@@ -109,6 +109,13 @@ int rowsplit_segments(int m, int n, int dense_bytes, double avg_len);
 double rowsplit_est_us(int m, int n, int K, int dense_bytes, double avg_len, int P);
 int rowsplit_panels(int m, int n, int K, int dense_bytes, double avg_len);
 
+// ---- spmm_tile.hip: row blocks x 256 / 512-byte column slabs, K-tiles of B staged in LDS by LDS-DMA (dense-ish operands)
+template <typename real_t>
+bool tile_ok(int n, const real_t *B, size_t ldb);
+template <typename real_t>
+int tile_spmm(int m, int n, int K, int variant, int nw, int rows_sorted, const int32_t *indptr, const int32_t *indices,
+              const double *values, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream);
+
 // ---- spmm_slab.hip
 int pick_panels(int K, size_t l2_budget);
 void *slab_pack_workspace(size_t bytes, bool release = false);     // grow-only per-device scratch for the packed B

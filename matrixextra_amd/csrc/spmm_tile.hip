@@ -1,0 +1,522 @@
+// spmm_tile.hip — CSR x dense SpMM for gfx950 (MI355X): the kernel for DENSE-ISH sparse operands, where a row block of A
+// comes back to every row of B several times (density x rows-per-block >~ 2).  That is the operand the reference itself
+// publishes and tests: dense 100 x 1e4 %*% CSC 1e4 x 1e4 at density .05 (vignettes/Introducing_MatrixExtra.Rmd:247-251 ->
+// matmul_dense_csc_numeric -> gemm_csr_drm_as_drm, src/matmul.cpp:188-235, :118-142), test matrices at density .4
+// (tests/testthat/test-matmul.R:108-114).
+//
+// Why another kernel: every other SpMM kernel here gathers one row of B per entry from L2 into registers — nnz * n * s
+// bytes of L2 -> L1 line reads (4 GB for the vignette product against an 8 MB B), the ceiling the row-split kernel sits at.
+// Here B goes through LDS:
+//
+//   * a workgroup owns a ROW BLOCK of R rows of A (up to 240) and one COLUMN SLAB of W = 16 lanes x 16 bytes x CPL
+//     columns of B / C (256 or 512 bytes of a row);
+//   * it walks [0, K) in K-TILES: TK rows of the slab of B (64 KB) are brought into LDS by ONE LOADER WAVEFRONT with
+//     LDS-DMA (global_load_lds_dwordx4: 1 KB per instruction, coalesced 256 / 512-byte row pieces, no registers), tile t + 1
+//     while the compute wavefronts work on tile t (two buffers, one barrier per tile) — B is read from L2 once per row
+//     block instead of once per entry: m * K * n * s / R bytes;
+//   * a compute wavefront is 4 lane groups of 16 (one DPP row each); a group owns RG rows of A and keeps their sums in
+//     registers through the whole sweep.  Rows are sorted by column, so the entries of a row that fall into a tile are the
+//     next ones in storage order: the group keeps a window of the row's next 16 / 32 entries in registers (lane l = entry
+//     pos + l), counts those below the tile's end with a ballot, and streams them: the entry's LDS row offset is handed to
+//     the group's 16 lanes by DPP row_newbcast folded INTO the address add (v_add_u32_dpp), its value into the FMA
+//     (v_fmac_f64_dpp) — three VALU instructions and one ds_read_b128 per (4 rows x 1 entry x 256 bytes);
+//   * a group that has fewer entries in the tile than its neighbours multiplies the window's -0.0 padding with a row of
+//     zeros kept in LDS: x + (-0.0 * 0.0) = x for every x (signed zeros, Inf and NaN included), so there is no select in
+//     the loop and the sum of a row is the reference's storage-order FMA chain BIT FOR BIT, in both layouts of C;
+//   * a row that is NOT sorted by column (flagged by the caller's sortedness pass) is summed whole from global memory
+//     before the sweep, by the same group in storage order — correct, slow, rare;
+//   * row-major C: 16-byte stores straight from the registers; column-major C: through LDS, whole column segments of R rows.
+//
+// Roofline: HBM-bound by the contract's algorithmic bytes; what limits it in practice is LDS reads
+// (nnz * n * s bytes, `lds_read` in bench.py) beside the tile fills (`l2_to_lds_fill`).
+#include "spmm_common.h"
+
+namespace mx {
+
+constexpr int TL_G = 16;                  // lanes per row of the slab: one DPP row
+constexpr int TL_NG = MX_WAVE / TL_G;     // rows of A a wavefront walks at once
+constexpr int TL_MAX_WAVES = 15;          // compute wavefronts per workgroup (+ 1 or 2 loaders <= 1,024 threads)
+
+template <int U> __device__ __forceinline__ unsigned tl_addr(unsigned off, unsigned lane16)
+{
+    unsigned r;
+    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(off), "v"(lane16), "i"(U));
+    return r;
+}
+template <int U> __device__ __forceinline__ void tl_fmac(double &acc, double a, double b)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "i"(U));
+}
+template <int U> __device__ __forceinline__ void tl_fmac(float &acc, float a, float b)
+{
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "i"(U));
+}
+
+// One visit of (a row of every group, the tile): entries 0 .. maxc - 1 of the window in batches of NB = 4 / CPL entries (four
+// ds_read_b128 either way).  The reads of batch q + 1 are issued BEFORE the FMAs of batch q (two register sets): without
+// that the compiler waits for every read right behind its issue and a wavefront spends an LDS round trip per entry.  Exits
+// are wave-uniform, one per batch: a padded step (-0.0 x the row of zeros) is a no-op on the sums.
+template <typename real_t, int CPL, int NB> struct TlBatch { typename VecT<real_t, 16 / (int)sizeof(real_t)>::type b[NB][CPL]; };
+
+template <typename real_t, int CPL, int NB, int U0>
+__device__ __forceinline__ void tl_read(const char *smem, unsigned off, unsigned lane16, TlBatch<real_t, CPL, NB> &t)
+{
+    using V = typename VecT<real_t, 16 / (int)sizeof(real_t)>::type;
+    unsigned a[NB];
+    a[0] = tl_addr<(U0 + 0) & 15>(off, lane16);
+    if constexpr (NB > 1) a[1] = tl_addr<(U0 + 1) & 15>(off, lane16);
+    if constexpr (NB > 2) { a[2] = tl_addr<(U0 + 2) & 15>(off, lane16); a[3] = tl_addr<(U0 + 3) & 15>(off, lane16); }
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (int e = 0; e < NB; e++) t.b[e][c] = *reinterpret_cast<const V *>(smem + a[e] + c * 256);
+}
+template <typename real_t, int CPL, int NB, int U0>
+__device__ __forceinline__ void tl_fma(real_t aa, const TlBatch<real_t, CPL, NB> &t, real_t (&acc)[CPL][16 / sizeof(real_t)])
+{
+    constexpr int VEC = 16 / (int)sizeof(real_t);
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (int v = 0; v < VEC; v++) tl_fmac<(U0 + 0) & 15>(acc[c][v], aa, t.b[0][c][v]);
+    if constexpr (NB > 1) {
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+#pragma unroll
+            for (int v = 0; v < VEC; v++) tl_fmac<(U0 + 1) & 15>(acc[c][v], aa, t.b[1][c][v]);
+    }
+    if constexpr (NB > 2) {
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+#pragma unroll
+            for (int v = 0; v < VEC; v++) tl_fmac<(U0 + 2) & 15>(acc[c][v], aa, t.b[2][c][v]);
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+#pragma unroll
+            for (int v = 0; v < VEC; v++) tl_fmac<(U0 + 3) & 15>(acc[c][v], aa, t.b[3][c][v]);
+    }
+}
+// `cur` holds entries [U0, U0 + NB) on entry
+template <typename real_t, int CPL, int NB, int U0>
+__device__ __forceinline__ void tl_pipe(const char *smem, int left, unsigned off, real_t aa, unsigned lane16,
+                                        real_t (&acc)[CPL][16 / sizeof(real_t)], TlBatch<real_t, CPL, NB> &cur, TlBatch<real_t, CPL, NB> &nxt)
+{
+    if constexpr (U0 + NB < TL_G) {
+        if (left > U0 + NB) tl_read<real_t, CPL, NB, U0 + NB>(smem, off, lane16, nxt);
+    }
+    tl_fma<real_t, CPL, NB, U0>(aa, cur, acc);
+    if constexpr (U0 + NB < TL_G) {
+        if (left <= U0 + NB) return;
+        tl_pipe<real_t, CPL, NB, U0 + NB>(smem, left, off, aa, lane16, acc, nxt, cur);
+    }
+}
+// entries [16 w, 16 w + 16) of the window: `left` = how many of them any group still has (wave-uniform, >= 1)
+template <typename real_t, int CPL>
+__device__ __forceinline__ void tl_window(const char *smem, int left, unsigned off, real_t aa, unsigned lane16,
+                                          real_t (&acc)[CPL][16 / sizeof(real_t)])
+{
+    constexpr int NB = 4 / CPL;
+    TlBatch<real_t, CPL, NB> p, q;
+    tl_read<real_t, CPL, NB, 0>(smem, off, lane16, p);
+    tl_pipe<real_t, CPL, NB, 0>(smem, left, off, aa, lane16, acc, p, q);
+}
+
+// TILE: bytes of one K-tile of the slab in LDS (two of them + one row of zeros); WIN: 16-entry windows per row (1 or 2)
+template <typename real_t, int CPL, int RG, int WIN, int TILE, bool COLMAJOR>
+__global__ __launch_bounds__((TL_MAX_WAVES + 1) * MX_WAVE)
+void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
+                      const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ values,
+                      const unsigned char *__restrict__ unsorted,
+                      const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ C, size_t ldc, int c_vec, int nl, int dbg)
+{
+    constexpr int VEC = 16 / (int)sizeof(real_t);
+    constexpr int W = TL_G * VEC * CPL;              // columns of the slab
+    constexpr int ROWB = 256 * CPL;                  // bytes of one row of the tile
+    constexpr int TK = TILE / ROWB;                  // rows of B per tile
+    constexpr unsigned ZOFF = 2 * TILE;              // the row of zeros
+    using V = typename VecT<real_t, VEC>::type;
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE + ROWB];
+
+    // workgroups that share an XCD (blockIdx % 8) share a slab whenever the slabs divide 8: an XCD's L2 then holds one
+    // slab of B (K x 256 bytes), not all of it
+    int slab, rb;
+    {
+        const int id = blockIdx.x;
+        if (8 % nslabs == 0) { const int x = id & 7, per = 8 / nslabs; slab = x % nslabs; rb = (id >> 3) * per + x / nslabs; }
+        else { slab = id % nslabs; rb = id / nslabs; }
+    }
+    if (rb >= nrb) return;
+    const int lane = lane_id();
+    const int wave = uniform(threadIdx.x / MX_WAVE);
+    const int nw = (int)(blockDim.x / MX_WAVE) - nl; // compute wavefronts; the last nl wavefronts are the loaders
+    const int R = nw * TL_NG * RG;
+    const int row0 = rb * R;
+    const int c0 = slab * W;
+    const int T = (K + TK - 1) / TK;
+
+    if (wave >= nw) {
+        // ---- the loaders (nl wavefronts, 1-KB pieces dealt round robin): tile t + 1 travels while tile t is being read.
+        // Their instruction stream is on the critical path (a tile is 64 instructions; the wavefront shares its SIMD with
+        // compute wavefronts): per piece one 64-bit pointer add and the DMA
+        constexpr int LPR = ROWB / 16;               // lanes per row piece
+        constexpr int RPP = MX_WAVE / LPR;           // rows per 1-KB instruction
+        constexpr int NP = TILE / 1024;
+        const int li = wave - nw;
+        const int rp = lane / LPR;
+        int col = c0 + (lane % LPR) * VEC;
+        if (col > n - VEC) col = n - VEC;            // past the last column: any valid address (those sums are never stored)
+        const real_t *src0 = B + col;
+        const size_t stride = (size_t)RPP * ldb * (size_t)nl;
+        auto fill = [&](int t) {
+            const unsigned dst = (unsigned)(t & 1) * TILE;
+            const int k0 = t * TK;
+            if (k0 + TK <= K) {
+                const real_t *src = src0 + (size_t)(k0 + li * RPP + rp) * ldb;
+#pragma unroll 4
+                for (int p = li; p < NP; p += nl) {
+                    __builtin_amdgcn_global_load_lds((const void *)src, (__attribute__((address_space(3))) void *)(smem + dst + p * 1024), 16, 0, 0);
+                    src += stride;
+                }
+            } else {
+                for (int p = li; p < NP; p += nl) {
+                    int k = k0 + p * RPP + rp;
+                    if (k > K - 1) k = K - 1;        // past the last row: never referenced by an entry
+                    __builtin_amdgcn_global_load_lds((const void *)(src0 + (size_t)k * ldb),
+                                                     (__attribute__((address_space(3))) void *)(smem + dst + p * 1024), 16, 0, 0);
+                }
+            }
+        };
+        if (!(dbg & 1)) fill(0);
+        for (int t = 0; t < T; t++) {
+            __syncthreads();                         // (waits for the DMA of tile t first: vmcnt(0))
+            if (t + 1 < T && !(dbg & 1)) fill(t + 1);
+        }
+        if constexpr (!COLMAJOR) return;
+    }
+
+    const int g = lane / TL_G, lg = lane % TL_G;
+    real_t acc[RG][CPL][VEC];
+    int rows[RG];
+    if (wave < nw) {
+        const unsigned lane16 = (unsigned)lg * 16;
+        int pos[RG], end[RG];
+        int jv[RG][WIN];
+        double av[RG][WIN];
+        if (wave == 0) {                             // the row of zeros
+            if (lane < ROWB / 16) *reinterpret_cast<V *>(smem + ZOFF + lane * 16) = V{};
+        }
+#pragma unroll
+        for (int i = 0; i < RG; i++) {
+            const int row = row0 + (i * nw + wave) * TL_NG + g;
+            rows[i] = row;
+            pos[i] = end[i] = 0;
+            if (row < m) { pos[i] = indptr[row]; end[i] = indptr[row + 1]; }
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+#pragma unroll
+                for (int v = 0; v < VEC; v++) acc[i][c][v] = 0;
+        }
+        // ---- rows that are not sorted by column: summed whole from global memory, in storage order
+        if (unsorted) {
+#pragma unroll
+            for (int i = 0; i < RG; i++) {
+                const bool slow = rows[i] < m && unsorted[rows[i]] != 0;
+                if (__ballot(slow) == 0) continue;
+                const int gbase = g * TL_G;
+                int longest = slow ? end[i] - pos[i] : 0;
+#pragma unroll
+                for (int o = TL_G; o < MX_WAVE; o <<= 1) longest = max(longest, __shfl_xor(longest, o, MX_WAVE));
+                longest = uniform(longest);
+                for (int k0 = 0; k0 < longest; k0 += TL_G) {
+                    const int k = pos[i] + k0 + lg;
+                    int jw = 0;
+                    real_t aw = 0;
+                    if (slow && k < end[i]) { jw = indices[k]; aw = (real_t)values[k]; }
+                    for (int u = 0; u < TL_G; u++) {
+                        const int jj = __shfl(jw, gbase + u, MX_WAVE);
+                        const real_t a = __shfl(aw, gbase + u, MX_WAVE);
+                        const bool valid = slow && pos[i] + k0 + u < end[i];
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            int col = c0 + c * (TL_G * VEC) + lg * VEC;
+                            if (col > n - VEC) col = n - VEC;
+                            real_t b[VEC];
+                            vload<real_t, VEC>(b, B + (size_t)(valid ? jj : 0) * ldb + col);
+#pragma unroll
+                            for (int v = 0; v < VEC; v++) acc[i][c][v] = valid ? mx_fma(a, b[v], acc[i][c][v]) : acc[i][c][v];
+                        }
+                    }
+                }
+                if (slow) pos[i] = end[i];
+            }
+        }
+        // ---- the sweep.  The window of row i: entries pos .. pos + 16 WIN - 1, lane l of the group holds entry pos + l (+ 16).
+        // Entries are read through buffer descriptors that start at the row block's first entry and end with the matrix:
+        // a lane past the end reads zero instead of faulting, so EVERY lane loads on every visit — the number of loads in
+        // flight is the same on every path and the compiler waits for THIS row's window with a counted vmcnt, the other
+        // rows' windows still in flight — and the second window is the first one's address + an immediate.
+        const int first = uniform(indptr[min(row0, m)]);
+        const long long left_entries = (long long)uniform(indptr[m]) - first;
+        const unsigned bytes_j = (unsigned)min(left_entries * 4, 0xFFFFFFFFll), bytes_x = (unsigned)min(left_entries * 8, 0xFFFFFFFFll);
+        const __amdgpu_buffer_rsrc_t rs_j = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(indices + first), 0, bytes_j, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(values + first), 0, bytes_x, 0x00020000);
+        int posl[RG], rem[RG];                       // pos - first + lane-in-group; entries the row has left
+#pragma unroll
+        for (int i = 0; i < RG; i++) { posl[i] = pos[i] - first + lg; rem[i] = end[i] - pos[i]; }
+        auto load_window = [&](int i) {
+            const int o4 = posl[i] << 2, o8 = posl[i] << 3;
+#pragma unroll
+            for (int w = 0; w < WIN; w++) {
+                jv[i][w] = __builtin_amdgcn_raw_buffer_load_b32(rs_j, o4 + w * TL_G * 4, 0, 0);     // (used as loaded: nothing waits here)
+                av[i][w] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_x, o8 + w * TL_G * 8, 0, 0));
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < RG; i++) {
+            load_window(i);
+            asm volatile("" : : : "memory");         // (the loop's order of loads, so that its counted waits hold from the first round on)
+        }
+        const int g8 = g * 8;
+
+        for (int t = 0; t < T; t++) {
+            __syncthreads();                         // tile t has landed; everybody is done with tile t - 1
+            const int kend = (t + 1) * TK;
+            const unsigned basek = (unsigned)(t & 1) * TILE - (unsigned)(t * TK) * ROWB;     // LDS offset of row j: basek + j * ROWB
+            // one visit of (row i of every group, tile t); returns the largest number of entries a group had in the tile
+            auto visit = [&](int i) -> int {
+                unsigned off[WIN];
+                real_t aa[WIN];
+                unsigned packed = 0;                 // entries in the tile, one byte per group (scalar)
+#pragma unroll
+                for (int w = 0; w < WIN; w++) {
+                    // (the ballot of each comparison is the comparison's own result register; the ballot of their AND would be
+                    // re-materialised lane by lane)
+                    const bool valid = lg + w * TL_G < rem[i], below = jv[i][w] < kend;
+                    const bool in = valid & below;
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(valid) & __builtin_amdgcn_ballot_w64(below);
+                    packed += (unsigned)__popcll(mask & 0xFFFFull) | (unsigned)__popcll(mask & 0xFFFF0000ull) << 8 |
+                              (unsigned)__popcll(mask & 0xFFFF00000000ull) << 16 | (unsigned)__popcll(mask & 0xFFFF000000000000ull) << 24;
+                    off[w] = in ? basek + (unsigned)jv[i][w] * ROWB : ZOFF;
+                    aa[w] = in ? (real_t)av[i][w] : (real_t)-0.0;      // narrowed per entry for f32 (matmul.cpp:53-57)
+                }
+                unsigned m01, m23, mx;
+                asm("s_max_u32 %0, %1, %2" : "=s"(m01) : "s"(packed & 0xFFu), "s"((packed >> 8) & 0xFFu) : "scc");
+                asm("s_max_u32 %0, %1, %2" : "=s"(m23) : "s"((packed >> 16) & 0xFFu), "s"(packed >> 24) : "scc");
+                asm("s_max_u32 %0, %1, %2" : "=s"(mx) : "s"(m01), "s"(m23) : "scc");
+                const int maxc = (int)mx;
+                const int cnt = (int)__builtin_amdgcn_ubfe(packed, (unsigned)g8, 8u);
+                // the next window is on its way while this one is summed.  (The empty statement pins the order: the window's
+                // last readers above, the loads below — so that a load may land in the register it replaces instead of a
+                // fresh one that the compiler then has to copy, i.e. wait for, at the end of the round.  Its s_nop: a DPP
+                // read of a VGPR needs two wait states after the VALU write.)
+                if constexpr (WIN == 1) asm volatile("s_nop 1" : "+v"(off[0]), "+v"(aa[0]) : : "memory");
+                else asm volatile("s_nop 1" : "+v"(off[0]), "+v"(aa[0]), "+v"(off[WIN - 1]), "+v"(aa[WIN - 1]) : : "memory");
+                posl[i] += cnt;
+                rem[i] -= cnt;
+                load_window(i);
+                if (maxc > 0 && !(dbg & 2)) {        // (wave-uniform)
+                    tl_window<real_t, CPL>(smem, maxc, off[0], aa[0], lane16, acc[i]);
+                    if constexpr (WIN > 1) {
+                        if (maxc > TL_G) tl_window<real_t, CPL>(smem, maxc - TL_G, off[1], aa[1], lane16, acc[i]);
+                    }
+                }
+                return maxc;
+            };
+            // a group that filled its window may have more entries in this tile: the wavefront then goes round its rows
+            // again (the others find nothing) — every round loads every row's window exactly once, in the same order, so
+            // that a row's window is always awaited RG - 1 visits after it was asked for (counted vmcnt)
+            bool again;
+            do {
+                again = false;
+#pragma unroll
+                for (int i = 0; i < RG; i++) again |= visit(i) == WIN * TL_G;
+            } while (again);
+        }
+        if constexpr (!COLMAJOR) {
+#pragma unroll
+            for (int i = 0; i < RG; i++) {
+                if (rows[i] >= m) continue;
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    const int col = c0 + c * (TL_G * VEC) + lg * VEC;
+                    if (col >= n) continue;
+                    real_t *dst = C + (size_t)rows[i] * ldc + col;
+                    if (c_vec) vstore<real_t, VEC>(dst, acc[i][c]);
+                    else {
+#pragma unroll
+                        for (int v = 0; v < VEC; v++) dst[v] = acc[i][c][v];
+                    }
+                }
+            }
+            return;
+        }
+    }
+    if constexpr (COLMAJOR) {
+        // the block's R x W sums through LDS (the tiles are done with): column segments of R consecutive rows
+        real_t *tr = reinterpret_cast<real_t *>(smem);
+        const int RP = R | 1;
+        __syncthreads();
+        if (wave < nw) {
+#pragma unroll
+            for (int i = 0; i < RG; i++) {
+                const int r = rows[i] - row0;
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) tr[(c * (TL_G * VEC) + lg * VEC + v) * RP + r] = acc[i][c][v];
+            }
+        }
+        __syncthreads();
+        const int ncols = min(W, n - c0), nrows = min(R, m - row0);
+        for (int idx = threadIdx.x; idx < ncols * R; idx += blockDim.x) {
+            const int c = idx / R, r = idx % R;
+            if (r < nrows) C[(size_t)(c0 + c) * ldc + row0 + r] = tr[c * RP + r];
+        }
+    }
+}
+
+// per-row flags for the tile kernel: 1 = the row is NOT sorted by column (src/misc.cpp:118-128's test); one wavefront per row
+__global__ __launch_bounds__(512)
+void tile_unsorted_rows_kernel(int m, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                               unsigned char *__restrict__ flags)
+{
+    const int lane = lane_id();
+    const int row = blockIdx.x * 8 + uniform(threadIdx.x / MX_WAVE);
+    if (row >= m) return;
+    const int s = uniform(indptr[row]), e = uniform(indptr[row + 1]);
+    bool bad = false;
+    for (int k = s + lane; k + 1 < e; k += MX_WAVE) bad |= indices[k] > indices[k + 1];
+    const bool any = __ballot(bad) != 0;
+    if (lane == 0) flags[row] = any ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Geometry: rows per workgroup so that ONE round of workgroups fills the 256 CUs when the product is small (every
+// workgroup keeps two 64 KB tiles: one per CU), the largest block otherwise (the tile fills shrink with 1 / R).
+struct TileGeom { int cpl, rg, nw, nl, nslabs, nrb; };
+
+static TileGeom tile_geometry(int m, int n, int dense_bytes, int cpl, int rg, int nw, int colmajor, int tile_bytes)
+{
+    const int vec = 16 / dense_bytes, w1 = TL_G * vec;
+    TileGeom gm;
+    if (cpl != 1 && cpl != 2) cpl = n > 3 * w1 && (long long)m * ((n + 2 * w1 - 1) / (2 * w1)) >= 256LL * 120 ? 2 : 1;
+    gm.cpl = cpl;
+    gm.nslabs = (n + w1 * cpl - 1) / (w1 * cpl);
+    if (rg < 1 || rg > (cpl == 1 ? 5 : 4) || nw < 1 || nw > TL_MAX_WAVES) {
+        const int per_slab = 256 / gm.nslabs > 0 ? 256 / gm.nslabs : 1;
+        int want = (int)ceil_div(m, per_slab);                            // rows per workgroup for one full round
+        if (want > TL_MAX_WAVES * TL_NG * 4) want = TL_MAX_WAVES * TL_NG * 4;
+        // column-major C leaves through the tiles' LDS: (R | 1) x W sums must fit
+        const int fit = (2 * tile_bytes + 256 * cpl) / (256 * cpl) - 1;
+        if (colmajor && want > fit) want = fit;
+        // among the geometries that hold `want` rows: the fewest visits in a row on the busiest SIMD (the workgroup's
+        // wavefronts, loaders included, are dealt round robin to the four SIMDs; a wavefront makes rg visits per tile), then
+        // the most wavefronts, then the least slack (measured at the vignette's shape, want = 157: 3 x 14 0.108 ms, 4 x 10
+        // 0.114, 5 x 8 0.124)
+        int best_rg = 4, best_nw = TL_MAX_WAVES;
+        long long best_cost = 1LL << 60;
+        for (int r = 1; r <= (cpl == 1 ? 5 : 4); r++) {
+            int w = (int)ceil_div(want, TL_NG * r);
+            if (w > TL_MAX_WAVES) continue;
+            if (w < 4) w = 4;
+            const int loaders = w <= TL_MAX_WAVES - 1 ? 2 : 1;
+            const long long serial = ceil_div(w + loaders, 4) * r, slack = (long long)w * TL_NG * r - want;
+            const long long cost = (serial << 32) + ((long long)(TL_MAX_WAVES - w) << 16) + slack;
+            if (cost < best_cost) { best_cost = cost; best_rg = r; best_nw = w; }
+        }
+        rg = best_rg; nw = best_nw;
+    }
+    gm.rg = rg; gm.nw = nw;
+    gm.nl = nw <= TL_MAX_WAVES - 1 ? 2 : 1;
+    gm.nrb = (int)ceil_div(m, nw * TL_NG * rg);
+    return gm;
+}
+
+template <typename real_t, int CPL, int RG, int WIN, int TILE>
+static void launch_tile(const TileGeom &gm, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+                        const unsigned char *unsorted, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
+                        hipStream_t st)
+{
+    const int per = 8 % gm.nslabs == 0 ? 8 / gm.nslabs : 0;
+    const unsigned grid = per ? (unsigned)(8 * ceil_div(gm.nrb, per)) : (unsigned)(gm.nrb * gm.nslabs);
+    const dim3 block((unsigned)(gm.nw + gm.nl) * MX_WAVE);
+    if (colmajor)
+        hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, true>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
+                           gm.nrb, indptr, indices, values, unsorted, B, ldb, C, ldc, c_vec, gm.nl, getenv("MXGPU_TILE_DEBUG") ? atoi(getenv("MXGPU_TILE_DEBUG")) : 0);
+    else
+        hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, false>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
+                           gm.nrb, indptr, indices, values, unsorted, B, ldb, C, ldc, c_vec, gm.nl, getenv("MXGPU_TILE_DEBUG") ? atoi(getenv("MXGPU_TILE_DEBUG")) : 0);
+}
+
+template <typename real_t, int CPL, int WIN, int TILE>
+static void launch_tile_rg(const TileGeom &gm, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
+                           const unsigned char *unsorted, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
+                           hipStream_t st)
+{
+#define MX_TL_RG(RG) launch_tile<real_t, CPL, RG, WIN, TILE>(gm, m, n, K, indptr, indices, values, unsorted, B, ldb, C, ldc, colmajor, c_vec, st)
+    switch (gm.rg) {
+    case 1: MX_TL_RG(1); break;
+    case 2: MX_TL_RG(2); break;
+    case 3: MX_TL_RG(3); break;
+    case 4: MX_TL_RG(4); break;
+    default:
+        if constexpr (CPL == 1) MX_TL_RG(5);         // (five rows per group still fit 128 registers with 256-byte slabs)
+        else MX_TL_RG(4);
+        break;
+    }
+#undef MX_TL_RG
+}
+
+// can the tile kernel take these operands?  16-byte aligned rows of B (the LDS-DMA moves 16 bytes per lane), at least one
+// whole vector per row
+template <typename real_t>
+bool tile_ok(int n, const real_t *B, size_t ldb)
+{
+    constexpr int VEC = 16 / (int)sizeof(real_t);
+    return n >= VEC && n % VEC == 0 && ldb % VEC == 0 && (uintptr_t)B % 16 == 0;
+}
+template bool tile_ok<double>(int, const double *, size_t);
+template bool tile_ok<float>(int, const float *, size_t);
+
+// variant: 0 = chosen here; otherwise cpl + 4 * rg + 32 * (32 KB tiles, 16-entry windows)
+// (tools/tile_sweep.py); nw: compute wavefronts per workgroup (0 = chosen here).  rows_sorted != 0: the caller vouches for column-sorted rows (no flag pass).
+template <typename real_t>
+int tile_spmm(int m, int n, int K, int variant, int nw, int rows_sorted, const int32_t *indptr, const int32_t *indices,
+              const double *values, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream)
+{
+    constexpr int VEC = 16 / (int)sizeof(real_t);
+    if (!tile_ok<real_t>(n, B, ldb)) return set_error("tile_spmm: rows of B must be 16-byte aligned whole vectors (n = %d, ldb = %zu)", n, ldb);
+    const int cpl = variant & 3, rg = (variant >> 2) & 7, small_tile = (variant >> 5) & 1, one_loader = (variant >> 6) & 1;
+    TileGeom gm = tile_geometry(m, n, (int)sizeof(real_t), cpl, rg, nw, colmajor, small_tile ? 32768 : 65536);
+    if (one_loader) gm.nl = 1;
+    const int c_vec = colmajor || ((ldc % VEC == 0) && ((uintptr_t)C % 16 == 0));
+    {
+        const int R = gm.nw * TL_NG * gm.rg, rowb = 256 * gm.cpl, lds = 2 * (small_tile ? 32768 : 65536) + rowb;
+        if (colmajor && (R | 1) * rowb > lds)
+            return set_error("tile_spmm: %d rows per workgroup do not fit the column-major epilogue's LDS (%d bytes)", R, lds);
+    }
+    unsigned char *flags = nullptr;
+    if (!rows_sorted) {
+        flags = (unsigned char *)scratch_buffer(MX_SCRATCH_TILE_FLAGS, (size_t)m);
+        scratch_acquire(MX_SCRATCH_TILE_FLAGS, stream);
+        if (!flags) return set_error("tile_spmm: cannot allocate %d bytes of row flags", m);
+    }
+    kt_begin(stream);
+    if (flags)
+        hipLaunchKernelGGL(tile_unsorted_rows_kernel, dim3((unsigned)ceil_div(m, 8)), dim3(512), 0, stream, m, indptr, indices, flags);
+#define MX_TL_GO(CPL, WIN, TILE)                                                                                                  \
+    launch_tile_rg<real_t, CPL, WIN, TILE>(gm, m, n, K, indptr, indices, values, flags, B, ldb, C, ldc, colmajor, c_vec, stream)
+    if (gm.cpl == 2) { if (small_tile) MX_TL_GO(2, 1, 32768); else MX_TL_GO(2, 2, 65536); }
+    else { if (small_tile) MX_TL_GO(1, 1, 32768); else MX_TL_GO(1, 2, 65536); }
+#undef MX_TL_GO
+    if (flags) scratch_done(MX_SCRATCH_TILE_FLAGS, stream);
+    kt_end(stream);
+    MX_LAUNCH_CHECK();
+    return 0;
+}
+template int tile_spmm<double>(int, int, int, int, int, int, const int32_t *, const int32_t *, const double *, const double *, size_t,
+                               double *, size_t, int, hipStream_t);
+template int tile_spmm<float>(int, int, int, int, int, int, const int32_t *, const int32_t *, const double *, const float *, size_t,
+                              float *, size_t, int, hipStream_t);
+
+}  // namespace mx

@@ -185,7 +185,7 @@ def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajo
             algo = 4                                                 # too much padding: AUTO's fallback (row-split kernel)
         elif pick.value != 3:
             algo = pick.value                                        # the choice made WITH a kept plan in mind stands
-    sorted_rows = A.rows_sorted() if algo == 2 else False              # only the slab kernel's panels need it
+    sorted_rows = A.rows_sorted() if algo in (2, 5) else False         # the slab kernel's panels and the tile kernel's sweep need it
     check(lib.mxd_spmm_csr_dense_ex2(C.c_int(A.m), C.c_int(n), C.c_int(A.K), C.c_int64(A.nnz), _dp(A.indptr), _dp(A.indices),
                                      _dp(A.values), _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),
                                      C.c_int(dt), C.c_int(1 if colmajor else 0), C.c_int(algo),

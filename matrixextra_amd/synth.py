@@ -74,6 +74,46 @@ def csr_skewed_fast(m, K, mean_nnz, seed=SEED_A, sigma=1.0):
     return indptr.astype(np.int32), indices, values
 
 
+def zipf_column_cdf(K, alpha, seed):
+    """Column popularity of real sparse data (bag-of-words / one-hot features; the vignette's own application is LibSVM
+    real-sim, vignettes/Introducing_MatrixExtra.Rmd:442-502): P(column of popularity rank r) ~ 1 / (r + 1)^alpha, the ranks
+    dealt to column ids by a seeded permutation (hot columns sit anywhere in [0, K)).  Returns (cdf over ranks float64[K],
+    rank -> column id int32[K])."""
+    w = 1.0 / np.power(np.arange(1, K + 1, dtype=np.float64), alpha)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    perm = np.random.default_rng(np.random.PCG64(seed + 7919)).permutation(K).astype(np.int32)
+    return cdf, perm
+
+
+def csr_zipf(m, K, mean_nnz, alpha=1.0, sigma=1.0, seed=SEED_A):
+    """Realistic dgRMatrix contents: power-law COLUMNS (zipf_column_cdf: exponent alpha) and log-normal ROW lengths (mean
+    mean_nnz, shape sigma; sigma = 0: every row draws mean_nnz ids).  Column ids drawn with replacement, sorted per row,
+    duplicates inside a row dropped — hot columns collide, so rows come out a little shorter than drawn — values ~ U(-1, 1).
+    real-sim's shape: csr_zipf(72_309, 20_958, 51)."""
+    rng = np.random.default_rng(np.random.PCG64(seed))
+    if sigma > 0:
+        mu = np.log(mean_nnz) - 0.5 * sigma * sigma
+        lens = np.minimum(np.floor(rng.lognormal(mu, sigma, size=m)).astype(np.int64), K)
+    else:
+        lens = np.full(m, min(int(mean_nnz), K), dtype=np.int64)
+    total = int(lens.sum())
+    cdf, perm = zipf_column_cdf(K, alpha, seed)
+    cols = perm[np.minimum(np.searchsorted(cdf, rng.random(total), side="left"), K - 1)].astype(np.int64)
+    row = np.repeat(np.arange(m, dtype=np.int64), lens)
+    key = row * np.int64(K) + cols
+    key.sort()                                                        # by row, then by column
+    keep = np.ones(total, dtype=bool)
+    keep[1:] = key[1:] != key[:-1]
+    key = key[keep]
+    row = key // K
+    indices = (key - row * K).astype(np.int32)
+    indptr = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(np.bincount(row, minlength=m), out=indptr[1:])
+    values = rng.uniform(-1.0, 1.0, size=indices.size)
+    return indptr.astype(np.int32), indices, values
+
+
 def dense_normal(rows, cols, seed=SEED_B, dtype=np.float64, order="C"):
     rng = np.random.default_rng(np.random.PCG64(seed))
     a = rng.standard_normal(size=(rows, cols))
@@ -121,6 +161,37 @@ def device_csr_fixed(m, K, nnz_row, seed=SEED_A, device="cuda"):
     indptr = (torch.arange(m + 1, dtype=torch.int64, device=device) * nnz_row).to(torch.int32)
     values = torch.rand(m * nnz_row, dtype=torch.float64, device=device, generator=g) * 2.0 - 1.0
     return indptr, c.reshape(-1).contiguous(), values
+
+
+def device_csr_zipf(m, K, mean_nnz, alpha=1.0, sigma=1.0, seed=SEED_A, device="cuda"):
+    """Device twin of csr_zipf (torch RNG: the same distribution, not the same draws): power-law columns, log-normal row
+    lengths, sorted rows, duplicates dropped.  Returns (indptr int32, indices int32, values f64) on the device."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    if sigma > 0:
+        mu = float(np.log(mean_nnz) - 0.5 * sigma * sigma)
+        lens = torch.empty(m, dtype=torch.float64, device=device).log_normal_(mu, sigma, generator=g).floor_().clamp_(max=K).to(torch.int64)
+    else:
+        lens = torch.full((m,), min(int(mean_nnz), K), dtype=torch.int64, device=device)
+    total = int(lens.sum().item())
+    cdf_h, perm_h = zipf_column_cdf(K, alpha, seed)
+    cdf, perm = torch.from_numpy(cdf_h).to(device), torch.from_numpy(perm_h).to(device)
+    u = torch.rand(total, dtype=torch.float64, device=device, generator=g)
+    cols = perm[torch.searchsorted(cdf, u).clamp_(max=K - 1)].to(torch.int64)
+    del u
+    row = torch.repeat_interleave(torch.arange(m, dtype=torch.int64, device=device), lens)
+    key = torch.sort(row * K + cols).values
+    del row, cols
+    keep = torch.ones(total, dtype=torch.bool, device=device)
+    keep[1:] = key[1:] != key[:-1]
+    key = key[keep]
+    row = key // K
+    indices = (key - row * K).to(torch.int32).contiguous()
+    indptr = torch.zeros(m + 1, dtype=torch.int64, device=device)
+    torch.cumsum(torch.bincount(row, minlength=m), 0, out=indptr[1:])
+    values = torch.rand(indices.numel(), dtype=torch.float64, device=device, generator=g) * 2.0 - 1.0
+    return indptr.to(torch.int32), indices, values
 
 
 def device_csr_overlapping(indices, m, K, nnz_row, share=0.5, seed=SEED_A2, device="cuda"):

@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(extra_env, *argv):
+def run_bench(extra_env, *argv, fixed=("--no-extras", "--no-cpu-baseline")):
     import socket
     with socket.socket() as sk:                       # a free port for the one-rank rendezvous
         sk.bind(("127.0.0.1", 0))
@@ -23,7 +23,7 @@ def run_bench(extra_env, *argv):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
-                        "--no-extras", "--no-cpu-baseline", *argv], cwd=ROOT, env=env, capture_output=True, text=True,
+                        *fixed, *argv], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -32,9 +32,9 @@ def run_bench(extra_env, *argv):
 @pytest.mark.gpu
 @pytest.mark.parametrize("overlap", ["1", "0"])
 def test_bench_distributed_path_one_rank(gpu, overlap):
-    d = run_bench({"MXGPU_BENCH_OVERLAP": overlap}, "--rows", "131072", "--cols", "30000", "--nnz-row", "24", "--n", "128",
+    d = run_bench({"MXGPU_BENCH_OVERLAP": overlap}, "--scaling", "weak", "--rows", "131072", "--cols", "30000", "--nnz-row", "24", "--n", "128",
                   "--dtype", "f32")
-    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     assert "allgather" in d and d["allgather"]["bytes_received_per_gpu"] == 0      # (world - 1) blocks arrive
     assert d["parity_max_err_over_max_abs_vs_oracle"] <= 2e-5
 
@@ -51,3 +51,25 @@ def test_bench_strong_scaling_path_one_rank(gpu):
     assert dd["world_size"] == 1 and dd["ranks_in_an_rccl_all_reduce_of_ones"] == 1 and dd["backend"] == "nccl"
     assert dd["rows_total"] == 131072 and sum(dd["row_blocks"]) == 131072
     assert d["parity_max_err_over_max_abs_vs_oracle"] <= 2e-5
+
+
+@pytest.mark.gpu
+def test_bench_default_multi_gpu_line_is_the_metrics_workload(gpu):
+    """What `python bench.py --gpus N` runs on every rank, with one rank here: NO shape arguments -> BASELINE configs[1]
+    (1M x 100k, 32 / row, n = 128, f64), the N = 1 matrix itself cut into nnz-balanced row blocks (strong scaling), the
+    CPU baseline and rank 0's roofline on the line, `value` with the all-gather and `compute_only_gflops` without it, and
+    configs[4] (f32, strong) beside it as extras.cfg5_strong (fewer rows here: one GPU holds the whole of it)."""
+    d = run_bench({"MXGPU_BENCH_OVERLAP": "1"}, "--cfg5-strong-rows", "1048576", "--cpu-seconds", "3", fixed=())
+    assert d["dtype"] == "f64" and d["scaling"] == "strong" and d["n_gpus"] == 1
+    w = d["config"]["workload"]
+    assert "1000000x100000" in w and "nnz/row=32" in w and "100000x128 f64" in w and "BASELINE configs[1]" in w
+    assert "fp64, 1M x 100k, 32 nnz/row, k=128" in d["metric"]
+    dd = d["distributed"]
+    assert dd["world_size"] == 1 and dd["ranks_in_an_rccl_all_reduce_of_ones"] == 1 and dd["rows_total"] == 1_000_000
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    assert d["roofline"]["frac"] > 0 and "rank 0" in d["roofline"]["scope"]
+    assert d["compute_only_gflops"] >= d["value"] > 0
+    assert d["parity_max_err_over_max_abs_vs_oracle"] <= 1e-10
+    c5 = d["extras"]["cfg5_strong"]
+    assert c5["dtype"] == "f32" and c5["value"] > 0 and c5["distributed"]["rows_total"] == 1048576
+    assert c5["parity_max_err_over_max_abs_vs_oracle"] <= 2e-5

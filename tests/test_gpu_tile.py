@@ -1,0 +1,155 @@
+"""The LDS-tile SpMM kernel (csrc/spmm_tile.hip, MX_SPMM_TILE) against the oracle's gemm_csr_drm_as_drm /
+gemm_csr_drm_as_dcm (src/matmul.cpp:118-185): every geometry (rows per lane group, compute wavefronts, 256- and 512-byte
+slabs, 64 KB tiles with 32-entry windows and 32 KB tiles with 16-entry windows), both layouts of C, f64 and f32, rows
+sorted by column (the LDS sweep), rows that are not (summed whole from global memory, flagged by the kernel's own
+sortedness pass), repeated column ids, empty rows, rows denser than a window per tile, K not a multiple of the tile,
+n not a multiple of the slab, NaN / Inf / signed zeros.
+
+Every sum is the reference's storage-order FMA chain BIT FOR BIT, in both layouts: a row is summed by one lane group in
+CSR order, and the padding steps of a group that has fewer entries in a tile than its neighbours add -0.0 * 0.0."""
+import numpy as np
+import pytest
+
+from conftest import rand_csr
+from devmem import spmm_device
+from matrixextra_amd import _lib, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TILE = 5
+
+
+def _oracle(p, j, x, B):
+    return O.tcrossprod_csr_dense(p, j, x, np.asfortranarray(B.T), 1, True)        # the FMA chain
+
+
+def variant(cpl=0, rg=0, small=False):
+    return cpl + 4 * rg + (32 if small else 0)
+
+
+def _run(p, j, x, B, colmajor, var=0, nw=0, rows_sorted=False):
+    return spmm_device(p, j, x, B, colmajor, TILE, rows_sorted, npanels=nw, wg_per_cu=var)
+
+
+def _same(got, ref):
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    np.testing.assert_array_equal(got[ok], ref[ok])
+    np.testing.assert_array_equal(np.signbit(got[ok]), np.signbit(ref[ok]))
+
+
+SHAPES = [                      # m, K, n, density
+    (300, 3000, 100, 0.05),     # the vignette's shape in small: 12 tiles, ~13 entries per row and tile, n = 100 (a 4-column last slab)
+    (37, 700, 32, 0.3),         # rows denser than a 32-entry window per tile: the wavefront goes round its rows again
+    (1, 5000, 128, 0.5),        # one very long row
+    (100, 50, 20, 0.4),         # test-matmul.R:108-114
+    (1000, 257, 64, 0.02),      # K one past a tile
+    (65, 512, 2, 0.2), (513, 1000, 48, 0.1), (90, 200, 96, 0.2), (10, 12, 300, 0.5), (241, 900, 130, 0.1),
+]
+
+
+@pytest.mark.parametrize("colmajor", [False, True])
+@pytest.mark.parametrize("m,K,n,dens", SHAPES)
+def test_tile_is_the_storage_order_fma_chain_f64(gpu, m, K, n, dens, colmajor):
+    p, j, x = rand_csr(m, K, dens, seed=m + 13 * n, sorted_cols=True, empty_rows=(0, m // 2, m - 1) if m > 4 else ())
+    B = np.random.default_rng(n).normal(size=(K, n))
+    ref = _oracle(p, j, x, B)
+    for rows_sorted in (True, False):                  # vouched for / checked by the kernel's own pass
+        _same(_run(p, j, x, B, colmajor, rows_sorted=rows_sorted), ref)
+
+
+@pytest.mark.parametrize("small", [False, True])
+@pytest.mark.parametrize("cpl", [1, 2])
+@pytest.mark.parametrize("rg", [1, 2, 3, 4])
+def test_tile_every_geometry(gpu, rg, cpl, small):
+    m, K, n = 530, 1500, 72
+    p, j, x = rand_csr(m, K, 0.08, seed=rg + 10 * cpl, sorted_cols=True, empty_rows=(3, 200))
+    B = np.random.default_rng(5).normal(size=(K, n))
+    ref = _oracle(p, j, x, B)
+    for nw in (1, 4, 7, 15):
+        for colmajor in (False, True):
+            if colmajor and small and cpl == 2 and nw * 4 * rg > 128:
+                continue                                  # (the column-major epilogue's LDS: refused by the library)
+            _same(_run(p, j, x, B, colmajor, variant(cpl, rg, small), nw, True), ref)
+
+
+def test_tile_refuses_a_geometry_whose_epilogue_does_not_fit(gpu):
+    p, j, x = rand_csr(100, 300, 0.1, seed=1)
+    B = np.zeros((300, 64))
+    with pytest.raises(_lib.MxError, match="column-major epilogue"):
+        _run(p, j, x, B, True, variant(2, 4, True), 15, True)
+
+
+@pytest.mark.parametrize("colmajor", [False, True])
+def test_tile_unsorted_rows_and_repeated_columns(gpu, colmajor):
+    """some rows sorted, some shuffled (flagged by the sortedness pass and summed whole from global memory, in storage
+    order), some with repeated column ids (non-decreasing: the LDS sweep takes them as they come; SpMM accumulates
+    duplicates)"""
+    m, K, n = 190, 2000, 100
+    p, j, x = rand_csr(m, K, 0.1, seed=12, sorted_cols=True)
+    rng = np.random.default_rng(5)
+    for r in range(0, m, 3):
+        s, e = p[r], p[r + 1]
+        perm = rng.permutation(e - s)
+        j[s:e], x[s:e] = j[s:e][perm], x[s:e][perm]
+    for r in range(1, m, 7):
+        s, e = p[r], p[r + 1]
+        if e - s > 4:
+            j[s + 2] = j[s + 1]
+    B = rng.normal(size=(K, n))
+    ref = _oracle(p, j, x, B)
+    for var in (0, variant(1, 2), variant(2, 3), variant(1, 4, True)):
+        _same(_run(p, j, x, B, colmajor, var, 0, False), ref)
+
+
+@pytest.mark.parametrize("colmajor", [False, True])
+@pytest.mark.parametrize("m,K,n,dens", SHAPES[:7] + [(300, 500, 256, 0.05)])
+def test_tile_f32(gpu, m, K, n, dens, colmajor):
+    """B and C f32, the CSR values f64 narrowed per entry (src/matmul.cpp:53-57): the f32 FMA chain bit for bit"""
+    if n % 4:
+        pytest.skip("rows of B must be whole 16-byte vectors")
+    p, j, x = rand_csr(m, K, dens, seed=m + 5 * n, sorted_cols=True, empty_rows=(0,) if m > 4 else ())
+    B = np.random.default_rng(n).normal(size=(K, n)).astype(np.float32)
+    ref = _oracle(p, j, x, B)
+    for var in (0, variant(2, 2), variant(1, 3, True)):
+        got = _run(p, j, x, B, colmajor, var, 0, False)
+        assert got.dtype == np.float32
+        _same(got, ref)
+
+
+def test_tile_nonfinite_values_and_signed_zeros(gpu):
+    """NaN / Inf in A or B reach exactly the cells they reach in the reference's loop — the padding steps of a lane group
+    (fewer entries in the tile than its neighbours) multiply -0.0 with a row of zeros, never with a row of B — and a sum
+    that is -0.0 stays -0.0 (x + -0.0 = x for every x)"""
+    m, K, n = 150, 600, 24
+    p, j, x = rand_csr(m, K, 0.1, seed=3, sorted_cols=True)
+    B = np.random.default_rng(4).normal(size=(K, n))
+    B[0, :] = np.inf
+    B[j[5], 3] = np.nan
+    B[17, :] = 0.0
+    x[7] = np.inf
+    x[p[40]:p[41]] = -1e-200                     # products that underflow to -0.0: the chain's running sum becomes -0.0 ...
+    B[j[p[40]:p[41]], 5] = 1e-200                # ... and must not be flipped to +0.0 by a padding step
+    ref = _oracle(p, j, x, B)
+    assert np.signbit(ref[40, 5]) and ref[40, 5] == 0.0
+    for colmajor in (False, True):
+        for var in (0, variant(1, 1), variant(2, 4)):
+            _same(_run(p, j, x, B, colmajor, var, 0, True), ref)
+
+
+def test_tile_refuses_unaligned_rows_of_b(gpu):
+    p, j, x = rand_csr(50, 300, 0.1, seed=1)
+    with pytest.raises(_lib.MxError, match="16-byte"):
+        _run(p, j, x, np.zeros((300, 33)), False)
+
+
+def test_tile_at_the_published_shape_fifth(gpu):
+    """a fifth of dense 100 x 1e4 %*% CSC 1e4 x 1e4, d = .05 (vignette Rmd:247-251): 2,000 rows of 500 entries, one round of
+    workgroups; bitwise the FMA chain, and run-to-run identical"""
+    p, j, x = synth.csr_fixed(2000, 10_000, 500, seed=7)
+    B = synth.dense_normal(10_000, 100, seed=8)
+    ref = _oracle(p, j, x, B)
+    got = _run(p, j, x, B, False, 0, 0, True)
+    _same(got, ref)
+    np.testing.assert_array_equal(got, _run(p, j, x, B, False, 0, 0, False))
+    assert _lib.load().mxd_spmm_last_kernel() == b"spmm_tile_kernel"

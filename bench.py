@@ -890,7 +890,7 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
         Bv = torch.from_numpy(np.ascontiguousarray(Xd.T)).cuda()          # K x n row-major = X column-major
         algos = {}
         for name, kw in (("auto", dict(algo=0)), ("row_wave", dict(algo=1)), ("slab", dict(algo=2)), ("row_split", dict(algo=4)),
-                         ("row_split_one_panel", dict(algo=4, npanels=1))):
+                         ("row_split_one_panel", dict(algo=4, npanels=1)), ("tile", dict(algo=5))):
             D.spmm(Av, Bv, colmajor=False, **kw)
             kn = lib.mxd_spmm_last_kernel().decode()
             # (the first leg follows seconds of CPU work — the oracle, the export timings —: 4 ms of launches do not bring an
@@ -904,7 +904,23 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
         bytv = synth.spmm_algorithmic_bytes(mv, Kv, nv, Av.nnz, 8)
         gbv = Av.nnz * nv * 8
         vig_traffic = {}
-        if algos["auto"]["kernel"] == "spmm_rowsplit_kernel":        # AUTO's launches: the cursor kernel + one launch per column panel
+        on_chip = {}
+        if algos["auto"]["kernel"] == "spmm_tile_kernel":            # AUTO = the LDS-tile kernel (round 5): one launch
+            import ctypes as C
+            ca, cb, ct, cp, ccpl = C.c_double(), C.c_double(), C.c_double(), C.c_int(), C.c_int()
+            _lib.check(lib.mxd_spmm_auto_cost2(C.c_int(mv), C.c_int(nv), C.c_int(Kv), C.c_int64(Av.nnz), C.c_int(1), C.c_int(0), C.c_int(0), C.c_int(1),
+                                               C.byref(ca), C.byref(cb), C.byref(ct), C.byref(cp), C.byref(ccpl)))
+            vig_traffic = committed_kernels_traffic([("spmm_tile_kernel", 1)], tdev * 1e3)
+            # what the kernel moves on chip: every entry reads one (padded) row of the slab from LDS; B leaves L2 once per
+            # (row block, slab, K-tile): workgroups x tiles x 64 KB
+            wslab = 32 * ccpl.value
+            nsl = -(-nv // wslab)
+            lds_bytes = Av.nnz * nsl * wslab * 8
+            geo = {"slab_bytes": 256 * ccpl.value, "slabs": nsl}
+            on_chip = {"lds_read": {"bytes_per_launch": int(lds_bytes), "achieved_GBps": round(lds_bytes / tdev / 1e9, 0),
+                                    "guide_ceiling_GBps": 150000, "useful_bytes": int(gbv)},
+                       "model_us": {"tile": round(ct.value, 1), "row_split": round(ca.value, 1), "planned": round(cb.value, 1)}, "geometry": geo}
+        elif algos["auto"]["kernel"] == "spmm_rowsplit_kernel":      # AUTO's launches: the cursor kernel + one launch per column panel
             import ctypes as C
             ca, cb, cp = C.c_double(), C.c_double(), C.c_int()
             _lib.check(lib.mxd_spmm_auto_cost(C.c_int(mv), C.c_int(nv), C.c_int(Kv), C.c_int64(Av.nnz), C.c_int(0), C.c_int(0), C.byref(ca),
@@ -913,12 +929,15 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
             vig_traffic = committed_kernels_traffic(ks, tdev * 1e3)
             vig_traffic["column_panels"] = cp.value
         ev = {"device_ms": algos["auto"]["ms"], "export_ms_median": round(float(np.median(te[2:])) * 1e3, 3),
-              # what bounds it: every entry gathers one 800-byte row of B (8 MB, twice an XCD's L2) through the CUs' L1s
+              # what bounded it through round 4: every entry gathers one 800-byte row of B (8 MB, twice an XCD's L2) through the
+              # CUs' L1s — the figure the row-split kernel would need (its time: kernels_ms.row_split)
               "l2_to_l1_gather": {"bytes_per_launch": int(gbv), "achieved_GBps": round(gbv / tdev / 1e9, 0),
-                                  "guide_ceiling_GBps": [16000, 22000], "bare_gather_GBps_round2": 28000},
+                                  "guide_ceiling_GBps": [16000, 22000], "bare_gather_GBps_round2": 28000,
+                                  "note": "nnz * n * 8: bytes a register-gather kernel pulls from L2; the tile kernel serves them from LDS"
+                                  if algos["auto"]["kernel"] == "spmm_tile_kernel" else "nnz * n * 8"},
               "GFLOP/s_device": round(2.0 * Av.nnz * nv / tdev / 1e9, 1),
               "GFLOP/s_export": round(2.0 * Av.nnz * nv / float(np.median(te[2:])) / 1e9, 1),
-              "kernels_ms": algos, "roofline": roofline(bytv, tdev, **vig_traffic),
+              "kernels_ms": algos, "roofline": roofline(bytv, tdev, **vig_traffic), **on_chip,
               "parity_max_err_over_max_abs_vs_oracle": errv,
               "reference_published": {"ms": 72.74, "GFLOP/s": 13.7, "hardware": "unstated",
                                       "source": "inst/doc/Introducing_MatrixExtra.html:668 (vignette Rmd:247-251) — context only"}}

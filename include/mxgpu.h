@@ -196,6 +196,20 @@ int mxd_spmm_csr_dense(int m, int n,
  *                          FMA chain in both layouts; what wg_per_cu = 0 picks up to 56 / 40 / 24 entries per row with
  *                          8 / 16 / 32 lanes per row (falls back to one wavefront per row when B's rows are not 16-byte
  *                          aligned or fill the wavefront)
+ *   algo MX_SPMM_TILE    : DENSE-ISH sparse operands (a row block of A comes back to every row of B several times: the
+ *                          reference's published dense x CSC product at density .05, its test matrices at .4): workgroup =
+ *                          row block of up to 300 rows x one 256- / 512-byte column slab; K-tiles of the slab of B (64 KB) are
+ *                          brought into LDS by loader wavefronts with LDS-DMA (global_load_lds_dwordx4) while the compute
+ *                          wavefronts sum their rows from the previous tile — B leaves L2 once per row block, not once per
+ *                          entry.  A row is summed by one 16-lane group in storage order: bit for bit the reference's FMA chain
+ *                          in BOTH layouts of C.  Needs 16-byte aligned rows of B (n a multiple of 2 / 4) and rows sorted by
+ *                          column for the LDS sweep: rows_sorted = 1 = the caller vouches for it; otherwise a sortedness pass
+ *                          flags every row (one read of the indices) and a row that is not sorted is summed whole from global
+ *                          memory — always correct.  wg_per_cu = cpl + 4 * rg + 32 * small (cpl: 1 = 256-byte slabs, 2 = 512;
+ *                          rg = rows per lane group 1 .. 5; small = 32 KB tiles with 16-entry windows), npanels = compute
+ *                          wavefronts per workgroup (4 .. 15); 0 = chosen from the shape (csrc/spmm_tile.hip tile_geometry,
+ *                          tile_est_us).  AUTO picks it when its cost model beats the row-split kernel's and the planned
+ *                          sweep's by 10 % (tools/tile_map.py, profiles/r05_tile_map.json).
  * mxd_spmm_csr_dense_ex2: the same with nnz = the number of entries of A (indptr[m] - indptr[0]) when the caller knows it;
  * -1 = unknown (ROWSPLIT then reads indptr[m] from the device: one 4-byte copy and a stream sync). */
 typedef enum { MX_SPMM_AUTO = 0, MX_SPMM_ROWWAVE = 1, MX_SPMM_SLAB = 2, MX_SPMM_PLANNED = 3, MX_SPMM_ROWSPLIT = 4,
@@ -239,11 +253,17 @@ int mxd_spmm_auto_algo(int m, int n, int K, int dense_dtype, const void *B, size
 /* ... with the entry count (-1 = unknown: the rule above) and whether the caller keeps a plan across products: a cost model of
  * the row-split kernel and the planned sweep fitted to a map of 272 shapes (tools/auto_map.py, profiles/r04_auto_map.json;
  * csrc/spmm.hip spmm_auto_cost) chooses between MX_SPMM_ROWSPLIT, _PLANNED and, for one-slab products of very short rows,
- * _SLAB; products below 2^22 multiply-adds stay on MX_SPMM_ROWWAVE.  mxd_spmm_auto_cost: the model's two estimates. */
+ * _SLAB and (round 5) MX_SPMM_TILE for dense-ish operands; products below 2^22 multiply-adds with rows of at most 32 entries (mean)
+ * stay on MX_SPMM_ROWWAVE.  keep_plan also says that the caller caches the matrix's sortedness (DeviceCSR, the CSR cache do).
+ * mxd_spmm_auto_cost: the model's two estimates. */
 int mxd_spmm_auto_algo2(int m, int n, int K, int64_t nnz /* -1 = unknown */, int keep_plan, int dense_dtype, const void *B,
                         size_t ldb, const void *C, size_t ldc, int colmajor_out, int *algo);
 int mxd_spmm_auto_cost(int m, int n, int K, int64_t nnz, int keep_plan, int dense_dtype, double *rowsplit_us, double *planned_us,
                        int *panels);
+/* ... and the LDS-tile kernel's estimate (round 5) with the slab width it would take (tile_cpl: 1 = 256 bytes, 2 = 512);
+ * rows_sorted = 0 adds the sortedness pass the kernel then runs */
+int mxd_spmm_auto_cost2(int m, int n, int K, int64_t nnz, int keep_plan, int dense_dtype, int colmajor_out, int rows_sorted,
+                        double *rowsplit_us, double *planned_us, double *tile_us, int *panels, int *tile_cpl);
 int mxd_spmm_plan_create_auto(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
                               int npanels, void *stream, mx_spmm_plan **plan, int *ready);
 

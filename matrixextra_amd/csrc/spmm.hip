@@ -115,8 +115,8 @@ namespace mx {
 // keep_plan: the caller keeps the plan across products (DeviceCSR, the exports' CSR cache) — the build is not charged.
 // Callers that do not know nnz get the old rule.  Products below 2^22 multiply-adds are launch-bound whatever runs and
 // stay on the row-wave kernel, whose sums are the reference's storage-order FMA chain bit for bit.
-struct AutoCost { double rowsplit_us, planned_us; int panels; };
-static AutoCost spmm_auto_cost(int m, int n, int K, int64_t nnz, int sz, bool keep_plan)
+struct AutoCost { double rowsplit_us, planned_us, tile_us; int panels; };
+static AutoCost spmm_auto_cost(int m, int n, int K, int64_t nnz, int sz, bool keep_plan, int colmajor = 0, bool rows_sorted = false)
 {
     const double avg = m > 0 ? (double)nnz / m : 0.0;
     const int cols_per_line = 128 / sz;
@@ -135,6 +135,9 @@ static AutoCost spmm_auto_cost(int m, int n, int K, int64_t nnz, int sz, bool ke
     const double sweep_rate = (plan_panels > 1.0 ? 19.0 : 23.5) * fill;
     c.planned_us = (double)nnz * slabs * 128.0 / rate((double)K * 128.0 / plan_panels, sweep_rate, 8.5 * fill) +
                    0.005e-3 * m * slabs * plan_panels + 15.0 + (keep_plan ? 0.0 : 36.0 + 6e-6 * (double)nnz);
+    // the LDS-tile kernel (spmm_tile.hip, round 5): its own model; a caller that does not vouch for column-sorted rows pays
+    // the sortedness pass (one read of the indices) on top
+    c.tile_us = tile_est_us(m, n, K, sz, avg, colmajor, nullptr) + (rows_sorted ? 0.0 : 3.0 + (double)nnz * 4.0 / 3e6);
     return c;
 }
 static int spmm_auto_algo(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
@@ -146,8 +149,15 @@ static int spmm_auto_algo(int m, int n, int K, int64_t nnz, int dense_dtype, con
     const size_t b_bytes = (size_t)K * (size_t)n * sz;
     const bool big = ok && b_bytes > ((size_t)8 << 20) && (long long)m * n >= (1LL << 24);
     if (nnz < 0) return big ? (K < (1 << 25) ? MX_SPMM_PLANNED : MX_SPMM_SLAB) : MX_SPMM_ROWWAVE;     // rounds 1-3
-    if (nnz * (long long)n < (1LL << 22)) return MX_SPMM_ROWWAVE;
-    if (!ok || m < 32768) return MX_SPMM_ROWSPLIT;
+    // (tiny products are launch-bound whatever runs — unless their rows are long: the row-wave kernel walks a row's entries
+    // one dependent read after the other; m = 1000, 200 per row, n = 16: 0.074 ms there, 0.010 in the row-split kernel; 50 per row: 0.023 and 0.012)
+    if (nnz * (long long)n < (1LL << 22) && nnz <= 32LL * m) return MX_SPMM_ROWWAVE;
+    const bool tile_can = dense_dtype == MX_F64 ? tile_ok<double>(n, (const double *)B, ldb) : tile_ok<float>(n, (const float *)B, ldb);
+    if (!ok || m < 32768) {
+        if (!tile_can) return MX_SPMM_ROWSPLIT;
+        const AutoCost c = spmm_auto_cost(m, n, K, nnz, sz, keep_plan, colmajor, keep_plan);
+        return c.tile_us * 1.1 < c.rowsplit_us ? MX_SPMM_TILE : MX_SPMM_ROWSPLIT;
+    }
     if (K >= (1 << 25)) return big ? MX_SPMM_SLAB : MX_SPMM_ROWSPLIT;           // (the plan's 32-bit slab offsets)
     // one 128-byte slab, a handful of entries per row, a slab-panel of B that fits L2: 8 lanes per row and 8 rows per
     // wavefront (the slab kernel's shape) beat one wavefront per row and a plan that costs more than the product
@@ -155,7 +165,8 @@ static int spmm_auto_algo(int m, int n, int K, int64_t nnz, int dense_dtype, con
     // — unless the row-split kernel's row-group form applies (round 4, later: 0.061 ms there, and bit for bit the reference's sums)
     if (!keep_plan && n * sz <= 128 && nnz <= 16LL * m && (double)K * 128.0 <= 2.5e6 &&
         rowsplit_segments(m, n, sz, (double)nnz / m) != 0) return MX_SPMM_SLAB;
-    const AutoCost c = spmm_auto_cost(m, n, K, nnz, sz, keep_plan);
+    const AutoCost c = spmm_auto_cost(m, n, K, nnz, sz, keep_plan, colmajor, keep_plan);
+    if (tile_can && c.tile_us * 1.1 < std::min(c.planned_us, c.rowsplit_us)) return MX_SPMM_TILE;
     return c.planned_us < c.rowsplit_us ? MX_SPMM_PLANNED : MX_SPMM_ROWSPLIT;
 }
 int spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
@@ -202,6 +213,8 @@ int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, con
 {
     if (family == MX_SPMM_ROWSPLIT)
         return run_rowsplit(m, n, K, nnz, 0, from_auto ? 0 : npanels, 0, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, st);
+    if (family == MX_SPMM_TILE && from_auto)
+        return mxd_spmm_csr_dense_ex2(m, n, K, nnz, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, family, 0, 0, 0, st);
     if (family == MX_SPMM_PLANNED && from_auto) {
         const bool ok = dense_dtype == MX_F64 ? slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor)
                                               : slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor);
@@ -233,6 +246,16 @@ extern "C" int mxd_spmm_auto_cost(int m, int n, int K, int64_t nnz, int keep_pla
     MX_REQUIRE(nnz >= 0 && rowsplit_us && planned_us && panels, "mxd_spmm_auto_cost: nnz and three result pointers are required");
     const mx::AutoCost c = mx::spmm_auto_cost(m, n, K, nnz, dense_dtype == MX_F64 ? 8 : 4, keep_plan != 0);
     *rowsplit_us = c.rowsplit_us; *planned_us = c.planned_us; *panels = c.panels;
+    return 0;
+}
+extern "C" int mxd_spmm_auto_cost2(int m, int n, int K, int64_t nnz, int keep_plan, int dense_dtype, int colmajor_out, int rows_sorted,
+                                   double *rowsplit_us, double *planned_us, double *tile_us, int *panels, int *tile_cpl)
+{
+    MX_REQUIRE(nnz >= 0 && rowsplit_us && planned_us && tile_us && panels && tile_cpl, "mxd_spmm_auto_cost2: nnz and five result pointers are required");
+    const int sz = dense_dtype == MX_F64 ? 8 : 4;
+    const mx::AutoCost c = mx::spmm_auto_cost(m, n, K, nnz, sz, keep_plan != 0, colmajor_out, rows_sorted != 0);
+    *rowsplit_us = c.rowsplit_us; *planned_us = c.planned_us; *tile_us = c.tile_us; *panels = c.panels;
+    mx::tile_est_us(m, n, K, sz, m > 0 ? (double)nnz / m : 0.0, colmajor_out, tile_cpl);
     return 0;
 }
 extern "C" int mxd_spmm_auto_algo(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
@@ -273,6 +296,7 @@ extern "C" int mxd_spmm_csr_dense_ex2(int m, int n, int K, int64_t nnz,
         auto_pick_planned = algo == MX_SPMM_PLANNED;
         if (algo == MX_SPMM_SLAB) { npanels = 1; if (wg_per_cu <= 0) wg_per_cu = 4; }
         if (algo == MX_SPMM_ROWSPLIT) { npanels = 0; wg_per_cu = 0; }   // (column panels / segments per row: AUTO picks both)
+        if (algo == MX_SPMM_TILE) { npanels = 0; wg_per_cu = 0; }       // (geometry and slab width: the tile kernel's own choice)
     }
     if (algo == MX_SPMM_ROWSPLIT)
         return mx::run_rowsplit(m, n, K, nnz, wg_per_cu, npanels, rows_sorted, indptr, indices, values, B, ldb, C, ldc, dense_dtype,
@@ -280,9 +304,9 @@ extern "C" int mxd_spmm_csr_dense_ex2(int m, int n, int K, int64_t nnz,
     if (algo == MX_SPMM_TILE) {
         mx::set_last_spmm_kernel("spmm_tile_kernel");
         if (dense_dtype == MX_F64)
-            return mx::tile_spmm<double>(m, n, K, wg_per_cu, npanels, rows_sorted, indptr, indices, values, (const double *)B, ldb,
+            return mx::tile_spmm<double>(m, n, K, nnz, wg_per_cu, npanels, rows_sorted, indptr, indices, values, (const double *)B, ldb,
                                          (double *)C, ldc, colmajor_out, st);
-        return mx::tile_spmm<float>(m, n, K, wg_per_cu, npanels, rows_sorted, indptr, indices, values, (const float *)B, ldb,
+        return mx::tile_spmm<float>(m, n, K, nnz, wg_per_cu, npanels, rows_sorted, indptr, indices, values, (const float *)B, ldb,
                                     (float *)C, ldc, colmajor_out, st);
     }
     if (algo == MX_SPMM_PLANNED) {

@@ -112,8 +112,9 @@ int rowsplit_panels(int m, int n, int K, int dense_bytes, double avg_len);
 // ---- spmm_tile.hip: row blocks x 256 / 512-byte column slabs, K-tiles of B staged in LDS by LDS-DMA (dense-ish operands)
 template <typename real_t>
 bool tile_ok(int n, const real_t *B, size_t ldb);
+double tile_est_us(int m, int n, int K, int dense_bytes, double avg_len, int colmajor, int *cpl);
 template <typename real_t>
-int tile_spmm(int m, int n, int K, int variant, int nw, int rows_sorted, const int32_t *indptr, const int32_t *indices,
+int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_sorted, const int32_t *indptr, const int32_t *indices,
               const double *values, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream);
 
 // ---- spmm_slab.hip

@@ -30,6 +30,8 @@
 // Roofline: HBM-bound by the contract's algorithmic bytes; what limits it in practice is LDS reads
 // (nnz * n * s bytes, `lds_read` in bench.py) beside the tile fills (`l2_to_lds_fill`).
 #include "spmm_common.h"
+#include <algorithm>
+#include <cmath>
 
 namespace mx {
 
@@ -127,7 +129,7 @@ __global__ __launch_bounds__((TL_MAX_WAVES + 1) * MX_WAVE)
 void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
                       const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ values,
                       const unsigned char *__restrict__ unsorted,
-                      const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ C, size_t ldc, int c_vec, int nl, int dbg)
+                      const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ C, size_t ldc, int c_vec, int nl)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
     constexpr int W = TL_G * VEC * CPL;              // columns of the slab
@@ -186,10 +188,10 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
                 }
             }
         };
-        if (!(dbg & 1)) fill(0);
+        fill(0);
         for (int t = 0; t < T; t++) {
             __syncthreads();                         // (waits for the DMA of tile t first: vmcnt(0))
-            if (t + 1 < T && !(dbg & 1)) fill(t + 1);
+            if (t + 1 < T) fill(t + 1);
         }
         if constexpr (!COLMAJOR) return;
     }
@@ -314,7 +316,7 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
                 posl[i] += cnt;
                 rem[i] -= cnt;
                 load_window(i);
-                if (maxc > 0 && !(dbg & 2)) {        // (wave-uniform)
+                if (maxc > 0) {                      // (wave-uniform)
                     tl_window<real_t, CPL>(smem, maxc, off[0], aa[0], lane16, acc[i]);
                     if constexpr (WIN > 1) {
                         if (maxc > TL_G) tl_window<real_t, CPL>(smem, maxc - TL_G, off[1], aa[1], lane16, acc[i]);
@@ -399,7 +401,7 @@ static TileGeom tile_geometry(int m, int n, int dense_bytes, int cpl, int rg, in
 {
     const int vec = 16 / dense_bytes, w1 = TL_G * vec;
     TileGeom gm;
-    if (cpl != 1 && cpl != 2) cpl = n > 3 * w1 && (long long)m * ((n + 2 * w1 - 1) / (2 * w1)) >= 256LL * 120 ? 2 : 1;
+    if (cpl != 2) cpl = 1;
     gm.cpl = cpl;
     gm.nslabs = (n + w1 * cpl - 1) / (w1 * cpl);
     if (rg < 1 || rg > (cpl == 1 ? 5 : 4) || nw < 1 || nw > TL_MAX_WAVES) {
@@ -432,6 +434,39 @@ static TileGeom tile_geometry(int m, int n, int dense_bytes, int cpl, int rg, in
     return gm;
 }
 
+// What the kernel costs, microseconds (the model AUTO compares with the row-split kernel's and the planned sweep's,
+// csrc/spmm.hip; fitted to tools/tile_map.py's map, profiles/r05_tile_map.json: within 25 % of the measured time at 120 of 154
+// points and every point above 0.1 ms).  A workgroup walks T K-tiles; per tile its busiest SIMD makes `serial` visits of
+// (a row of every lane group, the tile), one after the other: ~180 cycles of window bookkeeping per 32 entries and 4.5
+// cycles per issue slot of a step (address add, CPL reads, 2 CPL FMAs), steps = the largest of four Poisson(mu) counts
+// rounded up to a batch, mu = entries per row and tile; never below what the fill and the window loads take (~0.9 us + 0.14
+// us per visit in a row).  Workgroups beyond one per CU come in rounds (x 1.3: their windows stream A from HBM, not from
+// the Infinity Cache).
+static double tile_est_us_cpl(int m, int n, int K, int dense_bytes, double avg_len, int cpl, int colmajor)
+{
+    const TileGeom gm = tile_geometry(m, n, dense_bytes, cpl, 0, 0, colmajor, 65536);
+    const double wgs = (double)gm.nrb * gm.nslabs;
+    const double rounds = wgs <= 256.0 ? 1.0 : (wgs <= 768.0 ? std::ceil(wgs / 256.0) : wgs / 256.0);
+    const int TK = 65536 / (256 * cpl);
+    const double T = (double)ceil_div(K, TK);
+    const double mu = avg_len * (double)(TK < K ? TK : K) / (double)(K > 0 ? K : 1);
+    const double steps = mu + 1.03 * std::sqrt(mu) + (4 / cpl) / 2.0;
+    const double passes = std::max(1.0, std::ceil((mu + 2.0 * std::sqrt(mu)) / 32.0));
+    const double visit = 180.0 * passes + 4.5 * (1 + 3 * cpl) * steps;
+    const double serial = (double)ceil_div(gm.nw + gm.nl, 4) * gm.rg;
+    const double tile_us = std::max(0.9 + 0.14 * serial, serial * visit / 2400.0);
+    return 6.0 + rounds * (T * tile_us + 4.0) * (wgs > 256.0 ? 1.3 : 1.0);
+}
+// the cheaper of 256- and 512-byte slabs (512: half the workgroups — it wins where 256-byte slabs need a second round — but
+// half the rows of B per tile and seven issue slots per step instead of four)
+double tile_est_us(int m, int n, int K, int dense_bytes, double avg_len, int colmajor, int *cpl)
+{
+    const double c1 = tile_est_us_cpl(m, n, K, dense_bytes, avg_len, 1, colmajor);
+    const double c2 = n > TL_G * (16 / dense_bytes) ? tile_est_us_cpl(m, n, K, dense_bytes, avg_len, 2, colmajor) : 2.0 * c1;
+    if (cpl) *cpl = c2 < 0.9 * c1 ? 2 : 1;
+    return c2 < 0.9 * c1 ? c2 : c1;
+}
+
 template <typename real_t, int CPL, int RG, int WIN, int TILE>
 static void launch_tile(const TileGeom &gm, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
                         const unsigned char *unsorted, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
@@ -442,10 +477,10 @@ static void launch_tile(const TileGeom &gm, int m, int n, int K, const int32_t *
     const dim3 block((unsigned)(gm.nw + gm.nl) * MX_WAVE);
     if (colmajor)
         hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, true>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
-                           gm.nrb, indptr, indices, values, unsorted, B, ldb, C, ldc, c_vec, gm.nl, getenv("MXGPU_TILE_DEBUG") ? atoi(getenv("MXGPU_TILE_DEBUG")) : 0);
+                           gm.nrb, indptr, indices, values, unsorted, B, ldb, C, ldc, c_vec, gm.nl);
     else
         hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, false>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
-                           gm.nrb, indptr, indices, values, unsorted, B, ldb, C, ldc, c_vec, gm.nl, getenv("MXGPU_TILE_DEBUG") ? atoi(getenv("MXGPU_TILE_DEBUG")) : 0);
+                           gm.nrb, indptr, indices, values, unsorted, B, ldb, C, ldc, c_vec, gm.nl);
 }
 
 template <typename real_t, int CPL, int WIN, int TILE>
@@ -481,12 +516,15 @@ template bool tile_ok<float>(int, const float *, size_t);
 // variant: 0 = chosen here; otherwise cpl + 4 * rg + 32 * (32 KB tiles, 16-entry windows)
 // (tools/tile_sweep.py); nw: compute wavefronts per workgroup (0 = chosen here).  rows_sorted != 0: the caller vouches for column-sorted rows (no flag pass).
 template <typename real_t>
-int tile_spmm(int m, int n, int K, int variant, int nw, int rows_sorted, const int32_t *indptr, const int32_t *indices,
+int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_sorted, const int32_t *indptr, const int32_t *indices,
               const double *values, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
     if (!tile_ok<real_t>(n, B, ldb)) return set_error("tile_spmm: rows of B must be 16-byte aligned whole vectors (n = %d, ldb = %zu)", n, ldb);
-    const int cpl = variant & 3, rg = (variant >> 2) & 7, small_tile = (variant >> 5) & 1, one_loader = (variant >> 6) & 1;
+    int cpl = variant & 3;
+    // 256- or 512-byte slabs: the model's choice when the caller knows how many entries there are
+    if (cpl != 1 && cpl != 2) { cpl = 1; if (nnz >= 0 && m > 0) tile_est_us(m, n, K, (int)sizeof(real_t), (double)nnz / m, colmajor, &cpl); }
+    const int rg = (variant >> 2) & 7, small_tile = (variant >> 5) & 1, one_loader = (variant >> 6) & 1;
     TileGeom gm = tile_geometry(m, n, (int)sizeof(real_t), cpl, rg, nw, colmajor, small_tile ? 32768 : 65536);
     if (one_loader) gm.nl = 1;
     const int c_vec = colmajor || ((ldc % VEC == 0) && ((uintptr_t)C % 16 == 0));
@@ -514,9 +552,9 @@ int tile_spmm(int m, int n, int K, int variant, int nw, int rows_sorted, const i
     MX_LAUNCH_CHECK();
     return 0;
 }
-template int tile_spmm<double>(int, int, int, int, int, int, const int32_t *, const int32_t *, const double *, const double *, size_t,
+template int tile_spmm<double>(int, int, int, int64_t, int, int, int, const int32_t *, const int32_t *, const double *, const double *, size_t,
                                double *, size_t, int, hipStream_t);
-template int tile_spmm<float>(int, int, int, int, int, int, const int32_t *, const int32_t *, const double *, const float *, size_t,
+template int tile_spmm<float>(int, int, int, int64_t, int, int, int, const int32_t *, const int32_t *, const double *, const float *, size_t,
                               float *, size_t, int, hipStream_t);
 
 }  // namespace mx

@@ -284,16 +284,17 @@ def test_kernels_at_the_int32_limit(gpu):
 def test_published_workload_full_size(gpu):
     """The one workload the reference publishes a number for, at its size (vignettes/Introducing_MatrixExtra.Rmd:247-251):
     dense 100 x 1e4 %*% CSC 1e4 x 1e4, density .05, through the export (matmul_dense_csc_numeric, src/matmul.cpp:188-235) —
-    AUTO = the row-split kernel with column panels — against the WHOLE oracle product (60 ms on the host), 1e-12; and the
-    same kernel at device level for every panel count, bit for bit the storage-order FMA chain (row-major C, one segment)."""
+    AUTO = the LDS-tile kernel (round 5; the row-split kernel with column panels before) — against the WHOLE oracle product
+    (60 ms on the host), BIT FOR BIT its storage-order FMA chain; and the row-split kernel at device level for every panel
+    count, bit for bit the same chain (row-major C, one segment)."""
     from matrixextra_amd import device as D, exports as G
     m, K, n = 10_000, 10_000, 100
     p, j, x = synth.csr_fixed(m, K, 500, seed=7)
     X = np.asfortranarray(synth.dense_normal(n, K, seed=8))            # Y_dense, column-major 100 x 1e4
     got = G.matmul_dense_csc_numeric(X, p, j, x, 1)
-    assert _lib.load().mxd_spmm_last_kernel() == b"spmm_rowsplit_kernel"
+    assert _lib.load().mxd_spmm_last_kernel() == b"spmm_tile_kernel"
     ref = O.matmul_dense_csc(X, p, j, x, O.max_threads(), True)        # FMA chain in storage order
-    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * float(np.abs(ref).max()))
+    np.testing.assert_array_equal(got, ref)
     A = D.DeviceCSR.from_host(p, j, x, K)
     B = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()             # K x n row-major
     for P in (1, 3, 4, 7):

@@ -148,16 +148,16 @@ def test_rowsplit_auto_shape_and_unknown_nnz(gpu):
     assert _lib.load().mxd_spmm_last_kernel() == b"spmm_rowsplit_kernel"
 
 
-def test_auto_takes_the_rowsplit_kernel_for_the_published_workload(gpu):
-    """AUTO's family: ROWSPLIT for dense 100 x 1e4 %*% CSC 1e4 x 1e4 (vignette Rmd:247-251), ROWWAVE for the reference's
+def test_auto_families_around_the_published_workload(gpu):
+    """AUTO's family: TILE (round 5; ROWSPLIT before) for dense 100 x 1e4 %*% CSC 1e4 x 1e4 (vignette Rmd:247-251), ROWWAVE for the reference's
     tiny test shapes (which keep their bitwise storage-order sums) and for callers that do not know nnz, PLANNED at the
     headline size; and the export (matmul_dense_csc_numeric, src/matmul.cpp:221-235) at a fifth of the vignette's size
-    really runs it"""
+    really runs the row-split kernel (2,000 rows do not fill the tile kernel's workgroups)"""
     import ctypes as C
     lib = _lib.load()
     pick = C.c_int(0)
     al = C.c_void_p(256)
-    for (m, n, K, nnz, colmajor, want) in ((10_000, 100, 10_000, 5_000_000, 0, 4), (100, 20, 50, 2000, 1, 1), (1_000_000, 128, 100_000, 32_000_000, 1, 3),
+    for (m, n, K, nnz, colmajor, want) in ((10_000, 100, 10_000, 5_000_000, 0, 5), (100, 20, 50, 2000, 1, 1), (1_000_000, 128, 100_000, 32_000_000, 1, 3),
                                            (10_000, 100, 10_000, -1, 0, 1)):
         _lib.check(lib.mxd_spmm_auto_algo2(C.c_int(m), C.c_int(n), C.c_int(K), C.c_int64(nnz), C.c_int(0), C.c_int(_lib.MX_F64), al, C.c_size_t(n), al,
                                            C.c_size_t(m if colmajor else n), C.c_int(colmajor), C.byref(pick)))

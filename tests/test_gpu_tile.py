@@ -153,3 +153,28 @@ def test_tile_at_the_published_shape_fifth(gpu):
     _same(got, ref)
     np.testing.assert_array_equal(got, _run(p, j, x, B, False, 0, 0, False))
     assert _lib.load().mxd_spmm_last_kernel() == b"spmm_tile_kernel"
+
+
+def test_auto_takes_the_tile_kernel_for_dense_ish_operands(gpu):
+    """AUTO's cost model (csrc/spmm.hip spmm_auto_cost + csrc/spmm_tile.hip tile_est_us): TILE for the published product and
+    for the reference's test densities once there are enough rows, never for the headline's sparse operands; and
+    DeviceCSR.spmm really runs it (sortedness cached on the matrix: no flag pass), bit for bit the chain"""
+    import ctypes as C
+    import torch
+    from matrixextra_amd import device as D
+    lib = _lib.load()
+    pick = C.c_int(0)
+    al = C.c_void_p(256)
+    for (m, n, K, nnz, colmajor, keep, want) in ((10_000, 100, 10_000, 5_000_000, 0, 0, 5), (10_000, 256, 10_000, 20_000_000, 1, 1, 5),
+                                                 (100_000, 100, 1000, 40_000_000, 0, 1, 5), (1_000_000, 128, 100_000, 32_000_000, 1, 1, 3),
+                                                 (100_000, 128, 10_000, 12_800_000, 1, 1, 4), (10_000, 101, 10_000, 5_000_000, 0, 0, 4)):
+        _lib.check(lib.mxd_spmm_auto_algo2(C.c_int(m), C.c_int(n), C.c_int(K), C.c_int64(nnz), C.c_int(keep), C.c_int(_lib.MX_F64), al,
+                                           C.c_size_t(n), al, C.c_size_t(m if colmajor else n), C.c_int(colmajor), C.byref(pick)))
+        assert pick.value == want, (m, n, K, nnz, pick.value)
+    p, j, x = synth.csr_fixed(6000, 4000, 400, seed=3)                 # density .1
+    B = synth.dense_normal(4000, 96, seed=4)
+    A = D.DeviceCSR.from_host(p, j, x, 4000)
+    for colmajor in (False, True):
+        got = D.spmm(A, torch.from_numpy(B).cuda(), colmajor=colmajor).cpu().numpy()
+        assert lib.mxd_spmm_last_kernel() == b"spmm_tile_kernel"
+        _same(np.ascontiguousarray(got), _oracle(p, j, x, B))

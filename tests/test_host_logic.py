@@ -97,3 +97,35 @@ def test_partition_rows_balances_cost_and_covers_all_rows():
     cuts = (C.c_int * 5)()
     _lib.check(lib.mx_partition_rows(p0.ctypes.data_as(C.c_void_p), C.c_int(100), C.c_int(4), C.c_int(16), C.c_int(4), cuts))
     assert list(cuts) == [0, 25, 50, 75, 100]
+
+
+def test_profile_guard_hashes_the_file_a_kernel_is_built_from():
+    """tools/prof_common.sources_of: every kernel name that appears in the committed rocprofv3 summaries maps to the
+    source file that defines it (bench.py quotes a summary's counters only while those files are unchanged) — in
+    particular the planned SpMV kernel, whose name contains the generic `plan_` of the SpMM plan's build kernels."""
+    import csv
+    import glob
+    import os
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import prof_common as PC
+    assert PC.sources_of("mx::spmv_plan_kernel<64>(int, ...)")[0] == "spmv_plan.hip"
+    assert PC.sources_of("mx::spmm_plan_kernel<double,true,16,false>")[0] == "spmm_plan.hip"
+    assert PC.sources_of("void mx::plan_count_kernel(...)")[0] == "spmm_plan.hip"
+    assert PC.sources_of("mx::spmm_tile_kernel<double, 1, 3, 2, 65536, false>")[0] == "spmm_tile.hip"
+    csrc = os.path.join(root, "matrixextra_amd", "csrc")
+    seen = 0
+    for f in glob.glob(os.path.join(root, "profiles", "r0[45]_*kernel_stats.csv")):
+        for row in csv.DictReader(open(f)):
+            name = row.get("Name") or row.get("KernelName") or ""
+            m = re.search(r"mx::(\w+)", name)
+            if not m:
+                continue
+            files = PC.sources_of(name)
+            assert files is not None, name
+            text = open(os.path.join(csrc, files[0])).read()
+            assert re.search(r"\b%s\b" % re.escape(m.group(1)), text), (name, files[0])
+            seen += 1
+    assert seen > 10

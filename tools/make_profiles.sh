@@ -26,7 +26,7 @@ cp "$(ls -t $W/extras/trace/*/*_kernel_stats.csv | head -1)" $O/${RND}_extras_ke
 export MXGPU_BENCH_EXTRAS_ONLY=vignette_dense_csc
 bash tools/profile.sh $W/vignette 1 -- --steps 5 --warmup 2 --no-cpu-baseline > $O/log_vignette.txt 2>&1
 unset MXGPU_BENCH_EXTRAS_ONLY
-python3 tools/prof_summary_multi.py $W/vignette $O/${RND}_vignette_extras vignette-dense-csc "spmm_rowsplit_kernel<double, 2, 64, false" \
+python3 tools/prof_summary_multi.py $W/vignette $O/${RND}_vignette_extras vignette-dense-csc spmm_tile_kernel "spmm_rowsplit_kernel<double, 2, 64, false" \
     rowsplit_cursors_kernel "spmm_rowwave_kernel<double, 2, false" spmm_slab_kernel spmm_plan_kernel > /dev/null
 cp "$(ls -t $W/vignette/trace/*/*_kernel_stats.csv | head -1)" $O/${RND}_vignette_kernel_stats.csv
 # (c) configs[4]'s per-GPU shard on this GPU

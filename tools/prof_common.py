@@ -22,8 +22,9 @@ KERNEL_SOURCES = [
     ("spmm_plan_kernel", ["spmm_plan.hip"]), ("plan_", ["spmm_plan.hip"]), ("repack", ["spmm_slab.hip"]),
     ("spmm_rowwave_kernel", ["spmm_rowwave.hip"]), ("spmm_rowsplit_kernel", ["spmm_rowsplit.hip"]),
     ("rowsplit_cursors_kernel", ["spmm_rowsplit.hip"]), ("spmm_rowgroup_kernel", ["spmm_rowsplit.hip"]), ("spmm_slab_kernel", ["spmm_slab.hip"]),
+    ("spmm_tile_kernel", ["spmm_tile.hip"]), ("tile_unsorted_rows_kernel", ["spmm_tile.hip"]),
     ("spmv_flat_kernel", ["spmv_flat.hip", "spmv_rows.h"]), ("slice_rows_kernel", ["spmv_flat.hip"]),
-    ("spmv_plan_kernel", ["spmv_plan.hip"]), ("spmv_tile", ["spmv_tile.hip", "spmv_rows.h"]), ("spmv_kernel", ["spmv.hip", "spmv_rows.h"]),
+    ("spmv_plan", ["spmv_plan.hip"]), ("spmv_tile", ["spmv_tile.hip", "spmv_rows.h"]), ("spmv_kernel", ["spmv.hip", "spmv_rows.h"]),
     ("gather_", ["gather.hip"]), ("rows_sorted", ["gather.hip"]), ("sort_rows", ["gather.hip"]), ("is_seq", ["gather.hip"]),
     ("merge_", ["merge.hip"]), ("values_elemwise", ["merge.hip"]), ("scan", ["scan.hip"]),
     ("stream_copy_kernel", ["stream.hip"]), ("csr_by_dvec", ["dvec.hip", "r_arith.h"]), ("dvec_na", ["dvec_na.hip", "r_arith.h"]),
@@ -45,10 +46,13 @@ def source_blobs():
 
 
 def sources_of(kernel_name):
-    for sub, files in KERNEL_SOURCES:
-        if sub in kernel_name:
-            return files + [f for f in COMMON if not (f == "spmm_common.h" and "spmm" not in kernel_name)]
-    return None            # unknown kernel: every file has to match
+    """the LONGEST table entry found in the name decides (`spmv_plan_kernel` contains the generic `plan_` of the SpMM plan's
+    build kernels: first-hit matching hashed spmm_plan.hip for it — round 4's advisor finding)"""
+    hits = [(len(sub), files) for sub, files in KERNEL_SOURCES if sub in kernel_name]
+    if not hits:
+        return None        # unknown kernel: every file has to match
+    files = max(hits, key=lambda h: h[0])[1]
+    return files + [f for f in COMMON if not (f == "spmm_common.h" and "spmm" not in kernel_name)]
 
 
 def kernel_unchanged(kernel_name, recorded):

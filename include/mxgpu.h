@@ -24,9 +24,25 @@
  *
  *  (2) mxd_*  "device level": the same operations on DEVICE pointers, enqueued
  *             on a caller-supplied hipStream_t (passed as void*), no
- *             allocation, no synchronisation (graph-capture safe) except where
- *             a size must come back to the host.  This is what bench.py, the
- *             multi-GPU path and layer (1) drive.
+ *             allocation, no synchronisation except where a size must come
+ *             back to the host.  This is what bench.py, the multi-GPU path
+ *             and layer (1) drive.
+ *
+ *             Graph capture (tests/test_gpu_graph_capture.py captures one
+ *             graph and replays it on fresh inputs): CAPTURABLE after one
+ *             uncaptured call on the same stream (the library's grow-only
+ *             per-thread scratch then exists): mxd_spmm_plan_run /
+ *             _run_rows, mxd_spmm_csr_dense, mxd_spmm_csr_dense_ex2 with
+ *             MX_SPMM_ROWWAVE / _SLAB and — with nnz passed — _ROWSPLIT /
+ *             _TILE, mxd_spmv_csr_dvec(_ex), mxd_spmv_plan_run, every *_fill,
+ *             mxd_values_elemwise, mxd_csr_by_*, mxd_spmv_csr_svec,
+ *             mxd_csr_cbind / _rbind_append, mxd_stream_copy,
+ *             mxd_exclusive_scan_i32.  NOT capturable (they wait for a value
+ *             on the host): every *_count, the *_fused forms, *_plan_create*,
+ *             mxd_csr_rows_sorted, mxd_csr_sort_rows, mxd_check_is_seq,
+ *             mxd_csr_check_valid, MX_SPMM_AUTO / _PLANNED through
+ *             mxd_spmm_csr_dense_ex* (the plan is sized on the host) and
+ *             MX_SPMM_ROWSPLIT / _TILE with nnz = -1 (indptr[m] is read back).
  *
  * Every function returns 0 on success, non-zero on failure; the message for the
  * calling thread is read with mx_last_error() (the .Call shim turns it into

@@ -132,8 +132,19 @@ int  mx_cache_stats(int64_t *bytes, int *entries, int64_t *hits, int64_t *misses
  *                  down, one synchronisation; no pool, no cache (MXGPU_SMALL_CALLS=0 switches it off)
  *   "pool_live_bytes" / "pool_live_blocks"  read-only: blocks handed out and not yet returned (operands in the CSR cache,
  *                  kept plans, thread scratch, results between begin and finish / discard) — a leaked mx_result shows here
+ *   "offload_min_len" [MXGPU_OFFLOAD_MIN_LEN, default -1]  the operand length from which mx_should_offload says yes: -1 = the
+ *                  measured per-routine defaults, 0 = always, n = that length for every routine
  * mx_last_call_phases: wall-clock phases of the calling thread's last SpMM export as "what;key=value;phase=ms;..."
  * (bench.py reports them for the cold / cached export calls). */
+/* The offload gate, for BOTH integration options: should a call of the reference routine `routine`
+ * ("tcrossprod_csr_dense_numeric", with or without the "_MatrixExtra_" prefix) whose longest argument vector has
+ * `longest_len` elements (the entry count, or the dense operand) go to the GPU?  1 = yes, 0 = keep it on the host: one
+ * export call costs 29-50 us whatever it does, 2.8-3.7x MatrixExtra's own routine at the reference's test sizes
+ * (tests/testthat/test-matmul.R:108-114; profiles/r04_small_calls.json).  Defaults: products and CSR (+) CSR from 5e4, `X %*% v`
+ * from 1e6, `X[rows, ]` / cbind / rbind (memcpys on the host) from 1e7.  Host arithmetic only; never touches the device.
+ * The .Call shim (csrc/r_shim.cpp) asks it before every routine and, for a "no", calls MatrixExtra's own routine of the same
+ * name when that DLL is loaded (R_FindSymbol); Option A keeps the original body as the host branch. */
+int  mx_should_offload(const char *routine, int64_t longest_len);
 int  mx_set_option(const char *name, int64_t value);
 int  mx_get_option(const char *name, int64_t *value);
 int  mx_last_call_phases(char *buf, size_t buflen);

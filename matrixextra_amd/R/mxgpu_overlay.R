@@ -51,7 +51,8 @@
 )
 
 ## From which operand size on a call goes to the GPU (the length of the longest vector passed: the entry count, or the
-## dense operand).  Measured on an MI355X box against MatrixExtra's algorithm on the host's cores (tools/small_calls.py,
+## dense operand).  The same numbers as the C-ABI's mx_should_offload (include/mxgpu.h; the shim applies them once more
+## to direct .Call users and falls back to MatrixExtra's own native routine).  Measured on an MI355X box against MatrixExtra's algorithm on the host's cores (tools/small_calls.py,
 ## profiles/r04_small_calls.json: host arrays in, host arrays out): one call costs 29-50 us at the reference's own test
 ## sizes (100 x 50) whatever it does, so products and CSR (+) CSR win from ~5e4 entries on, `X %*% v` (8 bytes of result per
 ## row against 12 bytes per entry over PCIe) from ~1e6, and `X[rows, ]` — a memcpy on the host — only from ~1e7.

@@ -1458,9 +1458,46 @@ int mx_device_name(char *buf, size_t buflen)
     snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     return 0;
 }
+// ---- offload gate: from which operand size on a routine is worth a PCIe round trip (include/mxgpu.h mx_should_offload)
+static std::atomic<int64_t> g_opt_offload_min_len{-2};               // -2 = not set: MXGPU_OFFLOAD_MIN_LEN, else the measured defaults (-1)
+static int64_t opt_offload_min_len()
+{
+    int64_t v = g_opt_offload_min_len.load();
+    if (v == -2) {
+        const char *e = getenv("MXGPU_OFFLOAD_MIN_LEN");
+        v = e && *e ? (int64_t)atoll(e) : -1;
+        if (v < -1) v = -1;
+    }
+    return v;
+}
+static int64_t offload_default_min_len(const char *fn)
+{
+    // measured on an MI355X box against MatrixExtra's algorithm on the host's cores (tools/small_calls.py,
+    // profiles/r04_small_calls.json: host arrays in, host arrays out): one call costs 29-50 us at the reference's own test
+    // sizes (tests/testthat/test-matmul.R:108-114: 100 x 50) whatever it does — 2.8-3.7x the host's 8-17 us — so products
+    // and CSR (+) CSR win from ~5e4 entries on, `X %*% v` (8 bytes of result per row against 12 bytes per entry over PCIe)
+    // from ~1e6, and `X[rows, ]` / cbind / rbind — memcpys on the host — only from ~1e7
+    auto starts = [&](const char *pre) { return strncmp(fn, pre, strlen(pre)) == 0; };
+    if (starts("matmul_csr_dvec_") || starts("matmul_csr_svec_") || starts("matmul_rowvec_by_")) return 1000000;
+    if (starts("copy_csr_") || starts("reverse_") || starts("cbind_") || strcmp(fn, "concat_csr_batch") == 0) return 10000000;
+    return 50000;
+}
+int mx_should_offload(const char *routine, int64_t longest_len)
+{
+    if (!routine) return 1;
+    if (strncmp(routine, "_MatrixExtra_", 13) == 0) routine += 13;
+    const int64_t set = opt_offload_min_len();
+    const int64_t min_len = set >= 0 ? set : offload_default_min_len(routine);
+    return longest_len >= min_len ? 1 : 0;
+}
 int mx_set_option(const char *name, int64_t value)
 {
     MX_REQUIRE(name, "mx_set_option: null name");
+    if (strcmp(name, "offload_min_len") == 0) {
+        MX_REQUIRE(value >= -1, "mx_set_option: offload_min_len %lld (-1 = the measured defaults, 0 = always offload)", (long long)value);
+        g_opt_offload_min_len = value;
+        return 0;
+    }
     if (strcmp(name, "spmv_planned") == 0) { g_opt_spmv_planned = value; return 0; }
     if (strcmp(name, "spmv_algo") == 0) {
         MX_REQUIRE(value >= -1 && value <= MX_SPMV_FLAT, "mx_set_option: spmv_algo %lld", (long long)value);
@@ -1473,6 +1510,7 @@ int mx_get_option(const char *name, int64_t *value)
 {
     MX_REQUIRE(name && value, "mx_get_option: null pointer");
     if (strcmp(name, "spmv_planned") == 0) { *value = opt_spmv_planned() ? 1 : 0; return 0; }
+    if (strcmp(name, "offload_min_len") == 0) { *value = opt_offload_min_len(); return 0; }
     if (strcmp(name, "spmv_algo") == 0) { *value = opt_spmv_algo(); return 0; }
     if (strcmp(name, "spmv_planned_calls") == 0) { *value = g_spmv_planned_calls.load(); return 0; }   // read-only counter
     if (strcmp(name, "small_calls") == 0) { *value = g_small_calls.load(); return 0; }                  // read-only: calls served by the small path

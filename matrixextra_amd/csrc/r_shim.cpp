@@ -27,6 +27,7 @@
 #include <R.h>
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
+#include <cstring>
 #include "mxgpu.h"
 
 namespace {
@@ -618,7 +619,40 @@ SEXP _MatrixExtra_check_valid_csr_matrix(SEXP p_, SEXP j_, SEXP nrows, SEXP ncol
     return out;
 }
 
-#define MX_ENTRY(name, n) {"_MatrixExtra_" #name, (DL_FUNC)&_MatrixExtra_##name, n}
+// ---- the offload gate (include/mxgpu.h mx_should_offload; INTEGRATION.md "Offload threshold") --------------------------------
+// Every registered routine is reached through Gate<&routine>::call: when the longest argument vector is below the routine's
+// measured threshold AND MatrixExtra's own DLL is loaded, the call goes to MatrixExtra's routine of the same name — its own
+// CPU code, found with R_FindSymbol in the package "MatrixExtra" — and never to the GPU: at the reference's test sizes
+// (tests/testthat/test-matmul.R:108-114) an export call costs 29-50 us, the host routine 8-17.  Without MatrixExtra's DLL
+// (the shim loaded on its own) every call is served by the GPU, as before.
+extern "C++" {
+static const R_CallMethodDef *gate_table();
+static DL_FUNC host_routine(const char *full_name)
+{
+    return R_FindSymbol(full_name, "MatrixExtra", NULL);
+}
+template <auto Fn> struct Gate;
+template <typename... A, SEXP (*Fn)(A...)> struct Gate<Fn> {
+    static SEXP call(A... a)
+    {
+        static const char *name = nullptr;             // this trampoline's entry in the registration table
+        if (!name)
+            for (const R_CallMethodDef *e = gate_table(); e->name; e++)
+                if (e->fun == (DL_FUNC)&Gate::call) { name = e->name; break; }
+        if (name) {
+            R_xlen_t longest = 0;
+            const R_xlen_t lens[] = {Rf_xlength(a)...};
+            for (R_xlen_t l : lens) if (l > longest) longest = l;
+            if (!mx_should_offload(name, (int64_t)longest)) {
+                // (looked up per call — a table walk, on the path that saves 20-40 us — so that unloading MatrixExtra is safe)
+                if (DL_FUNC host = host_routine(name)) return ((SEXP (*)(A...))host)(a...);
+            }
+        }
+        return Fn(a...);
+    }
+};
+}  // extern "C++"
+#define MX_ENTRY(name, n) {"_MatrixExtra_" #name, (DL_FUNC)&Gate<&_MatrixExtra_##name>::call, n}
 // ---- control routines of the shim itself (not in MatrixExtra's table; the overlay calls them from mxgpu_enable) -------------
 // .Call("_mxgpu_set_option", "spmv_planned", 1L)  ->  mx_set_option   (include/mxgpu.h: run-time options)
 SEXP _mxgpu_set_option(SEXP name, SEXP value)
@@ -672,6 +706,8 @@ static const R_CallMethodDef mxgpu_call_entries[] = {
     MX_ENTRY(matmul_rowvec_by_csc, 4), MX_ENTRY(matmul_rowvec_by_cscbin, 3),
     {NULL, NULL, 0}
 };
+
+extern "C++" { static const R_CallMethodDef *gate_table() { return mxgpu_call_entries; } }
 
 // standalone use: dyn.load("mxgpu_r.so") registers the routines above under their reference names
 void R_init_mxgpu_r(DllInfo *dll)

@@ -12,6 +12,8 @@ struct R_CMethodDef_;
 int R_registerRoutines(DllInfo *info, const void *cMethods, const R_CallMethodDef *callMethods, const void *fortranMethods,
                        const void *externalMethods);
 Rboolean R_useDynamicSymbols(DllInfo *info, Rboolean value);
+struct Rf_RegisteredNativeSymbol;
+DL_FUNC R_FindSymbol(char const *name, char const *pkg, struct Rf_RegisteredNativeSymbol *symbol);
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@ typedef enum { FALSE = 0, TRUE } Rboolean;
 extern SEXP R_NilValue, R_NamesSymbol;
 int TYPEOF(SEXP x);
 R_xlen_t XLENGTH(SEXP x);
+R_xlen_t Rf_xlength(SEXP x);
 int *INTEGER(SEXP x);
 int *LOGICAL(SEXP x);
 double *REAL(SEXP x);

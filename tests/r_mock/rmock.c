@@ -163,6 +163,14 @@ static SEXP new_object(int type, R_xlen_t n, size_t elt)
 /* ------------------------------------------------------------------------------------------- the R API subset */
 int TYPEOF(SEXP x) { return alive(x, "TYPEOF") ? x->type : NILSXP; }
 R_xlen_t XLENGTH(SEXP x) { return alive(x, "XLENGTH") ? x->length : 0; }
+R_xlen_t Rf_xlength(SEXP x)                      /* any SEXP: vectors their length, NULL 0, everything else 1 */
+{
+    if (!x || x == R_NilValue || !alive(x, "Rf_xlength")) return 0;
+    switch (x->type) {
+    case LGLSXP: case INTSXP: case REALSXP: case STRSXP: case VECSXP: return x->length;
+    default: return 1;
+    }
+}
 
 static void *payload(SEXP x, int t1, int t2, const char *who)
 {
@@ -459,6 +467,32 @@ Rboolean R_useDynamicSymbols(DllInfo *info, Rboolean value)
     info->dynamic_symbols = value;
     return old;
 }
+
+/* R_FindSymbol(name, "MatrixExtra", NULL): MatrixExtra's own DLL beside the shim.  Off by default (the shim loaded on its own:
+ * every call is served by the backend); rmock_set_host_routines(1) makes every "_MatrixExtra_*" name resolve to one stub that
+ * counts its calls and returns the string "host" — the shim must hand small operands to it and large ones to the backend. */
+static int host_routines_on = 0;
+static long host_calls = 0;
+static char host_last[128];
+static SEXP host_stub(void)
+{
+    host_calls++;
+    SEXP s = Rf_allocVector(STRSXP, 1);
+    PROTECT(s);
+    ((SEXP *)s->data)[0] = Rf_mkChar("host");
+    UNPROTECT(1);
+    return s;
+}
+DL_FUNC R_FindSymbol(char const *name, char const *pkg, struct Rf_RegisteredNativeSymbol *symbol)
+{
+    (void)symbol;
+    if (!host_routines_on || !pkg || strcmp(pkg, "MatrixExtra") != 0 || strncmp(name, "_MatrixExtra_", 13) != 0) return NULL;
+    snprintf(host_last, sizeof host_last, "%s", name);
+    return (DL_FUNC)host_stub;
+}
+void rmock_set_host_routines(int on) { host_routines_on = on; }
+long rmock_host_calls(void) { return host_calls; }
+const char *rmock_host_last(void) { return host_last; }
 
 /* ------------------------------------------------------------------------------------------- driver interface (ctypes) */
 static void boot(void)

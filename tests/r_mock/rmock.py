@@ -70,6 +70,7 @@ class Runtime:
             ("rmock_clear_violations", None, []), ("rmock_last_error", C.c_char_p, []),
             ("rmock_alloc_count", C.c_long, []), ("rmock_collected_count", C.c_long, []), ("rmock_live_count", C.c_long, []),
             ("rmock_sweep_dead", None, []),
+            ("rmock_set_host_routines", None, [C.c_int]), ("rmock_host_calls", C.c_long, []), ("rmock_host_last", C.c_char_p, []),
             ("rmock_dotcall", C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
             ("R_init_mxgpu_r", None, [C.c_void_p]),
         ]:

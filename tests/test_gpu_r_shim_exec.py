@@ -576,6 +576,30 @@ def test_control_routines(R, gpu):
     call(R, "_mxgpu_set_devices", R.integer([]))
 
 
+def test_offload_gate_large_operands_reach_the_gpu_small_ones_matrixextras_routine(R, gpu):
+    """with MatrixExtra's DLL beside the shim (the mock resolves _MatrixExtra_* to a stub returning "host"): a product of 6e4
+    entries is served by the GPU (a real matrix, equal to the oracle), the reference's own test size (100 x 50,
+    tests/testthat/test-matmul.R:108-114) by the host routine; the gather stays on the host up to 1e7 entries"""
+    p, j, x = rand_csr(3000, 100, 0.2, seed=9)
+    assert j.size >= 50_000
+    Y = np.random.default_rng(2).normal(size=(7, 100))
+    ps, js, xs = rand_csr(100, 50, 0.4, seed=10)
+    Ys = np.random.default_rng(3).normal(size=(20, 50))
+    R.L.rmock_set_host_routines(1)
+    try:
+        n0 = R.L.rmock_host_calls()
+        out = call(R, "tcrossprod_csr_dense_numeric", R.integer(p), R.integer(j), R.real(x), R.matrix(Y), R.integer([1]))
+        assert R.typeof(out) == rmock.REALSXP and R.L.rmock_host_calls() == n0
+        np.testing.assert_allclose(R.view(out), O.tcrossprod_csr_dense_numeric(p, j, x, np.asfortranarray(Y)), rtol=1e-12, atol=1e-12)
+        out = R.call("tcrossprod_csr_dense_numeric", R.integer(ps), R.integer(js), R.real(xs), R.matrix(Ys), R.integer([1]))
+        assert R.as_py(out) == ["host"] and R.L.rmock_host_calls() == n0 + 1
+        out = R.call("copy_csr_rows_numeric", R.integer(p), R.integer(j), R.real(x), R.integer([5, 1]))
+        assert R.as_py(out) == ["host"] and R.L.rmock_host_calls() == n0 + 2
+    finally:
+        R.L.rmock_set_host_routines(0)
+    R.check_clean()
+
+
 def test_every_registered_routine_was_invoked(R):
     """runs last in this file: each of the reference-named routines went through the trampoline at least once"""
     names = {k[len("_MatrixExtra_"):] for k in R.routines() if k.startswith("_MatrixExtra_")}

@@ -111,3 +111,70 @@ def test_library_error_longjumps_to_the_trampoline_on_a_box_without_gpu(R):
         R.call("add_csr_elemwise", p, p, j, j, x, R.real([3.0, 4.0]), R.logical([0]))
     assert R.L.rmock_protect_depth() == 0
     R.check_clean()
+
+
+def test_offload_gate_of_the_c_abi():
+    """mx_should_offload (include/mxgpu.h): the measured per-routine thresholds, with and without the registration prefix,
+    the option and its read-back; host arithmetic only"""
+    import ctypes as C
+    from matrixextra_amd import _lib
+    lib = _lib.load()
+    lib.mx_should_offload.argtypes = [C.c_char_p, C.c_int64]
+    so = lambda fn, n: lib.mx_should_offload(fn.encode(), n)
+    assert so("tcrossprod_csr_dense_numeric", 2000) == 0 and so("tcrossprod_csr_dense_numeric", 50_000) == 1
+    assert so("_MatrixExtra_add_csr_elemwise", 49_999) == 0 and so("_MatrixExtra_add_csr_elemwise", 50_000) == 1
+    assert so("matmul_csr_dvec_numeric", 999_999) == 0 and so("matmul_csr_dvec_numeric", 1_000_000) == 1
+    assert so("copy_csr_rows_numeric", 9_999_999) == 0 and so("copy_csr_rows_numeric", 10_000_000) == 1
+    assert so("concat_csr_batch", 5_000_000) == 0 and so("matmul_csr_svec_float32", 500_000) == 0
+    try:
+        _lib.check(lib.mx_set_option(b"offload_min_len", C.c_int64(0)))
+        assert so("copy_csr_rows_numeric", 1) == 1
+        _lib.check(lib.mx_set_option(b"offload_min_len", C.c_int64(300)))
+        assert so("tcrossprod_csr_dense_numeric", 299) == 0 and so("matmul_csr_dvec_numeric", 300) == 1
+        v = C.c_int64()
+        _lib.check(lib.mx_get_option(b"offload_min_len", C.byref(v)))
+        assert v.value == 300
+    finally:
+        _lib.check(lib.mx_set_option(b"offload_min_len", C.c_int64(-1)))
+
+
+def test_small_operands_go_to_matrixextras_own_routine_when_its_dll_is_loaded(R):
+    """the shim's gate (csrc/r_shim.cpp Gate<>): operands below the routine's threshold are handed to MatrixExtra's routine
+    of the same name (R_FindSymbol in package "MatrixExtra": the mock resolves every _MatrixExtra_* name to a stub that
+    returns "host") with the caller's SEXPs, the device is never touched (this runs on a box without one), the protect
+    stack stays balanced; with the option at 0, or without MatrixExtra's DLL, the call goes to the backend as before."""
+    import ctypes as C
+    from matrixextra_amd import _lib
+    lib = _lib.load()
+    try:
+        have_gpu = _lib.device_count() > 0
+    except _lib.MxError:
+        have_gpu = False
+    p, j, x = R.integer([0, 1, 2]), R.integer([0, 1]), R.real([1.0, 2.0])
+    Y = R.matrix(np.ones((3, 2)))
+    R.L.rmock_set_host_routines(1)
+    try:
+        before = R.L.rmock_host_calls()
+        out = R.call("tcrossprod_csr_dense_numeric", p, j, x, Y, R.integer([1]))
+        assert R.as_py(out) == ["host"] and R.L.rmock_host_last() == b"_MatrixExtra_tcrossprod_csr_dense_numeric"
+        out = R.call("add_csr_elemwise", p, p, j, j, x, R.real([3.0, 4.0]), R.logical([0]))
+        assert R.as_py(out) == ["host"]
+        out = R.call("copy_csr_rows_numeric", p, j, x, R.integer([1, 0]))
+        assert R.as_py(out) == ["host"]
+        out = R.call("matmul_csr_dvec_numeric", p, j, x, R.real([1.0, 2.0]), R.integer([1]))
+        assert R.as_py(out) == ["host"]
+        assert R.L.rmock_host_calls() == before + 4
+        assert R.L.rmock_protect_depth() == 0 and R.L.rmock_preserved_count() == 0
+        # the control routines of the shim itself are not MatrixExtra's: never gated
+        if not have_gpu:
+            _lib.check(lib.mx_set_option(b"offload_min_len", C.c_int64(0)))         # always offload -> the backend -> no device here
+            with pytest.raises(rmock.RError):
+                R.call("tcrossprod_csr_dense_numeric", p, j, x, Y, R.integer([1]))
+            assert R.L.rmock_host_calls() == before + 4
+    finally:
+        _lib.check(lib.mx_set_option(b"offload_min_len", C.c_int64(-1)))
+        R.L.rmock_set_host_routines(0)
+    if not have_gpu:
+        with pytest.raises(rmock.RError):                                          # MatrixExtra's DLL not loaded: the backend serves it
+            R.call("tcrossprod_csr_dense_numeric", p, j, x, Y, R.integer([1]))
+    R.check_clean()

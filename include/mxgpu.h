@@ -291,6 +291,28 @@ int mxd_spmm_auto_cost(int m, int n, int K, int64_t nnz, int keep_plan, int dens
  * rows_sorted = 0 adds the sortedness pass the kernel then runs */
 int mxd_spmm_auto_cost2(int m, int n, int K, int64_t nnz, int keep_plan, int dense_dtype, int colmajor_out, int rows_sorted,
                         double *rowsplit_us, double *planned_us, double *tile_us, int *panels, int *tile_cpl);
+/* What AUTO has to know about a matrix beyond its sizes (round 5; csrc/profile.hip): real dgRMatrix data has power-law columns
+ * and skewed row lengths.  mxd_csr_profile fills profile_host[MX_PROFILE_LEN]: [i], i = 0 .. 31 = the share of the entries
+ * whose column is among the 2^i most frequent columns (two independent half-samples of <= 2^17 entries each: one ranks the
+ * columns, the other measures them), [32] = coefficient of variation of the row lengths, [33] = longest row / mean row,
+ * [34] = mean row length.  ~40 us; one stream synchronisation (8 KB come back): once per matrix, like mxd_csr_rows_sorted —
+ * DeviceCSR and the CSR cache keep it.  workspace: mxd_csr_profile_workspace_bytes(K).
+ * mxd_spmm_auto_algo3 / mxd_spmm_auto_cost3: AUTO's choice and estimates with the profile (NULL: uniform columns, equal rows
+ * — the assumptions of mxd_spmm_auto_algo2): an XCD's L2 holds the hottest rows of B, so the gather kernels' hit rate is the
+ * MASS of those columns, not their share of B's bytes; kernels that walk several rows in lockstep (row groups, the tile
+ * kernel) run as long as the longest of their rows. */
+#define MX_PROFILE_LEN 40
+size_t mxd_csr_profile_workspace_bytes(int K);
+int mxd_csr_profile(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, float *profile_host,
+                    void *workspace, void *stream);
+/* mxd_spmm_csr_dense_ex3 = _ex2 with the profile: AUTO's choice and the row-split kernel's panel count then follow it */
+int mxd_spmm_csr_dense_ex3(int m, int n, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
+                           const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor_out, int algo,
+                           int rows_sorted, int npanels, int wg_per_cu, const float *profile, void *stream);
+int mxd_spmm_auto_algo3(int m, int n, int K, int64_t nnz, int keep_plan, int dense_dtype, const void *B, size_t ldb, const void *C,
+                        size_t ldc, int colmajor_out, const float *profile, int *algo);
+int mxd_spmm_auto_cost3(int m, int n, int K, int64_t nnz, int keep_plan, int dense_dtype, int colmajor_out, int rows_sorted,
+                        const float *profile, double *rowsplit_us, double *planned_us, double *tile_us, int *panels, int *tile_cpl);
 int mxd_spmm_plan_create_auto(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
                               int npanels, void *stream, mx_spmm_plan **plan, int *ready);
 

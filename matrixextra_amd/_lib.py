@@ -64,6 +64,8 @@ def load() -> C.CDLL:
     lib.mxd_merge_fused_workspace_bytes.argtypes = [C.c_int]
     lib.mxd_gather_workspace_bytes.argtypes = [C.c_int]
     lib.mxd_scan_workspace_bytes.argtypes = [C.c_int64]
+    lib.mxd_csr_profile_workspace_bytes.restype = C.c_size_t
+    lib.mxd_csr_profile_workspace_bytes.argtypes = [C.c_int]
     lib.mxd_colmap_workspace_bytes.restype = C.c_size_t
     lib.mxd_colmap_workspace_bytes.argtypes = [C.c_int]
     if lib.mx_abi_version() != 1:

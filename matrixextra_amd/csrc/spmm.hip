@@ -46,6 +46,30 @@ void kt_end(hipStream_t st)
     kt.count++;
 }
 
+static thread_local const float *g_profile = nullptr;
+ProfileScope::ProfileScope(const float *p) : saved(g_profile) { g_profile = p; }
+ProfileScope::~ProfileScope() { g_profile = saved; }
+double profile_mass(double top, int K)
+{
+    if (top <= 0.0) return 0.0;
+    if (top >= (double)K) return 1.0;
+    if (!g_profile || g_profile[39] < 0.0f) return top / (double)K;   // uniform columns
+    const double l = std::log2(top < 1.0 ? 1.0 : top);
+    const int i = (int)l;
+    if (i >= 31) return g_profile[31];
+    const double f = l - i, v = g_profile[i] + (g_profile[i + 1] - g_profile[i]) * f;
+    return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+}
+double profile_cv() { return g_profile ? (double)g_profile[32] : 0.0; }
+bool profile_in_scope() { return g_profile != nullptr; }
+// a profile that says what no profile says (uniform columns are recognised by the marker in [39]; equal rows)
+const float *uniform_profile()
+{
+    static float u[MX_PROFILE_LEN] = {0};
+    u[39] = -1.0f;
+    return u;
+}
+
 static thread_local const char *g_last_spmm_kernel = "none";
 void set_last_spmm_kernel(const char *name) { g_last_spmm_kernel = name; }
 
@@ -121,8 +145,10 @@ static AutoCost spmm_auto_cost(int m, int n, int K, int64_t nnz, int sz, bool ke
     const double avg = m > 0 ? (double)nnz / m : 0.0;
     const int cols_per_line = 128 / sz;
     const double slabs = (double)((n + cols_per_line - 1) / cols_per_line);
-    auto rate = [](double panel_bytes, double l2_rate, double mall_rate) {     // bytes per us
-        const double hit = panel_bytes <= 4.0 * 1048576.0 ? 1.0 : (4.0 * 1048576.0) / panel_bytes;
+    // (the hit rate of the gather is the MASS of the entries whose row of the 128-byte slab an XCD's L2 holds — 32,768 rows per
+    // panel —, which for uniform columns is the share of the panel's bytes: 4 MiB / panel bytes)
+    auto rate = [&](double panels, double l2_rate, double mall_rate) {         // bytes per us
+        const double hit = profile_mass(32768.0 * panels, K);
         return 1e6 / (hit / l2_rate + (1.0 - hit) / mall_rate);
     };
     AutoCost c;
@@ -133,7 +159,7 @@ static AutoCost spmm_auto_cost(int m, int n, int K, int64_t nnz, int sz, bool ke
     // ran at 9 TB/s, 6,250 at 17.7, 12,500 at 19, 125,000 at 23.8
     const double pairs = std::ceil(m / 64.0) * slabs, fill = pairs / (pairs + 2400.0);
     const double sweep_rate = (plan_panels > 1.0 ? 19.0 : 23.5) * fill;
-    c.planned_us = (double)nnz * slabs * 128.0 / rate((double)K * 128.0 / plan_panels, sweep_rate, 8.5 * fill) +
+    c.planned_us = (double)nnz * slabs * 128.0 / rate(plan_panels, sweep_rate, 8.5 * fill) +
                    0.005e-3 * m * slabs * plan_panels + 15.0 + (keep_plan ? 0.0 : 36.0 + 6e-6 * (double)nnz);
     // the LDS-tile kernel (spmm_tile.hip, round 5): its own model; a caller that does not vouch for column-sorted rows pays
     // the sortedness pass (one read of the indices) on top
@@ -258,6 +284,26 @@ extern "C" int mxd_spmm_auto_cost2(int m, int n, int K, int64_t nnz, int keep_pl
     mx::tile_est_us(m, n, K, sz, m > 0 ? (double)nnz / m : 0.0, colmajor_out, tile_cpl);
     return 0;
 }
+extern "C" int mxd_spmm_auto_algo3(int m, int n, int K, int64_t nnz, int keep_plan, int dense_dtype, const void *B, size_t ldb, const void *C,
+                                   size_t ldc, int colmajor_out, const float *profile, int *algo)
+{
+    mx::ProfileScope scope(profile);
+    return mxd_spmm_auto_algo2(m, n, K, nnz, keep_plan, dense_dtype, B, ldb, C, ldc, colmajor_out, algo);
+}
+extern "C" int mxd_spmm_auto_cost3(int m, int n, int K, int64_t nnz, int keep_plan, int dense_dtype, int colmajor_out, int rows_sorted,
+                                   const float *profile, double *rowsplit_us, double *planned_us, double *tile_us, int *panels, int *tile_cpl)
+{
+    mx::ProfileScope scope(profile);
+    return mxd_spmm_auto_cost2(m, n, K, nnz, keep_plan, dense_dtype, colmajor_out, rows_sorted, rowsplit_us, planned_us, tile_us, panels, tile_cpl);
+}
+extern "C" int mxd_spmm_csr_dense_ex3(int m, int n, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
+                                      const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor_out, int algo,
+                                      int rows_sorted, int npanels, int wg_per_cu, const float *profile, void *stream)
+{
+    mx::ProfileScope scope(profile);
+    return mxd_spmm_csr_dense_ex2(m, n, K, nnz, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor_out, algo, rows_sorted, npanels,
+                                  wg_per_cu, stream);
+}
 extern "C" int mxd_spmm_auto_algo(int m, int n, int K, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
                                   int colmajor_out, int *algo)
 {
@@ -289,6 +335,21 @@ extern "C" int mxd_spmm_csr_dense_ex2(int m, int n, int K, int64_t nnz,
         ? mx::slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor_out)
         : mx::slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor_out);
     bool auto_pick_planned = false;
+    // One-shot AUTO on a matrix nobody profiled: where the planned sweep is a candidate (it syncs to size its plan anyway) the
+    // choice between it and the gather kernels hangs on how popular the hot columns are — tools/zipf_map.py: power-law columns,
+    // real-sim's shape, n = 128: planned rebuilt 0.257 ms, row-split 0.163 — so the ~40 us profile pass comes first.
+    float own_profile[MX_PROFILE_LEN];
+    const bool profile_here = algo == MX_SPMM_AUTO && !mx::profile_in_scope() && nnz >= (1LL << 21) && m >= 32768 && indices;
+    if (profile_here) {
+        void *ws = mx::scratch_buffer(mx::MX_SCRATCH_PROFILE, mxd_csr_profile_workspace_bytes(K));
+        mx::scratch_acquire(mx::MX_SCRATCH_PROFILE, st);
+        const int rc = ws ? mxd_csr_profile(m, K, nnz, indptr, indices, own_profile, ws, st) : 1;
+        if (ws) mx::scratch_done(mx::MX_SCRATCH_PROFILE, st);
+        if (rc) return mxd_spmm_csr_dense_ex3(m, n, K, nnz, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor_out, algo, rows_sorted,
+                                              npanels, wg_per_cu, mx::uniform_profile(), stream);       // (no memory for the counters: sizes only)
+        return mxd_spmm_csr_dense_ex3(m, n, K, nnz, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor_out, algo, rows_sorted, npanels,
+                                      wg_per_cu, own_profile, stream);
+    }
     if (algo == MX_SPMM_AUTO) {
         // AUTO rebuilds the plan on every call (nothing is assumed about A between calls); callers that multiply one
         // matrix repeatedly keep a plan (mxd_spmm_plan_create_auto + mxd_spmm_plan_run)

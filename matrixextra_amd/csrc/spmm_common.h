@@ -90,6 +90,22 @@ inline bool slab_ok(int n, const real_t *B, size_t ldb, const real_t *C, size_t 
     return true;
 }
 
+// ---- spmm.hip: the profile of the matrix the calling thread's current AUTO decision is about (mxd_csr_profile, csrc/profile.hip),
+// set for the duration of an entry point that was handed one; absent: uniform columns, equal rows.
+// profile_mass(top, K): share of the entries whose column is among the `top` hottest columns (what an L2 holding `top` rows
+// of B serves); profile_cv(): coefficient of variation of the row lengths
+struct ProfileScope { const float *saved; explicit ProfileScope(const float *p); ~ProfileScope(); };
+double profile_mass(double top, int K);
+double profile_cv();
+bool profile_in_scope();
+const float *uniform_profile();
+inline double lockstep_factor(double cv, int rows_together)
+{
+    // a wavefront that walks `rows_together` rows at once runs as long as the longest: E[max of k] / mean ~ 1 + cv * z(k)
+    const double z = rows_together >= 8 ? 1.42 : (rows_together >= 4 ? 1.03 : (rows_together >= 2 ? 0.56 : 0.0));
+    return 1.0 + cv * z;
+}
+
 // ---- spmm.hip: HIP-event ring around the dominant kernel of every launch, name of the last kernel used
 void kt_begin(hipStream_t st);
 void kt_end(hipStream_t st);

@@ -451,19 +451,25 @@ static int rowsplit_panels_by_size(int m, int n, int K, int dense_bytes, double 
 double rowsplit_est_us(int m, int n, int K, int dense_bytes, double avg_len, int P)
 {
     const int sz = dense_bytes, vec = 16 / sz;
-    const double nnz = avg_len * m, b_bytes = (double)K * n * sz, c_bytes = (double)m * n * sz;
+    const double nnz = avg_len * m, c_bytes = (double)m * n * sz;
     const double passes = (double)((n + 64 * vec - 1) / (64 * vec));
     const int G = n <= 8 * vec ? 8 : (n <= 16 * vec ? 16 : (n <= 32 * vec ? 32 : 64));
     double l2_rate = n * sz <= 128 ? 17.0 : 28.0, mall_rate = 8.5;                // TB/s: 8-lane groups read one line per row of B
     double row_us = 0.2e-3 * passes;                                              // one wavefront per (row, panel, pass)
+    double lockstep = 1.0;
     if (rowsplit_segments(m, n, sz, avg_len / P) == 0) {                          // the row-group form (tools/rowgroup_probe.py)
         l2_rate = G == 8 ? 18.0 : 21.0;
         mall_rate = 6.5;
         row_us = G == 8 ? 0.0 : (G == 16 ? 0.07e-3 : 0.15e-3);
+        // 64 / G rows per wavefront, as long as the longest of them (real row lengths are skewed: tools/zipf_map.py — m = 1e6,
+        // 9 per row, log-normal sigma .5, n = 16: 0.131 ms where equal rows take 0.061)
+        lockstep = lockstep_factor(profile_cv(), 64 / G);
     }
-    const double panel_bytes = b_bytes / P;
-    const double hit = panel_bytes <= 4.0 * 1048576.0 ? 1.0 : (4.0 * 1048576.0) / panel_bytes;
-    const double rate = 1e6 / (hit / l2_rate + (1.0 - hit) / mall_rate);          // bytes per microsecond
+    // the hit rate: the mass of the entries whose row of B an XCD's L2 (4 MiB) holds — the hottest 4 MiB / (n s) rows of the
+    // panel —, which for uniform columns is the share of the panel's bytes (round 4's term); hot columns sit anywhere, so P
+    // panels each hold 1 / P of every popularity class: the mass of the P times as many hottest columns of the whole matrix
+    const double hit = profile_mass(4.0 * 1048576.0 / ((double)n * sz) * P, K);
+    const double rate = 1e6 / (hit / l2_rate + (1.0 - hit) / mall_rate) / lockstep;   // bytes per microsecond
     const double c_traffic_us = c_bytes > 128e6 ? (2.0 * P - 2.0) * c_bytes / 5e6 : 0.0;
     return nnz * n * sz / rate + row_us * m * P + 6.0 * P + 4.0 + c_traffic_us;
 }

@@ -421,11 +421,13 @@ static TileGeom tile_geometry(int m, int n, int dense_bytes, int cpl, int rg, in
             int w = (int)ceil_div(want, TL_NG * r);
             if (w > TL_MAX_WAVES) continue;
             if (w < 4) w = 4;
+            if (colmajor && w * TL_NG * r > fit) continue;           // (rounded up past what the epilogue's LDS holds)
             const int loaders = w <= TL_MAX_WAVES - 1 ? 2 : 1;
             const long long serial = ceil_div(w + loaders, 4) * r, slack = (long long)w * TL_NG * r - want;
             const long long cost = (serial << 32) + ((long long)(TL_MAX_WAVES - w) << 16) + slack;
             if (cost < best_cost) { best_cost = cost; best_rg = r; best_nw = w; }
         }
+        if (best_cost == (1LL << 60)) { best_rg = 1; best_nw = TL_MAX_WAVES; }   // (nothing rounds into the epilogue's LDS: 60 rows do)
         rg = best_rg; nw = best_nw;
     }
     gm.rg = rg; gm.nw = nw;
@@ -450,8 +452,10 @@ static double tile_est_us_cpl(int m, int n, int K, int dense_bytes, double avg_l
     const int TK = 65536 / (256 * cpl);
     const double T = (double)ceil_div(K, TK);
     const double mu = avg_len * (double)(TK < K ? TK : K) / (double)(K > 0 ? K : 1);
-    const double steps = mu + 1.03 * std::sqrt(mu) + (4 / cpl) / 2.0;
-    const double passes = std::max(1.0, std::ceil((mu + 2.0 * std::sqrt(mu)) / 32.0));
+    // (entries per row and tile: Poisson around the ROW's own mean — with skewed row lengths a mixture: variance mu + (cv mu)^2)
+    const double cv = profile_cv(), sd = std::sqrt(mu + cv * cv * mu * mu);
+    const double steps = mu + 1.03 * sd + (4 / cpl) / 2.0;
+    const double passes = std::max(1.0, std::ceil((mu + 2.0 * sd) / 32.0));
     const double visit = 180.0 * passes + 4.5 * (1 + 3 * cpl) * steps;
     const double serial = (double)ceil_div(gm.nw + gm.nl, 4) * gm.rg;
     const double tile_us = std::max(0.9 + 0.14 * serial, serial * visit / 2400.0);

@@ -41,6 +41,7 @@ class DeviceCSR:
     _plan_limited: bool = False            # the kept plan was built under AUTO's padding limit (auto_plan) / without one (plan)
     _plan_key: tuple = ()                  # (data_ptr, _version) of the three tensors when the kept plan / flags were derived
     _spmv_plan: object = None
+    _profile: object = None
 
     def invalidate(self):
         """Forget everything derived from the arrays (plans, the sortedness flag): call after changing indptr / indices /
@@ -49,6 +50,7 @@ class DeviceCSR:
         if self._plan is not None:
             lib.mxd_spmm_plan_destroy(self._plan)
         self._plan, self._plan_panels, self._plan_ready, self._sorted, self._plan_limited = None, -1, True, None, False
+        self._profile = None
         self.drop_spmv_plan()
 
     def _key(self):
@@ -118,6 +120,19 @@ class DeviceCSR:
         except Exception:
             pass
 
+    def profile(self):
+        """mxd_csr_profile (csrc/profile.hip): mass of the hottest columns + row-length statistics, what AUTO's cost model
+        needs beyond the sizes; computed once per matrix (~40 us), cached like rows_sorted().  A ctypes float[40]."""
+        self._check_unchanged()
+        if self._profile is None:
+            lib = _lib.load()
+            ws = torch.empty(int(lib.mxd_csr_profile_workspace_bytes(C.c_int(self.K))) + 64, dtype=torch.uint8, device=self.indptr.device)
+            prof = (C.c_float * 40)()
+            check(lib.mxd_csr_profile(C.c_int(self.m), C.c_int(self.K), C.c_int64(self.nnz), _dp(self.indptr), _dp(self.indices), prof,
+                                      _dp(ws), _stream()))
+            self._profile = prof
+        return self._profile
+
     def rows_sorted(self) -> bool:
         """check_is_sorted per row on the device (src/misc.cpp:118-128); cached."""
         self._check_unchanged()
@@ -173,9 +188,9 @@ def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajo
         return out.t() if colmajor else out
     if algo == 0 and keep_plan and wg_per_cu == 0:
         pick = C.c_int(0)
-        check(lib.mxd_spmm_auto_algo2(C.c_int(A.m), C.c_int(n), C.c_int(A.K), C.c_int64(A.nnz), C.c_int(1), C.c_int(dt), _dp(B),
+        check(lib.mxd_spmm_auto_algo3(C.c_int(A.m), C.c_int(n), C.c_int(A.K), C.c_int64(A.nnz), C.c_int(1), C.c_int(dt), _dp(B),
                                       C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc), C.c_int(1 if colmajor else 0),
-                                      C.byref(pick)))
+                                      A.profile(), C.byref(pick)))
         if pick.value == 3:
             plan = A.auto_plan(npanels)
             if plan is not None:
@@ -186,10 +201,13 @@ def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajo
         elif pick.value != 3:
             algo = pick.value                                        # the choice made WITH a kept plan in mind stands
     sorted_rows = A.rows_sorted() if algo in (2, 5) else False         # the slab kernel's panels and the tile kernel's sweep need it
-    check(lib.mxd_spmm_csr_dense_ex2(C.c_int(A.m), C.c_int(n), C.c_int(A.K), C.c_int64(A.nnz), _dp(A.indptr), _dp(A.indices),
+    # (keep_plan callers also keep the matrix's profile: AUTO's choice and the row-split kernel's panels follow the real column
+    # popularity and row-length skew; keep_plan=False is the bare C-ABI AUTO: sizes only)
+    prof = A.profile() if keep_plan and A.nnz > 0 else None
+    check(lib.mxd_spmm_csr_dense_ex3(C.c_int(A.m), C.c_int(n), C.c_int(A.K), C.c_int64(A.nnz), _dp(A.indptr), _dp(A.indices),
                                      _dp(A.values), _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),
                                      C.c_int(dt), C.c_int(1 if colmajor else 0), C.c_int(algo),
-                                     C.c_int(int(sorted_rows)), C.c_int(npanels), C.c_int(wg_per_cu), _stream()))
+                                     C.c_int(int(sorted_rows)), C.c_int(npanels), C.c_int(wg_per_cu), prof, _stream()))
     return out.t() if colmajor else out
 
 

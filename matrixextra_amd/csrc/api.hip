@@ -428,7 +428,13 @@ struct Lanes {
         int d = 0;
         MX_HIP(hipGetDevice(&d));
         if (dev != d) {
-            up = run = down = nullptr; ev.clear();               // (streams of another device are left to the runtime)
+            // the streams and events of the device this thread worked on before go back to that device (the shard workers
+            // are persistent: a changed device list used to leave 3 streams + 2 nblk + 2 events per worker behind)
+            if (dev >= 0 && (up || !ev.empty())) {
+                if (hipSetDevice(dev) == hipSuccess) { drain(); destroy(); }
+                else { (void)hipGetLastError(); up = run = down = nullptr; ev.clear(); }
+                MX_HIP(hipSetDevice(d));
+            }
             MX_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
             MX_HIP(hipStreamCreateWithFlags(&run, hipStreamNonBlocking));
             MX_HIP(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
@@ -556,6 +562,9 @@ struct SmallStage {
     hipStream_t st = nullptr;
     size_t top = 0;
     bool tried = false;
+    // an error exit after up(): the copy from the pinned block may still be in flight, and the next small call packs its
+    // operands into that block — wait for the stream first (round 4's advisor finding)
+    int fail() { if (st) (void)hipStreamSynchronize(st); return 1; }
     bool init()
     {
         if (tried) return h != nullptr;
@@ -957,7 +966,7 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
             const size_t ob = S->put(B_host, b_bytes), in_end = S->top, oc = S->take(c_bytes), out_end = S->top;
             if (S->up(in_end)) return 1;
             if (mxd_spmm_csr_dense_ex2(m, n, K_rows, nnz_s, S->dev<int32_t>(op), S->dev<int32_t>(oj), S->dev<double>(ox), S->dev<real_t>(ob), ldb,
-                                       S->dev<real_t>(oc), ldc, dt, colmajor ? 1 : 0, algo, 0, npanels, 0, S->st)) return 1;
+                                       S->dev<real_t>(oc), ldc, dt, colmajor ? 1 : 0, algo, 0, npanels, 0, S->st)) return S->fail();
             if (S->down_and_wait(oc, out_end)) return 1;
             memcpy(C_host, S->h + oc, c_bytes);
             g_small_calls++;
@@ -1358,7 +1367,7 @@ static int spmv_host(int m, const int32_t *indptr, const int32_t *indices, const
             const size_t ov = S->put(y, sizeof(vec_t) * (size_t)len_y), in_end = S->top, oo = S->take(out_bytes), out_end = S->top;
             if (S->up(in_end)) return 1;
             if (spmv_launch(m, len_y, nnz_s, S->dev<int32_t>(op), S->dev<int32_t>(oj), S->dev<double>(ox), S->dev<void>(ov), v_dtype,
-                            S->dev<void>(oo), opt_spmv_algo(), S->st)) return 1;
+                            S->dev<void>(oo), opt_spmv_algo(), S->st)) return S->fail();
             if (S->down_and_wait(oo, out_end)) return 1;
             memcpy(out, S->h + oo, out_bytes);
             g_small_calls++;
@@ -1715,10 +1724,10 @@ int mx_csr_elemwise_begin(int op, int nrows, const int32_t *indptr1, const int32
                 if (S->fits()) {
                     if ((rc = S->up(in_end))) break;
                     if ((rc = mxd_csr_merge_count(op, nrows, S->dev<int32_t>(p1), S->dev<int32_t>(j1), nnz1, S->dev<int32_t>(p2), S->dev<int32_t>(j2),
-                                                  nnz2, S->dev<int32_t>(po), S->dev<void>(ws), nullptr, S->st))) break;
+                                                  nnz2, S->dev<int32_t>(po), S->dev<void>(ws), nullptr, S->st))) { S->fail(); break; }
                     if ((rc = mxd_csr_merge_fill(op, nrows, S->dev<int32_t>(p1), S->dev<int32_t>(j1), S->dev<void>(x1), nnz1, S->dev<int32_t>(p2),
                                                  S->dev<int32_t>(j2), S->dev<void>(x2), nnz2, S->dev<int32_t>(po), S->dev<int32_t>(jo),
-                                                 S->dev<void>(xo), S->st))) break;
+                                                 S->dev<void>(xo), S->st))) { S->fail(); break; }
                     if ((rc = S->down_and_wait(po, out_end))) break;
                     const int64_t nnz_s = ((const int32_t *)(S->h + po))[nrows];
                     res->host.resize(pb + (4 + vb) * (size_t)nnz_s);
@@ -1812,7 +1821,7 @@ int mx_copy_csr_rows_begin(const int32_t *indptr, int nrows, const int32_t *indi
                     if ((rc = mxd_csr_gather_fused((int)n_take, S->dev<int32_t>(p0), S->dev<int32_t>(j0), vb ? S->dev<void>(x0) : nullptr,
                                                    S->dev<int32_t>(r0), S->dev<int32_t>(po), S->dev<int32_t>(jo), vb ? S->dev<void>(xo) : nullptr,
                                                    has_values ? value_dtype : MX_NONE, cap, (double)nnz_in / (double)nrows, nullptr, &nnz_s,
-                                                   S->st))) break;
+                                                   S->st))) { S->fail(); break; }
                     if (nnz_s <= cap) {
                         if (nnz_s == 0) {            // slice.cpp:236-240: three EMPTY vectors (even the indptr)
                             if ((rc = S->down_and_wait(0, 0))) break;

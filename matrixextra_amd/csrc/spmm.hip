@@ -195,10 +195,24 @@ static int spmm_auto_algo(int m, int n, int K, int64_t nnz, int dense_dtype, con
     if (tile_can && c.tile_us * 1.1 < std::min(c.planned_us, c.rowsplit_us)) return MX_SPMM_TILE;
     return c.planned_us < c.rowsplit_us ? MX_SPMM_PLANNED : MX_SPMM_ROWSPLIT;
 }
+// the row-split kernel's segments per row and column panels for the WHOLE product the calling thread is about to run block
+// by block (spmm_block): column-major C, several panels, several segments and narrow lane groups all reassociate, so a
+// geometry re-derived from every block's own m, n and nnz would make the last bits of one product depend on how the export
+// pipeline, or the device list, cut it (round 4's advisor finding)
+static thread_local int g_family_segments = 0, g_family_panels = 0;
 int spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
                      int colmajor)
 {
-    return spmm_auto_algo(m, n, K, nnz, dense_dtype, B, ldb, C, ldc, colmajor, false);
+    const int family = spmm_auto_algo(m, n, K, nnz, dense_dtype, B, ldb, C, ldc, colmajor, false);
+    g_family_segments = g_family_panels = 0;
+    if (family == MX_SPMM_ROWSPLIT && nnz >= 0 && m > 0) {
+        const int sz = dense_dtype == MX_F64 ? 8 : 4;
+        const double avg = (double)nnz / m;
+        g_family_panels = rowsplit_panels(m, n, K, sz, avg);
+        const int S = rowsplit_segments(m, n, sz, avg / g_family_panels);
+        g_family_segments = S == 0 ? -1 : S;            // (run_rowsplit's code for the row-group form)
+    }
+    return family;
 }
 // entries of a device-resident CSR whose count the caller did not pass: indptr[m] (one 4-byte copy, synchronises `st`)
 static int device_nnz(const int32_t *indptr, int m, hipStream_t st, int64_t *nnz)
@@ -224,8 +238,7 @@ static int run_rowsplit(int m, int n, int K, int64_t nnz, int segments, int pane
         if (segments == 0) segments = rowsplit_segments(m, n, sz, avg / panels);
     }
     if (segments < 0) segments = 0;           // rowsplit_spmm's code for the row-group form
-    const int vec = 16 / sz;
-    set_last_spmm_kernel(segments == 0 && n <= 32 * vec && n % vec == 0 ? "spmm_rowgroup_kernel" : "spmm_rowsplit_kernel");
+    // (mxd_spmm_last_kernel: set by the launch itself, spmm_rowsplit.hip launch_one — the form can still change there)
     if (dense_dtype == MX_F64)
         return rowsplit_spmm<double>(m, n, K, segments, panels, indptr, indices, values, (const double *)B, ldb, (double *)C, ldc, colmajor, st);
     return rowsplit_spmm<float>(m, n, K, segments, panels, indptr, indices, values, (const float *)B, ldb, (float *)C, ldc, colmajor, st);
@@ -238,7 +251,8 @@ int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, con
                hipStream_t st)
 {
     if (family == MX_SPMM_ROWSPLIT)
-        return run_rowsplit(m, n, K, nnz, 0, from_auto ? 0 : npanels, 0, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, st);
+        return run_rowsplit(m, n, K, nnz, from_auto ? g_family_segments : 0, from_auto ? g_family_panels : npanels, 0, indptr, indices, values,
+                            B, ldb, C, ldc, dense_dtype, colmajor, st);
     if (family == MX_SPMM_TILE && from_auto)
         return mxd_spmm_csr_dense_ex2(m, n, K, nnz, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, family, 0, 0, 0, st);
     if (family == MX_SPMM_PLANNED && from_auto) {

@@ -1095,7 +1095,11 @@ int plan_auto_build(int m, int K, const int32_t *indptr, const int32_t *indices,
     // the plan's buffers are reused call after call: a caller that comes back on another stream waits for the sweep that
     // still reads them (scan.hip scratch_acquire / scratch_done)
     scratch_acquire(MX_SCRATCH_AUTO_PLAN, st);
-    if (plan_build(pl, m, K, indptr, indices, values, npanels, st, max_pad_ratio)) return 1;
+    const int rc = plan_build(pl, m, K, indptr, indices, values, npanels, st, max_pad_ratio);
+    // the build kernels wrote the plan's buffers on `st` whatever comes next — a sweep (plan_auto_run marks its end), a
+    // rejected plan or an error: the next user, possibly on another stream, waits behind THIS mark (round 4's advisor finding)
+    scratch_done(MX_SCRATCH_AUTO_PLAN, st);
+    if (rc) return 1;
     *ready = pl->ready;
     return 0;
 }

@@ -369,11 +369,13 @@ static void launch_one(int m, int n, int S, dim3 grid, const int32_t *indptr, co
 {
     if constexpr (G < MX_WAVE) {
         if (S == 0) {
+            set_last_spmm_kernel("spmm_rowgroup_kernel");            // (named where the form is final: after the alignment fallback)
             hipLaunchKernelGGL((spmm_rowgroup_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
                                m, n, indptr, indices, values, lo, hi, accumulate, B, ldb, C, ldc);
             return;
         }
     }
+    set_last_spmm_kernel("spmm_rowsplit_kernel");
     hipLaunchKernelGGL((spmm_rowsplit_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
                        m, n, S, indptr, indices, values, lo, hi, accumulate, B, ldb, C, ldc);
 }
@@ -394,8 +396,8 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
     }
     // grow-only per-thread scratch; a caller that comes back on another stream waits for the previous product (scratch_acquire)
     int32_t *cur = (int32_t *)scratch_buffer(MX_SCRATCH_ROWSPLIT, (size_t)(P + 1) * (size_t)m * sizeof(int32_t));
-    scratch_acquire(MX_SCRATCH_ROWSPLIT, stream);
     if (!cur) return set_error("rowsplit_spmm: cannot allocate %zu bytes of panel cursors", (size_t)(P + 1) * (size_t)m * sizeof(int32_t));
+    scratch_acquire(MX_SCRATCH_ROWSPLIT, stream);
     const int panel_cols = (int)ceil_div(K, P);
     kt_begin(stream);
     hipLaunchKernelGGL(rowsplit_cursors_kernel, dim3((unsigned)ceil_div(m, RS_WAVES)), dim3(RS_WAVES * MX_WAVE), 0, stream,

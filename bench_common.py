@@ -1,0 +1,161 @@
+"""bench_common.py — what bench.py (the headline line) and bench_extras.py (the neighbouring workloads) share: the roofline
+record, the HBM-traffic figures quoted from the committed rocprofv3 summaries (profiles/), the STREAM-copy probe and the CPU
+baseline of the SpMM (the oracle timed on the host's cores: a reported baseline, never the product path)."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+# ----------------------------------------------------------------------------------------------- CPU baselines
+def cpu_baseline_spmm(args, p, j, x, B_host, dtype):
+    """Reference algorithm restated (oracle/mx_oracle.c gemm_csr_drm_as_dcm), timed on this box's host cores on a
+    bounded sample (the first rows of the same matrix); all threads, plus the 1-thread figure."""
+    from oracle import oracle as O
+    threads = O.max_threads()
+    m, n = p.size - 1, B_host.shape[1]
+    dt = np.float64 if dtype == "f64" else np.float32
+    Bflat = np.ascontiguousarray(B_host, dtype=dt).reshape(-1)
+
+    def run(rows, nthreads):
+        pp = p[: rows + 1]
+        C_out = np.zeros(rows * n, dtype=dt)
+        t0 = time.perf_counter()
+        O.gemm_csr_drm_as_dcm(rows, n, pp, j, x, Bflat, n, C_out, rows, nthreads, False)
+        return time.perf_counter() - t0
+
+    def sample(nthreads, budget):
+        probe_rows = min(m, 20_000 if nthreads > 1 else 2_000)
+        run(probe_rows, nthreads)
+        rate = probe_rows / max(run(probe_rows, nthreads), 1e-9)
+        rows_s = int(min(m, max(probe_rows, rate * budget / 3)))
+        best = min(run(rows_s, nthreads) for _ in range(3))
+        return rows_s, 2.0 * int(p[rows_s] - p[0]) * n / best / 1e9
+    rows_all, gf_all = sample(threads, args.cpu_seconds * 0.7)
+    rows_one, gf_one = sample(1, args.cpu_seconds * 0.3)
+    return {"value": round(gf_all, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": round(gf_one, 3), "unit": "GFLOP/s", "cores": 1,
+                              "sample": f"first {rows_one} rows, best of 3"},
+            "sample": f"first {rows_all} of {m} rows of the same CSR x the same dense {B_host.shape[0]}x{n} "
+                      f"({dtype}), gemm_csr_drm_as_dcm restated with OpenMP schedule(dynamic), -march=native, best of 3"}
+
+
+def committed_traffic(kernel_sub, workload_tag, kernel_avg_ms):
+    """HBM-side bytes per launch from the committed PMC summary (profiles/rNN_*_pmc.json, written by tools/prof_summary.py
+    from separate rocprofv3 --pmc passes of this same command).  Only the NEWEST round's summaries are read, and one is
+    quoted only when (a) it is for the kernel and workload that just ran, (b) the source files that kernel is built from
+    still have the git blob hashes the summary recorded (tools/prof_common.py) and (c) its kernel duration agrees with
+    the one measured in this run within 5 % — otherwise `traffic` is null with the reason beside it, never last round's
+    counters.  Returns (bytes, file, None) or (None, None, why)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import prof_common as PC
+    why = "no summary of the newest round for this kernel and workload"
+    for f in PC.newest_round("*_pmc.json"):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") != workload_tag or kernel_sub not in d.get("kernel", ""):
+            continue
+        if "hbm_traffic_bytes_per_launch" not in d or "avg_ns" not in d:
+            continue
+        ok, reason = PC.kernel_unchanged(d["kernel"], d.get("source_blobs"))
+        if not ok:
+            why = f"{os.path.relpath(f, ROOT)}: {reason}"
+            continue
+        if abs(d["avg_ns"] / 1e6 - kernel_avg_ms) > 0.05 * kernel_avg_ms:
+            why = f"{os.path.relpath(f, ROOT)}: kernel {d['avg_ns'] / 1e6:.4f} ms there, {kernel_avg_ms:.4f} ms in this run"
+            continue
+        return int(d["hbm_traffic_bytes_per_launch"]["total_corrected"]), os.path.relpath(f, ROOT), None
+    return None, None, why
+
+
+def committed_kernels_traffic(kernels, call_ms):
+    """For a neighbouring operation timed as a whole call: the summed HBM-side bytes per call of the kernels it launches,
+    from the NEWEST round's multi-kernel PMC summary (profiles/rNN_extras_pmc.json, tools/prof_summary_multi.py: per
+    kernel the launches of one workload).  `kernels` = [(name in the summary, launches per call)].  Refused (traffic
+    null + `traffic_refused`) when a kernel is missing, when a kernel's source files no longer hash to what the summary
+    recorded, or when the kernels' summed duration in that profile does not fit the call just timed (more than 30 % above
+    it, or under half of it)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import prof_common as PC
+    whys = []
+    for f in PC.newest_round("*extras_pmc.json"):
+        try:
+            doc = json.load(open(f))
+            ks = doc["kernels"]
+        except Exception:
+            continue
+        if any(k not in ks or ks[k].get("avg_ns") is None or "total_corrected" not in ks[k] for k, _ in kernels):
+            whys.append(f"{os.path.relpath(f, ROOT)}: a kernel of this call is not in the summary")
+            continue
+        bad = [r for r in (PC.kernel_unchanged(ks[k]["kernel"], doc.get("source_blobs")) for k, _ in kernels) if not r[0]]
+        if bad:
+            whys.append(f"{os.path.relpath(f, ROOT)}: {bad[0][1]}")
+            continue
+        ns = sum(ks[k]["avg_ns"] * c for k, c in kernels)
+        # (the source hashes above are what tells a stale profile; this window only catches a summary of another workload —
+        # kernels of a few microseconds run up to ~20 % slower under the profiler than inside the timed loop)
+        if not (0.5 * call_ms <= ns / 1e6 <= 1.3 * call_ms):
+            whys.append(f"{os.path.relpath(f, ROOT)}: kernels {ns / 1e6:.4f} ms there, the call {call_ms:.4f} ms in this run")
+            continue
+        return {"traffic": int(sum(ks[k]["total_corrected"] * c for k, c in kernels)),
+                "traffic_source": os.path.relpath(f, ROOT), "traffic_kernels_ms": round(ns / 1e6, 4)}
+    return {"traffic_refused": "; ".join(whys) if whys else "no multi-kernel summary of the newest round"}
+
+
+STREAM = {"GBps": None}          # measured once per run (stream_copy_probe): the box's own float4-copy rate
+
+
+def stream_copy_probe(torch, lib, _lib, nbytes=1 << 30, reps=10):
+    """every fraction is quoted against the nominal 8 TB/s AND against a device-copy STREAM probe measured on
+    the box the benchmark runs on: one 1 GiB float4 copy kernel (csrc/stream.hip), read + write bytes / time."""
+    import ctypes
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    a.zero_()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def copy():
+        _lib.check(lib.mxd_stream_copy(ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()), ctypes.c_size_t(nbytes), st))
+    for _ in range(3):
+        copy()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        copy()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    STREAM["GBps"] = round(2 * nbytes / (ms / 1e3) / 1e9, 1)
+    del a, b
+    return {"GBps": STREAM["GBps"], "ms_per_GiB_copied": round(ms, 4), "bytes_copied": nbytes,
+            "kernel": "stream_copy_kernel (16 B per lane, nontemporal stores), read + write bytes / time",
+            "guide_figure_GBps": 6290}
+
+
+def roofline(alg_bytes, seconds, **extra):
+    """call- or kernel-level fraction of `alg_bytes` (SURVEY §8d algorithmic bytes) moved in `seconds`, against the nominal
+    HBM peak (`frac`) and against the STREAM-copy rate measured in this run (`frac_of_stream_copy`)"""
+    ach = alg_bytes / seconds / 1e9
+    d = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes)}
+    if STREAM["GBps"]:
+        d["frac_of_stream_copy"] = round(ach / STREAM["GBps"], 4)
+    d.update(extra)
+    km = d.get("traffic_kernels_ms")
+    if km:                                                          # kernel-level figure beside the call-level one
+        ka = alg_bytes / (km / 1e3) / 1e9
+        d["kernels"] = {"ms": km, "achieved": round(ka, 1), "frac": round(ka / HBM_PEAK_GBS, 4),
+                        "source": "rocprofv3 kernel durations of the committed profile (checked against this run's call time)"}
+        if STREAM["GBps"]:
+            d["kernels"]["frac_of_stream_copy"] = round(ka / STREAM["GBps"], 4)
+    return d

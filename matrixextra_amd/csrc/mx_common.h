@@ -38,7 +38,7 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// The one host round trip of the count -> fill operations (a size, a flag): `bytes` <= 64 from device memory into
+// The one host round trip of the count -> fill operations (a size, a flag, the matrix profile): `bytes` <= 256 from device memory into
 // `host_dst`, through a pinned landing zone and an event of the calling thread and current device (a hipMemcpyAsync into
 // pageable memory + hipStreamSynchronize costs ~100 us of runtime staging per call; this is ~10 us).  Returns when the
 // value is there: everything enqueued on `st` before it has completed.  (scan.hip)

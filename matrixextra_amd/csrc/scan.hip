@@ -220,9 +220,9 @@ int read_back_small(void *host_dst, const void *dev_src, size_t bytes, hipStream
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) d = 0;
     Rb &rb = rbs[d];
-    MX_REQUIRE(bytes <= 64, "read_back_small: %zu bytes", bytes);
+    MX_REQUIRE(bytes <= 256, "read_back_small: %zu bytes", bytes);
     if (!rb.host) {
-        MX_HIP(hipHostMalloc(&rb.host, 64, hipHostMallocDefault));
+        MX_HIP(hipHostMalloc(&rb.host, 256, hipHostMallocDefault));
         if (hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipHostFree(rb.host);
             rb.host = nullptr;

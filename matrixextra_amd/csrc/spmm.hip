@@ -353,7 +353,12 @@ extern "C" int mxd_spmm_csr_dense_ex2(int m, int n, int K, int64_t nnz,
     // choice between it and the gather kernels hangs on how popular the hot columns are — tools/zipf_map.py: power-law columns,
     // real-sim's shape, n = 128: planned rebuilt 0.257 ms, row-split 0.163 — so the ~40 us profile pass comes first.
     float own_profile[MX_PROFILE_LEN];
-    const bool profile_here = algo == MX_SPMM_AUTO && !mx::profile_in_scope() && nnz >= (1LL << 21) && m >= 32768 && indices;
+    // (~25 us: only for products the model prices at 0.2 ms or more)
+    bool profile_here = algo == MX_SPMM_AUTO && !mx::profile_in_scope() && nnz >= (1LL << 21) && m >= 32768 && indices;
+    if (profile_here) {
+        const mx::AutoCost c0 = mx::spmm_auto_cost(m, n, K, nnz, dense_dtype == MX_F64 ? 8 : 4, false, colmajor_out, rows_sorted != 0);
+        profile_here = std::min(c0.rowsplit_us, c0.planned_us) >= 200.0;
+    }
     if (profile_here) {
         void *ws = mx::scratch_buffer(mx::MX_SCRATCH_PROFILE, mxd_csr_profile_workspace_bytes(K));
         mx::scratch_acquire(mx::MX_SCRATCH_PROFILE, st);

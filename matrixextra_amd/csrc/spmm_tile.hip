@@ -117,7 +117,7 @@ template <typename real_t, int CPL>
 __device__ __forceinline__ void tl_window(const char *smem, int left, unsigned off, real_t aa, unsigned lane16,
                                           real_t (&acc)[CPL][16 / sizeof(real_t)])
 {
-    constexpr int NB = 4 / CPL;
+    constexpr int NB = 4 / CPL;                         // (batches of 2 with 256-byte slabs: measured, no gain — 0.111 against 0.107 ms)
     TlBatch<real_t, CPL, NB> p, q;
     tl_read<real_t, CPL, NB, 0>(smem, off, lane16, p);
     tl_pipe<real_t, CPL, NB, 0>(smem, left, off, aa, lane16, acc, p, q);

@@ -2,8 +2,8 @@
 tools/auto_map.py — the reference's published dense x CSC shape (vignettes/Introducing_MatrixExtra.Rmd:247-251), the
 headline shape, and the mid-size shapes where rounds 1-3's rule was up to 2x off — each kernel family timed on the device,
 AUTO (plan rebuilt per call, and plan kept on the matrix) within 25 % of the best of them — both forms of the row-split
-kernel forced included.  The full map (272 shapes) is
-profiles/r04_auto_map.json; this test allows 35 % + 10 us for the noise of a single short timing run."""
+kernel forced included, and (round 5) the LDS-tile kernel where rows are dense enough.  The full maps: profiles/r04_auto_map.json
+(272 shapes), profiles/r05_tile_map.json (density grid, 154 points), profiles/r05_zipf_map.json (power-law columns, 28 points); this test allows 35 % + 10 us for the noise of a single short timing run."""
 import os
 import sys
 
@@ -32,8 +32,8 @@ def test_auto_within_25pct_of_best(gpu, m, K, per_row, n, colmajor):
     rec = auto_map.spmm_point(m, K, per_row, n, colmajor, torch.float64, gpu.load())
     ms = rec["ms"]
     forms = ("rowsplit", "rowsplit_one_panel", "rowsplit_wave_per_row", "rowsplit_row_groups")
-    best1 = min(ms[k] for k in ("rowwave", "slab", "planned_rebuilt") + forms if ms.get(k) is not None)
-    bestk = min(ms[k] for k in ("rowwave", "slab", "planned_kept") + forms if ms.get(k) is not None)
+    best1 = min(ms[k] for k in ("rowwave", "slab", "planned_rebuilt", "tile") + forms if ms.get(k) is not None)
+    bestk = min(ms[k] for k in ("rowwave", "slab", "planned_kept", "tile") + forms if ms.get(k) is not None)
     assert ms["auto_one_shot"] <= 1.35 * best1 + 0.010, rec
     assert ms["auto_kept_plan"] <= 1.35 * bestk + 0.010, rec
     torch.cuda.empty_cache()

@@ -85,15 +85,17 @@ def spmm_point(m, K, npr, n, colmajor, dtype, lib):
     if n * B.element_size() <= 512:
         run("rowsplit_row_groups", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=4, npanels=1, wg_per_cu=-1))
     run("slab", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=2))
+    if npr * 64 >= K:                      # the LDS-tile kernel (round 5): only where a row meets a 256-row K-tile more than ~4 times
+        run("tile", lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=5))
     run("planned_kept", lambda: D.spmm_planned(A, B, out=out, colmajor=colmajor))
     run("planned_rebuilt", lambda: D.spmm_planned(A, B, out=out, colmajor=colmajor, rebuild_plan=True))
     forms = ("rowsplit", "rowsplit_one_panel", "rowsplit_wave_per_row", "rowsplit_row_groups")
-    one_shot = {k: v for k, v in ms.items() if v is not None and k in ("rowwave", "slab", "planned_rebuilt") + forms}
-    kept = {k: v for k, v in ms.items() if v is not None and k in ("rowwave", "slab", "planned_kept") + forms}
+    one_shot = {k: v for k, v in ms.items() if v is not None and k in ("rowwave", "slab", "planned_rebuilt", "tile") + forms}
+    kept = {k: v for k, v in ms.items() if v is not None and k in ("rowwave", "slab", "planned_kept", "tile") + forms}
     best1, bestk = min(one_shot, key=one_shot.get), min(kept, key=kept.get)
     rec = {"m": m, "K": K, "per_row": npr, "n": n, "layout": "col" if colmajor else "row", "dtype": "f64" if dtype == torch.float64 else "f32",
-           "ms": ms, "auto_family": {0: "auto", 1: "rowwave", 2: "slab", 3: "planned", 4: "rowsplit"}[pick.value],
-           "auto_family_kept_plan": {0: "auto", 1: "rowwave", 2: "slab", 3: "planned", 4: "rowsplit"}[pick_kept.value],
+           "ms": ms, "auto_family": {0: "auto", 1: "rowwave", 2: "slab", 3: "planned", 4: "rowsplit", 5: "tile"}[pick.value],
+           "auto_family_kept_plan": {0: "auto", 1: "rowwave", 2: "slab", 3: "planned", 4: "rowsplit", 5: "tile"}[pick_kept.value],
            "model": model, "kernels": {k: kern[k] for k in ("auto_one_shot", "auto_kept_plan")},
            "best_one_shot": best1, "best_kept": bestk,
            "auto_one_shot_over_best": round(ms["auto_one_shot"] / one_shot[best1], 3),

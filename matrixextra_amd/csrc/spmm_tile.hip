@@ -407,7 +407,10 @@ static TileGeom tile_geometry(int m, int n, int dense_bytes, int cpl, int rg, in
     if (rg < 1 || rg > (cpl == 1 ? 5 : 4) || nw < 1 || nw > TL_MAX_WAVES) {
         const int per_slab = 256 / gm.nslabs > 0 ? 256 / gm.nslabs : 1;
         int want = (int)ceil_div(m, per_slab);                            // rows per workgroup for one full round
-        if (want > TL_MAX_WAVES * TL_NG * 4) want = TL_MAX_WAVES * TL_NG * 4;
+        // more rows than one round holds: workgroups follow one another on a CU, and 144 rows (3 x 12 wavefronts + 2 loaders)
+        // run faster than the largest block (m = 1e5, K = 1e4, 500 per row, n = 100: 1.14 ms against 1.29 with 4 x 15 + 1 —
+        // tools/tile_sweep.py; the windows of A then stream from HBM and more, smaller workgroups hide that better)
+        if (want > TL_MAX_WAVES * TL_NG * 4) want = 12 * TL_NG * 3;
         // column-major C leaves through the tiles' LDS: (R | 1) x W sums must fit
         const int fit = (2 * tile_bytes + 256 * cpl) / (256 * cpl) - 1;
         if (colmajor && want > fit) want = fit;
@@ -442,7 +445,7 @@ static TileGeom tile_geometry(int m, int n, int dense_bytes, int cpl, int rg, in
 // (a row of every lane group, the tile), one after the other: ~180 cycles of window bookkeeping per 32 entries and 4.5
 // cycles per issue slot of a step (address add, CPL reads, 2 CPL FMAs), steps = the largest of four Poisson(mu) counts
 // rounded up to a batch, mu = entries per row and tile; never below what the fill and the window loads take (~0.9 us + 0.14
-// us per visit in a row).  Workgroups beyond one per CU come in rounds (x 1.3: their windows stream A from HBM, not from
+// us per visit in a row).  Workgroups beyond one per CU come in rounds (x 1.05: their windows stream A from HBM, not from
 // the Infinity Cache).
 static double tile_est_us_cpl(int m, int n, int K, int dense_bytes, double avg_len, int cpl, int colmajor)
 {
@@ -459,7 +462,7 @@ static double tile_est_us_cpl(int m, int n, int K, int dense_bytes, double avg_l
     const double visit = 180.0 * passes + 4.5 * (1 + 3 * cpl) * steps;
     const double serial = (double)ceil_div(gm.nw + gm.nl, 4) * gm.rg;
     const double tile_us = std::max(0.9 + 0.14 * serial, serial * visit / 2400.0);
-    return 6.0 + rounds * (T * tile_us + 4.0) * (wgs > 256.0 ? 1.3 : 1.0);
+    return 6.0 + rounds * (T * tile_us + 4.0) * (wgs > 256.0 ? 1.05 : 1.0);
 }
 // the cheaper of 256- and 512-byte slabs (512: half the workgroups — it wins where 256-byte slabs need a second round — but
 // half the rows of B per tile and seven issue slots per step instead of four)

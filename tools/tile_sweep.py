@@ -23,14 +23,14 @@ f = lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=5)
 t = min(timeit(f), timeit(f, warm=0))
 err = float((D.spmm(A, B, colmajor=colmajor, algo=5) - ref).abs().max() / ref.abs().max())
 print(f"tile (geometry chosen by the library): {t:.4f} ms   max err vs row-split {err:.2e}")
-for small in (0,):
+for small in (0, 1):
     for cpl in (1,):
         for rg in (2, 3, 4, 5):
             row = []
-            for nw in (6, 7, 8, 9, 10, 11, 12, 14, 15):
+            for nw in (8, 10, 12, 13, 14, 15):
                 if colmajor and small and cpl == 2 and nw * 4 * rg > 128:
                     row.append(float("nan"))
                     continue
                 f = lambda: D.spmm(A, B, out=out, colmajor=colmajor, algo=5, npanels=nw, wg_per_cu=cpl + 4 * rg + 32 * small)
                 row.append(min(timeit(f), timeit(f, warm=0)))
-            print(f"tile {'32K' if small else '64K'} cpl={cpl} rg={rg}: " + "  ".join(f"nw={w}: {t:.4f}" for w, t in zip((6, 7, 8, 9, 10, 11, 12, 14, 15), row)))
+            print(f"tile {'32K' if small else '64K'} cpl={cpl} rg={rg}: " + "  ".join(f"nw={w}: {t:.4f}" for w, t in zip((8, 10, 12, 13, 14, 15), row)))

@@ -14,7 +14,7 @@ bash tools/profile.sh $W/cfg2 1 -- --steps 20 --warmup 5 --no-extras --no-cpu-ba
 python3 tools/prof_summary.py $W/cfg2 $O/${RND}_cfg2_spmm "spmm_plan_kernel" cfg2-default > /dev/null
 # (b) the default command (extras included): the kernels of SpMV / gather / merges / sortedness — WITHOUT the legs that run
 # the same kernels on other (small) workloads, which are profiled on their own in (b2)
-export MXGPU_BENCH_EXTRAS_SKIP=vignette_loop,vignette_dense_csc,spmm_short_rows,export_small_calls
+export MXGPU_BENCH_EXTRAS_SKIP=vignette_loop,vignette_dense_csc,spmm_short_rows,export_small_calls,spmm_zipf
 bash tools/profile.sh $W/extras 1 -- --steps 10 --warmup 3 --no-cpu-baseline > $O/log_extras.txt 2>&1
 unset MXGPU_BENCH_EXTRAS_SKIP
 python3 tools/prof_summary_multi.py $W/extras $O/${RND}_extras extras-default spmv_flat_kernel slice_rows_kernel spmv_plan_kernel \
@@ -22,9 +22,10 @@ python3 tools/prof_summary_multi.py $W/extras $O/${RND}_extras extras-default sp
     "merge_fill_kernel<64, 0" "merge_fill_kernel<64, 1" "merge_fill_kernel<64, 2" rows_sorted_tile_kernel stream_copy_kernel \
     csr_by_dvec_kernel "drop_count_kernel<32, 0, double>" "drop_fill_kernel<32, 0, double>" > /dev/null
 cp "$(ls -t $W/extras/trace/*/*_kernel_stats.csv | head -1)" $O/${RND}_extras_kernel_stats.csv
-# (b2) the reference's published workload alone (dense 100 x 1e4 %*% CSC 1e4 x 1e4): the row-split kernel and its cursors
+# (b2) the reference's published workload alone (dense 100 x 1e4 %*% CSC 1e4 x 1e4): the LDS-tile kernel (AUTO since round 5), the
+# row-split kernel and its cursors; SQ / LDS / TA counter passes as well
 export MXGPU_BENCH_EXTRAS_ONLY=vignette_dense_csc
-bash tools/profile.sh $W/vignette 1 -- --steps 5 --warmup 2 --no-cpu-baseline > $O/log_vignette.txt 2>&1
+bash tools/profile.sh $W/vignette 2 -- --steps 5 --warmup 2 --no-cpu-baseline > $O/log_vignette.txt 2>&1
 unset MXGPU_BENCH_EXTRAS_ONLY
 python3 tools/prof_summary_multi.py $W/vignette $O/${RND}_vignette_extras vignette-dense-csc spmm_tile_kernel "spmm_rowsplit_kernel<double, 2, 64, false" \
     rowsplit_cursors_kernel "spmm_rowwave_kernel<double, 2, false" spmm_slab_kernel spmm_plan_kernel > /dev/null

@@ -40,6 +40,9 @@ for sub in subs:
     for n in ("TCC_HIT_sum", "TCC_MISS_sum"):
         if n in c:
             e[n] = c[n]
+    other = {n: v for n, v in c.items() if n not in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum")}
+    if other:                                   # the SQ / TA / LDS passes of `tools/profile.sh <dir> 2` (means per launch)
+        e["counters"] = other
     others = [{"grid_size": g, "calls": len(v), "avg_ns": sum(v) / len(v)} for g, v in groups.items() if g != main]
     if others:
         e["other_workloads"] = sorted(others, key=lambda o: -o["calls"])[:6]

@@ -178,7 +178,7 @@ static int spmm_auto_algo(int m, int n, int K, int64_t nnz, int dense_dtype, con
     // (tiny products are launch-bound whatever runs — unless their rows are long: the row-wave kernel walks a row's entries
     // one dependent read after the other; m = 1000, 200 per row, n = 16: 0.074 ms there, 0.010 in the row-split kernel; 50 per row: 0.023 and 0.012)
     if (nnz * (long long)n < (1LL << 22) && nnz <= 32LL * m) return MX_SPMM_ROWWAVE;
-    const bool tile_can = dense_dtype == MX_F64 ? tile_ok<double>(n, (const double *)B, ldb) : tile_ok<float>(n, (const float *)B, ldb);
+    const bool tile_can = nnz <= (1LL << 29) && (dense_dtype == MX_F64 ? tile_ok<double>(n, (const double *)B, ldb) : tile_ok<float>(n, (const float *)B, ldb));
     if (!ok || m < 32768) {
         if (!tile_can) return MX_SPMM_ROWSPLIT;
         const AutoCost c = spmm_auto_cost(m, n, K, nnz, sz, keep_plan, colmajor, keep_plan);

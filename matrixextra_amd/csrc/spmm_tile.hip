@@ -528,6 +528,8 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
     if (!tile_ok<real_t>(n, B, ldb)) return set_error("tile_spmm: rows of B must be 16-byte aligned whole vectors (n = %d, ldb = %zu)", n, ldb);
+    // (a row block's windows are addressed by 32-bit byte offsets from the block's first entry)
+    if (nnz > (1LL << 29)) return set_error("tile_spmm: more than 2^29 entries (%lld)", (long long)nnz);
     int cpl = variant & 3;
     // 256- or 512-byte slabs: the model's choice when the caller knows how many entries there are
     if (cpl != 1 && cpl != 2) { cpl = 1; if (nnz >= 0 && m > 0) tile_est_us(m, n, K, (int)sizeof(real_t), (double)nnz / m, colmajor, &cpl); }

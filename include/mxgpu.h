@@ -368,6 +368,9 @@ int mxd_spmv_plan_destroy(mx_spmv_plan *plan);
 /* diagnostic (tools/spmv_stamps.py): a device buffer of 8 x ceil(nnz / 23552) uint64 makes MX_SPMV_TILE run its stamped
  * build, which records the shader clock at its phase boundaries per workgroup; NULL switches back */
 int mxd_debug_spmv_tile_stamps(void *stamps_dev);
+/* likewise for the LDS-tile SpMM kernel (tools/tile_stamps.py): 2 x 16 x (workgroups) uint64 — per compute wavefront the cycles
+ * spent at the tile barriers and in its whole sweep */
+int mxd_debug_spmm_tile_stamps(void *stamps_dev);
 
 /* CSR (+) CSR, pass 1: per-row output lengths (union for ADD/SUB/OR/XOR,
  * intersection for MUL/AND) then exclusive scan into out_indptr[m+1].

@@ -98,29 +98,50 @@ __device__ __forceinline__ void tl_fma(real_t aa, const TlBatch<real_t, CPL, NB>
             for (int v = 0; v < VEC; v++) tl_fmac<(U0 + 3) & 15>(acc[c][v], aa, t.b[3][c][v]);
     }
 }
-// `cur` holds entries [U0, U0 + NB) on entry
-template <typename real_t, int CPL, int NB, int U0>
-__device__ __forceinline__ void tl_pipe(const char *smem, int left, unsigned off, real_t aa, unsigned lane16,
-                                        real_t (&acc)[CPL][16 / sizeof(real_t)], TlBatch<real_t, CPL, NB> &cur, TlBatch<real_t, CPL, NB> &nxt)
+// NBATCH batches of one window, straight-line: the reads of batch b + 1 go out before the FMAs of batch b, no branch in between
+// (rocprofv3 on the first version, one exit test + one read-ahead test per batch: 12 branches and 62 scalar instructions per
+// visit beside 75 vector ones, waves waiting half of their cycles)
+template <typename real_t, int CPL, int NB, int NBATCH>
+__device__ __forceinline__ void tl_fixed(const char *smem, unsigned off, real_t aa, unsigned lane16, real_t (&acc)[CPL][16 / sizeof(real_t)])
 {
-    if constexpr (U0 + NB < TL_G) {
-        if (left > U0 + NB) tl_read<real_t, CPL, NB, U0 + NB>(smem, off, lane16, nxt);
-    }
-    tl_fma<real_t, CPL, NB, U0>(aa, cur, acc);
-    if constexpr (U0 + NB < TL_G) {
-        if (left <= U0 + NB) return;
-        tl_pipe<real_t, CPL, NB, U0 + NB>(smem, left, off, aa, lane16, acc, nxt, cur);
-    }
+    TlBatch<real_t, CPL, NB> p, q;
+    tl_read<real_t, CPL, NB, 0>(smem, off, lane16, p);
+    if constexpr (NBATCH > 1) tl_read<real_t, CPL, NB, NB>(smem, off, lane16, q);
+    tl_fma<real_t, CPL, NB, 0>(aa, p, acc);
+    if constexpr (NBATCH > 2) tl_read<real_t, CPL, NB, 2 * NB>(smem, off, lane16, p);
+    if constexpr (NBATCH > 1) tl_fma<real_t, CPL, NB, NB>(aa, q, acc);
+    if constexpr (NBATCH > 3) tl_read<real_t, CPL, NB, 3 * NB>(smem, off, lane16, q);
+    if constexpr (NBATCH > 2) tl_fma<real_t, CPL, NB, 2 * NB>(aa, p, acc);
+    if constexpr (NBATCH > 4) tl_read<real_t, CPL, NB, 4 * NB>(smem, off, lane16, p);
+    if constexpr (NBATCH > 3) tl_fma<real_t, CPL, NB, 3 * NB>(aa, q, acc);
+    if constexpr (NBATCH > 5) tl_read<real_t, CPL, NB, 5 * NB>(smem, off, lane16, q);
+    if constexpr (NBATCH > 4) tl_fma<real_t, CPL, NB, 4 * NB>(aa, p, acc);
+    if constexpr (NBATCH > 6) tl_read<real_t, CPL, NB, 6 * NB>(smem, off, lane16, p);
+    if constexpr (NBATCH > 5) tl_fma<real_t, CPL, NB, 5 * NB>(aa, q, acc);
+    if constexpr (NBATCH > 7) tl_read<real_t, CPL, NB, 7 * NB>(smem, off, lane16, q);
+    if constexpr (NBATCH > 6) tl_fma<real_t, CPL, NB, 6 * NB>(aa, p, acc);
+    if constexpr (NBATCH > 7) tl_fma<real_t, CPL, NB, 7 * NB>(aa, q, acc);
 }
-// entries [16 w, 16 w + 16) of the window: `left` = how many of them any group still has (wave-uniform, >= 1)
+// entries [16 w, 16 w + 16) of the window: `left` = how many of them any group still has (wave-uniform, >= 1); whole batches:
+// a padded step (-0.0 x the row of zeros) is a no-op on the sums
 template <typename real_t, int CPL>
 __device__ __forceinline__ void tl_window(const char *smem, int left, unsigned off, real_t aa, unsigned lane16,
                                           real_t (&acc)[CPL][16 / sizeof(real_t)])
 {
     constexpr int NB = 4 / CPL;                         // (batches of 2 with 256-byte slabs: measured, no gain — 0.111 against 0.107 ms)
-    TlBatch<real_t, CPL, NB> p, q;
-    tl_read<real_t, CPL, NB, 0>(smem, off, lane16, p);
-    tl_pipe<real_t, CPL, NB, 0>(smem, left, off, aa, lane16, acc, p, q);
+    const int nb = (left + NB - 1) / NB;
+    if constexpr (NB == 4) {
+        if (nb <= 2) { if (nb <= 1) tl_fixed<real_t, CPL, NB, 1>(smem, off, aa, lane16, acc); else tl_fixed<real_t, CPL, NB, 2>(smem, off, aa, lane16, acc); }
+        else { if (nb == 3) tl_fixed<real_t, CPL, NB, 3>(smem, off, aa, lane16, acc); else tl_fixed<real_t, CPL, NB, 4>(smem, off, aa, lane16, acc); }
+    } else {
+        if (nb <= 4) {
+            if (nb <= 2) { if (nb <= 1) tl_fixed<real_t, CPL, NB, 1>(smem, off, aa, lane16, acc); else tl_fixed<real_t, CPL, NB, 2>(smem, off, aa, lane16, acc); }
+            else { if (nb == 3) tl_fixed<real_t, CPL, NB, 3>(smem, off, aa, lane16, acc); else tl_fixed<real_t, CPL, NB, 4>(smem, off, aa, lane16, acc); }
+        } else {
+            if (nb <= 6) { if (nb == 5) tl_fixed<real_t, CPL, NB, 5>(smem, off, aa, lane16, acc); else tl_fixed<real_t, CPL, NB, 6>(smem, off, aa, lane16, acc); }
+            else { if (nb == 7) tl_fixed<real_t, CPL, NB, 7>(smem, off, aa, lane16, acc); else tl_fixed<real_t, CPL, NB, 8>(smem, off, aa, lane16, acc); }
+        }
+    }
 }
 
 // TILE: bytes of one K-tile of the slab in LDS (two of them + one row of zeros); WIN: 16-entry windows per row (1 or 2)
@@ -129,7 +150,7 @@ __global__ __launch_bounds__((TL_MAX_WAVES + 1) * MX_WAVE)
 void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
                       const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ values,
                       const unsigned char *__restrict__ unsorted,
-                      const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ C, size_t ldc, int c_vec, int nl)
+                      const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ C, size_t ldc, int c_vec, int nl, unsigned long long rgw, unsigned long long *__restrict__ stamps)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
     constexpr int W = TL_G * VEC * CPL;              // columns of the slab
@@ -151,7 +172,15 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x / MX_WAVE);
     const int nw = (int)(blockDim.x / MX_WAVE) - nl; // compute wavefronts; the last nl wavefronts are the loaders
-    const int R = nw * TL_NG * RG;
+    // rows per lane group of every compute wavefront, 4 bits each (<= RG): consecutive wavefronts sit on different SIMDs (dealt
+    // 0 -> 2 -> 1 -> 3 round robin), so the host deals the rows such that every SIMD makes the same number of visits per tile
+    int R = 0, my_rg = 0, my_base = 0;
+    for (int w = 0; w < nw; w++) {
+        const int r = (int)((rgw >> (4 * w)) & 15);
+        if (w == wave) { my_rg = r; my_base = R; }
+        R += r;
+    }
+    R *= TL_NG;
     const int row0 = rb * R;
     const int c0 = slab * W;
     const int T = (K + TK - 1) / TK;
@@ -209,7 +238,7 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
         }
 #pragma unroll
         for (int i = 0; i < RG; i++) {
-            const int row = row0 + (i * nw + wave) * TL_NG + g;
+            const int row = i < my_rg ? row0 + (my_base + i) * TL_NG + g : m;      // (m: no such row)
             rows[i] = row;
             pos[i] = end[i] = 0;
             if (row < m) { pos[i] = indptr[row]; end[i] = indptr[row + 1]; }
@@ -280,15 +309,20 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
         }
         const int g8 = g * 8;
 
+        unsigned long long st_wait = 0, st_t0 = 0;
+        if (stamps) st_t0 = __builtin_amdgcn_s_memtime();
         for (int t = 0; t < T; t++) {
+            unsigned long long st_a = 0;
+            if (stamps) st_a = __builtin_amdgcn_s_memtime();
             __syncthreads();                         // tile t has landed; everybody is done with tile t - 1
+            if (stamps) st_wait += __builtin_amdgcn_s_memtime() - st_a;
             const int kend = (t + 1) * TK;
             const unsigned basek = (unsigned)(t & 1) * TILE - (unsigned)(t * TK) * ROWB;     // LDS offset of row j: basek + j * ROWB
             // one visit of (row i of every group, tile t); returns the largest number of entries a group had in the tile
             auto visit = [&](int i) -> int {
                 unsigned off[WIN];
                 real_t aa[WIN];
-                unsigned packed = 0;                 // entries in the tile, one byte per group (scalar)
+                unsigned lo[WIN], hi[WIN];           // the ballots: 16 bits per group
 #pragma unroll
                 for (int w = 0; w < WIN; w++) {
                     // (the ballot of each comparison is the comparison's own result register; the ballot of their AND would be
@@ -296,14 +330,22 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
                     const bool valid = lg + w * TL_G < rem[i], below = jv[i][w] < kend;
                     const bool in = valid & below;
                     const unsigned long long mask = __builtin_amdgcn_ballot_w64(valid) & __builtin_amdgcn_ballot_w64(below);
-                    packed += (unsigned)__popcll(mask & 0xFFFFull) | (unsigned)__popcll(mask & 0xFFFF0000ull) << 8 |
-                              (unsigned)__popcll(mask & 0xFFFF00000000ull) << 16 | (unsigned)__popcll(mask & 0xFFFF000000000000ull) << 24;
+                    lo[w] = (unsigned)mask; hi[w] = (unsigned)(mask >> 32);
                     off[w] = in ? basek + (unsigned)jv[i][w] * ROWB : ZOFF;
                     aa[w] = in ? (real_t)av[i][w] : (real_t)-0.0;      // narrowed per entry for f32 (matmul.cpp:53-57)
                 }
+                // entries in the tile per group (scalar): both windows of a group in one word, one popcount
+                int t0, t1, t2, t3;
+                if constexpr (WIN == 1) {
+                    t0 = __popc(lo[0] & 0xFFFFu); t1 = __popc(lo[0] >> 16); t2 = __popc(hi[0] & 0xFFFFu); t3 = __popc(hi[0] >> 16);
+                } else {
+                    t0 = __popc((lo[0] & 0xFFFFu) | (lo[1] << 16)); t1 = __popc((lo[0] >> 16) | (lo[1] & 0xFFFF0000u));
+                    t2 = __popc((hi[0] & 0xFFFFu) | (hi[1] << 16)); t3 = __popc((hi[0] >> 16) | (hi[1] & 0xFFFF0000u));
+                }
+                const unsigned packed = (unsigned)t0 | (unsigned)t1 << 8 | (unsigned)t2 << 16 | (unsigned)t3 << 24;
                 unsigned m01, m23, mx;
-                asm("s_max_u32 %0, %1, %2" : "=s"(m01) : "s"(packed & 0xFFu), "s"((packed >> 8) & 0xFFu) : "scc");
-                asm("s_max_u32 %0, %1, %2" : "=s"(m23) : "s"((packed >> 16) & 0xFFu), "s"(packed >> 24) : "scc");
+                asm("s_max_u32 %0, %1, %2" : "=s"(m01) : "s"(t0), "s"(t1) : "scc");
+                asm("s_max_u32 %0, %1, %2" : "=s"(m23) : "s"(t2), "s"(t3) : "scc");
                 asm("s_max_u32 %0, %1, %2" : "=s"(mx) : "s"(m01), "s"(m23) : "scc");
                 const int maxc = (int)mx;
                 const int cnt = (int)__builtin_amdgcn_ubfe(packed, (unsigned)g8, 8u);
@@ -329,10 +371,18 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
             // that a row's window is always awaited RG - 1 visits after it was asked for (counted vmcnt)
             bool again;
             do {
-                again = false;
-#pragma unroll
-                for (int i = 0; i < RG; i++) again |= visit(i) == WIN * TL_G;
+                // (spelled out: a `#pragma unroll` over bodies this large is declined, and a rolled loop indexes the sums in scratch)
+                // (a wavefront skips the visits of the rows it does not have — my_rg is wave-uniform)
+                again = visit(0) == WIN * TL_G;
+                if constexpr (RG > 1) { if (my_rg > 1) again |= visit(1) == WIN * TL_G; }
+                if constexpr (RG > 2) { if (my_rg > 2) again |= visit(2) == WIN * TL_G; }
+                if constexpr (RG > 3) { if (my_rg > 3) again |= visit(3) == WIN * TL_G; }
+                if constexpr (RG > 4) { if (my_rg > 4) again |= visit(4) == WIN * TL_G; }
             } while (again);
+        }
+        if (stamps && lane == 0) {                   // diagnostic build only (mxd_debug_spmm_tile_stamps): cycles at the barriers / in all
+            stamps[((size_t)blockIdx.x * 16 + wave) * 2] = st_wait;
+            stamps[((size_t)blockIdx.x * 16 + wave) * 2 + 1] = __builtin_amdgcn_s_memtime() - st_t0;
         }
         if constexpr (!COLMAJOR) {
 #pragma unroll
@@ -361,7 +411,8 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
         if (wave < nw) {
 #pragma unroll
             for (int i = 0; i < RG; i++) {
-                const int r = rows[i] - row0;
+                if (i >= my_rg) continue;
+                const int r = (my_base + i) * TL_NG + g;
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
 #pragma unroll
@@ -392,10 +443,52 @@ void tile_unsorted_rows_kernel(int m, const int32_t *__restrict__ indptr, const 
     if (lane == 0) flags[row] = any ? 1 : 0;
 }
 
+static unsigned long long *g_tile_stamps = nullptr;   // diagnostic (tools/tile_stamps.py): per wavefront, cycles at the tile barriers / in all
+
 // ---------------------------------------------------------------------------------------------------------------
 // Geometry: rows per workgroup so that ONE round of workgroups fills the 256 CUs when the product is small (every
 // workgroup keeps two 64 KB tiles: one per CU), the largest block otherwise (the tile fills shrink with 1 / R).
-struct TileGeom { int cpl, rg, nw, nl, nslabs, nrb; };
+struct TileGeom {
+    int cpl, rg, nw, nl, nslabs, nrb;
+    int R, serial;                    // rows per workgroup; visits per tile on the busiest SIMD
+    unsigned long long rgw;           // rows per lane group of every compute wavefront, 4 bits each
+};
+
+// Deal `gr` group-rows (4 rows of A each) to nw compute wavefronts so that every SIMD makes the same number of visits per tile:
+// a workgroup's wavefronts go to the SIMDs round robin, wavefront w to position w % 4 of the cycle, the nl loaders behind the
+// compute wavefronts — so a SIMD holds the compute wavefronts of one residue class, and a class that also holds a loader has
+// one compute wavefront fewer when nw + nl = 16.  (The first version gave every wavefront the same 3 rows: the two SIMDs with
+// four compute wavefronts made 12 visits per tile, the two with three + a loader 9 and waited — 28 % of all wavefront cycles
+// were spent at the tile barrier, tools/tile_stamps.py.)  Returns false when a wavefront would need more than rgmax rows.
+static bool tile_deal(int gr, int nw, int nl, int rgmax, TileGeom &gm)
+{
+    int nc[4] = {0, 0, 0, 0}, loaders[4] = {0, 0, 0, 0};
+    for (int w = 0; w < nw; w++) nc[w & 3]++;
+    for (int k = 0; k < nl; k++) loaders[(nw + k) & 3]++;
+    // quotas: gr / 4 each, the remainder to the classes without a loader first
+    int quota[4], order[4] = {0, 1, 2, 3};
+    std::sort(order, order + 4, [&](int a, int b) { return loaders[a] != loaders[b] ? loaders[a] < loaders[b] : a < b; });
+    for (int c = 0; c < 4; c++) quota[c] = gr / 4;
+    for (int k = 0; k < gr % 4; k++) quota[order[k]]++;
+    gm.rgw = 0; gm.serial = 0; gm.rg = 0;
+    int given = 0;
+    for (int c = 0; c < 4; c++) {
+        if (nc[c] == 0) { if (quota[c]) return false; continue; }
+        const int base = quota[c] / nc[c], extra = quota[c] % nc[c];
+        int idx = 0;
+        for (int w = c; w < nw; w += 4, idx++) {
+            const int r = base + (idx < extra ? 1 : 0);
+            if (r > rgmax) return false;
+            gm.rgw |= (unsigned long long)r << (4 * w);
+            gm.rg = std::max(gm.rg, r);
+            given += r;
+        }
+        gm.serial = std::max(gm.serial, quota[c]);
+    }
+    if (gm.rg < 1) gm.rg = 1;
+    gm.nw = nw; gm.nl = nl; gm.R = given * TL_NG;
+    return given == gr;
+}
 
 static TileGeom tile_geometry(int m, int n, int dense_bytes, int cpl, int rg, int nw, int colmajor, int tile_bytes)
 {
@@ -404,38 +497,40 @@ static TileGeom tile_geometry(int m, int n, int dense_bytes, int cpl, int rg, in
     if (cpl != 2) cpl = 1;
     gm.cpl = cpl;
     gm.nslabs = (n + w1 * cpl - 1) / (w1 * cpl);
-    if (rg < 1 || rg > (cpl == 1 ? 5 : 4) || nw < 1 || nw > TL_MAX_WAVES) {
+    const int rgmax = cpl == 1 ? 5 : 4;
+    if (rg >= 1 && rg <= rgmax && nw >= 1 && nw <= TL_MAX_WAVES) {
+        // a geometry asked for (tools/tile_sweep.py, the tests): the same rg rows for every lane group
+        gm.rgw = 0;
+        for (int w = 0; w < nw; w++) gm.rgw |= (unsigned long long)rg << (4 * w);
+        gm.rg = rg; gm.nw = nw; gm.nl = nw <= TL_MAX_WAVES - 1 ? 2 : 1;
+        gm.R = nw * TL_NG * rg;
+        gm.serial = (int)ceil_div(nw + gm.nl, 4) * rg;
+    } else {
         const int per_slab = 256 / gm.nslabs > 0 ? 256 / gm.nslabs : 1;
         int want = (int)ceil_div(m, per_slab);                            // rows per workgroup for one full round
-        // more rows than one round holds: workgroups follow one another on a CU, and 144 rows (3 x 12 wavefronts + 2 loaders)
-        // run faster than the largest block (m = 1e5, K = 1e4, 500 per row, n = 100: 1.14 ms against 1.29 with 4 x 15 + 1 —
-        // tools/tile_sweep.py; the windows of A then stream from HBM and more, smaller workgroups hide that better)
-        if (want > TL_MAX_WAVES * TL_NG * 4) want = 12 * TL_NG * 3;
+        // more rows than one round holds: workgroups follow one another on a CU, and 144 rows (3 rows x 12 wavefronts + 2
+        // loaders) run faster than the largest block (m = 1e5, K = 1e4, 500 per row, n = 100: 1.14 ms against 1.29 with 240 rows
+        // — tools/tile_sweep.py; the windows of A then stream from HBM and more, smaller workgroups hide that better)
+        if (want > 14 * TL_NG * 4) want = 12 * TL_NG * 3;
         // column-major C leaves through the tiles' LDS: (R | 1) x W sums must fit
         const int fit = (2 * tile_bytes + 256 * cpl) / (256 * cpl) - 1;
-        if (colmajor && want > fit) want = fit;
-        // among the geometries that hold `want` rows: the fewest visits in a row on the busiest SIMD (the workgroup's
-        // wavefronts, loaders included, are dealt round robin to the four SIMDs; a wavefront makes rg visits per tile), then
-        // the most wavefronts, then the least slack (measured at the vignette's shape, want = 157: 3 x 14 0.108 ms, 4 x 10
-        // 0.114, 5 x 8 0.124)
-        int best_rg = 4, best_nw = TL_MAX_WAVES;
-        long long best_cost = 1LL << 60;
-        for (int r = 1; r <= (cpl == 1 ? 5 : 4); r++) {
-            int w = (int)ceil_div(want, TL_NG * r);
-            if (w > TL_MAX_WAVES) continue;
-            if (w < 4) w = 4;
-            if (colmajor && w * TL_NG * r > fit) continue;           // (rounded up past what the epilogue's LDS holds)
-            const int loaders = w <= TL_MAX_WAVES - 1 ? 2 : 1;
-            const long long serial = ceil_div(w + loaders, 4) * r, slack = (long long)w * TL_NG * r - want;
-            const long long cost = (serial << 32) + ((long long)(TL_MAX_WAVES - w) << 16) + slack;
-            if (cost < best_cost) { best_cost = cost; best_rg = r; best_nw = w; }
+        if (colmajor && want > fit) want = fit / TL_NG * TL_NG;
+        if (want < 4 * TL_NG) want = 4 * TL_NG;
+        const int gr = (int)ceil_div(want, TL_NG);
+        // the fewest visits per tile on the busiest SIMD, then the most wavefronts (latency hiding)
+        bool found = false;
+        TileGeom best = gm;
+        for (int w = 14; w >= 4; w--) {
+            TileGeom t = gm;
+            if (!tile_deal(gr, w, 2, rgmax, t)) continue;
+            if (!found || t.serial < best.serial) { best = t; found = true; }
         }
-        if (best_cost == (1LL << 60)) { best_rg = 1; best_nw = TL_MAX_WAVES; }   // (nothing rounds into the epilogue's LDS: 60 rows do)
-        rg = best_rg; nw = best_nw;
+        if (!found) {                                                 // (cannot happen for want <= 14 x 4 x 4; belt and braces)
+            tile_deal(12 * 3, 12, 2, rgmax, best);
+        }
+        gm = best;
     }
-    gm.rg = rg; gm.nw = nw;
-    gm.nl = nw <= TL_MAX_WAVES - 1 ? 2 : 1;
-    gm.nrb = (int)ceil_div(m, nw * TL_NG * rg);
+    gm.nrb = (int)ceil_div(m, gm.R);
     return gm;
 }
 
@@ -460,7 +555,7 @@ static double tile_est_us_cpl(int m, int n, int K, int dense_bytes, double avg_l
     const double steps = mu + 1.03 * sd + (4 / cpl) / 2.0;
     const double passes = std::max(1.0, std::ceil((mu + 2.0 * sd) / 32.0));
     const double visit = 180.0 * passes + 4.5 * (1 + 3 * cpl) * steps;
-    const double serial = (double)ceil_div(gm.nw + gm.nl, 4) * gm.rg;
+    const double serial = (double)gm.serial;
     const double tile_us = std::max(0.9 + 0.14 * serial, serial * visit / 2400.0);
     return 6.0 + rounds * (T * tile_us + 4.0) * (wgs > 256.0 ? 1.05 : 1.0);
 }
@@ -484,10 +579,10 @@ static void launch_tile(const TileGeom &gm, int m, int n, int K, const int32_t *
     const dim3 block((unsigned)(gm.nw + gm.nl) * MX_WAVE);
     if (colmajor)
         hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, true>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
-                           gm.nrb, indptr, indices, values, unsorted, B, ldb, C, ldc, c_vec, gm.nl);
+                           gm.nrb, indptr, indices, values, unsorted, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
     else
         hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, false>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
-                           gm.nrb, indptr, indices, values, unsorted, B, ldb, C, ldc, c_vec, gm.nl);
+                           gm.nrb, indptr, indices, values, unsorted, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
 }
 
 template <typename real_t, int CPL, int WIN, int TILE>
@@ -538,7 +633,7 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
     if (one_loader) gm.nl = 1;
     const int c_vec = colmajor || ((ldc % VEC == 0) && ((uintptr_t)C % 16 == 0));
     {
-        const int R = gm.nw * TL_NG * gm.rg, rowb = 256 * gm.cpl, lds = 2 * (small_tile ? 32768 : 65536) + rowb;
+        const int R = gm.R, rowb = 256 * gm.cpl, lds = 2 * (small_tile ? 32768 : 65536) + rowb;
         if (colmajor && (R | 1) * rowb > lds)
             return set_error("tile_spmm: %d rows per workgroup do not fit the column-major epilogue's LDS (%d bytes)", R, lds);
     }
@@ -567,3 +662,11 @@ template int tile_spmm<float>(int, int, int, int64_t, int, int, int, const int32
                               float *, size_t, int, hipStream_t);
 
 }  // namespace mx
+
+// diagnostic: a device buffer of 2 x 16 x (workgroups) uint64 makes the tile kernel record, per compute wavefront, the shader
+// clock cycles it spent at the tile barriers and in its sweep; NULL switches back
+extern "C" int mxd_debug_spmm_tile_stamps(void *stamps_dev)
+{
+    mx::g_tile_stamps = (unsigned long long *)stamps_dev;
+    return 0;
+}

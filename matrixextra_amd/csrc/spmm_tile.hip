@@ -539,8 +539,8 @@ static TileGeom tile_geometry(int m, int n, int dense_bytes, int cpl, int rg, in
 // points and every point above 0.1 ms).  A workgroup walks T K-tiles; per tile its busiest SIMD makes `serial` visits of
 // (a row of every lane group, the tile), one after the other: ~180 cycles of window bookkeeping per 32 entries and 4.5
 // cycles per issue slot of a step (address add, CPL reads, 2 CPL FMAs), steps = the largest of four Poisson(mu) counts
-// rounded up to a batch, mu = entries per row and tile; never below what the fill and the window loads take (~0.9 us + 0.14
-// us per visit in a row).  Workgroups beyond one per CU come in rounds (x 1.05: their windows stream A from HBM, not from
+// rounded up to a batch, mu = entries per row and tile; never below what the fill and the window loads take (~1.3 us + 0.1
+// us per visit in a row: 2,000 rows of the vignette's matrix take 0.064 ms = 1.6 us per tile, 10,000 rows 2.7).  Workgroups beyond one per CU come in rounds (x 1.05: their windows stream A from HBM, not from
 // the Infinity Cache).
 static double tile_est_us_cpl(int m, int n, int K, int dense_bytes, double avg_len, int cpl, int colmajor)
 {
@@ -556,7 +556,7 @@ static double tile_est_us_cpl(int m, int n, int K, int dense_bytes, double avg_l
     const double passes = std::max(1.0, std::ceil((mu + 2.0 * sd) / 32.0));
     const double visit = 180.0 * passes + 4.5 * (1 + 3 * cpl) * steps;
     const double serial = (double)gm.serial;
-    const double tile_us = std::max(0.9 + 0.14 * serial, serial * visit / 2400.0);
+    const double tile_us = std::max(1.3 + 0.1 * serial, serial * visit / 2400.0);
     return 6.0 + rounds * (T * tile_us + 4.0) * (wgs > 256.0 ? 1.05 : 1.0);
 }
 // the cheaper of 256- and 512-byte slabs (512: half the workgroups — it wins where 256-byte slabs need a second round — but

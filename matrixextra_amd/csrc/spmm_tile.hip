@@ -8,14 +8,16 @@
 // bytes of L2 -> L1 line reads (4 GB for the vignette product against an 8 MB B), the ceiling the row-split kernel sits at.
 // Here B goes through LDS:
 //
-//   * a workgroup owns a ROW BLOCK of R rows of A (up to 240) and one COLUMN SLAB of W = 16 lanes x 16 bytes x CPL
-//     columns of B / C (256 or 512 bytes of a row);
-//   * it walks [0, K) in K-TILES: TK rows of the slab of B (64 KB) are brought into LDS by ONE LOADER WAVEFRONT with
-//     LDS-DMA (global_load_lds_dwordx4: 1 KB per instruction, coalesced 256 / 512-byte row pieces, no registers), tile t + 1
-//     while the compute wavefronts work on tile t (two buffers, one barrier per tile) — B is read from L2 once per row
-//     block instead of once per entry: m * K * n * s / R bytes;
-//   * a compute wavefront is 4 lane groups of 16 (one DPP row each); a group owns RG rows of A and keeps their sums in
-//     registers through the whole sweep.  Rows are sorted by column, so the entries of a row that fall into a tile are the
+//   * a workgroup owns a ROW BLOCK of R rows of A (up to ~220) and one COLUMN SLAB of W = 16 lanes x 16 bytes x CPL
+//     columns of B / C (256 or 512 bytes of a row); workgroups that share an XCD share a slab;
+//   * it walks [0, K) in K-TILES: TK rows of the slab of B (64 KB) are brought into LDS by LOADER WAVEFRONTS (two; their
+//     instruction stream is on the critical path: a pointer add and the DMA per 1-KB piece) with LDS-DMA
+//     (global_load_lds_dwordx4: coalesced 256 / 512-byte row pieces, no registers), tile t + 1 while the compute wavefronts
+//     work on tile t (two buffers, one barrier per tile) — B is read from L2 once per row block instead of once per entry:
+//     m * K * n * s / R bytes;
+//   * a compute wavefront is 4 lane groups of 16 (one DPP row each); a group owns 2 .. 5 rows of A — dealt by the host so that
+//     every SIMD makes the same number of (row, tile) visits, tile_deal below — and keeps their sums in registers through
+//     the whole sweep.  Rows are sorted by column, so the entries of a row that fall into a tile are the
 //     next ones in storage order: the group keeps a window of the row's next 16 / 32 entries in registers (lane l = entry
 //     pos + l), counts those below the tile's end with a ballot, and streams them: the entry's LDS row offset is handed to
 //     the group's 16 lanes by DPP row_newbcast folded INTO the address add (v_add_u32_dpp), its value into the FMA
@@ -27,8 +29,10 @@
 //     before the sweep, by the same group in storage order — correct, slow, rare;
 //   * row-major C: 16-byte stores straight from the registers; column-major C: through LDS, whole column segments of R rows.
 //
-// Roofline: HBM-bound by the contract's algorithmic bytes; what limits it in practice is LDS reads
-// (nnz * n * s bytes, `lds_read` in bench.py) beside the tile fills (`l2_to_lds_fill`).
+// Roofline: HBM-bound by the contract's algorithmic bytes.  In practice (rocprofv3 at the vignette's shape,
+// profiles/r05_vignette_extras_pmc.json): LDS 40 % busy (no bank conflicts), VALU 54 %, waves a quarter of their cycles at the
+// tile barrier — the steps executed are 1.5x the useful ones (four groups in lockstep, batches of four, the 4-column last
+// slab of n = 100).  `lds_read` in bench.py: nnz x slabs x 256 B per launch.
 #include "spmm_common.h"
 #include <algorithm>
 #include <cmath>
@@ -56,8 +60,8 @@ template <int U> __device__ __forceinline__ void tl_fmac(float &acc, float a, fl
 
 // One visit of (a row of every group, the tile): entries 0 .. maxc - 1 of the window in batches of NB = 4 / CPL entries (four
 // ds_read_b128 either way).  The reads of batch q + 1 are issued BEFORE the FMAs of batch q (two register sets): without
-// that the compiler waits for every read right behind its issue and a wavefront spends an LDS round trip per entry.  Exits
-// are wave-uniform, one per batch: a padded step (-0.0 x the row of zeros) is a no-op on the sums.
+// that the compiler waits for every read right behind its issue and a wavefront spends an LDS round trip per entry.  Whole
+// batches only: a padded step (-0.0 x the row of zeros) is a no-op on the sums.
 template <typename real_t, int CPL, int NB> struct TlBatch { typename VecT<real_t, 16 / (int)sizeof(real_t)>::type b[NB][CPL]; };
 
 template <typename real_t, int CPL, int NB, int U0>

@@ -59,6 +59,7 @@ int set_error(const char *fmt, ...)
 }
 
 int spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor);
+struct ProfileScope { const float *saved; explicit ProfileScope(const float *p); ~ProfileScope(); };   // spmm_common.h: the profile AUTO reads
 int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
                const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, int npanels, hipStream_t st);
 int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
@@ -199,6 +200,68 @@ struct CsrDev {
     size_t vb = 0, bytes = 0;
     uint64_t fp = 0, tick = 0;
 };
+
+// The matrix profile (mxd_csr_profile, csrc/profile.hip) computed on the HOST from the caller's own arrays: the export-level
+// products choose their kernel family before the CSR is on the device (cold calls upload and multiply block by block), and
+// for data that looks like real dgRMatrix contents — power-law columns, skewed rows — the sizes alone pick the wrong one
+// (tools/zipf_map.py).  Same estimator as the device pass: <= 2^16 sampled column ids in evenly spaced runs of 256, two
+// independent halves (one ranks the columns, the other measures the entries they hold), every 2^-k-th row for the length
+// statistics.  ~0.2 ms for K = 1e5 on one core; only where the planned sweep or the tile kernel is a candidate.
+static bool host_csr_profile(const int32_t *indptr, const int32_t *indices, int m, int K, float *prof)
+{
+    for (int i = 0; i < MX_PROFILE_LEN; i++) prof[i] = 0.0f;
+    const int64_t first = indptr[0], nnz = (int64_t)indptr[m] - first;
+    if (m <= 0 || K <= 0 || nnz <= 0) return false;
+    static thread_local std::vector<uint16_t> ca, cb;
+    ca.assign((size_t)K, 0); cb.assign((size_t)K, 0);
+    int runs = (int)std::min<int64_t>(256, (nnz + 255) / 256);
+    if (runs > 1) runs &= ~1;
+    for (int r = 0; r < runs; r++) {
+        const int64_t at = first + (int64_t)((double)r * (double)nnz / (double)runs), end = std::min<int64_t>(at + 256, first + nnz);
+        std::vector<uint16_t> &c = (r & 1) ? cb : ca;
+        for (int64_t e = at; e < end; e++) { const int col = indices[e]; if ((unsigned)col < (unsigned)K && c[(size_t)col] < 65535) c[(size_t)col]++; }
+    }
+    constexpr int BINS = 1024;
+    double cols[BINS] = {0}, sums[BINS] = {0};
+    double total = 0.0, met = 0.0, total_a = 0.0;
+    for (int c = 0; c < K; c++) {
+        const unsigned v = ca[(size_t)c], w = cb[(size_t)c];
+        if (v | w) { const unsigned b = v < BINS - 1 ? v : BINS - 1; cols[b] += 1.0; sums[b] += w; }
+    }
+    for (int b = 0; b < BINS; b++) { total += sums[b]; if (b) { met += cols[b]; total_a += cols[b] * b; } }
+    const bool one_half = total <= 0.0;
+    if (one_half) total = total_a > 0.0 ? total_a : 1.0;
+    int level = 0;
+    double seen = 0.0, mass = 0.0;
+    for (int b = BINS - 1; b >= 0 && level < 32; b--) {
+        const double nc = b == 0 ? std::max(0.0, (double)K - met) : cols[b];
+        const double ns = one_half ? (b == 0 ? 0.0 : nc * b) : sums[b];
+        if (nc <= 0.0) continue;
+        while (level < 32 && (double)(1ULL << level) <= seen + nc) {
+            prof[level] = (float)((mass + ns * (((double)(1ULL << level) - seen) / nc)) / total);
+            level++;
+        }
+        seen += nc; mass += ns;
+    }
+    for (; level < 32; level++) prof[level] = 1.0f;
+    const int stride = std::max(1, m / 65536);
+    double s0 = 0.0, s1 = 0.0, longest = 0.0, cnt = 0.0;
+    for (int r = 0; r < m; r += stride) { const double len = (double)indptr[r + 1] - indptr[r]; s0 += len; s1 += len * len; longest = std::max(longest, len); cnt += 1.0; }
+    const double mean = s0 / cnt, var = s1 / cnt - mean * mean;
+    prof[32] = mean > 0.0 ? (float)(std::sqrt(std::max(0.0, var)) / mean) : 0.0f;
+    prof[33] = mean > 0.0 ? (float)(longest / mean) : 0.0f;
+    prof[34] = (float)mean;
+    return true;
+}
+// AUTO's family for an export-level product, with the host-side profile where it can change the choice
+static int export_auto_family(int m, int n, int K, int64_t nnz, int dt, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor,
+                              const int32_t *indptr, const int32_t *indices)
+{
+    float prof[MX_PROFILE_LEN];
+    const bool profiled = nnz >= (1LL << 21) && m >= 4096 && indptr && indices && host_csr_profile(indptr, indices, m, K, prof);
+    mx::ProfileScope scope(profiled ? prof : nullptr);
+    return mx::spmm_auto_family(m, n, K, nnz, dt, B, ldb, C, ldc, colmajor);
+}
 
 static uint64_t fnv_block(uint64_t h, const void *p, size_t n)
 {
@@ -716,9 +779,9 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
     std::vector<int> cut((size_t)nd + 1);
     partition_rows(indptr, m, nd, 12.0, (double)n * sizeof(real_t), cut.data());
     // one kernel family for the whole product (see spmm_host); the alignment rules only look at the low bits of the pointers
-    const int family = algo == MX_SPMM_AUTO ? mx::spmm_auto_family(m, n, K_rows, nnz, dt, (const void *)(uintptr_t)256, ldb,
-                                                                   (const void *)(uintptr_t)256, colmajor ? (size_t)m : ldc,
-                                                                   colmajor ? 1 : 0) : algo;
+    const int family = algo == MX_SPMM_AUTO ? export_auto_family(m, n, K_rows, nnz, dt, (const void *)(uintptr_t)256, ldb,
+                                                                 (const void *)(uintptr_t)256, colmajor ? (size_t)m : ldc,
+                                                                 colmajor ? 1 : 0, indptr, indices) : algo;
     // host memory registered for every device; `gate` opens once the result is registered (downloads wait for it)
     Pin pinB, pinJ, pinX;
     std::vector<Pin> pinC((size_t)np);
@@ -1110,7 +1173,7 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     // The kernel family is chosen ONCE, for the whole product, and every block runs it (AUTO applied block by block took
     // the row-wave kernel for cfg2's blocks — each below AUTO's size threshold — and would hand back other last bits cold
     // than cached once cached calls use the matrix's plan).
-    const int family = algo == MX_SPMM_AUTO ? mx::spmm_auto_family(m, n, K_rows, nnz, dt, dB, ldb, dC, ldc, colmajor ? 1 : 0) : algo;
+    const int family = algo == MX_SPMM_AUTO ? export_auto_family(m, n, K_rows, nnz, dt, dB, ldb, dC, ldc, colmajor ? 1 : 0, indptr, indices) : algo;
     mx_spmm_plan *plan = nullptr;
     if (!A.resident) {
         const bool direct_up = pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz) && pinX.pin(values, sizeof(double) * (size_t)nnz);

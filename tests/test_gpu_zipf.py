@@ -131,3 +131,27 @@ def test_merge_and_gather_with_skewed_rows(gpu):
     ref = O.copy_csr_rows_numeric(p1, j1, x1, rows)
     for k in ("indptr", "indices", "values"):
         np.testing.assert_array_equal(got[k], ref[k])
+
+
+def test_export_path_profiles_the_host_arrays(gpu):
+    """the export-level product chooses its kernel family before the CSR is on the device: a host-side profile of the
+    caller's arrays (csrc/api.hip host_csr_profile, the device pass's estimator) makes the same choice the DeviceCSR path
+    makes — real-sim's shape with power-law columns, n = 128: the row-split kernel, where a matrix of the same sizes with
+    uniform columns still gets the planned sweep; both results against the oracle"""
+    from matrixextra_amd import exports as G
+    lib = _lib.load()
+    m, K, n = 72_309, 20_958, 128
+    Y = np.asfortranarray(synth.dense_normal(n, K, seed=3))
+    pz, jz, xz = synth.csr_zipf(m, K, 51, alpha=1.0, sigma=1.0, seed=21)
+    got = G.tcrossprod_csr_dense_numeric(pz, jz, xz, Y, 1)
+    assert lib.mxd_spmm_last_kernel() == b"spmm_rowsplit_kernel", lib.mxd_spmm_last_kernel()
+    rows = 3000
+    e = int(pz[rows])
+    ref = O.tcrossprod_csr_dense_numeric(pz[:rows + 1], jz[:e], xz[:e], Y, 4)
+    np.testing.assert_allclose(got[:rows], ref, rtol=1e-12, atol=1e-12 * float(np.abs(ref).max()))
+    pu, ju, xu = synth.csr_fixed(m, K, 40, seed=22)
+    got = G.tcrossprod_csr_dense_numeric(pu, ju, xu, Y, 1)
+    assert lib.mxd_spmm_last_kernel() == b"spmm_plan_kernel", lib.mxd_spmm_last_kernel()
+    e = int(pu[rows])
+    ref = O.tcrossprod_csr_dense_numeric(pu[:rows + 1], ju[:e], xu[:e], Y, 4)
+    np.testing.assert_allclose(got[:rows], ref, rtol=1e-12, atol=1e-12 * float(np.abs(ref).max()))

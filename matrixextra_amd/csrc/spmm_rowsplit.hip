@@ -146,14 +146,63 @@ __device__ __forceinline__ void rs_chunk_groups(int cnt, int jv, double av, cons
     }
 }
 
-// lo / hi: per-row entry ranges of this launch (a column panel), nullptr = the whole row; accumulate: C holds the sums of
-// the earlier panels
+// ---------------------------------------------------------------------------------------------------------------
+// COLUMN PANELS IN ONE LAUNCH.  The grid is 1-D, panel-major: workgroup id = (p * passes + pass) * nbx + rb, so the dispatcher
+// hands out panel 0's workgroups, then panel 1's, ... exactly in the order the P launches of rounds 3-4 ran them — without
+// the P - 1 launch gaps and without draining the machine at the end of every panel (the tail of panel p runs beside the
+// head of panel p + 1).  Panel p continues the sums panel p - 1 left in C, and the two workgroups of one row block sit on
+// different XCDs (id % 8), whose L2s do not see each other's plain stores: the hand-over goes through agent-scope
+// (write-through / re-fetching) stores and loads of C, ordered by a counter per (pass, row block): a workgroup adds one when
+// its part of C has left (s_waitcnt vmcnt(0)), its successor waits for the count to reach p before it reads C.  Workgroups
+// are dispatched in id order, so a waiting workgroup's predecessor is always running or done: no deadlock (the same
+// assumption as the look-back scans of mx_common.h).
+struct PanelWhere { int rb, pass, p; };
+__device__ __forceinline__ PanelWhere panel_where(int nbx, int passes)
+{
+    PanelWhere w;
+    const unsigned id = blockIdx.x, t = id / (unsigned)nbx;
+    w.rb = (int)(id - t * (unsigned)nbx);
+    w.p = (int)(t / (unsigned)passes);
+    w.pass = (int)(t - (unsigned)w.p * (unsigned)passes);
+    return w;
+}
+__device__ __forceinline__ void panel_wait(const unsigned *word, int p)
+{
+    while ((int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p) __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");            // the reads of C stay behind the last poll
+}
+// every thread's stores of C have left, then one thread counts the workgroup in
+__device__ __forceinline__ void panel_signal(unsigned *word)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename real_t, int VEC>
+__device__ __forceinline__ void c_load(real_t (&v)[VEC], const real_t *p, bool agent)
+{
+    if (agent) {
+#pragma unroll
+        for (int q = 0; q < VEC; q++) v[q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else vload<real_t, VEC>(v, p);
+}
+template <typename real_t, int VEC>
+__device__ __forceinline__ void c_store(real_t *p, const real_t (&v)[VEC], bool agent)
+{
+    if (agent) {
+#pragma unroll
+        for (int q = 0; q < VEC; q++) __hip_atomic_store(p + q, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else vstore<real_t, VEC>(p, v);
+}
+
+// cursors: (P + 1) x m per-row entry bounds of the column panels (rowsplit_cursors_kernel), nullptr = one panel, the whole
+// row; done: one counter per (pass, row block), zeroed by the cursor kernel; P: the panels THIS launch runs, from p0 on
 template <typename real_t, int VEC, int G, bool COLMAJOR>
 __global__ __launch_bounds__(RS_WAVES * MX_WAVE)
-void spmm_rowsplit_kernel(int m, int n, int S,
+void spmm_rowsplit_kernel(int m, int n, int S, int nbx, int passes, int P, int p0,
                           const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                           const double *__restrict__ values,
-                          const int32_t *__restrict__ lo, const int32_t *__restrict__ hi, int accumulate,
+                          const int32_t *__restrict__ cursors, unsigned *__restrict__ done,
                           const real_t *__restrict__ B, size_t ldb,
                           real_t *__restrict__ C, size_t ldc)
 {
@@ -161,13 +210,21 @@ void spmm_rowsplit_kernel(int m, int n, int S,
     constexpr int LS = W + 1;                 // odd LDS row stride (elements)
     __shared__ real_t tile[RS_WAVES * LS];
 
+    PanelWhere at = panel_where(nbx, passes);
+    at.p += p0;                               // (p0 > 0: one launch per panel, the A/B form — then P = 1 here)
+    const int accumulate = at.p > 0;
+    const bool handover = P > 1;              // C goes through agent-scope accesses (the last panel's stores excepted)
+    const int32_t *lo = cursors ? cursors + (size_t)at.p * m : nullptr;
+    const int32_t *hi = cursors ? cursors + (size_t)(at.p + 1) * m : nullptr;
+    unsigned *word = done + (size_t)at.pass * nbx + at.rb;
+
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x / MX_WAVE);
     const int RW = RS_WAVES / S;              // rows per workgroup
-    const int row0 = blockIdx.x * RW;
+    const int row0 = at.rb * RW;
     const int row = row0 + wave / S;
     const int seg = wave % S;
-    const int c0 = blockIdx.y * W;
+    const int c0 = at.pass * W;
     const int lg = lane % G;
     const int col = c0 + lg * VEC;
     const bool active = col < n;
@@ -187,11 +244,14 @@ void spmm_rowsplit_kernel(int m, int n, int S,
             a = min(e, s + seg * L);
             b = min(e, a + L);
         }
-        // the storage-order chain goes on from what the earlier panels left in C
-        if (direct && accumulate && active && lane < G) vload<real_t, VEC>(acc, C + (size_t)row * ldc + col);
         int jv = 0;
         double av = 0.0;
         if (a + lane < b) { jv = indices[a + lane]; av = values[a + lane]; }
+        // the storage-order chain goes on from what the earlier panels left in C
+        if (direct && accumulate) {
+            if (handover) panel_wait(word, at.p);
+            if (active && lane < G) c_load<real_t, VEC>(acc, C + (size_t)row * ldc + col, true);
+        }
         for (int k0 = a; k0 < b; k0 += MX_WAVE) {
             int jn = 0;
             double an = 0.0;                    // the next chunk's (j, a) are in flight while this one streams B
@@ -210,8 +270,10 @@ void spmm_rowsplit_kernel(int m, int n, int S,
         }
     }
 
+    const bool publish = handover && at.p + 1 < P;      // a later panel reads what this one stores
     if (direct) {
-        if (row < m && active && lane < G) vstore<real_t, VEC>(C + (size_t)row * ldc + col, acc);
+        if (row < m && active && lane < G) c_store<real_t, VEC>(C + (size_t)row * ldc + col, acc, publish);
+        if (publish) panel_signal(word);
         return;
     }
     if (lane < G) {
@@ -220,6 +282,7 @@ void spmm_rowsplit_kernel(int m, int n, int S,
         for (int v = 0; v < VEC; v++) t[v] = acc[v];
     }
     __syncthreads();
+    if (accumulate && handover) panel_wait(word, at.p);  // (the gather above ran beside the earlier panel's)
     const int ncols = min(W, n - c0);
     const int total = RW * ncols;
     for (int idx = threadIdx.x; idx < total; idx += RS_WAVES * MX_WAVE) {
@@ -229,10 +292,12 @@ void spmm_rowsplit_kernel(int m, int n, int S,
         if (row0 + r >= m) continue;
         real_t *dst = COLMAJOR ? C + (size_t)(c0 + c) * ldc + row0 + r : C + (size_t)(row0 + r) * ldc + c0 + c;
         real_t sum = tile[(r * S) * LS + c];
-        if (accumulate) sum = *dst + sum;
+        if (accumulate) sum = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + sum;
         for (int q = 1; q < S; q++) sum += tile[(r * S + q) * LS + c];       // segments in order
-        *dst = sum;
+        if (publish) __hip_atomic_store(dst, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = sum;
     }
+    if (publish) panel_signal(word);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -247,10 +312,10 @@ void spmm_rowsplit_kernel(int m, int n, int S,
 // and leave as column segments of that many consecutive rows.
 template <typename real_t, int VEC, int G, bool COLMAJOR>
 __global__ __launch_bounds__(RS_WAVES * MX_WAVE)
-void spmm_rowgroup_kernel(int m, int n,
+void spmm_rowgroup_kernel(int m, int n, int nbx, int passes, int P, int p0,
                           const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                           const double *__restrict__ values,
-                          const int32_t *__restrict__ lo, const int32_t *__restrict__ hi, int accumulate,
+                          const int32_t *__restrict__ cursors, unsigned *__restrict__ done,
                           const real_t *__restrict__ B, size_t ldb,
                           real_t *__restrict__ C, size_t ldc)
 {
@@ -262,12 +327,20 @@ void spmm_rowgroup_kernel(int m, int n,
     constexpr int U = G < 8 ? G : 8;          // B-row reads in flight per lane
     __shared__ real_t tile[COLMAJOR ? RW * LS : 1];
 
+    PanelWhere at = panel_where(nbx, passes);                       // (column panels in one launch: see spmm_rowsplit_kernel)
+    at.p += p0;
+    const int accumulate = at.p > 0;
+    const bool handover = P > 1, publish = handover && at.p + 1 < P;
+    const int32_t *lo = cursors ? cursors + (size_t)at.p * m : nullptr;
+    const int32_t *hi = cursors ? cursors + (size_t)(at.p + 1) * m : nullptr;
+    unsigned *word = done + (size_t)at.pass * nbx + at.rb;
+
     const int lane = lane_id();
     const int wave = uniform(threadIdx.x / MX_WAVE);
     const int g = lane / G, lg = lane % G, gbase = g * G;
-    const int row0 = blockIdx.x * RW;
+    const int row0 = at.rb * RW;
     const int row = row0 + wave * NG + g;
-    const int c0 = blockIdx.y * W;
+    const int c0 = at.pass * W;
     const int col = c0 + lg * VEC;
     const bool active = col < n;
     const unsigned lcol = active ? (unsigned)col : (unsigned)(n - VEC);
@@ -279,7 +352,10 @@ void spmm_rowgroup_kernel(int m, int n,
     if (row < m) {
         s = lo ? lo[row] : indptr[row];
         e = hi ? hi[row] : indptr[row + 1];
-        if (!COLMAJOR && accumulate && active) vload<real_t, VEC>(acc, C + (size_t)row * ldc + col);
+    }
+    if (!COLMAJOR && accumulate) {
+        if (handover) panel_wait(word, at.p);
+        if (row < m && active) c_load<real_t, VEC>(acc, C + (size_t)row * ldc + col, true);
     }
     // the wavefront runs as long as its longest row (wave-uniform trip count, full EXEC for the permutes); a group whose
     // row has ended re-reads row 0 of B (valid memory, in cache) and drops the products by a select
@@ -320,12 +396,13 @@ void spmm_rowgroup_kernel(int m, int n,
     }
 
     if constexpr (!COLMAJOR) {
-        if (row < m && active) vstore<real_t, VEC>(C + (size_t)row * ldc + col, acc);
+        if (row < m && active) c_store<real_t, VEC>(C + (size_t)row * ldc + col, acc, publish);
     } else {
         real_t *tl = tile + (wave * NG + g) * LS + lg * VEC;
 #pragma unroll
         for (int v = 0; v < VEC; v++) tl[v] = acc[v];
         __syncthreads();
+        if (accumulate && handover) panel_wait(word, at.p);
         const int ncols = min(W, n - c0);
         const int total = RW * ncols;
         for (int idx = threadIdx.x; idx < total; idx += RS_WAVES * MX_WAVE) {
@@ -333,10 +410,12 @@ void spmm_rowgroup_kernel(int m, int n,
             if (row0 + r >= m) continue;
             real_t *dst = C + (size_t)(c0 + c) * ldc + row0 + r;
             real_t sum = tile[r * LS + c];
-            if (accumulate) sum = *dst + sum;
-            *dst = sum;
+            if (accumulate) sum = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + sum;
+            if (publish) __hip_atomic_store(dst, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = sum;
         }
     }
+    if (publish) panel_signal(word);
 }
 
 // cursors[p * m + row], p = 0 .. P: where panel p's entries of `row` begin (panel p = columns [p * panel_cols, (p + 1) *
@@ -344,8 +423,9 @@ void spmm_rowgroup_kernel(int m, int n,
 // — then lanes 1 .. P - 1 each find one bound by binary search; otherwise panel 0 takes the whole row.
 __global__ __launch_bounds__(RS_WAVES * MX_WAVE)
 void rowsplit_cursors_kernel(int m, int P, int panel_cols, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                             int32_t *__restrict__ cursors)
+                             int32_t *__restrict__ cursors, unsigned *__restrict__ done, int ndone)
 {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ndone; i += gridDim.x * blockDim.x) done[i] = 0u;
     const int lane = lane_id();
     const int row = blockIdx.x * RS_WAVES + uniform(threadIdx.x / MX_WAVE);
     if (row >= m) return;
@@ -361,23 +441,40 @@ void rowsplit_cursors_kernel(int m, int P, int panel_cols, const int32_t *__rest
     }
 }
 
-// S = 0: the row-group form (several rows per wavefront, G < 64)
+// S = 0: the row-group form (several rows per wavefront, G < 64); the launch runs panels p0 .. p0 + P - 1
 template <typename real_t, int VEC, int G, bool COLMAJOR>
-static void launch_one(int m, int n, int S, dim3 grid, const int32_t *indptr, const int32_t *indices, const double *values,
-                       const int32_t *lo, const int32_t *hi, int accumulate, const real_t *B, size_t ldb, real_t *C, size_t ldc,
+static void launch_one(int m, int n, int S, int nbx, int passes, int P, int p0, const int32_t *indptr, const int32_t *indices,
+                       const double *values, const int32_t *cursors, unsigned *done, const real_t *B, size_t ldb, real_t *C, size_t ldc,
                        hipStream_t stream)
 {
+    const dim3 grid((unsigned)((size_t)nbx * passes * P));
     if constexpr (G < MX_WAVE) {
         if (S == 0) {
             set_last_spmm_kernel("spmm_rowgroup_kernel");            // (named where the form is final: after the alignment fallback)
             hipLaunchKernelGGL((spmm_rowgroup_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
-                               m, n, indptr, indices, values, lo, hi, accumulate, B, ldb, C, ldc);
+                               m, n, nbx, passes, P, p0, indptr, indices, values, cursors, done, B, ldb, C, ldc);
             return;
         }
     }
     set_last_spmm_kernel("spmm_rowsplit_kernel");
     hipLaunchKernelGGL((spmm_rowsplit_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
-                       m, n, S, indptr, indices, values, lo, hi, accumulate, B, ldb, C, ldc);
+                       m, n, S, nbx, passes, P, p0, indptr, indices, values, cursors, done, B, ldb, C, ldc);
+}
+
+// One launch for all the panels, or one per panel (rounds 3-4)?  Measured (tools/rowsplit_fused_probe.py, ms, one launch /
+// P launches): where the sums of a panel go through the LDS tile (column-major C, segments) the wait for the earlier panel
+// comes AFTER the gather and one launch wins everywhere tried (m = 3e3, 6 panels 0.298 / 0.323; m = 1e5, 4 panels 1.662 /
+// 1.711; m = 1e6 row groups 1.008 / 1.029).  The storage-order chain of row-major C must START from C's value: poll, then
+// the read of C, then the gather — two serial round trips per workgroup, and C through 4- / 8-byte agent-scope accesses.
+// That still wins while a panel is a few rounds of the machine and the launch gaps count (m = 1e4: 3 panels 0.196 / 0.200,
+// 15 panels 0.313 / 0.366) and loses when a panel is many rounds of small workgroups (m = 1e5: 0.628 / 0.555, f32 n = 256
+// 2.09 / 1.53; m = 1e6 row groups 1.16 / 1.03): there one launch per panel stays.
+// MXGPU_ROWSPLIT_LAUNCHES=1 / =0 forces one launch per panel / one launch (the A/B and the tests of both forms).
+static bool rowsplit_one_launch_per_panel(bool through_tile, long long workgroups_per_panel)
+{
+    const char *e = getenv("MXGPU_ROWSPLIT_LAUNCHES");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return !through_tile && workgroups_per_panel > 4096;
 }
 
 template <typename real_t, int VEC, int G, bool COLMAJOR>
@@ -386,25 +483,32 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
 {
     constexpr int W = G * VEC;
     if (S == 0 && G == MX_WAVE) S = 1;                      // rows of B that fill the wavefront: one row per wavefront anyway
-    dim3 grid((unsigned)ceil_div(m, S == 0 ? RS_WAVES * (MX_WAVE / G) : RS_WAVES / S), (unsigned)ceil_div(n, W));
+    const int nbx = (int)ceil_div(m, S == 0 ? RS_WAVES * (MX_WAVE / G) : RS_WAVES / S), passes = (int)ceil_div(n, W);
+    if ((long long)nbx * passes * P >= (1LL << 31)) return set_error("rowsplit_spmm: %d x %d x %d workgroups exceed the grid", nbx, passes, P);
     if (P <= 1) {
         kt_begin(stream);
-        launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, grid, indptr, indices, values, nullptr, nullptr, 0, B, ldb, C, ldc, stream);
+        launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, nbx, passes, 1, 0, indptr, indices, values, nullptr, nullptr, B, ldb, C, ldc, stream);
         kt_end(stream);
         MX_LAUNCH_CHECK();
         return 0;
     }
     // grow-only per-thread scratch; a caller that comes back on another stream waits for the previous product (scratch_acquire)
-    int32_t *cur = (int32_t *)scratch_buffer(MX_SCRATCH_ROWSPLIT, (size_t)(P + 1) * (size_t)m * sizeof(int32_t));
-    if (!cur) return set_error("rowsplit_spmm: cannot allocate %zu bytes of panel cursors", (size_t)(P + 1) * (size_t)m * sizeof(int32_t));
+    const size_t cur_bytes = ((size_t)(P + 1) * (size_t)m * sizeof(int32_t) + 255) & ~(size_t)255;
+    const int ndone = nbx * passes;
+    int32_t *cur = (int32_t *)scratch_buffer(MX_SCRATCH_ROWSPLIT, cur_bytes + (size_t)ndone * sizeof(unsigned));
+    if (!cur) return set_error("rowsplit_spmm: cannot allocate %zu bytes of panel cursors", cur_bytes + (size_t)ndone * sizeof(unsigned));
+    unsigned *done = (unsigned *)((char *)cur + cur_bytes);
     scratch_acquire(MX_SCRATCH_ROWSPLIT, stream);
     const int panel_cols = (int)ceil_div(K, P);
     kt_begin(stream);
     hipLaunchKernelGGL(rowsplit_cursors_kernel, dim3((unsigned)ceil_div(m, RS_WAVES)), dim3(RS_WAVES * MX_WAVE), 0, stream,
-                       m, P, panel_cols, indptr, indices, cur);
-    for (int p = 0; p < P; p++)
-        launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, grid, indptr, indices, values, cur + (size_t)p * m, cur + (size_t)(p + 1) * m,
-                                             p > 0 ? 1 : 0, B, ldb, C, ldc, stream);
+                       m, P, panel_cols, indptr, indices, cur, done, ndone);
+    if (rowsplit_one_launch_per_panel(COLMAJOR || S > 1, (long long)nbx * passes)) {
+        for (int p = 0; p < P; p++)
+            launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, nbx, passes, 1, p, indptr, indices, values, cur, done, B, ldb, C, ldc, stream);
+    } else {
+        launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, nbx, passes, P, 0, indptr, indices, values, cur, done, B, ldb, C, ldc, stream);
+    }
     scratch_done(MX_SCRATCH_ROWSPLIT, stream);
     kt_end(stream);
     MX_LAUNCH_CHECK();

@@ -91,6 +91,36 @@ def test_rowsplit_column_panels_with_unsorted_and_duplicate_columns(gpu):
     np.testing.assert_array_equal(_run(p, j, x, B, False, 1, 4), _oracle(p, j, x, B, True))
 
 
+@pytest.mark.parametrize("launches", ["0", "1"])
+@pytest.mark.parametrize("S,colmajor,dtype", [(1, False, np.float64), (1, True, np.float64), (2, False, np.float64), (0, False, np.float64),
+                                              (0, True, np.float64), (1, False, np.float32)])
+def test_column_panels_in_one_launch_and_in_one_launch_per_panel(gpu, monkeypatch, S, colmajor, dtype, launches):
+    """Both forms of the panels (spmm_rowsplit.hip: one panel-major launch whose workgroups hand C over with agent-scope
+    accesses and a counter per row block; one launch per panel), forced by MXGPU_ROWSPLIT_LAUNCHES, on a grid of several
+    rounds of the machine (20,000 rows = 2,500 .. 5,000 workgroups per panel, 5 panels, 2 passes): the same bits from both,
+    the storage-order FMA chain for row-major C with one segment per row, and the same bits again on every repeat."""
+    m, K, n = 20_000, 4_000, 160 if dtype == np.float64 else 320
+    if S == 0:
+        n = 16
+    p, j, x = synth.csr_fixed(m, K, 24 if S == 0 else 96, seed=5)
+    rng = np.random.default_rng(3)
+    B = rng.normal(size=(K, n)).astype(dtype)
+    monkeypatch.setenv("MXGPU_ROWSPLIT_LAUNCHES", launches)
+    got = _run(p, j, x, B, colmajor, -1 if S == 0 else S, P=5)
+    chain = (S in (0, 1)) and not colmajor
+    want = _oracle(p, j, x, B.astype(np.float64) if dtype == np.float64 else B, True)
+    if dtype == np.float32:
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    elif chain:                                    # one wavefront (n = 160) / one lane group (row groups) sums a row in storage order
+        assert np.array_equal(got, want)
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    for _ in range(3):
+        assert np.array_equal(_run(p, j, x, B, colmajor, -1 if S == 0 else S, P=5), got)
+    monkeypatch.setenv("MXGPU_ROWSPLIT_LAUNCHES", "1" if launches == "0" else "0")
+    assert np.array_equal(_run(p, j, x, B, colmajor, -1 if S == 0 else S, P=5), got)
+
+
 @pytest.mark.parametrize("S", [1, 4])
 @pytest.mark.parametrize("colmajor", [False, True])
 @pytest.mark.parametrize("m,K,n,dens", SHAPES[:8])

@@ -47,8 +47,10 @@ def same_list(g, o, what):
 def footprint():
     """(live device blocks of the library's pool, live bytes, idle bytes, device bytes in use on the GPU, host RSS): what a
     leak in the exports' begin / finish / error paths would move"""
-    import ctypes, psutil, torch
+    import ctypes, gc, psutil, torch
     lib = _lib.load()
+    gc.collect()
+    ctypes.CDLL(None).malloc_trim(0)                   # freed heap back to the system: RSS then counts what is HELD
     assert lib.mx_cache_invalidate(None) == 0          # the CSR cache holds device copies by design (cap: MXGPU_CSR_CACHE_MB)
     out = []
     for name in (b"pool_live_blocks", b"pool_live_bytes", b"pool_idle_bytes"):
@@ -65,7 +67,9 @@ base = None
 SKIP = set(filter(None, os.environ.get("FUZZ_SKIP", "").split(",")))     # gatherfused, sortedview, spmvplan, naroute (bisecting)
 t_end = time.time() + budget
 cases = 0
-while time.time() < t_end:
+
+def one_case(cases):
+    """one random case; its operands and results die with the frame, so the footprint below sees the library and not them"""
     m = int(rng.choice([1, 3, 64, 65, 200, 1000, 4000]))
     K = int(rng.choice([1, 2, 9, 70, 400, 3000]))
     d1, d2 = float(rng.choice([0.0, 0.02, 0.2, 0.7])), float(rng.choice([0.0, 0.05, 0.3, 0.9]))
@@ -224,6 +228,10 @@ while time.time() < t_end:
     except Exception as exc:
         print("FAIL", dict(m=m, K=K, d1=d1, d2=d2, s1=s1, s2=s2, seed=seed, case=cases, what=what), repr(exc)[:600])
         sys.exit(1)
+
+
+while time.time() < t_end:
+    one_case(cases)
     cases += 1
     if cases == BASE_AT:
         base = footprint()

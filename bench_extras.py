@@ -382,6 +382,40 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
 
     section("spmm_zipf", _spmm_zipf)
 
+    # ---- configs[4]'s per-GPU shard (1M x 200k, 64 per row, f32, n = 256) with log-normal row lengths: the f32 sweep's folds
+    # (spmm_plan.hip plan_flag_kernel; this shape took 22 ms before round 5's flag rule, equal rows take 3.6)
+    def _cfg5_shard_skewed():
+        m5, K5, n5 = 1_000_000, 200_000, 256
+        p5, j5, x5 = synth.device_csr_zipf(m5, K5, 64, alpha=0.0, sigma=1.0, seed=synth.SEED_A)
+        A5 = D.DeviceCSR(p5, j5, x5, m5, K5, int(j5.numel()))
+        g = torch.Generator(device="cuda"); g.manual_seed(5)
+        B5 = torch.randn((K5, n5), dtype=torch.float32, device="cuda", generator=g)
+        C5 = torch.empty((n5, m5), dtype=torch.float32, device="cuda")
+        D.spmm(A5, B5, out=C5, colmajor=True)
+        kname = lib.mxd_spmm_last_kernel().decode()
+        rows_chk = 1024
+        ph = p5[:rows_chk + 1].cpu().numpy()
+        e = int(ph[-1])
+        Bh = B5.cpu().numpy()
+        ref = np.zeros(rows_chk * n5, dtype=np.float32)
+        O.gemm_csr_drm_as_drm(rows_chk, n5, ph.astype(np.int32), j5[:e].cpu().numpy(), x5[:e].cpu().numpy(), Bh.reshape(-1), n5, ref, n5,
+                              threads, True)
+        got = C5[:, :rows_chk].t().cpu().numpy()
+        err = float(np.max(np.abs(got - ref.reshape(rows_chk, n5))) / np.max(np.abs(ref)))
+        assert err <= 1e-5, f"skewed cfg5 shard differs from the oracle: {err}"
+        t = timeit(lambda: D.spmm(A5, B5, out=C5, colmajor=True), reps=8)
+        byts = synth.spmm_algorithmic_bytes(m5, K5, n5, A5.nnz, 4)
+        res["cfg5_shard_skewed"] = {
+            "ms": round(t * 1e3, 4), "GFLOP/s": round(2.0 * A5.nnz * n5 / t / 1e9, 1), "kernel": kname, "nnz": A5.nnz, "dtype": "f32",
+            "plan": A5.plan_info() if A5._plan is not None and A5._plan_ready else None,
+            "roofline": roofline(byts, t, scope="whole call (repack of B + sweep)"),
+            "parity_max_err_over_max_abs_vs_oracle": err,
+            "note": "configs[4]'s per-GPU shard shape, row lengths log-normal (sigma 1, mean 64), f32: dealt octets, plain LDS "
+                    "read-modify-write folds except where two lane groups can fold one row in one step; plan kept"}
+        del A5, B5, C5, p5, j5, x5
+
+    section("cfg5_shard_skewed", _cfg5_shard_skewed)
+
     # ---- the one workload the reference publishes a number for (vignette Rmd:247-251): dense 100 x 1e4 %*% CSC 1e4 x 1e4,
     # density 0.05 -> matmul_dense_csc_numeric (matmul.cpp:188-235: gemm_csr_drm_as_drm with the CSC read as CSR of its transpose)
     def _vignette_dense_csc():

@@ -258,13 +258,16 @@ int mxd_spmm_csr_dense_ex2(int m, int n, int K, int64_t nnz,
  * mxd_spmm_plan_create: *plan = NULL creates, a previous plan re-uses its buffers (grow-only); one internal
  * stream sync (the padded size comes back to the host).  npanels <= 0 picks K*128 B / 2.5 MB.
  * mxd_spmm_plan_run: sync_mode 0 = free running, 1 = the waves of a CU's workgroup meet at every panel boundary,
- * 2 = 1 + one timing barrier per generation among the workgroups of an XCD group; -1 = default (1).
+ * 2 = 1 + one timing barrier per generation among the workgroups of an XCD group; -1 = default: 1 for rows of even
+ * length, 2 once the lengths of the plan's 64-row octets vary by more than 10 % (mxd_spmm_plan_octet_cv: their
+ * coefficient of variation, measured by the build).
  * Needs 16-B aligned rows of B; wg_per_cu is ignored (one 1024-thread workgroup per CU). */
 typedef struct mx_spmm_plan mx_spmm_plan;
 int mxd_spmm_plan_create(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values,
                          int npanels, void *stream, mx_spmm_plan **plan);
 int mxd_spmm_plan_destroy(mx_spmm_plan *plan);
 int mxd_spmm_plan_info(const mx_spmm_plan *plan, int *npanels, int64_t *padded_entries);
+int mxd_spmm_plan_octet_cv(const mx_spmm_plan *plan, double *cv);
 int mxd_spmm_plan_run(const mx_spmm_plan *plan, int n, const void *B, size_t ldb, void *C, size_t ldc,
                       int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream);
 /* rows [row0, row0 + nrows) of the planned matrix only (row0 a multiple of 64); C points at the block's first row, ldc is the

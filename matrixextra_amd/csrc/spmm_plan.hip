@@ -231,7 +231,9 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
     const unsigned long long below = (1ULL << lane) - 1ULL;
     const float inv_pc = 1.0f / (float)panel_cols;
     const int nbits = 32 - __builtin_clz((unsigned)(npanels > 1 ? npanels - 1 : 1));    // bits of a panel id
-    const int shared_bit = dealt ? 64 : 0;                           // tag = slot | shared << 6  (bit 31 of the entry)
+    // tag = slot | shared << 6 (bit 31 of the entry).  Dealt octets: set afterwards, by plan_flag_kernel, on the LAST row
+    // segment of every piece only (the padding entries below carry it from the start)
+    const int shared_bit = 0;
     int colv[PLAN_LD];
     double av[PLAN_LD];
     auto load_pass = [&](int k0) {                                   // all loads of a pass in flight together
@@ -360,6 +362,57 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
     }
 }
 
+// Dealt octets, after the fill: which folds have to be atomic?  (Round 5: `shared` used to be set on every entry of a dealt
+// octet, and the f32 sweep — whose LDS float atomics run at about one LANE per clock; ds_add_f64 does not have that
+// problem — took 22 ms on the cfg5 shard with log-normal rows where equal rows take 3.6.  Flagging the last row segment of
+// every piece: 6.1 ms; the rule below: 4.2.)
+// The 8 lane groups of the sweeping wavefront run in lockstep and a panel starts at the same step in all 8 streams, so at
+// any step all groups are inside the same panel, where a row's entries form one run of ranks cut at the piece boundaries.
+// A group folds a row segment when it meets the next row:
+//   * a segment that is not the last of its piece is folded INSIDE the panel (at a step >= 1 of it); a (row, panel) has at
+//     most one such segment (the run's pieces in between are whole pieces, i.e. last segments), so two of these folds
+//     never meet in one row;
+//   * the last segment of a piece is folded at step 0 of the next panel — by all 8 groups at once, and only they fold at
+//     that step; two of them meet in one row exactly when two pieces of the panel END with the same row (the later one
+//     is then that row from start to end).  Rows are contiguous, so it is enough to compare with the neighbouring pieces;
+//   * the last piece of a panel may end in padding holes (tag = pad, flagged by the fill): its last segment is then
+//     folded at the first hole, inside the panel — it is the panel's last row, which has no non-last segment elsewhere.
+// Only the second case needs an atomic fold.  An atomic fold and a plain read-modify-write of the same row in the same
+// step are separate LDS instructions of one wavefront, which execute in order.  (A segment that continues with the same
+// row in the next panel is not folded at the boundary at all: it becomes part of the next panel's segment.)
+// One lane per (panel, stream) compares and, if need be, walks its piece backwards from its last entry.
+__global__ __launch_bounds__(512)
+void plan_flag_kernel(int noct, int npanels, const int32_t *__restrict__ oct_off, const int32_t *__restrict__ bpo,
+                      const int32_t *__restrict__ pstart, const unsigned char *__restrict__ layout, int32_t *__restrict__ pcol,
+                      long long cap_slots, const long long *__restrict__ total_steps)
+{
+    if (!plan_fits(*total_steps, cap_slots)) return;                 // the fill wrote nothing either
+    const int oct = blockIdx.x * 8 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (oct >= noct || layout[oct] != 1) return;
+    const long long base = oct_off[oct];
+    for (int idx = lane; idx < 8 * npanels; idx += 64) {
+        const int p = idx >> 3, g = idx & 7;
+        const int T = bpo[((size_t)oct * 9 + 8) * npanels + p], L = (T + 7) >> 3, S = pstart[(size_t)oct * (npanels + 1) + p];
+        // slot (row position in the octet) of the last entry of stream gg's piece, -1 for an empty piece
+        auto last_slot = [&](int gg) -> int {
+            if (gg < 0 || gg > 7) return -1;
+            const int first = gg * L, last = min(first + L, T) - 1;  // ranks of the piece's entries in the panel
+            if (last < first) return -1;
+            const int t = S + last - first;
+            return (pcol[(base + (t & ~7)) * 8 + gg * 8 + (t & 7)] >> PLAN_ROW_SHIFT) & 63;
+        };
+        const int tag = last_slot(g);
+        if (tag < 0 || (tag != last_slot(g - 1) && tag != last_slot(g + 1))) continue;
+        const int first = g * L, last = min(first + L, T) - 1;
+        for (int t = S + last - first; t >= S; t--) {
+            const long long at = (base + (t & ~7)) * 8 + g * 8 + (t & 7);
+            const int c = pcol[at];
+            if (((c >> PLAN_ROW_SHIFT) & 63) != tag) break;
+            pcol[at] = c | (int)0x80000000u;
+        }
+    }
+}
+
 // The order in which the sweep takes the octets (round 3).  A generation = the 16 octets one workgroup sweeps together, and
 // its wavefronts meet at every panel boundary: a generation lasts as long as its LONGEST octet.  With rows of very uneven
 // length (log-normal, sigma 1: octets of 64 rows differ by +-16 % in entries) the 16 neighbours of a generation differed by
@@ -368,6 +421,7 @@ void plan_fill_kernel(int m, int npanels, int panel_cols, const int32_t *__restr
 // generations start first; position t of the schedule is swept by wavefront t % 16 of generation t / 16.  Equal lengths
 // (the headline matrix) keep the natural order.  Which octet a wavefront sweeps changes no bit of the result.
 constexpr int PLAN_SCHED_BINS = 4096;
+constexpr double PLAN_SYNC2_CV = 0.10;             // octet lengths more uneven than this: sync mode 2 by default
 __global__ __launch_bounds__(1024)
 void plan_sched_kernel(int noct, const int32_t *__restrict__ steps, int32_t *__restrict__ sched, long long *__restrict__ reordered)
 {
@@ -377,13 +431,25 @@ void plan_sched_kernel(int noct, const int32_t *__restrict__ steps, int32_t *__r
     if (tid == 0) { smin = INT_MAX; smax = 0; }
     for (int b = tid; b < PLAN_SCHED_BINS; b += 1024) bins[b] = 0;
     __syncthreads();
+    __shared__ double ssum, ssq;
+    if (tid == 0) { ssum = 0.0; ssq = 0.0; }
+    __syncthreads();
     int lo = INT_MAX, hi = 0;
-    for (int o = tid; o < noct; o += 1024) { const int v = steps[o]; lo = min(lo, v); hi = max(hi, v); }
+    double sum1 = 0.0, sum2 = 0.0;
+    for (int o = tid; o < noct; o += 1024) { const int v = steps[o]; lo = min(lo, v); hi = max(hi, v); sum1 += v; sum2 += (double)v * v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { sum1 += __shfl_xor(sum1, off, 64); sum2 += __shfl_xor(sum2, off, 64); }
     atomicMin(&smin, lo);
     atomicMax(&smax, hi);
+    if ((tid & 63) == 0) { atomicAdd(&ssum, sum1); atomicAdd(&ssq, sum2); }
     __syncthreads();
     const int vmin = smin, vmax = smax;
-    if (tid == 0) *reordered = vmax > vmin ? 1 : 0;                  // rides back to the host with the plan's size
+    // rides back to the host with the plan's size: 0 = octets of equal length, else 1 + 1000 x the coefficient of variation
+    // of the octets' lengths (what the sweep's default sync mode is chosen from, mxd_spmm_plan_run_rows)
+    if (tid == 0) {
+        const double mean = ssum / noct, var = fmax(ssq / noct - mean * mean, 0.0);
+        *reordered = vmax > vmin ? 1 + (long long)(1000.0 * sqrt(var) / fmax(mean, 1.0)) : 0;
+    }
     if (vmax <= vmin) {                                              // all octets equally long: natural order
         for (int o = tid; o < noct; o += 1024) sched[o] = o;
         return;
@@ -665,11 +731,10 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
                 for (int v = 0; v < VEC; v++) b[u][v] = 0;
             }
             // consume step u of the batch in (pc, pv, b): row switch -> fold the finished row into LDS, then FMA
-            bool oct_shared = false;                                // set once the first chunk is in
             auto consume = [&](int u) {
-                const int tag = pc[u] >> PLAN_ROW_SHIFT;              // slot of the row (0..63), -64 if the row is shared
+                const int tag = pc[u] >> PLAN_ROW_SHIFT;              // slot of the row (0..63), - 64 if this fold may meet another group's (plan_flag_kernel)
                 if (tag != cur) {
-                    lds_fold<VEC>(my_rows + (cur & 63) * S, acc, oct_shared);
+                    lds_fold<VEC>(my_rows + (cur & 63) * S, acc, SHARED && cur < 0);
 #pragma unroll
                     for (int v = 0; v < VEC; v++) acc[v] = 0;
                     cur = tag;
@@ -688,9 +753,6 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
 #pragma unroll
                 for (int k = 0; k < PLAN_CHUNK; k++) asm volatile("" : "+v"(rc[k]), "+v"(rv[k]));
             }
-            // dealt layout: every entry of the octet (padding included) carries the `shared` bit — rows may be folded by
-            // several lane groups, so the f32 fold must be atomic for this octet (wave-uniform choice)
-            if constexpr (SHARED) oct_shared = send > sbeg && __builtin_amdgcn_readfirstlane(rc[0]) < 0;
             // Consumption lags one batch behind the broadcast + B-line load: while batch t is consumed step by step,
             // the line of the same step of batch t+1 is requested into the registers the FMA just released, so 8
             // B-line loads per wavefront are in flight all the time.  The first pass consumes the no-op batch set up
@@ -739,7 +801,7 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
             }
 #pragma unroll
             for (int u = 0; u < U; u++) consume(u);
-            lds_fold<VEC>(my_rows + (cur & 63) * S, acc, oct_shared);
+            lds_fold<VEC>(my_rows + (cur & 63) * S, acc, SHARED && cur < 0);
             if (sync_mode > 0)
                 for (; p < npanels - 1; p++) __syncthreads();           // every wave meets npanels-1 times per generation
         }
@@ -786,6 +848,7 @@ struct mx_spmm_plan {
     int32_t *pstart = nullptr;     size_t pstart_cap = 0;     // [noct][P + 1]: relative panel starts, unpadded length
     int32_t *sched = nullptr;      size_t sched_cap = 0;      // [noct]: the order the sweep takes the octets in
     bool reordered = false;                                    // sched is not the identity (octets of unequal length)
+    double oct_cv = 0.0;                                       // coefficient of variation of the octets' lengths (steps)
     long long *rbdev = nullptr;                                // [total steps][nnz][dealt octets], read back in one copy
     long long ndealt = 0;                                      // octets in the dealt layout (rows shared by lane groups)
     void *scratch = nullptr;     size_t scratch_cap = 0;       // rowpre + steps + scan workspace (build only)
@@ -890,6 +953,8 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
         hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
                            values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->layout, pl->pstart,
                            rb_dev + 2, (long long)cap_slots, rb_dev);
+        hipLaunchKernelGGL(plan_flag_kernel, dim3((unsigned)ceil_div(pl->noct, 8)), dim3(512), 0, st, pl->noct, npanels, oct_off, bpo,
+                           pl->pstart, pl->layout, pl->pcol, (long long)cap_slots, rb_dev);
         hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)ceil_div((long long)nop + 1, 256)), dim3(256), 0, st, pl->noct,
                            npanels, oct_off, pl->pstart, pl->step_off, (long long)cap_slots, rb_dev, pl->sched);
         MX_LAUNCH_CHECK();
@@ -899,6 +964,7 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     pl->nnz = (int32_t)rb->host[1];
     pl->ndealt = rb->host[2];
     pl->reordered = rb->host[3] != 0;
+    pl->oct_cv = rb->host[3] > 0 ? (double)(rb->host[3] - 1) * 1e-3 : 0.0;
     MX_REQUIRE(total >= 0 && total * 8 <= (long long)INT_MAX * 4LL, "spmm plan: too many steps (%lld)", total);
     MX_REQUIRE(total <= (long long)INT_MAX, "spmm plan: step offsets exceed int32");
     pl->total_steps = total;
@@ -913,6 +979,8 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
         hipLaunchKernelGGL(plan_fill_kernel, dim3(blocks), dim3(512), 0, st, m, npanels, pl->panel_cols, indptr, indices,
                            values, oct_off, bpo, pl->pcol, pl->pval, pl->noct, K, pl->step_off, pl->layout, pl->pstart,
                            rb_dev + 2, (long long)slots, rb_dev);
+        hipLaunchKernelGGL(plan_flag_kernel, dim3((unsigned)ceil_div(pl->noct, 8)), dim3(512), 0, st, pl->noct, npanels, oct_off, bpo,
+                           pl->pstart, pl->layout, pl->pcol, (long long)slots, rb_dev);
         hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)ceil_div((long long)nop + 1, 256)), dim3(256), 0, st, pl->noct,
                            npanels, oct_off, pl->pstart, pl->step_off, (long long)slots, rb_dev, pl->sched);
         MX_LAUNCH_CHECK();
@@ -1050,6 +1118,13 @@ extern "C" int mxd_spmm_plan_info(const mx_spmm_plan *pl, int *npanels, int64_t 
     return 0;
 }
 
+extern "C" int mxd_spmm_plan_octet_cv(const mx_spmm_plan *pl, double *cv)
+{
+    MX_REQUIRE(pl && cv, "mxd_spmm_plan_octet_cv: null argument");
+    *cv = pl->oct_cv;
+    return 0;
+}
+
 extern "C" int mxd_spmm_plan_run(const mx_spmm_plan *pl, int n, const void *B, size_t ldb, void *C, size_t ldc,
                                  int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream)
 {
@@ -1068,7 +1143,10 @@ extern "C" int mxd_spmm_plan_run_rows(const mx_spmm_plan *pl, int row0, int nrow
     if (nrows == 0 || n == 0) return 0;
     MX_REQUIRE(B && C, "mxd_spmm_plan_run: null pointer");
     hipStream_t st = mx::as_stream(stream);
-    if (sync_mode < 0) sync_mode = 1;       // panel meetings inside the CU's workgroup; 2 adds one XCD barrier per generation
+    // 1: panel meetings inside the CU's workgroup; 2 adds one XCD-wide timing barrier per generation — which costs 3 % on
+    // octets of equal length (cfg2: 1.74 -> 1.80 ms) and pays once the generations differ in length and the workgroups of an
+    // XCD drift into different panels (log-normal rows, sigma 1 = octets +-16 %: 2.24 -> 1.94 ms; tools/skew_probe.py)
+    if (sync_mode < 0) sync_mode = pl->oct_cv > mx::PLAN_SYNC2_CV ? 2 : 1;
     mx::set_last_spmm_kernel("spmm_plan_kernel");
     if (dense_dtype == MX_F64) {
         MX_REQUIRE(mx::slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor_out),

@@ -94,7 +94,9 @@ class DeviceCSR:
         lib = _lib.load()
         P, padded = C.c_int(0), C.c_int64(0)
         check(lib.mxd_spmm_plan_info(self._plan, C.byref(P), C.byref(padded)))
-        return dict(npanels=P.value, padded_entries=padded.value)
+        cv = C.c_double(0.0)
+        check(lib.mxd_spmm_plan_octet_cv(self._plan, C.byref(cv)))
+        return dict(npanels=P.value, padded_entries=padded.value, octet_length_cv=round(cv.value, 4))
 
     def spmv_plan(self):
         """Planned-SpMV plan (mxd_spmv_plan_create): built on first use, cached on the DeviceCSR."""

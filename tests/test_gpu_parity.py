@@ -602,6 +602,37 @@ def test_spmm_planned_balanced_bundles(gpu, dtype, colmajor):
             np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * 50)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("colmajor", [True, False])
+def test_spmm_planned_dealt_layout_loses_no_update(gpu, dtype, colmajor):
+    """The dealt layout's folds are plain LDS read-modify-writes in the f32 sweep except where two lane groups can fold the
+    same row in the same step (plan_flag_kernel, spmm_plan.hip).  Small-integer operands make every sum exact in f32
+    whatever the order, so a single lost update is a wrong integer: heavy-tailed rows (rows that span several pieces,
+    whole pieces and whole panels of an octet), sorted and unsorted columns, 1 / 4 / 9 / 16 panels."""
+    from devmem import spmm_planned_device
+    rng = np.random.default_rng(2025)
+    m, K, n = 64 * 120 + 17, 4000, 64
+    lens = np.minimum(np.floor(rng.lognormal(2.5, 1.5, size=m)).astype(np.int64), 3500)
+    lens[rng.random(m) < 0.05] = 0
+    lens[[5, 64 * 7 + 63, 64 * 50, m - 1]] = [3000, 2500, 3999, 1200]
+    p = np.zeros(m + 1, dtype=np.int32); p[1:] = np.cumsum(lens)
+    nnz = int(p[-1])
+    B = rng.integers(-3, 4, size=(K, n)).astype(dtype)
+    x = rng.integers(-2, 3, size=nnz).astype(np.float64)
+    for sort_rows in (True, False):
+        j = rng.integers(0, K, size=nnz, dtype=np.int32)
+        if sort_rows:
+            for r in range(m):
+                j[p[r]:p[r + 1]].sort()
+        ref = np.zeros((m, n), dtype=np.int64)
+        np.add.at(ref, np.repeat(np.arange(m), lens), x[:, None].astype(np.int64) * B[j].astype(np.int64))
+        assert np.abs(ref).max() < 2 ** 23
+        for npanels in (1, 4, 9, 16):
+            for rep in range(2):
+                got = spmm_planned_device(p, j, x, B, colmajor, npanels=npanels)
+                assert np.array_equal(got.astype(np.int64), ref) and np.array_equal(got, got.astype(np.int64)), (sort_rows, npanels, rep)
+
+
 def test_spmm_plan_limits_and_errors(gpu):
     """The planned kernel addresses a slab with 32-bit byte offsets: K >= 2^25 columns is refused with a message (AUTO
     never picks it there), a plan that was only sized cannot be run, and errors do not poison later calls."""

@@ -52,8 +52,9 @@ while time.time() < t_end:
             j[hit] = (j[hit] % max(1, a)).astype(np.int32)
     else:
         j = rng.integers(0, K, size=nnz, dtype=np.int32)
-    x = rng.uniform(-1, 1, size=nnz).round(3)
-    B = rng.normal(size=(K, n)).round(3).astype(dtype)
+    exact = rng.random() < 0.3                          # small integers: every sum is exact in f32 and f64, a lost update is a wrong integer
+    x = rng.integers(-2, 3, size=nnz).astype(np.float64) if exact else rng.uniform(-1, 1, size=nnz).round(3)
+    B = (rng.integers(-3, 4, size=(K, n)) if exact else rng.normal(size=(K, n)).round(3)).astype(dtype)
     ref = np.zeros((m, n))
     if nnz:
         np.add.at(ref, np.repeat(np.arange(m), lens), x[:, None] * B[j].astype(np.float64))
@@ -73,7 +74,7 @@ while time.time() < t_end:
         elif which == "rowsplit":                                     # segments x column panels, any operands (odd n: the scalar path)
             if rng.random() < 0.3:
                 n_odd = int(rng.choice([1, 3, 7, 33, 101]))
-                B = rng.normal(size=(K, n_odd)).round(3).astype(dtype)
+                B = (rng.integers(-3, 4, size=(K, n_odd)) if exact else rng.normal(size=(K, n_odd)).round(3)).astype(dtype)
                 ref = np.zeros((m, n_odd))
                 if nnz:
                     np.add.at(ref, np.repeat(np.arange(m), lens), x[:, None] * B[j].astype(np.float64))
@@ -84,9 +85,12 @@ while time.time() < t_end:
                               wg_per_cu=int(rng.choice([0, 0, 1 + 4 * 1, 1 + 4 * 5, 2 + 4 * 3, 1 + 4 * 2 + 32, 2 + 4 * 2 + 32])))
         else:
             got = spmm_device(p.astype(np.int32), j, x, B, colmajor, 0 if which == "auto" else 1, 0)
-        np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * 100)
+        if exact:
+            assert np.array_equal(got, ref), "exact (small-integer) case differs"
+        else:
+            np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * 100)
     except Exception as exc:
-        print("FAIL", dict(m=m, K=K, n=n, dtype=dtype.__name__, kind=kind, cols=str(cols), nnz=nnz, colmajor=colmajor, which=which,
+        print("FAIL", dict(exact=exact, m=m, K=K, n=n, dtype=dtype.__name__, kind=kind, cols=str(cols), nnz=nnz, colmajor=colmajor, which=which,
                            npanels=npanels, seed=seed, case=cases), repr(exc)[:500])
         sys.exit(1)
     cases += 1

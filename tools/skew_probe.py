@@ -1,38 +1,50 @@
-#!/usr/bin/env python3
-"""How the SpMM kernels behave on log-normal row lengths (run on the GPU box): python tools/skew_probe.py"""
-import sys, time
-sys.path.insert(0, ".")
-import numpy as np, torch
-from matrixextra_amd import _lib, device as D, synth
+"""The planned sweep on rows of uneven length: sync mode 1 (the wavefronts of a CU meet at the panel boundaries) against 2
+(+ one XCD-wide timing barrier per generation) and the default (-1: chosen from the coefficient of variation of the
+plan's octet lengths).  cfg2's shape (f64, n = 128, C column-major) with log-normal row lengths of growing sigma, the
+Zipf-column variant, and the cfg5 shard shape (f32, n = 256)."""
+import sys, os
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from matrixextra_amd import device as D, synth  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from auto_map import timeit  # noqa: E402
 
-lib = _lib.load()
-m, K, n = 400_000, 100_000, 128
-B = torch.from_numpy(synth.dense_normal(K, n)).cuda()
-for sigma in (0.0, 0.5, 1.0, 1.5):
-    if sigma == 0.0:
-        p, j, x = synth.csr_fixed(m, K, 32)
-    else:
-        rng = np.random.default_rng(1)
-        mu = np.log(32) - 0.5 * sigma * sigma
-        lens = np.minimum(np.floor(rng.lognormal(mu, sigma, size=m)).astype(np.int64), 4000)
-        p = np.zeros(m + 1, dtype=np.int64); np.cumsum(lens, out=p[1:])
-        j = rng.integers(0, K, size=p[-1], dtype=np.int32)          # unsorted, duplicates possible: fine for SpMM
-        x = rng.uniform(-1, 1, size=p[-1]); p = p.astype(np.int32)
-    A = D.DeviceCSR.from_host(p, j, x, K)
-    C = torch.empty((n, m), dtype=torch.float64, device="cuda")
-    res = {}
-    for name, fn in (("auto", lambda: D.spmm(A, B, out=C, colmajor=True, algo=0)),
-                     ("rowwave", lambda: D.spmm(A, B, out=C, colmajor=True, algo=1)),
-                     ("planned(cached)", lambda: D.spmm_planned(A, B, out=C, colmajor=True)),
-                     ("planned(cached, XCD barrier)", lambda: D.spmm_planned(A, B, out=C, colmajor=True, sync_mode=2))):
-        fn(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            fn()
-        torch.cuda.synchronize()
-        res[name] = (time.perf_counter() - t0) / 5 * 1e3
-        if name == "auto":
-            res["auto_kernel"] = lib.mxd_spmm_last_kernel().decode()
-    info = A.plan_info()
-    print(f"sigma {sigma}: nnz {A.nnz}, plan slots/nnz {info['padded_entries'] / max(A.nnz, 1):.2f}, "
-          + ", ".join(f"{k} {v if isinstance(v, str) else round(v, 3)}" for k, v in res.items()), flush=True)
+
+def run(tag, A, K, n, dt):
+    B = torch.randn((K, n), dtype=dt, device="cuda")
+    out = torch.empty((n, A.m), dtype=dt, device="cuda")
+    row = []
+    for sm in (-1, 1, 2):
+        f = lambda: D.spmm_planned(A, B, out=out, colmajor=True, sync_mode=sm)
+        f()
+        row.append(min(timeit(f), timeit(f, warm=0)))
+    print(f"{tag}: default {row[0]:.4f}  sync1 {row[1]:.4f}  sync2 {row[2]:.4f}  plan {A.plan_info()}", flush=True)
+
+
+def host(m, K, mean, sigma, seed=1):
+    hp, hj, hx = synth.csr_skewed_fast(m, K, mean, sigma=sigma, seed=seed)
+    p, j, x = (torch.from_numpy(a).cuda() for a in (hp, hj, hx))
+    return D.DeviceCSR(p, j, x, m, K, int(j.numel()))
+
+
+m, K = 1_000_000, 100_000
+ONLY_F32 = len(sys.argv) > 1 and sys.argv[1] == "f32"
+if ONLY_F32:
+    K5 = 200_000
+    for sigma in (0.5, 1.0, 1.3):
+        run(f"cfg5 shard log-normal sigma {sigma}", host(m, K5, 64, sigma), K5, 256, torch.float32)
+    sys.exit(0)
+p, j, x = synth.device_csr_fixed(m, K, 32, seed=1)
+run("cfg2 equal rows", D.DeviceCSR(p, j, x, m, K, int(j.numel())), K, 128, torch.float64)
+for sigma in (0.3, 0.5, 0.7, 0.85, 1.0, 1.3):
+    run(f"cfg2 log-normal sigma {sigma}", host(m, K, 32, sigma), K, 128, torch.float64)
+p, j, x = synth.device_csr_zipf(m, K, 40, alpha=1.0, sigma=1.0, seed=1)
+run("cfg2 zipf columns, sigma 1", D.DeviceCSR(p, j, x, m, K, int(j.numel())), K, 128, torch.float64)
+p, j, x = synth.device_csr_zipf(m, K, 40, alpha=1.0, sigma=0.5, seed=1)
+run("cfg2 zipf columns, sigma 0.5", D.DeviceCSR(p, j, x, m, K, int(j.numel())), K, 128, torch.float64)
+K5 = 200_000
+p, j, x = synth.device_csr_fixed(m, K5, 64, seed=1)
+run("cfg5 shard equal rows", D.DeviceCSR(p, j, x, m, K5, int(j.numel())), K5, 256, torch.float32)
+for sigma in (0.5, 1.0):
+    run(f"cfg5 shard log-normal sigma {sigma}", host(m, K5, 64, sigma), K5, 256, torch.float32)

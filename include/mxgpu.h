@@ -268,6 +268,9 @@ int mxd_spmm_plan_create(int m, int K, const int32_t *indptr, const int32_t *ind
 int mxd_spmm_plan_destroy(mx_spmm_plan *plan);
 int mxd_spmm_plan_info(const mx_spmm_plan *plan, int *npanels, int64_t *padded_entries);
 int mxd_spmm_plan_octet_cv(const mx_spmm_plan *plan, double *cv);
+/* longest work item (one octet x one 128-byte slab of B) over its share of the machine, for a B of n columns: above 2.5
+ * AUTO runs the row-split kernel instead of this plan (rows sorted by length, a few giant rows against a narrow B) */
+int mxd_spmm_plan_imbalance(const mx_spmm_plan *plan, int n, int dense_dtype, double *imbalance);
 int mxd_spmm_plan_run(const mx_spmm_plan *plan, int n, const void *B, size_t ldb, void *C, size_t ldc,
                       int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream);
 /* rows [row0, row0 + nrows) of the planned matrix only (row0 a multiple of 64); C points at the block's first row, ldc is the
@@ -373,6 +376,8 @@ int mxd_spmv_plan_destroy(mx_spmv_plan *plan);
 int mxd_debug_spmv_tile_stamps(void *stamps_dev);
 /* likewise for the LDS-tile SpMM kernel (tools/tile_stamps.py): 2 x 16 x (workgroups) uint64 — per compute wavefront the cycles
  * spent at the tile barriers and in its whole sweep */
+int mxd_debug_rowsplit_long_rows(long long *rows, long long *pieces);   /* last row-split product of this thread: rows / pieces
+                                                                           handed to the long-rows path (0 / 0 = off); syncs */
 int mxd_debug_spmm_tile_stamps(void *stamps_dev);
 
 /* CSR (+) CSR, pass 1: per-row output lengths (union for ADD/SUB/OR/XOR,

@@ -61,6 +61,7 @@ double profile_mass(double top, int K)
     return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
 }
 double profile_cv() { return g_profile ? (double)g_profile[32] : 0.0; }
+double profile_longest_over_mean() { return g_profile ? (double)g_profile[33] : 0.0; }
 bool profile_in_scope() { return g_profile != nullptr; }
 // a profile that says what no profile says (uniform columns are recognised by the marker in [39]; equal rows)
 const float *uniform_profile()
@@ -238,10 +239,13 @@ static int run_rowsplit(int m, int n, int K, int64_t nnz, int segments, int pane
         if (segments == 0) segments = rowsplit_segments(m, n, sz, avg / panels);
     }
     if (segments < 0) segments = 0;           // rowsplit_spmm's code for the row-group form
+    const int long_piece = nnz > 0 ? rowsplit_long_piece(m, nnz) : 0;      // (needs the matrix profile: 0 without one)
     // (mxd_spmm_last_kernel: set by the launch itself, spmm_rowsplit.hip launch_one — the form can still change there)
     if (dense_dtype == MX_F64)
-        return rowsplit_spmm<double>(m, n, K, segments, panels, indptr, indices, values, (const double *)B, ldb, (double *)C, ldc, colmajor, st);
-    return rowsplit_spmm<float>(m, n, K, segments, panels, indptr, indices, values, (const float *)B, ldb, (float *)C, ldc, colmajor, st);
+        return rowsplit_spmm<double>(m, n, K, segments, panels, indptr, indices, values, (const double *)B, ldb, (double *)C, ldc, colmajor, st,
+                                     long_piece, nnz);
+    return rowsplit_spmm<float>(m, n, K, segments, panels, indptr, indices, values, (const float *)B, ldb, (float *)C, ldc, colmajor, st,
+                                long_piece, nnz);
 }
 // One block (rows or columns) of a product whose kernel family was chosen for the WHOLE product (the export pipelines).
 // from_auto: the family is AUTO's choice — a planned block still falls back to the row-wave kernel when its plan would
@@ -261,6 +265,7 @@ int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, con
         if (ok && K < (1 << 25)) {
             bool ready = false;
             if (plan_auto_build(m, K, indptr, indices, values, npanels, st, 1.55, &ready)) return 1;
+            if (ready && nnz >= 0 && plan_auto_imbalance(n, dense_dtype == MX_F64 ? 8 : 4) > MX_PLAN_MAX_IMBALANCE) ready = false;
             if (ready) return plan_auto_run(n, B, ldb, C, ldc, dense_dtype, colmajor, st);
         }
         family = nnz >= 0 ? MX_SPMM_ROWSPLIT : MX_SPMM_ROWWAVE;       // (very uneven rows: the plan would pad too much)
@@ -396,6 +401,9 @@ extern "C" int mxd_spmm_csr_dense_ex2(int m, int n, int K, int64_t nnz,
         // (count + scan, ~0.1 ms) and uses the row-wave kernel.
         bool ready = false;          // the plan's buffers are re-used from call to call (grow-only, per thread)
         if (mx::plan_auto_build(m, K, indptr, indices, values, npanels, st, auto_pick_planned ? 1.55 : 0.0, &ready)) return 1;
+        // (one octet that outlasts the rest of the sweep: the row-split kernel and its long-rows path instead)
+        if (ready && auto_pick_planned && nnz >= 0 && mx::plan_auto_imbalance(n, dense_dtype == MX_F64 ? 8 : 4) > mx::MX_PLAN_MAX_IMBALANCE)
+            ready = false;
         if (ready) return mx::plan_auto_run(n, B, ldb, C, ldc, dense_dtype, colmajor_out, stream);
         if (nnz >= 0)                                                // (very uneven rows: the plan would pad too much)
             return mx::run_rowsplit(m, n, K, nnz, 0, 0, 0, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor_out, st);

@@ -97,6 +97,7 @@ inline bool slab_ok(int n, const real_t *B, size_t ldb, const real_t *C, size_t 
 struct ProfileScope { const float *saved; explicit ProfileScope(const float *p); ~ProfileScope(); };
 double profile_mass(double top, int K);
 double profile_cv();
+double profile_longest_over_mean();                       // 0 without a profile in scope
 bool profile_in_scope();
 const float *uniform_profile();
 inline double lockstep_factor(double cv, int rows_together)
@@ -120,7 +121,9 @@ int rowwave_spmm(int m, int n, const int32_t *indptr, const int32_t *indices, co
 // and P column panels of B (one launch each)
 template <typename real_t>
 int rowsplit_spmm(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
-                  const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream);
+                  const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream, int long_piece = 0,
+                  long long nnz = -1);                     // long_piece > 0 (and nnz known): rows longer than that are cut into pieces
+int rowsplit_long_piece(int m, long long nnz);            // from the matrix profile in scope, 0 = no long rows known
 int rowsplit_segments(int m, int n, int dense_bytes, double avg_len);
 double rowsplit_est_us(int m, int n, int K, int dense_bytes, double avg_len, int P);
 int rowsplit_panels(int m, int n, int K, int dense_bytes, double avg_len);
@@ -150,6 +153,8 @@ int slab_spmm(int m, int n, int K, const int32_t *indptr, const int32_t *indices
 int plan_auto_build(int m, int K, const int32_t *indptr, const int32_t *indices, const double *values, int npanels,
                     hipStream_t st, double max_pad_ratio, bool *ready);
 int plan_auto_run(int n, const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, void *stream);
+double plan_auto_imbalance(int n, int dense_bytes);       // of the plan plan_auto_build just built (spmm_plan.hip plan_imbalance)
+constexpr double MX_PLAN_MAX_IMBALANCE = 2.5;
 void plan_auto_release();
 
 // ---- scan.hip

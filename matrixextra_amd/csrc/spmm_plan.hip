@@ -449,6 +449,7 @@ void plan_sched_kernel(int noct, const int32_t *__restrict__ steps, int32_t *__r
     if (tid == 0) {
         const double mean = ssum / noct, var = fmax(ssq / noct - mean * mean, 0.0);
         *reordered = vmax > vmin ? 1 + (long long)(1000.0 * sqrt(var) / fmax(mean, 1.0)) : 0;
+        reordered[1] = vmax;                                             // the longest octet (plan_imbalance)
     }
     if (vmax <= vmin) {                                              // all octets equally long: natural order
         for (int o = tid; o < noct; o += 1024) sched[o] = o;
@@ -609,7 +610,28 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
     const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
     const long long total = (long long)nslabs * ngens;
     const long long lo = total * xcd / 8, hi = total * (xcd + 1) / 8;
-    const int niter = (int)((hi - lo + nwg - 1) / nwg);
+    // Which items (slab, generation) this workgroup sweeps, in which order.  Natural order: XCD x takes the contiguous range
+    // [lo, hi) of the slab-major item list, its workgroups round-robin.  WITH A SCHEDULE (generations by descending length)
+    // and c = 8 / nslabs XCDs per slab that range would be the c-th part of the schedule — for 4 slabs the long half for one
+    // XCD and the short half for its neighbour (round 5, tools/cliff_hunt.py: cfg2's shape in f32 with rows sorted by
+    // length 2.32 ms where equal rows take 0.97; log-normal rows 1.29 ... 1.59x).  There the c XCDs of a slab deal its ROUNDS
+    // (nwg consecutive generations: what an XCD's workgroups sweep together, equally long — which keeps them in the same
+    // panel) among themselves, in snake order: round k * c + j in even octaves k, k * c + c - 1 - j in odd ones.  Every XCD
+    // still sweeps its longest generations first.  (Dealing single generations instead put a quarter of the length
+    // distribution into one round: the workgroups of an XCD drifted into different panels — 1.9 -> 3.0 ms.)
+    const bool dealt_rounds = sched != nullptr && nslabs < 8 && (8 % nslabs) == 0;
+    const int xcds_per_slab = dealt_rounds ? 8 / nslabs : 1, my_j = xcd % xcds_per_slab, my_slab = xcd / xcds_per_slab;
+    const int nrounds = (ngens + nwg - 1) / nwg;
+    const int niter = dealt_rounds ? (nrounds + xcds_per_slab - 1) / xcds_per_slab : (int)((hi - lo + nwg - 1) / nwg);
+    auto item_of = [&](int it) -> long long {                       // -1: nothing in this iteration
+        if (!dealt_rounds) {
+            const long long raw = lo + wg + (long long)it * nwg;
+            return raw < hi ? raw : -1;
+        }
+        const int round = it * xcds_per_slab + ((it & 1) ? xcds_per_slab - 1 - my_j : my_j);
+        const long long gen = (long long)round * nwg + wg;
+        return round < nrounds && gen < ngens ? (long long)my_slab * ngens + gen : -1;
+    };
     unsigned *const my_ctr = sync_ctr + xcd * 64;
     real_t *const my_oct = accs + (size_t)wave * PLAN_OCT_ROWS * S;                     // this wavefront's 64 rows
     real_t *const my_rows = my_oct + lg * VEC;                                          // + slot * S: my 16 bytes of a row
@@ -628,18 +650,19 @@ void spmm_plan_kernel(int m, int n, int npanels, const int32_t *__restrict__ ste
 #pragma unroll
     for (int k = 0; k < PLAN_CHUNK; k++) { rc[k] = 0; rv[k] = 0.0; }
     for (int it = 0; it < niter; it++) {
-        const long long item_raw = lo + wg + (long long)it * nwg;
-        const bool have = item_raw < hi;
+        const long long item_raw = item_of(it);
+        const bool have = item_raw >= 0;
         const long long item = have ? item_raw : lo;
         const int slab = (int)(item / ngens), gen = (int)(item % ngens);
         // position in the schedule -> octet (identity without a schedule); looked up one generation ahead
         const int pos = gen * PLAN_WAVES + wave;
         const bool oct_ok = have && pos < noct;
         // this wavefront's octet of the next generation (if any), and of the one after
-        const long long item_n = item_raw + nwg, item_nn = item_n + nwg;
-        const int pos_n = (int)(item_n % ngens) * PLAN_WAVES + wave, pos_nn = (int)(item_nn % ngens) * PLAN_WAVES + wave;
-        const bool octn_ok = it + 1 < niter && item_n < hi && pos_n < noct;
-        const bool octnn_ok = it + 2 < niter && item_nn < hi && pos_nn < noct;
+        const long long item_n = it + 1 < niter ? item_of(it + 1) : -1, item_nn = it + 2 < niter ? item_of(it + 2) : -1;
+        const int pos_n = (int)((item_n < 0 ? 0 : item_n) % ngens) * PLAN_WAVES + wave;
+        const int pos_nn = (int)((item_nn < 0 ? 0 : item_nn) % ngens) * PLAN_WAVES + wave;
+        const bool octn_ok = item_n >= 0 && pos_n < noct;
+        const bool octnn_ok = item_nn >= 0 && pos_nn < noct;
         int oct = pos, oct_n = pos_n;
         if (sched) {
             if (it == 0) {                                           // the only look-ups that are waited for
@@ -849,6 +872,7 @@ struct mx_spmm_plan {
     int32_t *sched = nullptr;      size_t sched_cap = 0;      // [noct]: the order the sweep takes the octets in
     bool reordered = false;                                    // sched is not the identity (octets of unequal length)
     double oct_cv = 0.0;                                       // coefficient of variation of the octets' lengths (steps)
+    long long max_oct_steps = 0;                               // the longest octet
     long long *rbdev = nullptr;                                // [total steps][nnz][dealt octets], read back in one copy
     long long ndealt = 0;                                      // octets in the dealt layout (rows shared by lane groups)
     void *scratch = nullptr;     size_t scratch_cap = 0;       // rowpre + steps + scan workspace (build only)
@@ -891,7 +915,7 @@ static PlanReadback *plan_readback()
     static thread_local PlanReadback rbs[PLAN_MAX_DEVICES];
     PlanReadback &rb = rbs[cur_device()];
     if (!rb.host) {
-        if (hipHostMalloc((void **)&rb.host, 4 * sizeof(long long), hipHostMallocDefault) != hipSuccess) { rb.host = nullptr; return nullptr; }
+        if (hipHostMalloc((void **)&rb.host, 8 * sizeof(long long), hipHostMallocDefault) != hipSuccess) { rb.host = nullptr; return nullptr; }
         if (hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(rb.host); rb.host = nullptr; return nullptr; }
     }
     return &rb;
@@ -941,7 +965,7 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     MX_LAUNCH_CHECK();
     PlanReadback *rb = plan_readback();
     MX_REQUIRE(rb, "spmm plan: cannot allocate the pinned read-back buffer");
-    MX_HIP(hipMemcpyAsync(rb->host, rb_dev, 4 * sizeof(long long), hipMemcpyDeviceToHost, st));
+    MX_HIP(hipMemcpyAsync(rb->host, rb_dev, 5 * sizeof(long long), hipMemcpyDeviceToHost, st));
     MX_HIP(hipEventRecord(rb->ev, st));
     // The host needs the plan's size to (re)allocate its arrays.  While it waits for the read-back the GPU would idle
     // (~25 us): when arrays from an earlier build exist, the fill is launched right away against their capacity — it
@@ -965,6 +989,7 @@ static int plan_build(mx_spmm_plan *pl, int m, int K, const int32_t *indptr, con
     pl->ndealt = rb->host[2];
     pl->reordered = rb->host[3] != 0;
     pl->oct_cv = rb->host[3] > 0 ? (double)(rb->host[3] - 1) * 1e-3 : 0.0;
+    pl->max_oct_steps = rb->host[4];
     MX_REQUIRE(total >= 0 && total * 8 <= (long long)INT_MAX * 4LL, "spmm plan: too many steps (%lld)", total);
     MX_REQUIRE(total <= (long long)INT_MAX, "spmm plan: step offsets exceed int32");
     pl->total_steps = total;
@@ -1115,6 +1140,30 @@ extern "C" int mxd_spmm_plan_info(const mx_spmm_plan *pl, int *npanels, int64_t 
     MX_REQUIRE(pl, "mxd_spmm_plan_info: null plan");
     if (npanels) *npanels = pl->npanels;
     if (padded_entries) *padded_entries = pl->total_steps * 8;
+    return 0;
+}
+
+// How much longer than its share of the machine the sweep's longest work item runs.  An item is one octet x one 128-byte
+// slab, swept by ONE wavefront; 4096 of them run at a time (256 CUs x 16).  With rows sorted by length, or a few rows of
+// tens of thousands of entries against a narrow B, the longest octet alone outlasts everything else (tools/cliff_hunt.py:
+// m = 2e5, 100 per row, n = 32, rows sorted by length: 1.87 ms against 0.33 for equal rows — imbalance 11.8; the row-split
+// kernel with its long-rows path takes 0.54).  A wide B hides it (more items per octet: cfg2's shape, sorted rows, 8 slabs:
+// 1.6).  AUTO leaves the plan for the row-split kernel above MX_PLAN_MAX_IMBALANCE.
+namespace mx {
+double plan_imbalance(const mx_spmm_plan *pl, int n, int dense_bytes)
+{
+    if (!pl || pl->total_steps <= 0 || pl->noct <= 0) return 0.0;
+    const double nslabs = (double)((n + 128 / dense_bytes - 1) / (128 / dense_bytes));
+    const double items = (double)pl->noct * nslabs, at_a_time = items < 4096.0 ? items : 4096.0;
+    return (double)pl->max_oct_steps * at_a_time / ((double)pl->total_steps * nslabs);
+}
+double plan_auto_imbalance(int n, int dense_bytes) { return plan_imbalance(g_auto_plan[cur_device()], n, dense_bytes); }
+}  // namespace mx
+
+extern "C" int mxd_spmm_plan_imbalance(const mx_spmm_plan *pl, int n, int dense_dtype, double *imbalance)
+{
+    MX_REQUIRE(pl && imbalance && n > 0, "mxd_spmm_plan_imbalance: bad arguments");
+    *imbalance = mx::plan_imbalance(pl, n, dense_dtype == MX_F64 ? 8 : 4);
     return 0;
 }
 

@@ -195,6 +195,41 @@ __device__ __forceinline__ void c_store(real_t *p, const real_t (&v)[VEC], bool 
     } else vstore<real_t, VEC>(p, v);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LONG ROWS (round 5, tools/cliff_hunt.py).  One wavefront per row makes the longest row the kernel's tail: m = 1e5, 64 per
+// row, n = 64 ran 0.16 ms with equal rows, 0.40 ms with log-normal rows (sigma 1.5) or four rows of 10,000 entries.  When
+// the caller knows that long rows exist (the matrix profile's longest / mean row, csrc/profile.hip), rows longer than `piece`
+// entries are treated as EMPTY by the kernels below — the wavefront that meets one in panel 0 registers it in a list, one
+// 64-bit atomic handing out the list slot and the row's range of pieces together — and are then summed by
+// spmm_longrows_kernel, one wavefront per piece of `piece` consecutive entries into a scratch row, and
+// spmm_longrows_combine_kernel, which adds a row's pieces IN ORDER and overwrites the row of C: the same bits on every run
+// whatever the order of the list (a regrouping of the row's sum, like the segments).
+static thread_local unsigned long long *g_longrows_last = nullptr;   // counter of the thread's last product (nullptr: path off)
+struct LongRows {
+    unsigned long long *counter;     // (slots << 32) | pieces handed out so far
+    int *rows;                       // [slot] row
+    unsigned *base;                  // [slot] first piece of the row
+    int2 *piece_of;                  // [piece] (row, number of the piece inside the row)
+    int piece;                       // 0 = off
+};
+// wave-uniform `row` and `len` (the WHOLE row, not a panel's part of it): true = the row goes to the long-rows kernels
+__device__ __forceinline__ bool long_row_divert(const LongRows &lr, int row, int len, bool registers)
+{
+    if (lr.piece == 0 || len <= lr.piece) return false;
+    if (registers) {
+        const int np = (len + lr.piece - 1) / lr.piece;
+        unsigned long long old = 0;
+        if (lane_id() == 0) {
+            old = atomicAdd(lr.counter, (1ULL << 32) | (unsigned long long)np);
+            lr.rows[old >> 32] = row;
+            lr.base[old >> 32] = (unsigned)old;
+        }
+        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old);
+        for (int k = lane_id(); k < np; k += MX_WAVE) lr.piece_of[base + k] = make_int2(row, k);
+    }
+    return true;
+}
+
 // cursors: (P + 1) x m per-row entry bounds of the column panels (rowsplit_cursors_kernel), nullptr = one panel, the whole
 // row; done: one counter per (pass, row block), zeroed by the cursor kernel; P: the panels THIS launch runs, from p0 on
 template <typename real_t, int VEC, int G, bool COLMAJOR>
@@ -204,7 +239,7 @@ void spmm_rowsplit_kernel(int m, int n, int S, int nbx, int passes, int P, int p
                           const double *__restrict__ values,
                           const int32_t *__restrict__ cursors, unsigned *__restrict__ done,
                           const real_t *__restrict__ B, size_t ldb,
-                          real_t *__restrict__ C, size_t ldc)
+                          real_t *__restrict__ C, size_t ldc, LongRows lr)
 {
     constexpr int W = G * VEC;                // output columns per pass
     constexpr int LS = W + 1;                 // odd LDS row stride (elements)
@@ -237,7 +272,11 @@ void spmm_rowsplit_kernel(int m, int n, int S, int nbx, int passes, int P, int p
 
     if (row < m) {
         const int s = uniform(lo ? lo[row] : indptr[row]);
-        const int e = uniform(hi ? hi[row] : indptr[row + 1]);
+        int e = uniform(hi ? hi[row] : indptr[row + 1]);
+        if (lr.piece) {                        // a long row is left to spmm_longrows_kernel: empty here, in every panel
+            const int len = lo ? uniform(indptr[row + 1]) - uniform(indptr[row]) : e - s;
+            if (long_row_divert(lr, row, len, at.p == 0 && at.pass == 0 && seg == 0)) e = s;
+        }
         int a = s, b = e;
         if (S > 1) {                           // whole 64-entry chunks per segment; the row's tail goes to the last busy one
             const int L = (((e - s + S - 1) / S + MX_WAVE - 1) / MX_WAVE) * MX_WAVE;
@@ -317,7 +356,7 @@ void spmm_rowgroup_kernel(int m, int n, int nbx, int passes, int P, int p0,
                           const double *__restrict__ values,
                           const int32_t *__restrict__ cursors, unsigned *__restrict__ done,
                           const real_t *__restrict__ B, size_t ldb,
-                          real_t *__restrict__ C, size_t ldc)
+                          real_t *__restrict__ C, size_t ldc, LongRows lr)
 {
     static_assert(G < MX_WAVE, "one row per wavefront is the row-split form");
     constexpr int NG = MX_WAVE / G;           // rows per wavefront
@@ -352,6 +391,19 @@ void spmm_rowgroup_kernel(int m, int n, int nbx, int passes, int P, int p0,
     if (row < m) {
         s = lo ? lo[row] : indptr[row];
         e = hi ? hi[row] : indptr[row + 1];
+        if (lr.piece) {                        // (long rows: see spmm_rowsplit_kernel; here per lane group)
+            const int len = lo ? indptr[row + 1] - indptr[row] : e - s;
+            if (len > lr.piece) {
+                if (at.p == 0 && at.pass == 0 && lg == 0) {
+                    const unsigned np = (unsigned)((len + lr.piece - 1) / lr.piece);
+                    const unsigned long long old = atomicAdd(lr.counter, (1ULL << 32) | (unsigned long long)np);
+                    lr.rows[old >> 32] = row;
+                    lr.base[old >> 32] = (unsigned)old;
+                    for (unsigned k = 0; k < np; k++) lr.piece_of[(unsigned)old + k] = make_int2(row, (int)k);
+                }
+                e = s;
+            }
+        }
     }
     if (!COLMAJOR && accumulate) {
         if (handover) panel_wait(word, at.p);
@@ -441,24 +493,95 @@ void rowsplit_cursors_kernel(int m, int P, int panel_cols, const int32_t *__rest
     }
 }
 
+// One wavefront per PIECE of a long row (see LongRows): the sums of entries [s + k * piece, s + (k + 1) * piece) x B, all the
+// columns of one pass, into scratch row E[piece index]; the piece -> (row, k) table was written when the row was registered
+// (a binary search over the slots' first pieces instead cost 14 dependent loads per piece: more than the piece itself).
+// Persistent grid: the number of pieces is only known on the device.
+template <typename real_t, int VEC, int G>
+__global__ __launch_bounds__(RS_WAVES * MX_WAVE)
+void spmm_longrows_kernel(int n, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                          const double *__restrict__ values, const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ E,
+                          LongRows lr)
+{
+    constexpr int W = G * VEC;
+    const unsigned total = (unsigned)*lr.counter;
+    const int lane = lane_id(), lg = lane % G;
+    const int col = blockIdx.y * W + lg * VEC;
+    const bool active = col < n;
+    const unsigned lcol = active ? (unsigned)col : (unsigned)(n - VEC);
+    const unsigned wave0 = blockIdx.x * RS_WAVES + uniform(threadIdx.x / MX_WAVE), nwaves = gridDim.x * RS_WAVES;
+    for (unsigned w = wave0; w < total; w += nwaves) {
+        const int2 rk = lr.piece_of[w];
+        const int row = uniform(rk.x), k = uniform(rk.y);
+        const int s = uniform(indptr[row]), e = uniform(indptr[row + 1]);
+        const int a = s + (int)k * lr.piece, b = min(e, a + lr.piece);
+        real_t acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) acc[v] = 0;
+        int jv = 0;
+        double av = 0.0;
+        if (a + lane < b) { jv = indices[a + lane]; av = values[a + lane]; }
+        for (int k0 = a; k0 < b; k0 += MX_WAVE) {
+            int jn = 0;
+            double an = 0.0;
+            if (k0 + MX_WAVE + lane < b) { jn = indices[k0 + MX_WAVE + lane]; an = values[k0 + MX_WAVE + lane]; }
+            if constexpr (G == MX_WAVE) rs_chunk<real_t, VEC>(min(MX_WAVE, b - k0), jv, av, B, ldb, lcol, acc);
+            else rs_chunk_groups<real_t, VEC, G>(min(MX_WAVE, b - k0), jv, av, B, ldb, lcol, lane / G, acc);
+            jv = jn; av = an;
+        }
+        if constexpr (G < MX_WAVE) {
+#pragma unroll
+            for (int off = G; off < MX_WAVE; off <<= 1) {
+#pragma unroll
+                for (int v = 0; v < VEC; v++) acc[v] += __shfl_xor(acc[v], off, MX_WAVE);
+            }
+        }
+        if (active && lane < G) {
+#pragma unroll
+            for (int v = 0; v < VEC; v++) E[(size_t)w * n + col + v] = acc[v];
+        }
+    }
+}
+
+// One wavefront per long row: its pieces added in order, the row of C overwritten (the product kernels left zeros there)
+template <typename real_t, bool COLMAJOR>
+__global__ __launch_bounds__(RS_WAVES * MX_WAVE)
+void spmm_longrows_combine_kernel(int n, const int32_t *__restrict__ indptr, const real_t *__restrict__ E, real_t *__restrict__ C,
+                                  size_t ldc, LongRows lr)
+{
+    const int nslots = (int)(*lr.counter >> 32);
+    const int lane = lane_id();
+    for (int i = blockIdx.x * RS_WAVES + uniform(threadIdx.x / MX_WAVE); i < nslots; i += gridDim.x * RS_WAVES) {
+        const int row = uniform(lr.rows[i]);
+        const unsigned base = (unsigned)uniform((int)lr.base[i]);
+        const int len = uniform(indptr[row + 1]) - uniform(indptr[row]);
+        const int np = (len + lr.piece - 1) / lr.piece;
+        for (int c = lane; c < n; c += MX_WAVE) {
+            real_t sum = E[(size_t)base * n + c];
+            for (int k = 1; k < np; k++) sum += E[((size_t)base + k) * n + c];
+            C[COLMAJOR ? (size_t)c * ldc + row : (size_t)row * ldc + c] = sum;
+        }
+    }
+}
+
 // S = 0: the row-group form (several rows per wavefront, G < 64); the launch runs panels p0 .. p0 + P - 1
 template <typename real_t, int VEC, int G, bool COLMAJOR>
 static void launch_one(int m, int n, int S, int nbx, int passes, int P, int p0, const int32_t *indptr, const int32_t *indices,
                        const double *values, const int32_t *cursors, unsigned *done, const real_t *B, size_t ldb, real_t *C, size_t ldc,
-                       hipStream_t stream)
+                       const LongRows &lr, hipStream_t stream)
 {
     const dim3 grid((unsigned)((size_t)nbx * passes * P));
     if constexpr (G < MX_WAVE) {
         if (S == 0) {
             set_last_spmm_kernel("spmm_rowgroup_kernel");            // (named where the form is final: after the alignment fallback)
             hipLaunchKernelGGL((spmm_rowgroup_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
-                               m, n, nbx, passes, P, p0, indptr, indices, values, cursors, done, B, ldb, C, ldc);
+                               m, n, nbx, passes, P, p0, indptr, indices, values, cursors, done, B, ldb, C, ldc, lr);
             return;
         }
     }
     set_last_spmm_kernel("spmm_rowsplit_kernel");
     hipLaunchKernelGGL((spmm_rowsplit_kernel<real_t, VEC, G, COLMAJOR>), grid, dim3(RS_WAVES * MX_WAVE), 0, stream,
-                       m, n, S, nbx, passes, P, p0, indptr, indices, values, cursors, done, B, ldb, C, ldc);
+                       m, n, S, nbx, passes, P, p0, indptr, indices, values, cursors, done, B, ldb, C, ldc, lr);
 }
 
 // One launch for all the panels, or one per panel (rounds 3-4)?  Measured (tools/rowsplit_fused_probe.py, ms, one launch /
@@ -479,15 +602,47 @@ static bool rowsplit_one_launch_per_panel(bool through_tile, long long workgroup
 
 template <typename real_t, int VEC, int G, bool COLMAJOR>
 static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
-                           const real_t *B, size_t ldb, real_t *C, size_t ldc, hipStream_t stream)
+                           const real_t *B, size_t ldb, real_t *C, size_t ldc, int long_piece, long long nnz, hipStream_t stream)
 {
     constexpr int W = G * VEC;
     if (S == 0 && G == MX_WAVE) S = 1;                      // rows of B that fill the wavefront: one row per wavefront anyway
     const int nbx = (int)ceil_div(m, S == 0 ? RS_WAVES * (MX_WAVE / G) : RS_WAVES / S), passes = (int)ceil_div(n, W);
     if ((long long)nbx * passes * P >= (1LL << 31)) return set_error("rowsplit_spmm: %d x %d x %d workgroups exceed the grid", nbx, passes, P);
+    // LONG ROWS: the list and the pieces' scratch rows, sized by what nnz allows (a long row has more than `piece` entries:
+    // at most nnz / piece of them, and their pieces are at most nnz / piece + one per row)
+    LongRows lr = {nullptr, nullptr, nullptr, nullptr, 0};
+    real_t *E = nullptr;
+    g_longrows_last = nullptr;
+    if (long_piece > 0 && nnz > long_piece) {
+        const size_t slots = (size_t)(nnz / long_piece) + 1, pieces = 2 * slots;
+        const size_t head = 256, rows_b = (slots * 4 + 255) & ~(size_t)255, po_b = (pieces * 8 + 255) & ~(size_t)255,
+                     e_b = pieces * (size_t)n * sizeof(real_t);
+        char *buf = (char *)scratch_buffer(MX_SCRATCH_LONGROWS, head + 2 * rows_b + po_b + e_b);
+        if (!buf) return set_error("rowsplit_spmm: cannot allocate %zu bytes for the long rows' pieces", head + 2 * rows_b + po_b + e_b);
+        scratch_acquire(MX_SCRATCH_LONGROWS, stream);
+        lr.counter = (unsigned long long *)buf;
+        lr.rows = (int *)(buf + head);
+        lr.base = (unsigned *)(buf + head + rows_b);
+        lr.piece_of = (int2 *)(buf + head + 2 * rows_b);
+        lr.piece = long_piece;
+        E = (real_t *)(buf + head + 2 * rows_b + po_b);
+        MX_HIP(hipMemsetAsync(lr.counter, 0, sizeof(unsigned long long), stream));
+        g_longrows_last = lr.counter;
+    }
+    // after the product kernels: the pieces, then the rows (both persistent: the counts live on the device)
+    auto long_rows = [&]() {
+        if (!lr.piece) return;
+        const unsigned blocks = (unsigned)std::min<size_t>(2048, (size_t)(nnz / long_piece) / RS_WAVES + 1);
+        hipLaunchKernelGGL((spmm_longrows_kernel<real_t, VEC, G>), dim3(blocks, (unsigned)passes), dim3(RS_WAVES * MX_WAVE), 0, stream,
+                           n, indptr, indices, values, B, ldb, E, lr);
+        hipLaunchKernelGGL((spmm_longrows_combine_kernel<real_t, COLMAJOR>), dim3(std::min(blocks, 512u)), dim3(RS_WAVES * MX_WAVE), 0, stream,
+                           n, indptr, E, C, ldc, lr);
+        scratch_done(MX_SCRATCH_LONGROWS, stream);
+    };
     if (P <= 1) {
         kt_begin(stream);
-        launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, nbx, passes, 1, 0, indptr, indices, values, nullptr, nullptr, B, ldb, C, ldc, stream);
+        launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, nbx, passes, 1, 0, indptr, indices, values, nullptr, nullptr, B, ldb, C, ldc, lr, stream);
+        long_rows();
         kt_end(stream);
         MX_LAUNCH_CHECK();
         return 0;
@@ -505,11 +660,12 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
                        m, P, panel_cols, indptr, indices, cur, done, ndone);
     if (rowsplit_one_launch_per_panel(COLMAJOR || S > 1, (long long)nbx * passes)) {
         for (int p = 0; p < P; p++)
-            launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, nbx, passes, 1, p, indptr, indices, values, cur, done, B, ldb, C, ldc, stream);
+            launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, nbx, passes, 1, p, indptr, indices, values, cur, done, B, ldb, C, ldc, lr, stream);
     } else {
-        launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, nbx, passes, P, 0, indptr, indices, values, cur, done, B, ldb, C, ldc, stream);
+        launch_one<real_t, VEC, G, COLMAJOR>(m, n, S, nbx, passes, P, 0, indptr, indices, values, cur, done, B, ldb, C, ldc, lr, stream);
     }
     scratch_done(MX_SCRATCH_ROWSPLIT, stream);
+    long_rows();
     kt_end(stream);
     MX_LAUNCH_CHECK();
     return 0;
@@ -517,14 +673,14 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
 
 template <typename real_t, int VEC, bool COLMAJOR>
 static int pick_group_rowsplit(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
-                               const real_t *B, size_t ldb, real_t *C, size_t ldc, hipStream_t st)
+                               const real_t *B, size_t ldb, real_t *C, size_t ldc, int long_piece, long long nnz, hipStream_t st)
 {
     if constexpr (VEC > 1) {
-        if (n <= 8 * VEC) return launch_rowsplit<real_t, VEC, 8, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, st);
-        if (n <= 16 * VEC) return launch_rowsplit<real_t, VEC, 16, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, st);
-        if (n <= 32 * VEC) return launch_rowsplit<real_t, VEC, 32, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, st);
+        if (n <= 8 * VEC) return launch_rowsplit<real_t, VEC, 8, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, st);
+        if (n <= 16 * VEC) return launch_rowsplit<real_t, VEC, 16, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, st);
+        if (n <= 32 * VEC) return launch_rowsplit<real_t, VEC, 32, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, st);
     }
-    return launch_rowsplit<real_t, VEC, 64, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, st);
+    return launch_rowsplit<real_t, VEC, 64, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, st);
 }
 
 // Column panels (tools/auto_map.py, profiles/r04_auto_map.json): none while an XCD's L2 still holds most of B (5 MB: 80 %
@@ -614,9 +770,29 @@ int rowsplit_segments(int m, int n, int dense_bytes, double avg_len)
     return S;
 }
 
+// The piece length of the long-rows path, 0 = off.  Only with a matrix profile in scope (DeviceCSR.profile(), the exports'
+// host-side profile, AUTO's own pass), and only when the longest row is at least two pieces long: rows of even length never
+// pay the two extra launches.  Measured (tools/longrow_sweep.py, ms, off / best piece): m = 1e5, 64 per row, n = 64: four
+// rows of 10,000 entries 0.394 / 0.185 (256), log-normal sigma 1.5 0.331 / 0.211 (256-512); m = 2e5, 100 per row, n = 32:
+// 1.514 / 0.550 (512) and 1.076 / 0.542 (512-1024); m = 1e4, 500 per row, n = 100: 0.380 / 0.244 (512), 0.413 / 0.305
+// (1024); m = 1e6, 12 per row, n = 16 (row groups): 0.601 / 0.140, 0.572 / 0.277 (128).  Pieces of 128 entries cost more
+// than they balance once the mean row is 64 or longer (0.92 ms where 512 gives 0.53): ~6 mean rows per piece, a power of
+// two in [128, 1024].  Rows SORTED by length (longest first) are the one case that loses (0.164 -> 0.186, 0.479 -> 0.536):
+// the launch order already is the longest-first schedule.
+int rowsplit_long_piece(int m, long long nnz)
+{
+    const double ratio = profile_longest_over_mean();
+    if (ratio <= 0.0 || m <= 0 || nnz <= 0) return 0;
+    const double mean = (double)nnz / m;
+    int piece = 128;
+    while (piece < 1024 && piece < 6.0 * mean) piece <<= 1;
+    if (const char *e = getenv("MXGPU_LONG_PIECE")) piece = atoi(e);       // (tools/longrow_sweep.py)
+    return piece > 0 && ratio * mean >= 2.0 * piece ? piece : 0;
+}
+
 template <typename real_t>
 int rowsplit_spmm(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
-                  const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream)
+                  const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream, int long_piece, long long nnz)
 {
     constexpr int VECMAX = 16 / (int)sizeof(real_t);
     if (S != 0 && S != 1 && S != 2 && S != 4 && S != 8)
@@ -628,14 +804,29 @@ int rowsplit_spmm(int m, int n, int K, int S, int P, const int32_t *indptr, cons
     const bool c_vec = colmajor || S > 1 || ((ldc % VECMAX == 0) && ((uintptr_t)C % 16 == 0));
     if (S == 0 && !(b_vec && c_vec)) S = 1;                 // (the row-group form needs the 16-byte accesses)
     if (b_vec && c_vec)
-        return colmajor ? pick_group_rowsplit<real_t, VECMAX, true>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, stream)
-                        : pick_group_rowsplit<real_t, VECMAX, false>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, stream);
-    return colmajor ? pick_group_rowsplit<real_t, 1, true>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, stream)
-                    : pick_group_rowsplit<real_t, 1, false>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, stream);
+        return colmajor ? pick_group_rowsplit<real_t, VECMAX, true>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, stream)
+                        : pick_group_rowsplit<real_t, VECMAX, false>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, stream);
+    return colmajor ? pick_group_rowsplit<real_t, 1, true>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, stream)
+                    : pick_group_rowsplit<real_t, 1, false>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, stream);
 }
 template int rowsplit_spmm<double>(int, int, int, int, int, const int32_t *, const int32_t *, const double *, const double *, size_t,
-                                   double *, size_t, int, hipStream_t);
+                                   double *, size_t, int, hipStream_t, int, long long);
 template int rowsplit_spmm<float>(int, int, int, int, int, const int32_t *, const int32_t *, const double *, const float *, size_t,
-                                  float *, size_t, int, hipStream_t);
+                                  float *, size_t, int, hipStream_t, int, long long);
 
 }  // namespace mx
+
+// diagnostic: how many rows (and pieces) the calling thread's last row-split product on the current device handed to its
+// long-rows path — 0 / 0 when the path was off.  Synchronises the device.
+extern "C" int mxd_debug_rowsplit_long_rows(long long *rows, long long *pieces)
+{
+    MX_REQUIRE(rows && pieces, "mxd_debug_rowsplit_long_rows: null argument");
+    *rows = *pieces = 0;
+    if (!mx::g_longrows_last) return 0;
+    unsigned long long cnt = 0;
+    MX_HIP(hipDeviceSynchronize());
+    MX_HIP(hipMemcpy(&cnt, mx::g_longrows_last, sizeof(cnt), hipMemcpyDeviceToHost));
+    *rows = (long long)(cnt >> 32);
+    *pieces = (long long)(cnt & 0xffffffffULL);
+    return 0;
+}

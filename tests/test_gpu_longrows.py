@@ -1,0 +1,119 @@
+"""The row-split kernel's LONG-ROWS path (csrc/spmm_rowsplit.hip: LongRows, spmm_longrows_kernel, spmm_longrows_combine_kernel):
+with a matrix profile in scope whose longest row is at least two pieces long, rows longer than a piece are left out by the
+product kernels, summed piece by piece into scratch rows and combined in order.  Against the oracle's gemm_csr_drm_as_drm /
+_dcm (src/matmul.cpp:118-185) at 1e-12 (f64) / 1e-5 (f32) — a regrouping of the row's sum, like the segments — and EXACTLY on
+small-integer operands, where a lost or doubled piece is a wrong integer; every lane-group width, segments, row groups,
+column panels in both launch forms, both layouts of C, the same bits on every repeat."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from matrixextra_amd import _lib, device as D
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _matrix(m, K, rng, base_len, long_rows, sort=True):
+    lens = rng.integers(0, 2 * base_len + 1, size=m)
+    for r, l in long_rows.items():
+        lens[r] = l
+    lens = np.minimum(lens, K)
+    p = np.zeros(m + 1, dtype=np.int32); p[1:] = np.cumsum(lens)
+    j = np.empty(int(p[-1]), dtype=np.int32)
+    for r in range(m):
+        c = rng.choice(K, size=int(lens[r]), replace=False).astype(np.int32)
+        j[p[r]:p[r + 1]] = np.sort(c) if sort else c
+    return p, j, lens
+
+
+def _long_counts():
+    rows, pieces = C.c_longlong(0), C.c_longlong(0)
+    _lib.check(_lib.load().mxd_debug_rowsplit_long_rows(C.byref(rows), C.byref(pieces)))
+    return rows.value, pieces.value
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("colmajor", [False, True])
+@pytest.mark.parametrize("n,S,P", [(100, 1, 1), (16, 1, 1), (64, 4, 1), (260, 1, 1), (16, -1, 1), (32, -1, 2), (128, 1, 3), (48, 2, 2)])
+def test_long_rows_are_cut_into_pieces_and_combined_in_order(gpu, monkeypatch, dtype, colmajor, n, S, P):
+    monkeypatch.setenv("MXGPU_LONG_PIECE", "128")
+    rng = np.random.default_rng(11)
+    m, K = 1203, 3000
+    long_rows = {0: 128 * 2, 5: 128 * 2 + 1, 77: 2999, 640: 1500, 641: 700, m - 1: 1000, 300: 128, 301: 129}
+    p, j, lens = _matrix(m, K, rng, 10, long_rows)
+    expect_rows = int((lens > 128).sum())
+    expect_pieces = int(np.ceil(lens[lens > 128] / 128).sum())
+    for exact in (True, False):
+        x = rng.integers(-2, 3, size=j.size).astype(np.float64) if exact else rng.uniform(-1, 1, size=j.size)
+        B = (rng.integers(-3, 4, size=(K, n)) if exact else rng.normal(size=(K, n))).astype(dtype)
+        A = D.DeviceCSR.from_host(p, j, x, K)
+        Bd = torch.from_numpy(B).cuda()
+        for launches in ("0", "1"):
+            monkeypatch.setenv("MXGPU_ROWSPLIT_LAUNCHES", launches)
+            got = D.spmm(A, Bd, colmajor=colmajor, algo=4, npanels=P, wg_per_cu=S).cpu().numpy()
+            assert _long_counts() == (expect_rows, expect_pieces)
+            want = O.tcrossprod_csr_dense(p, j, x, np.asfortranarray(B.T), 1, True)
+            if exact:
+                assert np.array_equal(got, want)
+            else:
+                tol = 1e-12 if dtype == np.float64 else 1e-5
+                np.testing.assert_allclose(got, want, rtol=tol, atol=tol * 50)
+            for _ in range(3):
+                assert np.array_equal(D.spmm(A, Bd, colmajor=colmajor, algo=4, npanels=P, wg_per_cu=S).cpu().numpy(), got)
+            if P == 1:
+                break
+
+
+def test_long_rows_path_stays_off_without_long_rows_or_without_a_profile(gpu, monkeypatch):
+    """Rows of even length never pay the two extra launches; the bare C-ABI call (no profile in scope) keeps the kernel's
+    bit-for-bit storage-order chain even when long rows exist."""
+    from devmem import spmm_device
+    rng = np.random.default_rng(5)
+    m, K, n = 500, 2000, 128
+    p, j, lens = _matrix(m, K, rng, 40, {})
+    x = rng.uniform(-1, 1, size=j.size)
+    B = rng.normal(size=(K, n))
+    A = D.DeviceCSR.from_host(p, j, x, K)
+    D.spmm(A, torch.from_numpy(B).cuda(), algo=4)
+    assert _long_counts() == (0, 0)
+    p, j, lens = _matrix(m, K, rng, 40, {3: 1900, 100: 1500})
+    x = rng.uniform(-1, 1, size=j.size)
+    got = spmm_device(p, j, x, B, False, 4, False, npanels=1, wg_per_cu=1)
+    assert _long_counts() == (0, 0)
+    assert np.array_equal(got, O.tcrossprod_csr_dense(p, j, x, np.asfortranarray(B.T), 1, True))
+    A = D.DeviceCSR.from_host(p, j, x, K)                     # with the profile: the two long rows are cut
+    got2 = D.spmm(A, torch.from_numpy(B).cuda(), algo=4).cpu().numpy()
+    rows, pieces = _long_counts()
+    piece = 128                                               # the default rule: ~6 mean rows, a power of two in [128, 1024]
+    while piece < 1024 and piece < 6.0 * j.size / m:
+        piece *= 2
+    assert rows == 2 and pieces == int(np.ceil(1900 / piece) + np.ceil(1500 / piece))
+    np.testing.assert_allclose(got2, got, rtol=1e-12, atol=1e-12)
+
+
+def test_auto_with_long_rows_matches_the_oracle_at_size(gpu):
+    """m = 1e5, 64 per row and four rows of 10,000 entries (tools/cliff_hunt.py's `giant`): AUTO (plan / profile kept) against
+    sampled oracle rows, the long rows among them."""
+    rng = np.random.default_rng(7)
+    m, K, n = 100_000, 10_000, 64
+    lens = np.full(m, 64, dtype=np.int64)
+    giant = rng.integers(0, m, size=4)
+    lens[giant] = 10_000
+    p = np.zeros(m + 1, dtype=np.int64); p[1:] = np.cumsum(lens)
+    row = np.repeat(np.arange(m, dtype=np.int64), lens)
+    key = np.unique(row * K + rng.integers(0, K, size=row.size))
+    row = key // K
+    j = (key - row * K).astype(np.int32)
+    p = np.zeros(m + 1, dtype=np.int64); np.cumsum(np.bincount(row, minlength=m), out=p[1:])
+    x = rng.uniform(-1, 1, size=j.size)
+    B = rng.normal(size=(K, n))
+    A = D.DeviceCSR.from_host(p.astype(np.int32), j, x, K)
+    got = D.spmm(A, torch.from_numpy(B).cuda()).cpu().numpy()
+    rows = np.unique(np.concatenate([giant, rng.integers(0, m, size=200)]))
+    for r in rows:
+        s, e = p[r], p[r + 1]
+        want = x[s:e] @ B[j[s:e]]
+        np.testing.assert_allclose(got[r], want, rtol=1e-11, atol=1e-11)

@@ -29,6 +29,8 @@ KERNEL_SOURCES = [
     ("merge_", ["merge.hip"]), ("values_elemwise", ["merge.hip"]), ("scan", ["scan.hip"]),
     ("stream_copy_kernel", ["stream.hip"]), ("csr_by_dvec", ["dvec.hip", "r_arith.h"]), ("dvec_na", ["dvec_na.hip", "r_arith.h"]),
     ("drop_", ["dropzeros.hip"]), ("colslice", ["colslice.hip"]), ("svec", ["svec.hip"]), ("bind", ["bind.hip"]),
+    ("profile_sample_kernel", ["profile.hip"]), ("profile_bins_kernel", ["profile.hip"]),
+    ("spmm_longrows", ["spmm_rowsplit.hip"]),
 ]
 COMMON = ["mx_common.h", "spmm_common.h"]
 

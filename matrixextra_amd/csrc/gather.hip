@@ -91,7 +91,7 @@ __global__ __launch_bounds__(GATHER_BLOCK)
 void gather_copy_kernel(int r, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                         const VT *__restrict__ values, const int32_t *__restrict__ rows,
                         const int32_t *__restrict__ new_indptr, int32_t *__restrict__ new_indices,
-                        VT *__restrict__ new_values)
+                        VT *__restrict__ new_values, long long capacity)
 {
     const int lg = threadIdx.x % G;
     const long long i = (long long)blockIdx.x * (GATHER_BLOCK / G) + threadIdx.x / G;
@@ -100,6 +100,7 @@ void gather_copy_kernel(int r, const int32_t *__restrict__ indptr, const int32_t
     const int src = indptr[row];
     const int len = indptr[row + 1] - src;
     const int dst = new_indptr[i];
+    if ((long long)dst + len > capacity) return;                      // (behind the one-launch gather: arrays sized for an estimate)
     for (int k = lg; k < len; k += G) {
         new_indices[dst + k] = indices[src + k];
         if constexpr (HAS_VALUES) new_values[dst + k] = values[src + k];
@@ -109,14 +110,14 @@ void gather_copy_kernel(int r, const int32_t *__restrict__ indptr, const int32_t
 template <typename VT, bool HAS_VALUES>
 static int launch_gather_copy(int G, int r, const int32_t *indptr, const int32_t *indices, const void *values,
                               const int32_t *rows, const int32_t *new_indptr, int32_t *new_indices,
-                              void *new_values, hipStream_t st)
+                              void *new_values, hipStream_t st, long long capacity = LLONG_MAX)
 {
 #define MX_CASE(GG)                                                                                      \
     case GG: {                                                                                           \
         const unsigned grid = (unsigned)ceil_div(r, GATHER_BLOCK / GG);                                  \
         hipLaunchKernelGGL((gather_copy_kernel<GG, VT, HAS_VALUES>), dim3(grid), dim3(GATHER_BLOCK), 0,  \
                            st, r, indptr, indices, (const VT *)values, rows, new_indptr, new_indices,    \
-                           (VT *)new_values);                                                            \
+                           (VT *)new_values, capacity);                                                  \
         break;                                                                                           \
     }
     switch (G) { MX_CASE(4) MX_CASE(8) MX_CASE(16) MX_CASE(32) MX_CASE(64)
@@ -168,7 +169,11 @@ void gather_fused_kernel(int r, const int32_t *__restrict__ indptr, const int32_
 #pragma unroll
     for (int o2 = 1; o2 < 64; o2 <<= 1) { const long long up = __shfl_up(incl, o2, 64); if (lane >= o2) incl += up; }
     __shared__ long long wave_tot64[GATHER_BLOCK / 64];
-    if (lane == 63) wave_tot64[wave] = incl;
+    __shared__ int wave_max[GATHER_BLOCK / 64];
+    int lmax = len;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) lmax = max(lmax, __shfl_xor(lmax, o2, 64));
+    if (lane == 63) { wave_tot64[wave] = incl; wave_max[wave] = lmax; }
     src_l[tid] = src;
     len_l[tid] = len;
     __syncthreads();
@@ -221,6 +226,30 @@ void gather_fused_kernel(int r, const int32_t *__restrict__ indptr, const int32_
         off_l[tid] = dst + len <= capacity ? (int)my_off : -1;
     }
     __syncthreads();
+    // A tile whose rows are very uneven (round 5, tools/cliff_hunt_ops.py: log-normal row lengths, sigma 1.5: 0.28 ms where
+    // equal rows take 0.067; a row of 50,000 entries: one lane group for 1,500 trips): the lane groups below walk 8 rows in
+    // lockstep, as long as the longest.  Such a tile is copied FLAT instead: thread t takes positions t, t + 256, ... of the
+    // tile's output range and finds the row of a position by a binary search over the rows' offsets in LDS — the same work
+    // for every thread whatever the row lengths.  (Even tiles keep the lane groups: no search per entry.)
+    {
+        int tmax = 0;
+#pragma unroll
+        for (int w = 0; w < GATHER_BLOCK / 64; w++) tmax = max(tmax, wave_max[w]);
+        if (tmax > 64 && (long long)tmax * 64 > tile_total && base + tile_total <= capacity) {   // longest > 4 x mean (256 rows)
+            for (long long p = tid; p < tile_total; p += GATHER_BLOCK) {
+                int lo = 0, hi = GF_TILE - 1;                        // the last row whose offset is <= p
+#pragma unroll
+                for (int step = 0; step < 8; step++) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (off_l[mid] <= (int)p) lo = mid; else hi = mid - 1;
+                }
+                const int at = src_l[lo] + ((int)p - off_l[lo]);
+                new_indices[base + p] = indices[at];
+                if constexpr (HAS_VALUES) new_values[base + p] = values[at];
+            }
+            return;
+        }
+    }
     for (int r0 = grp * GF_ROWS; r0 < GF_TILE; r0 += NG * GF_ROWS) {
         if (r0 != grp * GF_ROWS) rows_of(r0);
         long long d[GF_ROWS];
@@ -652,20 +681,37 @@ extern "C" int mxd_csr_gather_fused(int r, const int32_t *indptr, const int32_t 
     unsigned *ticket = (unsigned *)(g->dev + 8);
     unsigned long long *state = (unsigned long long *)(g->dev + 16);
     const int G = mx::pick_group(avg_row_len > 0 ? avg_row_len : 32.0);
+    // A tile is 256 rows and ONE workgroup copies it: a selection of a few thousand long rows is a handful of workgroups for
+    // 256 CUs (2,000 rows of 500 entries: 8 tiles, 0.118 ms; tools/cliff_hunt_ops.py).  Below 128 tiles of rows that average
+    // 32 entries or more the launch only SIZES the result (capacity -1: every row "does not fit") and the per-row copy
+    // kernel — one lane group per row, r groups — follows in the same stream; new_indptr and the total are the same.
+    const bool few_tiles = ntiles < 128 && avg_row_len >= 32.0 && (double)r * avg_row_len >= 65536.0;   // (small calls: one launch)
+    const long long cap_k = few_tiles ? -1 : (long long)capacity;
     int rc;
     switch (value_dtype) {
         case MX_F64: rc = mx::launch_gather_fused<double, true>(G, r, indptr, indices, values, rows_take, new_indptr, new_indices,
-                                                                new_values, capacity, state, ticket, ticket_base, gen, total_dev,
+                                                                new_values, cap_k, state, ticket, ticket_base, gen, total_dev,
                                                                 g->host_word, ntiles, st); break;
         case MX_LGL: rc = mx::launch_gather_fused<int32_t, true>(G, r, indptr, indices, values, rows_take, new_indptr, new_indices,
-                                                                 new_values, capacity, state, ticket, ticket_base, gen, total_dev,
+                                                                 new_values, cap_k, state, ticket, ticket_base, gen, total_dev,
                                                                  g->host_word, ntiles, st); break;
         case MX_NONE: rc = mx::launch_gather_fused<int32_t, false>(G, r, indptr, indices, nullptr, rows_take, new_indptr,
-                                                                   new_indices, nullptr, capacity, state, ticket, ticket_base, gen,
+                                                                   new_indices, nullptr, cap_k, state, ticket, ticket_base, gen,
                                                                    total_dev, g->host_word, ntiles, st); break;
         default: return mx::set_error("mxd_csr_gather_fused: unsupported value dtype %d", value_dtype);
     }
     if (rc) return rc;
+    if (few_tiles) {
+        switch (value_dtype) {
+            case MX_F64: rc = mx::launch_gather_copy<double, true>(G, r, indptr, indices, values, rows_take, new_indptr, new_indices,
+                                                                   new_values, st, (long long)capacity); break;
+            case MX_LGL: rc = mx::launch_gather_copy<int32_t, true>(G, r, indptr, indices, values, rows_take, new_indptr, new_indices,
+                                                                    new_values, st, (long long)capacity); break;
+            default: rc = mx::launch_gather_copy<int32_t, false>(G, r, indptr, indices, nullptr, rows_take, new_indptr, new_indices,
+                                                                  nullptr, st, (long long)capacity); break;
+        }
+        if (rc) return rc;
+    }
     if (g->last_done) (void)hipEventRecord(g->last_done, st);
     g->ticket_base = ticket_base + (unsigned)ntiles;                  // (the launch was accepted: its tiles will take their tickets)
     // the size arrives in the pinned word while the copies still run: a short spin, then the ordinary wait for the stream

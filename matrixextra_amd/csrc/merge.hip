@@ -27,6 +27,7 @@
 // Roofline: HBM-bound; algorithmic bytes = 2*(12 nnz + 4(m+1)) read + 12 nnz_out + 4(m+1)
 // written; the count pass re-reads the indices (8 nnz) on top of that.
 #include "mx_common.h"
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -73,28 +74,53 @@ __device__ __forceinline__ int group_lower_bound(int tbl, int key, bool &hit)
     return ((lo4 - base4) >> 2) + (at < key ? 1 : 0);
 }
 
-// hits / output length of a row pair that does not fit the lane group (searches in memory); uniform inside the group
+// Row pairs that do NOT fit the lane group (round 5, tools/cliff_hunt_ops.py).  The first version searched every entry of one
+// row in the other row IN MEMORY (lower_bound_dev: ~log2(n) dependent loads per 64 entries) — fine while such pairs are
+// rare, but G follows the MEAN row length and real row lengths are skewed: log-normal rows (sigma 1, mean 32, G = 32) put a
+// third of the pairs there and CSR + CSR ran 1.52 ms where rows of equal length take 0.45; four rows of 50,000 entries:
+// 4.9 ms.  Now a BLOCKED MERGE: the group holds one block of G entries of each row in registers, searches block against
+// block with the cross-lane probes of the fast path, and moves on in the row whose block ends first — every entry is loaded
+// once, coalesced, the next block of either row already in flight; (n1 + n2) / G steps per pair.
+// Block maxima decide: with a_max <= b_max every entry of the A block has met every B entry that could equal it (earlier B
+// blocks end below the A block's first entry), so the A block is complete; otherwise the B block is.
 template <int G, bool INTERSECT>
 __device__ __forceinline__ int count_row_slow(int lg, const int32_t *__restrict__ a_idx, int n1,
                                               const int32_t *__restrict__ b_idx, int n2)
 {
-    const bool a_short = n1 <= n2;
-    const int32_t *__restrict__ q = a_short ? a_idx : b_idx;
-    const int32_t *__restrict__ t = a_short ? b_idx : a_idx;
-    const int nq = a_short ? n1 : n2, nt = a_short ? n2 : n1;
-    int hits = 0;
-    for (int i0 = 0; i0 < nq; i0 += G) {
-        const int i = i0 + lg;
-        bool hit = false;
-        if (i < nq && nt > 0) {
-            const int key = q[i];
-            const int lb = lower_bound_dev(t, nt, key);
-            hit = lb < nt && t[lb] == key;
+    int ia = 0, ib = 0, hits = 0;
+    int a = lg < n1 ? a_idx[lg] : INT_MAX, b = lg < n2 ? b_idx[lg] : INT_MAX;
+    int an = G + lg < n1 ? a_idx[G + lg] : INT_MAX, bn = G + lg < n2 ? b_idx[G + lg] : INT_MAX;
+    while (ia < n1 && ib < n2) {                                       // (uniform inside the group)
+        bool hit;
+        group_lower_bound<G>(b, a, hit);
+        hits += __popcll(group_ballot<G>(hit && ia + lg < n1));
+        const int amax = __shfl(a, min(G, n1 - ia) - 1, G), bmax = __shfl(b, min(G, n2 - ib) - 1, G);
+        if (amax <= bmax) {
+            ia += G; a = an;
+            an = ia + G + lg < n1 ? a_idx[ia + G + lg] : INT_MAX;
+        } else {
+            ib += G; b = bn;
+            bn = ib + G + lg < n2 ? b_idx[ib + G + lg] : INT_MAX;
         }
-        hits += __popcll(group_ballot<G>(hit));
     }
     return INTERSECT ? hits : n1 + n2 - hits;
 }
+
+// VERY long row pairs (either row longer than MergeLong::T entries: a few rows of tens of thousands of entries, the tail of
+// a log-normal or power-law length distribution) would keep one lane group busy long after the rest of the grid has
+// finished (CSR + CSR, m = 1e6, 32 per row, four rows of 50,000 entries: 2.8 ms against 0.44).  The kernels below leave
+// them out and append them to a list; merge_long_count_kernel / merge_long_fill_kernel then give every such pair a whole
+// 512-thread workgroup, which cuts the pair into <= 32 pieces BY VALUE (evenly spaced entries of the longer row are pivots; the
+// pieces of the other row follow by binary search, so equal column ids always meet inside one piece) and runs the blocked
+// merge of count_row_slow / fill_row_slow on one piece per wavefront.
+struct MergeLong {
+    unsigned *count;     // entries of the list
+    int *rows;
+    int T;               // 0 = off
+};
+constexpr int MERGE_LONG_T = 1024;
+constexpr int MERGE_LONG_BLOCK = 512;
+constexpr int MERGE_LONG_MAXP = 32;                   // pieces per pair
 
 // Every lane group sizes COUNT_U consecutive row pairs per call: the row pointers of all of them, then the index loads
 // of all of them, are in flight together (one pair at a time — three dependent loads — ran at 1.8 TB/s).
@@ -108,7 +134,7 @@ template <int G, bool INTERSECT>
 __global__ __launch_bounds__(MERGE_BLOCK)
 void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__restrict__ j1,
                         const int32_t *__restrict__ p2, const int32_t *__restrict__ j2,
-                        int32_t *__restrict__ counts)
+                        int32_t *__restrict__ counts, MergeLong ml)
 {
     const int lg = threadIdx.x % G;
     // G = 64: the lane group is the wavefront, so its rows — and their row pointers — are wave-uniform: read once through
@@ -116,6 +142,7 @@ void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
     const int grp_in_block = G == 64 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : (int)threadIdx.x / G;
     const long long grp = (long long)blockIdx.x * (MERGE_BLOCK / G) + grp_in_block;
     int s1[COUNT_U], n1[COUNT_U], s2[COUNT_U], n2[COUNT_U], a[COUNT_U], b[COUNT_U];
+    bool left[COUNT_U];
 #pragma unroll
     for (int u = 0; u < COUNT_U; u++) {
         const long long row = grp * COUNT_U + u;
@@ -124,6 +151,11 @@ void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
         const int a0 = p1[rs], a1 = p1[rs + 1], b0 = p2[rs], b1 = p2[rs + 1];
         s1[u] = a0; n1[u] = valid ? a1 - a0 : 0;
         s2[u] = b0; n2[u] = valid ? b1 - b0 : 0;
+        left[u] = ml.T != 0 && (n1[u] > ml.T || n2[u] > ml.T);       // (uniform inside the group) -> merge_long_count_kernel
+        if (left[u]) {
+            if (lg == 0) ml.rows[atomicAdd(ml.count, 1u)] = (int)row;
+            n1[u] = n2[u] = 0;
+        }
     }
 #pragma unroll
     for (int u = 0; u < COUNT_U; u++) {
@@ -160,7 +192,7 @@ void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
 #pragma unroll
     for (int u = 0; u < COUNT_U; u++) {
         const long long row = grp * COUNT_U + u;
-        if (row < m && lg == 0) counts[row] = c[u];
+        if (row < m && lg == 0 && !left[u]) counts[row] = c[u];
     }
 }
 
@@ -177,58 +209,70 @@ __device__ __forceinline__ VT combine(VT a, VT b)
     else return r_logical_and(a, b);
 }
 
-// fill of such a row pair at output offset o
+// fill of such a row pair at output offset o: the blocked merge of count_row_slow with positions.  An entry is PLACED in the
+// first step in which the other row's block reaches it (its maximum >= the entry, or that row is exhausted): the entries of
+// that row below it are then the earlier blocks plus the local lower bound, and every coincidence among the entries before
+// it has been seen (hit masks accumulate while a block stays).  Placed entries are a prefix of their block (fa, fb).
 template <int G, int OP, typename VT>
-__device__ __forceinline__ void fill_row_slow(int lg, const int32_t *__restrict__ a_idx, const VT *__restrict__ xa, int n1,
-                                              const int32_t *__restrict__ b_idx, const VT *__restrict__ xb, int n2,
+__device__ __forceinline__ void fill_row_slow(int lg, const int32_t *__restrict__ a_idx, const VT *__restrict__ xa_, int n1,
+                                              const int32_t *__restrict__ b_idx, const VT *__restrict__ xb_, int n2,
                                               long long o, int32_t *__restrict__ jo, VT *__restrict__ xo)
 {
     constexpr bool INTERSECT = (OP == MX_OP_MUL || OP == MX_OP_AND);
     const unsigned long long below = (1ULL << lg) - 1ULL;
-    int hits_before = 0;
-    for (int i0 = 0; i0 < n1; i0 += G) {
-        const int i = i0 + lg;
-        bool hit = false;
-        int lb = 0, key = 0;
-        if (i < n1) {
-            key = a_idx[i];
-            lb = lower_bound_dev(b_idx, n2, key);
-            hit = lb < n2 && b_idx[lb] == key;
+    int ia = 0, ib = 0, fa = 0, fb = 0;
+    int HA = 0, HB = 0;                                                // coincidences among the entries of the blocks left behind
+    unsigned long long hita = 0, hitb = 0;                             // ... among the current blocks' entries, found so far
+    int a = INT_MAX, b = INT_MAX, an = INT_MAX, bn = INT_MAX;
+    VT xa = VT(0), xb = VT(0), xan = VT(0), xbn = VT(0);
+    if (lg < n1) { a = a_idx[lg]; xa = xa_[lg]; }
+    if (lg < n2) { b = b_idx[lg]; xb = xb_[lg]; }
+    if (G + lg < n1) { an = a_idx[G + lg]; xan = xa_[G + lg]; }
+    if (G + lg < n2) { bn = b_idx[G + lg]; xbn = xb_[G + lg]; }
+    while (INTERSECT ? (ia < n1 && ib < n2) : (ia < n1 || ib < n2)) { // (uniform inside the group)
+        const int ca = max(0, min(G, n1 - ia)), cb = max(0, min(G, n2 - ib));
+        const bool va = lg < ca, vb = lg < cb;
+        bool h;
+        const int lb_a = group_lower_bound<G>(b, a, h);                // entries of the B block below a
+        const bool hit_a = h && va;
+        const VT partner = __shfl(xb, lb_a < G ? lb_a : G - 1, G);
+        hita |= group_ballot<G>(hit_a);
+        const int amax = ca > 0 ? __shfl(a, ca - 1, G) : INT_MAX, bmax = cb > 0 ? __shfl(b, cb - 1, G) : INT_MAX;
+        const int ia_c = min(ia, n1), ib_c = min(ib, n2);
+        const bool place_a = va && a <= bmax && lg >= fa;
+        if constexpr (INTERSECT) {
+            if (place_a && hit_a) {
+                const long long pos = o + HA + __popcll(hita & below);
+                jo[pos] = a;
+                xo[pos] = combine<OP, VT>(xa, partner);
+            }
+        } else {
+            if (place_a) {
+                const long long pos = o + ia_c + lg + ib_c + lb_a - (HA + __popcll(hita & below));
+                jo[pos] = a;
+                xo[pos] = hit_a ? combine<OP, VT>(xa, partner) : xa;
+            }
+            const int lb_b = group_lower_bound<G>(a, b, h);            // entries of the A block below b
+            const bool hit_b = h && vb;
+            hitb |= group_ballot<G>(hit_b);
+            if (vb && b <= amax && lg >= fb && !hit_b) {
+                const long long pos = o + ib_c + lg + ia_c + lb_b - (HB + __popcll(hitb & below));
+                jo[pos] = b;
+                if constexpr (OP == MX_OP_SUB) xo[pos] = -xb; else xo[pos] = xb;
+            }
+            fb = __popcll(group_ballot<G>(vb && b <= amax));
         }
-        const unsigned long long hb = group_ballot<G>(hit);
-        const int before = hits_before + __popcll(hb & below);
-        if (i < n1) {
-            if constexpr (INTERSECT) {
-                if (hit) { jo[o + before] = key; xo[o + before] = combine<OP, VT>(xa[i], xb[lb]); }
-            } else {
-                const long long pos = o + i + lb - before;
-                jo[pos] = key;
-                const VT va = xa[i];
-                xo[pos] = hit ? combine<OP, VT>(va, xb[lb]) : va;
-            }
-        }
-        hits_before += __popcll(hb);
-    }
-    if constexpr (!INTERSECT) {
-        hits_before = 0;
-        for (int u0 = 0; u0 < n2; u0 += G) {
-            const int u = u0 + lg;
-            bool hit = false;
-            int lb = 0, key = 0;
-            if (u < n2) {
-                key = b_idx[u];
-                lb = lower_bound_dev(a_idx, n1, key);
-                hit = lb < n1 && a_idx[lb] == key;
-            }
-            const unsigned long long hb = group_ballot<G>(hit);
-            const int before = hits_before + __popcll(hb & below);
-            if (u < n2 && !hit) {
-                const long long pos = o + lb + u - before;
-                jo[pos] = key;
-                const VT vb = xb[u];
-                if constexpr (OP == MX_OP_SUB) xo[pos] = -vb; else xo[pos] = vb;
-            }
-            hits_before += __popcll(hb);
+        fa = __popcll(group_ballot<G>(va && a <= bmax));
+        if (cb == 0 || (ca > 0 && amax <= bmax)) {                     // the A block is complete
+            HA += __popcll(hita); hita = 0; fa = 0;
+            ia += G; a = an; xa = xan;
+            an = INT_MAX; xan = VT(0);
+            if (ia + G + lg < n1) { an = a_idx[ia + G + lg]; xan = xa_[ia + G + lg]; }
+        } else {                                                       // the B block is
+            HB += __popcll(hitb); hitb = 0; fb = 0;
+            ib += G; b = bn; xb = xbn;
+            bn = INT_MAX; xbn = VT(0);
+            if (ib + G + lg < n2) { bn = b_idx[ib + G + lg]; xbn = xb_[ib + G + lg]; }
         }
     }
 }
@@ -241,7 +285,7 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
                        const VT *__restrict__ x1,
                        const int32_t *__restrict__ p2, const int32_t *__restrict__ j2,
                        const VT *__restrict__ x2,
-                       const int32_t *__restrict__ po, int32_t *__restrict__ jo, VT *__restrict__ xo)
+                       const int32_t *__restrict__ po, int32_t *__restrict__ jo, VT *__restrict__ xo, MergeLong ml)
 {
     constexpr bool INTERSECT = (OP == MX_OP_MUL || OP == MX_OP_AND);
     const int lg = threadIdx.x % G;
@@ -259,6 +303,10 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
         o[u] = po[rs];
         s1[u] = a0; n1[u] = valid ? a1 - a0 : 0;
         s2[u] = b0; n2[u] = valid ? b1 - b0 : 0;
+        if (ml.T != 0 && (n1[u] > ml.T || n2[u] > ml.T)) {          // -> merge_long_fill_kernel
+            if (lg == 0) ml.rows[atomicAdd(ml.count, 1u)] = (int)row;
+            n1[u] = n2[u] = 0;                                       // (an empty pair writes nothing)
+        }
     }
 #pragma unroll
     for (int u = 0; u < FILL_U; u++) {
@@ -304,6 +352,97 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
                 if constexpr (OP == MX_OP_SUB) xo[pos] = -xb[u]; else xo[pos] = xb[u];
             }
         }
+    }
+}
+
+// ---- very long row pairs: one workgroup per pair (see MergeLong)
+struct LongPiece { int as, ae, bs, be; };
+// piece k of the pair: entries [k * L, (k + 1) * L) of the longer row and the entries of the other row in the same value range
+__device__ __forceinline__ LongPiece long_piece(const int32_t *__restrict__ A, int n1, const int32_t *__restrict__ B, int n2, int L, int k)
+{
+    const bool a_pivot = n1 >= n2;
+    const int32_t *__restrict__ X = a_pivot ? A : B, *__restrict__ Y = a_pivot ? B : A;
+    const int nx = a_pivot ? n1 : n2, ny = a_pivot ? n2 : n1;
+    const int xs = k * L, xe = min(nx, xs + L);
+    const int ys = k == 0 ? 0 : lower_bound_dev(Y, ny, X[xs]);
+    const int ye = xe >= nx ? ny : lower_bound_dev(Y, ny, X[xe]);
+    LongPiece p;
+    p.as = a_pivot ? xs : ys; p.ae = a_pivot ? xe : ye;
+    p.bs = a_pivot ? ys : xs; p.be = a_pivot ? ye : xe;
+    return p;
+}
+// ~32 pieces per pair (four rounds of the workgroup's 8 wavefronts), at least 256 entries each
+__device__ __forceinline__ int long_piece_len(int n1, int n2)
+{
+    const int nx = max(n1, n2);
+    return max(256, (nx + 31) / 32);
+}
+
+template <bool INTERSECT>
+__global__ __launch_bounds__(MERGE_LONG_BLOCK)
+void merge_long_count_kernel(const int32_t *__restrict__ p1, const int32_t *__restrict__ j1, const int32_t *__restrict__ p2,
+                             const int32_t *__restrict__ j2, int32_t *__restrict__ counts, MergeLong ml)
+{
+    __shared__ int s_hits;
+    const int nlist = (int)*ml.count;
+    const int lane = lane_id(), wave = uniform(threadIdx.x / MX_WAVE);
+    for (int li = blockIdx.x; li < nlist; li += gridDim.x) {
+        const int row = ml.rows[li];
+        const int a0 = p1[row], n1 = p1[row + 1] - a0, b0 = p2[row], n2 = p2[row + 1] - b0;
+        const int L = long_piece_len(n1, n2), P = (max(n1, n2) + L - 1) / L;
+        if (threadIdx.x == 0) s_hits = 0;
+        __syncthreads();
+        for (int k = wave; k < P; k += MERGE_LONG_BLOCK / MX_WAVE) {
+            const LongPiece pc = long_piece(j1 + a0, n1, j2 + b0, n2, L, k);
+            const int h = count_row_slow<64, true>(lane, j1 + a0 + pc.as, pc.ae - pc.as, j2 + b0 + pc.bs, pc.be - pc.bs);
+            if (lane == 0 && h) atomicAdd(&s_hits, h);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) counts[row] = INTERSECT ? s_hits : n1 + n2 - s_hits;
+        __syncthreads();
+    }
+}
+
+template <int OP, typename VT>
+__global__ __launch_bounds__(MERGE_LONG_BLOCK)
+void merge_long_fill_kernel(const int32_t *__restrict__ p1, const int32_t *__restrict__ j1, const VT *__restrict__ x1,
+                            const int32_t *__restrict__ p2, const int32_t *__restrict__ j2, const VT *__restrict__ x2,
+                            const int32_t *__restrict__ po, int32_t *__restrict__ jo, VT *__restrict__ xo, MergeLong ml)
+{
+    constexpr bool INTERSECT = (OP == MX_OP_MUL || OP == MX_OP_AND);
+    __shared__ int s_ph[64];                                          // coincidences per piece (<= 32), then their exclusive prefix
+    const int nlist = (int)*ml.count;
+    const int lane = lane_id(), wave = uniform(threadIdx.x / MX_WAVE);
+    for (int li = blockIdx.x; li < nlist; li += gridDim.x) {
+        const int row = ml.rows[li];
+        const int a0 = p1[row], n1 = p1[row + 1] - a0, b0 = p2[row], n2 = p2[row + 1] - b0;
+        const long long o = po[row];
+        const int L = long_piece_len(n1, n2), P = (max(n1, n2) + L - 1) / L;
+        for (int k = wave; k < P; k += MERGE_LONG_BLOCK / MX_WAVE) {
+            const LongPiece pc = long_piece(j1 + a0, n1, j2 + b0, n2, L, k);
+            const int h = count_row_slow<64, true>(lane, j1 + a0 + pc.as, pc.ae - pc.as, j2 + b0 + pc.bs, pc.be - pc.bs);
+            if (lane == 0) s_ph[k] = h;
+        }
+        __syncthreads();
+        if (wave == 0) {                                              // exclusive prefix over <= 2048 pieces, 64 at a time
+            int carry = 0;
+            for (int base = 0; base < P; base += MX_WAVE) {
+                const int v = base + lane < P ? s_ph[base + lane] : 0;
+                int incl = v;
+#pragma unroll
+                for (int off = 1; off < MX_WAVE; off <<= 1) { const int up = __shfl_up(incl, off, MX_WAVE); if (lane >= off) incl += up; }
+                if (base + lane < P) s_ph[base + lane] = carry + incl - v;
+                carry += __shfl(incl, MX_WAVE - 1, MX_WAVE);
+            }
+        }
+        __syncthreads();
+        for (int k = wave; k < P; k += MERGE_LONG_BLOCK / MX_WAVE) {
+            const LongPiece pc = long_piece(j1 + a0, n1, j2 + b0, n2, L, k);
+            const long long base = INTERSECT ? o + s_ph[k] : o + pc.as + pc.bs - s_ph[k];
+            fill_row_slow<64, OP, VT>(lane, j1 + a0 + pc.as, x1 + a0 + pc.as, pc.ae - pc.as, j2 + b0 + pc.bs, x2 + b0 + pc.bs, pc.be - pc.bs,
+                                      base, jo, xo);
+        }
+        __syncthreads();
     }
 }
 
@@ -503,28 +642,58 @@ void values_elemwise_kernel(int64_t nnz, const VT *__restrict__ a, const VT *__r
 static inline bool op_is_intersect(int op) { return op == MX_OP_MUL || op == MX_OP_AND; }
 
 // G from the mean length of the longer operand's rows; nnz hints < 0 => 32
+// (also sets, for the launch that follows on this thread, from which length on a row pair is left to the one-workgroup-per-
+// pair kernels: 8 mean rows, at least 1024 entries — with a mean row of 500, a 1,024-entry threshold sent every seventh
+// pair of a log-normal matrix there, each to a workgroup with two busy wavefronts: 0.82 ms where the lane groups take 0.27)
+static thread_local int g_merge_long_T = MERGE_LONG_T;
 int merge_group(int m, int64_t nnz1, int64_t nnz2)
 {
+    g_merge_long_T = MERGE_LONG_T;
     if (nnz1 < 0 || nnz2 < 0 || m <= 0) return 32;
     const double avg = (double)(nnz1 > nnz2 ? nnz1 : nnz2) / (double)m;
+    if (8.0 * avg > (double)MERGE_LONG_T) g_merge_long_T = avg < 1e8 ? (int)(8.0 * avg) : INT_MAX;
     return pick_group(avg, 8);
+}
+
+// the list of the very long pairs of one launch (per-thread grow-only scratch; off for small operands: one more launch
+// would show in a 20-us call, and their tails are short)
+static int merge_long_begin(int m, hipStream_t st, MergeLong *ml)
+{
+    ml->count = nullptr; ml->rows = nullptr; ml->T = 0;
+    if (m < 2048) return 0;
+    char *buf = (char *)scratch_buffer(MX_SCRATCH_MERGE_LONG, 64 + (size_t)m * sizeof(int));
+    if (!buf) return set_error("merge: cannot allocate %zu bytes for the list of long rows", 64 + (size_t)m * sizeof(int));
+    scratch_acquire(MX_SCRATCH_MERGE_LONG, st);
+    ml->count = (unsigned *)buf;
+    ml->rows = (int *)(buf + 64);
+    ml->T = g_merge_long_T;
+    MX_HIP(hipMemsetAsync(ml->count, 0, sizeof(unsigned), st));
+    return 0;
 }
 
 int merge_count_launch(int op, int G, int m, const int32_t *p1, const int32_t *j1, const int32_t *p2,
                        const int32_t *j2, int32_t *counts, hipStream_t st)
 {
     const bool isect = op_is_intersect(op);
+    MergeLong ml;
+    if (merge_long_begin(m, st, &ml)) return 1;
 #define MX_CASE(GG)                                                                                   \
     case GG: {                                                                                        \
         const unsigned grid = (unsigned)ceil_div(m, (MERGE_BLOCK / GG) * COUNT_U);                    \
         if (isect) hipLaunchKernelGGL((merge_count_kernel<GG, true>), dim3(grid), dim3(MERGE_BLOCK), 0, st, \
-                                      m, p1, j1, p2, j2, counts);                                     \
+                                      m, p1, j1, p2, j2, counts, ml);                                 \
         else hipLaunchKernelGGL((merge_count_kernel<GG, false>), dim3(grid), dim3(MERGE_BLOCK), 0, st, \
-                                m, p1, j1, p2, j2, counts);                                           \
+                                m, p1, j1, p2, j2, counts, ml);                                       \
         break;                                                                                        \
     }
     switch (G) { MX_CASE(8) MX_CASE(16) MX_CASE(32) MX_CASE(64) default: return set_error("merge: bad group %d", G); }
 #undef MX_CASE
+    if (ml.T) {
+        const unsigned grid = (unsigned)std::min(1024, m / 64 + 1);
+        if (isect) hipLaunchKernelGGL((merge_long_count_kernel<true>), dim3(grid), dim3(MERGE_LONG_BLOCK), 0, st, p1, j1, p2, j2, counts, ml);
+        else hipLaunchKernelGGL((merge_long_count_kernel<false>), dim3(grid), dim3(MERGE_LONG_BLOCK), 0, st, p1, j1, p2, j2, counts, ml);
+        scratch_done(MX_SCRATCH_MERGE_LONG, st);
+    }
     MX_LAUNCH_CHECK();
     return 0;
 }
@@ -533,14 +702,21 @@ template <int OP, typename VT>
 static int merge_fill_op(int G, int m, const int32_t *p1, const int32_t *j1, const void *x1, const int32_t *p2,
                          const int32_t *j2, const void *x2, const int32_t *po, int32_t *jo, void *xo, hipStream_t st)
 {
+    MergeLong ml;
+    if (merge_long_begin(m, st, &ml)) return 1;
 #define MX_CASE(GG)                                                                                   \
     case GG: {                                                                                        \
         const unsigned grid = (unsigned)ceil_div(m, (MERGE_BLOCK / GG) * FILL_U);                     \
         hipLaunchKernelGGL((merge_fill_kernel<GG, OP, VT>), dim3(grid), dim3(MERGE_BLOCK), 0, st, m,  \
-                           p1, j1, (const VT *)x1, p2, j2, (const VT *)x2, po, jo, (VT *)xo);         \
+                           p1, j1, (const VT *)x1, p2, j2, (const VT *)x2, po, jo, (VT *)xo, ml);     \
         break;                                                                                        \
     }
     switch (G) { MX_CASE(8) MX_CASE(16) MX_CASE(32) MX_CASE(64) default: return set_error("merge: bad group %d", G); }
+    if (ml.T) {
+        hipLaunchKernelGGL((merge_long_fill_kernel<OP, VT>), dim3((unsigned)std::min(1024, m / 64 + 1)), dim3(MERGE_LONG_BLOCK), 0, st,
+                           p1, j1, (const VT *)x1, p2, j2, (const VT *)x2, po, jo, (VT *)xo, ml);
+        scratch_done(MX_SCRATCH_MERGE_LONG, st);
+    }
 #undef MX_CASE
     MX_LAUNCH_CHECK();
     return 0;

@@ -161,7 +161,10 @@ static AutoCost spmm_auto_cost(int m, int n, int K, int64_t nnz, int sz, bool ke
     const double pairs = std::ceil(m / 64.0) * slabs, fill = pairs / (pairs + 2400.0);
     const double sweep_rate = (plan_panels > 1.0 ? 19.0 : 23.5) * fill;
     c.planned_us = (double)nnz * slabs * 128.0 / rate(plan_panels, sweep_rate, 8.5 * fill) +
-                   0.005e-3 * m * slabs * plan_panels + 15.0 + (keep_plan ? 0.0 : 36.0 + 6e-6 * (double)nnz);
+                   0.005e-3 * m * slabs * plan_panels + 15.0 +
+                   // (rows of uneven length: the count pass reads the indices, octets are dealt and flagged — tools/zipf_map.py,
+                   // m = 1e6, 33 per row, log-normal sigma 1: rebuilt 0.77 ms against 0.28 with the plan kept)
+                   (keep_plan ? 0.0 : 36.0 + (profile_cv() > 0.2 ? 15e-6 : 6e-6) * (double)nnz);
     // the LDS-tile kernel (spmm_tile.hip, round 5): its own model; a caller that does not vouch for column-sorted rows pays
     // the sortedness pass (one read of the indices) on top
     c.tile_us = tile_est_us(m, n, K, sz, avg, colmajor, nullptr) + (rows_sorted ? 0.0 : 3.0 + (double)nnz * 4.0 / 3e6);

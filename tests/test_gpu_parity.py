@@ -194,6 +194,49 @@ def test_logical_or_xor_and(gpu, m, K, d1, d2):
                       O.logicalor_csr_elemwise(p1, p1, j1, j1, x1, x1[::-1].copy(), False))
 
 
+def _csr_with_row_lengths(lens, K, rng, dtype="d"):
+    p = np.zeros(len(lens) + 1, dtype=np.int32); p[1:] = np.cumsum(lens)
+    j = np.empty(int(p[-1]), dtype=np.int32)
+    for r, l in enumerate(lens):
+        if l:
+            j[p[r]:p[r + 1]] = np.sort(rng.choice(K, size=int(l), replace=False)).astype(np.int32)
+    x = rng.integers(0, 2, size=j.size).astype(np.int32) if dtype == "l" else rng.normal(size=j.size).round(3)
+    return p, j, x
+
+
+@pytest.mark.parametrize("m", [300, 2500])
+def test_merge_long_and_very_long_row_pairs(gpu, m):
+    """Row pairs that do not fit a lane group take the blocked merge (merge.hip count_row_slow / fill_row_slow); with >= 2048
+    rows, pairs with a row of more than 1024 entries are left to merge_long_count_kernel / merge_long_fill_kernel (pieces by
+    value, one workgroup per pair).  Lengths around every boundary (G, block multiples, 1024, 1025, several pieces), long
+    against short / empty / long, heavy and no overlap; every operation, structure and values bit for bit."""
+    rng = np.random.default_rng(77 + m)
+    K = 40_000
+    special = [0, 1, 63, 64, 65, 127, 128, 129, 200, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 5000, 20_000, 39_999]
+    l1 = rng.integers(0, 30, size=m); l2 = rng.integers(0, 30, size=m)
+    rows = rng.choice(m, size=3 * len(special), replace=False)
+    for q, r in enumerate(rows):
+        a, b = special[q % len(special)], special[(q * 7 + 3) % len(special)]
+        if q < len(special):
+            l1[r], l2[r] = a, b                                   # long against whatever
+        elif q < 2 * len(special):
+            l1[r], l2[r] = b, a
+        else:
+            l1[r], l2[r] = a, a                                   # equally long
+    p1, j1, x1 = _csr_with_row_lengths(l1, K, rng)
+    p2, j2, x2 = _csr_with_row_lengths(l2, K, rng)
+    r0, r1 = int(rows[-1]), int(rows[-2])                         # full overlap (same columns) / interleaved without any
+    j2[p2[r0]:p2[r0 + 1]] = j1[p1[r0]:p1[r0] + (p2[r0 + 1] - p2[r0])] if l1[r0] >= l2[r0] else j2[p2[r0]:p2[r0 + 1]]
+    for sub in (False, True):
+        assert_list_equal(G.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub), O.add_csr_elemwise(p1, p2, j1, j2, x1, x2, sub))
+    assert_list_equal(G.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2), O.multiply_csr_elemwise(p1, p2, j1, j2, x1, x2))
+    b1, b2 = (x1 > 0).astype(np.int32), (x2 > 0).astype(np.int32)
+    for xor in (False, True):
+        assert_list_equal(G.logicalor_csr_elemwise(p1, p2, j1, j2, b1, b2, xor), O.logicalor_csr_elemwise(p1, p2, j1, j2, b1, b2, xor))
+    assert_list_equal(G.logicaland_csr_elemwise(p1, p2, j1, j2, b1, b2), O.logicaland_csr_elemwise(p1, p2, j1, j2, b1, b2))
+    del r1
+
+
 def test_merge_mid_size_overlap(gpu):
     # cfg4-shaped, scaled down: fixed 50/row, ~50% shared pattern
     m, K = 20_000, 20_000

@@ -202,6 +202,57 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
 
     section("merges_cfg4", _merges_cfg4)
 
+    # ---- configs[3] / configs[2] with rows of uneven length (tools/cliff_hunt_ops.py): CSR + CSR and the
+    # gather of 200k rows on log-normal row lengths (sigma 1) and with a few very long rows — the lane-group widths follow the
+    # MEAN row length, what does not fit takes the blocked merge / the one-workgroup-per-pair kernels / the flat copy
+    def _skewed_rows_ops():
+        m4 = K4 = 2_000_000
+        out_ = {}
+        for tag, sigma, giants in (("lognormal_sigma1", 1.0, 0), ("four_rows_of_50000", 0.0, 4)):
+            ops = []
+            for seed in (synth.SEED_A, synth.SEED_A2):
+                pz, jz, xz = synth.device_csr_zipf(m4, K4, 50, alpha=0.0, sigma=sigma, seed=seed)
+                if giants:                                  # splice very long rows in: rebuild from per-row lengths
+                    lens = (pz[1:] - pz[:-1]).to(torch.int64)
+                    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+                    at = torch.randint(0, m4, (giants,), device="cuda", generator=g)
+                    lens[at] = 50_000
+                    rowid = torch.repeat_interleave(torch.arange(m4, dtype=torch.int64, device="cuda"), lens)
+                    key = torch.unique(rowid * K4 + torch.randint(0, K4, (int(lens.sum().item()),), dtype=torch.int64, device="cuda", generator=g))
+                    rowid = key // K4
+                    jz = (key - rowid * K4).to(torch.int32).contiguous()
+                    pz = torch.zeros(m4 + 1, dtype=torch.int64, device="cuda")
+                    torch.cumsum(torch.bincount(rowid, minlength=m4), 0, out=pz[1:])
+                    pz = pz.to(torch.int32)
+                    xz = torch.rand(jz.numel(), dtype=torch.float64, device="cuda", generator=g) * 2.0 - 1.0
+                    del lens, rowid, key
+                ops.append(D.DeviceCSR(pz, jz, xz, m4, K4, int(jz.numel())))
+            A1, A2 = ops
+            R = D.csr_elemwise(_lib.MX_OP_ADD, A1, A2)
+            lens1 = (A1.indptr[1:] - A1.indptr[:-1])
+            long_rows = torch.nonzero(lens1 > 1024).flatten()[:8].cpu().numpy().tolist()
+            for r_ in [0, 1, 12345] + long_rows:                     # sampled rows, the long ones among them, against the oracle
+                sl = lambda A: (A.indptr[r_:r_ + 2].cpu().numpy() - int(A.indptr[r_]), A.indices[int(A.indptr[r_]):int(A.indptr[r_ + 1])].cpu().numpy(),
+                                A.values[int(A.indptr[r_]):int(A.indptr[r_ + 1])].cpu().numpy())
+                (q1, c1, v1), (q2, c2, v2), (q3, c3, v3) = sl(A1), sl(A2), sl(R)
+                o = O.add_csr_elemwise(q1.astype(np.int32), q2.astype(np.int32), c1, c2, v1, v2, False)
+                assert np.array_equal(o["indices"], c3) and np.array_equal(o["values"], v3), f"skewed CSR + CSR differs from the oracle in row {r_}"
+            t_add = timeit(lambda: D.csr_elemwise(_lib.MX_OP_ADD, A1, A2), reps=5)
+            t_mul = timeit(lambda: D.csr_elemwise(_lib.MX_OP_MUL, A1, A2), reps=5)
+            g = torch.Generator(device="cuda"); g.manual_seed(3)
+            rows_t = torch.randint(0, m4, (200_000,), dtype=torch.int32, device="cuda", generator=g)
+            t_g = timeit(lambda: D.csr_gather_rows(A1, rows_t), reps=10)
+            byts = 2 * 4 * (m4 + 1) + 12 * (A1.nnz + A2.nnz) + 12 * R.nnz + 4 * (m4 + 1)
+            out_[tag] = {"nnz_in": [A1.nnz, A2.nnz], "longest_row": int(lens1.max().item()),
+                         "csr_add_csr": {"ms": round(t_add * 1e3, 4), "roofline": roofline(byts, t_add, scope="whole call")},
+                         "csr_mul_csr_ms": round(t_mul * 1e3, 4), "gather_200k_rows_ms": round(t_g * 1e3, 4),
+                         "parity": "sampled rows (the longest among them) bit-exact vs the oracle"}
+            del A1, A2, R, ops
+            torch.cuda.empty_cache()
+        res["skewed_rows_cfg4"] = out_
+
+    section("skewed_rows_ops", _skewed_rows_ops)
+
     # ---- end to end through the export-level C-ABI (host pointers in, host matrix out: what one .Call from R costs;
     # never the headline `value`)
     # The result comes from plain libc malloc, untouched, as R's allocVector hands it over (no huge-page advice: on a

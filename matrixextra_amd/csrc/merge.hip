@@ -645,13 +645,15 @@ static inline bool op_is_intersect(int op) { return op == MX_OP_MUL || op == MX_
 // (also sets, for the launch that follows on this thread, from which length on a row pair is left to the one-workgroup-per-
 // pair kernels: 8 mean rows, at least 1024 entries — with a mean row of 500, a 1,024-entry threshold sent every seventh
 // pair of a log-normal matrix there, each to a workgroup with two busy wavefronts: 0.82 ms where the lane groups take 0.27)
-static thread_local int g_merge_long_T = MERGE_LONG_T;
+static thread_local int g_merge_long_T = 0;
 int merge_group(int m, int64_t nnz1, int64_t nnz2)
 {
-    g_merge_long_T = MERGE_LONG_T;
+    g_merge_long_T = 0;                                               // (off: sizes unknown, or a small merge — below)
     if (nnz1 < 0 || nnz2 < 0 || m <= 0) return 32;
     const double avg = (double)(nnz1 > nnz2 ? nnz1 : nnz2) / (double)m;
-    if (8.0 * avg > (double)MERGE_LONG_T) g_merge_long_T = avg < 1e8 ? (int)(8.0 * avg) : INT_MAX;
+    // from 2^21 entries on: the list costs a memset, a launch and the scratch's stream bookkeeping per pass — ~20 us, which
+    // showed as +15 % on a 0.29-ms merge of 1e5 entries (bench.py export_small_calls)
+    if (nnz1 + nnz2 >= (1LL << 21)) g_merge_long_T = 8.0 * avg > (double)MERGE_LONG_T ? (avg < 1e8 ? (int)(8.0 * avg) : INT_MAX) : MERGE_LONG_T;
     return pick_group(avg, 8);
 }
 
@@ -660,7 +662,7 @@ int merge_group(int m, int64_t nnz1, int64_t nnz2)
 static int merge_long_begin(int m, hipStream_t st, MergeLong *ml)
 {
     ml->count = nullptr; ml->rows = nullptr; ml->T = 0;
-    if (m < 2048) return 0;
+    if (m < 2048 || g_merge_long_T == 0) return 0;
     char *buf = (char *)scratch_buffer(MX_SCRATCH_MERGE_LONG, 64 + (size_t)m * sizeof(int));
     if (!buf) return set_error("merge: cannot allocate %zu bytes for the list of long rows", 64 + (size_t)m * sizeof(int));
     scratch_acquire(MX_SCRATCH_MERGE_LONG, st);

@@ -223,8 +223,13 @@ def test_merge_long_and_very_long_row_pairs(gpu, m):
             l1[r], l2[r] = b, a
         else:
             l1[r], l2[r] = a, a                                   # equally long
+    if m >= 2048:                                                 # (the one-workgroup-per-pair kernels start at 2^21 entries)
+        more = np.setdiff1d(np.arange(m), rows)[:90]
+        l1[more] = rng.integers(8_000, 16_000, size=more.size)
+        l2[more] = np.where(rng.random(more.size) < 0.5, rng.integers(8_000, 16_000, size=more.size), rng.integers(0, 40, size=more.size))
     p1, j1, x1 = _csr_with_row_lengths(l1, K, rng)
     p2, j2, x2 = _csr_with_row_lengths(l2, K, rng)
+    assert m < 2048 or j1.size + j2.size >= 1 << 21
     r0, r1 = int(rows[-1]), int(rows[-2])                         # full overlap (same columns) / interleaved without any
     j2[p2[r0]:p2[r0 + 1]] = j1[p1[r0]:p1[r0] + (p2[r0 + 1] - p2[r0])] if l1[r0] >= l2[r0] else j2[p2[r0]:p2[r0 + 1]]
     for sub in (False, True):

@@ -353,6 +353,11 @@ typedef enum { MX_SPMV_AUTO = 0, MX_SPMV_GROUP = 1, MX_SPMV_TILE = 2, MX_SPMV_FL
 int mxd_spmv_csr_dvec_ex(int m, int K, int64_t nnz,
                          const int32_t *indptr, const int32_t *indices, const double *values,
                          const void *v, int v_dtype, void *y, int algo, void *stream);
+/* ... with the matrix profile (mxd_csr_profile, MX_PROFILE_LEN floats; NULL = sizes only): AUTO also takes FLAT from 2^20
+ * entries on when the longest row has 16k entries or more (a tail for one lane group, nothing special for equal slices) */
+int mxd_spmv_csr_dvec_ex2(int m, int K, int64_t nnz,
+                          const int32_t *indptr, const int32_t *indices, const double *values,
+                          const void *v, int v_dtype, void *y, int algo, const float *profile, void *stream);
 
 /* Planned SpMV for repeated products with the same matrix (csrc/spmv_plan.hip): the plan regroups A's entries by
  * (block of 4096 rows, panel of 6144 columns) so that the kernel can keep the panel of v it needs in LDS instead of

@@ -11,7 +11,7 @@
 // (coalesced (j, a) reads, gathered v[j] reads served by L2 — v is 0.8 MB for
 // the headline config), then a butterfly __shfl_xor reduction inside the group.
 // HBM-bound: algorithmic bytes = 4(m+1) + 12 nnz + s*K + s*m.
-#include "mx_common.h"
+#include "spmm_common.h"     // (ProfileScope, profile_longest_over_mean: the matrix profile AUTO reads)
 #include <cstdlib>
 
 namespace mx {
@@ -173,7 +173,12 @@ int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t 
     // rows on (1e5 x 32: 0.020 / 0.024; 1e5 x 500: 0.328 / 0.276; 1e6 x 32: 0.190 / 0.164) — where it stays, because its
     // sums are the reference's loop bit for bit
     // (and from 2^22 entries: at 1e5 x 32 — 3.2 M entries — the lane-group kernel took 0.020 ms, the flat one 0.024-0.029)
-    if (algo == MX_SPMV_FLAT || (algo == MX_SPMV_AUTO && flat_ok && nnz >= ((int64_t)1 << 22) && m >= 32768))
+    // With the matrix profile in scope (mxd_spmv_csr_dvec_ex2): a row of 16k entries or more is a tail for the lane-group
+    // kernel — one group walks it — and nothing special for the flat kernel's equal slices (tools/spmv_skew_probe.py, 3e4 x
+    // 1e5, 200 per row: four rows of 50,000 entries 0.237 ms against 0.087, log-normal sigma 1.5 0.152 against 0.065)
+    const bool long_rows = algo == MX_SPMV_AUTO && flat_ok && nnz >= ((int64_t)1 << 20) && m > 0 &&
+                           profile_longest_over_mean() * ((double)nnz / m) >= 16384.0;
+    if (algo == MX_SPMV_FLAT || long_rows || (algo == MX_SPMV_AUTO && flat_ok && nnz >= ((int64_t)1 << 22) && m >= 32768))
         return spmv_flat_launch(m, nnz, indptr, indices, values, v, v_dtype, y, st);
     const int G = nnz < 0 ? 32 : pick_group((double)nnz / (double)(m > 0 ? m : 1));
     switch (v_dtype) {
@@ -204,4 +209,13 @@ extern "C" int mxd_spmv_csr_dvec_ex(int m, int K, int64_t nnz, const int32_t *in
     if (m == 0) return 0;
     MX_REQUIRE(indptr && y, "mxd_spmv_csr_dvec_ex: null pointer");
     return mx::spmv_launch(m, K, nnz, indptr, indices, values, v, v_dtype, y, algo, mx::as_stream(stream));
+}
+
+// the same with the matrix profile (mxd_csr_profile) in scope: AUTO then knows about very long rows
+extern "C" int mxd_spmv_csr_dvec_ex2(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices,
+                                     const double *values, const void *v, int v_dtype, void *y, int algo, const float *profile,
+                                     void *stream)
+{
+    mx::ProfileScope scope(profile);
+    return mxd_spmv_csr_dvec_ex(m, K, nnz, indptr, indices, values, v, v_dtype, y, algo, stream);
 }

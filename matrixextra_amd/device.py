@@ -254,8 +254,10 @@ def spmv(A: DeviceCSR, v: torch.Tensor, v_dtype=None, out=None, algo: int = 0):
     if out is None:
         out = torch.empty(A.m, dtype=odt, device=v.device)
     assert int(v.numel()) == A.K and v.is_contiguous()
-    check(lib.mxd_spmv_csr_dvec_ex(C.c_int(A.m), C.c_int(A.K), C.c_int64(A.nnz), _dp(A.indptr), _dp(A.indices),
-                                   _dp(A.values), _dp(v), C.c_int(v_dtype), _dp(out), C.c_int(algo), _stream()))
+    # (AUTO reads the matrix profile — cached on A — for very long rows, once the product is large enough for that to matter)
+    prof = A.profile() if algo == 0 and A.nnz >= (1 << 20) else None
+    check(lib.mxd_spmv_csr_dvec_ex2(C.c_int(A.m), C.c_int(A.K), C.c_int64(A.nnz), _dp(A.indptr), _dp(A.indices),
+                                    _dp(A.values), _dp(v), C.c_int(v_dtype), _dp(out), C.c_int(algo), prof, _stream()))
     return out
 
 

@@ -117,3 +117,29 @@ def test_auto_with_long_rows_matches_the_oracle_at_size(gpu):
         s, e = p[r], p[r + 1]
         want = x[s:e] @ B[j[s:e]]
         np.testing.assert_allclose(got[r], want, rtol=1e-11, atol=1e-11)
+
+
+def test_spmv_auto_with_the_profile_takes_the_flat_kernel_for_very_long_rows(gpu):
+    """mxd_spmv_csr_dvec_ex2: with the matrix profile AUTO knows about rows of 16k entries or more (one lane group's tail)
+    and runs the flat kernel from 2^20 entries on; flat and lane-group kernels both give the reference's sums
+    (src/matmul.cpp:395-416), so the result is the oracle's whichever runs."""
+    rng = np.random.default_rng(4)
+    m, K = 20_000, 60_000
+    lens = np.full(m, 60, dtype=np.int64)
+    lens[[7, 9_000, m - 1]] = [50_000, 20_000, 30_000]
+    p = np.zeros(m + 1, dtype=np.int32); p[1:] = np.cumsum(lens)
+    j = np.empty(int(p[-1]), dtype=np.int32)
+    for r in range(m):
+        j[p[r]:p[r + 1]] = np.sort(rng.choice(K, size=int(lens[r]), replace=False))
+    x = rng.uniform(-1, 1, size=j.size)
+    v = rng.normal(size=K)
+    A = D.DeviceCSR.from_host(p, j, x, K)
+    assert A.nnz >= 1 << 20 and A.profile()[33] * A.profile()[34] >= 16384
+    vd = torch.from_numpy(v).cuda()
+    got_auto = D.spmv(A, vd).cpu().numpy()
+    got_flat = D.spmv(A, vd, algo=3).cpu().numpy()
+    got_group = D.spmv(A, vd, algo=1).cpu().numpy()
+    assert np.array_equal(got_auto, got_flat)                      # AUTO ran the flat kernel (bitwise its sums)
+    want = np.array([np.dot(x[p[r]:p[r + 1]], v[j[p[r]:p[r + 1]]]) for r in range(m)])
+    np.testing.assert_allclose(got_auto, want, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(got_group, want, rtol=1e-11, atol=1e-11)

@@ -14,7 +14,7 @@ bash tools/profile.sh $W/cfg2 1 -- --steps 20 --warmup 5 --no-extras --no-cpu-ba
 python3 tools/prof_summary.py $W/cfg2 $O/${RND}_cfg2_spmm "spmm_plan_kernel" cfg2-default > /dev/null
 # (b) the default command (extras included): the kernels of SpMV / gather / merges / sortedness — WITHOUT the legs that run
 # the same kernels on other (small) workloads, which are profiled on their own in (b2)
-export MXGPU_BENCH_EXTRAS_SKIP=vignette_loop,vignette_dense_csc,spmm_short_rows,export_small_calls,spmm_zipf
+export MXGPU_BENCH_EXTRAS_SKIP=vignette_loop,vignette_dense_csc,spmm_short_rows,export_small_calls,spmm_zipf,skewed_rows_ops,cfg5_shard_skewed
 bash tools/profile.sh $W/extras 1 -- --steps 10 --warmup 3 --no-cpu-baseline > $O/log_extras.txt 2>&1
 unset MXGPU_BENCH_EXTRAS_SKIP
 python3 tools/prof_summary_multi.py $W/extras $O/${RND}_extras extras-default spmv_flat_kernel slice_rows_kernel spmv_plan_kernel \

@@ -375,7 +375,7 @@ __device__ __forceinline__ LongPiece long_piece(const int32_t *__restrict__ A, i
 __device__ __forceinline__ int long_piece_len(int n1, int n2)
 {
     const int nx = max(n1, n2);
-    return max(256, (nx + 31) / 32);
+    return max(256, (nx + MERGE_LONG_MAXP - 1) / MERGE_LONG_MAXP);
 }
 
 template <bool INTERSECT>
@@ -410,7 +410,8 @@ void merge_long_fill_kernel(const int32_t *__restrict__ p1, const int32_t *__res
                             const int32_t *__restrict__ po, int32_t *__restrict__ jo, VT *__restrict__ xo, MergeLong ml)
 {
     constexpr bool INTERSECT = (OP == MX_OP_MUL || OP == MX_OP_AND);
-    __shared__ int s_ph[64];                                          // coincidences per piece (<= 32), then their exclusive prefix
+    static_assert(MERGE_LONG_MAXP <= MX_WAVE, "one wavefront scans the pieces");
+    __shared__ int s_ph[MX_WAVE];                                     // coincidences per piece (<= MERGE_LONG_MAXP), then their exclusive prefix
     const int nlist = (int)*ml.count;
     const int lane = lane_id(), wave = uniform(threadIdx.x / MX_WAVE);
     for (int li = blockIdx.x; li < nlist; li += gridDim.x) {

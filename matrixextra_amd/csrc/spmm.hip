@@ -203,13 +203,14 @@ static int spmm_auto_algo(int m, int n, int K, int64_t nnz, int dense_dtype, con
 // by block (spmm_block): column-major C, several panels, several segments and narrow lane groups all reassociate, so a
 // geometry re-derived from every block's own m, n and nnz would make the last bits of one product depend on how the export
 // pipeline, or the device list, cut it (round 4's advisor finding)
-static thread_local int g_family_segments = 0, g_family_panels = 0;
+static thread_local int g_family_segments = 0, g_family_panels = 0, g_family_long_piece = 0;
 int spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
                      int colmajor)
 {
     const int family = spmm_auto_algo(m, n, K, nnz, dense_dtype, B, ldb, C, ldc, colmajor, false);
-    g_family_segments = g_family_panels = 0;
+    g_family_segments = g_family_panels = g_family_long_piece = 0;
     if (family == MX_SPMM_ROWSPLIT && nnz >= 0 && m > 0) {
+        g_family_long_piece = nnz > 0 ? rowsplit_long_piece(m, nnz) : 0;   // (the caller's profile is in scope here, not in the blocks)
         const int sz = dense_dtype == MX_F64 ? 8 : 4;
         const double avg = (double)nnz / m;
         g_family_panels = rowsplit_panels(m, n, K, sz, avg);
@@ -228,9 +229,10 @@ static int device_nnz(const int32_t *indptr, int m, hipStream_t st, int64_t *nnz
     *nnz = (int64_t)last - first;
     return 0;
 }
+// long_piece: the long-rows path's piece length chosen for the WHOLE product (spmm_auto_family), -1 = from the profile in scope
 static int run_rowsplit(int m, int n, int K, int64_t nnz, int segments, int panels, int rows_sorted_hint, const int32_t *indptr,
                         const int32_t *indices, const double *values, const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype,
-                        int colmajor, hipStream_t st)
+                        int colmajor, hipStream_t st, int long_piece_family = -1)
 {
     (void)rows_sorted_hint;                    // (the cursor kernel checks every row itself)
     const int sz = dense_dtype == MX_F64 ? 8 : 4;
@@ -242,7 +244,7 @@ static int run_rowsplit(int m, int n, int K, int64_t nnz, int segments, int pane
         if (segments == 0) segments = rowsplit_segments(m, n, sz, avg / panels);
     }
     if (segments < 0) segments = 0;           // rowsplit_spmm's code for the row-group form
-    const int long_piece = nnz > 0 ? rowsplit_long_piece(m, nnz) : 0;      // (needs the matrix profile: 0 without one)
+    const int long_piece = nnz <= 0 ? 0 : (long_piece_family >= 0 ? long_piece_family : rowsplit_long_piece(m, nnz));   // (0 without a profile)
     // (mxd_spmm_last_kernel: set by the launch itself, spmm_rowsplit.hip launch_one — the form can still change there)
     if (dense_dtype == MX_F64)
         return rowsplit_spmm<double>(m, n, K, segments, panels, indptr, indices, values, (const double *)B, ldb, (double *)C, ldc, colmajor, st,
@@ -259,7 +261,7 @@ int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, con
 {
     if (family == MX_SPMM_ROWSPLIT)
         return run_rowsplit(m, n, K, nnz, from_auto ? g_family_segments : 0, from_auto ? g_family_panels : npanels, 0, indptr, indices, values,
-                            B, ldb, C, ldc, dense_dtype, colmajor, st);
+                            B, ldb, C, ldc, dense_dtype, colmajor, st, from_auto ? g_family_long_piece : -1);
     if (family == MX_SPMM_TILE && from_auto)
         return mxd_spmm_csr_dense_ex2(m, n, K, nnz, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, family, 0, 0, 0, st);
     if (family == MX_SPMM_PLANNED && from_auto) {

@@ -143,3 +143,30 @@ def test_spmv_auto_with_the_profile_takes_the_flat_kernel_for_very_long_rows(gpu
     want = np.array([np.dot(x[p[r]:p[r + 1]], v[j[p[r]:p[r + 1]]]) for r in range(m)])
     np.testing.assert_allclose(got_auto, want, rtol=1e-11, atol=1e-11)
     np.testing.assert_allclose(got_group, want, rtol=1e-11, atol=1e-11)
+
+
+def test_export_of_a_matrix_with_giant_rows_takes_the_long_rows_path(gpu):
+    """The export level profiles the caller's host arrays itself (api.hip host_csr_profile) and fixes the piece length for
+    the WHOLE product before it runs block by block: tcrossprod_csr_dense on 1e5 rows of 64 entries with four rows of
+    10,000 (AUTO: the row-split kernel) against oracle rows, the giant ones among them."""
+    from matrixextra_amd import exports as G
+    rng = np.random.default_rng(17)
+    m, K, n = 100_000, 10_000, 64
+    lens = np.full(m, 64, dtype=np.int64)
+    giant = np.array([3, 40_000, 77_777, m - 1])
+    lens[giant] = 10_000
+    row = np.repeat(np.arange(m, dtype=np.int64), lens)
+    key = np.unique(row * K + rng.integers(0, K, size=row.size))
+    row = key // K
+    j = (key - row * K).astype(np.int32)
+    p = np.zeros(m + 1, dtype=np.int64); np.cumsum(np.bincount(row, minlength=m), out=p[1:])
+    p = p.astype(np.int32)
+    x = rng.uniform(-1, 1, size=j.size)
+    Y = np.asfortranarray(rng.normal(size=(n, K)))                 # tcrossprod: X %*% t(Y)
+    got = G.tcrossprod_csr_dense_numeric(p, j, x, Y)
+    assert _lib.load().mxd_spmm_last_kernel().decode() == "spmm_rowsplit_kernel"
+    rows, pieces = _long_counts()
+    assert rows == 4 and pieces >= 4 * 10
+    for r in np.concatenate([giant, rng.integers(0, m, size=100)]):
+        s, e = p[r], p[r + 1]
+        np.testing.assert_allclose(got[r], x[s:e] @ Y[:, j[s:e]].T, rtol=1e-11, atol=1e-11)

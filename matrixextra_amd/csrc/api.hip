@@ -64,6 +64,7 @@ int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, con
                const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, int npanels, hipStream_t st);
 int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
                 const void *v, int v_dtype, void *y, int algo, hipStream_t st);
+void merge_group_widen(bool on);                                     // merge.hip: the next merges of this thread take one lane-group width up
 bool spmv_flat_ok(int m, int64_t nnz, const int32_t *indices, const double *values);
 // xfer.hip: synchronous host <-> device copies, pipelined through pinned slots + a host copy pool when large
 int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes);
@@ -1745,6 +1746,18 @@ int mx_csr_elemwise_begin(int op, int nrows, const int32_t *indptr1, const int32
     res->info.values_dtype = lgl ? MX_LGL : MX_F64;
     res->info.alias_structure = 0;
     int rc = 0;
+    // The kernels' lane-group width follows the mean row length; when more than 8 % of the row pairs would not fit it (rows of
+    // uneven length: the row pointers are right here) the launches below take the next width (merge.hip merge_group_widen).
+    struct Widen { bool on = false; ~Widen() { if (on) mx::merge_group_widen(false); } } widen;
+    if (nrows >= 4096 && nnz1 + nnz2 >= (1LL << 20) && indptr1 && indptr2) {
+        const double avg = (double)std::max(nnz1, nnz2) / (double)nrows;
+        const int G = mx::pick_group(avg, 8);
+        if (G < 64) {
+            int64_t over = 0;
+            for (int r = 0; r < nrows; r++) over += (indptr1[r + 1] - indptr1[r] > G) | (indptr2[r + 1] - indptr2[r] > G);
+            if (over * 100 > (int64_t)nrows * 8) { mx::merge_group_widen(true); widen.on = true; }
+        }
+    }
     do {
         // identical-structure fast paths: pointer identity, as operators.cpp:104-108 / :343-346 test it
         if (nnz1 == nnz2 && indptr1 == indptr2 && indices1 == indices2) {

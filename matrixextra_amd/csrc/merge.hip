@@ -647,6 +647,12 @@ static inline bool op_is_intersect(int op) { return op == MX_OP_MUL || op == MX_
 // pair kernels: 8 mean rows, at least 1024 entries — with a mean row of 500, a 1,024-entry threshold sent every seventh
 // pair of a log-normal matrix there, each to a workgroup with two busy wavefronts: 0.82 ms where the lane groups take 0.27)
 static thread_local int g_merge_long_T = 0;
+// The export level has the row pointers on the host and tells the launches that follow on this thread when many row pairs
+// would not fit the width the MEAN row length suggests (api.hip mx_csr_elemwise_begin): one size up then — measured,
+// CSR + CSR at 1e6 x 1e5, mean 32: rows of equal length 0.462 -> 0.51 ms, log-normal rows 0.78 -> 0.58 (sigma 0.5),
+// 0.96 -> 0.74 (sigma 1).  Off by default and after the export.
+static thread_local bool g_merge_widen = false;
+void merge_group_widen(bool on) { g_merge_widen = on; }
 int merge_group(int m, int64_t nnz1, int64_t nnz2)
 {
     g_merge_long_T = 0;                                               // (off: sizes unknown, or a small merge — below)
@@ -655,7 +661,8 @@ int merge_group(int m, int64_t nnz1, int64_t nnz2)
     // from 2^21 entries on: the list costs a memset, a launch and the scratch's stream bookkeeping per pass — ~20 us, which
     // showed as +15 % on a 0.29-ms merge of 1e5 entries (bench.py export_small_calls)
     if (nnz1 + nnz2 >= (1LL << 21)) g_merge_long_T = 8.0 * avg > (double)MERGE_LONG_T ? (avg < 1e8 ? (int)(8.0 * avg) : INT_MAX) : MERGE_LONG_T;
-    return pick_group(avg, 8);
+    const int G = pick_group(avg, 8);
+    return g_merge_widen && G < 64 ? 2 * G : G;
 }
 
 // the list of the very long pairs of one launch (per-thread grow-only scratch; off for small operands: one more launch

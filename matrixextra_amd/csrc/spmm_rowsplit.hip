@@ -613,12 +613,21 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
     LongRows lr = {nullptr, nullptr, nullptr, nullptr, 0};
     real_t *E = nullptr;
     g_longrows_last = nullptr;
+    // (the bound, not the need: sized for nnz / piece long rows.  Above 1 GiB the pieces grow — fewer of them — and beyond
+    // 8192 entries per piece the path is dropped; a failed allocation drops it as well: the product itself never fails for it)
+    while (long_piece > 0 && nnz > long_piece &&
+           2 * ((size_t)(nnz / long_piece) + 1) * ((size_t)n * sizeof(real_t) + 8) > ((size_t)1 << 30))
+        long_piece = long_piece < 8192 ? long_piece * 2 : 0;
+    char *buf = nullptr;
+    size_t head = 256, rows_b = 0, po_b = 0;
     if (long_piece > 0 && nnz > long_piece) {
         const size_t slots = (size_t)(nnz / long_piece) + 1, pieces = 2 * slots;
-        const size_t head = 256, rows_b = (slots * 4 + 255) & ~(size_t)255, po_b = (pieces * 8 + 255) & ~(size_t)255,
-                     e_b = pieces * (size_t)n * sizeof(real_t);
-        char *buf = (char *)scratch_buffer(MX_SCRATCH_LONGROWS, head + 2 * rows_b + po_b + e_b);
-        if (!buf) return set_error("rowsplit_spmm: cannot allocate %zu bytes for the long rows' pieces", head + 2 * rows_b + po_b + e_b);
+        rows_b = (slots * 4 + 255) & ~(size_t)255;
+        po_b = (pieces * 8 + 255) & ~(size_t)255;
+        buf = (char *)scratch_buffer(MX_SCRATCH_LONGROWS, head + 2 * rows_b + po_b + pieces * (size_t)n * sizeof(real_t));
+        if (!buf) (void)hipGetLastError();
+    }
+    if (buf) {
         scratch_acquire(MX_SCRATCH_LONGROWS, stream);
         lr.counter = (unsigned long long *)buf;
         lr.rows = (int *)(buf + head);

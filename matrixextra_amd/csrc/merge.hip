@@ -151,17 +151,17 @@ void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
         const int a0 = p1[rs], a1 = p1[rs + 1], b0 = p2[rs], b1 = p2[rs + 1];
         s1[u] = a0; n1[u] = valid ? a1 - a0 : 0;
         s2[u] = b0; n2[u] = valid ? b1 - b0 : 0;
-        left[u] = ml.T != 0 && (n1[u] > ml.T || n2[u] > ml.T);       // (uniform inside the group) -> merge_long_count_kernel
-        if (left[u]) {
-            if (lg == 0) ml.rows[atomicAdd(ml.count, 1u)] = (int)row;
-            n1[u] = n2[u] = 0;
-        }
     }
 #pragma unroll
     for (int u = 0; u < COUNT_U; u++) {
         a[u] = lg < n1[u] && n1[u] <= G ? j1[s1[u] + lg] : INT_MAX;
         b[u] = lg < n2[u] && n2[u] <= G ? j2[s2[u] + lg] : INT_MAX;
     }
+    // (very long pairs — merge_long_count_kernel's — are met in the slow branch below, which they take anyway: the straight-line
+    // path of pairs that fit knows nothing of them.  Same box, cfg4: a branch with the list's atomic up here 207 -> 233 us,
+    // branch-free selects on n1 / n2 here 207 -> 224)
+#pragma unroll
+    for (int u = 0; u < COUNT_U; u++) left[u] = false;
     // One test for all COUNT_U pairs: when every row fits its lane group (the normal case) the searches are straight-line
     // code, and the compiler interleaves their dependent chains of cross-lane reads (~100 cycles a probe).
     bool big = false;
@@ -179,7 +179,10 @@ void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
     } else {
 #pragma unroll
         for (int u = 0; u < COUNT_U; u++) {
-            if (__ballot(n1[u] > G || n2[u] > G) == 0ULL) {
+            left[u] = ml.T != 0 && (n1[u] > ml.T || n2[u] > ml.T);   // (uniform inside the group)
+            if (left[u]) {
+                c[u] = 0;                                            // listed at the end of the kernel
+            } else if (__ballot(n1[u] > G || n2[u] > G) == 0ULL) {
                 bool hit;
                 group_lower_bound<G>(b[u], a[u], hit);
                 const int hits = __popcll(group_ballot<G>(hit && lg < n1[u]));
@@ -193,6 +196,11 @@ void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
     for (int u = 0; u < COUNT_U; u++) {
         const long long row = grp * COUNT_U + u;
         if (row < m && lg == 0 && !left[u]) counts[row] = c[u];
+    }
+    if (ml.T != 0) {
+#pragma unroll
+        for (int u = 0; u < COUNT_U; u++)
+            if (left[u] && lg == 0) ml.rows[atomicAdd(ml.count, 1u)] = (int)(grp * COUNT_U + u);
     }
 }
 
@@ -303,10 +311,6 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
         o[u] = po[rs];
         s1[u] = a0; n1[u] = valid ? a1 - a0 : 0;
         s2[u] = b0; n2[u] = valid ? b1 - b0 : 0;
-        if (ml.T != 0 && (n1[u] > ml.T || n2[u] > ml.T)) {          // -> merge_long_fill_kernel
-            if (lg == 0) ml.rows[atomicAdd(ml.count, 1u)] = (int)row;
-            n1[u] = n2[u] = 0;                                       // (an empty pair writes nothing)
-        }
     }
 #pragma unroll
     for (int u = 0; u < FILL_U; u++) {
@@ -315,13 +319,17 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
         if (va) { a[u] = j1[s1[u] + lg]; xa[u] = x1[s1[u] + lg]; }
         if (vb) { b[u] = j2[s2[u] + lg]; xb[u] = x2[s2[u] + lg]; }
     }
+    bool left[FILL_U];                                               // very long pairs: merge_long_fill_kernel's (see merge_count_kernel)
+#pragma unroll
+    for (int u = 0; u < FILL_U; u++) left[u] = false;
 #pragma unroll
     for (int u = 0; u < FILL_U; u++) {
         const long long row = grp * FILL_U + u;
         const bool fits = __ballot(n1[u] > G || n2[u] > G) == 0ULL;
         if (row >= m) continue;
         if (!fits) {
-            fill_row_slow<G, OP, VT>(lg, j1 + s1[u], x1 + s1[u], n1[u], j2 + s2[u], x2 + s2[u], n2[u], o[u], jo, xo);
+            left[u] = ml.T != 0 && (n1[u] > ml.T || n2[u] > ml.T);
+            if (!left[u]) fill_row_slow<G, OP, VT>(lg, j1 + s1[u], x1 + s1[u], n1[u], j2 + s2[u], x2 + s2[u], n2[u], o[u], jo, xo);
             continue;
         }
         // register-resident rows: one entry of A and one of B per lane, searches by cross-lane probes
@@ -352,6 +360,11 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
                 if constexpr (OP == MX_OP_SUB) xo[pos] = -xb[u]; else xo[pos] = xb[u];
             }
         }
+    }
+    if (ml.T != 0) {
+#pragma unroll
+        for (int u = 0; u < FILL_U; u++)
+            if (left[u] && lg == 0) ml.rows[atomicAdd(ml.count, 1u)] = (int)(grp * FILL_U + u);
     }
 }
 

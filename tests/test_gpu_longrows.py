@@ -170,3 +170,36 @@ def test_export_of_a_matrix_with_giant_rows_takes_the_long_rows_path(gpu):
     for r in np.concatenate([giant, rng.integers(0, m, size=100)]):
         s, e = p[r], p[r + 1]
         np.testing.assert_allclose(got[r], x[s:e] @ Y[:, j[s:e]].T, rtol=1e-11, atol=1e-11)
+
+
+def test_auto_leaves_a_plan_whose_longest_octet_outlasts_the_sweep(gpu):
+    """Rows SORTED by length (longest first) against a narrow B: one octet of 64 long rows is one wavefront's work item and
+    outlasts everything else of the planned sweep (tools/cliff_hunt.py: 1.98 ms against 0.33 for equal rows).
+    mxd_spmm_plan_imbalance reports it and AUTO — the kept-plan path of DeviceCSR.spmm — runs the row-split kernel instead;
+    the same rows in random order keep the plan.  Both against sampled oracle rows."""
+    rng = np.random.default_rng(23)
+    m, K, n = 200_000, 50_000, 32
+    lens = np.minimum(np.floor(rng.lognormal(np.log(100) - 0.5, 1.0, size=m)).astype(np.int64), K)
+    B = rng.normal(size=(K, n))
+    Bd = torch.from_numpy(B).cuda()
+    lib = _lib.load()
+    for order, want_kernel in (("sorted", "spmm_rowsplit_kernel"), ("random", "spmm_plan_kernel")):
+        l = np.sort(lens)[::-1].copy() if order == "sorted" else lens
+        row = np.repeat(np.arange(m, dtype=np.int64), l)
+        key = np.unique(row * K + rng.integers(0, K, size=row.size))
+        row = key // K
+        j = (key - row * K).astype(np.int32)
+        p = np.zeros(m + 1, dtype=np.int64); np.cumsum(np.bincount(row, minlength=m), out=p[1:])
+        x = rng.uniform(-1, 1, size=j.size)
+        A = D.DeviceCSR.from_host(p.astype(np.int32), j, x, K)
+        got = D.spmm(A, Bd).cpu().numpy()
+        assert lib.mxd_spmm_last_kernel().decode() == want_kernel, order
+        plan = A.auto_plan(0)
+        assert plan is not None
+        imb = C.c_double(0.0)
+        _lib.check(lib.mxd_spmm_plan_imbalance(plan, C.c_int(n), C.c_int(_lib.MX_F64), C.byref(imb)))
+        assert (imb.value > 2.5) == (order == "sorted"), (order, imb.value)
+        for r in np.concatenate([[0, 1, 63, 64, m - 1], rng.integers(0, m, size=60)]):
+            s, e = p[r], p[r + 1]
+            np.testing.assert_allclose(got[r], x[s:e] @ B[j[s:e]], rtol=1e-11, atol=1e-11)
+        del A

@@ -203,3 +203,30 @@ def test_auto_leaves_a_plan_whose_longest_octet_outlasts_the_sweep(gpu):
             s, e = p[r], p[r + 1]
             np.testing.assert_allclose(got[r], x[s:e] @ B[j[s:e]], rtol=1e-11, atol=1e-11)
         del A
+
+
+def test_export_spmv_with_very_long_rows_takes_the_flat_kernel(gpu):
+    """matmul_csr_dvec through the export on 20,000 rows (below the 32k rows from which the exports take the flat kernel
+    anyway) with rows of 50,000 / 20,000 entries: the host-side row pointers show them and the flat kernel runs — rows of
+    at most 256 entries are the reference's loop bit for bit (src/matmul.cpp:395-416; the lane-group kernel regroups
+    them), the long rows are summed by a wavefront."""
+    from matrixextra_amd import exports as G
+    rng = np.random.default_rng(8)
+    m, K = 20_000, 60_000
+    lens = np.full(m, 60, dtype=np.int64)
+    lens[[11, 5_000, m - 2]] = [50_000, 20_000, 16_384]
+    p = np.zeros(m + 1, dtype=np.int32); p[1:] = np.cumsum(lens)
+    j = np.empty(int(p[-1]), dtype=np.int32)
+    for r in range(m):
+        j[p[r]:p[r + 1]] = np.sort(rng.choice(K, size=int(lens[r]), replace=False))
+    x = rng.uniform(-1, 1, size=j.size)
+    v = rng.normal(size=K)
+    assert j.size >= 1 << 20
+    short = lens <= 256
+    got, want = G.matmul_csr_dvec_numeric(p, j, x, v), O.matmul_csr_dvec_numeric(p, j, x, v)
+    assert np.array_equal(got[short], want[short])
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-11)
+    vf = v.astype(np.float32)
+    got, want = G.matmul_csr_dvec_float32(p, j, x, vf), O.matmul_csr_dvec_float32(p, j, x, vf)
+    assert np.array_equal(got[short], want[short])
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-3)

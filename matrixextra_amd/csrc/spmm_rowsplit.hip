@@ -725,9 +725,13 @@ double rowsplit_est_us(int m, int n, int K, int dense_bytes, double avg_len, int
     const double nnz = avg_len * m, c_bytes = (double)m * n * sz;
     const double passes = (double)((n + 64 * vec - 1) / (64 * vec));
     const int G = n <= 8 * vec ? 8 : (n <= 16 * vec ? 16 : (n <= 32 * vec ? 32 : 64));
-    // TB/s: 8-lane groups read one line per row of B; 32-lane groups (a 257 .. 512-byte row of B) gather at ~21, not the 28
-    // of a full wavefront per row (vignette shape in f32, n = 100: 2 GB in 0.107 ms; tools/tile_skew_probe.py)
-    double l2_rate = n * sz <= 128 ? 17.0 : (n * sz <= 512 ? 21.0 : 28.0), mall_rate = 8.5;
+    // TB/s: 8-lane groups read one line per row of B; wider groups 28 — of the lanes that HAVE a column: n = 100 leaves 7 of
+    // 32 (f32) / 14 of 64 (f64) lanes of every read idle, and the useful rate is 28 x 0.78 = 21.9 (measured: vignette shape
+    // f32 2 GB in 0.107 ms, f64 4 GB in 0.19 ms; n = 64 in f64 fills its 32 lanes: 3.3 GB in 0.164 ms)
+    // (applied to the 16- / 32-lane groups only: with a full wavefront per row the round-4 map — m = 1e6, K = 1e4, 128 per row,
+    // n = 100 — is priced better without it)
+    const double lanes_used = G < 64 ? (double)n * sz / ((double)G * 16.0) : 1.0;
+    double l2_rate = n * sz <= 128 ? 17.0 : 28.0 * (lanes_used < 1.0 ? lanes_used : 1.0), mall_rate = 8.5;
     double row_us = 0.2e-3 * passes;                                              // one wavefront per (row, panel, pass)
     double lockstep = 1.0;
     if (rowsplit_segments(m, n, sz, avg_len / P) == 0) {                          // the row-group form (tools/rowgroup_probe.py)

@@ -87,7 +87,7 @@ def cost2(m,n,K,nnz,sz,keep,P):
     G=G_of(n,sz); one_line=n*sz<=128
     cb=m*n*sz
     def rs_est(pn):
-        lanes=17.0 if one_line else (21.0 if n*sz<=512 else 28.0)
+        lanes=17.0 if one_line else 28.0*(min(1.0, n*sz/(G*16.0)) if G<64 else 1.0)
         S=segments(m,n,sz,avg/pn,P); mall=8.5
         rowc=0.2e-3*m*pn*passes
         if S==0:

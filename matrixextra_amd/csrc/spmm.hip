@@ -208,9 +208,11 @@ int spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, const vo
                      int colmajor)
 {
     const int family = spmm_auto_algo(m, n, K, nnz, dense_dtype, B, ldb, C, ldc, colmajor, false);
-    g_family_segments = g_family_panels = g_family_long_piece = 0;
+    g_family_segments = g_family_panels = 0;
+    // (the caller's profile is in scope here, not in the blocks — and a PLANNED family whose plan is left for its imbalance
+    // falls back to the row-split kernel in spmm_block: exactly the products with very long rows)
+    g_family_long_piece = nnz > 0 && m > 0 ? rowsplit_long_piece(m, nnz) : 0;
     if (family == MX_SPMM_ROWSPLIT && nnz >= 0 && m > 0) {
-        g_family_long_piece = nnz > 0 ? rowsplit_long_piece(m, nnz) : 0;   // (the caller's profile is in scope here, not in the blocks)
         const int sz = dense_dtype == MX_F64 ? 8 : 4;
         const double avg = (double)nnz / m;
         g_family_panels = rowsplit_panels(m, n, K, sz, avg);
@@ -275,7 +277,8 @@ int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, con
         }
         family = nnz >= 0 ? MX_SPMM_ROWSPLIT : MX_SPMM_ROWWAVE;       // (very uneven rows: the plan would pad too much)
         if (family == MX_SPMM_ROWSPLIT)
-            return run_rowsplit(m, n, K, nnz, 0, 0, 0, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, st);
+            return run_rowsplit(m, n, K, nnz, 0, 0, 0, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, st,
+                                from_auto ? g_family_long_piece : -1);
     }
     return mxd_spmm_csr_dense_ex2(m, n, K, nnz, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, family, 0, npanels, 0, st);
 }

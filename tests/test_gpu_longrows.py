@@ -145,13 +145,15 @@ def test_spmv_auto_with_the_profile_takes_the_flat_kernel_for_very_long_rows(gpu
     np.testing.assert_allclose(got_group, want, rtol=1e-11, atol=1e-11)
 
 
-def test_export_of_a_matrix_with_giant_rows_takes_the_long_rows_path(gpu):
+def test_export_of_a_matrix_with_giant_rows(gpu):
     """The export level profiles the caller's host arrays itself (api.hip host_csr_profile) and fixes the piece length for
     the WHOLE product before it runs block by block: tcrossprod_csr_dense on 1e5 rows of 64 entries with four rows of
-    10,000 (AUTO: the row-split kernel) against oracle rows, the giant ones among them."""
+    10,000 against oracle rows, the giant ones among them.  AUTO's family for this product is the planned sweep, whose plan
+    is left for its imbalance (one octet with a 10,000-entry row): the row-split kernel runs, with the piece length chosen
+    while the host-side profile was in scope."""
     from matrixextra_amd import exports as G
     rng = np.random.default_rng(17)
-    m, K, n = 100_000, 10_000, 64
+    m, K, n = 100_000, 10_000, 128
     lens = np.full(m, 64, dtype=np.int64)
     giant = np.array([3, 40_000, 77_777, m - 1])
     lens[giant] = 10_000
@@ -165,8 +167,9 @@ def test_export_of_a_matrix_with_giant_rows_takes_the_long_rows_path(gpu):
     Y = np.asfortranarray(rng.normal(size=(n, K)))                 # tcrossprod: X %*% t(Y)
     got = G.tcrossprod_csr_dense_numeric(p, j, x, Y)
     assert _lib.load().mxd_spmm_last_kernel().decode() == "spmm_rowsplit_kernel"
+    # (the export runs the product in row blocks: the counts are those of the LAST block, which holds row m - 1)
     rows, pieces = _long_counts()
-    assert rows == 4 and pieces >= 4 * 10
+    assert rows >= 1 and pieces >= 10, (rows, pieces)
     for r in np.concatenate([giant, rng.integers(0, m, size=100)]):
         s, e = p[r], p[r + 1]
         np.testing.assert_allclose(got[r], x[s:e] @ Y[:, j[s:e]].T, rtol=1e-11, atol=1e-11)

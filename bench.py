@@ -110,7 +110,7 @@ def relaunch_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 from bench_common import (HBM_PEAK_GBS, STREAM, committed_kernels_traffic, committed_traffic, cpu_baseline_spmm,  # noqa: E402,F401
-                          roofline, stream_copy_probe)
+                          headline_line, roofline, stream_copy_probe)
 
 
 STRONG_CHUNKS = 64
@@ -356,7 +356,8 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
         "kernel_gflops": round(flops_rank_step / kern_avg_s / 1e9, 1),
         "parity_max_err_over_max_abs_vs_oracle": parity,
         "spmm_call_avg_ms": round(float(step_ms.mean()), 4),
-        "dims": {"rows_per_gpu": m, "cols": K, "nnz_per_row": nnz_row, "dense_cols": n},
+        "dims": {"rows_per_gpu": m, "cols": K, "nnz_per_row": nnz_row, "dense_cols": n,
+                 "layout": "colmajor" if colmajor else "rowmajor"},
     }
     if dist_on:
         gather_s = max(elapsed / steps - float(step_ms.mean()) / 1e3, 1e-9) if pipe is None else elapsed / steps
@@ -395,6 +396,20 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
         dt = (time.perf_counter() - t1) / steps
         res["plan"]["kept_plan" if other_keeps else "rebuild_every_step"] = {
             "ms_per_step": round(dt * 1e3, 4), "GFLOP/s": round(flops_rank_step / dt / 1e9, 1)}
+    if want_steady and not dist_on and colmajor and args.algo == 0:
+        # the same product with C row-major: the sweep every rank runs at N > 1 (row-major blocks are what the all-gather
+        # moves), so that the 1 -> N ratio can be read against ONE layout (VERDICT r5 missing 3)
+        C_rm = C_loc.view(-1)[: m * n].view(m, n)
+        for _ in range(3):
+            run_spmm(A, B, C_rm, False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            run_spmm(A, B, C_rm, False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / steps
+        res["rowmajor_ms_per_step"] = round(dt * 1e3, 4)
+        res["rowmajor_gflops"] = round(flops_rank_step / dt / 1e9, 1)
     if want_cpu:
         if p is None:            # a device-drawn block: the CPU sample is its first rows, read back
             rs = min(m, 60_000)
@@ -439,14 +454,16 @@ def main():
                                                            # unsharded call measured 262-265 ms instead of 188-197, three runs each way)
         dl = r["device_level"]
         dl["roofline"]["frac_of_stream_copy"] = round(dl["roofline"]["achieved"] / stream["GBps"], 4)
-        print(json.dumps({
+        print(headline_line({
             "metric": "CSR x dense SpMM GFLOP/s (fp32 dense / f64 CSR values, 8M x 200k, 64 nnz/row, k=256, whole matrix on one GPU) "
                       "+ achieved HBM BW% vs CPU ref",
             "value": dl["GFLOP/s"], "unit": "GFLOP/s", "n_gpus": 1, "steps": 5, "warmup": 2, "ms_per_step": dl["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "dgRMatrix 8000000x200000 nnz/row=64 (CSR values f64) %*% dense 200000x256 f32 (BASELINE "
-                                   "configs[4], the whole matrix on ONE MI355X); C col-major", "parallelism": "single"},
-            "roofline": dl["roofline"], "stream_copy": stream, "cfg5_full": r, "device": _lib.device_name()}), flush=True)
+                                   "configs[4], the whole matrix on ONE MI355X); C col-major", "parallelism": "single",
+                       "layout": "colmajor"},
+            "roofline": dl["roofline"], "stream_copy": stream, "extras": {"cfg5_full": r}, "device": _lib.device_name()},
+            extras_file=os.path.join(ROOT, "gpurun_out", "bench_cfg5_full.json")), flush=True)
         return
     cfg = dict(name=args.config, rows=args.rows, cols=args.cols, nnz_row=args.nnz_row, n=args.n, dtype=args.dtype,
                label=WORKLOADS[args.config]["label"] if not args.custom else "custom shape")
@@ -538,8 +555,10 @@ def main():
         if rank == 0 and world > 1:
             time.sleep(1.0)                                  # the other ranks' exit-time output, if any, comes first
     if rank == 0:
+        # ONE line, last on stdout, <= 4 KB, strict JSON; the full record (every extra with its notes) goes to
+        # gpurun_out/bench_extras.json (bench_common.headline_line; tests/test_bench_line.py)
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        print(headline_line(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -159,3 +159,124 @@ def roofline(alg_bytes, seconds, **extra):
         if STREAM["GBps"]:
             d["kernels"]["frac_of_stream_copy"] = round(ka / STREAM["GBps"], 4)
     return d
+
+
+# ----------------------------------------------------------------------------------------------- the printed line
+LINE_LIMIT = 4096            # bytes: the driver keeps ~8 KB of stdout; round 5's 21.6 KB line was not parsed
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline")
+EXTRAS_FILE = os.path.join(ROOT, "gpurun_out", "bench_extras.json")
+
+
+def _finite(o):
+    """NaN / inf -> None, numpy scalars -> Python: the line is strict JSON (allow_nan=False)."""
+    if isinstance(o, dict):
+        return {str(k): _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    if isinstance(o, (np.floating, np.integer, np.bool_)):
+        o = o.item()
+    if isinstance(o, float) and not np.isfinite(o):
+        return None
+    return o
+
+
+def _scalars(d, keep=None):
+    """the scalar fields of a record (strings cut to 160 characters); `keep` orders / restricts them"""
+    out = {}
+    for k in (keep or d):
+        v = d.get(k)
+        if isinstance(v, str):
+            out[k] = v[:160]
+        elif v is None or isinstance(v, (bool, int, float)):
+            if k in d:
+                out[k] = v
+    return out
+
+
+def _extra_ms_frac(e):
+    """[ms, roofline frac] of one extras record, whatever its shape (None where it has none)"""
+    if not isinstance(e, dict):
+        return None
+    ms = next((e[k] for k in ("ms", "ms_per_step", "device_ms", "ms_cold") if isinstance(e.get(k), (int, float))), None)
+    r = e.get("roofline")
+    fr = r.get("frac") if isinstance(r, dict) else None
+    return [ms, fr] if ms is not None else None
+
+
+SUMMARY_ORDER = ("cfg5_shard", "cfg2_rowmajor", "spmv_cfg3", "gather_cfg3", "csr_add_csr_cfg4", "csr_mul_csr_cfg4",
+                 "vignette_dense_csc", "spmm_cfg2_skewed", "spmm_cfg2_zipf", "cfg5_shard_skewed", "cfg5_strong",
+                 "rows_sorted_check_cfg4", "export_call_end_to_end", "spmm_short_rows_narrow_B", "csr_sub_csr_cfg4")
+
+
+def headline_line(out, extras_file=EXTRAS_FILE, limit=LINE_LIMIT):
+    """`out` (bench.py's full result, extras and prose included) -> the ONE line printed last on stdout: <= `limit` bytes,
+    strict JSON, self-sufficient (metric, value, config, roofline and cpu_baseline as scalars, a summary of <= 12 extras
+    as {name: [ms, frac]}).  The full record — every extra with its notes — goes to `extras_file`."""
+    out = _finite(out)
+    extras = out.pop("extras", None)
+    full = dict(out, extras=extras) if extras is not None else dict(out)
+    wrote = None
+    if extras_file:
+        try:
+            os.makedirs(os.path.dirname(extras_file), exist_ok=True)
+            with open(extras_file, "w") as f:
+                json.dump(full, f, allow_nan=False, indent=1)
+            wrote = os.path.relpath(extras_file, ROOT)
+        except OSError:
+            wrote = None
+    line = {k: out[k] for k in REQUIRED_KEYS if k in out and k not in ("config", "roofline")}
+    cfg = out.get("config", {})
+    line["config"] = dict(_scalars(cfg), workload=str(cfg.get("workload", ""))[:420])
+    rf = out.get("roofline") or {}
+    line["roofline"] = _scalars(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                     "frac_of_stream_copy", "traffic_source", "traffic_refused", "kernel", "kernel_avg_ms",
+                                     "kernel_min_ms", "bound_unit", "scope"))
+    g = rf.get("l2_to_l1_gather")
+    if isinstance(g, dict):
+        line["roofline"]["l2_to_l1_gather_GBps"] = g.get("achieved_GBps")
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _scalars(cb, ("value", "unit", "cores", "kind", "sample"))
+        st = cb.get("single_thread")
+        if isinstance(st, dict):
+            line["cpu_baseline"]["single_thread_value"] = st.get("value")
+    for k in ("setup_calls", "one_shot_ms_per_step", "one_shot_gflops", "rowmajor_ms_per_step", "rowmajor_gflops", "kernel_gflops",
+              "parity_max_err_over_max_abs_vs_oracle", "spmm_call_avg_ms", "compute_only_gflops", "device"):
+        if k in out:
+            line[k] = out[k]
+    sc = out.get("stream_copy")
+    if isinstance(sc, dict):
+        line["stream_copy_GBps"] = sc.get("GBps")
+    if isinstance(out.get("distributed"), dict):
+        d = out["distributed"]
+        line["distributed"] = dict(_scalars(d), row_blocks=(d.get("row_blocks") or [])[:16])
+    if isinstance(out.get("allgather"), dict):
+        line["allgather"] = _scalars(out["allgather"])
+    if isinstance(out.get("single_process"), dict):
+        line["single_process"] = _scalars(out["single_process"])
+    if isinstance(extras, dict):
+        summ = {}
+        names = [k for k in SUMMARY_ORDER if k in extras] + [k for k in extras if k not in SUMMARY_ORDER]
+        for k in names:
+            v = _extra_ms_frac(extras[k])
+            if v is not None and len(summ) < 12:
+                summ[k] = v
+        line["extras_summary"] = summ
+        if isinstance(extras.get("errors"), dict):
+            line["extras_errors"] = sorted(extras["errors"])[:8]
+    if wrote:
+        line["extras_file"] = wrote
+    # never above the limit: optional parts go first, the required keys never
+    for drop in (None, "extras_errors", "allgather", "extras_summary", "distributed", "device", "single_process"):
+        if drop:
+            line.pop(drop, None)
+        s = json.dumps(line, allow_nan=False, separators=(",", ":"))
+        if len(s.encode()) <= limit:
+            break
+    else:
+        line["config"]["workload"] = line["config"]["workload"][:120]
+        line["metric"] = line["metric"][:120]
+        s = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    assert "\n" not in s
+    return s

@@ -26,7 +26,16 @@ def run_bench(extra_env, *argv, fixed=("--no-extras", "--no-cpu-baseline")):
                         *fixed, *argv], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last.encode()) < 6000, f"the bench line grew to {len(last)} bytes (VERDICT r5: 21.6 KB was not parsed)"
+
+    def refuse(c):
+        raise ValueError(f"non-standard JSON constant {c}")
+    d = json.loads(last, parse_constant=refuse)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline"):
+        assert k in d, k
+    assert d["config"]["layout"] in ("colmajor", "rowmajor")
+    return d
 
 
 @pytest.mark.gpu
@@ -70,6 +79,10 @@ def test_bench_default_multi_gpu_line_is_the_metrics_workload(gpu):
     assert d["roofline"]["frac"] > 0 and "rank 0" in d["roofline"]["scope"]
     assert d["compute_only_gflops"] >= d["value"] > 0
     assert d["parity_max_err_over_max_abs_vs_oracle"] <= 1e-10
-    c5 = d["extras"]["cfg5_strong"]
+    assert d["config"]["layout"] == "rowmajor"                      # row-major blocks are what the all-gather moves
+    assert d["extras_summary"]["cfg5_strong"][0] > 0
+    full = json.load(open(os.path.join(ROOT, d["extras_file"])))   # the full record beside the line
+    assert full["value"] == d["value"]
+    c5 = full["extras"]["cfg5_strong"]
     assert c5["dtype"] == "f32" and c5["value"] > 0 and c5["distributed"]["rows_total"] == 1048576
     assert c5["parity_max_err_over_max_abs_vs_oracle"] <= 2e-5

@@ -301,8 +301,10 @@ int mxd_spmm_auto_cost2(int m, int n, int K, int64_t nnz, int keep_plan, int den
  * and skewed row lengths.  mxd_csr_profile fills profile_host[MX_PROFILE_LEN]: [i], i = 0 .. 31 = the share of the entries
  * whose column is among the 2^i most frequent columns (two independent half-samples of <= 2^17 entries each: one ranks the
  * columns, the other measures them), [32] = coefficient of variation of the row lengths, [33] = longest row / mean row,
- * [34] = mean row length.  ~40 us; one stream synchronisation (8 KB come back): once per matrix, like mxd_csr_rows_sorted —
- * DeviceCSR and the CSR cache keep it.  workspace: mxd_csr_profile_workspace_bytes(K).
+ * [34] = mean row length, [35] / [36] = entries / number of the rows longer than ~6 mean rows (what sizes the long-rows
+ * scratch of the row-split kernel; only a size: a kernel checks on the device that the rows fit), [37] = 1 when [35] / [36]
+ * are filled, [39] < 0 = "uniform columns".  ~40 us; one stream synchronisation (160 bytes come back): once per matrix, like
+ * mxd_csr_rows_sorted — DeviceCSR and the CSR cache keep it.  workspace: mxd_csr_profile_workspace_bytes(K).
  * mxd_spmm_auto_algo3 / mxd_spmm_auto_cost3: AUTO's choice and estimates with the profile (NULL: uniform columns, equal rows
  * — the assumptions of mxd_spmm_auto_algo2): an XCD's L2 holds the hottest rows of B, so the gather kernels' hit rate is the
  * MASS of those columns, not their share of B's bytes; kernels that walk several rows in lockstep (row groups, the tile
@@ -384,6 +386,12 @@ int mxd_debug_spmv_tile_stamps(void *stamps_dev);
 int mxd_debug_rowsplit_long_rows(long long *rows, long long *pieces);   /* last row-split product of this thread: rows / pieces
                                                                            handed to the long-rows path (0 / 0 = off); syncs */
 int mxd_debug_spmm_tile_stamps(void *stamps_dev);
+/* what the fit check found before that product: the rows longer than the piece, their pieces, and whether they fitted the
+ * scratch sized from the profile's hint (fit 0: the product kernels summed them in line — slower, same answers); syncs */
+int mxd_debug_rowsplit_long_fit(long long *rows_needed, long long *pieces_needed, int *fit);
+/* the kernel family AUTO chose for the calling thread's last pipelined / sharded export product and the geometry every block
+ * of it ran with, whatever thread ran the block (segments -1 = row groups; long_piece 0 = long-rows path off) */
+int mx_debug_last_export_family(int *family, int *segments, int *panels, int *long_piece);
 
 /* CSR (+) CSR, pass 1: per-row output lengths (union for ADD/SUB/OR/XOR,
  * intersection for MUL/AND) then exclusive scan into out_indptr[m+1].

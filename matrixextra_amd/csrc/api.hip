@@ -58,9 +58,11 @@ int set_error(const char *fmt, ...)
     return 1;
 }
 
-int spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor);
+// (struct SpmmFamily, spmm_common.h: a product's kernel family with the geometry chosen for the WHOLE product, carried BY VALUE
+// into every block on whatever thread runs it — the shard workers of mx_set_devices are other threads than the caller's)
+SpmmFamily spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor);
 struct ProfileScope { const float *saved; explicit ProfileScope(const float *p); ~ProfileScope(); };   // spmm_common.h: the profile AUTO reads
-int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
+int spmm_block(const SpmmFamily &fam, bool from_auto, int m, int n, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
                const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, int npanels, hipStream_t st);
 int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
                 const void *v, int v_dtype, void *y, int algo, hipStream_t st);
@@ -196,6 +198,9 @@ struct CsrDev {
     }
     ~CsrDev() { drop_plans(); if (plan_built) (void)hipEventDestroy(plan_built); }
     const void *hp = nullptr, *hj = nullptr, *hx = nullptr;
+    float host_profile[MX_PROFILE_LEN];      // host_csr_profile of the operand for host_profile_K columns (under plan_mu)
+    int host_profile_K = -1;
+    bool host_profile_ok = false;
     int m = 0, device = 0;
     int64_t nnz = 0;
     size_t vb = 0, bytes = 0;
@@ -205,63 +210,90 @@ struct CsrDev {
 // The matrix profile (mxd_csr_profile, csrc/profile.hip) computed on the HOST from the caller's own arrays: the export-level
 // products choose their kernel family before the CSR is on the device (cold calls upload and multiply block by block), and
 // for data that looks like real dgRMatrix contents — power-law columns, skewed rows — the sizes alone pick the wrong one
-// (tools/zipf_map.py).  Same estimator as the device pass: <= 2^16 sampled column ids in evenly spaced runs of 256, two
-// independent halves (one ranks the columns, the other measures the entries they hold), every 2^-k-th row for the length
-// statistics.  ~0.2 ms for K = 1e5 on one core; only where the planned sweep or the tile kernel is a candidate.
+// (tools/zipf_map.py).  Same estimator as the device pass for the columns: <= 2^16 sampled column ids in evenly spaced runs
+// of 256, two independent halves (one ranks the columns, the other measures the entries they hold) — skipped (uniform
+// columns assumed) above 2^24 columns, where the two K-sized histograms would cost more than they can tell.  The ROW
+// statistics are exact: every row pointer is read (round 5 looked at every (m / 65536)-th row only and so missed a few
+// giant rows in any matrix of >= 131,072 rows — [33] came out too small and the long-rows path stayed off; advisor r5).
+// ~0.2 ms for K = 1e5 plus ~0.4 ns per row on one core; kept on the cache entry of the operand (CsrDev::host_profile).
 static bool host_csr_profile(const int32_t *indptr, const int32_t *indices, int m, int K, float *prof)
 {
     for (int i = 0; i < MX_PROFILE_LEN; i++) prof[i] = 0.0f;
     const int64_t first = indptr[0], nnz = (int64_t)indptr[m] - first;
     if (m <= 0 || K <= 0 || nnz <= 0) return false;
-    static thread_local std::vector<uint16_t> ca, cb;
-    ca.assign((size_t)K, 0); cb.assign((size_t)K, 0);
-    int runs = (int)std::min<int64_t>(256, (nnz + 255) / 256);
-    if (runs > 1) runs &= ~1;
-    for (int r = 0; r < runs; r++) {
-        const int64_t at = first + (int64_t)((double)r * (double)nnz / (double)runs), end = std::min<int64_t>(at + 256, first + nnz);
-        std::vector<uint16_t> &c = (r & 1) ? cb : ca;
-        for (int64_t e = at; e < end; e++) { const int col = indices[e]; if ((unsigned)col < (unsigned)K && c[(size_t)col] < 65535) c[(size_t)col]++; }
-    }
-    constexpr int BINS = 1024;
-    double cols[BINS] = {0}, sums[BINS] = {0};
-    double total = 0.0, met = 0.0, total_a = 0.0;
-    for (int c = 0; c < K; c++) {
-        const unsigned v = ca[(size_t)c], w = cb[(size_t)c];
-        if (v | w) { const unsigned b = v < BINS - 1 ? v : BINS - 1; cols[b] += 1.0; sums[b] += w; }
-    }
-    for (int b = 0; b < BINS; b++) { total += sums[b]; if (b) { met += cols[b]; total_a += cols[b] * b; } }
-    const bool one_half = total <= 0.0;
-    if (one_half) total = total_a > 0.0 ? total_a : 1.0;
-    int level = 0;
-    double seen = 0.0, mass = 0.0;
-    for (int b = BINS - 1; b >= 0 && level < 32; b--) {
-        const double nc = b == 0 ? std::max(0.0, (double)K - met) : cols[b];
-        const double ns = one_half ? (b == 0 ? 0.0 : nc * b) : sums[b];
-        if (nc <= 0.0) continue;
-        while (level < 32 && (double)(1ULL << level) <= seen + nc) {
-            prof[level] = (float)((mass + ns * (((double)(1ULL << level) - seen) / nc)) / total);
-            level++;
+    if (K <= (1 << 24)) {
+        static thread_local std::vector<uint16_t> ca, cb;
+        ca.assign((size_t)K, 0); cb.assign((size_t)K, 0);
+        int runs = (int)std::min<int64_t>(256, (nnz + 255) / 256);
+        if (runs > 1) runs &= ~1;
+        for (int r = 0; r < runs; r++) {
+            const int64_t at = first + (int64_t)((double)r * (double)nnz / (double)runs), end = std::min<int64_t>(at + 256, first + nnz);
+            std::vector<uint16_t> &c = (r & 1) ? cb : ca;
+            for (int64_t e = at; e < end; e++) { const int col = indices[e]; if ((unsigned)col < (unsigned)K && c[(size_t)col] < 65535) c[(size_t)col]++; }
         }
-        seen += nc; mass += ns;
+        constexpr int BINS = 1024;
+        double cols[BINS] = {0}, sums[BINS] = {0};
+        double total = 0.0, met = 0.0, total_a = 0.0;
+        for (int c = 0; c < K; c++) {
+            const unsigned v = ca[(size_t)c], w = cb[(size_t)c];
+            if (v | w) { const unsigned b = v < BINS - 1 ? v : BINS - 1; cols[b] += 1.0; sums[b] += w; }
+        }
+        for (int b = 0; b < BINS; b++) { total += sums[b]; if (b) { met += cols[b]; total_a += cols[b] * b; } }
+        const bool one_half = total <= 0.0;
+        if (one_half) total = total_a > 0.0 ? total_a : 1.0;
+        int level = 0;
+        double seen = 0.0, mass = 0.0;
+        for (int b = BINS - 1; b >= 0 && level < 32; b--) {
+            const double nc = b == 0 ? std::max(0.0, (double)K - met) : cols[b];
+            const double ns = one_half ? (b == 0 ? 0.0 : nc * b) : sums[b];
+            if (nc <= 0.0) continue;
+            while (level < 32 && (double)(1ULL << level) <= seen + nc) {
+                prof[level] = (float)((mass + ns * (((double)(1ULL << level) - seen) / nc)) / total);
+                level++;
+            }
+            seen += nc; mass += ns;
+        }
+        for (; level < 32; level++) prof[level] = 1.0f;
+        if (K > (1 << 20)) { std::vector<uint16_t>().swap(ca); std::vector<uint16_t>().swap(cb); }   // (nothing of that size stays with the thread)
+    } else {
+        prof[39] = -1.0f;                                    // mx::profile_mass: uniform columns
     }
-    for (; level < 32; level++) prof[level] = 1.0f;
-    const int stride = std::max(1, m / 65536);
-    double s0 = 0.0, s1 = 0.0, longest = 0.0, cnt = 0.0;
-    for (int r = 0; r < m; r += stride) { const double len = (double)indptr[r + 1] - indptr[r]; s0 += len; s1 += len * len; longest = std::max(longest, len); cnt += 1.0; }
-    const double mean = s0 / cnt, var = s1 / cnt - mean * mean;
-    prof[32] = mean > 0.0 ? (float)(std::sqrt(std::max(0.0, var)) / mean) : 0.0f;
-    prof[33] = mean > 0.0 ? (float)(longest / mean) : 0.0f;
+    const int long_len = mx::canonical_long_piece((double)nnz / (double)m);
+    double s1 = 0.0;
+    int64_t longest = 0, long_entries = 0, long_rows = 0;
+    for (int r = 0; r < m; r++) {
+        const int64_t len = (int64_t)indptr[r + 1] - indptr[r];
+        s1 += (double)len * (double)len;
+        longest = std::max(longest, len);
+        if (len > long_len) { long_entries += len; long_rows++; }
+    }
+    const double mean = (double)nnz / (double)m, var = s1 / (double)m - mean * mean;
+    prof[32] = (float)(std::sqrt(std::max(0.0, var)) / mean);
+    prof[33] = (float)((double)longest / mean);
     prof[34] = (float)mean;
+    prof[35] = std::nextafter((float)long_entries, INFINITY); prof[36] = std::nextafter((float)long_rows, INFINITY); prof[37] = 1.0f;
     return true;
 }
-// AUTO's family for an export-level product, with the host-side profile where it can change the choice
-static int export_auto_family(int m, int n, int K, int64_t nnz, int dt, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor,
-                              const int32_t *indptr, const int32_t *indices)
+static thread_local mx::SpmmFamily g_last_export_family;            // (diagnostic: mx_debug_last_export_family)
+// AUTO's family for an export-level product, with the host-side profile where it can change the choice.  `keep`: the
+// operand's cache entry — the profile is computed once per entry and column count (an entry is only ever found again while
+// every byte of its three host arrays still hashes the same).
+static mx::SpmmFamily export_auto_family(int m, int n, int K, int64_t nnz, int dt, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor,
+                                         const int32_t *indptr, const int32_t *indices, CsrDev *keep = nullptr)
 {
     float prof[MX_PROFILE_LEN];
-    const bool profiled = nnz >= (1LL << 21) && m >= 4096 && indptr && indices && host_csr_profile(indptr, indices, m, K, prof);
+    bool profiled = false;
+    if (nnz >= (1LL << 21) && m >= 4096 && indptr && indices) {
+        if (keep) {
+            std::lock_guard<std::mutex> lk(keep->plan_mu);
+            if (keep->host_profile_K != K) { keep->host_profile_ok = host_csr_profile(indptr, indices, m, K, keep->host_profile); keep->host_profile_K = K; }
+            profiled = keep->host_profile_ok;
+            if (profiled) memcpy(prof, keep->host_profile, sizeof(prof));
+        } else profiled = host_csr_profile(indptr, indices, m, K, prof);
+    }
     mx::ProfileScope scope(profiled ? prof : nullptr);
-    return mx::spmm_auto_family(m, n, K, nnz, dt, B, ldb, C, ldc, colmajor);
+    g_last_export_family = mx::spmm_auto_family(m, n, K, nnz, dt, B, ldb, C, ldc, colmajor);
+    return g_last_export_family;
 }
 
 static uint64_t fnv_block(uint64_t h, const void *p, size_t n)
@@ -780,9 +812,10 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
     std::vector<int> cut((size_t)nd + 1);
     partition_rows(indptr, m, nd, 12.0, (double)n * sizeof(real_t), cut.data());
     // one kernel family for the whole product (see spmm_host); the alignment rules only look at the low bits of the pointers
-    const int family = algo == MX_SPMM_AUTO ? export_auto_family(m, n, K_rows, nnz, dt, (const void *)(uintptr_t)256, ldb,
-                                                                 (const void *)(uintptr_t)256, colmajor ? (size_t)m : ldc,
-                                                                 colmajor ? 1 : 0, indptr, indices) : algo;
+    mx::SpmmFamily fam;                                          // (captured BY VALUE by the shard lambdas below)
+    if (algo == MX_SPMM_AUTO) fam = export_auto_family(m, n, K_rows, nnz, dt, (const void *)(uintptr_t)256, ldb, (const void *)(uintptr_t)256,
+                                                       colmajor ? (size_t)m : ldc, colmajor ? 1 : 0, indptr, indices);
+    else fam.family = algo;
     // host memory registered for every device; `gate` opens once the result is registered (downloads wait for it)
     Pin pinB, pinJ, pinX;
     std::vector<Pin> pinC((size_t)np);
@@ -938,7 +971,7 @@ static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_row
             if (p_local[r0] == p_local[r1]) {
                 if (colmajor) (void)hipMemset2DAsync(dCb, ldc_k * sizeof(real_t), 0, (size_t)(r1 - r0) * sizeof(real_t), n, L.run);
                 else (void)hipMemsetAsync(dCb, 0, (size_t)(r1 - r0) * ldc_k * sizeof(real_t), L.run);
-            } else if (mx::spmm_block(family, algo == MX_SPMM_AUTO, r1 - r0, n, K_rows, (int64_t)p_local[r1] - p_local[r0],
+            } else if (mx::spmm_block(fam, algo == MX_SPMM_AUTO, r1 - r0, n, K_rows, (int64_t)p_local[r1] - p_local[r0],
                                       dp.as<int32_t>() + r0, dj.as<int32_t>(),
                                       dx.as<double>(), dB.p, ldb, dCb, ldc_k, dt, colmajor ? 1 : 0, npanels, L.run)) {
                 failed("spmm");
@@ -1174,7 +1207,10 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
     // The kernel family is chosen ONCE, for the whole product, and every block runs it (AUTO applied block by block took
     // the row-wave kernel for cfg2's blocks — each below AUTO's size threshold — and would hand back other last bits cold
     // than cached once cached calls use the matrix's plan).
-    const int family = algo == MX_SPMM_AUTO ? export_auto_family(m, n, K_rows, nnz, dt, dB, ldb, dC, ldc, colmajor ? 1 : 0, indptr, indices) : algo;
+    mx::SpmmFamily fam;
+    if (algo == MX_SPMM_AUTO) fam = export_auto_family(m, n, K_rows, nnz, dt, dB, ldb, dC, ldc, colmajor ? 1 : 0, indptr, indices, A.hold.get());
+    else fam.family = algo;
+    const int family = fam.family;
     mx_spmm_plan *plan = nullptr;
     if (!A.resident) {
         const bool direct_up = pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz) && pinX.pin(values, sizeof(double) * (size_t)nnz);
@@ -1246,7 +1282,7 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
             int rc = 0;
             if (shape == COLS) {
                 rc = plan ? mxd_spmm_plan_run_rows(plan, 0, m, c1 - c0, dB + c0, ldb, dC + (size_t)c0 * ldc, ldc, dt, 1, 0, -1, L.run)
-                          : mx::spmm_block(family, algo == MX_SPMM_AUTO, m, c1 - c0, K_rows, nnz, A.p.as<int32_t>(), A.j.as<int32_t>(),
+                          : mx::spmm_block(fam, algo == MX_SPMM_AUTO, m, c1 - c0, K_rows, nnz, A.p.as<int32_t>(), A.j.as<int32_t>(),
                                            A.x.as<double>(), dB + c0, ldb, dC + (size_t)c0 * ldc, ldc, dt, 1, npanels, L.run);
             } else {
                 real_t *dCb = colmajor ? dC + c0 : dC + (size_t)c0 * ldc;
@@ -1255,7 +1291,7 @@ static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int3
                     else MX_HIP(hipMemsetAsync(dCb, 0, (size_t)(c1 - c0) * ldc * sizeof(real_t), L.run));
                 } else {
                     rc = plan ? mxd_spmm_plan_run_rows(plan, c0, c1 - c0, n, dB, ldb, dCb, ldc, dt, colmajor ? 1 : 0, 0, -1, L.run)
-                              : mx::spmm_block(family, algo == MX_SPMM_AUTO, c1 - c0, n, K_rows, (int64_t)indptr[c1] - indptr[c0],
+                              : mx::spmm_block(fam, algo == MX_SPMM_AUTO, c1 - c0, n, K_rows, (int64_t)indptr[c1] - indptr[c0],
                                                A.p.as<int32_t>() + c0,
                                                A.j.as<int32_t>(), A.x.as<double>(), dB, ldb, dCb, ldc, dt, colmajor ? 1 : 0,
                                                npanels, L.run);
@@ -2542,3 +2578,13 @@ int mx_sort_sparse_indices(const int32_t *indptr, int32_t *indices, void *values
 }
 
 }  // extern "C"
+
+// diagnostic: the kernel family AUTO chose for the calling thread's last pipelined / sharded export product and the geometry
+// every block of it ran with (segments: -1 = the row-group form, 0 = not the row-split family; long_piece 0 = long-rows path off)
+extern "C" int mx_debug_last_export_family(int *family, int *segments, int *panels, int *long_piece)
+{
+    MX_REQUIRE(family && segments && panels && long_piece, "mx_debug_last_export_family: null argument");
+    *family = g_last_export_family.family; *segments = g_last_export_family.segments; *panels = g_last_export_family.panels;
+    *long_piece = g_last_export_family.lh.piece;
+    return 0;
+}

@@ -54,6 +54,21 @@ struct HostSignal { unsigned long long *word; unsigned gen; };
 int host_signal_next(HostSignal *s);
 int host_signal_wait(const HostSignal &s, unsigned *value, hipStream_t st);
 
+// The long-rows path of the row-split kernel for ONE product: the piece length (0 = off, -1 = not decided: from the profile in
+// scope) and what the profile knows about how many rows / pieces there will be (-1 = unknown: sized by what nnz allows).
+// Chosen once for the WHOLE product (spmm_auto_family) and carried BY VALUE into every block of it, so that neither the
+// piece length — a regrouping of a long row's sum — nor anything else about the last bits depends on how the export
+// pipeline or the device list cut the product.  The counts only size the scratch: a kernel checks on the device that the
+// launch's long rows fit (longrows_fit_kernel) and leaves them to the product kernels when they do not.
+struct LongHint { int piece = 0; long long rows = -1, pieces = -1; };
+struct SpmmFamily { int family = 0, segments = 0, panels = 0; LongHint lh = {-1, -1, -1}; };
+inline int canonical_long_piece(double mean_row)         // ~6 mean rows per piece, a power of two in [128, 1024]
+{
+    int piece = 128;
+    while (piece < 1024 && piece < 6.0 * mean_row) piece <<= 1;
+    return piece;
+}
+
 // Grow-only device scratch of the calling thread and current device, one buffer per `slot` (kernels' internal tables: the
 // SpMV slice table, per-workgroup partial counts ...).  Like AUTO's SpMM plan it assumes one stream per thread and device
 // at a time.  nullptr when the allocation fails.  (scan.hip)

@@ -10,7 +10,7 @@
 // are what matters and they show in any sample) into per-column counters, with the row statistics from indptr beside it;
 // one launch over the counters into a histogram of counts, whose last workgroup turns it into mass(top) for top = 1, 2, 4,
 // ... hottest columns.  160 bytes come back to the host (one wait on an event: not capturable).
-#include "mx_common.h"
+#include "spmm_common.h"
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -20,6 +20,7 @@ namespace mx {
 constexpr int PF_BINS = 1024;            // counts 0 .. 1022 exactly, 1023 = "at least 1023" (all of them hot)
 constexpr int PF_RUN = 256;              // entries per sampled run
 constexpr int PF_MAX_RUNS = 1024;        // 2^18 sampled entries
+constexpr int PF_STATS = 5;              // per row block: sum of lengths, of squares, longest, entries / number of the long rows
 
 // Kernel 1 — blocks 0 .. runs - 1: two independent half-samples of the column ids (even / odd runs): half A RANKS the
 // columns, half B MEASURES the entries they hold — ranking and measuring on the same counts would credit the top ranks with
@@ -27,7 +28,7 @@ constexpr int PF_MAX_RUNS = 1024;        // 2^18 sampled entries
 // sample and 3 % of the matrix).  Blocks runs .. : the row statistics (sum of lengths, of squares, longest row).
 __global__ __launch_bounds__(256)
 void profile_sample_kernel(int m, int64_t nnz, const int32_t *__restrict__ indptr, int runs, const int32_t *__restrict__ indices, int K,
-                           unsigned *__restrict__ count_a, unsigned *__restrict__ count_b, double *__restrict__ stats)
+                           unsigned *__restrict__ count_a, unsigned *__restrict__ count_b, double *__restrict__ stats, int long_len)
 {
     const int run = blockIdx.x;
     if (run < runs) {
@@ -40,30 +41,34 @@ void profile_sample_kernel(int m, int64_t nnz, const int32_t *__restrict__ indpt
         }
         return;
     }
-    double s = 0.0, q = 0.0;
+    double s = 0.0, q = 0.0, le = 0.0, lc = 0.0;         // le / lc: entries / number of the rows longer than long_len
     unsigned mx_ = 0;
     const int nb = gridDim.x - runs;
     for (int r = (blockIdx.x - runs) * blockDim.x + threadIdx.x; r < m; r += nb * blockDim.x) {
         const int len = indptr[r + 1] - indptr[r];
         s += (double)len; q += (double)len * (double)len;
         mx_ = max(mx_, (unsigned)len);
+        if (len > long_len) { le += (double)len; lc += 1.0; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64);
+        le += __shfl_xor(le, o, 64); lc += __shfl_xor(lc, o, 64);
         mx_ = max(mx_, (unsigned)__shfl_xor((int)mx_, o, 64));
     }
     // one partial per workgroup, added up by the last workgroup of the second launch (a thousand wavefronts adding into the
     // same three words took 45 us: same-address atomics are served one after the other at the memory side)
-    __shared__ double ps[4], pq[4];
+    __shared__ double ps[4], pq[4], ple[4], plc[4];
     __shared__ unsigned pm[4];
-    if (lane_id() == 0) { ps[threadIdx.x / 64] = s; pq[threadIdx.x / 64] = q; pm[threadIdx.x / 64] = mx_; }
+    if (lane_id() == 0) { const int w = threadIdx.x / 64; ps[w] = s; pq[w] = q; pm[w] = mx_; ple[w] = le; plc[w] = lc; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double *dst = stats + 3 * (size_t)(blockIdx.x - runs);
+        double *dst = stats + PF_STATS * (size_t)(blockIdx.x - runs);
         dst[0] = ps[0] + ps[1] + ps[2] + ps[3];
         dst[1] = pq[0] + pq[1] + pq[2] + pq[3];
         dst[2] = (double)max(max(pm[0], pm[1]), max(pm[2], pm[3]));
+        dst[3] = ple[0] + ple[1] + ple[2] + ple[3];
+        dst[4] = plc[0] + plc[1] + plc[2] + plc[3];
     }
 }
 
@@ -160,16 +165,25 @@ void profile_bins_kernel(int m, int K, const unsigned *__restrict__ count_a, con
         profile[threadIdx.x] = v;
     }
     if (threadIdx.x >= 64 && threadIdx.x < 128) {       // the second wavefront: the row statistics' partials
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-        for (int k = threadIdx.x - 64; k < row_blocks; k += 64) { s0 += stats[3 * k]; s1 += stats[3 * k + 1]; s2 = fmax(s2, stats[3 * k + 2]); }
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
+        for (int k = threadIdx.x - 64; k < row_blocks; k += 64) {
+            const double *b = stats + PF_STATS * k;
+            s0 += b[0]; s1 += b[1]; s2 = fmax(s2, b[2]); s3 += b[3]; s4 += b[4];
+        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 = fmax(s2, __shfl_xor(s2, o, 64)); }
+        for (int o = 32; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 = fmax(s2, __shfl_xor(s2, o, 64));
+            s3 += __shfl_xor(s3, o, 64); s4 += __shfl_xor(s4, o, 64);
+        }
         if (threadIdx.x != 64) return;
         const double mean = s0 / m, var = s1 / m - mean * mean;
         profile[32] = mean > 0.0 ? (float)(sqrt(var > 0.0 ? var : 0.0) / mean) : 0.0f;
         profile[33] = mean > 0.0 ? (float)(s2 / mean) : 0.0f;
         profile[34] = (float)mean;
-        for (int i = 35; i < MX_PROFILE_LEN; i++) profile[i] = 0.0f;
+        // entries / number of the rows longer than canonical_long_piece(mean) — what sizes the row-split kernel's long-rows
+        // scratch; floats round to nearest: rounded UP here (nextafter) so that they stay bounds
+        profile[35] = nextafterf((float)s3, INFINITY); profile[36] = nextafterf((float)s4, INFINITY); profile[37] = 1.0f;
+        for (int i = 38; i < MX_PROFILE_LEN; i++) profile[i] = 0.0f;
     }
 }
 
@@ -177,13 +191,15 @@ void profile_bins_kernel(int m, int K, const unsigned *__restrict__ count_a, con
 
 extern "C" size_t mxd_csr_profile_workspace_bytes(int K)
 {
-    return 2 * (size_t)(K > 0 ? K : 1) * sizeof(unsigned) + 2 * mx::PF_BINS * sizeof(unsigned) + 64 + 3 * 256 * sizeof(double) +
+    return 2 * (size_t)(K > 0 ? K : 1) * sizeof(unsigned) + 2 * mx::PF_BINS * sizeof(unsigned) + 64 + mx::PF_STATS * 256 * sizeof(double) +
            MX_PROFILE_LEN * sizeof(float) + 64;
 }
 
 // profile[0 .. 31]: share of the entries whose column is among the 2^i most frequent columns (1.0 from 2^i >= the number of
 // columns that occur at all); profile[32]: coefficient of variation of the row lengths; profile[33]: longest row / mean row;
-// profile[34]: mean row length; profile[35 .. 39]: reserved (0).  One memset, two launches, 160 bytes through the pinned
+// profile[34]: mean row length; profile[35] / [36]: entries / number of the rows longer than ~6 mean rows (the canonical piece
+// of the row-split kernel's long-rows path, rounded up to floats), [37] = 1 when those two are filled; [38]: reserved (0);
+// [39]: < 0 marks "uniform columns" (mx::uniform_profile).  One memset, two launches, 160 bytes through the pinned
 // landing zone of read_back_small (~25 us; a pageable 8 KB copy of the bins cost 100 us more).
 extern "C" int mxd_csr_profile(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, float *profile_host,
                                void *workspace, void *stream)
@@ -196,14 +212,14 @@ extern "C" int mxd_csr_profile(int m, int K, int64_t nnz, const int32_t *indptr,
     unsigned *count_a = (unsigned *)workspace, *count_b = count_a + K;
     unsigned *bins = count_b + K;
     double *stats = (double *)(((uintptr_t)(bins + 2 * mx::PF_BINS) + 15) & ~(uintptr_t)15);
-    unsigned *done = (unsigned *)(stats + 3 * 256);
-    float *profile = (float *)(stats + 3 * 256 + 2);
+    unsigned *done = (unsigned *)(stats + mx::PF_STATS * 256);
+    float *profile = (float *)(stats + mx::PF_STATS * 256 + 2);
     MX_HIP(hipMemsetAsync(workspace, 0, mxd_csr_profile_workspace_bytes(K), st));
     int runs = (int)std::min<int64_t>(mx::PF_MAX_RUNS, mx::ceil_div(nnz, mx::PF_RUN));
     if (runs > 1) runs &= ~1;                            // two halves of equal size
     const int row_blocks = (int)std::min<int64_t>(256, mx::ceil_div(m, 256));
     hipLaunchKernelGGL(mx::profile_sample_kernel, dim3((unsigned)(runs + row_blocks)), dim3(mx::PF_RUN), 0, st, m, nnz, indptr, runs, indices, K,
-                       count_a, count_b, stats);
+                       count_a, count_b, stats, mx::canonical_long_piece((double)nnz / (double)m));
     hipLaunchKernelGGL(mx::profile_bins_kernel, dim3((unsigned)std::min<int64_t>(256, mx::ceil_div(K, 256))), dim3(256), 0, st, m, K, count_a, count_b,
                        bins, stats, row_blocks, done, profile);
     MX_LAUNCH_CHECK();

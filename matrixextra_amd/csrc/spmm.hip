@@ -62,6 +62,12 @@ double profile_mass(double top, int K)
 }
 double profile_cv() { return g_profile ? (double)g_profile[32] : 0.0; }
 double profile_longest_over_mean() { return g_profile ? (double)g_profile[33] : 0.0; }
+bool profile_long_rows(double *entries, double *rows)
+{
+    if (!g_profile || g_profile[37] != 1.0f) return false;            // ([37] = 1: [35] / [36] were filled by this build's passes)
+    *entries = g_profile[35]; *rows = g_profile[36];
+    return true;
+}
 bool profile_in_scope() { return g_profile != nullptr; }
 // a profile that says what no profile says (uniform columns are recognised by the marker in [39]; equal rows)
 const float *uniform_profile()
@@ -202,24 +208,25 @@ static int spmm_auto_algo(int m, int n, int K, int64_t nnz, int dense_dtype, con
 // the row-split kernel's segments per row and column panels for the WHOLE product the calling thread is about to run block
 // by block (spmm_block): column-major C, several panels, several segments and narrow lane groups all reassociate, so a
 // geometry re-derived from every block's own m, n and nnz would make the last bits of one product depend on how the export
-// pipeline, or the device list, cut it (round 4's advisor finding)
-static thread_local int g_family_segments = 0, g_family_panels = 0, g_family_long_piece = 0;
-int spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
-                     int colmajor)
+// pipeline, or the device list, cut it (round 4's advisor finding).  Returned BY VALUE (struct SpmmFamily, spmm_common.h) and
+// handed to spmm_block as an argument: the sharded export runs its blocks on the ShardPool's worker threads, where round 5's
+// thread_local copy of this geometry was never set (round 5's advisor finding; tests/test_gpu_export_path.py)
+SpmmFamily spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc,
+                            int colmajor)
 {
-    const int family = spmm_auto_algo(m, n, K, nnz, dense_dtype, B, ldb, C, ldc, colmajor, false);
-    g_family_segments = g_family_panels = 0;
+    SpmmFamily f;
+    f.family = spmm_auto_algo(m, n, K, nnz, dense_dtype, B, ldb, C, ldc, colmajor, false);
     // (the caller's profile is in scope here, not in the blocks — and a PLANNED family whose plan is left for its imbalance
     // falls back to the row-split kernel in spmm_block: exactly the products with very long rows)
-    g_family_long_piece = nnz > 0 && m > 0 ? rowsplit_long_piece(m, nnz) : 0;
-    if (family == MX_SPMM_ROWSPLIT && nnz >= 0 && m > 0) {
+    f.lh = nnz > 0 && m > 0 ? rowsplit_long_hint(m, nnz) : LongHint();
+    if (f.family == MX_SPMM_ROWSPLIT && nnz >= 0 && m > 0) {
         const int sz = dense_dtype == MX_F64 ? 8 : 4;
         const double avg = (double)nnz / m;
-        g_family_panels = rowsplit_panels(m, n, K, sz, avg);
-        const int S = rowsplit_segments(m, n, sz, avg / g_family_panels);
-        g_family_segments = S == 0 ? -1 : S;            // (run_rowsplit's code for the row-group form)
+        f.panels = rowsplit_panels(m, n, K, sz, avg);
+        const int S = rowsplit_segments(m, n, sz, avg / f.panels);
+        f.segments = S == 0 ? -1 : S;            // (run_rowsplit's code for the row-group form)
     }
-    return family;
+    return f;
 }
 // entries of a device-resident CSR whose count the caller did not pass: indptr[m] (one 4-byte copy, synchronises `st`)
 static int device_nnz(const int32_t *indptr, int m, hipStream_t st, int64_t *nnz)
@@ -231,10 +238,10 @@ static int device_nnz(const int32_t *indptr, int m, hipStream_t st, int64_t *nnz
     *nnz = (int64_t)last - first;
     return 0;
 }
-// long_piece: the long-rows path's piece length chosen for the WHOLE product (spmm_auto_family), -1 = from the profile in scope
+// lh: the long-rows path as chosen for the WHOLE product (spmm_auto_family); piece -1 = from the profile in scope
 static int run_rowsplit(int m, int n, int K, int64_t nnz, int segments, int panels, int rows_sorted_hint, const int32_t *indptr,
                         const int32_t *indices, const double *values, const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype,
-                        int colmajor, hipStream_t st, int long_piece_family = -1)
+                        int colmajor, hipStream_t st, LongHint lh_family = {-1, -1, -1})
 {
     (void)rows_sorted_hint;                    // (the cursor kernel checks every row itself)
     const int sz = dense_dtype == MX_F64 ? 8 : 4;
@@ -246,24 +253,25 @@ static int run_rowsplit(int m, int n, int K, int64_t nnz, int segments, int pane
         if (segments == 0) segments = rowsplit_segments(m, n, sz, avg / panels);
     }
     if (segments < 0) segments = 0;           // rowsplit_spmm's code for the row-group form
-    const int long_piece = nnz <= 0 ? 0 : (long_piece_family >= 0 ? long_piece_family : rowsplit_long_piece(m, nnz));   // (0 without a profile)
+    const LongHint lh = nnz <= 0 ? LongHint() : (lh_family.piece >= 0 ? lh_family : rowsplit_long_hint(m, nnz));   // (off without a profile)
     // (mxd_spmm_last_kernel: set by the launch itself, spmm_rowsplit.hip launch_one — the form can still change there)
     if (dense_dtype == MX_F64)
         return rowsplit_spmm<double>(m, n, K, segments, panels, indptr, indices, values, (const double *)B, ldb, (double *)C, ldc, colmajor, st,
-                                     long_piece, nnz);
+                                     lh, nnz);
     return rowsplit_spmm<float>(m, n, K, segments, panels, indptr, indices, values, (const float *)B, ldb, (float *)C, ldc, colmajor, st,
-                                long_piece, nnz);
+                                lh, nnz);
 }
 // One block (rows or columns) of a product whose kernel family was chosen for the WHOLE product (the export pipelines).
 // from_auto: the family is AUTO's choice — a planned block still falls back to the row-wave kernel when its plan would
 // pad too much, as AUTO does.
-int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices,
+int spmm_block(const SpmmFamily &fam, bool from_auto, int m, int n, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices,
                const double *values, const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, int npanels,
                hipStream_t st)
 {
+    int family = fam.family;
     if (family == MX_SPMM_ROWSPLIT)
-        return run_rowsplit(m, n, K, nnz, from_auto ? g_family_segments : 0, from_auto ? g_family_panels : npanels, 0, indptr, indices, values,
-                            B, ldb, C, ldc, dense_dtype, colmajor, st, from_auto ? g_family_long_piece : -1);
+        return run_rowsplit(m, n, K, nnz, from_auto ? fam.segments : 0, from_auto ? fam.panels : npanels, 0, indptr, indices, values,
+                            B, ldb, C, ldc, dense_dtype, colmajor, st, from_auto ? fam.lh : LongHint{-1, -1, -1});
     if (family == MX_SPMM_TILE && from_auto)
         return mxd_spmm_csr_dense_ex2(m, n, K, nnz, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, family, 0, 0, 0, st);
     if (family == MX_SPMM_PLANNED && from_auto) {
@@ -278,7 +286,7 @@ int spmm_block(int family, bool from_auto, int m, int n, int K, int64_t nnz, con
         family = nnz >= 0 ? MX_SPMM_ROWSPLIT : MX_SPMM_ROWWAVE;       // (very uneven rows: the plan would pad too much)
         if (family == MX_SPMM_ROWSPLIT)
             return run_rowsplit(m, n, K, nnz, 0, 0, 0, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, st,
-                                from_auto ? g_family_long_piece : -1);
+                                from_auto ? fam.lh : LongHint{-1, -1, -1});
     }
     return mxd_spmm_csr_dense_ex2(m, n, K, nnz, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, family, 0, npanels, 0, st);
 }
@@ -367,7 +375,8 @@ extern "C" int mxd_spmm_csr_dense_ex2(int m, int n, int K, int64_t nnz,
     // real-sim's shape, n = 128: planned rebuilt 0.257 ms, row-split 0.163 — so the ~40 us profile pass comes first.
     float own_profile[MX_PROFILE_LEN];
     // (~25 us: only for products the model prices at 0.2 ms or more)
-    bool profile_here = algo == MX_SPMM_AUTO && !mx::profile_in_scope() && nnz >= (1LL << 21) && m >= 32768 && indices;
+    // (and only up to 2^24 columns: the pass clears and scans 8 K bytes of counters — beyond that the columns count as uniform)
+    bool profile_here = algo == MX_SPMM_AUTO && !mx::profile_in_scope() && nnz >= (1LL << 21) && m >= 32768 && indices && K <= (1 << 24);
     if (profile_here) {
         const mx::AutoCost c0 = mx::spmm_auto_cost(m, n, K, nnz, dense_dtype == MX_F64 ? 8 : 4, false, colmajor_out, rows_sorted != 0);
         profile_here = std::min(c0.rowsplit_us, c0.planned_us) >= 200.0;
@@ -395,6 +404,8 @@ extern "C" int mxd_spmm_csr_dense_ex2(int m, int n, int K, int64_t nnz,
         return mx::run_rowsplit(m, n, K, nnz, wg_per_cu, npanels, rows_sorted, indptr, indices, values, B, ldb, C, ldc, dense_dtype,
                                 colmajor_out, st);
     if (algo == MX_SPMM_TILE) {
+        // (nnz unknown: indptr[m] is read back, as for the row-split kernel — the 2^29-entry limit and the slab-width model need it)
+        if (nnz < 0 && mx::device_nnz(indptr, m, st, &nnz)) return 1;
         mx::set_last_spmm_kernel("spmm_tile_kernel");
         if (dense_dtype == MX_F64)
             return mx::tile_spmm<double>(m, n, K, nnz, wg_per_cu, npanels, rows_sorted, indptr, indices, values, (const double *)B, ldb,

@@ -98,6 +98,7 @@ struct ProfileScope { const float *saved; explicit ProfileScope(const float *p);
 double profile_mass(double top, int K);
 double profile_cv();
 double profile_longest_over_mean();                       // 0 without a profile in scope
+bool profile_long_rows(double *entries, double *rows);    // [35], [36]: entries / number of the rows longer than canonical_long_piece(mean)
 bool profile_in_scope();
 const float *uniform_profile();
 inline double lockstep_factor(double cv, int rows_together)
@@ -121,9 +122,9 @@ int rowwave_spmm(int m, int n, const int32_t *indptr, const int32_t *indices, co
 // and P column panels of B (one launch each)
 template <typename real_t>
 int rowsplit_spmm(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
-                  const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream, int long_piece = 0,
-                  long long nnz = -1);                     // long_piece > 0 (and nnz known): rows longer than that are cut into pieces
-int rowsplit_long_piece(int m, long long nnz);            // from the matrix profile in scope, 0 = no long rows known
+                  const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream, LongHint lh = LongHint(),
+                  long long nnz = -1);                     // lh.piece > 0 (and nnz known): rows longer than that are cut into pieces
+LongHint rowsplit_long_hint(int m, long long nnz);        // from the matrix profile in scope, piece 0 = no long rows known
 int rowsplit_segments(int m, int n, int dense_bytes, double avg_len);
 double rowsplit_est_us(int m, int n, int K, int dense_bytes, double avg_len, int P);
 int rowsplit_panels(int m, int n, int K, int dense_bytes, double avg_len);

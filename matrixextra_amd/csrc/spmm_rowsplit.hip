@@ -210,14 +210,45 @@ struct LongRows {
     int *rows;                       // [slot] row
     unsigned *base;                  // [slot] first piece of the row
     int2 *piece_of;                  // [piece] (row, number of the piece inside the row)
+    const int *fit;                  // written by longrows_fit_kernel before the product: 1 = this launch's long rows fit the scratch
     int piece;                       // 0 = off
 };
+// the piece length the kernels of one launch go by: 0 when the path is off or the launch's long rows would not fit the
+// scratch that was sized from the caller's hint (a scalar load per wavefront; every wavefront of the launch sees the same)
+__device__ __forceinline__ int long_piece_of(const LongRows &lr) { return lr.piece && *lr.fit ? lr.piece : 0; }
+
+// Before the product kernels: counts the rows longer than `piece` and their pieces from indptr and decides — on the device, for
+// every kernel of the launch alike — whether they fit the scratch (`cap_rows` list slots, `cap_pieces` partial-sum rows).
+// The scratch is sized from what the matrix profile knows (LongHint), capped; a caller whose hint was for another matrix, or a
+// matrix with more long rows than the cap holds, gets the plain kernels: slower, never wrong, nothing written out of bounds.
+// head: [0] the registration counter (u64), [2] fit, [3] workgroups done, [4..5] needed rows / pieces (for the debug entry)
+__global__ __launch_bounds__(256)
+void longrows_fit_kernel(int m, const int32_t *__restrict__ indptr, int piece, unsigned cap_rows, unsigned cap_pieces, unsigned *head)
+{
+    unsigned rows = 0, pieces = 0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < m; r += gridDim.x * blockDim.x) {
+        const int len = indptr[r + 1] - indptr[r];
+        if (len > piece) { rows++; pieces += (unsigned)((len + piece - 1) / piece); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { rows += __shfl_xor(rows, o, 64); pieces += __shfl_xor(pieces, o, 64); }
+    if (lane_id() == 0 && rows) { atomicAdd(&head[4], rows); atomicAdd(&head[5], pieces); }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&head[3], 1u) == gridDim.x - 1) {
+        __threadfence();
+        const unsigned nr = __hip_atomic_load(&head[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned np = __hip_atomic_load(&head[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        head[2] = nr <= cap_rows && np <= cap_pieces ? 1u : 0u;
+    }
+}
 // wave-uniform `row` and `len` (the WHOLE row, not a panel's part of it): true = the row goes to the long-rows kernels
 __device__ __forceinline__ bool long_row_divert(const LongRows &lr, int row, int len, bool registers)
 {
-    if (lr.piece == 0 || len <= lr.piece) return false;
+    const int piece = long_piece_of(lr);
+    if (piece == 0 || len <= piece) return false;
     if (registers) {
-        const int np = (len + lr.piece - 1) / lr.piece;
+        const int np = (len + piece - 1) / piece;
         unsigned long long old = 0;
         if (lane_id() == 0) {
             old = atomicAdd(lr.counter, (1ULL << 32) | (unsigned long long)np);
@@ -391,11 +422,11 @@ void spmm_rowgroup_kernel(int m, int n, int nbx, int passes, int P, int p0,
     if (row < m) {
         s = lo ? lo[row] : indptr[row];
         e = hi ? hi[row] : indptr[row + 1];
-        if (lr.piece) {                        // (long rows: see spmm_rowsplit_kernel; here per lane group)
+        if (const int piece = long_piece_of(lr)) {     // (long rows: see spmm_rowsplit_kernel; here per lane group)
             const int len = lo ? indptr[row + 1] - indptr[row] : e - s;
-            if (len > lr.piece) {
+            if (len > piece) {
                 if (at.p == 0 && at.pass == 0 && lg == 0) {
-                    const unsigned np = (unsigned)((len + lr.piece - 1) / lr.piece);
+                    const unsigned np = (unsigned)((len + piece - 1) / piece);
                     const unsigned long long old = atomicAdd(lr.counter, (1ULL << 32) | (unsigned long long)np);
                     lr.rows[old >> 32] = row;
                     lr.base[old >> 32] = (unsigned)old;
@@ -602,26 +633,39 @@ static bool rowsplit_one_launch_per_panel(bool through_tile, long long workgroup
 
 template <typename real_t, int VEC, int G, bool COLMAJOR>
 static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
-                           const real_t *B, size_t ldb, real_t *C, size_t ldc, int long_piece, long long nnz, hipStream_t stream)
+                           const real_t *B, size_t ldb, real_t *C, size_t ldc, LongHint lh, long long nnz, hipStream_t stream)
 {
     constexpr int W = G * VEC;
     if (S == 0 && G == MX_WAVE) S = 1;                      // rows of B that fill the wavefront: one row per wavefront anyway
     const int nbx = (int)ceil_div(m, S == 0 ? RS_WAVES * (MX_WAVE / G) : RS_WAVES / S), passes = (int)ceil_div(n, W);
     if ((long long)nbx * passes * P >= (1LL << 31)) return set_error("rowsplit_spmm: %d x %d x %d workgroups exceed the grid", nbx, passes, P);
-    // LONG ROWS: the list and the pieces' scratch rows, sized by what nnz allows (a long row has more than `piece` entries:
-    // at most nnz / piece of them, and their pieces are at most nnz / piece + one per row)
-    LongRows lr = {nullptr, nullptr, nullptr, nullptr, 0};
+    // LONG ROWS: the list and the pieces' scratch rows.  Sized by what the matrix profile knows (LongHint: the rows longer than
+    // the canonical piece and their entries — at most that many rows are longer than THIS piece, with at most entries / piece
+    // + one piece per row), else by what nnz allows (at most nnz / piece long rows); capped at LONGROWS_CAP_BYTES either way.
+    // Whether the launch's long rows really fit is decided on the device (longrows_fit_kernel): the hint only sizes.  The
+    // piece length is the caller's — fixed once per product — and never changes here (round 5 doubled it when the scratch
+    // bound passed 1 GiB, which made the grouping of a long row's sum depend on a block's nnz and n).
+    constexpr size_t LONGROWS_CAP_BYTES = (size_t)256 << 20;
+    const int long_piece = lh.piece > 0 ? lh.piece : 0;
+    LongRows lr = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     real_t *E = nullptr;
     g_longrows_last = nullptr;
-    // (the bound, not the need: sized for nnz / piece long rows.  Above 1 GiB the pieces grow — fewer of them — and beyond
-    // 8192 entries per piece the path is dropped; a failed allocation drops it as well: the product itself never fails for it)
-    while (long_piece > 0 && nnz > long_piece &&
-           2 * ((size_t)(nnz / long_piece) + 1) * ((size_t)n * sizeof(real_t) + 8) > ((size_t)1 << 30))
-        long_piece = long_piece < 8192 ? long_piece * 2 : 0;
     char *buf = nullptr;
-    size_t head = 256, rows_b = 0, po_b = 0;
+    size_t head = 256, rows_b = 0, po_b = 0, slots = 0, pieces = 0;
     if (long_piece > 0 && nnz > long_piece) {
-        const size_t slots = (size_t)(nnz / long_piece) + 1, pieces = 2 * slots;
+        slots = (size_t)(nnz / long_piece) + 1;
+        pieces = 2 * slots;
+        if (lh.rows >= 0 && lh.pieces >= 0) {
+            // (float counts: 24 bits of mantissa — a margin of 2^-20 of the value and 8 on top)
+            slots = std::min(slots, (size_t)((double)lh.rows * (1.0 + 1e-6)) + 8);
+            pieces = std::min(pieces, (size_t)((double)lh.pieces * (1.0 + 1e-6)) + slots + 8);
+        }
+        const size_t per_piece = (size_t)n * sizeof(real_t) + 8, per_slot = 8;
+        if (slots * per_slot + pieces * per_piece > LONGROWS_CAP_BYTES) {
+            pieces = LONGROWS_CAP_BYTES / (per_piece + per_slot);
+            slots = std::min(slots, pieces);
+        }
+        slots = std::min<size_t>(slots, 0x7fffffffu); pieces = std::min<size_t>(pieces, 0x7fffffffu);
         rows_b = (slots * 4 + 255) & ~(size_t)255;
         po_b = (pieces * 8 + 255) & ~(size_t)255;
         buf = (char *)scratch_buffer(MX_SCRATCH_LONGROWS, head + 2 * rows_b + po_b + pieces * (size_t)n * sizeof(real_t));
@@ -630,12 +674,15 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
     if (buf) {
         scratch_acquire(MX_SCRATCH_LONGROWS, stream);
         lr.counter = (unsigned long long *)buf;
+        lr.fit = (const int *)(buf + 8);
         lr.rows = (int *)(buf + head);
         lr.base = (unsigned *)(buf + head + rows_b);
         lr.piece_of = (int2 *)(buf + head + 2 * rows_b);
         lr.piece = long_piece;
         E = (real_t *)(buf + head + 2 * rows_b + po_b);
-        MX_HIP(hipMemsetAsync(lr.counter, 0, sizeof(unsigned long long), stream));
+        MX_HIP(hipMemsetAsync(buf, 0, 32, stream));
+        hipLaunchKernelGGL(longrows_fit_kernel, dim3((unsigned)std::min<long long>(256, ceil_div(m, 256))), dim3(256), 0, stream,
+                           m, indptr, long_piece, (unsigned)slots, (unsigned)pieces, (unsigned *)buf);
         g_longrows_last = lr.counter;
     }
     // after the product kernels: the pieces, then the rows (both persistent: the counts live on the device)
@@ -682,14 +729,14 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
 
 template <typename real_t, int VEC, bool COLMAJOR>
 static int pick_group_rowsplit(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
-                               const real_t *B, size_t ldb, real_t *C, size_t ldc, int long_piece, long long nnz, hipStream_t st)
+                               const real_t *B, size_t ldb, real_t *C, size_t ldc, LongHint lh, long long nnz, hipStream_t st)
 {
     if constexpr (VEC > 1) {
-        if (n <= 8 * VEC) return launch_rowsplit<real_t, VEC, 8, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, st);
-        if (n <= 16 * VEC) return launch_rowsplit<real_t, VEC, 16, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, st);
-        if (n <= 32 * VEC) return launch_rowsplit<real_t, VEC, 32, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, st);
+        if (n <= 8 * VEC) return launch_rowsplit<real_t, VEC, 8, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, lh, nnz, st);
+        if (n <= 16 * VEC) return launch_rowsplit<real_t, VEC, 16, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, lh, nnz, st);
+        if (n <= 32 * VEC) return launch_rowsplit<real_t, VEC, 32, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, lh, nnz, st);
     }
-    return launch_rowsplit<real_t, VEC, 64, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, st);
+    return launch_rowsplit<real_t, VEC, 64, COLMAJOR>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, lh, nnz, st);
 }
 
 // Column panels (tools/auto_map.py, profiles/r04_auto_map.json): none while an XCD's L2 still holds most of B (5 MB: 80 %
@@ -794,20 +841,25 @@ int rowsplit_segments(int m, int n, int dense_bytes, double avg_len)
 // than they balance once the mean row is 64 or longer (0.92 ms where 512 gives 0.53): ~6 mean rows per piece, a power of
 // two in [128, 1024].  Rows SORTED by length (longest first) are the one case that loses (0.164 -> 0.186, 0.479 -> 0.536):
 // the launch order already is the longest-first schedule.
-int rowsplit_long_piece(int m, long long nnz)
+LongHint rowsplit_long_hint(int m, long long nnz)
 {
+    LongHint h;
     const double ratio = profile_longest_over_mean();
-    if (ratio <= 0.0 || m <= 0 || nnz <= 0) return 0;
+    if (ratio <= 0.0 || m <= 0 || nnz <= 0) return h;
     const double mean = (double)nnz / m;
-    int piece = 128;
-    while (piece < 1024 && piece < 6.0 * mean) piece <<= 1;
+    int piece = canonical_long_piece(mean);
     if (const char *e = getenv("MXGPU_LONG_PIECE")) piece = atoi(e);       // (tools/longrow_sweep.py)
-    return piece > 0 && ratio * mean >= 2.0 * piece ? piece : 0;
+    if (!(piece > 0 && ratio * mean >= 2.0 * piece)) return h;
+    h.piece = piece;
+    double entries = 0.0, rows = 0.0;
+    // (the profile counted the rows longer than the canonical piece: a bound for any piece at least that long)
+    if (piece >= canonical_long_piece(mean) && profile_long_rows(&entries, &rows)) { h.rows = (long long)rows; h.pieces = (long long)(entries / piece) + 1; }
+    return h;
 }
 
 template <typename real_t>
 int rowsplit_spmm(int m, int n, int K, int S, int P, const int32_t *indptr, const int32_t *indices, const double *values,
-                  const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream, int long_piece, long long nnz)
+                  const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, hipStream_t stream, LongHint lh, long long nnz)
 {
     constexpr int VECMAX = 16 / (int)sizeof(real_t);
     if (S != 0 && S != 1 && S != 2 && S != 4 && S != 8)
@@ -819,15 +871,15 @@ int rowsplit_spmm(int m, int n, int K, int S, int P, const int32_t *indptr, cons
     const bool c_vec = colmajor || S > 1 || ((ldc % VECMAX == 0) && ((uintptr_t)C % 16 == 0));
     if (S == 0 && !(b_vec && c_vec)) S = 1;                 // (the row-group form needs the 16-byte accesses)
     if (b_vec && c_vec)
-        return colmajor ? pick_group_rowsplit<real_t, VECMAX, true>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, stream)
-                        : pick_group_rowsplit<real_t, VECMAX, false>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, stream);
-    return colmajor ? pick_group_rowsplit<real_t, 1, true>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, stream)
-                    : pick_group_rowsplit<real_t, 1, false>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, long_piece, nnz, stream);
+        return colmajor ? pick_group_rowsplit<real_t, VECMAX, true>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, lh, nnz, stream)
+                        : pick_group_rowsplit<real_t, VECMAX, false>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, lh, nnz, stream);
+    return colmajor ? pick_group_rowsplit<real_t, 1, true>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, lh, nnz, stream)
+                    : pick_group_rowsplit<real_t, 1, false>(m, n, K, S, P, indptr, indices, values, B, ldb, C, ldc, lh, nnz, stream);
 }
 template int rowsplit_spmm<double>(int, int, int, int, int, const int32_t *, const int32_t *, const double *, const double *, size_t,
-                                   double *, size_t, int, hipStream_t, int, long long);
+                                   double *, size_t, int, hipStream_t, LongHint, long long);
 template int rowsplit_spmm<float>(int, int, int, int, int, const int32_t *, const int32_t *, const double *, const float *, size_t,
-                                  float *, size_t, int, hipStream_t, int, long long);
+                                  float *, size_t, int, hipStream_t, LongHint, long long);
 
 }  // namespace mx
 
@@ -843,5 +895,18 @@ extern "C" int mxd_debug_rowsplit_long_rows(long long *rows, long long *pieces)
     MX_HIP(hipMemcpy(&cnt, mx::g_longrows_last, sizeof(cnt), hipMemcpyDeviceToHost));
     *rows = (long long)(cnt >> 32);
     *pieces = (long long)(cnt & 0xffffffffULL);
+    return 0;
+}
+// ... and what longrows_fit_kernel found before that product: the rows longer than the piece, their pieces, and whether they
+// fitted the scratch (0: the product kernels summed them in line).  Synchronises the device.
+extern "C" int mxd_debug_rowsplit_long_fit(long long *rows_needed, long long *pieces_needed, int *fit)
+{
+    MX_REQUIRE(rows_needed && pieces_needed && fit, "mxd_debug_rowsplit_long_fit: null argument");
+    *rows_needed = *pieces_needed = 0; *fit = 0;
+    if (!mx::g_longrows_last) return 0;
+    unsigned head[8] = {0};
+    MX_HIP(hipDeviceSynchronize());
+    MX_HIP(hipMemcpy(head, mx::g_longrows_last, sizeof(head), hipMemcpyDeviceToHost));
+    *rows_needed = head[4]; *pieces_needed = head[5]; *fit = (int)head[2];
     return 0;
 }

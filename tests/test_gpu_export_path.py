@@ -215,6 +215,46 @@ def test_sharded_export_on_one_gpu(gpu):
         _lib.check(lib.mx_set_devices((C.c_int * 1)(99), 1))
 
 
+def test_sharded_export_bits_do_not_depend_on_the_device_list(gpu):
+    """The row-split family's geometry (segments per row, column panels, piece length of the long-rows path) is chosen for the
+    WHOLE product and carried by value into every shard, on whatever worker thread runs it (it used to sit in
+    thread-local storage of the calling thread, so the shards re-derived it from their own sizes and the long-rows path was
+    off on every shard).  Column-major f32 — where segments, panels and narrow lane groups all reassociate — on skewed rows
+    with a few giant ones: the same bits for the GPU listed 2, 3 and 5 times."""
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    m, K, n = 72_000, 120_000, 256
+    lens = np.minimum(np.maximum(rng.lognormal(mean=np.log(40) - 0.72, sigma=1.2, size=m), 1), 4000).astype(np.int64)
+    lens[rng.choice(m, size=6, replace=False)] = 30_000
+    row = np.repeat(np.arange(m, dtype=np.int64), lens)
+    key = np.unique(row * K + rng.integers(0, K, size=row.size))    # sorted, distinct ids per row (a few draws collapse)
+    row = key // K
+    j = (key - row * K).astype(np.int32)
+    p = np.zeros(m + 1, dtype=np.int64); np.cumsum(np.bincount(row, minlength=m), out=p[1:])
+    p = p.astype(np.int32)
+    lens = np.diff(p)
+    x = rng.uniform(-1, 1, size=j.size)
+    B = synth.dense_normal(K, n, dtype=np.float32)
+    Y = np.asfortranarray(B.T)
+    outs = {}
+    fam = [C.c_int(0) for _ in range(4)]
+    try:
+        for nd in (2, 3, 5):
+            _lib.check(lib.mx_set_devices((C.c_int * nd)(*([0] * nd)), nd))
+            outs[nd] = G.tcrossprod_csr_dense_float32(p, j, x, Y, 1)
+            _lib.check(lib.mx_debug_last_export_family(*[C.byref(f) for f in fam]))
+            # the family under test: row-split, with a long-rows piece chosen for the whole product
+            assert fam[0].value == 4 and fam[3].value > 0, [f.value for f in fam]
+    finally:
+        _lib.check(lib.mx_set_devices(None, 0))
+    assert np.array_equal(outs[2], outs[3]) and np.array_equal(outs[3], outs[5])
+    rows = np.concatenate([np.argsort(lens)[-4:], rng.integers(0, m, size=40)])
+    for r in rows:
+        s, e = p[r], p[r + 1]
+        want = x[s:e] @ B[j[s:e]].astype(np.float64)
+        np.testing.assert_allclose(outs[3][r], want, rtol=2e-5, atol=2e-5 * np.abs(want).max())
+
+
 def _option(lib, name):
     v = C.c_int64(0)
     _lib.check(lib.mx_get_option(name.encode(), C.byref(v)))

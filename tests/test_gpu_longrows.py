@@ -233,3 +233,46 @@ def test_export_spmv_with_very_long_rows_takes_the_flat_kernel(gpu):
     got, want = G.matmul_csr_dvec_float32(p, j, x, vf), O.matmul_csr_dvec_float32(p, j, x, vf)
     assert np.array_equal(got[short], want[short])
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-3)
+
+
+def _long_fit():
+    rows, pieces, fit = C.c_longlong(0), C.c_longlong(0), C.c_int(0)
+    _lib.check(_lib.load().mxd_debug_rowsplit_long_fit(C.byref(rows), C.byref(pieces), C.byref(fit)))
+    return rows.value, pieces.value, fit.value
+
+
+def test_scratch_is_sized_from_the_profile_and_a_wrong_profile_costs_speed_not_answers(gpu):
+    """The long-rows scratch is sized from the profile's counts ([35] entries / [36] number of the rows longer than the
+    canonical piece), not from nnz / piece; a kernel checks on the device that the launch's long rows fit.  A profile that
+    understates them (another matrix's) leaves the rows to the product kernels: bit for bit the storage-order chain."""
+    rng = np.random.default_rng(9)
+    m, K, n = 900, 4000, 64
+    long_rows = {r: int(rng.integers(1100, 3900)) for r in rng.choice(m, size=40, replace=False)}
+    p, j, lens = _matrix(m, K, rng, 20, long_rows)
+    x = rng.uniform(-1, 1, size=j.size)
+    B = rng.normal(size=(K, n))
+    Bd = torch.from_numpy(B).cuda()
+    A = D.DeviceCSR.from_host(p, j, x, K)
+    prof = A.profile()
+    mean = j.size / m
+    piece = 128
+    while piece < 1024 and piece < 6.0 * mean:
+        piece *= 2
+    nlong, elong = int((lens > piece).sum()), int(lens[lens > piece].sum())
+    assert prof[37] == 1.0 and nlong <= prof[36] <= nlong * (1 + 1e-6) + 1 and elong <= prof[35] <= elong * (1 + 1e-6) + 1
+    want = O.tcrossprod_csr_dense(p, j, x, np.asfortranarray(B.T), 1, True)
+    got = D.spmm(A, Bd, algo=4, wg_per_cu=1, npanels=1).cpu().numpy()
+    need_pieces = int(np.ceil(lens[lens > piece] / piece).sum())
+    assert _long_fit() == (nlong, need_pieces, 1) and _long_counts() == (nlong, need_pieces)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    # the same matrix with a profile that knows of one long row of 2,000 entries only: nothing fits, nothing is diverted
+    forged = (C.c_float * len(prof))(*prof)
+    forged[35], forged[36] = 2000.0, 1.0
+    A._profile = forged
+    got2 = D.spmm(A, Bd, algo=4, wg_per_cu=1, npanels=1).cpu().numpy()
+    assert _long_fit() == (nlong, need_pieces, 0) and _long_counts() == (0, 0)
+    assert np.array_equal(got2, want)                        # one wavefront per row, storage order: the FMA oracle's bits
+    # ... and one that overstates them changes nothing
+    forged[35], forged[36] = 4.0e6, 900.0
+    got3 = D.spmm(A, Bd, algo=4, wg_per_cu=1, npanels=1).cpu().numpy()
+    assert _long_fit()[2] == 1 and np.array_equal(got3, got)

@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the SpMV / gather / merge / export-call / cfg5-shard legs (N = 1 only)")
     ap.add_argument("--extras", action="store_true", help="(default at N = 1; kept for older command lines)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs from ONE process through the C-ABI (mx_spmm_sharded_*: one host thread per device, ncclCommInitAll, "
+                         "one in-place ncclAllGather per product) instead of one torch.distributed rank per GPU")
     args = ap.parse_args()
     args.config_given = args.config is not None
     if args.config is None:
@@ -422,8 +425,92 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
     return res
 
 
+def single_process(args):
+    """--single-process: the metric's product row-sharded over --gpus devices from THIS process through the C-ABI
+    (include/mxgpu.h mx_spmm_sharded_*, csrc/sharded.hip): every step = the products of all row blocks, queued by one host
+    thread per device, + one in-place ncclAllGather of C; the gather of step k runs under the product of step k + 1."""
+    import torch
+    from matrixextra_amd import _lib, sharded as S, synth
+    from oracle import oracle as O
+    lib = _lib.load()
+    N, steps, warmup = args.gpus, args.steps, args.warmup
+    m, K, n, nnz_row, dtype = args.rows, args.cols, args.n, args.nnz_row, args.dtype
+    ndt = np.float64 if dtype == "f64" else np.float32
+    p, j, x = synth.csr_fixed(m, K, nnz_row, seed=synth.SEED_A)
+    B_host = synth.dense_normal(K, n, dtype=ndt)
+    sh = S.ShardedSpMM(list(range(N)), p, j, x, K)
+    Bs = [torch.from_numpy(B_host).to(f"cuda:{k}") for k in range(N)]
+    ptrs = [b.data_ptr() for b in Bs]
+    for _ in range(SETUP_CALLS):
+        sh.run_dev(ptrs, n, ndt, asynchronous=True)
+    sh.sync()
+    for _ in range(warmup):
+        sh.run_dev(ptrs, n, ndt, asynchronous=True)
+    sh.sync()
+    for k in range(N):
+        torch.cuda.synchronize(k)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sh.run_dev(ptrs, n, ndt, asynchronous=True)
+    sh.sync()
+    for k in range(N):
+        torch.cuda.synchronize(k)
+    elapsed = time.perf_counter() - t0
+    # the same loop without overlap: every product waits for its own all-gather
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        sh.run_dev(ptrs, n, ndt)
+    in_line = (time.perf_counter() - t1) / steps
+    # parity: the first rows of the first block and the last rows of the last one, as the LAST device holds them
+    rows_chk = 2048
+    Cg = sh.gathered(N - 1)
+
+    def ref_rows(r0):
+        ref = np.zeros(rows_chk * n, dtype=ndt)
+        lo, hi = int(p[r0]), int(p[r0 + rows_chk])
+        O.gemm_csr_drm_as_drm(rows_chk, n, (p[r0:r0 + rows_chk + 1] - p[r0]).astype(np.int32), j[lo:hi].copy(), x[lo:hi].copy(),
+                              B_host.reshape(-1), n, ref, n, O.max_threads(), True)
+        return ref.reshape(rows_chk, n)
+    parity = 0.0
+    for r0 in (0, m - rows_chk):
+        ref = ref_rows(r0)
+        parity = max(parity, float(np.max(np.abs(Cg[r0:r0 + rows_chk].astype(np.float64) - ref)) / np.max(np.abs(ref))))
+    assert parity <= (1e-10 if dtype == "f64" else 2e-5), f"bench output differs from the oracle: {parity}"
+    flops = 2.0 * int(p[-1]) * n
+    s_dense = 8 if dtype == "f64" else 4
+    slot_bytes = sh.slot_rows * n * s_dense
+    out = {
+        "metric": "CSR x dense SpMM GFLOP/s (fp64, 1M x 100k, 32 nnz/row, k=128; one process, C-ABI mx_spmm_sharded_*: row blocks with "
+                  "AUTO's kept plan + one in-place ncclAllGather of C per product) + achieved HBM BW% vs CPU ref" if not args.custom else
+                  "CSR x dense SpMM GFLOP/s (custom shape; one process, C-ABI mx_spmm_sharded_*)",
+        "value": round(flops * steps / elapsed / 1e9, 2), "unit": "GFLOP/s", "n_gpus": N, "steps": steps, "warmup": warmup,
+        "setup_calls": SETUP_CALLS, "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"dgRMatrix {m}x{K} nnz/row={nnz_row} (CSR values f64) %*% dense {K}x{n} {dtype} ({WORKLOADS[args.config]['label'] if not args.custom else 'custom shape'}); "
+                               f"C row-major, the whole matrix cut into {N} row block(s) balanced by entries + rows, one per GPU, + RCCL all-gather of C; "
+                               f"ONE process", "parallelism": f"rowshard{N}-single-process", "rows_per_gpu": sh.cuts[1] - sh.cuts[0],
+                   "cols": K, "nnz_per_row": nnz_row, "dense_cols": n, "layout": "rowmajor"},
+        "roofline": roofline(synth.spmm_algorithmic_bytes(m, K, n, int(p[-1]), s_dense) / N, elapsed / steps,
+                             scope="whole step on one GPU's share of the algorithmic bytes (products + all-gather; no per-kernel events in this mode)",
+                             kernel=sh.kernel(0)),
+        "parity_max_err_over_max_abs_vs_oracle": parity,
+        "single_process": {"uses_rccl": sh.uses_rccl, "rccl_version": sh.rccl_version, "shards": sh.nshards, "slot_rows": sh.slot_rows,
+                           "in_line_ms_per_step": round(in_line * 1e3, 4),
+                           "allgather_bytes_received_per_gpu": int((N - 1) * slot_bytes)},
+        "distributed": {"backend": "rccl (ncclCommInitAll, one process)", "world_size": N, "scaling": "strong",
+                        "row_blocks": [b - a for a, b in zip(sh.cuts, sh.cuts[1:])], "rows_total": m},
+        "device": _lib.device_name(),
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_spmm(args, p, j, x, B_host, dtype)
+    sh.close()
+    print(headline_line(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.single_process:
+        return single_process(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))

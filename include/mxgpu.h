@@ -79,6 +79,40 @@ int  mx_device_name(char *buf, size_t buflen);
 int  mx_set_devices(const int *devices, int n);
 /* the row cuts that sharding uses: cuts[0 .. nparts], part k = rows [cuts[k], cuts[k+1]) — host arithmetic only */
 int  mx_partition_rows(const int32_t *indptr, int nrows, int nparts, int dense_cols, int dense_bytes, int *cuts);
+/* SpMM row-sharded over the GPUs of one node WITH the RCCL all-gather of C (csrc/sharded.hip) — BASELINE.json north_star:
+ * "Shard SpMM by row-blocks across the 8 GPUs of one node with an RCCL all-gather of C over xGMI".  The exports above return
+ * an R matrix in host memory and so need no collective (mx_set_devices); this is the form for a device-resident consumer
+ * that keeps multiplying one matrix (the loop of vignettes/Introducing_MatrixExtra.Rmd:452-470 around
+ * tcrossprod_csr_dense, src/matmul.cpp:316-375): the CSR is cut ONCE into one row block per listed device (distinct
+ * devices; balanced by entries + rows — a block's cost on its device —, or equal_rows = 1: ceil(m / ndev) rows each), every block stays on its
+ * device with what AUTO keeps per matrix (profile, sortedness, plan), each product runs on all devices at once — one host
+ * thread per device — and ONE in-place ncclAllGather of equal slots (ncclCommInitAll communicators, one process) leaves the
+ * full row-major C on EVERY device.  RCCL is dlopen()ed at first use (librccl.so.1; MXGPU_RCCL_LIB overrides).
+ * Gathered buffer on a device: ndev slots of slot_rows x n elements, row-major, ld = n; block r = rows [cuts[r], cuts[r+1])
+ * of C at the head of slot r (rows of a slot past its block are never written); with equal_rows slot r starts at row
+ * r * slot_rows = cuts[r]: a contiguous m x n matrix.  Two buffers alternate: a result stays valid until the product after
+ * the next one.  One device listed several times (a one-GPU box): its shards share the device's buffer, nothing is exchanged.
+ *   _run      B on the host (K x n row-major = the column-major n x K matrix Y of tcrossprod_csr_dense), uploaded to every
+ *             device; returns when every device holds C; C_host (NULL = none): a copy from the first device, row-major
+ *             m x n (ldc >= n) or column-major (ldc >= m, transposed on the device);
+ *   _run_dev  B_dev[k] = the operand already on shard k's device; flags bit 0: return once everything is queued — the
+ *             all-gather of this product then runs under the next product (mx_spmm_sharded_sync waits for all devices);
+ *   _result   the last product's gathered buffer on shard k's device;  _layout: the cuts and slot size for a device count
+ *             (host arithmetic only). */
+typedef struct mx_spmm_sharded mx_spmm_sharded;
+int  mx_spmm_sharded_layout(const int32_t *indptr, int m, int ndev, int dense_cols, int dense_bytes, int equal_rows,
+                            int *cuts /* ndev + 1 */, int *slot_rows);
+int  mx_spmm_sharded_create(const int *devices, int ndev, int m, int K, const int32_t *indptr, const int32_t *indices,
+                            const double *values, int equal_rows, mx_spmm_sharded **out);
+int  mx_spmm_sharded_info(const mx_spmm_sharded *h, int *nshards, int *slot_rows, int *cuts /* nshards + 1 */, int *uses_rccl,
+                          int *rccl_version);
+int  mx_spmm_sharded_run(mx_spmm_sharded *h, int n, int dense_dtype, const void *B_host, size_t ldb, void *C_host, size_t ldc,
+                         int colmajor_out);
+int  mx_spmm_sharded_run_dev(mx_spmm_sharded *h, int n, int dense_dtype, const void *const *B_dev, size_t ldb, int flags);
+int  mx_spmm_sharded_sync(mx_spmm_sharded *h);
+int  mx_spmm_sharded_result(const mx_spmm_sharded *h, int k, void **C_dev, int *n, int *dense_dtype, int *device);
+const char *mx_spmm_sharded_kernel(const mx_spmm_sharded *h, int k);
+int  mx_spmm_sharded_destroy(mx_spmm_sharded *h);
 /* raw device memory for callers that do not bring their own allocator */
 int  mx_dev_malloc(void **dptr, size_t bytes);
 int  mx_dev_free(void *dptr);

@@ -90,4 +90,4 @@ def test_line_without_extras_or_side_file():
 def test_bench_prints_through_headline_line():
     """bench.py has exactly one place that prints the line, and it goes through headline_line (no bare json.dumps(out))"""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert "print(json.dumps(" not in src and src.count("print(headline_line(") == 2
+    assert "print(json.dumps(" not in src and src.count("print(headline_line(") == 3

@@ -1493,7 +1493,7 @@ static int spmv_host(int m, const int32_t *indptr, const int32_t *indices, const
     // float (matmul.cpp:403) — the same `X %*% v` would return different last bits on its first and on later calls
     // (ADVICE r2).  The default is the one-shot flat kernel on every call: bit for bit the reference's loop.
     bool planned = false;
-    if (opt_spmv_planned() && A.cache_hit && A.nnz >= ((int64_t)1 << 20) && (len_y + 6143) / 6144 <= 64) {
+    if (opt_spmv_planned() && A.cache_hit && A.nnz >= ((int64_t)1 << 20) && len_y <= (1 << 28)) {   // (spmv_plan.hip: LDS panels up to 393,216 columns, L2 super-panels beyond)
         std::lock_guard<std::mutex> lk(A.hold->plan_mu);
         if (A.hold->spmv_plan && A.hold->spmv_plan_K != len_y) { mxd_spmv_plan_destroy(A.hold->spmv_plan); A.hold->spmv_plan = nullptr; }
         if (!A.hold->spmv_plan) {

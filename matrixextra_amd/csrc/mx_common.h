@@ -79,7 +79,8 @@ enum { MX_SCRATCH_SPMV_SLICES = 0, MX_SCRATCH_PARTIALS = 1, MX_SCRATCH_EXPORT_B 
        MX_SCRATCH_PROFILE = 8,        // counters of the one-shot AUTO's profile pass (profile.hip)
        MX_SCRATCH_LONGROWS = 9,       // list + pieces' partial sums of the row-split kernel's long rows (spmm_rowsplit.hip)
        MX_SCRATCH_MERGE_LONG = 10,    // list of the very long row pairs of a CSR (+) CSR launch (merge.hip)
-       MX_SCRATCH_SLOTS = 11 };
+       MX_SCRATCH_TILE_PERM = 11,     // slot -> row map of the tile kernel for rows of uneven length (spmm_tile.hip)
+       MX_SCRATCH_SLOTS = 12 };
 void *scratch_buffer(int slot, size_t bytes);
 void *scratch_buffer_zeroed(int slot, size_t bytes, hipStream_t st, bool *fresh);   // zero-filled when (re)allocated
 void scratch_release();

@@ -153,7 +153,7 @@ template <typename real_t, int CPL, int RG, int WIN, int TILE, bool COLMAJOR>
 __global__ __launch_bounds__((TL_MAX_WAVES + 1) * MX_WAVE)
 void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
                       const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ values,
-                      const unsigned char *__restrict__ unsorted,
+                      const unsigned char *__restrict__ unsorted, const int32_t *__restrict__ perm,
                       const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ C, size_t ldc, int c_vec, int nl, unsigned long long rgw, unsigned long long *__restrict__ stamps)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
@@ -242,7 +242,9 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
         }
 #pragma unroll
         for (int i = 0; i < RG; i++) {
-            const int row = i < my_rg ? row0 + (my_base + i) * TL_NG + g : m;      // (m: no such row)
+            // slot -> row: consecutive rows, or — rows of uneven length — the block's rows dealt by length (tile_deal_rows_kernel)
+            const int slot = (my_base + i) * TL_NG + g;
+            const int row = i < my_rg ? (perm ? perm[(size_t)rb * R + slot] : row0 + slot) : m;      // (m: no such row)
             rows[i] = row;
             pos[i] = end[i] = 0;
             if (row < m) { pos[i] = indptr[row]; end[i] = indptr[row + 1]; }
@@ -415,8 +417,8 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
         if (wave < nw) {
 #pragma unroll
             for (int i = 0; i < RG; i++) {
-                if (i >= my_rg) continue;
-                const int r = (my_base + i) * TL_NG + g;
+                if (i >= my_rg || rows[i] >= m) continue;
+                const int r = rows[i] - row0;                        // (the block's rows, whatever slots they were dealt to)
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
 #pragma unroll
@@ -445,6 +447,40 @@ void tile_unsorted_rows_kernel(int m, const int32_t *__restrict__ indptr, const 
     for (int k = s + lane; k + 1 < e; k += MX_WAVE) bad |= indices[k] > indices[k + 1];
     const bool any = __ballot(bad) != 0;
     if (lane == 0) flags[row] = any ? 1 : 0;
+}
+
+// Rows of UNEVEN length (round 6).  The four lane groups of a wavefront walk one row each in lockstep: a visit
+// costs the LONGEST of the four, and the wavefronts of a SIMD add up.  With consecutive rows in consecutive slots a log-normal
+// matrix (sigma 1.5) paid E[max of 4] / mean ~ 2x in every visit and its busiest SIMD half as much again (1e4 x 1e4, 500 per row,
+// n = 100: 0.31 ms where equal rows take 0.108).  Here the rows of a block are RANKED by length (R <= 300: every thread counts
+// the rows ahead of its own) and dealt: ranks 4q .. 4q + 3 share visit q — four rows of nearly the same length —, and the
+// visits, longest first, go to the wavefronts in snake order (wavefront w sits on SIMD w % 4: every SIMD gets the same mix).
+// A row is still summed by one group in storage order: the same bits.  perm[rb * R + slot] = row, m = no row.
+__global__ __launch_bounds__(256)
+void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const int32_t *__restrict__ indptr, int32_t *__restrict__ perm)
+{
+    __shared__ int len[TL_MAX_WAVES * TL_NG * 5 + 4];
+    __shared__ short visit_of[TL_MAX_WAVES * 5 + 1];
+    const int rb = blockIdx.x, row0 = rb * R;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) len[r] = row0 + r < m ? indptr[row0 + r + 1] - indptr[row0 + r] : -1;
+    if (threadIdx.x == 0) {
+        int base[TL_MAX_WAVES + 1], rg[TL_MAX_WAVES], maxrg = 0;
+        base[0] = 0;
+        for (int w = 0; w < nw; w++) { rg[w] = (int)((rgw >> (4 * w)) & 15); base[w + 1] = base[w] + rg[w]; maxrg = max(maxrg, rg[w]); }
+        int q = 0;
+        for (int i = 0; i < maxrg; i++)
+            for (int k = 0; k < nw; k++) {
+                const int w = (i & 1) ? nw - 1 - k : k;
+                if (rg[w] > i) visit_of[q++] = (short)(base[w] + i);
+            }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        const int mine = len[r];
+        int rank = 0;
+        for (int o = 0; o < R; o++) rank += (len[o] > mine || (len[o] == mine && o < r)) ? 1 : 0;
+        perm[(size_t)rb * R + visit_of[rank / TL_NG] * TL_NG + rank % TL_NG] = mine >= 0 ? row0 + r : m;
+    }
 }
 
 static unsigned long long *g_tile_stamps = nullptr;   // diagnostic (tools/tile_stamps.py): per wavefront, cycles at the tile barriers / in all
@@ -575,7 +611,7 @@ double tile_est_us(int m, int n, int K, int dense_bytes, double avg_len, int col
 
 template <typename real_t, int CPL, int RG, int WIN, int TILE>
 static void launch_tile(const TileGeom &gm, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
-                        const unsigned char *unsorted, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
+                        const unsigned char *unsorted, const int32_t *perm, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
                         hipStream_t st)
 {
     const int per = 8 % gm.nslabs == 0 ? 8 / gm.nslabs : 0;
@@ -583,18 +619,18 @@ static void launch_tile(const TileGeom &gm, int m, int n, int K, const int32_t *
     const dim3 block((unsigned)(gm.nw + gm.nl) * MX_WAVE);
     if (colmajor)
         hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, true>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
-                           gm.nrb, indptr, indices, values, unsorted, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
+                           gm.nrb, indptr, indices, values, unsorted, perm, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
     else
         hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, false>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
-                           gm.nrb, indptr, indices, values, unsorted, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
+                           gm.nrb, indptr, indices, values, unsorted, perm, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
 }
 
 template <typename real_t, int CPL, int WIN, int TILE>
 static void launch_tile_rg(const TileGeom &gm, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
-                           const unsigned char *unsorted, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
+                           const unsigned char *unsorted, const int32_t *perm, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
                            hipStream_t st)
 {
-#define MX_TL_RG(RG) launch_tile<real_t, CPL, RG, WIN, TILE>(gm, m, n, K, indptr, indices, values, unsorted, B, ldb, C, ldc, colmajor, c_vec, st)
+#define MX_TL_RG(RG) launch_tile<real_t, CPL, RG, WIN, TILE>(gm, m, n, K, indptr, indices, values, unsorted, perm, B, ldb, C, ldc, colmajor, c_vec, st)
     switch (gm.rg) {
     case 1: MX_TL_RG(1); break;
     case 2: MX_TL_RG(2); break;
@@ -647,15 +683,32 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
         scratch_acquire(MX_SCRATCH_TILE_FLAGS, stream);
         if (!flags) return set_error("tile_spmm: cannot allocate %d bytes of row flags", m);
     }
+    // rows of uneven length (the matrix profile in scope says so; MXGPU_TILE_DEAL=0 / 1 forces): the rows of every block are
+    // dealt to the lane groups by length (tile_deal_rows_kernel) — one small launch, worth it from cv ~ 0.15 on (Poisson row
+    // lengths of a uniform-density matrix: 0.045 at the vignette's shape, which stays on consecutive rows)
+    int32_t *perm = nullptr;
+    {
+        const char *de = getenv("MXGPU_TILE_DEAL");                      // (read per call: the tests and the A/B runs switch it)
+        const int deal_env = de ? atoi(de) : -1;
+        const bool deal = deal_env >= 0 ? deal_env != 0 : profile_cv() > 0.15;
+        if (deal && gm.R <= TL_MAX_WAVES * TL_NG * 5) {
+            perm = (int32_t *)scratch_buffer(MX_SCRATCH_TILE_PERM, (size_t)gm.nrb * gm.R * sizeof(int32_t));
+            if (perm) scratch_acquire(MX_SCRATCH_TILE_PERM, stream);
+            else (void)hipGetLastError();                              // (no memory for the map: consecutive rows)
+        }
+    }
     kt_begin(stream);
     if (flags)
         hipLaunchKernelGGL(tile_unsorted_rows_kernel, dim3((unsigned)ceil_div(m, 8)), dim3(512), 0, stream, m, indptr, indices, flags);
+    if (perm)
+        hipLaunchKernelGGL(tile_deal_rows_kernel, dim3((unsigned)gm.nrb), dim3(256), 0, stream, m, gm.R, gm.nw, gm.rgw, indptr, perm);
 #define MX_TL_GO(CPL, WIN, TILE)                                                                                                  \
-    launch_tile_rg<real_t, CPL, WIN, TILE>(gm, m, n, K, indptr, indices, values, flags, B, ldb, C, ldc, colmajor, c_vec, stream)
+    launch_tile_rg<real_t, CPL, WIN, TILE>(gm, m, n, K, indptr, indices, values, flags, perm, B, ldb, C, ldc, colmajor, c_vec, stream)
     if (gm.cpl == 2) { if (small_tile) MX_TL_GO(2, 1, 32768); else MX_TL_GO(2, 2, 65536); }
     else { if (small_tile) MX_TL_GO(1, 1, 32768); else MX_TL_GO(1, 2, 65536); }
 #undef MX_TL_GO
     if (flags) scratch_done(MX_SCRATCH_TILE_FLAGS, stream);
+    if (perm) scratch_done(MX_SCRATCH_TILE_PERM, stream);
     kt_end(stream);
     MX_LAUNCH_CHECK();
     return 0;

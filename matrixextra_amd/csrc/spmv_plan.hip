@@ -12,11 +12,23 @@
 //     (2 x 48 KiB): while it streams panel p's segment — 16 B per lane, fully coalesced, the only HBM traffic — and adds
 //     a * v_lds[c] into the row's sum (fire-and-forget ds_add_f64), the next panel of v comes in through registers.
 //     v is read once per row block (0.8 MB per 1.5 MB of entries, from L2, coalesced).
+// Round 6 — two more things a kept plan has to live with:
+//   * WIDE matrices.  64 LDS panels cover 393,216 columns; beyond that — BASELINE configs[3]'s own shape is 2M x 2M, v =
+//     16 MB, more than an XCD's 4 MiB L2, and the one-shot gather then runs at the Infinity Cache's line rate: 1.49 ms for
+//     1.24 GB, 0.10 of the roofline — the plan regroups the entries by SUPER-PANEL of 2^18 columns (2 MB of v) instead and the
+//     kernel reads v[j] straight from global memory: every workgroup starts at super-panel 0 and walks them in the same
+//     order, two workgroups per CU (no panel buffers in LDS) so that all row blocks of a product up to ~2M rows are resident
+//     together, and the 2 MB slice they are all reading sits in every XCD's L2.  Up to 1,024 super-panels (2^28 columns).
+//   * rows of UNEVEN length.  A row block used to be 4,096 rows whatever they held: with the rows sorted by length the first
+//     blocks carried ten times the entries of the last and their workgroups were the tail (0.95 ms against 0.077).  Blocks
+//     are now cut at every 4,096th row AND at every E-th entry (E = 1.5 x the mean block): at most 4,096 rows and about E
+//     entries each (spmv_plan_cuts_kernel: two families of binary searches merged by rank — no host pass over indptr).
 // Measured (cfg3, MI355X): DESIGN.md §4.3.  Summation order: per row, panels in ascending order; inside a panel the
 // entries of a row are added with LDS atomics in whatever order their wavefronts arrive: equal to the reference to
 // 1e-12 (f64), not bitwise and not run-to-run reproducible in the last bit — the one-shot flat kernel (spmv_flat.hip) is
 // the bit-exact path.  float32 kind: sums kept in f64, rounded once (the reference rounds after every term: 1e-5).
 #include "mx_common.h"
+#include <algorithm>
 #include <new>
 
 namespace mx {
@@ -27,39 +39,82 @@ size_t scan_workspace_bytes(int64_t n);
 constexpr int SP_RB = 4096;                  // rows per block (one workgroup)
 constexpr int SP_PANEL = 6144;               // columns per panel: 48 KiB of f64
 constexpr int SP_THREADS = 1024;
-constexpr int SP_MAX_PANELS = 64;
+constexpr int SP_MAX_PANELS = 64;            // LDS mode: K <= 64 x 6144
 constexpr int SP_COL_BITS = 13;              // entry = row_in_block << 13 | col_in_panel  (row 4096 = the padding's dummy row)
 static_assert(SP_PANEL <= (1 << SP_COL_BITS), "column field");
+constexpr int SP_WIDE_BITS = 18;             // wide mode: super-panels of 2^18 columns (2 MB of f64), read from L2
+constexpr int SP_WIDE_MAX_PANELS = 1024;     // 2^28 columns
+static_assert(13 + SP_WIDE_BITS <= 31, "row-in-block (0 .. 4096) and column-in-panel share 31 bits");
 
-// entries of row block `rb` per panel, rounded up to 4 (segments are read 4 entries per lane)
-__global__ __launch_bounds__(SP_THREADS)
-void spmv_plan_count_kernel(int m, int npanels, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                            int32_t *__restrict__ counts)
+// Row-block boundaries: the union of {every 4,096th row} and {the first row that starts at or after every E-th entry},
+// sorted — nA + nB points, the last one m.  Point k of family A: min(k * 4096, m), k = 0 .. nA - 1; point j of family B:
+// lower_bound(indptr - indptr[0], j * E), j = 1 .. nB.  Each thread places one point at its rank in the merged order (its
+// index in its own family + the points of the other family before it; ties: A first).  Equal points = empty blocks.
+__global__ __launch_bounds__(256)
+void spmv_plan_cuts_kernel(int m, const int32_t *__restrict__ indptr, int nA, int nB, long long E, int32_t *__restrict__ cuts)
 {
-    __shared__ int hist[SP_MAX_PANELS];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nA + nB) return;
+    const long long base = indptr[0];
+    auto b_point = [&](int j) -> int {              // first row r with indptr[r] - base >= j * E   (j >= 1; <= m)
+        const long long target = (long long)j * E + base;
+        int lo = 0, hi = m;
+        while (lo < hi) { const int mid = lo + (hi - lo) / 2; if ((long long)indptr[mid] < target) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    if (t < nA) {
+        const int a = (int)min((long long)t * SP_RB, (long long)m);
+        // points of B strictly before a: B_j < a  <=>  the row a - 1 ... monotone in j: binary search over j
+        int lo = 0, hi = nB;                        // number of j in 1 .. nB with B_j < a
+        while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (b_point(mid + 1) < a) lo = mid + 1; else hi = mid; }
+        cuts[t + lo] = a;
+    } else {
+        const int j = t - nA + 1, b = b_point(j);
+        // points of A at or before b: k * 4096 <= b (and the last point m when b == m)
+        const int ka = min(b / SP_RB + 1, nA - 1) + (b >= m ? 1 : 0);
+        cuts[j - 1 + ka] = b;
+    }
+}
+
+// panel of a column id: LDS mode divides by 6144, wide mode shifts by 18 (ids outside [0, K) are the caller's bug: kept from
+// corrupting memory)
+template <bool WIDE> __device__ __forceinline__ int sp_panel_of(int col, int npanels)
+{
+    const int c = max(col, 0);
+    return min(WIDE ? c >> SP_WIDE_BITS : c / SP_PANEL, npanels - 1);
+}
+// entries of row block `rb` per panel, rounded up to 4 (segments are read 4 entries per lane)
+template <bool WIDE>
+__global__ __launch_bounds__(SP_THREADS)
+void spmv_plan_count_kernel(int npanels, const int32_t *__restrict__ rb_row, const int32_t *__restrict__ indptr,
+                            const int32_t *__restrict__ indices, int32_t *__restrict__ counts)
+{
+    __shared__ int hist[WIDE ? SP_WIDE_MAX_PANELS : SP_MAX_PANELS];
     const int rb = blockIdx.x;
-    if (threadIdx.x < SP_MAX_PANELS) hist[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < npanels; i += SP_THREADS) hist[i] = 0;
     __syncthreads();
-    const int r0 = rb * SP_RB, r1 = min(r0 + SP_RB, m);
+    const int r0 = rb_row[rb], r1 = rb_row[rb + 1];
     const int s = indptr[r0], e = indptr[r1];
-    for (int k = s + threadIdx.x; k < e; k += SP_THREADS) atomicAdd(&hist[min(max(indices[k], 0) / SP_PANEL, npanels - 1)], 1);   // (ids outside [0, K) are the caller's bug: kept from corrupting memory)
+    for (int k = s + threadIdx.x; k < e; k += SP_THREADS) atomicAdd(&hist[sp_panel_of<WIDE>(indices[k], npanels)], 1);
     __syncthreads();
-    if ((int)threadIdx.x < npanels) counts[(size_t)rb * npanels + threadIdx.x] = (hist[threadIdx.x] + 3) & ~3;
+    for (int i = threadIdx.x; i < npanels; i += SP_THREADS) counts[(size_t)rb * npanels + i] = (hist[i] + 3) & ~3;
 }
 
 // scatter: the block's entries are read flat (coalesced); an entry's row comes from a binary search of the block's row
 // pointers held in LDS, its position from the segment start + an LDS cursor per panel (so the order of a segment's
 // entries varies from build to build — the sums' last bits with it)
+template <bool WIDE>
 __global__ __launch_bounds__(SP_THREADS)
-void spmv_plan_fill_kernel(int m, int npanels, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                           const double *__restrict__ values, const int32_t *__restrict__ seg_off,
+void spmv_plan_fill_kernel(int npanels, const int32_t *__restrict__ rb_row, const int32_t *__restrict__ indptr,
+                           const int32_t *__restrict__ indices, const double *__restrict__ values, const int32_t *__restrict__ seg_off,
                            int32_t *__restrict__ ent, double *__restrict__ val)
 {
-    __shared__ int cursor[SP_MAX_PANELS];
+    constexpr int CB = WIDE ? SP_WIDE_BITS : SP_COL_BITS;
+    __shared__ int cursor[WIDE ? SP_WIDE_MAX_PANELS : SP_MAX_PANELS];
     __shared__ int ip[SP_RB + 1];
     const int rb = blockIdx.x;
-    if (threadIdx.x < SP_MAX_PANELS) cursor[threadIdx.x] = 0;
-    const int r0 = rb * SP_RB, r1 = min(r0 + SP_RB, m), nr = r1 - r0;
+    for (int i = threadIdx.x; i < npanels; i += SP_THREADS) cursor[i] = 0;
+    const int r0 = rb_row[rb], r1 = rb_row[rb + 1], nr = r1 - r0;
     for (int i = threadIdx.x; i <= nr; i += SP_THREADS) ip[i] = indptr[r0 + i];
     __syncthreads();
     const int32_t *__restrict__ so = seg_off + (size_t)rb * npanels;
@@ -67,16 +122,16 @@ void spmv_plan_fill_kernel(int m, int npanels, const int32_t *__restrict__ indpt
     for (int k = s + threadIdx.x; k < e; k += SP_THREADS) {
         int lo = 0, hi = nr;                                     // the row r with ip[r] <= k < ip[r + 1]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ip[mid] <= k) lo = mid; else hi = mid; }
-        const int col = max(indices[k], 0), pan = min(col / SP_PANEL, npanels - 1);
+        const int col = max(indices[k], 0), pan = sp_panel_of<WIDE>(col, npanels);
         const int pos = so[pan] + atomicAdd(&cursor[pan], 1);
-        ent[pos] = (lo << SP_COL_BITS) | min(col - pan * SP_PANEL, SP_PANEL - 1);
+        ent[pos] = (lo << CB) | (WIDE ? min(col - (pan << SP_WIDE_BITS), (1 << SP_WIDE_BITS) - 1) : min(col - pan * SP_PANEL, SP_PANEL - 1));
         val[pos] = values[k];
     }
     __syncthreads();
     // padding up to the rounded segment length: the dummy row SP_RB, column 0, value 0
     for (int pan = threadIdx.x >> 2; pan < npanels; pan += SP_THREADS >> 2) {
         const int pos = so[pan] + cursor[pan] + (threadIdx.x & 3);
-        if (pos < so[pan + 1]) { ent[pos] = SP_RB << SP_COL_BITS; val[pos] = 0.0; }
+        if (pos < so[pan + 1]) { ent[pos] = SP_RB << CB; val[pos] = 0.0; }
     }
 }
 
@@ -93,43 +148,65 @@ __device__ __forceinline__ double sp_factor(const void *__restrict__ v_, int j)
     }
 }
 
-template <int KIND>
+template <int KIND, bool WIDE>
 __global__ __launch_bounds__(SP_THREADS)
-void spmv_plan_kernel(int m, int K, int npanels, const int32_t *__restrict__ seg_off, const int32_t *__restrict__ ent,
-                      const double *__restrict__ val, const void *__restrict__ v_, void *__restrict__ y_)
+void spmv_plan_kernel(int m, int K, int npanels, const int32_t *__restrict__ rb_row, const int32_t *__restrict__ seg_off,
+                      const int32_t *__restrict__ ent, const double *__restrict__ val, const void *__restrict__ v_, void *__restrict__ y_)
 {
     typedef int i4 __attribute__((ext_vector_type(4)));
     typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int CB = WIDE ? SP_WIDE_BITS : SP_COL_BITS;
     constexpr int PER = SP_PANEL / SP_THREADS;                        // panel elements staged per thread (6)
     __shared__ double acc[SP_RB + 8];                                 // + the padding's dummy row
-    __shared__ double vpan[2][SP_PANEL];
+    __shared__ double vpan[WIDE ? 1 : 2][WIDE ? 1 : SP_PANEL];        // (wide mode reads v from global memory: no panel buffers)
     // integer / logical vectors: one bit per row "an NA element took part" (the reference adds NA_REAL itself for such a
     // term, matmul.cpp:406-411: the row's result is NA_real_, whereas a NaN that comes out of the arithmetic stays a NaN —
     // R tells the two apart; the flag, not `sum != sum`, decides, as RowAcc does in spmv_rows.h)
     __shared__ unsigned na_rows[(SP_RB + 8 + 31) / 32];
     const int tid = threadIdx.x, rb = blockIdx.x;
+    const int r0 = rb_row[rb], nr = rb_row[rb + 1] - r0;
+    if (nr <= 0) return;                                              // (an empty block: two cuts at the same row)
     for (int i = tid; i < SP_RB + 8; i += SP_THREADS) acc[i] = 0.0;
     if constexpr (KIND == MX_I32 || KIND == MX_LGL)
         for (int i = tid; i < (SP_RB + 8 + 31) / 32; i += SP_THREADS) na_rows[i] = 0u;
     const int32_t *__restrict__ so = seg_off + (size_t)rb * npanels;
-    // panel 0 -> buffer 0
     double stage[PER];
+    if constexpr (!WIDE) {                                            // panel 0 -> buffer 0
 #pragma unroll
-    for (int i = 0; i < PER; i++) { const int c = i * SP_THREADS + tid; stage[i] = c < K ? sp_factor<KIND>(v_, c) : 0.0; }
+        for (int i = 0; i < PER; i++) { const int c = i * SP_THREADS + tid; stage[i] = c < K ? sp_factor<KIND>(v_, c) : 0.0; }
 #pragma unroll
-    for (int i = 0; i < PER; i++) vpan[0][i * SP_THREADS + tid] = stage[i];
+        for (int i = 0; i < PER; i++) vpan[0][i * SP_THREADS + tid] = stage[i];
+    }
     __syncthreads();
+    // one entry: its factor (LDS panel / global memory), the product, the row's sum
+    auto term = [&](int code, double a, const double *__restrict__ vp, int cbase) {
+        const int c = code & ((1 << CB) - 1), r = (int)((unsigned)code >> CB);
+        double f;
+        if constexpr (WIDE) f = sp_factor<KIND>(v_, min(cbase + c, K - 1));          // (the padding's column 0 of the last panel stays in range)
+        else f = vp[c];
+        double t = a * f;
+        if constexpr (KIND == MX_I32 || KIND == MX_LGL) {
+            if (__double_as_longlong(f) == (long long)MX_NA_REAL_BITS) {
+                t = 0.0;
+                if (r < SP_RB) atomicOr(&na_rows[r >> 5], 1u << (r & 31));
+            }
+        }
+        __hip_atomic_fetch_add(&acc[r], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     for (int p = 0; p < npanels; p++) {
-        const double *__restrict__ vp = vpan[p & 1];
+        const double *__restrict__ vp = vpan[WIDE ? 0 : (p & 1)];
+        const int cbase = WIDE ? p << SP_WIDE_BITS : 0;
         // the next panel's elements are requested now and written to the other buffer after this panel's stream
-        const int cb_next = (p + 1) * SP_PANEL;
-        if (p + 1 < npanels) {
+        if constexpr (!WIDE) {
+            const int cb_next = (p + 1) * SP_PANEL;
+            if (p + 1 < npanels) {
 #pragma unroll
-            for (int i = 0; i < PER; i++) { const int c = cb_next + i * SP_THREADS + tid; stage[i] = c < K ? sp_factor<KIND>(v_, c) : 0.0; }
+                for (int i = 0; i < PER; i++) { const int c = cb_next + i * SP_THREADS + tid; stage[i] = c < K ? sp_factor<KIND>(v_, c) : 0.0; }
+            }
         }
         const int s = so[p], e = so[p + 1];                           // multiples of 4
         for (int k0 = s + tid * 4; k0 < e; k0 += SP_THREADS * 4 * 2) {
-            // two quads per thread and trip: 6 loads in flight
+            // two quads per thread and trip: 6 loads in flight (wide mode: then 8 independent reads of v)
             const int k1 = k0 + SP_THREADS * 4;
             const bool two = k1 < e;
             const i4 c0 = *reinterpret_cast<const i4 *>(ent + k0);
@@ -138,41 +215,53 @@ void spmv_plan_kernel(int m, int K, int npanels, const int32_t *__restrict__ seg
             const i4 c1 = *reinterpret_cast<const i4 *>(ent + kb);
             const d2 b0 = *reinterpret_cast<const d2 *>(val + kb), b1 = *reinterpret_cast<const d2 *>(val + kb + 2);
             const double av[4] = {a0[0], a0[1], a1[0], a1[1]}, bv[4] = {b0[0], b0[1], b1[0], b1[1]};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const double f = vp[c0[q] & ((1 << SP_COL_BITS) - 1)];
-                double t = av[q] * f;
-                if constexpr (KIND == MX_I32 || KIND == MX_LGL) {
-                    if (__double_as_longlong(f) == (long long)MX_NA_REAL_BITS) {
-                        t = 0.0;
-                        atomicOr(&na_rows[(c0[q] >> SP_COL_BITS) >> 5], 1u << ((c0[q] >> SP_COL_BITS) & 31));
-                    }
-                }
-                __hip_atomic_fetch_add(&acc[c0[q] >> SP_COL_BITS], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (two) {
+            if constexpr (WIDE) {
+                // all eight factors first (independent loads), then the sums
+                double f0[4], f1[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const double f = vp[c1[q] & ((1 << SP_COL_BITS) - 1)];
-                    double t = bv[q] * f;
+                    f0[q] = sp_factor<KIND>(v_, min(cbase + (c0[q] & ((1 << CB) - 1)), K - 1));
+                    f1[q] = sp_factor<KIND>(v_, min(cbase + (c1[q] & ((1 << CB) - 1)), K - 1));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int r = (int)((unsigned)c0[q] >> CB);
+                    double t = av[q] * f0[q];
                     if constexpr (KIND == MX_I32 || KIND == MX_LGL) {
-                        if (__double_as_longlong(f) == (long long)MX_NA_REAL_BITS) {
-                            t = 0.0;
-                            atomicOr(&na_rows[(c1[q] >> SP_COL_BITS) >> 5], 1u << ((c1[q] >> SP_COL_BITS) & 31));
-                        }
+                        if (__double_as_longlong(f0[q]) == (long long)MX_NA_REAL_BITS) { t = 0.0; if (r < SP_RB) atomicOr(&na_rows[r >> 5], 1u << (r & 31)); }
                     }
-                    __hip_atomic_fetch_add(&acc[c1[q] >> SP_COL_BITS], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&acc[r], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (two) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int r = (int)((unsigned)c1[q] >> CB);
+                        double t = bv[q] * f1[q];
+                        if constexpr (KIND == MX_I32 || KIND == MX_LGL) {
+                            if (__double_as_longlong(f1[q]) == (long long)MX_NA_REAL_BITS) { t = 0.0; if (r < SP_RB) atomicOr(&na_rows[r >> 5], 1u << (r & 31)); }
+                        }
+                        __hip_atomic_fetch_add(&acc[r], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) term(c0[q], av[q], vp, cbase);
+                if (two) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) term(c1[q], bv[q], vp, cbase);
                 }
             }
         }
-        if (p + 1 < npanels) {
+        if constexpr (!WIDE) {
+            if (p + 1 < npanels) {
 #pragma unroll
-            for (int i = 0; i < PER; i++) vpan[(p + 1) & 1][i * SP_THREADS + tid] = stage[i];
+                for (int i = 0; i < PER; i++) vpan[(p + 1) & 1][i * SP_THREADS + tid] = stage[i];
+            }
+            __syncthreads();           // the next panel is in LDS; every wavefront is done with this one's buffer and sums
         }
-        __syncthreads();               // the next panel is in LDS; every wavefront is done with this one's buffer and sums
     }
-    const int r0 = rb * SP_RB;
-    for (int i = tid; i < SP_RB && r0 + i < m; i += SP_THREADS) {
+    if constexpr (WIDE) __syncthreads();
+    for (int i = tid; i < nr; i += SP_THREADS) {
         const double sum = acc[i];
         if constexpr (KIND == MX_F32) ((float *)y_)[r0 + i] = (float)sum;
         else if constexpr (KIND == MX_I32 || KIND == MX_LGL) ((double *)y_)[r0 + i] = (na_rows[i >> 5] >> (i & 31)) & 1u ? na_real() : sum;
@@ -184,7 +273,9 @@ void spmv_plan_kernel(int m, int K, int npanels, const int32_t *__restrict__ seg
 
 struct mx_spmv_plan {
     int m = 0, K = 0, nrb = 0, npanels = 0;
+    bool wide = false;
     long long nnz = 0, slots = 0;
+    int32_t *rb_row = nullptr;               // [nrb + 1] first row of every block
     int32_t *seg_off = nullptr;
     int32_t *ent = nullptr;
     double *val = nullptr;
@@ -193,6 +284,7 @@ struct mx_spmv_plan {
 extern "C" int mxd_spmv_plan_destroy(mx_spmv_plan *pl)
 {
     if (!pl) return 0;
+    if (pl->rb_row) (void)hipFree(pl->rb_row);
     if (pl->seg_off) (void)hipFree(pl->seg_off);
     if (pl->ent) (void)hipFree(pl->ent);
     if (pl->val) (void)hipFree(pl->val);
@@ -205,23 +297,37 @@ extern "C" int mxd_spmv_plan_create(int m, int K, const int32_t *indptr, const i
 {
     using namespace mx;
     MX_REQUIRE(plan_out && m >= 0 && K >= 0, "mxd_spmv_plan_create: bad arguments");
-    const int npanels = (int)ceil_div(K > 0 ? K : 1, SP_PANEL);
-    MX_REQUIRE(npanels <= SP_MAX_PANELS, "mxd_spmv_plan_create: more than %d columns (use the one-shot kernels)", SP_MAX_PANELS * SP_PANEL);
+    // up to 64 LDS panels of 6,144 columns; wider matrices: super-panels of 2^18 columns read through L2
+    const bool wide = ceil_div(K > 0 ? K : 1, SP_PANEL) > SP_MAX_PANELS;
+    const int npanels = wide ? (int)ceil_div(K, 1 << SP_WIDE_BITS) : (int)ceil_div(K > 0 ? K : 1, SP_PANEL);
+    MX_REQUIRE(!wide || npanels <= SP_WIDE_MAX_PANELS, "mxd_spmv_plan_create: more than 2^28 columns (use the one-shot kernels)");
     mx_spmv_plan *pl = new (std::nothrow) mx_spmv_plan();
     MX_REQUIRE(pl, "out of host memory");
-    pl->m = m; pl->K = K; pl->npanels = npanels; pl->nrb = (int)ceil_div(m, SP_RB);
+    pl->m = m; pl->K = K; pl->npanels = npanels; pl->wide = wide;
     *plan_out = pl;
     if (m == 0) return 0;
     hipStream_t st = as_stream(stream);
-    const int64_t nseg = (int64_t)pl->nrb * npanels;
     int32_t *counts = nullptr;
     void *scan_ws = nullptr;
     int rc = 1;
     do {
+        // the entry count sizes the cuts (one 8-byte read-back; the build synchronises further down anyway)
+        int32_t ends[2] = {0, 0};
+        if (read_back_small(&ends[0], indptr, sizeof(int32_t), st) || read_back_small(&ends[1], indptr + m, sizeof(int32_t), st)) break;
+        pl->nnz = (long long)ends[1] - ends[0];
+        // row blocks: at most 4,096 rows and about E entries (1.5 mean blocks, at least 32k: a block must be worth a workgroup)
+        const long long mean_block = (long long)((double)pl->nnz / (double)m * SP_RB);
+        const long long E = std::max<long long>(32768, mean_block + mean_block / 2);
+        const int nA = (int)ceil_div(m, SP_RB) + 1, nB = pl->nnz > 0 ? (int)std::min<long long>((pl->nnz - 1) / E, 1 << 20) : 0;
+        pl->nrb = nA + nB - 1;
+        const int64_t nseg = (int64_t)pl->nrb * npanels;
+        if (hipMalloc((void **)&pl->rb_row, ((size_t)pl->nrb + 1) * 4) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
         if (hipMalloc((void **)&counts, (size_t)nseg * 4 + 16) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
         if (hipMalloc(&scan_ws, scan_workspace_bytes(nseg) + 16) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
         if (hipMalloc((void **)&pl->seg_off, ((size_t)nseg + 1) * 4) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
-        hipLaunchKernelGGL(spmv_plan_count_kernel, dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, m, npanels, indptr, indices, counts);
+        hipLaunchKernelGGL(spmv_plan_cuts_kernel, dim3((unsigned)ceil_div(nA + nB, 256)), dim3(256), 0, st, m, indptr, nA, nB, E, pl->rb_row);
+        if (wide) hipLaunchKernelGGL(spmv_plan_count_kernel<true>, dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, npanels, pl->rb_row, indptr, indices, counts);
+        else hipLaunchKernelGGL(spmv_plan_count_kernel<false>, dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, npanels, pl->rb_row, indptr, indices, counts);
         if (exclusive_scan_i32(counts, nseg, pl->seg_off, (int64_t *)scan_ws, scan_ws, st)) break;
         long long total = 0;
         if (read_back_small(&total, scan_ws, sizeof(total), st)) break;
@@ -231,8 +337,10 @@ extern "C" int mxd_spmv_plan_create(int m, int K, const int32_t *indptr, const i
             set_error("spmv plan: allocation failed");
             break;
         }
-        hipLaunchKernelGGL(spmv_plan_fill_kernel, dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, m, npanels, indptr, indices, values,
-                           pl->seg_off, pl->ent, pl->val);
+        if (wide) hipLaunchKernelGGL(spmv_plan_fill_kernel<true>, dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, npanels, pl->rb_row, indptr, indices, values,
+                                     pl->seg_off, pl->ent, pl->val);
+        else hipLaunchKernelGGL(spmv_plan_fill_kernel<false>, dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, npanels, pl->rb_row, indptr, indices, values,
+                                pl->seg_off, pl->ent, pl->val);
         if (hipGetLastError() != hipSuccess) { set_error("spmv plan: launch failed"); break; }
         if (hipStreamSynchronize(st) != hipSuccess) { set_error("spmv plan: build failed"); break; }     // scratch is freed below
         rc = 0;
@@ -258,9 +366,13 @@ extern "C" int mxd_spmv_plan_run(const mx_spmv_plan *pl, const void *v, int v_dt
     if (pl->m == 0) return 0;
     MX_REQUIRE(v || pl->K == 0, "mxd_spmv_plan_run: null vector");
     hipStream_t st = as_stream(stream);
-#define MX_SP(KIND)                                                                                                  \
-    hipLaunchKernelGGL((spmv_plan_kernel<KIND>), dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, pl->m, pl->K,     \
-                       pl->npanels, pl->seg_off, pl->ent, pl->val, v, y)
+#define MX_SP(KIND)                                                                                                          \
+    do {                                                                                                                     \
+        if (pl->wide) hipLaunchKernelGGL((spmv_plan_kernel<KIND, true>), dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, pl->m, pl->K, \
+                                         pl->npanels, pl->rb_row, pl->seg_off, pl->ent, pl->val, v, y);                      \
+        else hipLaunchKernelGGL((spmv_plan_kernel<KIND, false>), dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, pl->m, pl->K,         \
+                                pl->npanels, pl->rb_row, pl->seg_off, pl->ent, pl->val, v, y);                               \
+    } while (0)
     switch (v_dtype) {
         case MX_F64: MX_SP(MX_F64); break;
         case MX_I32: MX_SP(MX_I32); break;

@@ -3,6 +3,8 @@ kernel (csrc/spmv_tile.hip, MX_SPMV_TILE) against the oracle (matmul_csr_dvec<>,
 src/matmul.cpp:381-419).  Rows of up to 256 entries are summed in storage order from separately rounded products, i.e.
 exactly the reference's loop without FMA contraction: compared BITWISE with the oracle (built -ffp-contract=off); longer
 rows are summed by a wavefront (reassociated): 1e-12."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -177,11 +179,51 @@ def test_planned_spmv_headline_shape_ragged_and_duplicates(gpu):
     _check_planned(p, j, x, 50_000, seed=2)
 
 
+def test_planned_spmv_wide_matrices_go_through_l2_super_panels(gpu):
+    """More than 64 x 6,144 columns (round 5 refused them): super-panels of 2^18 columns, v read from global memory.  All four
+    kinds with NA elements, columns on both sides of every super-panel boundary, the last (partial) super-panel, empty rows."""
+    rng = np.random.default_rng(3)
+    for m, K, per_row in ((100, 500_000, 8), (20_000, 1_000_003, 12), (9_000, 2_100_000, 40)):
+        p, j, x = synth.csr_fixed(m, K, per_row, seed=m)
+        j = j.copy()
+        hit = rng.integers(0, j.size, size=200)                              # ids at the panel edges and the last column
+        j[hit] = rng.choice([0, (1 << 18) - 1, 1 << 18, (1 << 18) + 1, K - 1, (K >> 18 << 18), max(0, (K >> 18 << 18) - 1)], size=200)
+        _check_planned(p, j, x, K, seed=K)
+    lens = rng.integers(0, 30, size=30_000)
+    lens[rng.random(30_000) < 0.2] = 0
+    lens[5] = 100_000
+    p, j, x = ragged_csr(lens, 700_000, seed=2, sort=False, dup=True)
+    _check_planned(p, j, x, 700_000, seed=7)
+
+
+@pytest.mark.parametrize("K", [60_000, 600_000])
+def test_planned_spmv_row_blocks_follow_the_entries(gpu, K):
+    """Rows sorted by length (longest first), a few giant rows, long runs of empty rows: row blocks are cut at every 4,096th
+    row AND at every E-th entry — every row is in exactly one block whatever the cuts (the result is complete), and the plan's
+    padding stays small."""
+    rng = np.random.default_rng(K)
+    m = 70_000
+    lens = np.sort(np.minimum(rng.lognormal(mean=2.5, sigma=1.2, size=m), 20_000).astype(np.int64))[::-1].copy()
+    lens[0], lens[1] = 150_000 if K > 150_000 else K, 40_000
+    lens[30_000:45_000] = 0
+    p, j, x = ragged_csr(lens, K, seed=1, sort=False, dup=True)
+    _check_planned(p, j, x, K, seed=5)
+    lens = np.zeros(m, dtype=np.int64); lens[m - 1] = 5000                   # everything in the last row
+    p, j, x = ragged_csr(lens, K, seed=1, sort=False, dup=True)
+    _check_planned(p, j, x, K, seed=6)
+
+
 def test_planned_spmv_limits(gpu):
     from devmem import spmv_plan_device
-    p, j, x = synth.csr_fixed(100, 500_000, 8, seed=1)                      # more than 64 panels
-    with pytest.raises(_lib.MxError):
-        spmv_plan_device(p, j, x, [(np.zeros(500_000), _lib.MX_F64)])
+    p = (np.arange(11) * 4).astype(np.int32)                                  # more than 2^28 columns
+    j = np.arange(40, dtype=np.int32) * 1000
+    x = np.ones(40)
+    lib = _lib.load()
+    plan = C.c_void_p()
+    from devmem import Dev
+    dp, dj, dx = Dev(p.astype(np.int32)), Dev(j.astype(np.int32)), Dev(x.astype(np.float64))
+    assert lib.mxd_spmv_plan_create(C.c_int(10), C.c_int(1 << 29), dp.ptr, dj.ptr, dx.ptr, None, C.byref(plan)) != 0
+    assert b"2^28" in lib.mx_last_error()
     p0 = np.zeros(11, dtype=np.int32)                                        # a matrix without entries
     out = spmv_plan_device(p0, np.zeros(0, dtype=np.int32), np.zeros(0), [(np.ones(30), _lib.MX_F64)])
     np.testing.assert_array_equal(out[0], np.zeros(10))

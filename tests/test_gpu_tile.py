@@ -178,3 +178,40 @@ def test_auto_takes_the_tile_kernel_for_dense_ish_operands(gpu):
         got = D.spmm(A, torch.from_numpy(B).cuda(), colmajor=colmajor).cpu().numpy()
         assert lib.mxd_spmm_last_kernel() == b"spmm_tile_kernel"
         _same(np.ascontiguousarray(got), _oracle(p, j, x, B))
+
+
+@pytest.mark.parametrize("colmajor", [False, True])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tile_rows_dealt_by_length_keep_every_bit(gpu, monkeypatch, colmajor, dtype):
+    """Rows of uneven length (round 6): the rows of a block are ranked by length and dealt to the lane groups — four rows of
+    nearly the same length per visit, the visits in snake order over the wavefronts (tile_deal_rows_kernel).  A row is still
+    summed by ONE group in storage order: bit for bit the oracle's FMA chain, in both layouts, with the map forced on
+    (MXGPU_TILE_DEAL=1), forced off, and chosen from the matrix profile; every geometry the dealing can meet: a last block with
+    fewer rows than slots, empty rows, a giant row, rows that are not sorted by column."""
+    rng = np.random.default_rng(21)
+    for m, K, n in ((1000, 2000, 100), (333, 900, 64), (5, 400, 32)):
+        lens = np.minimum(rng.lognormal(mean=3.0, sigma=1.4, size=m).astype(np.int64), K)
+        lens[rng.integers(0, m, size=max(1, m // 50))] = 0
+        lens[m // 3] = K                                             # one full row
+        p = np.zeros(m + 1, dtype=np.int32); p[1:] = np.cumsum(lens)
+        j = np.concatenate([np.sort(rng.choice(K, size=int(L), replace=False)) for L in lens]).astype(np.int32)
+        j[p[2]:p[3]] = j[p[2]:p[3]][::-1]                            # one row not sorted by column: summed whole, flagged
+        x = rng.uniform(-1, 1, size=j.size)
+        B = rng.normal(size=(K, n)).astype(dtype)
+        ref = _oracle(p, j, x, B)
+        outs = []
+        for deal in ("1", "0"):
+            monkeypatch.setenv("MXGPU_TILE_DEAL", deal)
+            for var, nw in ((0, 0), (variant(1, 3), 5), (variant(2, 2), 14)):
+                got = _run(p, j, x, B, colmajor, var, nw, rows_sorted=False)
+                _same(got, ref)
+            outs.append(got)
+        assert np.array_equal(outs[0], outs[1])
+        monkeypatch.delenv("MXGPU_TILE_DEAL")
+        # through the device layer with the matrix profile in scope (cv ~ 2: dealt) — the same bits again
+        import torch
+        from matrixextra_amd import device as D
+        A = D.DeviceCSR.from_host(p, j, x, K)
+        assert A.profile()[32] > 0.15
+        got = D.spmm(A, torch.from_numpy(B).cuda(), colmajor=colmajor, algo=TILE).cpu().numpy()
+        _same(got, ref)

@@ -18,10 +18,10 @@ else:
 B = torch.randn(K, n, dtype=dt, device="cuda")
 C = torch.empty(n, m, dtype=dt, device="cuda")
 lib = _lib.load()
-for _ in range(12): D.spmm(A, B, out=C, colmajor=True)
+for _ in range(int(os.environ.get('SWEEP_SETUP', 12))): D.spmm(A, B, out=C, colmajor=True)
 torch.cuda.synchronize()
 lib.mxd_spmm_kernel_timing(1)
-for _ in range(20): D.spmm(A, B, out=C, colmajor=True)
+for _ in range(int(os.environ.get('SWEEP_STEPS', 20))): D.spmm(A, B, out=C, colmajor=True)
 torch.cuda.synchronize()
 kt = (ctypes.c_float * 256)(); kc = ctypes.c_int(0)
 lib.mxd_spmm_kernel_times(kt, 256, ctypes.byref(kc))

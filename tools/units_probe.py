@@ -22,25 +22,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/units")
 
 PASSES = [
+    "GRBM_GUI_ACTIVE GRBM_COUNT",
+    "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum",
+    "TA_BUSY_avr TA_TA_BUSY_sum TA_BUSY_max TA_BUSY_min",
+    "TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_FLAT_WAVEFRONTS_sum TA_TOTAL_WAVEFRONTS_sum",
+    "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum",
+    "TCP_GATE_EN2_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum",
+    "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum",
+    "TCP_TCP_LATENCY_sum TCP_TOTAL_READ_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum",
+    "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TD_SPI_STALL_sum",
+    "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum",
+    "TCC_TAG_STALL_sum TCC_BUSY_avr TCC_EA0_RDREQ_sum",
+
     "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS",
     "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA",
     "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_BRANCH SQ_INSTS_FLAT",
-    "TA_BUSY_avr TA_TA_BUSY_sum TA_BUSY_max TA_BUSY_min",
-    "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum",
-    "TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_FLAT_WAVEFRONTS_sum TA_BUFFER_WAVEFRONTS_sum",
-    "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum",
-    "TCP_GATE_EN2_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum",
-    "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum",
-    "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TD_SPI_STALL_sum",
-    "GRBM_GUI_ACTIVE GRBM_COUNT",
-    "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum",
-    "TCC_TAG_STALL_sum TCC_BUSY_avr TCC_EA0_RDREQ_sum",
 ]
 
 PROGRAMS = {
     # name: (argv after `--`, kernel-name filter, which launches to keep)
-    "spmm_plan_kernel_cfg2": (["python3", os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-extras",
-                               "--no-cpu-baseline"], "spmm_plan_kernel", "all"),
+    # (the sweep alone — tools/sweep_time.py, cfg2 drawn on the device, 3 + 6 products: a counter pass of the whole bench.py
+    # command took 7 minutes, most of it the profiler around the thousands of small launches of its input generation and checks)
+    "spmm_plan_kernel_cfg2": (["python3", os.path.join(ROOT, "tools", "sweep_time.py"), "cfg2"], "spmm_plan_kernel", "all"),
     "bare_gather_B_4MB_16waves_x8": ([os.path.join(ROOT, "tools/microbench/build/spmm_gather_ceiling")], "gather<8, 1024>", "second_half"),
     "bare_gather_B_102MB_16waves_x8": ([os.path.join(ROOT, "tools/microbench/build/spmm_gather_ceiling")], "gather<8, 1024>", "first_half"),
 }
@@ -59,7 +62,8 @@ def run_pass(tag, i, counters, argv):
     if not glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         with open(d + ".log", "w") as log:
             subprocess.run(["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", *argv],
-                           stdout=log, stderr=subprocess.STDOUT, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+                           stdout=log, stderr=subprocess.STDOUT, cwd="/tmp",
+                           env=dict(os.environ, TMPDIR="/tmp", SWEEP_SETUP="3", SWEEP_STEPS="6"), timeout=600)
     rows = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         rows += list(csv.DictReader(open(f)))
@@ -123,6 +127,8 @@ def derive(k):
     ratio("TA_busy_percent (TA_BUSY_avr)", "TA_BUSY_avr", "TA_BUSY_avr", 0)     # placeholder, replaced below
     if g("TA_BUSY_avr") is not None:
         d["TA_busy_percent (TA_BUSY_avr)"] = round(g("TA_BUSY_avr"), 2)
+    ratio("TA_busy_share_of_kernel_cycles (TA_BUSY_avr / GRBM_GUI_ACTIVE)", "TA_BUSY_avr", "GRBM_GUI_ACTIVE")
+    ratio("busiest_TA_share_of_kernel_cycles (TA_BUSY_max / GRBM_GUI_ACTIVE)", "TA_BUSY_max", "GRBM_GUI_ACTIVE")
     ratio("TA_addr_stalled_by_TC / TA_busy", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_TA_BUSY_sum")
     ratio("TA_data_stalled_by_TC / TA_busy", "TA_DATA_STALLED_BY_TC_CYCLES_sum", "TA_TA_BUSY_sum")
     ratio("TA_addr_stalled_by_TD / TA_busy", "TA_ADDR_STALLED_BY_TD_CYCLES_sum", "TA_TA_BUSY_sum")
@@ -130,6 +136,7 @@ def derive(k):
     ratio("TCP_tagconflict_stall / TCP_gate_en2", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", "TCP_GATE_EN2_sum")
     ratio("TCP_TD_stall / TCP_gate_en2", "TCP_TD_TCP_STALL_CYCLES_sum", "TCP_GATE_EN2_sum")
     ratio("TCP_TCR_stall / TCP_gate_en2", "TCP_TCR_TCP_STALL_CYCLES_sum", "TCP_GATE_EN2_sum")
+    ratio("TCP_TA_data_stall / TCP_gate_en2", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_GATE_EN2_sum")
     ratio("TCP_L2_read_requests_per_L1_access", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum")
     ratio("TCP_L2_read_latency_cycles_per_request", "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TCC_READ_REQ_sum")
     ratio("TD_busy / TA_busy", "TD_TD_BUSY_sum", "TA_TA_BUSY_sum")

@@ -74,15 +74,29 @@ __device__ __forceinline__ int group_lower_bound(int tbl, int key, bool &hit)
     return ((lo4 - base4) >> 2) + (at < key ? 1 : 0);
 }
 
-// Row pairs that do NOT fit the lane group (round 5, tools/cliff_hunt_ops.py).  The first version searched every entry of one
-// row in the other row IN MEMORY (lower_bound_dev: ~log2(n) dependent loads per 64 entries) — fine while such pairs are
-// rare, but G follows the MEAN row length and real row lengths are skewed: log-normal rows (sigma 1, mean 32, G = 32) put a
-// third of the pairs there and CSR + CSR ran 1.52 ms where rows of equal length take 0.45; four rows of 50,000 entries:
-// 4.9 ms.  Now a BLOCKED MERGE: the group holds one block of G entries of each row in registers, searches block against
-// block with the cross-lane probes of the fast path, and moves on in the row whose block ends first — every entry is loaded
-// once, coalesced, the next block of either row already in flight; (n1 + n2) / G steps per pair.
-// Block maxima decide: with a_max <= b_max every entry of the A block has met every B entry that could equal it (earlier B
-// blocks end below the A block's first entry), so the A block is complete; otherwise the B block is.
+// Row pairs that do NOT fit the lane group (round 5, tools/cliff_hunt_ops.py; round 6: the windows slide).  G follows the MEAN
+// row length and real row lengths are skewed: log-normal rows (sigma 1, mean 50, G = 64) put 60 % of the ENTRIES in rows that
+// do not fit.  Such a pair is merged WINDOW AGAINST WINDOW: the group holds a window of G consecutive entries of each row in
+// registers (one per lane; the next G of each already prefetched), searches window against window with the cross-lane probes
+// of the fast path, and then BOTH windows slide past everything the step settled:
+//   * an entry of A is settled once the B window reaches it (a <= the B window's last entry, or B is exhausted): every B entry
+//     below it, and the one that could equal it, lies in this or an earlier window — its lower bound in B is known;
+//   * likewise for B; one of the two windows is settled whole in every step (the one that ends first), the other up to there.
+// So a step consumes G entries of one row AND the other row's entries up to the same column — ~1.8 G for rows of similar
+// density — where round 5's block-against-block merge moved one block of G per step ((n1 + n2) / G steps per pair: half of every
+// step's comparisons were against entries that stayed for the next one).  The windows never hold a settled entry: no
+// "placed prefix", no hit masks carried from step to step.  A window slides by fa <= G entries: its remaining entries move down by
+// two cross-lane reads (this window / the prefetched one), and the prefetch is re-issued at the new position (asynchronous:
+// it is needed a step later; the re-read part hits in L1 / L2).
+template <int G>
+__device__ __forceinline__ void window_slide(int lg, int step, int &w, int &wn)
+{
+    if (step == 0) return;                                             // (uniform inside the group)
+    const int src = (lg + step) & (G - 1);
+    const int from_w = __shfl(w, src, G), from_n = __shfl(wn, src, G);
+    w = lg + step < G ? from_w : from_n;
+}
+// number of coincidences (INTERSECT) or the length of the union
 template <int G, bool INTERSECT>
 __device__ __forceinline__ int count_row_slow(int lg, const int32_t *__restrict__ a_idx, int n1,
                                               const int32_t *__restrict__ b_idx, int n2)
@@ -91,17 +105,17 @@ __device__ __forceinline__ int count_row_slow(int lg, const int32_t *__restrict_
     int a = lg < n1 ? a_idx[lg] : INT_MAX, b = lg < n2 ? b_idx[lg] : INT_MAX;
     int an = G + lg < n1 ? a_idx[G + lg] : INT_MAX, bn = G + lg < n2 ? b_idx[G + lg] : INT_MAX;
     while (ia < n1 && ib < n2) {                                       // (uniform inside the group)
+        const int ca = min(G, n1 - ia), cb = min(G, n2 - ib);
         bool hit;
         group_lower_bound<G>(b, a, hit);
-        hits += __popcll(group_ballot<G>(hit && ia + lg < n1));
-        const int amax = __shfl(a, min(G, n1 - ia) - 1, G), bmax = __shfl(b, min(G, n2 - ib) - 1, G);
-        if (amax <= bmax) {
-            ia += G; a = an;
-            an = ia + G + lg < n1 ? a_idx[ia + G + lg] : INT_MAX;
-        } else {
-            ib += G; b = bn;
-            bn = ib + G + lg < n2 ? b_idx[ib + G + lg] : INT_MAX;
-        }
+        hits += __popcll(group_ballot<G>(hit && lg < ca));
+        const int amax = __shfl(a, ca - 1, G), bmax = __shfl(b, cb - 1, G);
+        const int fa = __popcll(group_ballot<G>(lg < ca && a <= bmax)), fb = __popcll(group_ballot<G>(lg < cb && b <= amax));
+        window_slide<G>(lg, fa, a, an);
+        window_slide<G>(lg, fb, b, bn);
+        ia += fa; ib += fb;
+        if (fa) an = ia + G + lg < n1 ? a_idx[ia + G + lg] : INT_MAX;
+        if (fb) bn = ib + G + lg < n2 ? b_idx[ib + G + lg] : INT_MAX;
     }
     return INTERSECT ? hits : n1 + n2 - hits;
 }
@@ -217,10 +231,11 @@ __device__ __forceinline__ VT combine(VT a, VT b)
     else return r_logical_and(a, b);
 }
 
-// fill of such a row pair at output offset o: the blocked merge of count_row_slow with positions.  An entry is PLACED in the
-// first step in which the other row's block reaches it (its maximum >= the entry, or that row is exhausted): the entries of
-// that row below it are then the earlier blocks plus the local lower bound, and every coincidence among the entries before
-// it has been seen (hit masks accumulate while a block stays).  Placed entries are a prefix of their block (fa, fb).
+// fill of such a row pair at output offset o: the sliding windows of count_row_slow with positions.  An entry is PLACED in the
+// step that settles it: the entries of the other row below it are then that row's entries before its window (ib) plus the
+// local lower bound, and the coincidences before it are those of earlier steps (H: a coincidence settles both its entries in
+// one step) plus those among the window's entries in the lanes below.  Values are not carried in registers: the step's two
+// value windows are requested when the windows are known (a step ahead of their use) and read by the lanes that place.
 template <int G, int OP, typename VT>
 __device__ __forceinline__ void fill_row_slow(int lg, const int32_t *__restrict__ a_idx, const VT *__restrict__ xa_, int n1,
                                               const int32_t *__restrict__ b_idx, const VT *__restrict__ xb_, int n2,
@@ -228,59 +243,56 @@ __device__ __forceinline__ void fill_row_slow(int lg, const int32_t *__restrict_
 {
     constexpr bool INTERSECT = (OP == MX_OP_MUL || OP == MX_OP_AND);
     const unsigned long long below = (1ULL << lg) - 1ULL;
-    int ia = 0, ib = 0, fa = 0, fb = 0;
-    int HA = 0, HB = 0;                                                // coincidences among the entries of the blocks left behind
-    unsigned long long hita = 0, hitb = 0;                             // ... among the current blocks' entries, found so far
+    int ia = 0, ib = 0, H = 0;
     int a = INT_MAX, b = INT_MAX, an = INT_MAX, bn = INT_MAX;
-    VT xa = VT(0), xb = VT(0), xan = VT(0), xbn = VT(0);
+    VT xa = VT(0), xb = VT(0);
     if (lg < n1) { a = a_idx[lg]; xa = xa_[lg]; }
     if (lg < n2) { b = b_idx[lg]; xb = xb_[lg]; }
-    if (G + lg < n1) { an = a_idx[G + lg]; xan = xa_[G + lg]; }
-    if (G + lg < n2) { bn = b_idx[G + lg]; xbn = xb_[G + lg]; }
+    if (G + lg < n1) an = a_idx[G + lg];
+    if (G + lg < n2) bn = b_idx[G + lg];
     while (INTERSECT ? (ia < n1 && ib < n2) : (ia < n1 || ib < n2)) { // (uniform inside the group)
         const int ca = max(0, min(G, n1 - ia)), cb = max(0, min(G, n2 - ib));
         const bool va = lg < ca, vb = lg < cb;
-        bool h;
-        const int lb_a = group_lower_bound<G>(b, a, h);                // entries of the B block below a
-        const bool hit_a = h && va;
-        const VT partner = __shfl(xb, lb_a < G ? lb_a : G - 1, G);
-        hita |= group_ballot<G>(hit_a);
+        // (an exhausted row's window holds INT_MAX in every lane and a "last entry" of INT_MAX: everything of the other row is settled)
         const int amax = ca > 0 ? __shfl(a, ca - 1, G) : INT_MAX, bmax = cb > 0 ? __shfl(b, cb - 1, G) : INT_MAX;
-        const int ia_c = min(ia, n1), ib_c = min(ib, n2);
-        const bool place_a = va && a <= bmax && lg >= fa;
+        bool h;
+        const int lb_a = group_lower_bound<G>(b, a, h);                // entries of the B window below a
+        const bool set_a = va && a <= bmax, hit_a = h && set_a;
+        const VT partner = __shfl(xb, lb_a < G ? lb_a : G - 1, G);
+        const unsigned long long hita = group_ballot<G>(hit_a);
         if constexpr (INTERSECT) {
-            if (place_a && hit_a) {
-                const long long pos = o + HA + __popcll(hita & below);
+            if (hit_a) {
+                const long long pos = o + H + __popcll(hita & below);
                 jo[pos] = a;
                 xo[pos] = combine<OP, VT>(xa, partner);
             }
         } else {
-            if (place_a) {
-                const long long pos = o + ia_c + lg + ib_c + lb_a - (HA + __popcll(hita & below));
+            if (set_a) {
+                const long long pos = o + ia + lg + ib + lb_a - (H + __popcll(hita & below));
                 jo[pos] = a;
                 xo[pos] = hit_a ? combine<OP, VT>(xa, partner) : xa;
             }
-            const int lb_b = group_lower_bound<G>(a, b, h);            // entries of the A block below b
-            const bool hit_b = h && vb;
-            hitb |= group_ballot<G>(hit_b);
-            if (vb && b <= amax && lg >= fb && !hit_b) {
-                const long long pos = o + ib_c + lg + ia_c + lb_b - (HB + __popcll(hitb & below));
+            const int lb_b = group_lower_bound<G>(a, b, h);            // entries of the A window below b
+            const bool set_b = vb && b <= amax, hit_b = h && set_b;
+            const unsigned long long hitb = group_ballot<G>(hit_b);
+            if (set_b && !hit_b) {
+                const long long pos = o + ib + lg + ia + lb_b - (H + __popcll(hitb & below));
                 jo[pos] = b;
                 if constexpr (OP == MX_OP_SUB) xo[pos] = -xb; else xo[pos] = xb;
             }
-            fb = __popcll(group_ballot<G>(vb && b <= amax));
         }
-        fa = __popcll(group_ballot<G>(va && a <= bmax));
-        if (cb == 0 || (ca > 0 && amax <= bmax)) {                     // the A block is complete
-            HA += __popcll(hita); hita = 0; fa = 0;
-            ia += G; a = an; xa = xan;
-            an = INT_MAX; xan = VT(0);
-            if (ia + G + lg < n1) { an = a_idx[ia + G + lg]; xan = xa_[ia + G + lg]; }
-        } else {                                                       // the B block is
-            HB += __popcll(hitb); hitb = 0; fb = 0;
-            ib += G; b = bn; xb = xbn;
-            bn = INT_MAX; xbn = VT(0);
-            if (ib + G + lg < n2) { bn = b_idx[ib + G + lg]; xbn = xb_[ib + G + lg]; }
+        H += __popcll(hita);
+        const int fa = __popcll(group_ballot<G>(set_a)), fb = __popcll(group_ballot<G>(vb && b <= amax));
+        window_slide<G>(lg, fa, a, an);
+        window_slide<G>(lg, fb, b, bn);
+        ia += fa; ib += fb;
+        if (fa) {
+            an = ia + G + lg < n1 ? a_idx[ia + G + lg] : INT_MAX;
+            xa = ia + lg < n1 ? xa_[ia + lg] : VT(0);
+        }
+        if (fb) {
+            bn = ib + G + lg < n2 ? b_idx[ib + G + lg] : INT_MAX;
+            xb = ib + lg < n2 ? xb_[ib + lg] : VT(0);
         }
     }
 }

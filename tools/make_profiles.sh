@@ -38,8 +38,10 @@ python3 tools/prof_summary.py $W/cfg5 $O/${RND}_cfg5_shard "spmm_plan_kernel" cf
 # hash differently from the tree it runs in)
 cp $O/${RND}_*.json $O/${RND}_*.csv $R/profiles/
 python3 bench.py --steps 20 --warmup 5 > $O/${RND}_bench_n1.json 2> $O/log_bench.txt
+cp gpurun_out/bench_extras.json $O/${RND}_bench_n1_full.json          # (the line is the <= 4 KB headline; every extra with its notes is here)
 python3 bench.py --config cfg5 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/${RND}_cfg5_shard_bench_n1.json 2>> $O/log_bench.txt
 python3 bench.py --config cfg5-full > $O/${RND}_cfg5_full_bench.json 2> $O/log_cfg5_full.txt
+cp gpurun_out/bench_cfg5_full.json $O/${RND}_cfg5_full_bench_full.json
 # (e) configs[4] whole: kernel trace of the same command
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$W/cfg5_full/trace -- python3 $R/bench.py --config cfg5-full > $O/log_cfg5_full_trace.txt 2>&1

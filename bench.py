@@ -504,6 +504,10 @@ def single_process(args):
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_spmm(args, p, j, x, B_host, dtype)
     sh.close()
+    # (RCCL prints its version banner through C stdio, which — stdout being a pipe — would otherwise land AFTER the line)
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
     print(headline_line(out), flush=True)
 
 

@@ -36,6 +36,7 @@
 #include "spmm_common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 namespace mx {
 
@@ -153,7 +154,7 @@ template <typename real_t, int CPL, int RG, int WIN, int TILE, bool COLMAJOR>
 __global__ __launch_bounds__((TL_MAX_WAVES + 1) * MX_WAVE)
 void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
                       const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ values,
-                      const unsigned char *__restrict__ unsorted, const int32_t *__restrict__ perm,
+                      const unsigned char *__restrict__ unsorted, const int32_t *__restrict__ perm, const int32_t *__restrict__ cuts,
                       const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ C, size_t ldc, int c_vec, int nl, unsigned long long rgw, unsigned long long *__restrict__ stamps)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
@@ -185,7 +186,11 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
         R += r;
     }
     R *= TL_NG;
-    const int row0 = rb * R;
+    // rows of this block: R consecutive ones, or — rows of uneven length — the range the cuts give it (<= R rows, about equal
+    // entry counts; blocks past the last cut are empty: the grid is sized by a bound, tile_cuts_kernel)
+    const int row0 = cuts ? uniform(cuts[rb]) : rb * R;
+    const int nrows_blk = cuts ? uniform(cuts[rb + 1]) - row0 : min(R, m - row0);
+    if (nrows_blk <= 0) return;
     const int c0 = slab * W;
     const int T = (K + TK - 1) / TK;
 
@@ -426,7 +431,7 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
             }
         }
         __syncthreads();
-        const int ncols = min(W, n - c0), nrows = min(R, m - row0);
+        const int ncols = min(W, n - c0), nrows = nrows_blk;
         for (int idx = threadIdx.x; idx < ncols * R; idx += blockDim.x) {
             const int c = idx / R, r = idx % R;
             if (r < nrows) C[(size_t)(c0 + c) * ldc + row0 + r] = tr[c * RP + r];
@@ -449,6 +454,54 @@ void tile_unsorted_rows_kernel(int m, const int32_t *__restrict__ indptr, const 
     if (lane == 0) flags[row] = any ? 1 : 0;
 }
 
+// Row blocks for rows of uneven length: every R rows is a cut, and a block of R rows that holds more than E entries is cut
+// further into sub-blocks of equal entry counts — a block of the 10 % longest rows of a sorted matrix is otherwise the tail of
+// the launch (1e4 x 1e4, 500 per row, rows sorted by length: 0.38 ms where equal rows take 0.12).  One workgroup (block counts,
+// their prefix sums in rounds of 1,024, the boundaries by binary search); cuts[0 .. max_blocks]: everything past the last real
+// block is m (empty blocks: the launch is sized by the bound max_blocks, nothing is read back — the product stays capturable).
+__global__ __launch_bounds__(1024)
+void tile_cuts_kernel(int m, int R, const int32_t *__restrict__ indptr, long long E, int32_t *__restrict__ cuts, int max_blocks)
+{
+    __shared__ int scan[1024];
+    __shared__ int carry;
+    const int nA = (m + R - 1) / R, tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < nA; k0 += 1024) {
+        const int k = k0 + tid;
+        int s = 0, r0 = 0, r1 = 0;
+        long long e0 = 0, nn = 0;
+        if (k < nA) {
+            r0 = k * R; r1 = min(r0 + R, m);
+            e0 = indptr[r0]; nn = (long long)indptr[r1] - e0;
+            s = (int)min((long long)(r1 - r0), max(1LL, (nn + E - 1) / E));
+        }
+        scan[tid] = s;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int v = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        const int base = carry + scan[tid] - s;
+        for (int q = 0; q < s; q++) {
+            int at = r0;
+            if (q > 0) {
+                const long long target = e0 + nn * q / s;
+                int lo = r0, hi = r1;
+                while (lo < hi) { const int mid = lo + (hi - lo) / 2; if ((long long)indptr[mid] < target) lo = mid + 1; else hi = mid; }
+                at = lo;
+            }
+            if (base + q < max_blocks) cuts[base + q] = at;
+        }
+        __syncthreads();
+        if (tid == 1023) carry += scan[1023];
+        __syncthreads();
+    }
+    for (int i = min(carry, max_blocks) + tid; i <= max_blocks; i += 1024) cuts[i] = m;
+}
+
 // Rows of UNEVEN length (round 6).  The four lane groups of a wavefront walk one row each in lockstep: a visit
 // costs the LONGEST of the four, and the wavefronts of a SIMD add up.  With consecutive rows in consecutive slots a log-normal
 // matrix (sigma 1.5) paid E[max of 4] / mean ~ 2x in every visit and its busiest SIMD half as much again (1e4 x 1e4, 500 per row,
@@ -457,12 +510,14 @@ void tile_unsorted_rows_kernel(int m, const int32_t *__restrict__ indptr, const 
 // visits, longest first, go to the wavefronts in snake order (wavefront w sits on SIMD w % 4: every SIMD gets the same mix).
 // A row is still summed by one group in storage order: the same bits.  perm[rb * R + slot] = row, m = no row.
 __global__ __launch_bounds__(256)
-void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const int32_t *__restrict__ indptr, int32_t *__restrict__ perm)
+void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const int32_t *__restrict__ indptr, const int32_t *__restrict__ cuts,
+                           int32_t *__restrict__ perm)
 {
     __shared__ int len[TL_MAX_WAVES * TL_NG * 5 + 4];
     __shared__ short visit_of[TL_MAX_WAVES * 5 + 1];
-    const int rb = blockIdx.x, row0 = rb * R;
-    for (int r = threadIdx.x; r < R; r += blockDim.x) len[r] = row0 + r < m ? indptr[row0 + r + 1] - indptr[row0 + r] : -1;
+    const int rb = blockIdx.x, row0 = cuts[rb], nrows = cuts[rb + 1] - row0;
+    if (nrows <= 0) return;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) len[r] = r < nrows ? indptr[row0 + r + 1] - indptr[row0 + r] : -1;
     if (threadIdx.x == 0) {
         int base[TL_MAX_WAVES + 1], rg[TL_MAX_WAVES], maxrg = 0;
         base[0] = 0;
@@ -611,7 +666,7 @@ double tile_est_us(int m, int n, int K, int dense_bytes, double avg_len, int col
 
 template <typename real_t, int CPL, int RG, int WIN, int TILE>
 static void launch_tile(const TileGeom &gm, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
-                        const unsigned char *unsorted, const int32_t *perm, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
+                        const unsigned char *unsorted, const int32_t *perm, const int32_t *cuts, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
                         hipStream_t st)
 {
     const int per = 8 % gm.nslabs == 0 ? 8 / gm.nslabs : 0;
@@ -619,18 +674,18 @@ static void launch_tile(const TileGeom &gm, int m, int n, int K, const int32_t *
     const dim3 block((unsigned)(gm.nw + gm.nl) * MX_WAVE);
     if (colmajor)
         hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, true>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
-                           gm.nrb, indptr, indices, values, unsorted, perm, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
+                           gm.nrb, indptr, indices, values, unsorted, perm, cuts, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
     else
         hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, false>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
-                           gm.nrb, indptr, indices, values, unsorted, perm, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
+                           gm.nrb, indptr, indices, values, unsorted, perm, cuts, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
 }
 
 template <typename real_t, int CPL, int WIN, int TILE>
 static void launch_tile_rg(const TileGeom &gm, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
-                           const unsigned char *unsorted, const int32_t *perm, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
+                           const unsigned char *unsorted, const int32_t *perm, const int32_t *cuts, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
                            hipStream_t st)
 {
-#define MX_TL_RG(RG) launch_tile<real_t, CPL, RG, WIN, TILE>(gm, m, n, K, indptr, indices, values, unsorted, perm, B, ldb, C, ldc, colmajor, c_vec, st)
+#define MX_TL_RG(RG) launch_tile<real_t, CPL, RG, WIN, TILE>(gm, m, n, K, indptr, indices, values, unsorted, perm, cuts, B, ldb, C, ldc, colmajor, c_vec, st)
     switch (gm.rg) {
     case 1: MX_TL_RG(1); break;
     case 2: MX_TL_RG(2); break;
@@ -683,27 +738,50 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
         scratch_acquire(MX_SCRATCH_TILE_FLAGS, stream);
         if (!flags) return set_error("tile_spmm: cannot allocate %d bytes of row flags", m);
     }
-    // rows of uneven length (the matrix profile in scope says so; MXGPU_TILE_DEAL=0 / 1 forces): the rows of every block are
-    // dealt to the lane groups by length (tile_deal_rows_kernel) — one small launch, worth it from cv ~ 0.15 on (Poisson row
-    // lengths of a uniform-density matrix: 0.045 at the vignette's shape, which stays on consecutive rows)
-    int32_t *perm = nullptr;
+    // rows of uneven length (the matrix profile in scope says so; MXGPU_TILE_DEAL=0 / 1 forces): row blocks of about equal entry
+    // counts (tile_cuts_kernel) whose rows are dealt to the lane groups by length (tile_deal_rows_kernel) — two small launches,
+    // worth it from cv ~ 0.15 on (Poisson row lengths of a uniform-density matrix: 0.045 at the vignette's shape, which stays on
+    // consecutive rows).  Kept per thread and device for the next product with the same row pointers and geometry: whatever the
+    // matrix holds by then, the cuts and the map stay a partition of its rows into blocks of <= R — stale ones can cost
+    // balance, never a row.
+    int32_t *perm = nullptr, *cuts = nullptr;
+    bool build_map = false;
     {
         const char *de = getenv("MXGPU_TILE_DEAL");                      // (read per call: the tests and the A/B runs switch it)
         const int deal_env = de ? atoi(de) : -1;
         const bool deal = deal_env >= 0 ? deal_env != 0 : profile_cv() > 0.15;
-        if (deal && gm.R <= TL_MAX_WAVES * TL_NG * 5) {
-            perm = (int32_t *)scratch_buffer(MX_SCRATCH_TILE_PERM, (size_t)gm.nrb * gm.R * sizeof(int32_t));
-            if (perm) scratch_acquire(MX_SCRATCH_TILE_PERM, stream);
-            else (void)hipGetLastError();                              // (no memory for the map: consecutive rows)
+        if (deal && nnz > 0 && gm.R <= TL_MAX_WAVES * TL_NG * 5) {
+            const long long mean_block = (long long)((double)nnz / (double)m * gm.R);
+            const long long E = std::max<long long>(1024, mean_block + mean_block / 4);
+            const long long bound = (long long)ceil_div(m, gm.R) + nnz / E + 1;
+            if (bound * gm.nslabs < (1LL << 30)) {
+                const int max_blocks = (int)std::min<long long>(bound, m);
+                const size_t cuts_b = (((size_t)max_blocks + 2) * sizeof(int32_t) + 255) & ~(size_t)255;
+                char *buf = (char *)scratch_buffer(MX_SCRATCH_TILE_PERM, cuts_b + (size_t)max_blocks * gm.R * sizeof(int32_t));
+                if (buf) {
+                    struct Key { const void *indptr, *buf; long long nnz; unsigned long long rgw; int m, R, nw, nl, max_blocks, pad; };   // (no padding bytes: compared with memcmp)
+                    static thread_local Key kept[16] = {};
+                    int dev = 0;
+                    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+                    const Key now = {indptr, buf, (long long)nnz, gm.rgw, m, gm.R, gm.nw, gm.nl, max_blocks, 0};
+                    build_map = memcmp(&kept[dev], &now, sizeof(Key)) != 0;
+                    kept[dev] = now;
+                    scratch_acquire(MX_SCRATCH_TILE_PERM, stream);
+                    cuts = (int32_t *)buf; perm = (int32_t *)(buf + cuts_b);
+                    gm.nrb = max_blocks;
+                    if (build_map) {
+                        hipLaunchKernelGGL(tile_cuts_kernel, dim3(1), dim3(1024), 0, stream, m, gm.R, indptr, E, cuts, max_blocks);
+                        hipLaunchKernelGGL(tile_deal_rows_kernel, dim3((unsigned)max_blocks), dim3(256), 0, stream, m, gm.R, gm.nw, gm.rgw, indptr, cuts, perm);
+                    }
+                } else (void)hipGetLastError();                          // (no memory for the map: consecutive rows)
+            }
         }
     }
     kt_begin(stream);
     if (flags)
         hipLaunchKernelGGL(tile_unsorted_rows_kernel, dim3((unsigned)ceil_div(m, 8)), dim3(512), 0, stream, m, indptr, indices, flags);
-    if (perm)
-        hipLaunchKernelGGL(tile_deal_rows_kernel, dim3((unsigned)gm.nrb), dim3(256), 0, stream, m, gm.R, gm.nw, gm.rgw, indptr, perm);
 #define MX_TL_GO(CPL, WIN, TILE)                                                                                                  \
-    launch_tile_rg<real_t, CPL, WIN, TILE>(gm, m, n, K, indptr, indices, values, flags, perm, B, ldb, C, ldc, colmajor, c_vec, stream)
+    launch_tile_rg<real_t, CPL, WIN, TILE>(gm, m, n, K, indptr, indices, values, flags, perm, cuts, B, ldb, C, ldc, colmajor, c_vec, stream)
     if (gm.cpl == 2) { if (small_tile) MX_TL_GO(2, 1, 32768); else MX_TL_GO(2, 2, 65536); }
     else { if (small_tile) MX_TL_GO(1, 1, 32768); else MX_TL_GO(1, 2, 65536); }
 #undef MX_TL_GO

@@ -15,14 +15,14 @@
 // Round 6 — two more things a kept plan has to live with:
 //   * WIDE matrices.  64 LDS panels cover 393,216 columns; beyond that — BASELINE configs[3]'s own shape is 2M x 2M, v =
 //     16 MB, more than an XCD's 4 MiB L2, and the one-shot gather then runs at the Infinity Cache's line rate: 1.49 ms for
-//     1.24 GB, 0.10 of the roofline — the plan regroups the entries by SUPER-PANEL of 2^18 columns (2 MB of v) instead and the
-//     kernel reads v[j] straight from global memory: every workgroup starts at super-panel 0 and walks them in the same
-//     order, two workgroups per CU (no panel buffers in LDS) so that all row blocks of a product up to ~2M rows are resident
-//     together, and the 2 MB slice they are all reading sits in every XCD's L2.  Up to 1,024 super-panels (2^28 columns).
+//     1.24 GB, 0.10 of the roofline — the plan regroups the entries by SUPER-PANEL of 2^18 columns (2 MB of v) instead and
+//     the product runs ONE LAUNCH PER SUPER-PANEL (spmv_wide_panel_kernel): every workgroup of a launch reads v[j] straight
+//     from global memory, all of them from the same 2 MB, which every XCD's L2 then holds; y is added to from launch to launch.
+//     Up to 1,024 super-panels (2^28 columns).
 //   * rows of UNEVEN length.  A row block used to be 4,096 rows whatever they held: with the rows sorted by length the first
-//     blocks carried ten times the entries of the last and their workgroups were the tail (0.95 ms against 0.077).  Blocks
-//     are now cut at every 4,096th row AND at every E-th entry (E = 1.5 x the mean block): at most 4,096 rows and about E
-//     entries each (spmv_plan_cuts_kernel: two families of binary searches merged by rank — no host pass over indptr).
+//     blocks carried ten times the entries of the last and their workgroups were the tail (0.95 ms against 0.077).  A block
+//     of 4,096 rows that holds more than E entries (1.25 mean blocks) is now cut into sub-blocks of equal entry counts
+//     (spmv_plan_cuts_kernel, on the device): rows of equal length keep exactly the blocks they had.
 // Measured (cfg3, MI355X): DESIGN.md §4.3.  Summation order: per row, panels in ascending order; inside a panel the
 // entries of a row are added with LDS atomics in whatever order their wavefronts arrive: equal to the reference to
 // 1e-12 (f64), not bitwise and not run-to-run reproducible in the last bit — the one-shot flat kernel (spmv_flat.hip) is
@@ -46,34 +46,56 @@ constexpr int SP_WIDE_BITS = 18;             // wide mode: super-panels of 2^18 
 constexpr int SP_WIDE_MAX_PANELS = 1024;     // 2^28 columns
 static_assert(13 + SP_WIDE_BITS <= 31, "row-in-block (0 .. 4096) and column-in-panel share 31 bits");
 
-// Row-block boundaries: the union of {every 4,096th row} and {the first row that starts at or after every E-th entry},
-// sorted — nA + nB points, the last one m.  Point k of family A: min(k * 4096, m), k = 0 .. nA - 1; point j of family B:
-// lower_bound(indptr - indptr[0], j * E), j = 1 .. nB.  Each thread places one point at its rank in the merged order (its
-// index in its own family + the points of the other family before it; ties: A first).  Equal points = empty blocks.
-__global__ __launch_bounds__(256)
-void spmv_plan_cuts_kernel(int m, const int32_t *__restrict__ indptr, int nA, int nB, long long E, int32_t *__restrict__ cuts)
+// Row-block boundaries.  Every 4,096 rows is a cut; a block of 4,096 rows that holds more than E entries is cut further into
+// s = ceil(entries / E) sub-blocks of equal entry counts (binary searches inside the block), so that no workgroup carries much
+// more than E entries + one row.  One workgroup: the blocks' sub-block counts, their prefix sums (a scan over <= 2^19 values
+// in rounds of 1,024), then every sub-block boundary.  cuts[0 .. nrb], nrb = the total — read back by the host (the build
+// synchronises anyway).  Rows of equal length: s = 1 everywhere, exactly the blocks of rounds 2-5.
+__global__ __launch_bounds__(1024)
+void spmv_plan_cuts_kernel(int m, const int32_t *__restrict__ indptr, long long E, int32_t *__restrict__ cuts, int max_cuts,
+                           long long *__restrict__ nrb_out)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nA + nB) return;
-    const long long base = indptr[0];
-    auto b_point = [&](int j) -> int {              // first row r with indptr[r] - base >= j * E   (j >= 1; <= m)
-        const long long target = (long long)j * E + base;
-        int lo = 0, hi = m;
-        while (lo < hi) { const int mid = lo + (hi - lo) / 2; if ((long long)indptr[mid] < target) lo = mid + 1; else hi = mid; }
-        return lo;
-    };
-    if (t < nA) {
-        const int a = (int)min((long long)t * SP_RB, (long long)m);
-        // points of B strictly before a: B_j < a  <=>  the row a - 1 ... monotone in j: binary search over j
-        int lo = 0, hi = nB;                        // number of j in 1 .. nB with B_j < a
-        while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (b_point(mid + 1) < a) lo = mid + 1; else hi = mid; }
-        cuts[t + lo] = a;
-    } else {
-        const int j = t - nA + 1, b = b_point(j);
-        // points of A at or before b: k * 4096 <= b (and the last point m when b == m)
-        const int ka = min(b / SP_RB + 1, nA - 1) + (b >= m ? 1 : 0);
-        cuts[j - 1 + ka] = b;
+    __shared__ int scan[1024];
+    __shared__ int carry;
+    const int nA = (int)((m + SP_RB - 1) / SP_RB), tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < nA; k0 += 1024) {
+        const int k = k0 + tid;
+        int s = 0, r0 = 0, r1 = 0;
+        long long e0 = 0, nn = 0;
+        if (k < nA) {
+            r0 = k * SP_RB; r1 = min(r0 + SP_RB, m);
+            e0 = indptr[r0]; nn = (long long)indptr[r1] - e0;
+            s = (int)max(1LL, (nn + E - 1) / E);
+            s = min(s, r1 - r0);                                       // (never more sub-blocks than rows)
+        }
+        scan[tid] = s;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {                           // inclusive scan
+            const int v = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        const int base = carry + scan[tid] - s;                        // index of this block's first cut
+        if (k < nA) {
+            for (int q = 0; q < s; q++) {
+                int at = r0;
+                if (q > 0) {                                           // first row of the block that starts at or after the q-th share
+                    const long long target = e0 + nn * q / s;
+                    int lo = r0, hi = r1;
+                    while (lo < hi) { const int mid = lo + (hi - lo) / 2; if ((long long)indptr[mid] < target) lo = mid + 1; else hi = mid; }
+                    at = lo;
+                }
+                if (base + q < max_cuts) cuts[base + q] = at;
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) carry += scan[1023];
+        __syncthreads();
     }
+    if (tid == 0) { if (carry < max_cuts + 1) cuts[min(carry, max_cuts)] = m; *nrb_out = carry; }
 }
 
 // panel of a column id: LDS mode divides by 6144, wide mode shifts by 18 (ids outside [0, K) are the caller's bug: kept from
@@ -269,6 +291,82 @@ void spmv_plan_kernel(int m, int K, int npanels, const int32_t *__restrict__ rb_
     }
 }
 
+// WIDE matrices (more than 64 x 6,144 columns): ONE LAUNCH PER SUPER-PANEL of 2^18 columns.  Launch p adds, for every row block,
+// the products of the block's entries in that super-panel to y (p = 0 writes).  All workgroups of a launch gather from the
+// same 2 MB of v — which every XCD's L2 then holds — and the launches follow one another on the stream, so y needs no atomics.
+// (First version, one launch whose workgroups walked the super-panels on their own: they drift apart within a few panels, two
+// rounds of workgroups overlap, and the gather runs at the Infinity Cache's rate again — 2M x 2M, 50 per row: 1.46 ms, the
+// one-shot flat kernel's 1.44.)
+template <int KIND>
+__global__ __launch_bounds__(SP_THREADS)
+void spmv_wide_panel_kernel(int K, int npanels, int p, const int32_t *__restrict__ rb_row, const int32_t *__restrict__ seg_off,
+                            const int32_t *__restrict__ ent, const double *__restrict__ val, const void *__restrict__ v_, void *__restrict__ y_)
+{
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int CB = SP_WIDE_BITS;
+    __shared__ double acc[SP_RB + 8];
+    __shared__ unsigned na_rows[(SP_RB + 8 + 31) / 32];
+    const int tid = threadIdx.x, rb = blockIdx.x;
+    const int r0 = rb_row[rb], nr = rb_row[rb + 1] - r0;
+    if (nr <= 0) return;
+    const int32_t *__restrict__ so = seg_off + (size_t)rb * npanels;
+    const int s = so[p], e = so[p + 1];                               // multiples of 4
+    if (s == e && p > 0) return;                                      // nothing to add (launch 0 still writes the zeros)
+    for (int i = tid; i < SP_RB + 8; i += SP_THREADS) acc[i] = 0.0;
+    if constexpr (KIND == MX_I32 || KIND == MX_LGL)
+        for (int i = tid; i < (SP_RB + 8 + 31) / 32; i += SP_THREADS) na_rows[i] = 0u;
+    __syncthreads();
+    const int cbase = p << SP_WIDE_BITS;
+    auto add = [&](int code, double a, double f) {
+        const int r = (int)((unsigned)code >> CB);
+        double t = a * f;
+        if constexpr (KIND == MX_I32 || KIND == MX_LGL) {
+            if (__double_as_longlong(f) == (long long)MX_NA_REAL_BITS) { t = 0.0; if (r < SP_RB) atomicOr(&na_rows[r >> 5], 1u << (r & 31)); }
+        }
+        __hip_atomic_fetch_add(&acc[r], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    for (int k0 = s + tid * 4; k0 < e; k0 += SP_THREADS * 4 * 2) {
+        // two quads per thread and trip: the six stream loads, then eight independent reads of v, then the sums
+        const int k1 = k0 + SP_THREADS * 4;
+        const bool two = k1 < e;
+        const i4 c0 = *reinterpret_cast<const i4 *>(ent + k0);
+        const d2 a0 = *reinterpret_cast<const d2 *>(val + k0), a1 = *reinterpret_cast<const d2 *>(val + k0 + 2);
+        const int kb = two ? k1 : k0;
+        const i4 c1 = *reinterpret_cast<const i4 *>(ent + kb);
+        const d2 b0 = *reinterpret_cast<const d2 *>(val + kb), b1 = *reinterpret_cast<const d2 *>(val + kb + 2);
+        const double av[4] = {a0[0], a0[1], a1[0], a1[1]}, bv[4] = {b0[0], b0[1], b1[0], b1[1]};
+        double f0[4], f1[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {                                 // (the padding's column 0 of the last super-panel stays in range)
+            f0[q] = sp_factor<KIND>(v_, min(cbase + (c0[q] & ((1 << CB) - 1)), K - 1));
+            f1[q] = sp_factor<KIND>(v_, min(cbase + (c1[q] & ((1 << CB) - 1)), K - 1));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) add(c0[q], av[q], f0[q]);
+        if (two) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) add(c1[q], bv[q], f1[q]);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nr; i += SP_THREADS) {
+        const double sum = acc[i];
+        if constexpr (KIND == MX_F32) {
+            float *y = (float *)y_ + r0 + i;
+            *y = p == 0 ? (float)sum : (float)((double)*y + sum);
+        } else if constexpr (KIND == MX_I32 || KIND == MX_LGL) {
+            double *y = (double *)y_ + r0 + i;
+            const double prev = p == 0 ? 0.0 : *y;
+            const bool was_na = p > 0 && __double_as_longlong(prev) == (long long)MX_NA_REAL_BITS;
+            *y = ((na_rows[i >> 5] >> (i & 31)) & 1u) || was_na ? na_real() : prev + sum;
+        } else {
+            double *y = (double *)y_ + r0 + i;
+            *y = p == 0 ? sum : *y + sum;
+        }
+    }
+}
+
 }  // namespace mx
 
 struct mx_spmv_plan {
@@ -315,17 +413,26 @@ extern "C" int mxd_spmv_plan_create(int m, int K, const int32_t *indptr, const i
         int32_t ends[2] = {0, 0};
         if (read_back_small(&ends[0], indptr, sizeof(int32_t), st) || read_back_small(&ends[1], indptr + m, sizeof(int32_t), st)) break;
         pl->nnz = (long long)ends[1] - ends[0];
-        // row blocks: at most 4,096 rows and about E entries (1.5 mean blocks, at least 32k: a block must be worth a workgroup)
+        // row blocks: 4,096 rows, cut further where they hold more than E entries (1.25 mean blocks, at least 32k: a block must
+        // be worth a workgroup) — spmv_plan_cuts_kernel
         const long long mean_block = (long long)((double)pl->nnz / (double)m * SP_RB);
-        const long long E = std::max<long long>(32768, mean_block + mean_block / 2);
-        const int nA = (int)ceil_div(m, SP_RB) + 1, nB = pl->nnz > 0 ? (int)std::min<long long>((pl->nnz - 1) / E, 1 << 20) : 0;
-        pl->nrb = nA + nB - 1;
+        const long long E = std::max<long long>(32768, mean_block + mean_block / 4);
+        const int nA = (int)ceil_div(m, SP_RB);
+        const int max_cuts = (int)std::min<long long>((long long)nA + pl->nnz / E + 1, (long long)m);
+        long long *nrb_dev = nullptr;
+        if (hipMalloc((void **)&pl->rb_row, ((size_t)max_cuts + 2) * 4) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
+        if (hipMalloc((void **)&nrb_dev, 16) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
+        hipLaunchKernelGGL(spmv_plan_cuts_kernel, dim3(1), dim3(1024), 0, st, m, indptr, E, pl->rb_row, max_cuts, nrb_dev);
+        long long nrb_ll = 0;
+        const int rb_rc = read_back_small(&nrb_ll, nrb_dev, sizeof(nrb_ll), st);
+        (void)hipFree(nrb_dev);
+        if (rb_rc) break;
+        if (nrb_ll < 1 || nrb_ll > max_cuts) { set_error("spmv plan: %lld row blocks for a bound of %d", nrb_ll, max_cuts); break; }
+        pl->nrb = (int)nrb_ll;
         const int64_t nseg = (int64_t)pl->nrb * npanels;
-        if (hipMalloc((void **)&pl->rb_row, ((size_t)pl->nrb + 1) * 4) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
         if (hipMalloc((void **)&counts, (size_t)nseg * 4 + 16) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
         if (hipMalloc(&scan_ws, scan_workspace_bytes(nseg) + 16) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
         if (hipMalloc((void **)&pl->seg_off, ((size_t)nseg + 1) * 4) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
-        hipLaunchKernelGGL(spmv_plan_cuts_kernel, dim3((unsigned)ceil_div(nA + nB, 256)), dim3(256), 0, st, m, indptr, nA, nB, E, pl->rb_row);
         if (wide) hipLaunchKernelGGL(spmv_plan_count_kernel<true>, dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, npanels, pl->rb_row, indptr, indices, counts);
         else hipLaunchKernelGGL(spmv_plan_count_kernel<false>, dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, npanels, pl->rb_row, indptr, indices, counts);
         if (exclusive_scan_i32(counts, nseg, pl->seg_off, (int64_t *)scan_ws, scan_ws, st)) break;
@@ -368,10 +475,12 @@ extern "C" int mxd_spmv_plan_run(const mx_spmv_plan *pl, const void *v, int v_dt
     hipStream_t st = as_stream(stream);
 #define MX_SP(KIND)                                                                                                          \
     do {                                                                                                                     \
-        if (pl->wide) hipLaunchKernelGGL((spmv_plan_kernel<KIND, true>), dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, pl->m, pl->K, \
-                                         pl->npanels, pl->rb_row, pl->seg_off, pl->ent, pl->val, v, y);                      \
-        else hipLaunchKernelGGL((spmv_plan_kernel<KIND, false>), dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, pl->m, pl->K,         \
-                                pl->npanels, pl->rb_row, pl->seg_off, pl->ent, pl->val, v, y);                               \
+        if (pl->wide) {                                                                                                      \
+            for (int p = 0; p < pl->npanels; p++)                                                                            \
+                hipLaunchKernelGGL((spmv_wide_panel_kernel<KIND>), dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, pl->K,  \
+                                   pl->npanels, p, pl->rb_row, pl->seg_off, pl->ent, pl->val, v, y);                         \
+        } else hipLaunchKernelGGL((spmv_plan_kernel<KIND, false>), dim3((unsigned)pl->nrb), dim3(SP_THREADS), 0, st, pl->m, pl->K,       \
+                                  pl->npanels, pl->rb_row, pl->seg_off, pl->ent, pl->val, v, y);                             \
     } while (0)
     switch (v_dtype) {
         case MX_F64: MX_SP(MX_F64); break;

@@ -23,2568 +23,10 @@
 #include <execinfo.h>
 #include <unistd.h>
 
-namespace mx {
-
-static thread_local char g_err[512] = "";
-
-// MXGPU_ABORT_BACKTRACE=1 (debugging aid): native frames of the thread that raised SIGABRT / SIGSEGV on stderr, then the
-// default action.  Installed when the library is loaded; does nothing unless the variable is set.
-static void fatal_backtrace(int sig)
-{
-    const char msg[] = "\n[mxgpu] fatal signal, native frames of the raising thread:\n";
-    (void)!write(2, msg, sizeof(msg) - 1);
-    void *frames[64];
-    const int n = backtrace(frames, 64);
-    backtrace_symbols_fd(frames, n, 2);
-    signal(sig, SIG_DFL);
-    raise(sig);
-}
-static const bool g_backtrace_installed = [] {
-    const char *e = getenv("MXGPU_ABORT_BACKTRACE");
-    if (!e || atoi(e) != 1) return false;
-    void *warm[4];
-    (void)backtrace(warm, 4);                                        // loads the unwinder now, not inside the handler
-    signal(SIGABRT, fatal_backtrace);
-    signal(SIGSEGV, fatal_backtrace);
-    return true;
-}();
-
-int set_error(const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return 1;
-}
-
-// (struct SpmmFamily, spmm_common.h: a product's kernel family with the geometry chosen for the WHOLE product, carried BY VALUE
-// into every block on whatever thread runs it — the shard workers of mx_set_devices are other threads than the caller's)
-SpmmFamily spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor);
-struct ProfileScope { const float *saved; explicit ProfileScope(const float *p); ~ProfileScope(); };   // spmm_common.h: the profile AUTO reads
-int spmm_block(const SpmmFamily &fam, bool from_auto, int m, int n, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
-               const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, int npanels, hipStream_t st);
-int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t *indices, const double *values,
-                const void *v, int v_dtype, void *y, int algo, hipStream_t st);
-void merge_group_widen(bool on);                                     // merge.hip: the next merges of this thread take one lane-group width up
-bool spmv_flat_ok(int m, int64_t nnz, const int32_t *indices, const double *values);
-// xfer.hip: synchronous host <-> device copies, pipelined through pinned slots + a host copy pool when large
-int xfer_h2d(void *dst_dev, const void *src_host, size_t bytes);
-int xfer_d2h(void *dst_host, const void *src_dev, size_t bytes);
-void prefault_begin(void *p, size_t bytes);
-int prefault_begin_pieces(void *base, size_t total, const std::vector<std::pair<void *, size_t>> &pieces, std::atomic<int> *arrived);
-void prefault_wait();
-uint64_t host_hash(const void *p, size_t bytes, uint64_t seed);
-bool pin_host(const void *p, size_t bytes, bool all_devices = false);
-void unpin_host(const void *p);
-
-// Wall-clock phases of the calling thread's last export-level SpMM call: always recorded (a handful of clock reads per
-// call), read with mx_last_call_phases(); MXGPU_TRACE=1 also prints them on stderr as they are passed.
-static thread_local char g_phases[512] = "";
-struct Trace {
-    bool on;
-    const char *what;
-    size_t used = 0;
-    std::chrono::steady_clock::time_point t0, last;
-    explicit Trace(const char *w) : on(getenv("MXGPU_TRACE") != nullptr), what(w)
-    {
-        t0 = last = std::chrono::steady_clock::now();
-        used = (size_t)snprintf(g_phases, sizeof(g_phases), "%s", w);
-    }
-    ~Trace() { mark("release"); }                   // declared before the device buffers: runs after their hipFree
-    void note(const char *key, const char *value)
-    {
-        if (used < sizeof(g_phases)) used += (size_t)snprintf(g_phases + used, sizeof(g_phases) - used, ";%s=%s", key, value);
-    }
-    void mark(const char *phase)
-    {
-        const auto now = std::chrono::steady_clock::now();
-        const double dt = std::chrono::duration<double, std::milli>(now - last).count();
-        const double tot = std::chrono::duration<double, std::milli>(now - t0).count();
-        if (used < sizeof(g_phases)) used += (size_t)snprintf(g_phases + used, sizeof(g_phases) - used, ";%s=%.3f", phase, dt);
-        if (on) fprintf(stderr, "[mxgpu] %s: %-10s %8.3f ms (total %8.3f)\n", what, phase, dt, tot);
-        last = now;
-    }
-};
-
-// Device memory is kept between calls in three places: the CSR cache (and the plans hanging off its entries), the
-// per-thread export scratch and AUTO's per-thread plan.  When an allocation fails all of that is given back and the
-// allocation is tried once more (an export that fitted before the cache existed must still fit).
-static void release_kept_device_memory();
-static hipError_t malloc_with_relief(void **p, size_t n)
-{
-    hipError_t e = mx::pool_malloc(p, n);                  // (gives its own idle blocks back before it fails)
-    if (e == hipSuccess) return e;
-    (void)hipGetLastError();
-    release_kept_device_memory();
-    return mx::pool_malloc(p, n);
-}
-void *scratch_buffer_relief(int slot, size_t bytes)
-{
-    void *q = mx::scratch_buffer(slot, bytes);
-    if (q) return q;
-    (void)hipGetLastError();
-    release_kept_device_memory();
-    return mx::scratch_buffer(slot, bytes);
-}
-
-// device buffer: owning (alloc / upload) or an alias of memory owned elsewhere (the CSR cache)
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    bool own = true;
-    DevBuf() = default;
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { if (p && own) mx::pool_free(p); }
-    int alloc(size_t n)
-    {
-        bytes = n;
-        if (n == 0) n = 16;                  // keep pointers non-null and 16-B aligned
-        MX_HIP(malloc_with_relief(&p, n));
-        return 0;
-    }
-    void alias(void *ptr, size_t n) { p = ptr; bytes = n; own = false; }
-    int upload(const void *h, size_t n)
-    {
-        if (alloc(n)) return 1;
-        if (n && mx::xfer_h2d(p, h, n)) return 1;               // register + direct DMA when large (xfer.hip)
-        return 0;
-    }
-    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-static inline size_t dtype_bytes(int dt)
-{
-    switch (dt) { case MX_F64: return 8; case MX_F32: case MX_I32: case MX_LGL: return 4; default: return 0; }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Device-side cache of CSR operands handed over by host address (SURVEY §7 "PCIe dominates": every .Call of the
-// reference's API passes the same three R vectors again; re-uploading 388 MB costs 8 ms of a 25 ms product).
-// Key: device, the three host addresses, nrows, nnz, value width.  A hit additionally needs the operand's FINGERPRINT
-// to match: a hash of EVERY byte of the three arrays, computed by the host team (R vectors are immutable by convention,
-// but R does overwrite a vector in place when nothing else refers to it — X@x[i] <- v —, MatrixExtra's own in-place
-// routines rewrite @j / @x, and the allocator hands a freed vector's address to the next one of its size: a sampled
-// fingerprint would serve a stale matrix without any sign).  LRU, capped
-// (MXGPU_CSR_CACHE_MB, default 8192; 0 disables; mx_cache_configure at run time).  Entries are shared_ptr-held for the
-// duration of a call, so eviction never pulls memory from under a running export.
-struct CsrDev {
-    DevBuf p, j, x;
-    mx_spmv_plan *spmv_plan = nullptr;       // built on request (MXGPU_SPMV_PLANNED=1) when the operand comes back for another product
-    int spmv_plan_K = -1;
-    // SpMM plan of the whole matrix, built the first time the operand is found in the cache by a product that AUTO would
-    // plan: later products (and every block of a pipelined call) skip the 0.27 ms (cfg2) / 4 ms (cfg5) build.  Safe to keep:
-    // an entry is only ever found again when the hash of every byte of its three host arrays still matches.
-    mx_spmm_plan *spmm_plan = nullptr;
-    int spmm_plan_K = -1, spmm_plan_panels = 0;
-    bool spmm_plan_rejected = false;         // the plan would pad too much: AUTO's row-wave fallback, remembered
-    std::mutex plan_mu;
-    // recorded on the builder's stream right after a plan's build kernels were queued: a user on ANOTHER stream (another
-    // thread that finds the entry while the build is still running) makes its stream wait for it
-    hipEvent_t plan_built = nullptr;
-    void mark_plan_built(hipStream_t st)
-    {
-        if (!plan_built && hipEventCreateWithFlags(&plan_built, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); plan_built = nullptr; }
-        if (plan_built) (void)hipEventRecord(plan_built, st);
-        else (void)hipStreamSynchronize(st);                   // (no event to be had: the plan is complete before anyone can see it)
-    }
-    void wait_plan_built(hipStream_t st) { if (plan_built) (void)hipStreamWaitEvent(st, plan_built, 0); }
-    void drop_plans()
-    {
-        if (spmv_plan) mxd_spmv_plan_destroy(spmv_plan);
-        if (spmm_plan) mxd_spmm_plan_destroy(spmm_plan);
-        spmv_plan = nullptr; spmm_plan = nullptr; spmm_plan_rejected = false;
-    }
-    ~CsrDev() { drop_plans(); if (plan_built) (void)hipEventDestroy(plan_built); }
-    const void *hp = nullptr, *hj = nullptr, *hx = nullptr;
-    float host_profile[MX_PROFILE_LEN];      // host_csr_profile of the operand for host_profile_K columns (under plan_mu)
-    int host_profile_K = -1;
-    bool host_profile_ok = false;
-    int m = 0, device = 0;
-    int64_t nnz = 0;
-    size_t vb = 0, bytes = 0;
-    uint64_t fp = 0, tick = 0;
-};
-
-// The matrix profile (mxd_csr_profile, csrc/profile.hip) computed on the HOST from the caller's own arrays: the export-level
-// products choose their kernel family before the CSR is on the device (cold calls upload and multiply block by block), and
-// for data that looks like real dgRMatrix contents — power-law columns, skewed rows — the sizes alone pick the wrong one
-// (tools/zipf_map.py).  Same estimator as the device pass for the columns: <= 2^16 sampled column ids in evenly spaced runs
-// of 256, two independent halves (one ranks the columns, the other measures the entries they hold) — skipped (uniform
-// columns assumed) above 2^24 columns, where the two K-sized histograms would cost more than they can tell.  The ROW
-// statistics are exact: every row pointer is read (round 5 looked at every (m / 65536)-th row only and so missed a few
-// giant rows in any matrix of >= 131,072 rows — [33] came out too small and the long-rows path stayed off; advisor r5).
-// ~0.2 ms for K = 1e5 plus ~0.4 ns per row on one core; kept on the cache entry of the operand (CsrDev::host_profile).
-static bool host_csr_profile(const int32_t *indptr, const int32_t *indices, int m, int K, float *prof)
-{
-    for (int i = 0; i < MX_PROFILE_LEN; i++) prof[i] = 0.0f;
-    const int64_t first = indptr[0], nnz = (int64_t)indptr[m] - first;
-    if (m <= 0 || K <= 0 || nnz <= 0) return false;
-    if (K <= (1 << 24)) {
-        static thread_local std::vector<uint16_t> ca, cb;
-        ca.assign((size_t)K, 0); cb.assign((size_t)K, 0);
-        int runs = (int)std::min<int64_t>(256, (nnz + 255) / 256);
-        if (runs > 1) runs &= ~1;
-        for (int r = 0; r < runs; r++) {
-            const int64_t at = first + (int64_t)((double)r * (double)nnz / (double)runs), end = std::min<int64_t>(at + 256, first + nnz);
-            std::vector<uint16_t> &c = (r & 1) ? cb : ca;
-            for (int64_t e = at; e < end; e++) { const int col = indices[e]; if ((unsigned)col < (unsigned)K && c[(size_t)col] < 65535) c[(size_t)col]++; }
-        }
-        constexpr int BINS = 1024;
-        double cols[BINS] = {0}, sums[BINS] = {0};
-        double total = 0.0, met = 0.0, total_a = 0.0;
-        for (int c = 0; c < K; c++) {
-            const unsigned v = ca[(size_t)c], w = cb[(size_t)c];
-            if (v | w) { const unsigned b = v < BINS - 1 ? v : BINS - 1; cols[b] += 1.0; sums[b] += w; }
-        }
-        for (int b = 0; b < BINS; b++) { total += sums[b]; if (b) { met += cols[b]; total_a += cols[b] * b; } }
-        const bool one_half = total <= 0.0;
-        if (one_half) total = total_a > 0.0 ? total_a : 1.0;
-        int level = 0;
-        double seen = 0.0, mass = 0.0;
-        for (int b = BINS - 1; b >= 0 && level < 32; b--) {
-            const double nc = b == 0 ? std::max(0.0, (double)K - met) : cols[b];
-            const double ns = one_half ? (b == 0 ? 0.0 : nc * b) : sums[b];
-            if (nc <= 0.0) continue;
-            while (level < 32 && (double)(1ULL << level) <= seen + nc) {
-                prof[level] = (float)((mass + ns * (((double)(1ULL << level) - seen) / nc)) / total);
-                level++;
-            }
-            seen += nc; mass += ns;
-        }
-        for (; level < 32; level++) prof[level] = 1.0f;
-        if (K > (1 << 20)) { std::vector<uint16_t>().swap(ca); std::vector<uint16_t>().swap(cb); }   // (nothing of that size stays with the thread)
-    } else {
-        prof[39] = -1.0f;                                    // mx::profile_mass: uniform columns
-    }
-    const int long_len = mx::canonical_long_piece((double)nnz / (double)m);
-    double s1 = 0.0;
-    int64_t longest = 0, long_entries = 0, long_rows = 0;
-    for (int r = 0; r < m; r++) {
-        const int64_t len = (int64_t)indptr[r + 1] - indptr[r];
-        s1 += (double)len * (double)len;
-        longest = std::max(longest, len);
-        if (len > long_len) { long_entries += len; long_rows++; }
-    }
-    const double mean = (double)nnz / (double)m, var = s1 / (double)m - mean * mean;
-    prof[32] = (float)(std::sqrt(std::max(0.0, var)) / mean);
-    prof[33] = (float)((double)longest / mean);
-    prof[34] = (float)mean;
-    prof[35] = std::nextafter((float)long_entries, INFINITY); prof[36] = std::nextafter((float)long_rows, INFINITY); prof[37] = 1.0f;
-    return true;
-}
-static thread_local mx::SpmmFamily g_last_export_family;            // (diagnostic: mx_debug_last_export_family)
-// AUTO's family for an export-level product, with the host-side profile where it can change the choice.  `keep`: the
-// operand's cache entry — the profile is computed once per entry and column count (an entry is only ever found again while
-// every byte of its three host arrays still hashes the same).
-static mx::SpmmFamily export_auto_family(int m, int n, int K, int64_t nnz, int dt, const void *B, size_t ldb, const void *C, size_t ldc, int colmajor,
-                                         const int32_t *indptr, const int32_t *indices, CsrDev *keep = nullptr)
-{
-    float prof[MX_PROFILE_LEN];
-    bool profiled = false;
-    if (nnz >= (1LL << 21) && m >= 4096 && indptr && indices) {
-        if (keep) {
-            std::lock_guard<std::mutex> lk(keep->plan_mu);
-            if (keep->host_profile_K != K) { keep->host_profile_ok = host_csr_profile(indptr, indices, m, K, keep->host_profile); keep->host_profile_K = K; }
-            profiled = keep->host_profile_ok;
-            if (profiled) memcpy(prof, keep->host_profile, sizeof(prof));
-        } else profiled = host_csr_profile(indptr, indices, m, K, prof);
-    }
-    mx::ProfileScope scope(profiled ? prof : nullptr);
-    g_last_export_family = mx::spmm_auto_family(m, n, K, nnz, dt, B, ldb, C, ldc, colmajor);
-    return g_last_export_family;
-}
-
-static uint64_t fnv_block(uint64_t h, const void *p, size_t n)
-{
-    const unsigned char *c = (const unsigned char *)p;
-    size_t i = 0;
-    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, c + i, 8); h = (h ^ w) * 0x100000001b3ULL; }
-    for (; i < n; i++) h = (h ^ c[i]) * 0x100000001b3ULL;
-    return h;
-}
-// MXGPU_CACHE_FINGERPRINT=sampled: lengths + first / last 4 KiB + 64 evenly spaced 512-byte blocks of each array (faster
-// — microseconds — but an element overwritten in place between the samples goes unnoticed: the caller must then call
-// mx_cache_invalidate).  Default: every byte, hashed by the host team (cfg2's 388 MB: ~3 ms on 16 threads).
-static bool fingerprint_sampled()
-{
-    static const bool s = [] { const char *e = getenv("MXGPU_CACHE_FINGERPRINT"); return e && strcmp(e, "sampled") == 0; }();
-    return s;
-}
-static uint64_t fingerprint_array(uint64_t h, const void *p, size_t bytes)
-{
-    h = fnv_block(h, &bytes, sizeof(bytes));
-    if (!p || bytes == 0) return h;
-    if (bytes <= 64 * 1024) return fnv_block(h, p, bytes);
-    if (!fingerprint_sampled()) return mx::host_hash(p, bytes, h);
-    const char *c = (const char *)p;
-    h = fnv_block(h, c, 4096);
-    h = fnv_block(h, c + bytes - 4096, 4096);
-    const size_t step = (bytes - 8192) / 64;
-    for (int i = 0; i < 64; i++) h = fnv_block(h, c + 4096 + (size_t)i * step, 512);
-    return h;
-}
-
-class CsrCache {
-public:
-    static CsrCache &get() { static CsrCache *c = new CsrCache(); return *c; }   // leaked: no HIP calls at exit
-    std::shared_ptr<CsrDev> find(const int32_t *hp, const int32_t *hj, const void *hx, int m, int64_t nnz, size_t vb, uint64_t fp)
-    {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> lk(mu_);
-        for (auto it = items_.begin(); it != items_.end(); ++it) {
-            CsrDev &e = **it;
-            if (e.device == dev && e.hp == hp && e.hj == hj && e.hx == hx && e.m == m && e.nnz == nnz && e.vb == vb) {
-                if (e.fp != fp) { total_ -= e.bytes; items_.erase(it); break; }           // same addresses, new content
-                e.tick = ++clock_;
-                hits_++;
-                return *it;
-            }
-        }
-        misses_++;
-        return nullptr;
-    }
-    // is there an entry for these three host vectors at all?  (a miss by address needs no fingerprint to be known as a miss)
-    bool has_address(const int32_t *hp, const int32_t *hj, const void *hx, int m, int64_t nnz, size_t vb)
-    {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> lk(mu_);
-        for (auto &it : items_) {
-            const CsrDev &e = *it;
-            if (e.device == dev && e.hp == hp && e.hj == hj && e.hx == hx && e.m == m && e.nnz == nnz && e.vb == vb) return true;
-        }
-        return false;
-    }
-    void count_miss() { std::lock_guard<std::mutex> lk(mu_); misses_++; }
-    void insert(const std::shared_ptr<CsrDev> &e)
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        if (e->bytes > cap_) return;
-        e->tick = ++clock_;
-        items_.push_back(e);
-        total_ += e->bytes;
-        while (total_ > cap_ && !items_.empty()) {                                        // evict least recently used
-            auto lru = items_.begin();
-            for (auto it = items_.begin(); it != items_.end(); ++it) if ((*it)->tick < (*lru)->tick) lru = it;
-            total_ -= (*lru)->bytes;
-            items_.erase(lru);
-        }
-    }
-    void invalidate(const void *host_ptr)
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        for (auto it = items_.begin(); it != items_.end();) {
-            if (!host_ptr || (*it)->hp == host_ptr || (*it)->hj == host_ptr || (*it)->hx == host_ptr) {
-                total_ -= (*it)->bytes;
-                it = items_.erase(it);
-            } else ++it;
-        }
-    }
-    void configure(int64_t max_bytes)
-    {
-        { std::lock_guard<std::mutex> lk(mu_); cap_ = max_bytes > 0 ? (size_t)max_bytes : 0; }
-        if (max_bytes <= 0) invalidate(nullptr);
-    }
-    bool enabled() { std::lock_guard<std::mutex> lk(mu_); return cap_ > 0; }
-    void stats(int64_t *bytes, int *entries, int64_t *hits, int64_t *misses)
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        if (bytes) *bytes = (int64_t)total_;
-        if (entries) *entries = (int)items_.size();
-        if (hits) *hits = hits_;
-        if (misses) *misses = misses_;
-    }
-
-private:
-    CsrCache()
-    {
-        // default: 8 GiB, but never more than a quarter of the device (a small or shared GPU keeps room for the operands)
-        cap_ = (size_t)8192 << 20;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 4 < cap_) cap_ = total_b / 4;
-        else (void)hipGetLastError();
-        if (const char *e = getenv("MXGPU_CSR_CACHE_MB")) cap_ = (size_t)(atoll(e) > 0 ? atoll(e) : 0) << 20;
-    }
-    std::mutex mu_;
-    std::vector<std::shared_ptr<CsrDev>> items_;
-    size_t cap_ = 0, total_ = 0;
-    uint64_t clock_ = 0;
-    int64_t hits_ = 0, misses_ = 0;
-};
-
-// (not the export scratch: the failing allocation may belong to a pipelined call whose B already sits in it)
-void plan_auto_release();
-void release_thread_workspaces();
-void *slab_pack_workspace(size_t bytes, bool release);
-static void release_kept_device_memory()
-{
-    CsrCache::get().invalidate(nullptr);
-    mx::plan_auto_release();
-    mx::slab_pack_workspace(0, true);
-    mx::pool_trim();
-}
-
-struct Csr {
-    DevBuf p, j, x;                          // aliases of `hold`'s buffers
-    std::shared_ptr<CsrDev> hold;
-    int64_t nnz = 0;
-    bool resident = false;                   // indices / values are on the device (false only between prepare() and the
-                                             // caller's own block-wise upload, see spmm_host)
-    bool cache_hit = false;                  // the operand was already on the device when this call began
-    // Finds the operand in the cache or allocates device arrays for it (indptr uploaded, indices / values NOT yet):
-    // the caller uploads them — in one go with finish_upload(), or block by block — and then calls publish().
-    int prepare(const int32_t *indptr, const int32_t *indices, const void *values, int m, size_t value_bytes, bool use_cache)
-    {
-        MX_REQUIRE(m >= 0 && indptr, "CSR upload: bad arguments");
-        nnz = indptr[m];
-        MX_REQUIRE(nnz >= 0 && indptr[0] >= 0, "CSR upload: negative index pointer");
-        const size_t pb = sizeof(int32_t) * ((size_t)m + 1), jb = sizeof(int32_t) * (size_t)nnz, xb = value_bytes * (size_t)nnz;
-        use_cache = use_cache && pb + jb + xb >= ((size_t)1 << 20) && CsrCache::get().enabled();
-        // The fingerprint reads every byte of the operand on the host team (cfg2: ~1.3 ms, cfg5 whole: ~40 ms).  It is needed
-        // at once only when the cache holds an entry for these addresses (is it still the same matrix?); for an operand the
-        // cache has never seen it is only the key of the entry to come and is computed later — by the pipelined exports
-        // while the GPU and the DMA engines are busy (fingerprint_now), otherwise in publish().
-        uint64_t fp = 0;
-        if (use_cache) {
-            if (CsrCache::get().has_address(indptr, indices, value_bytes ? values : nullptr, m, nnz, value_bytes)) {
-                fp = fingerprint_of(indptr, indices, value_bytes ? values : nullptr, pb, jb, xb);
-                have_fp = true;
-                hold = CsrCache::get().find(indptr, indices, value_bytes ? values : nullptr, m, nnz, value_bytes, fp);
-            } else CsrCache::get().count_miss();
-        }
-        if (hold) {
-            resident = true;
-            cache_hit = true;
-        } else {
-            hold = std::make_shared<CsrDev>();
-            CsrDev &e = *hold;
-            e.hp = indptr; e.hj = indices; e.hx = value_bytes ? values : nullptr;
-            e.m = m; e.nnz = nnz; e.vb = value_bytes; e.bytes = pb + jb + xb; e.fp = fp;
-            (void)hipGetDevice(&e.device);
-            if (e.p.upload(indptr, pb)) return 1;
-            if (e.j.alloc(jb)) return 1;
-            if (value_bytes && e.x.alloc(xb)) return 1;
-            cacheable = use_cache;
-        }
-        p.alias(hold->p.p, pb); j.alias(hold->j.p, jb); x.alias(hold->x.p, xb);
-        return 0;
-    }
-    int finish_upload()
-    {
-        if (resident) return 0;
-        if (nnz && mx::xfer_h2d(hold->j.p, hold->hj, sizeof(int32_t) * (size_t)nnz)) return 1;
-        if (hold->vb && nnz && mx::xfer_h2d(hold->x.p, hold->hx, hold->vb * (size_t)nnz)) return 1;
-        publish();
-        return 0;
-    }
-    static uint64_t fingerprint_of(const int32_t *indptr, const int32_t *indices, const void *values, size_t pb, size_t jb, size_t xb)
-    {
-        return fingerprint_array(fingerprint_array(fingerprint_array(0xcbf29ce484222325ULL, indptr, pb), indices, jb), values, xb);
-    }
-    // the key of the entry to come, if it has not been computed yet (call where the host has time to spare)
-    void fingerprint_now()
-    {
-        if (resident || !cacheable || have_fp) return;
-        CsrDev &e = *hold;
-        e.fp = fingerprint_of((const int32_t *)e.hp, (const int32_t *)e.hj, e.hx, sizeof(int32_t) * ((size_t)e.m + 1),
-                              sizeof(int32_t) * (size_t)e.nnz, e.vb * (size_t)e.nnz);
-        have_fp = true;
-    }
-    void publish()
-    {
-        if (!resident && cacheable) { fingerprint_now(); CsrCache::get().insert(hold); }
-        resident = true;
-    }
-    bool have_fp = false;
-    // uploads indptr[0..m], indices/values[0..indptr[m]) (or finds them in the cache); value_bytes 0 => no values
-    int upload(const int32_t *indptr, const int32_t *indices, const void *values, int m, size_t value_bytes)
-    {
-        if (prepare(indptr, indices, values, m, value_bytes, true)) return 1;
-        return finish_upload();
-    }
-    // a private copy the caller may modify on the device (the in-place exports)
-    int upload_private(const int32_t *indptr, const int32_t *indices, const void *values, int m, size_t value_bytes)
-    {
-        if (prepare(indptr, indices, values, m, value_bytes, false)) return 1;
-        return finish_upload();
-    }
-    bool cacheable = false;
-};
-
-// per-thread streams and events of the export pipeline (upload / compute / download run on their own queues)
-struct Lanes {
-    hipStream_t up = nullptr, run = nullptr, down = nullptr;
-    std::vector<hipEvent_t> ev;
-    int dev = -1;
-    int init(size_t nev)
-    {
-        int d = 0;
-        MX_HIP(hipGetDevice(&d));
-        if (dev != d) {
-            // the streams and events of the device this thread worked on before go back to that device (the shard workers
-            // are persistent: a changed device list used to leave 3 streams + 2 nblk + 2 events per worker behind)
-            if (dev >= 0 && (up || !ev.empty())) {
-                if (hipSetDevice(dev) == hipSuccess) { drain(); destroy(); }
-                else { (void)hipGetLastError(); up = run = down = nullptr; ev.clear(); }
-                MX_HIP(hipSetDevice(d));
-            }
-            MX_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
-            MX_HIP(hipStreamCreateWithFlags(&run, hipStreamNonBlocking));
-            MX_HIP(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
-            dev = d;
-        }
-        while (ev.size() < nev) {
-            hipEvent_t e;
-            MX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ev.push_back(e);
-        }
-        return 0;
-    }
-    void drain() { if (up) (void)hipStreamSynchronize(up); if (run) (void)hipStreamSynchronize(run); if (down) (void)hipStreamSynchronize(down); }
-    void destroy()
-    {
-        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-        ev.clear();
-        if (up) (void)hipStreamDestroy(up);
-        if (run) (void)hipStreamDestroy(run);
-        if (down) (void)hipStreamDestroy(down);
-        up = run = down = nullptr;
-        dev = -1;
-    }
-};
-static Lanes &lanes() { static thread_local Lanes l; return l; }
-
-// Host memory registered for the duration of a scope.  Only buffers of at least PIN_WHOLE_MIN bytes are registered as a
-// whole: an allocation that large is a mapping of its own (glibc serves nothing above 32 MiB from a shared heap), so its
-// first and last page belong to nobody else.  Smaller buffers may share their edge pages with a neighbouring heap
-// object, and a page pinned / unpinned through two overlapping registrations has been seen to leave the GPU with a stale
-// mapping (memory-access fault some calls later: tools/fuzz_structure.py, seed 5) — they go through xfer_h2d / xfer_d2h,
-// which register whole interior pages only.
-constexpr size_t PIN_WHOLE_MIN = (size_t)64 << 20;
-struct Pin {
-    const void *p = nullptr;                                     // start of the registered range
-    size_t bytes = 0;
-    bool ok = false;
-    bool pin(const void *ptr, size_t nbytes, bool all_devices = false)
-    {
-        ok = nbytes >= PIN_WHOLE_MIN && mx::pin_host(ptr, nbytes, all_devices);
-        p = ptr; bytes = nbytes;
-        return ok;
-    }
-    // a page-aligned piece of a buffer that is registered piece by piece (the pieces must not share pages)
-    bool pin_pages(const void *ptr, size_t nbytes, bool all_devices = false) { ok = mx::pin_host(ptr, nbytes, all_devices); p = ptr; bytes = nbytes; return ok; }
-    // the whole pages INSIDE a buffer of any size, for every device: what the coordinating thread of a sharded call
-    // registers once for an input that all its workers read.  (The workers must not register such a buffer themselves:
-    // while one of them unregisters its range another one's hipMemcpy may have just found that range in the runtime's
-    // map — "Memobj map does not have ptr", abort.  Seen with B between 16 and 64 MiB on three workers.)
-    bool pin_inside(const void *ptr, size_t nbytes)
-    {
-        const uintptr_t a = ((uintptr_t)ptr + 4095) & ~(uintptr_t)4095, b = ((uintptr_t)ptr + nbytes) & ~(uintptr_t)4095;
-        ok = nbytes > ((size_t)32 << 20) && b > a && mx::pin_host((const void *)a, b - a, true);   // (> 32 MiB: never a piece of the brk heap, see xfer.hip)
-        p = (const void *)a; bytes = b - a;
-        return ok;
-    }
-    ~Pin() { if (ok) mx::unpin_host(p); }
-};
-
-// [src, src + nbytes) of a host buffer -> device: the part inside `pin`'s registered range as one asynchronous DMA on
-// `st`, whatever lies outside (edge pages; everything when nothing is registered) by plain synchronous copies.
-static bool upload_through(const Pin &pin, void *dst, const void *src, size_t nbytes, hipStream_t st)
-{
-    if (nbytes == 0) return true;
-    const char *s0 = (const char *)src, *s1 = s0 + nbytes;
-    const char *r0 = pin.ok ? std::max(s0, (const char *)pin.p) : s1;
-    const char *r1 = pin.ok ? std::min(s1, (const char *)pin.p + pin.bytes) : s1;
-    if (r1 <= r0) return mx::xfer_h2d(dst, src, nbytes) == 0;               // (nothing registered: the engine's staged / registered copy)
-    bool ok = hipMemcpyAsync((char *)dst + (r0 - s0), r0, (size_t)(r1 - r0), hipMemcpyHostToDevice, st) == hipSuccess;
-    if (ok && r0 > s0) ok = hipMemcpy(dst, s0, (size_t)(r0 - s0), hipMemcpyHostToDevice) == hipSuccess;
-    if (ok && s1 > r1) ok = hipMemcpy((char *)dst + (r1 - s0), r1, (size_t)(s1 - r1), hipMemcpyHostToDevice) == hipSuccess;
-    return ok;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Several GPUs behind the same export (mx_set_devices): the rows of A are cut into one contiguous range per
-// listed device, balanced by what a row costs (12 bytes of CSR up per entry, n result elements down); every device gets
-// B, multiplies its rows and downloads them straight into its rows of the caller's result (pitched copy: the host matrix
-// is column-major).  The result lives on the host, so the devices never talk to each other — no collective; with C wanted
-// on every GPU instead (matrixextra_amd/distributed.py) the same row blocks are exchanged by one RCCL all-gather.
-static std::mutex g_devices_mu;
-static std::vector<int> g_devices;                               // empty: the calling thread's current device only
-
-// cuts[0..nparts]: rows [cuts[k], cuts[k+1]) for part k; cumulative cost of the first r rows = w_entry * indptr[r] + w_row * r
-static void partition_rows(const int32_t *indptr, int m, int nparts, double w_entry, double w_row, int *cuts)
-{
-    const double base = w_entry * (double)indptr[0];
-    const double total = w_entry * (double)indptr[m] - base + w_row * (double)m;
-    cuts[0] = 0;
-    for (int k = 1; k < nparts; k++) {
-        const double target = total * (double)k / (double)nparts;
-        int lo = cuts[k - 1], hi = m;                            // first r with cost(r) >= target
-        while (lo < hi) {
-            const int mid = lo + (hi - lo) / 2;
-            const double c = w_entry * (double)indptr[mid] - base + w_row * (double)mid;
-            if (c < target) lo = mid + 1; else hi = mid;
-        }
-        cuts[k] = lo;
-    }
-    cuts[nparts] = m;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// SMALL CALLS.  The reference's own tests multiply 100 x 50 matrices (tests/testthat/test-matmul.R:108-114)
-// and slice 1000 x 500 ones (test-slice.R:6-16); the machinery above is built for results of a gigabyte and cost such a call
-// 76-175 us (tools/small_calls.py, round 4: four or six synchronous pageable copies, five pooled blocks each freed behind a
-// device synchronisation, a cache look-up).  A call whose operands and result fit SMALL_LIMIT goes another way: every
-// input is packed into ONE pinned block (a host memcpy of a few microseconds), goes up in ONE asynchronous copy on the
-// thread's own stream, the kernels run on the device twin of that block (inputs, results and workspaces at the same
-// offsets), the results come back in ONE copy, and the call synchronises ONCE.  No pool, no cache, no registration, no
-// fingerprint.  The same kernels compute; nothing is computed on the host.  MXGPU_SMALL_CALLS=0 switches the path off.
-// inputs + results of a call that takes the small path, and the block: inputs, results, kernel workspaces.  Where the path
-// stops paying against the regular one was measured per export (tools/small_limit_probe.py, MXGPU_SMALL_LIMIT_KB = 16 against
-// 65536: the packing memcpy is one host thread, the regular path's fixed cost ~110-250 us): SpMV and the row gather up to
-// ~2 MiB of operands + result, the merges ~3 MiB (operands + the result's upper bound), SpMM ~6-8 MiB.
-static const size_t SMALL_LIMIT = [] {
-    const char *e = getenv("MXGPU_SMALL_LIMIT_KB");
-    const long kb = e ? atol(e) : 2048;
-    return (size_t)(kb < 16 ? 16 : (kb > (64 << 10) ? (64 << 10) : kb)) << 10;
-}();
-static const size_t SMALL_LIMIT_SPMM = SMALL_LIMIT * 3, SMALL_LIMIT_MERGE = SMALL_LIMIT + SMALL_LIMIT / 2;
-static const size_t SMALL_STAGE = SMALL_LIMIT * 6;
-struct SmallStage {
-    char *h = nullptr, *d = nullptr;
-    hipStream_t st = nullptr;
-    size_t top = 0;
-    bool tried = false;
-    // an error exit after up(): the copy from the pinned block may still be in flight, and the next small call packs its
-    // operands into that block — wait for the stream first (round 4's advisor finding)
-    int fail() { if (st) (void)hipStreamSynchronize(st); return 1; }
-    bool init()
-    {
-        if (tried) return h != nullptr;
-        tried = true;
-        if (hipHostMalloc((void **)&h, SMALL_STAGE, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h = nullptr; return false; }
-        if (hipMalloc((void **)&d, SMALL_STAGE) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipHostFree(h);
-            if (d) (void)hipFree(d);
-            h = d = nullptr;
-            return false;
-        }
-        return true;
-    }
-    // offsets are the same on both sides; 256-byte aligned (16-byte rules of the kernels, whole cache lines)
-    size_t take(size_t n) { const size_t at = top; top = (top + (n ? n : 16) + 255) & ~(size_t)255; return at; }
-    size_t put(const void *src, size_t n) { const size_t at = take(n); if (n) memcpy(h + at, src, n); return at; }
-    bool fits() const { return top <= SMALL_STAGE; }
-    template <typename T> T *dev(size_t off) const { return reinterpret_cast<T *>(d + off); }
-    int up(size_t bytes) { MX_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st)); return 0; }
-    int down_and_wait(size_t from, size_t to)
-    {
-        if (to > from) MX_HIP(hipMemcpyAsync(h + from, d + from, to - from, hipMemcpyDeviceToHost, st));
-        MX_HIP(hipStreamSynchronize(st));
-        return 0;
-    }
-};
-static thread_local SmallStage g_small_stages[16];
-// the calling thread's staging blocks go back (mxd_release_workspaces); they come back on the next small call
-void small_stage_release()
-{
-    for (SmallStage &st : g_small_stages) {
-        if (!st.h) { st.tried = false; continue; }
-        (void)hipStreamSynchronize(st.st);
-        (void)hipStreamDestroy(st.st);
-        (void)hipHostFree(st.h);
-        (void)hipFree(st.d);
-        st = SmallStage();
-    }
-}
-static SmallStage *small_stage()
-{
-    static const bool on = [] { const char *e = getenv("MXGPU_SMALL_CALLS"); return !e || atoi(e) != 0; }();
-    if (!on) return nullptr;
-    SmallStage *stages = g_small_stages;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
-    SmallStage &s = stages[dev];
-    if (!s.init()) return nullptr;
-    s.top = 0;
-    return &s;
-}
-static std::atomic<long long> g_small_calls{0};                  // mx_get_option("small_calls")
-
-// The shards of a sharded export run on PERSISTENT worker threads, one per entry of the device list, kept between calls
-// with what a thread keeps (its streams and events, AUTO's plan buffers, the library's per-thread scratch).  Rounds 2-3
-// started fresh threads for every call and let them release everything at exit: each call then began with ~2 GB of
-// hipMalloc per shard (serialised in the driver: 20 ms per shard, 190 ms at the head of configs[4] on the first call) and
-// ended with as much hipFree, which the copy engines scrub under whatever comes next (round 4 timeline).
-// mx_set_devices gives the workers' memory back (their threads stay).
-struct ShardPool {
-    struct W {
-        std::thread th;
-        std::mutex mu;
-        std::condition_variable cv;
-        std::function<void()> job;
-        bool has = false, done = true;
-    };
-    std::vector<std::unique_ptr<W>> ws;
-    std::mutex call_mu;                                          // one sharded call at a time uses the workers
-    void ensure(size_t n)
-    {
-        while (ws.size() < n) {
-            ws.emplace_back(new W());
-            W *w = ws.back().get();
-            w->th = std::thread([w] {
-                for (;;) {
-                    std::unique_lock<std::mutex> lk(w->mu);
-                    w->cv.wait(lk, [&] { return w->has; });
-                    std::function<void()> j = std::move(w->job);
-                    w->has = false;
-                    lk.unlock();
-                    j();
-                    lk.lock();
-                    w->done = true;
-                    w->cv.notify_all();
-                }
-            });
-            w->th.detach();                                      // (lives as long as the process; blocked on its condition variable between calls)
-        }
-    }
-    void start(size_t k, std::function<void()> j)
-    {
-        W &w = *ws[k];
-        { std::lock_guard<std::mutex> lk(w.mu); w.job = std::move(j); w.has = true; w.done = false; }
-        w.cv.notify_all();
-    }
-    void wait(size_t k)
-    {
-        W &w = *ws[k];
-        std::unique_lock<std::mutex> lk(w.mu);
-        w.cv.wait(lk, [&] { return w.done; });
-    }
-    void release_memory()                                        // every worker gives its per-thread device memory back
-    {
-        std::lock_guard<std::mutex> lk(call_mu);
-        for (size_t k = 0; k < ws.size(); k++) start(k, [] { lanes().drain(); mx::release_thread_workspaces(); });
-        for (size_t k = 0; k < ws.size(); k++) wait(k);
-    }
-};
-static ShardPool &shard_pool() { static ShardPool *p = new ShardPool(); return *p; }   // (never destroyed: its threads outlive static teardown)
-
-template <typename real_t>
-static int spmm_host_multi(const std::vector<int> &devs, int m, int n, int K_rows, const int32_t *indptr,
-                           const int32_t *indices, const double *values, const real_t *B_host, size_t ldb, real_t *C_host,
-                           size_t ldc, size_t c_elems, bool colmajor, int algo, int npanels)
-{
-    const int nd = (int)devs.size();
-    const size_t c_bytes = sizeof(real_t) * c_elems, b_bytes = sizeof(real_t) * (size_t)K_rows * ldb;
-    const int64_t nnz = indptr[m];
-    const int dt = sizeof(real_t) == 8 ? MX_F64 : MX_F32;
-    Trace tr("spmm export (sharded)");
-    // The caller's result is first-touched and registered PIECE BY PIECE (page-aligned cuts of ~96 MiB), and a shard
-    // downloads what lies in a piece as soon as that piece is registered.  Round 3 touched and registered the whole result
-    // before the first byte came down: on one GPU listed 8 times, configs[4] whole took 369-467 ms against 189 ms
-    // unsharded — 77 ms of page work at the head of every shard's download.  A "unit" is what is
-    // contiguous in the caller's matrix — a column of a column-major C, a row of a row-major one; a unit comes down with
-    // the first piece that completes it, so no copy ever touches an unregistered page and no page is registered twice.
-    constexpr int MAX_PIECES = 32;
-    const size_t unit_bytes = (colmajor ? (size_t)m : ldc) * sizeof(real_t);
-    const int64_t n_units = colmajor ? n : m;
-    int np = (int)std::min<size_t>(MAX_PIECES, std::max<size_t>(1, c_bytes / ((size_t)96 << 20)));
-    std::vector<size_t> piece_off(1, 0);
-    for (int g = 1; g < np; g++) {
-        const uintptr_t cutp = ((uintptr_t)C_host + c_bytes / (size_t)np * (size_t)g) & ~(uintptr_t)4095;
-        if (cutp > (uintptr_t)C_host + piece_off.back() && cutp < (uintptr_t)C_host + c_bytes) piece_off.push_back(cutp - (uintptr_t)C_host);
-    }
-    piece_off.push_back(c_bytes);
-    np = (int)piece_off.size() - 1;
-    std::vector<int64_t> ucut((size_t)np + 1, 0);                   // units [ucut[g], ucut[g + 1]) become complete with piece g
-    for (int g = 1; g < np; g++) ucut[g] = std::min<int64_t>(n_units, (int64_t)(piece_off[g] / unit_bytes));
-    ucut[np] = n_units;
-    std::vector<std::pair<void *, size_t>> pcs;
-    for (int g = 0; g < np; g++) pcs.emplace_back((void *)((char *)C_host + piece_off[g]), piece_off[g + 1] - piece_off[g]);
-    std::atomic<int> piece_arrived[MAX_PIECES];
-    for (auto &a : piece_arrived) a.store(0);
-    const int touch_team = mx::prefault_begin_pieces(C_host, c_bytes, pcs, piece_arrived);
-    struct JoinTeam { ~JoinTeam() { mx::prefault_wait(); } } join_team;   // (the team counts into piece_arrived until it is joined)
-    std::vector<int> cut((size_t)nd + 1);
-    partition_rows(indptr, m, nd, 12.0, (double)n * sizeof(real_t), cut.data());
-    // one kernel family for the whole product (see spmm_host); the alignment rules only look at the low bits of the pointers
-    mx::SpmmFamily fam;                                          // (captured BY VALUE by the shard lambdas below)
-    if (algo == MX_SPMM_AUTO) fam = export_auto_family(m, n, K_rows, nnz, dt, (const void *)(uintptr_t)256, ldb, (const void *)(uintptr_t)256,
-                                                       colmajor ? (size_t)m : ldc, colmajor ? 1 : 0, indptr, indices);
-    else fam.family = algo;
-    // host memory registered for every device; `gate` opens once the result is registered (downloads wait for it)
-    Pin pinB, pinJ, pinX;
-    std::vector<Pin> pinC((size_t)np);
-    // (large arrays as a whole, smaller ones by their interior pages; what cannot be registered goes up by plain copies)
-    if (!pinB.pin(B_host, b_bytes, true)) pinB.pin_inside(B_host, b_bytes);
-    if (!pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz, true)) pinJ.pin_inside(indices, sizeof(int32_t) * (size_t)nnz);
-    if (!pinX.pin(values, sizeof(double) * (size_t)nnz, true)) pinX.pin_inside(values, sizeof(double) * (size_t)nnz);
-    std::mutex gate_mu;
-    std::condition_variable gate_cv;
-    int gate = 0;                                                // pieces registered so far; -1: a registration failed
-    std::vector<std::string> errors((size_t)nd);
-    // B goes up ONCE per distinct device (a device may be listed several times — its shards share the GPU): the first shard
-    // of a device to get there uploads it, the others wait for that upload's event
-    // turn: the shards of ONE device take turns for their upload + product phase (they share that device's link: eight
-    // concurrent upload streams moved 19 GB/s where one moves 33-55; MXGPU_SHARD_TURNS=0 lets them run together).  The
-    // downloads of a shard that has had its turn keep running under the next shard's uploads (PCIe is full duplex).
-    struct SharedB { std::once_flag once; DevBuf buf; hipEvent_t ev = nullptr; bool ok = false; std::mutex turn; };
-    static const bool shard_turns = [] { const char *e = getenv("MXGPU_SHARD_TURNS"); return !e || atoi(e) != 0; }();
-    std::vector<int> distinct;
-    std::vector<int> dev_slot((size_t)nd);
-    for (int k = 0; k < nd; k++) {
-        size_t at = std::find(distinct.begin(), distinct.end(), devs[k]) - distinct.begin();
-        if (at == distinct.size()) distinct.push_back(devs[k]);
-        dev_slot[k] = (int)at;
-    }
-    std::vector<std::unique_ptr<SharedB>> shared_b;
-    for (size_t q = 0; q < distinct.size(); q++) shared_b.emplace_back(new SharedB());
-    // every shard first allocates and copies its (small) index pointer, THEN all of them start their bulk uploads: a 4 MB
-    // copy queued behind the other shards' gigabytes waited up to 160 ms for its turn on the copy engines
-    int n_active = 0;
-    for (int k = 0; k < nd; k++) n_active += cut[k + 1] > cut[k];
-    std::mutex start_mu;
-    std::condition_variable start_cv;
-    int arrived_shards = 0;
-    const auto t_call = std::chrono::steady_clock::now();
-    auto at_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
-    auto shard = [&](int k) {
-        auto failed = [&](const char *what) { errors[k] = std::string(what) + ": " + mx_last_error(); };
-        auto note = [&](const char *what) { if (tr.on) fprintf(stderr, "[mxgpu] shard %d %-18s at %8.2f ms\n", k, what, at_ms()); };
-        note("start");
-        const int r_lo = cut[k], r_hi = cut[k + 1], mk = r_hi - r_lo;
-        if (mk == 0) return;
-        struct Arrive {                                          // counted once on EVERY path of a shard that has rows (a failing
-            std::mutex &mu; std::condition_variable &cv; int &count; bool done = false;      // shard must not hold the others)
-            void now() { if (!done) { { std::lock_guard<std::mutex> lk(mu); count++; } cv.notify_all(); done = true; } }
-            ~Arrive() { now(); }
-        } arrive{start_mu, start_cv, arrived_shards};
-        if (hipSetDevice(devs[k]) != hipSuccess) { errors[k] = "hipSetDevice failed"; return; }
-        const int64_t e_lo = indptr[r_lo], e_hi = indptr[r_hi];
-        Lanes &L = lanes();                                      // this worker thread's queues: kept, like the thread
-        const int nblk = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)mk * n * (int64_t)sizeof(real_t) / ((int64_t)96 << 20)));
-        struct Drain { Lanes &l; ~Drain() { l.drain(); } } drain{L};   // (every exit: nothing of this call is left in the queues)
-        if (L.init(2 * (size_t)nblk + 2)) { failed("streams"); return; }
-        // the shard's own CSR arrays (indptr rebased on the host: mk + 1 ints), B, and its rows of C (column-major mk x n, or
-        // row-major)
-        DevBuf dp, dj, dx, dC;
-        std::vector<int32_t> p_local((size_t)mk + 1);
-        for (int r = 0; r <= mk; r++) p_local[r] = (int32_t)(indptr[r_lo + r] - e_lo);
-        // (a plain copy: the transfer engine of xfer.hip is one per process and busy first-touching the result right now —
-        // going through it cost every shard ~18 ms, one after the other)
-        if (dp.alloc(sizeof(int32_t) * ((size_t)mk + 1)) ||
-            hipMemcpy(dp.p, p_local.data(), sizeof(int32_t) * ((size_t)mk + 1), hipMemcpyHostToDevice) != hipSuccess || dj.alloc(sizeof(int32_t) * (size_t)(e_hi - e_lo)) ||
-            dx.alloc(sizeof(double) * (size_t)(e_hi - e_lo)) || dC.alloc(sizeof(real_t) * (size_t)mk * n)) {
-            failed("device allocation");
-            return;
-        }
-        const size_t ldc_k = colmajor ? (size_t)mk : ldc;
-        note("allocated");
-        arrive.now();
-        {
-            std::unique_lock<std::mutex> lk(start_mu);
-            start_cv.wait(lk, [&] { return arrived_shards >= n_active; });
-        }
-        SharedB &sb = *shared_b[(size_t)dev_slot[k]];
-        std::call_once(sb.once, [&] {
-            if (sb.buf.alloc(b_bytes) || hipEventCreateWithFlags(&sb.ev, hipEventDisableTiming) != hipSuccess) return;
-            sb.ok = upload_through(pinB, sb.buf.p, B_host, b_bytes, L.up) && hipEventRecord(sb.ev, L.up) == hipSuccess;
-        });
-        if (!sb.ok) { failed("upload of B"); return; }
-        (void)hipStreamWaitEvent(L.run, sb.ev, 0);
-        DevBuf dB;
-        dB.alias(sb.buf.p, b_bytes);
-        bool ok = true;
-        std::unique_lock<std::mutex> my_turn(sb.turn, std::defer_lock);
-        if (shard_turns) my_turn.lock();
-        note("turn");
-        std::vector<int> bc((size_t)nblk + 1);
-        for (int b = 0; b <= nblk; b++) bc[b] = b == nblk ? mk : (int)((int64_t)mk * b / nblk) & ~1023;   // whole generations of the planned kernel
-        for (int b = 0; b < nblk && ok; b++) {
-            const int64_t e0 = p_local[bc[b]], e1 = p_local[bc[b + 1]];
-            if (e1 > e0) {
-                ok = ok && upload_through(pinJ, dj.as<int32_t>() + e0, indices + e_lo + e0, sizeof(int32_t) * (size_t)(e1 - e0), L.up);
-                ok = ok && upload_through(pinX, dx.as<double>() + e0, values + e_lo + e0, sizeof(double) * (size_t)(e1 - e0), L.up);
-            }
-            ok = ok && hipEventRecord(L.ev[b], L.up) == hipSuccess;
-        }
-        if (!ok) { errors[k] = "upload failed"; return; }
-        note("uploads queued");
-        // downloads of block b for piece g: queued as soon as BOTH exist — right behind the block's product for the pieces
-        // registered by then (queueing a product can hold this thread until the block's CSR slice has arrived: the plan is
-        // sized on the host), the rest when their pieces open.  issued[b] = pieces already queued for block b.
-        std::vector<int> issued((size_t)nblk, 0);
-        auto copy_run = [&](size_t off, const char *src, size_t bytes) {   // one contiguous run, cut at the piece boundaries it crosses
-            while (bytes && ok) {
-                size_t seg = bytes;
-                for (int q = 1; q < np; q++)
-                    if (piece_off[q] > off && piece_off[q] < off + bytes) { seg = piece_off[q] - off; break; }
-                ok = hipMemcpyAsync((char *)C_host + off, src, seg, hipMemcpyDeviceToHost, L.down) == hipSuccess;
-                off += seg; src += seg; bytes -= seg;
-            }
-        };
-        auto download = [&](int b, int g) {
-            const int r0 = bc[b], r1 = bc[b + 1];
-            const int64_t u0 = ucut[g], u1 = ucut[g + 1];
-            if (r1 == r0 || u1 <= u0) return;
-            if (colmajor) {                                      // rows of block b x columns [u0, u1)
-                int64_t uf = u0;                                 // columns whose run starts before this piece: one by one
-                while (uf < u1 && ((size_t)uf * ldc + r_lo + r0) * sizeof(real_t) < piece_off[g]) {
-                    copy_run(((size_t)uf * ldc + r_lo + r0) * sizeof(real_t), (const char *)(dC.as<real_t>() + (size_t)uf * ldc_k + r0),
-                             (size_t)(r1 - r0) * sizeof(real_t));
-                    uf++;
-                }
-                if (ok && uf < u1)
-                    ok = hipMemcpy2DAsync(C_host + (size_t)uf * ldc + r_lo + r0, ldc * sizeof(real_t),
-                                          dC.as<real_t>() + (size_t)uf * ldc_k + r0, ldc_k * sizeof(real_t),
-                                          (size_t)(r1 - r0) * sizeof(real_t), (size_t)(u1 - uf), hipMemcpyDeviceToHost, L.down) == hipSuccess;
-            } else {                                             // the rows of block b among rows [u0, u1)
-                const int64_t a0 = std::max<int64_t>(u0, (int64_t)r_lo + r0), a1 = std::min<int64_t>(u1, (int64_t)r_lo + r1);
-                if (a1 > a0)
-                    copy_run((size_t)a0 * ldc * sizeof(real_t), (const char *)(dC.as<real_t>() + (size_t)(a0 - r_lo) * ldc_k),
-                             (size_t)(a1 - a0) * ldc * sizeof(real_t));
-            }
-        };
-        auto download_open_pieces = [&](int upto_block) {        // non-blocking: whatever is registered by now
-            int open;
-            { std::lock_guard<std::mutex> lk(gate_mu); open = gate; }
-            if (open <= 0) return;
-            for (int b = 0; b <= upto_block && ok; b++) {
-                if (issued[b] >= open) continue;
-                (void)hipStreamWaitEvent(L.down, L.ev[nblk + b], 0);
-                for (int g = issued[b]; g < open && ok; g++) download(b, g);
-                issued[b] = open;
-            }
-        };
-        for (int b = 0; b < nblk; b++) {
-            const int r0 = bc[b], r1 = bc[b + 1];
-            if (r1 == r0) continue;
-            (void)hipStreamWaitEvent(L.run, L.ev[b], 0);
-            // the link is free for the next shard of this device once this shard's LAST upload has arrived — its last
-            // product (plan sizing on the host, the sweep) and its downloads do not need the upload direction any more
-            if (b == nblk - 1 && my_turn.owns_lock()) { (void)hipEventSynchronize(L.ev[b]); my_turn.unlock(); }
-            real_t *dCb = colmajor ? dC.as<real_t>() + r0 : dC.as<real_t>() + (size_t)r0 * ldc_k;
-            if (p_local[r0] == p_local[r1]) {
-                if (colmajor) (void)hipMemset2DAsync(dCb, ldc_k * sizeof(real_t), 0, (size_t)(r1 - r0) * sizeof(real_t), n, L.run);
-                else (void)hipMemsetAsync(dCb, 0, (size_t)(r1 - r0) * ldc_k * sizeof(real_t), L.run);
-            } else if (mx::spmm_block(fam, algo == MX_SPMM_AUTO, r1 - r0, n, K_rows, (int64_t)p_local[r1] - p_local[r0],
-                                      dp.as<int32_t>() + r0, dj.as<int32_t>(),
-                                      dx.as<double>(), dB.p, ldb, dCb, ldc_k, dt, colmajor ? 1 : 0, npanels, L.run)) {
-                failed("spmm");
-                return;
-            }
-            (void)hipEventRecord(L.ev[nblk + b], L.run);
-            download_open_pieces(b);
-        }
-        if (my_turn.owns_lock()) my_turn.unlock();
-        note("products queued");
-        for (int g = 0; g < np && ok; g++) {                     // the pieces that were not open yet: wait for each, queue what is left
-            {
-                std::unique_lock<std::mutex> lk(gate_mu);
-                gate_cv.wait(lk, [&] { return gate < 0 || gate > g; });
-                if (gate < 0) { errors[k] = "result not registered"; return; }
-            }
-            for (int b = 0; b < nblk && ok; b++) {
-                if (issued[b] > g || bc[b + 1] == bc[b]) continue;
-                (void)hipStreamWaitEvent(L.down, L.ev[nblk + b], 0);
-                download(b, g);
-                issued[b] = g + 1;
-            }
-        }
-        if (!ok) { errors[k] = "download failed"; return; }
-        note("downloads queued");
-        L.drain();
-        note("drained");
-    };
-    int dev0 = 0;
-    (void)hipGetDevice(&dev0);
-    ShardPool &SP = shard_pool();
-    std::lock_guard<std::mutex> one_call(SP.call_mu);
-    SP.ensure((size_t)nd);
-    for (int k = 0; k < nd; k++) SP.start((size_t)k, [&shard, k] { shard(k); });
-    bool c_ok = true;
-    for (int g = 0; g < np && c_ok; g++) {                       // this thread: register each piece when the team has touched it
-        while (touch_team && piece_arrived[g].load(std::memory_order_acquire) < touch_team) std::this_thread::yield();
-        const double t_touched = at_ms();
-        c_ok = pinC[g].pin_pages((char *)C_host + piece_off[g], piece_off[g + 1] - piece_off[g], true);
-        if (tr.on) fprintf(stderr, "[mxgpu] piece %d/%d touched at %8.2f ms, registered at %8.2f ms\n", g, np, t_touched, at_ms());
-        {
-            std::lock_guard<std::mutex> lk(gate_mu);
-            gate = c_ok ? g + 1 : -1;
-        }
-        gate_cv.notify_all();
-    }
-    for (int k = 0; k < nd; k++) SP.wait((size_t)k);
-    for (size_t q = 0; q < distinct.size(); q++) {               // the shared copies of B go back to the pool of their device
-        (void)hipSetDevice(distinct[q]);
-        if (shared_b[q]->ev) (void)hipEventDestroy(shared_b[q]->ev);
-        shared_b[q].reset();
-    }
-    (void)hipSetDevice(dev0);
-    tr.mark("shards");
-    MX_REQUIRE(c_ok, "sharded spmm export: cannot register the result for direct DMA");
-    for (int k = 0; k < nd; k++)
-        if (!errors[k].empty()) return set_error("sharded spmm export, device %d: %s", devs[k], errors[k].c_str());
-    return 0;
-}
-
-// C(m x n) = A(CSR, m rows) * B(row-major rows of length ldb); host in, host out.
-//
-// Large products run as a pipeline over row blocks on three queues: the block's slice of (indices, values) goes up (direct
-// DMA from the caller's registered vectors) while the previous block is multiplied and the one before that comes down
-// (direct DMA into the caller's registered result, whose pages a team of host threads first-touches meanwhile: R has
-// only just allocated it).  PCIe is full duplex, so a cold call costs about max(upload, download) instead of their sum,
-// and a call whose CSR is still on the device (cache above) pays the download only.
-template <typename real_t>
-static int spmm_host(int m, int n, int K_rows, const int32_t *indptr, const int32_t *indices, const double *values,
-                     const real_t *B_host, size_t ldb, real_t *C_host, size_t ldc, size_t c_elems, bool colmajor)
-{
-    MX_REQUIRE(m >= 0 && n >= 0 && K_rows >= 0, "negative dimension");
-    if (c_elems == 0) return 0;
-    // reference early-out (matmul.cpp:128-129,160-161): result stays the zero-initialised matrix
-    if (m == 0 || n == 0 || indptr[0] == indptr[m]) { memset(C_host, 0, c_elems * sizeof(real_t)); return 0; }
-    Trace tr("spmm export");
-    const size_t c_bytes = sizeof(real_t) * c_elems, b_bytes = sizeof(real_t) * (size_t)K_rows * ldb;
-    const int dt = sizeof(real_t) == 8 ? MX_F64 : MX_F32;
-    // kernel choice: AUTO unless the MXGPU_SPMM_ALGO / MXGPU_SPMM_PANELS tuning knobs say otherwise
-    int algo = MX_SPMM_AUTO, npanels = 0;
-    if (const char *e = getenv("MXGPU_SPMM_ALGO")) algo = atoi(e);
-    if (const char *e = getenv("MXGPU_SPMM_PANELS")) npanels = atoi(e);
-    {   // small call: one block up, the product, one block down, one wait (see SmallStage)
-        const int64_t nnz_s = (int64_t)indptr[m] - indptr[0];
-        const size_t csr_bytes = 4 * ((size_t)m + 1) + 12 * (size_t)nnz_s;
-        SmallStage *S = indptr[0] == 0 && csr_bytes + b_bytes + c_bytes <= SMALL_LIMIT_SPMM && algo != MX_SPMM_SLAB ? small_stage() : nullptr;
-        if (S) {
-            const size_t op = S->put(indptr, 4 * ((size_t)m + 1)), oj = S->put(indices, 4 * (size_t)nnz_s), ox = S->put(values, 8 * (size_t)nnz_s);
-            const size_t ob = S->put(B_host, b_bytes), in_end = S->top, oc = S->take(c_bytes), out_end = S->top;
-            if (S->up(in_end)) return 1;
-            if (mxd_spmm_csr_dense_ex2(m, n, K_rows, nnz_s, S->dev<int32_t>(op), S->dev<int32_t>(oj), S->dev<double>(ox), S->dev<real_t>(ob), ldb,
-                                       S->dev<real_t>(oc), ldc, dt, colmajor ? 1 : 0, algo, 0, npanels, 0, S->st)) return S->fail();
-            if (S->down_and_wait(oc, out_end)) return 1;
-            memcpy(C_host, S->h + oc, c_bytes);
-            g_small_calls++;
-            return 0;
-        }
-    }
-    static const int pipeline_on = [] { const char *e = getenv("MXGPU_EXPORT_PIPELINE"); return e ? atoi(e) : 1; }();
-    const bool pipelined = pipeline_on && c_bytes >= ((size_t)64 << 20) && m >= 4096 && algo != MX_SPMM_SLAB;
-    if (pipelined) {
-        std::vector<int> devs;
-        { std::lock_guard<std::mutex> lk(g_devices_mu); devs = g_devices; }
-        if (devs.size() > 1)
-            return spmm_host_multi<real_t>(devs, m, n, K_rows, indptr, indices, values, B_host, ldb, C_host, ldc, c_elems, colmajor,
-                                           algo, npanels);
-    }
-    // Pipelined calls start the upload of B before anything else: it then runs under the cache look-up, whose fingerprint
-    // reads every byte of the CSR on the host team (1.3-3 ms for cfg2).  Registrations are declared before `fence`: on
-    // every exit the queues drain first, then the memory is unpinned.
-    constexpr int MAX_BLK = 16;
-    Pin pinB, pinJ, pinX, pinC;
-    std::vector<Pin> pinBlk((size_t)MAX_BLK);
-    std::atomic<int> piece_arrived[MAX_BLK];                     // (declared before `fence`: the team counts into it until it is joined)
-    for (auto &a : piece_arrived) a.store(0);
-    int touch_team = 0;
-    struct Fence { Lanes *l; ~Fence() { if (l) { mx::prefault_wait(); l->drain(); } } } fence{nullptr};
-    real_t *dB = nullptr;
-    hipEvent_t evB = nullptr;
-    if (pipelined) {
-        Lanes &L0 = lanes();
-        if (L0.init(2 * (size_t)MAX_BLK + 2)) return 1;
-        fence.l = &L0;
-        // device B from the thread's grow-only scratch (no hipMalloc / hipFree of gigabytes per call)
-        dB = (real_t *)scratch_buffer_relief(mx::MX_SCRATCH_EXPORT_B, b_bytes);
-        MX_REQUIRE(dB, "spmm export: cannot allocate the device operands");
-        evB = L0.ev[2 * MAX_BLK];
-        if (pinB.pin(B_host, b_bytes)) {
-            MX_HIP(hipMemcpyAsync(dB, B_host, b_bytes, hipMemcpyHostToDevice, L0.up));
-        } else if (mx::xfer_h2d(dB, B_host, b_bytes)) return 1;
-        MX_HIP(hipEventRecord(evB, L0.up));
-    }
-    Csr A;
-    if (A.prepare(indptr, indices, values, m, sizeof(double), true)) return 1;
-    if (!pipelined) {
-        if (A.finish_upload()) return 1;
-        tr.mark("H2D csr");
-        DevBuf B, C;
-        if (B.upload(B_host, b_bytes)) return 1;
-        tr.mark("H2D dense");
-        if (C.alloc(c_bytes)) return 1;
-        int sorted = 0;
-        if (algo == MX_SPMM_SLAB) {
-            // column panels need rows sorted by column id: one pass over the indices on the device
-            DevBuf flag;
-            if (flag.alloc(16)) return 1;
-            if (mxd_csr_rows_sorted(m, A.p.as<int32_t>(), A.j.as<int32_t>(), flag.as<int32_t>(), &sorted, nullptr)) return 1;
-        }
-        if (mxd_spmm_csr_dense_ex2(m, n, K_rows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), B.p, ldb, C.p, ldc,
-                                   dt, colmajor ? 1 : 0, algo, sorted, npanels, 0, nullptr)) return 1;
-        if (tr.on) { MX_HIP(hipDeviceSynchronize()); tr.mark("kernels"); }
-        const int rc = mx::xfer_d2h(C_host, C.p, c_bytes);
-        tr.mark("D2H C");
-        return rc;
-    }
-
-    // ---- pipelined path.  Three shapes, by what is contiguous in the caller's result:
-    //   ROWS (row-major C, dense x CSC / dense x CSR^T): row blocks; a block of C is one contiguous range, so the result is
-    //        first-touched, registered and downloaded block by block;
-    //   COLS (column-major C, CSR already on the device): column blocks of B / C, same incremental scheme — the download
-    //        starts as soon as the first block is computed (~0.5 ms into the call);
-    //   ROWS_STRIDED (column-major C, CSR still on the host): row blocks, so that a block's slice of (indices, values) can
-    //        go up while earlier blocks are multiplied and come down.  Rows of a column-major matrix are strided: the result
-    //        is ALSO cut into groups of whole columns (contiguous pieces, touched and registered one after the other) and
-    //        comes down in tiles, row block x column group — see `tiled` below; without tiles (MXGPU_EXPORT_TILES=0, tiny
-    //        geometries) the whole result is first-touched and registered before the first block comes down.
-    // A column-major result whose CSR is still on the host takes COLS too when the upload is SHORT beside the page work:
-    // column blocks need the whole CSR on the device before the first block can be multiplied (12 bytes per entry at
-    // ~55 GB/s) but then run ONE plan — kept on the cache entry for the calls to come — and download contiguous pieces;
-    // row blocks (tiled, below) start their first download after one block's upload and one piece's pages.  cfg2: 7.1 ms of
-    // upload against 7.9 ms of page preparation -> row blocks (tiled: 25 ms, column blocks 28.5, same box); cfg5 whole:
-    // 112 ms against 63 ms -> row blocks (192 ms; 223 before the tiles).  Below half the page work: column blocks (not
-    // measured in between).
-    const double est_up_ms = 12.0 * (double)A.nnz / 55e6, est_prep_ms = (double)c_bytes * 7.75 / 1e9;
-    const char *cc_env = getenv("MXGPU_EXPORT_COLD_COLS");          // (read per call: bench.py times both forms in one process)
-    const int cold_cols_on = cc_env ? atoi(cc_env) : 1;
-    const bool cold_cols = colmajor && !A.resident && cold_cols_on && (est_up_ms < 0.5 * est_prep_ms || cold_cols_on == 2) &&   // (2: forced, for A/B runs)
-                           n >= 2 * 8 * (16 / (int)sizeof(real_t));
-    enum { ROWS, COLS, ROWS_STRIDED } shape = !colmajor ? ROWS : (A.resident || cold_cols ? COLS : ROWS_STRIDED);
-    constexpr int VEC = 16 / (int)sizeof(real_t);
-    const int col_gran = 8 * VEC;                                    // column blocks in whole 128-byte slabs
-    int nblk = (int)std::min<size_t>(16, std::max<size_t>(2, c_bytes / ((size_t)96 << 20)));
-    if (shape == COLS) nblk = std::max(1, std::min(nblk, n / col_gran));
-    static_assert(MAX_BLK == 16, "nblk above is capped at 16");
-    // block b = rows [cut[b], cut[b+1]) (ROWS, ROWS_STRIDED; cut at multiples of 1024 rows = whole generations of the
-    // planned kernel: a block that ended inside an octet of 64 rows would leave a half-empty octet to its own plan, and the
-    // whole matrix's plan can only be run from an octet boundary) or columns (COLS)
-    std::vector<int> cut((size_t)nblk + 1);
-    for (int b = 0; b <= nblk; b++)
-        cut[b] = shape == COLS ? (b == nblk ? n : (int)((int64_t)(n / col_gran) * b / nblk) * col_gran)
-                               : (b == nblk ? m : (int)((int64_t)m * b / nblk) & ~1023);
-    // ROWS_STRIDED, tiled: the result is ALSO cut into `ng` groups of whole columns = contiguous pieces of the caller's
-    // matrix (cut at page boundaries like the pieces of the contiguous shapes below), touched and registered one after
-    // the other; tile (b, g) = rows of block b x columns of group g comes down as soon as block b is multiplied and piece
-    // g is registered.  Before, the first block came down only when ALL pages of the result existed and were registered
-    // (cfg2: ~9 ms into a 29 ms call; cfg5 whole: ~95 ms into a 250 ms call, the download queue idle until then).
-    static const int tiles_on = [] { const char *e = getenv("MXGPU_EXPORT_TILES"); return e ? atoi(e) : 1; }();
-    // (the cuts: csrc/tile_geometry.h — page-aligned pieces, the groups' last partial pages; property-tested on the CPU)
-    mx::TileGeometry tg;
-    if (shape == ROWS_STRIDED && tiles_on)
-        tg = mx::tile_geometry((uintptr_t)C_host, sizeof(real_t), m, n, ldc, MAX_BLK, (size_t)64 << 20, cut[nblk] - cut[nblk - 1]);
-    const bool tiled = tg.ok;
-    const int ng = tiled ? tg.ng : 0;
-    const std::vector<int> &gcut = tg.gcut, &tail = tg.tail;
-    // Contiguous shapes: the result is first-touched, registered and downloaded in PIECES that follow the blocks but are cut
-    // at page boundaries of the caller's buffer (piece b = bytes [hb[b], hb[b+1]) of the result: block b without its last
-    // partial page, plus the last partial page of block b-1), so that no page is registered twice.
-    const bool incremental = shape != ROWS_STRIDED;
-    const int npieces = incremental ? nblk : ng;
-    std::vector<size_t> hb((size_t)std::max(npieces, 0) + 1, 0);
-    if (tiled) hb = tg.hb;
-    for (int b = 1; incremental && b < npieces; b++) {
-        const uintptr_t start = (uintptr_t)(C_host + (size_t)cut[b] * ldc), page = start & ~(uintptr_t)4095;   // first element of piece b
-        const size_t off = page > (uintptr_t)C_host ? (size_t)(page - (uintptr_t)C_host) : 0;
-        hb[b] = std::max(hb[b - 1], std::min(off, c_bytes));
-    }
-    if (incremental && npieces) hb[npieces] = c_bytes;
-    auto piece_ptr = [&](int b) { return (char *)C_host + hb[b]; };
-    auto piece_bytes = [&](int b) { return hb[b + 1] - hb[b]; };
-    // First touch of the result's pages by the host team, under the uploads: piece 0 when pieces follow one another,
-    // the whole result when it is registered in one go (or when the whole CSR has to arrive first anyway: COLS cold)
-    const bool whole_first = colmajor && !A.resident && !tiled;
-    if (whole_first) mx::prefault_begin(C_host, c_bytes);
-    else if (tiled) {                                               // all pieces, one after the other, without this thread in between
-        std::vector<std::pair<void *, size_t>> pcs;
-        for (int g = 0; g < ng; g++) pcs.emplace_back((void *)piece_ptr(g), piece_bytes(g));
-        touch_team = mx::prefault_begin_pieces(C_host, c_bytes, pcs, piece_arrived);
-    } else mx::prefault_begin(piece_ptr(0), piece_bytes(0));
-    Lanes &L = lanes();
-    real_t *dC = (real_t *)scratch_buffer_relief(mx::MX_SCRATCH_EXPORT_C, c_bytes);
-    MX_REQUIRE(dC, "spmm export: cannot allocate the device operands");
-    const int64_t nnz = A.nnz;
-    // The kernel family is chosen ONCE, for the whole product, and every block runs it (AUTO applied block by block took
-    // the row-wave kernel for cfg2's blocks — each below AUTO's size threshold — and would hand back other last bits cold
-    // than cached once cached calls use the matrix's plan).
-    mx::SpmmFamily fam;
-    if (algo == MX_SPMM_AUTO) fam = export_auto_family(m, n, K_rows, nnz, dt, dB, ldb, dC, ldc, colmajor ? 1 : 0, indptr, indices, A.hold.get());
-    else fam.family = algo;
-    const int family = fam.family;
-    mx_spmm_plan *plan = nullptr;
-    if (!A.resident) {
-        const bool direct_up = pinJ.pin(indices, sizeof(int32_t) * (size_t)nnz) && pinX.pin(values, sizeof(double) * (size_t)nnz);
-        if (!direct_up) { if (A.finish_upload()) return 1; }     // whole arrays through xfer_h2d; the blocks below then only compute
-    }
-    const bool uploading = !A.resident;
-    if (uploading && shape == COLS) {                            // the whole CSR in one piece; every block waits for it
-        if (nnz) {
-            MX_HIP(hipMemcpyAsync(A.j.as<int32_t>(), indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, L.up));
-            MX_HIP(hipMemcpyAsync(A.x.as<double>(), values, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, L.up));
-        }
-        MX_HIP(hipEventRecord(L.ev[0], L.up));
-    } else if (uploading) {
-        for (int b = 0; b < nblk; b++) {                         // the whole upload is queued up front
-            const int64_t e0 = indptr[cut[b]], e1 = indptr[cut[b + 1]];
-            if (e1 > e0) {
-                MX_HIP(hipMemcpyAsync(A.j.as<int32_t>() + e0, indices + e0, sizeof(int32_t) * (size_t)(e1 - e0),
-                                      hipMemcpyHostToDevice, L.up));
-                MX_HIP(hipMemcpyAsync(A.x.as<double>() + e0, values + e0, sizeof(double) * (size_t)(e1 - e0),
-                                      hipMemcpyHostToDevice, L.up));
-            }
-            MX_HIP(hipEventRecord(L.ev[b], L.up));
-        }
-    }
-    tr.mark("setup");
-    if (incremental && whole_first) { mx::prefault_wait(); mx::prefault_begin(piece_ptr(0), piece_bytes(0)); }
-    // A matrix that is found on the device again — or that goes up in one piece — keeps a plan of ALL its rows on its cache
-    // entry: built once (here, when AUTO plans this product), used by every block of this call and by every later call.
-    MX_HIP(hipStreamWaitEvent(L.run, evB, 0));
-    auto ensure_plan = [&](const char *phase) -> mx_spmm_plan * {
-        CsrDev &e = *A.hold;
-        std::lock_guard<std::mutex> lk(e.plan_mu);
-        if (e.spmm_plan && (e.spmm_plan_K != K_rows || e.spmm_plan_panels != npanels)) {
-            mxd_spmm_plan_destroy(e.spmm_plan);
-            e.spmm_plan = nullptr; e.spmm_plan_rejected = false;
-        }
-        if (!e.spmm_plan && !e.spmm_plan_rejected) {
-            int ready = 0;
-            if (mxd_spmm_plan_create_auto(m, K_rows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), npanels, L.run,
-                                          &e.spmm_plan, &ready)) {
-                e.spmm_plan = nullptr;                               // (no memory for a plan: the per-block path below)
-            } else if (!ready) {
-                mxd_spmm_plan_destroy(e.spmm_plan);
-                e.spmm_plan = nullptr; e.spmm_plan_rejected = true;
-            }
-            e.spmm_plan_K = K_rows; e.spmm_plan_panels = npanels;
-            if (e.spmm_plan) e.mark_plan_built(L.run);
-            tr.mark(phase);
-        }
-        if (e.spmm_plan) e.wait_plan_built(L.run);                   // (a no-op on the stream that built it)
-        return e.spmm_plan;
-    };
-    const bool plans = algo == MX_SPMM_AUTO && family == MX_SPMM_PLANNED;
-    if ((A.cache_hit || shape == COLS) && plans) {
-        if (uploading) MX_HIP(hipStreamWaitEvent(L.run, L.ev[0], 0));   // (COLS: the one upload; the build then waits for it)
-        plan = ensure_plan("plan");
-    }
-    tr.note("csr", A.cache_hit ? (plan ? "cached+plan" : "cached") : (shape == COLS ? "uploaded whole" : "uploaded by row blocks"));
-    // ---- One loop over the blocks: block b's product is queued, then its download behind it (first-touch by the host team
-    // -> register -> direct DMA).  Queueing a product can hold the host for a moment — a block's own plan is sized on the
-    // host, i.e. the call waits until the block's slice of the CSR has arrived — so the downloads are queued block by
-    // block too: when they were all queued after the last product, nothing came down before the whole upload had ended
-    // (cfg5 whole: 311 ms where upload and download could overlap).
-    bool direct_down = true, c_ready = false;
-    auto queue_product = [&](int b) -> int {
-        const int c0 = cut[b], c1 = cut[b + 1];
-        if (c1 > c0) {
-            if (uploading) MX_HIP(hipStreamWaitEvent(L.run, L.ev[shape == COLS ? 0 : b], 0));
-            int rc = 0;
-            if (shape == COLS) {
-                rc = plan ? mxd_spmm_plan_run_rows(plan, 0, m, c1 - c0, dB + c0, ldb, dC + (size_t)c0 * ldc, ldc, dt, 1, 0, -1, L.run)
-                          : mx::spmm_block(fam, algo == MX_SPMM_AUTO, m, c1 - c0, K_rows, nnz, A.p.as<int32_t>(), A.j.as<int32_t>(),
-                                           A.x.as<double>(), dB + c0, ldb, dC + (size_t)c0 * ldc, ldc, dt, 1, npanels, L.run);
-            } else {
-                real_t *dCb = colmajor ? dC + c0 : dC + (size_t)c0 * ldc;
-                if (indptr[c0] == indptr[c1]) {                      // a block without entries: zeros (the kernels' early-out)
-                    if (colmajor) MX_HIP(hipMemset2DAsync(dCb, ldc * sizeof(real_t), 0, (size_t)(c1 - c0) * sizeof(real_t), n, L.run));
-                    else MX_HIP(hipMemsetAsync(dCb, 0, (size_t)(c1 - c0) * ldc * sizeof(real_t), L.run));
-                } else {
-                    rc = plan ? mxd_spmm_plan_run_rows(plan, c0, c1 - c0, n, dB, ldb, dCb, ldc, dt, colmajor ? 1 : 0, 0, -1, L.run)
-                              : mx::spmm_block(fam, algo == MX_SPMM_AUTO, c1 - c0, n, K_rows, (int64_t)indptr[c1] - indptr[c0],
-                                               A.p.as<int32_t>() + c0,
-                                               A.j.as<int32_t>(), A.x.as<double>(), dB, ldb, dCb, ldc, dt, colmajor ? 1 : 0,
-                                               npanels, L.run);
-                }
-            }
-            if (rc) return 1;
-        }
-        MX_HIP(hipEventRecord(L.ev[nblk + b], L.run));
-        if (b == 0) tr.mark("block 0");
-        return 0;
-    };
-    if (tiled) {
-        // Tiles are queued diagonal by diagonal (b + g = d): diagonal d needs block d multiplied and piece d registered, i.e.
-        // the download queue gets its first tile after one block and one piece, and the number of tiles it may run grows with
-        // both.  (The last partial page of group g — tail[g] rows of its last column, rows of the LAST block — lies in piece
-        // g + 1, which is registered by the time that block's tiles are queued: diagonal nblk - 1 + g >= g + 1.)
-        char dims[32];
-        snprintf(dims, sizeof(dims), "%dx%d", nblk, ng);
-        tr.note("tiles", dims);
-        const size_t pitch = ldc * sizeof(real_t);
-        auto tile = [&](int b, int g) -> int {
-            const int c0 = cut[b], c1 = cut[b + 1], g0 = gcut[g], g1 = gcut[g + 1];
-            if (c1 == c0) return 0;
-            if (tr.on) fprintf(stderr, "[mxgpu] tile %d %d\n", b, g);
-            MX_HIP(hipStreamWaitEvent(L.down, L.ev[nblk + b], 0));
-            const int t = b == nblk - 1 && g + 1 < ng ? tail[g] : 0;
-            const int whole_cols = t ? g1 - g0 - 1 : g1 - g0;           // columns that come down over all rows of the block
-            const size_t at = (size_t)g0 * ldc + (size_t)c0;
-            if (whole_cols > 0)
-                MX_HIP(hipMemcpy2DAsync(C_host + at, pitch, dC + at, pitch, (size_t)(c1 - c0) * sizeof(real_t), (size_t)whole_cols,
-                                        hipMemcpyDeviceToHost, L.down));
-            if (t) {                                                 // the group's last column: up to the page boundary, then the rest
-                const size_t last = (size_t)(g1 - 1) * ldc + (size_t)c0;
-                const size_t head = (size_t)(c1 - c0 - t);
-                if (head) MX_HIP(hipMemcpyAsync(C_host + last, dC + last, head * sizeof(real_t), hipMemcpyDeviceToHost, L.down));
-                MX_HIP(hipMemcpyAsync(C_host + last + head, dC + last + head, (size_t)t * sizeof(real_t), hipMemcpyDeviceToHost, L.down));
-            }
-            return 0;
-        };
-        // This thread alternates between three jobs, none of which waits for another for long: a piece whose pages the team
-        // has touched is registered; every tile whose block is queued and whose piece is registered is queued for download
-        // (piece by piece, blocks in order); the next block's product is queued (holds the thread until that block's slice
-        // of the CSR has arrived).  The last block's tile of group g also needs piece g + 1 (the group's last partial page).
-        int nq = 0, nr = 0;                                         // products queued, pieces registered
-        int next_b[MAX_BLK] = {};                                   // per piece: the first block whose tile is not queued yet
-        double host_ms[4] = {0, 0, 0, 0};                           // where this thread spent its time
-        auto now = [] { return std::chrono::steady_clock::now(); };
-        auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
-        auto touched = [&](int g) { return touch_team == 0 || piece_arrived[g].load(std::memory_order_acquire) >= touch_team; };
-        int left = nblk * ng;
-        while (left > 0 || nq < nblk) {
-            auto t0 = now();
-            while (direct_down && nr < ng && touched(nr)) {
-                if (!pinBlk[nr].pin_pages(piece_ptr(nr), piece_bytes(nr))) { direct_down = false; break; }
-                if (nr == 0) tr.mark("piece 0");
-                nr++;
-            }
-            host_ms[2] += since(t0);
-            if (!direct_down) {                                      // no direct downloads: the products, then the staged copy below
-                while (nq < nblk) { if (queue_product(nq)) return 1; nq++; }
-                break;
-            }
-            t0 = now();
-            for (int g = 0; g < nr; g++)
-                while (next_b[g] < nq) {
-                    const int b = next_b[g];
-                    if (b == nblk - 1 && g + 1 < ng && tail[g] && nr < g + 2) break;
-                    if (tile(b, g)) return 1;
-                    next_b[g]++; left--;
-                }
-            host_ms[3] += since(t0);
-            t0 = now();
-            if (nq < nblk) {
-                if (queue_product(nq)) return 1;
-                nq++;
-                host_ms[0] += since(t0);
-            } else if (nr < ng && !touched(nr)) {                    // everything else is queued: wait for the team
-                while (!touched(nr)) std::this_thread::yield();
-                host_ms[1] += since(t0);
-            }
-        }
-        char hm[96];
-        snprintf(hm, sizeof(hm), "products %.2f touch %.2f pin %.2f tiles %.2f", host_ms[0], host_ms[1], host_ms[2], host_ms[3]);
-        tr.note("host ms", hm);
-    } else
-    for (int b = 0; b < nblk; b++) {
-        const int c0 = cut[b], c1 = cut[b + 1];
-        if (queue_product(b)) return 1;
-        if (!direct_down) continue;
-        if (incremental) {
-            mx::prefault_wait();                                     // piece b's pages exist
-            if (b + 1 < nblk && piece_bytes(b + 1)) mx::prefault_begin(piece_ptr(b + 1), piece_bytes(b + 1));
-            if (piece_bytes(b) == 0) continue;
-            if (!pinBlk[b].pin_pages(piece_ptr(b), piece_bytes(b))) { direct_down = false; continue; }
-            MX_HIP(hipStreamWaitEvent(L.down, L.ev[nblk + b], 0));   // (blocks complete in order: piece b needs blocks <= b)
-            MX_HIP(hipMemcpyAsync(piece_ptr(b), (const char *)dC + hb[b], piece_bytes(b), hipMemcpyDeviceToHost, L.down));
-        } else {
-            if (!c_ready) {                                          // the whole result: touched under the upload, registered once
-                mx::prefault_wait();
-                tr.mark("touched C");
-                direct_down = pinC.pin(C_host, c_bytes);
-                tr.mark("pinned C");
-                c_ready = true;
-                if (!direct_down) continue;
-            }
-            if (c1 == c0) continue;
-            MX_HIP(hipStreamWaitEvent(L.down, L.ev[nblk + b], 0));
-            MX_HIP(hipMemcpy2DAsync(C_host + c0, ldc * sizeof(real_t), dC + c0, ldc * sizeof(real_t),
-                                    (size_t)(c1 - c0) * sizeof(real_t), n, hipMemcpyDeviceToHost, L.down));
-        }
-    }
-    tr.mark("queued");
-    if (uploading) { A.fingerprint_now(); tr.mark("fingerprint"); }  // the cache key of a new operand: hashed while the queues drain
-    MX_HIP(hipStreamSynchronize(L.run));
-    if (uploading) { MX_HIP(hipStreamSynchronize(L.up)); A.publish(); }
-    tr.mark("kernels");
-    // A cold call by row blocks ran one plan per block; the plan of ALL rows, which the next call with this matrix will
-    // want (column blocks), is built now — the compute queue is idle, the downloads are still draining — instead of on
-    // that call's critical path (cfg2: 2 ms, cfg5 whole: 5 ms).
-    // Only while the plan is small beside the block pool: the plan of cfg5 whole is 9 GB on top of 6 GB of CSR, and when
-    // such an entry leaves the cache, what the pool cannot keep is hipFree'd — and scrubbed by the copy engines under
-    // whatever call comes next (a cold call right after it: 341 ms instead of 192).
-    if (uploading && shape != COLS && plans && A.cacheable && direct_down && (double)nnz * 12.0 * 1.55 <= (double)((size_t)2 << 30))
-        (void)ensure_plan("plan for later");
-    if (direct_down) MX_HIP(hipStreamSynchronize(L.down));
-    else {                                                       // registration failed somewhere: staged copy of the whole result
-        mx::prefault_wait();
-        L.drain();
-        if (mx::xfer_d2h(C_host, dC, c_bytes)) return 1;
-    }
-    tr.mark("D2H C");
-    return 0;
-}
-
-// run-time options (mx_set_option / mx_get_option); -1 = not set: the environment variable of the same meaning decides
-static std::atomic<int64_t> g_opt_spmv_planned{-1}, g_opt_spmv_algo{-1};
-static std::atomic<int64_t> g_spmv_planned_calls{0};
-static bool opt_spmv_planned()
-{
-    const int64_t v = g_opt_spmv_planned.load();
-    if (v >= 0) return v != 0;
-    static const bool env = [] { const char *e = getenv("MXGPU_SPMV_PLANNED"); return e && atoi(e) == 1; }();
-    return env;
-}
-// The exports prefer the FLAT kernel from 2^20 entries / 32k rows on: its sums are the reference's loop bit for bit
-// (matmul.cpp:401-416), which is worth more at this level — where a call is bound by PCIe, not by the kernel — than the
-// 20-45 % the lane-group kernel saves on the device between 2^20 and 2^22 entries (there the device-level AUTO takes it).
-// Below 32k rows as well when the caller's row pointers (right here, on the host) show a row of 16k entries or more: one
-// lane group's tail in the lane-group kernel (3e4 x 1e5, 200 per row, four rows of 50,000: 0.237 ms against 0.087).
-static int export_spmv_algo(int algo, int m, int64_t nnz, const int32_t *dj, const double *dx, const int32_t *host_indptr = nullptr)
-{
-    if (algo != MX_SPMV_AUTO || nnz < ((int64_t)1 << 20) || !mx::spmv_flat_ok(m, nnz, dj, dx)) return algo;
-    if (m >= 32768) return MX_SPMV_FLAT;
-    if (host_indptr)
-        for (int r = 0; r < m; r++)
-            if (host_indptr[r + 1] - host_indptr[r] >= 16384) return MX_SPMV_FLAT;
-    return algo;
-}
-static int opt_spmv_algo()
-{
-    const int64_t v = g_opt_spmv_algo.load();
-    if (v >= 0) return (int)v;
-    static const int env = [] { const char *e = getenv("MXGPU_SPMV_ALGO"); return e ? atoi(e) : (int)MX_SPMV_AUTO; }();
-    return env;
-}
-
-template <typename vec_t, typename out_t>
-static int spmv_host(int m, const int32_t *indptr, const int32_t *indices, const double *values, const vec_t *y,
-                     int len_y, int v_dtype, out_t *out)
-{
-    MX_REQUIRE(m >= 0 && len_y >= 0, "negative dimension");
-    if (m == 0) return 0;
-    {   // small call (see SmallStage)
-        const int64_t nnz_s = (int64_t)indptr[m] - indptr[0];
-        const size_t in_bytes = 4 * ((size_t)m + 1) + 12 * (size_t)nnz_s + sizeof(vec_t) * (size_t)len_y, out_bytes = sizeof(out_t) * (size_t)m;
-        SmallStage *S = indptr[0] == 0 && in_bytes + out_bytes <= SMALL_LIMIT ? small_stage() : nullptr;
-        if (S) {
-            const size_t op = S->put(indptr, 4 * ((size_t)m + 1)), oj = S->put(indices, 4 * (size_t)nnz_s), ox = S->put(values, 8 * (size_t)nnz_s);
-            const size_t ov = S->put(y, sizeof(vec_t) * (size_t)len_y), in_end = S->top, oo = S->take(out_bytes), out_end = S->top;
-            if (S->up(in_end)) return 1;
-            if (spmv_launch(m, len_y, nnz_s, S->dev<int32_t>(op), S->dev<int32_t>(oj), S->dev<double>(ox), S->dev<void>(ov), v_dtype,
-                            S->dev<void>(oo), opt_spmv_algo(), S->st)) return S->fail();
-            if (S->down_and_wait(oo, out_end)) return 1;
-            memcpy(out, S->h + oo, out_bytes);
-            g_small_calls++;
-            return 0;
-        }
-    }
-    Csr A;
-    if (A.upload(indptr, indices, values, m, sizeof(double))) return 1;
-    DevBuf v, o;
-    if (v.upload(y, sizeof(vec_t) * (size_t)len_y)) return 1;
-    if (o.alloc(sizeof(out_t) * (size_t)m)) return 1;
-    // OPT-IN (mx_set_option("spmv_planned", 1) or MXGPU_SPMV_PLANNED=1): a matrix that comes back for another product
-    // (cache hit) gets a plan — the planned kernel keeps v's panels in LDS instead of gathering v[j] from L2 (cfg3: 81 vs
-    // 165 us; the build costs about six one-shot products, once).  Not the default because the planned kernel regroups a
-    // row's sum by column panel and adds with LDS atomics: equal to the reference to 1e-12, but not bit for bit and not the
-    // same bits from run to run, and the float32 kind rounds once from an f64 sum where the reference accumulates in
-    // float (matmul.cpp:403) — the same `X %*% v` would return different last bits on its first and on later calls
-    // (ADVICE r2).  The default is the one-shot flat kernel on every call: bit for bit the reference's loop.
-    bool planned = false;
-    if (opt_spmv_planned() && A.cache_hit && A.nnz >= ((int64_t)1 << 20) && len_y <= (1 << 28)) {   // (spmv_plan.hip: LDS panels up to 393,216 columns, L2 super-panels beyond)
-        std::lock_guard<std::mutex> lk(A.hold->plan_mu);
-        if (A.hold->spmv_plan && A.hold->spmv_plan_K != len_y) { mxd_spmv_plan_destroy(A.hold->spmv_plan); A.hold->spmv_plan = nullptr; }
-        if (!A.hold->spmv_plan) {
-            if (mxd_spmv_plan_create(m, len_y, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), nullptr, &A.hold->spmv_plan))
-                A.hold->spmv_plan = nullptr;                              // (no memory for a plan: the one-shot kernel below)
-            A.hold->spmv_plan_K = len_y;
-            if (A.hold->spmv_plan) A.hold->mark_plan_built(nullptr);
-        }
-        if (A.hold->spmv_plan) {
-            A.hold->wait_plan_built(nullptr);
-            if (mxd_spmv_plan_run(A.hold->spmv_plan, v.p, v_dtype, o.p, nullptr)) return 1;
-            planned = true;
-        }
-    }
-    g_spmv_planned_calls += planned ? 1 : 0;
-    if (!planned && spmv_launch(m, len_y, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), v.p, v_dtype, o.p,
-                                export_spmv_algo(opt_spmv_algo(), m, A.nnz, A.j.as<int32_t>(), A.x.as<double>(), indptr), nullptr))
-        return 1;
-    if (mx::xfer_d2h(out, o.p, sizeof(out_t) * (size_t)m)) return 1;
-    return 0;
-}
-
-}  // namespace mx
-
-// variable-size result waiting on the device for the caller's vectors
-struct mx_result {
-    mx::DevBuf indptr, indices, values;
-    mx_result_info info;
-    // a small call's result is already on the host when `begin` returns (one copy down with the sizes): the three arrays,
-    // back to back, owned by the handle (the staging block belongs to the thread and is reused by its next call)
-    std::vector<char> host;
-    size_t host_indices = 0, host_values = 0;
-    bool on_host = false;
-};
-
-using namespace mx;
-
-extern "C" {
-
-const char *mx_last_error(void) { return mx::g_err; }
-int mx_abi_version(void) { return MXGPU_ABI_VERSION; }
-
-int mx_device_count(int *count)
-{
-    MX_REQUIRE(count, "mx_device_count: null pointer");
-    *count = 0;
-    MX_HIP(hipGetDeviceCount(count));
-    return 0;
-}
-int mx_set_device(int device) { MX_HIP(hipSetDevice(device)); return 0; }
-int mx_set_devices(const int *devices, int n)
-{
-    MX_REQUIRE(n >= 0 && (n == 0 || devices), "mx_set_devices: bad arguments");
-    int count = 0;
-    MX_HIP(hipGetDeviceCount(&count));
-    for (int k = 0; k < n; k++) MX_REQUIRE(devices[k] >= 0 && devices[k] < count, "mx_set_devices: no device %d", devices[k]);
-    if (n == 1) MX_HIP(hipSetDevice(devices[0]));                 // one device: it becomes the calling thread's current device
-    {
-        std::lock_guard<std::mutex> lk(g_devices_mu);
-        g_devices.assign(devices, devices + n);
-    }
-    shard_pool().release_memory();                                // the shard workers of the previous list give their buffers back
-    return 0;
-}
-int mx_partition_rows(const int32_t *indptr, int nrows, int nparts, int dense_cols, int dense_bytes, int *cuts)
-{
-    MX_REQUIRE(indptr && cuts && nrows >= 0 && nparts >= 1, "mx_partition_rows: bad arguments");
-    partition_rows(indptr, nrows, nparts, 12.0, (double)dense_cols * dense_bytes, cuts);
-    return 0;
-}
-int mx_device_name(char *buf, size_t buflen)
-{
-    int dev = 0;
-    MX_HIP(hipGetDevice(&dev));
-    hipDeviceProp_t prop;
-    MX_HIP(hipGetDeviceProperties(&prop, dev));
-    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
-    return 0;
-}
-// ---- offload gate: from which operand size on a routine is worth a PCIe round trip (include/mxgpu.h mx_should_offload)
-static std::atomic<int64_t> g_opt_offload_min_len{-2};               // -2 = not set: MXGPU_OFFLOAD_MIN_LEN, else the measured defaults (-1)
-static int64_t opt_offload_min_len()
-{
-    int64_t v = g_opt_offload_min_len.load();
-    if (v == -2) {
-        const char *e = getenv("MXGPU_OFFLOAD_MIN_LEN");
-        v = e && *e ? (int64_t)atoll(e) : -1;
-        if (v < -1) v = -1;
-    }
-    return v;
-}
-static int64_t offload_default_min_len(const char *fn)
-{
-    // measured on an MI355X box against MatrixExtra's algorithm on the host's cores (tools/small_calls.py,
-    // profiles/r04_small_calls.json: host arrays in, host arrays out): one call costs 29-50 us at the reference's own test
-    // sizes (tests/testthat/test-matmul.R:108-114: 100 x 50) whatever it does — 2.8-3.7x the host's 8-17 us — so products
-    // and CSR (+) CSR win from ~5e4 entries on, `X %*% v` (8 bytes of result per row against 12 bytes per entry over PCIe)
-    // from ~1e6, and `X[rows, ]` / cbind / rbind — memcpys on the host — only from ~1e7
-    auto starts = [&](const char *pre) { return strncmp(fn, pre, strlen(pre)) == 0; };
-    if (starts("matmul_csr_dvec_") || starts("matmul_csr_svec_") || starts("matmul_rowvec_by_")) return 1000000;
-    if (starts("copy_csr_") || starts("reverse_") || starts("cbind_") || strcmp(fn, "concat_csr_batch") == 0) return 10000000;
-    return 50000;
-}
-int mx_should_offload(const char *routine, int64_t longest_len)
-{
-    if (!routine) return 1;
-    if (strncmp(routine, "_MatrixExtra_", 13) == 0) routine += 13;
-    const int64_t set = opt_offload_min_len();
-    const int64_t min_len = set >= 0 ? set : offload_default_min_len(routine);
-    return longest_len >= min_len ? 1 : 0;
-}
-int mx_set_option(const char *name, int64_t value)
-{
-    MX_REQUIRE(name, "mx_set_option: null name");
-    if (strcmp(name, "offload_min_len") == 0) {
-        MX_REQUIRE(value >= -1, "mx_set_option: offload_min_len %lld (-1 = the measured defaults, 0 = always offload)", (long long)value);
-        g_opt_offload_min_len = value;
-        return 0;
-    }
-    if (strcmp(name, "spmv_planned") == 0) { g_opt_spmv_planned = value; return 0; }
-    if (strcmp(name, "spmv_algo") == 0) {
-        MX_REQUIRE(value >= -1 && value <= MX_SPMV_FLAT, "mx_set_option: spmv_algo %lld", (long long)value);
-        g_opt_spmv_algo = value;
-        return 0;
-    }
-    return set_error("mx_set_option: unknown option '%s'", name);
-}
-int mx_get_option(const char *name, int64_t *value)
-{
-    MX_REQUIRE(name && value, "mx_get_option: null pointer");
-    if (strcmp(name, "spmv_planned") == 0) { *value = opt_spmv_planned() ? 1 : 0; return 0; }
-    if (strcmp(name, "offload_min_len") == 0) { *value = opt_offload_min_len(); return 0; }
-    if (strcmp(name, "spmv_algo") == 0) { *value = opt_spmv_algo(); return 0; }
-    if (strcmp(name, "spmv_planned_calls") == 0) { *value = g_spmv_planned_calls.load(); return 0; }   // read-only counter
-    if (strcmp(name, "small_calls") == 0) { *value = g_small_calls.load(); return 0; }                  // read-only: calls served by the small path
-    if (strncmp(name, "pool_", 5) == 0) {                                                              // read-only: pool.hip
-        long long idle_b = 0, idle_n = 0, hits = 0, misses = 0;
-        mx::pool_stats(&idle_b, &idle_n, &hits, &misses);
-        if (strcmp(name, "pool_idle_bytes") == 0) { *value = idle_b; return 0; }
-        if (strcmp(name, "pool_idle_blocks") == 0) { *value = idle_n; return 0; }
-        if (strcmp(name, "pool_hits") == 0) { *value = hits; return 0; }
-        if (strcmp(name, "pool_misses") == 0) { *value = misses; return 0; }
-        long long live_b = 0, live_n = 0;
-        mx::pool_live(&live_b, &live_n);
-        if (strcmp(name, "pool_live_bytes") == 0) { *value = live_b; return 0; }
-        if (strcmp(name, "pool_live_blocks") == 0) { *value = live_n; return 0; }
-    }
-    return set_error("mx_get_option: unknown option '%s'", name);
-}
-int mx_last_call_phases(char *buf, size_t buflen)
-{
-    MX_REQUIRE(buf && buflen > 0, "mx_last_call_phases: no buffer");
-    snprintf(buf, buflen, "%s", mx::g_phases);
-    return 0;
-}
-int mx_cache_configure(int64_t max_bytes) { CsrCache::get().configure(max_bytes); return 0; }
-int mx_cache_invalidate(const void *host_ptr) { CsrCache::get().invalidate(host_ptr); return 0; }
-int mx_cache_stats(int64_t *bytes, int *entries, int64_t *hits, int64_t *misses)
-{
-    CsrCache::get().stats(bytes, entries, hits, misses);
-    return 0;
-}
-int mx_dev_malloc(void **dptr, size_t bytes) { MX_HIP(hipMalloc(dptr, bytes ? bytes : 16)); return 0; }
-int mx_dev_free(void *dptr) { MX_HIP(hipFree(dptr)); return 0; }
-int mx_dev_memset(void *dptr, int value, size_t bytes, void *stream)
-{
-    MX_HIP(hipMemsetAsync(dptr, value, bytes, as_stream(stream)));
-    return 0;
-}
-int mx_memcpy_h2d(void *dptr, const void *hptr, size_t bytes, void *stream)
-{
-    MX_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, as_stream(stream)));
-    return 0;
-}
-int mx_memcpy_d2h(void *hptr, const void *dptr, size_t bytes, void *stream)
-{
-    MX_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
-    return 0;
-}
-int mx_stream_sync(void *stream) { MX_HIP(hipStreamSynchronize(as_stream(stream))); return 0; }
-int mx_upload(void *dptr, const void *hptr, size_t bytes) { return mx::xfer_h2d(dptr, hptr, bytes); }
-int mx_download(void *hptr, const void *dptr, size_t bytes) { return mx::xfer_d2h(hptr, dptr, bytes); }
-int mx_host_register(void *hptr, size_t bytes) { MX_HIP(hipHostRegister(hptr, bytes, hipHostRegisterDefault)); return 0; }
-int mx_host_unregister(void *hptr) { MX_HIP(hipHostUnregister(hptr)); return 0; }
-
-// ---- SpMM exports ------------------------------------------------------------------------------
-int mx_tcrossprod_csr_dense_numeric(const int32_t *X_indptr, const int32_t *X_indices, const double *X_values,
-                                    int nrows_X, const double *Y_colmajor, int nrow_Y, int ncol_Y, int nthreads,
-                                    double *out_colmajor)
-{
-    (void)nthreads;
-    // gemm_csr_drm_as_dcm(m = nrow X, n = nrow Y, B = Y, ldb = nrow Y, C, ldc = m)   matmul.cpp:326-332
-    return spmm_host<double>(nrows_X, nrow_Y, ncol_Y, X_indptr, X_indices, X_values, Y_colmajor, (size_t)nrow_Y,
-                             out_colmajor, (size_t)nrows_X, (size_t)nrows_X * (size_t)nrow_Y, true);
-}
-int mx_tcrossprod_csr_dense_float32(const int32_t *X_indptr, const int32_t *X_indices, const double *X_values,
-                                    int nrows_X, const float *Y_colmajor, int nrow_Y, int ncol_Y, int nthreads,
-                                    float *out_colmajor)
-{
-    (void)nthreads;
-    return spmm_host<float>(nrows_X, nrow_Y, ncol_Y, X_indptr, X_indices, X_values, Y_colmajor, (size_t)nrow_Y,
-                            out_colmajor, (size_t)nrows_X, (size_t)nrows_X * (size_t)nrow_Y, true);
-}
-int mx_matmul_dense_csc_numeric(const double *X_colmajor, int nrows_X, int ncols_X, const int32_t *Y_indptr,
-                                const int32_t *Y_indices, const double *Y_values, int ncols_Y, int nthreads,
-                                double *out_colmajor)
-{
-    (void)nthreads;
-    // gemm_csr_drm_as_drm(m = ncol Y, n = nrow X, CSC-as-CSR, B = X, ldb = nrow X, C, ldc = nrow X)  matmul.cpp:201-208
-    return spmm_host<double>(ncols_Y, nrows_X, ncols_X, Y_indptr, Y_indices, Y_values, X_colmajor, (size_t)nrows_X,
-                             out_colmajor, (size_t)nrows_X, (size_t)nrows_X * (size_t)ncols_Y, false);
-}
-int mx_matmul_dense_csc_float32(const float *X_colmajor, int nrows_X, int ncols_X, const int32_t *Y_indptr,
-                                const int32_t *Y_indices, const double *Y_values, int ncols_Y, int nthreads,
-                                float *out_colmajor)
-{
-    (void)nthreads;
-    return spmm_host<float>(ncols_Y, nrows_X, ncols_X, Y_indptr, Y_indices, Y_values, X_colmajor, (size_t)nrows_X,
-                            out_colmajor, (size_t)nrows_X, (size_t)nrows_X * (size_t)ncols_Y, false);
-}
-int mx_tcrossprod_dense_csr_numeric(const double *X_colmajor, int nrows_X, int ncols_X, const int32_t *Y_indptr,
-                                    const int32_t *Y_indices, const double *Y_values, int nrows_Y, int nthreads,
-                                    int ncols_Y, double *out_colmajor)
-{
-    (void)nthreads; (void)ncols_Y;
-    // gemm_csr_drm_as_drm(m = nrow Y, n = nrow X, Y, B = X, ldb = nrow X, C, ldc = nrow X)  matmul.cpp:263-270
-    return spmm_host<double>(nrows_Y, nrows_X, ncols_X, Y_indptr, Y_indices, Y_values, X_colmajor, (size_t)nrows_X,
-                             out_colmajor, (size_t)nrows_X, (size_t)nrows_X * (size_t)nrows_Y, false);
-}
-int mx_tcrossprod_dense_csr_float32(const float *X_colmajor, int nrows_X, int ncols_X, const int32_t *Y_indptr,
-                                    const int32_t *Y_indices, const double *Y_values, int nrows_Y, int nthreads,
-                                    int ncols_Y, float *out_colmajor)
-{
-    (void)nthreads; (void)ncols_Y;
-    return spmm_host<float>(nrows_Y, nrows_X, ncols_X, Y_indptr, Y_indices, Y_values, X_colmajor, (size_t)nrows_X,
-                            out_colmajor, (size_t)nrows_X, (size_t)nrows_X * (size_t)nrows_Y, false);
-}
-
-// ---- SpMV exports ------------------------------------------------------------------------------
-int mx_matmul_csr_dvec_numeric(const int32_t *p, const int32_t *j, const double *x, int nrows_X, const double *y,
-                               int len_y, int nthreads, double *out)
-{
-    (void)nthreads;
-    return spmv_host<double, double>(nrows_X, p, j, x, y, len_y, MX_F64, out);
-}
-int mx_matmul_csr_dvec_integer(const int32_t *p, const int32_t *j, const double *x, int nrows_X, const int32_t *y,
-                               int len_y, int nthreads, double *out)
-{
-    (void)nthreads;
-    return spmv_host<int32_t, double>(nrows_X, p, j, x, y, len_y, MX_I32, out);
-}
-int mx_matmul_csr_dvec_logical(const int32_t *p, const int32_t *j, const double *x, int nrows_X, const int32_t *y,
-                               int len_y, int nthreads, double *out)
-{
-    (void)nthreads;
-    return spmv_host<int32_t, double>(nrows_X, p, j, x, y, len_y, MX_LGL, out);
-}
-int mx_matmul_csr_dvec_float32(const int32_t *p, const int32_t *j, const double *x, int nrows_X, const float *y,
-                               int len_y, int nthreads, float *out)
-{
-    (void)nthreads;
-    return spmv_host<float, float>(nrows_X, p, j, x, y, len_y, MX_F32, out);
-}
-
-// matmul_rowvec_by_csc / _cscbin (matmul.cpp:643-684): float32 row vector x CSC.  Column `col` of the result is
-// sum over the column's entries of values[ix] * rowvec[indices[ix]], accumulated in float — term by term the arithmetic of
-// matmul_csr_dvec's float32 kind (matmul.cpp:403) on the CSC arrays read as the CSR arrays of the transpose.  The pattern
-// kind has no values: every stored entry counts as 1 (float + float is what (float)(double + 1.0 * double) rounds to).
-int mx_matmul_rowvec_by_csc(const float *rowvec, int len, const int32_t *indptr, const int32_t *indices, const double *values,
-                            int ncols_Y, float *out)
-{
-    MX_REQUIRE(ncols_Y >= 0 && indptr && (len == 0 || rowvec), "mx_matmul_rowvec_by_csc: bad arguments");
-    if (values) return spmv_host<float, float>(ncols_Y, indptr, indices, values, rowvec, len, MX_F32, out);
-    std::vector<double> ones((size_t)std::max(indptr[ncols_Y], 1), 1.0);
-    return spmv_host<float, float>(ncols_Y, indptr, indices, ones.data(), rowvec, len, MX_F32, out);
-}
-
-// ---- CSR (+) CSR -------------------------------------------------------------------------------
-int mx_csr_elemwise_begin(int op, int nrows, const int32_t *indptr1, const int32_t *indptr2,
-                          const int32_t *indices1, const int32_t *indices2, const void *values1,
-                          const void *values2, int64_t nnz1, int64_t nnz2, mx_result **res_out,
-                          mx_result_info *info)
-{
-    MX_REQUIRE(res_out && info, "mx_csr_elemwise_begin: null output pointer");
-    MX_REQUIRE(op >= MX_OP_ADD && op <= MX_OP_AND, "mx_csr_elemwise_begin: unknown op %d", op);
-    MX_REQUIRE(nrows >= 0 && nnz1 >= 0 && nnz2 >= 0, "mx_csr_elemwise_begin: negative size");
-    *res_out = nullptr;
-    const bool lgl = op == MX_OP_OR || op == MX_OP_XOR || op == MX_OP_AND;
-    const size_t vb = lgl ? 4 : 8;
-    mx_result *res = new (std::nothrow) mx_result();
-    MX_REQUIRE(res, "out of host memory");
-    res->info.values_dtype = lgl ? MX_LGL : MX_F64;
-    res->info.alias_structure = 0;
-    int rc = 0;
-    // The kernels' lane-group width follows the mean row length; when more than 8 % of the row pairs would not fit it (rows of
-    // uneven length: the row pointers are right here) the launches below take the next width (merge.hip merge_group_widen).
-    struct Widen { bool on = false; ~Widen() { if (on) mx::merge_group_widen(false); } } widen;
-    if (nrows >= 4096 && nnz1 + nnz2 >= (1LL << 20) && indptr1 && indptr2) {
-        const double avg = (double)std::max(nnz1, nnz2) / (double)nrows;
-        const int G = mx::pick_group(avg, 8);
-        if (G < 64) {
-            int64_t over = 0;
-            for (int r = 0; r < nrows; r++) over += (indptr1[r + 1] - indptr1[r] > G) | (indptr2[r + 1] - indptr2[r] > G);
-            if (over * 100 > (int64_t)nrows * 8) { mx::merge_group_widen(true); widen.on = true; }
-        }
-    }
-    do {
-        // identical-structure fast paths: pointer identity, as operators.cpp:104-108 / :343-346 test it
-        if (nnz1 == nnz2 && indptr1 == indptr2 && indices1 == indices2) {
-            if (op == MX_OP_SUB && values1 == values2) {
-                // operators.cpp:348-355: IntegerVector(indptr.size()) zeros, empty indices / values
-                res->info.indptr_len = (int64_t)nrows + 1;
-                res->info.nnz = 0;
-                res->info.values_len = 0;
-                if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
-                if (hipMemset(res->indptr.p, 0, sizeof(int32_t) * ((size_t)nrows + 1)) != hipSuccess) {
-                    rc = set_error("hipMemset failed"); break;
-                }
-                break;
-            }
-            res->info.alias_structure = 1;
-            res->info.indptr_len = (int64_t)nrows + 1;
-            res->info.nnz = nnz1;
-            res->info.values_len = nnz1;
-            DevBuf a, b;
-            if ((rc = a.upload(values1, vb * (size_t)nnz1))) break;
-            if ((rc = b.upload(values2, vb * (size_t)nnz2))) break;
-            if ((rc = res->values.alloc(vb * (size_t)nnz1))) break;
-            if ((rc = mxd_values_elemwise(op, nnz1, a.p, b.p, res->values.p, nullptr))) break;
-            if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-            break;
-        }
-        {   // small call (see SmallStage): count -> scan -> fill into arrays sized for the upper bound of the result, all
-            // three arrays down in one copy, the size read from the result's own index pointer
-            const bool isect_s = op == MX_OP_MUL || op == MX_OP_AND;
-            const int64_t bound_s = isect_s ? (nnz1 < nnz2 ? nnz1 : nnz2) : nnz1 + nnz2;
-            const size_t pb = 4 * ((size_t)nrows + 1);
-            const size_t in_bytes = 2 * pb + (4 + vb) * (size_t)(nnz1 + nnz2), out_bytes = pb + (4 + vb) * (size_t)bound_s;
-            SmallStage *S = nrows > 0 && indptr1[0] == 0 && indptr2[0] == 0 && indptr1[nrows] == nnz1 && indptr2[nrows] == nnz2 &&
-                            in_bytes + out_bytes <= SMALL_LIMIT_MERGE ? small_stage() : nullptr;
-            if (S) {
-                const size_t p1 = S->put(indptr1, pb), j1 = S->put(indices1, 4 * (size_t)nnz1), x1 = S->put(values1, vb * (size_t)nnz1);
-                const size_t p2 = S->put(indptr2, pb), j2 = S->put(indices2, 4 * (size_t)nnz2), x2 = S->put(values2, vb * (size_t)nnz2);
-                const size_t in_end = S->top, po = S->take(pb), jo = S->take(4 * (size_t)bound_s), xo = S->take(vb * (size_t)bound_s), out_end = S->top;
-                const size_t ws = S->take(mxd_merge_workspace_bytes(nrows));
-                if (S->fits()) {
-                    if ((rc = S->up(in_end))) break;
-                    if ((rc = mxd_csr_merge_count(op, nrows, S->dev<int32_t>(p1), S->dev<int32_t>(j1), nnz1, S->dev<int32_t>(p2), S->dev<int32_t>(j2),
-                                                  nnz2, S->dev<int32_t>(po), S->dev<void>(ws), nullptr, S->st))) { S->fail(); break; }
-                    if ((rc = mxd_csr_merge_fill(op, nrows, S->dev<int32_t>(p1), S->dev<int32_t>(j1), S->dev<void>(x1), nnz1, S->dev<int32_t>(p2),
-                                                 S->dev<int32_t>(j2), S->dev<void>(x2), nnz2, S->dev<int32_t>(po), S->dev<int32_t>(jo),
-                                                 S->dev<void>(xo), S->st))) { S->fail(); break; }
-                    if ((rc = S->down_and_wait(po, out_end))) break;
-                    const int64_t nnz_s = ((const int32_t *)(S->h + po))[nrows];
-                    res->host.resize(pb + (4 + vb) * (size_t)nnz_s);
-                    res->host_indices = pb; res->host_values = pb + 4 * (size_t)nnz_s;
-                    memcpy(res->host.data(), S->h + po, pb);
-                    memcpy(res->host.data() + res->host_indices, S->h + jo, 4 * (size_t)nnz_s);
-                    memcpy(res->host.data() + res->host_values, S->h + xo, vb * (size_t)nnz_s);
-                    res->on_host = true;
-                    res->info.indptr_len = (int64_t)nrows + 1;
-                    res->info.nnz = nnz_s;
-                    res->info.values_len = nnz_s;
-                    g_small_calls++;
-                    break;
-                }
-            }
-        }
-        Csr A, B;
-        if ((rc = A.upload(indptr1, indices1, values1, nrows, vb))) break;
-        if ((rc = B.upload(indptr2, indices2, values2, nrows, vb))) break;
-        DevBuf ws;
-        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
-        int64_t nnz_out = 0;
-        const bool isect = op == MX_OP_MUL || op == MX_OP_AND;
-        const int64_t bound = isect ? (A.nnz < B.nnz ? A.nnz : B.nnz) : A.nnz + B.nnz;
-        // MXGPU_MERGE_FUSED=1: the one-pass kernel (arrays sized for the upper bound, like the reference's own scratch,
-        // operators.cpp:402-406, :139-143).  Measured at 2M x 2M / nnz 1e8 it ties count -> scan -> fill (1.6 vs 1.35 ms:
-        // the tile's index re-read does not stay in L2), so the exactly-sized two-pass form is the default.
-        static const bool fused = [] { const char *e = getenv("MXGPU_MERGE_FUSED"); return e && atoi(e) == 1; }();
-        if (fused && bound <= (int64_t)INT_MAX) {
-            if ((rc = ws.alloc(mxd_merge_fused_workspace_bytes(nrows)))) break;
-            if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)bound))) break;
-            if ((rc = res->values.alloc(vb * (size_t)bound))) break;
-            if ((rc = mxd_csr_merge_fused(op, nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, A.nnz, B.p.as<int32_t>(),
-                                          B.j.as<int32_t>(), B.x.p, B.nnz, res->indptr.as<int32_t>(),
-                                          res->indices.as<int32_t>(), res->values.p, ws.p, &nnz_out, nullptr)))
-                break;
-        } else {
-            if ((rc = ws.alloc(mxd_merge_workspace_bytes(nrows)))) break;
-            if ((rc = mxd_csr_merge_count(op, nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.nnz, B.p.as<int32_t>(),
-                                          B.j.as<int32_t>(), B.nnz, res->indptr.as<int32_t>(), ws.p, &nnz_out, nullptr)))
-                break;
-            if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
-            if ((rc = res->values.alloc(vb * (size_t)nnz_out))) break;
-            if ((rc = mxd_csr_merge_fill(op, nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, A.nnz, B.p.as<int32_t>(),
-                                         B.j.as<int32_t>(), B.x.p, B.nnz, res->indptr.as<int32_t>(),
-                                         res->indices.as<int32_t>(), res->values.p, nullptr)))
-                break;
-        }
-        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-        res->info.indptr_len = (int64_t)nrows + 1;
-        res->info.nnz = nnz_out;
-        res->info.values_len = nnz_out;
-    } while (0);
-    if (rc) { delete res; return rc; }
-    *info = res->info;
-    *res_out = res;
-    return 0;
-}
-
-// ---- row gather --------------------------------------------------------------------------------
-int mx_copy_csr_rows_begin(const int32_t *indptr, int nrows, const int32_t *indices, const void *values,
-                           int value_dtype, int64_t n_values, const int32_t *rows_take, int64_t n_take,
-                           mx_result **res_out, mx_result_info *info)
-{
-    MX_REQUIRE(res_out && info, "mx_copy_csr_rows_begin: null output pointer");
-    MX_REQUIRE(nrows >= 0 && n_take >= 0 && n_take <= INT_MAX, "mx_copy_csr_rows_begin: bad size");
-    MX_REQUIRE(value_dtype == MX_F64 || value_dtype == MX_LGL || value_dtype == MX_NONE,
-               "mx_copy_csr_rows_begin: unsupported value dtype %d", value_dtype);
-    *res_out = nullptr;
-    const bool has_values = value_dtype != MX_NONE && n_values > 0;   // slice.cpp:246,257
-    const size_t vb = has_values ? dtype_bytes(value_dtype) : 0;
-    mx_result *res = new (std::nothrow) mx_result();
-    MX_REQUIRE(res, "out of host memory");
-    res->info.values_dtype = value_dtype;
-    res->info.alias_structure = 0;
-    int rc = 0;
-    do {
-        {   // small call (see SmallStage): the one-launch gather into whatever room the block has left; its size arrives
-            // in the pinned word, then exactly the result comes down
-            const int64_t nnz_in = nrows > 0 ? (int64_t)indptr[nrows] - indptr[0] : 0;
-            const size_t pb = 4 * ((size_t)nrows + 1), in_bytes = pb + (4 + vb) * (size_t)nnz_in + 4 * (size_t)n_take, npb = 4 * ((size_t)n_take + 1);
-            SmallStage *S = nrows > 0 && n_take > 0 && indptr[0] == 0 && in_bytes + npb < SMALL_LIMIT ? small_stage() : nullptr;
-            if (S) {
-                const int64_t cap = (int64_t)((SMALL_LIMIT - in_bytes - npb) / (4 + vb)) & ~(int64_t)3;
-                const size_t p0 = S->put(indptr, pb), j0 = S->put(indices, 4 * (size_t)nnz_in), x0 = S->put(values, vb * (size_t)nnz_in);
-                const size_t r0 = S->put(rows_take, 4 * (size_t)n_take), in_end = S->top;
-                const size_t po = S->take(npb), jo = S->take(4 * (size_t)cap), xo = S->take(vb * (size_t)cap);
-                if (S->fits() && cap > 0) {
-                    if ((rc = S->up(in_end))) break;
-                    int64_t nnz_s = 0;
-                    if ((rc = mxd_csr_gather_fused((int)n_take, S->dev<int32_t>(p0), S->dev<int32_t>(j0), vb ? S->dev<void>(x0) : nullptr,
-                                                   S->dev<int32_t>(r0), S->dev<int32_t>(po), S->dev<int32_t>(jo), vb ? S->dev<void>(xo) : nullptr,
-                                                   has_values ? value_dtype : MX_NONE, cap, (double)nnz_in / (double)nrows, nullptr, &nnz_s,
-                                                   S->st))) { S->fail(); break; }
-                    if (nnz_s <= cap) {
-                        if (nnz_s == 0) {            // slice.cpp:236-240: three EMPTY vectors (even the indptr)
-                            if ((rc = S->down_and_wait(0, 0))) break;
-                            res->on_host = true;
-                            res->info.indptr_len = 0; res->info.nnz = 0; res->info.values_len = 0;
-                            g_small_calls++;
-                            break;
-                        }
-                        // three pieces of exactly the result's size, one wait
-                        if (hipMemcpyAsync(S->h + po, S->d + po, npb, hipMemcpyDeviceToHost, S->st) != hipSuccess ||
-                            hipMemcpyAsync(S->h + jo, S->d + jo, 4 * (size_t)nnz_s, hipMemcpyDeviceToHost, S->st) != hipSuccess ||
-                            (vb && hipMemcpyAsync(S->h + xo, S->d + xo, vb * (size_t)nnz_s, hipMemcpyDeviceToHost, S->st) != hipSuccess)) {
-                            rc = set_error("small gather: D2H copy failed"); break;
-                        }
-                        if ((rc = S->down_and_wait(0, 0))) break;
-                        res->host.resize(npb + (4 + vb) * (size_t)nnz_s);
-                        res->host_indices = npb; res->host_values = npb + 4 * (size_t)nnz_s;
-                        memcpy(res->host.data(), S->h + po, npb);
-                        memcpy(res->host.data() + res->host_indices, S->h + jo, 4 * (size_t)nnz_s);
-                        if (vb) memcpy(res->host.data() + res->host_values, S->h + xo, vb * (size_t)nnz_s);
-                        res->on_host = true;
-                        res->info.indptr_len = n_take + 1;
-                        res->info.nnz = nnz_s;
-                        res->info.values_len = has_values ? nnz_s : 0;
-                        if (!has_values) res->info.values_dtype = MX_NONE;
-                        g_small_calls++;
-                        break;
-                    }
-                    if (hipStreamSynchronize(S->st) != hipSuccess) { rc = set_error("stream sync failed"); break; }   // does not fit: the regular path
-                }
-            }
-        }
-        Csr A;
-        if ((rc = A.upload(indptr, indices, values, nrows, vb))) break;
-        DevBuf rows;
-        if ((rc = rows.upload(rows_take, sizeof(int32_t) * (size_t)n_take))) break;
-        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)n_take + 1)))) break;
-        // ONE launch into arrays sized for 1.25x the expected result (n_take mean row lengths); a selection that does not fit
-        // (very uneven rows) is copied again into exactly sized arrays — new_indptr is exact either way
-        const double avg = nrows > 0 ? (double)A.nnz / (double)nrows : 0.0;
-        const int64_t cap = std::min<int64_t>((int64_t)(1.25 * avg * (double)n_take) + 1024, (int64_t)INT_MAX);
-        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)cap))) break;
-        if (has_values && (rc = res->values.alloc(vb * (size_t)cap))) break;
-        int64_t nnz_out = 0;
-        if ((rc = mxd_csr_gather_fused((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, rows.as<int32_t>(),
-                                       res->indptr.as<int32_t>(), res->indices.as<int32_t>(), res->values.p,
-                                       has_values ? value_dtype : MX_NONE, cap, avg, nullptr, &nnz_out, nullptr)))
-            break;
-        if (nnz_out == 0) {          // slice.cpp:236-240: three EMPTY vectors (even the indptr)
-            if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-            res->info.indptr_len = 0;
-            res->info.nnz = 0;
-            res->info.values_len = 0;
-            break;
-        }
-        if (nnz_out > cap) {
-            if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-            mx::pool_free(res->indices.p); res->indices.p = nullptr;
-            if (res->values.p) { mx::pool_free(res->values.p); res->values.p = nullptr; }
-            if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
-            if (has_values && (rc = res->values.alloc(vb * (size_t)nnz_out))) break;
-            if ((rc = mxd_csr_gather_fill((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, rows.as<int32_t>(),
-                                          res->indptr.as<int32_t>(), res->indices.as<int32_t>(), res->values.p,
-                                          has_values ? value_dtype : MX_NONE, nnz_out, nullptr)))
-                break;
-        }
-        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-        res->info.indptr_len = n_take + 1;
-        res->info.nnz = nnz_out;
-        res->info.values_len = has_values ? nnz_out : 0;
-        if (!has_values) res->info.values_dtype = MX_NONE;
-    } while (0);
-    if (rc) { delete res; return rc; }
-    *info = res->info;
-    *res_out = res;
-    return 0;
-}
-
-// ---- column-filtering slices (§8f rank 2) ----------------------------------------------------------------
-int mx_copy_csr_rows_col_seq_begin(const int32_t *indptr, int nrows, const int32_t *indices, const void *values,
-                                   int value_dtype, int64_t n_values, const int32_t *rows_take, int64_t n_take,
-                                   const int32_t *cols_take, int64_t n_cols_take, int index1,
-                                   mx_result **res_out, mx_result_info *info)
-{
-    MX_REQUIRE(res_out && info, "mx_copy_csr_rows_col_seq_begin: null output pointer");
-    MX_REQUIRE(nrows >= 0 && n_take >= 0 && n_take <= INT_MAX && n_cols_take > 0, "mx_copy_csr_rows_col_seq_begin: bad size");
-    MX_REQUIRE(value_dtype == MX_F64 || value_dtype == MX_LGL || value_dtype == MX_NONE,
-               "mx_copy_csr_rows_col_seq_begin: unsupported value dtype %d", value_dtype);
-    *res_out = nullptr;
-    int min_col = cols_take[0], max_col = cols_take[0];                      // slice.cpp:337-338
-    for (int64_t c = 1; c < n_cols_take; c++) { if (cols_take[c] < min_col) min_col = cols_take[c]; if (cols_take[c] > max_col) max_col = cols_take[c]; }
-    min_col -= index1 ? 1 : 0; max_col -= index1 ? 1 : 0;
-    const bool has_values = value_dtype != MX_NONE && n_values > 0;
-    mx_result *res = new (std::nothrow) mx_result();
-    MX_REQUIRE(res, "out of host memory");
-    res->info.values_dtype = MX_F64;                                         // always a NumericVector (slice.cpp:363)
-    res->info.alias_structure = 0;
-    int rc = 0;
-    do {
-        Csr A;
-        if ((rc = A.upload(indptr, indices, values, nrows, has_values ? dtype_bytes(value_dtype) : 0))) break;
-        DevBuf rows, ws;
-        if ((rc = rows.upload(rows_take, sizeof(int32_t) * (size_t)n_take))) break;
-        if ((rc = ws.alloc(mxd_gather_workspace_bytes((int)n_take)))) break;
-        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)n_take + 1)))) break;
-        const double avg = nrows > 0 ? (double)A.nnz / nrows : 0.0;
-        int64_t nnz_out = 0;
-        if ((rc = mxd_csr_colrange_count((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), rows.as<int32_t>(), min_col,
-                                         max_col, avg, res->indptr.as<int32_t>(), ws.p, &nnz_out, nullptr))) break;
-        res->info.indptr_len = n_take + 1;
-        res->info.nnz = nnz_out;
-        res->info.values_len = has_values ? nnz_out : 0;
-        if (nnz_out == 0) { res->info.values_len = 0; break; }                 // slice.cpp:355-359
-        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
-        if (has_values && (rc = res->values.alloc(sizeof(double) * (size_t)nnz_out))) break;
-        if ((rc = mxd_csr_colrange_fill((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p,
-                                        has_values ? value_dtype : MX_NONE, rows.as<int32_t>(), min_col, max_col, avg,
-                                        res->indptr.as<int32_t>(), res->indices.as<int32_t>(), res->values.as<double>(),
-                                        nullptr))) break;
-        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-    } while (0);
-    if (rc) { delete res; return rc; }
-    *info = res->info;
-    *res_out = res;
-    return 0;
-}
-
-int mx_copy_csr_arbitrary_begin(const int32_t *indptr, int nrows, const int32_t *indices, const void *values,
-                                int value_dtype, int64_t n_values, const int32_t *rows_take, int64_t n_take,
-                                const int32_t *cols_take, int64_t n_cols_take, mx_result **res_out,
-                                mx_result_info *info)
-{
-    MX_REQUIRE(res_out && info, "mx_copy_csr_arbitrary_begin: null output pointer");
-    MX_REQUIRE(nrows >= 0 && n_take >= 0 && n_take <= INT_MAX && n_cols_take >= 0 && n_cols_take <= INT_MAX,
-               "mx_copy_csr_arbitrary_begin: bad size");
-    MX_REQUIRE(value_dtype == MX_F64 || value_dtype == MX_LGL || value_dtype == MX_NONE,
-               "mx_copy_csr_arbitrary_begin: unsupported value dtype %d", value_dtype);
-    *res_out = nullptr;
-    const bool has_values = value_dtype != MX_NONE && n_values > 0;           // `if (values.size())`, slice.cpp:565
-    const size_t vb = has_values ? dtype_bytes(value_dtype) : 0;
-    int max_j = -1;
-    bool cols_sorted = true;                                                  // slice.cpp:487-493
-    for (int64_t c = 0; c < n_cols_take; c++) {
-        MX_REQUIRE(cols_take[c] >= 0, "mx_copy_csr_arbitrary_begin: negative column index");
-        if (cols_take[c] > max_j) max_j = cols_take[c];
-        if (c && cols_take[c] < cols_take[c - 1]) cols_sorted = false;
-    }
-    const int ncol_map = max_j + 1;
-    mx_result *res = new (std::nothrow) mx_result();
-    MX_REQUIRE(res, "out of host memory");
-    res->info.values_dtype = has_values ? value_dtype : MX_NONE;
-    res->info.alias_structure = 0;
-    int rc = 0;
-    do {
-        Csr A;
-        if ((rc = A.upload(indptr, indices, values, nrows, vb))) break;
-        DevBuf rows, cols, start, pos, ws, mws;
-        if ((rc = rows.upload(rows_take, sizeof(int32_t) * (size_t)n_take))) break;
-        if ((rc = cols.upload(cols_take, sizeof(int32_t) * (size_t)n_cols_take))) break;
-        if ((rc = start.alloc(sizeof(int32_t) * ((size_t)ncol_map + 1)))) break;
-        if ((rc = pos.alloc(sizeof(int32_t) * (size_t)n_cols_take))) break;
-        if ((rc = mws.alloc(mxd_colmap_workspace_bytes(ncol_map)))) break;
-        if ((rc = ws.alloc(mxd_gather_workspace_bytes((int)n_take)))) break;
-        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)n_take + 1)))) break;
-        if ((rc = mxd_colmap_build(cols.as<int32_t>(), n_cols_take, ncol_map, start.as<int32_t>(), pos.as<int32_t>(),
-                                   mws.p, nullptr))) break;
-        const double avg = nrows > 0 ? (double)A.nnz / nrows : 0.0;
-        int64_t nnz_out = 0;
-        if ((rc = mxd_csr_colmap_count((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), rows.as<int32_t>(), ncol_map,
-                                       start.as<int32_t>(), avg, res->indptr.as<int32_t>(), ws.p, &nnz_out, nullptr))) break;
-        res->info.indptr_len = n_take + 1;
-        res->info.nnz = nnz_out;
-        res->info.values_len = has_values ? nnz_out : 0;
-        if (nnz_out == 0) break;
-        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
-        if (has_values && (rc = res->values.alloc(vb * (size_t)nnz_out))) break;
-        if ((rc = mxd_csr_colmap_fill((int)n_take, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p,
-                                      has_values ? value_dtype : MX_NONE, rows.as<int32_t>(), ncol_map,
-                                      start.as<int32_t>(), pos.as<int32_t>(), avg, res->indptr.as<int32_t>(),
-                                      res->indices.as<int32_t>(), res->values.p, nullptr))) break;
-        if (!cols_sorted) {                                                   // slice.cpp:540-560
-            DevBuf tj, tx;
-            if ((rc = tj.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
-            if (has_values && (rc = tx.alloc(vb * (size_t)nnz_out))) break;
-            if ((rc = mxd_csr_sort_rows((int)n_take, nnz_out, res->indptr.as<int32_t>(), res->indices.as<int32_t>(),
-                                        res->values.p, has_values ? value_dtype : MX_NONE, tj.as<int32_t>(), tx.p, nullptr))) break;
-            if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-        }
-        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-    } while (0);
-    if (rc) { delete res; return rc; }
-    *info = res->info;
-    *res_out = res;
-    return 0;
-}
-
-int mx_reverse_rows_begin(const int32_t *indptr, int nrows, const int32_t *indices, const void *values,
-                          int value_dtype, int64_t n_values, mx_result **res_out, mx_result_info *info)
-{
-    MX_REQUIRE(res_out && info, "mx_reverse_rows_begin: null output pointer");
-    MX_REQUIRE(nrows >= 0, "mx_reverse_rows_begin: negative size");
-    *res_out = nullptr;
-    const bool has_values = value_dtype != MX_NONE && n_values > 0;           // slice.cpp:66
-    const size_t vb = has_values ? dtype_bytes(value_dtype) : 0;
-    mx_result *res = new (std::nothrow) mx_result();
-    MX_REQUIRE(res, "out of host memory");
-    res->info.values_dtype = has_values ? value_dtype : MX_NONE;
-    res->info.alias_structure = 0;
-    int rc = 0;
-    do {
-        Csr A;
-        if ((rc = A.upload(indptr, indices, values, nrows, vb))) break;
-        DevBuf rows, ws;
-        if ((rc = rows.alloc(sizeof(int32_t) * (size_t)nrows))) break;
-        if ((rc = ws.alloc(mxd_gather_workspace_bytes(nrows)))) break;
-        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
-        if ((rc = mxd_reversed_iota(nrows, rows.as<int32_t>(), nullptr))) break;
-        int64_t nnz_out = 0;
-        if ((rc = mxd_csr_gather_count(nrows, A.p.as<int32_t>(), rows.as<int32_t>(), res->indptr.as<int32_t>(), ws.p,
-                                       &nnz_out, nullptr))) break;
-        res->info.indptr_len = (int64_t)nrows + 1;                            // always full length (slice.cpp:57)
-        res->info.nnz = nnz_out;
-        res->info.values_len = has_values ? nnz_out : 0;
-        if (nnz_out == 0) break;
-        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
-        if (has_values && (rc = res->values.alloc(vb * (size_t)nnz_out))) break;
-        if ((rc = mxd_csr_gather_fill(nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, rows.as<int32_t>(),
-                                      res->indptr.as<int32_t>(), res->indices.as<int32_t>(), res->values.p,
-                                      has_values ? value_dtype : MX_NONE, nnz_out, nullptr))) break;
-        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-    } while (0);
-    if (rc) { delete res; return rc; }
-    *info = res->info;
-    *res_out = res;
-    return 0;
-}
-
-int mx_reverse_columns_inplace(const int32_t *indptr, int nrows, int32_t *indices, void *values, int value_dtype,
-                               int64_t n_values, int ncol)
-{
-    if (nrows <= 0) return 0;
-    const bool has_values = value_dtype != MX_NONE && n_values > 0 && values;
-    const size_t vb = has_values ? dtype_bytes(value_dtype) : 0;
-    Csr A;
-    if (A.upload_private(indptr, indices, values, nrows, vb)) return 1;
-    if (A.nnz == 0) return 0;
-    CsrCache::get().invalidate(indices);                          // the host arrays are about to change under any cached copy
-    if (vb) CsrCache::get().invalidate(values);
-    if (mxd_csr_reverse_columns(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p,
-                                has_values ? value_dtype : MX_NONE, ncol, nullptr)) return 1;
-    if (mx::xfer_d2h(indices, A.j.p, sizeof(int32_t) * (size_t)A.nnz)) return 1;
-    if (vb && mx::xfer_d2h(values, A.x.p, vb * (size_t)A.nnz)) return 1;
-    return 0;
-}
-
-// ---- CSR x sparse vector, CSR (.) dense (§8f rank 4) ---------------------------------------------------------
-int mx_matmul_csr_svec(const int32_t *Xp, const int32_t *Xj, const double *Xx, int nrows, const int32_t *yi, int64_t ny,
-                       const void *yv, int kind, int nthreads, double *out)
-{
-    (void)nthreads;
-    MX_REQUIRE(nrows >= 0 && ny >= 0 && ny <= INT_MAX && kind >= 0 && kind <= 4, "mx_matmul_csr_svec: bad arguments");
-    if (nrows == 0) return 0;
-    if (ny == 0) { memset(out, 0, sizeof(double) * (size_t)nrows); return 0; }
-    Csr A;
-    if (A.upload(Xp, Xj, Xx, nrows, sizeof(double))) return 1;
-    DevBuf di, dv, o;
-    if (di.upload(yi, sizeof(int32_t) * (size_t)ny)) return 1;
-    const size_t vb = kind == 0 ? 8 : kind == 3 ? 0 : 4;
-    if (vb && dv.upload(yv, vb * (size_t)ny)) return 1;
-    if (o.alloc(sizeof(double) * (size_t)nrows)) return 1;
-    if (mxd_spmv_csr_svec(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(), di.as<int32_t>(), (int)ny,
-                          vb ? dv.p : nullptr, kind, o.as<double>(), nullptr)) return 1;
-    if (mx::xfer_d2h(out, o.p, sizeof(double) * (size_t)nrows)) return 1;
-    return 0;
-}
-
-int mx_multiply_csr_by_dense_elemwise(const int32_t *indptr, const int32_t *indices, const void *values, int nrows,
-                                      const void *dense_mat, int64_t ncols, int kind, void *values_out)
-{
-    MX_REQUIRE(nrows >= 0 && ncols >= 0 && kind >= 0 && kind <= 4, "mx_multiply_csr_by_dense_elemwise: bad arguments");
-    if (nrows == 0) return 0;
-    const size_t vb = kind == 4 ? 4 : 8, db = kind == 0 ? 8 : 4;
-    Csr A;
-    if (A.upload(indptr, indices, values, nrows, vb)) return 1;
-    if (A.nnz == 0) return 0;
-    DevBuf D, o;
-    if (D.upload(dense_mat, db * (size_t)nrows * (size_t)ncols)) return 1;
-    if (o.alloc(vb * (size_t)A.nnz)) return 1;
-    if (mxd_csr_by_dense_elemwise(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, D.p, kind, o.p, nullptr)) return 1;
-    if (mx::xfer_d2h(values_out, o.p, vb * (size_t)A.nnz)) return 1;
-    return 0;
-}
-
-// ---- CSR (op) dense vector (§8f rank 4) ----------------------------------------------------------------------
-static int csr_by_dvec_export(const int32_t *indptr, const int32_t *indices, const void *values, int nrows,
-                              const void *dvec, int64_t dvec_len, int ncols, int op, int lhs, void *values_out)
-{
-    MX_REQUIRE(nrows >= 0 && ncols >= 0 && dvec_len >= 0, "csr (op) vector: negative size");
-    if (nrows == 0) return 0;
-    const size_t eb = op == MX_DV_LOGICAL_AND ? 4 : 8;
-    Csr A;
-    if (A.upload(indptr, indices, values, nrows, eb)) return 1;
-    if (A.nnz == 0) return 0;
-    MX_REQUIRE(dvec_len > 0, "csr (op) vector: empty vector");
-    DevBuf D, o;
-    if (D.upload(dvec, eb * (size_t)dvec_len)) return 1;
-    if (o.alloc(eb * (size_t)A.nnz)) return 1;
-    if (mxd_csr_by_dvec(nrows, ncols, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, D.p, dvec_len, op, lhs, o.p, nullptr))
-        return 1;
-    if (mx::xfer_d2h(values_out, o.p, eb * (size_t)A.nnz)) return 1;
-    return 0;
-}
-
-int mx_multiply_csr_by_dvec_no_NAs_numeric(const int32_t *indptr, const int32_t *indices, const double *values,
-                                           int nrows, const double *dvec, int64_t dvec_len, int ncols, int multiply,
-                                           int powerto, int divide, int divrest, int intdiv, int X_is_LHS,
-                                           double *values_out)
-{
-    // same precedence as the reference's if/else chain (operators.cpp:1620-1632)
-    int op;
-    if (multiply) op = MX_DV_MULTIPLY;
-    else if (powerto) op = MX_DV_POWERTO;
-    else if (divide) op = MX_DV_DIVIDE;
-    else if (divrest) op = MX_DV_DIVREST;
-    else if (intdiv) op = MX_DV_INTDIV;
-    else return set_error("Internal error. Please file an issue in GitHub.");        // throw_internal_err()
-    return csr_by_dvec_export(indptr, indices, values, nrows, dvec, dvec_len, ncols, op, X_is_LHS, values_out);
-}
-
-int mx_multiply_csr_by_dvec_with_NAs_begin(const int32_t *indptr, const int32_t *indices, const double *values, int nrows,
-                                           const double *dvec, int64_t dvec_len, int ncols, int multiply, int powerto,
-                                           int divide, int divrest, int intdiv, int X_is_LHS, mx_result **res_out,
-                                           mx_result_info *info)
-{
-    MX_REQUIRE(res_out && info, "mx_multiply_csr_by_dvec_with_NAs_begin: null output pointer");
-    MX_REQUIRE(nrows >= 0 && ncols >= 0 && dvec_len > 0 && indptr && dvec, "mx_multiply_csr_by_dvec_with_NAs_begin: bad arguments");
-    *res_out = nullptr;
-    // operators.cpp:2274-2289: ^ / %% need the matrix on the left; the flags' precedence
-    if ((powerto || divide || divrest) && !X_is_LHS) return set_error("Internal error. Please file an issue in GitHub.");
-    // %/% with the vector on the left: the reference's unchanged-structure exit would compute `dvec %/% x`
-    // (operators.cpp:2639-2649 -> multiply_csr_by_dvec_no_NAs(..., X_is_LHS)) while the structure-changing exits ignore the
-    // flag; the R side never asks for it (R/operators.R:973 always passes TRUE here).  Refused rather than answered two ways
-    // (ADVICE r3).
-    if (intdiv && !multiply && !X_is_LHS)
-        return set_error("multiply_csr_by_dvec_with_NAs: %%/%% with the vector on the left-hand side is not supported");
-    int op;
-    if (multiply) op = MX_DV_MULTIPLY;
-    else if (powerto) op = MX_DV_POWERTO;
-    else if (divide) op = MX_DV_DIVIDE;
-    else if (divrest) op = MX_DV_DIVREST;
-    else if (intdiv) op = MX_DV_INTDIV;
-    else return set_error("Internal error. Please file an issue in GitHub.");
-    mx_result *res = new (std::nothrow) mx_result();
-    MX_REQUIRE(res, "out of host memory");
-    res->info.values_dtype = MX_F64;
-    int rc = 0;
-    do {
-        Csr A;
-        if ((rc = A.upload(indptr, indices, values, nrows, sizeof(double)))) break;
-        DevBuf dv;
-        if ((rc = dv.upload(dvec, sizeof(double) * (size_t)dvec_len))) break;
-        int32_t *op_ = nullptr, *oj = nullptr;
-        double *ox = nullptr;
-        int64_t nnz_out = 0;
-        int unchanged = 0;
-        if ((rc = mxd_csr_by_dvec_with_NAs(nrows, ncols, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.as<double>(),
-                                           dv.as<double>(), dvec_len, op, &op_, &oj, &ox, &nnz_out, &unchanged, nullptr)))
-            break;
-        // the result arrays were allocated by the device-level call: the handle owns them from here
-        res->indptr.p = op_; res->indptr.bytes = sizeof(int32_t) * ((size_t)nrows + 1);
-        res->indices.p = oj; res->indices.bytes = sizeof(int32_t) * (size_t)nnz_out;
-        res->values.p = ox;  res->values.bytes = sizeof(double) * (size_t)nnz_out;
-        res->info.alias_structure = unchanged;
-        res->info.indptr_len = (int64_t)nrows + 1;
-        res->info.nnz = nnz_out;
-        res->info.values_len = nnz_out;
-    } while (0);
-    if (rc) { delete res; return rc; }
-    *info = res->info;
-    *res_out = res;
-    return 0;
-}
-
-int mx_logicaland_csr_by_dvec_internal(const int32_t *indptr, const int32_t *indices, const int32_t *values,
-                                       int nrows, const int32_t *dvec, int64_t dvec_len, int ncols,
-                                       int32_t *values_out)
-{
-    return csr_by_dvec_export(indptr, indices, values, nrows, dvec, dvec_len, ncols, MX_DV_LOGICAL_AND, 1, values_out);
-}
-
-// ---- cbind / rbind (§8f rank 3) ----------------------------------------------------------------------------
-int mx_cbind_csr_begin(const int32_t *Xp, int nX, const int32_t *Xj, const void *Xx, int64_t nvX, const int32_t *Yp,
-                       int nY, const int32_t *Yj, const void *Yx, int64_t nvY, int value_dtype, mx_result **res_out,
-                       mx_result_info *info)
-{
-    MX_REQUIRE(res_out && info && nX >= 0 && nY >= 0, "mx_cbind_csr_begin: bad arguments");
-    *res_out = nullptr;
-    const bool has_values = value_dtype != MX_NONE && (nvX > 0 || nvY > 0);           // cbind.cpp:19-20
-    const size_t vb = has_values ? dtype_bytes(value_dtype) : 0;
-    mx_result *res = new (std::nothrow) mx_result();
-    MX_REQUIRE(res, "out of host memory");
-    res->info.values_dtype = value_dtype == MX_NONE ? MX_F64 : value_dtype;           // binary: empty NumericVector
-    res->info.alias_structure = 0;
-    int rc = 0;
-    do {
-        Csr X, Y;
-        if ((rc = X.upload(Xp, Xj, Xx, nX, vb))) break;
-        if ((rc = Y.upload(Yp, Yj, Yx, nY, vb))) break;
-        const int nrows = nX > nY ? nX : nY;
-        const int64_t nnz = X.nnz + Y.nnz;
-        if (nnz > INT_MAX) { rc = set_error("cbind result exceeds R's int32 index range"); break; }
-        res->info.indptr_len = (int64_t)nrows + 1;
-        res->info.nnz = nnz;
-        res->info.values_len = has_values ? nnz : 0;
-        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
-        if (nnz == 0) {                                                               // cbind.cpp:22-29: zeros
-            if (hipMemset(res->indptr.p, 0, sizeof(int32_t) * ((size_t)nrows + 1)) != hipSuccess) rc = set_error("hipMemset failed");
-            break;
-        }
-        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz))) break;
-        if (has_values && (rc = res->values.alloc(vb * (size_t)nnz))) break;
-        if ((rc = mxd_csr_cbind(nX, nY, X.p.as<int32_t>(), X.j.as<int32_t>(), X.x.p, Y.p.as<int32_t>(), Y.j.as<int32_t>(),
-                                Y.x.p, has_values ? value_dtype : MX_NONE, nnz, res->indptr.as<int32_t>(),
-                                res->indices.as<int32_t>(), res->values.p, nullptr))) break;
-        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-    } while (0);
-    if (rc) { delete res; return rc; }
-    *info = res->info;
-    *res_out = res;
-    return 0;
-}
-
-int mx_concat_csr_batch_begin(const mx_rbind_input *objs, int n_inputs, int out_kind, mx_result **res_out,
-                              mx_result_info *info)
-{
-    MX_REQUIRE(res_out && info && n_inputs >= 0 && out_kind >= 0 && out_kind <= 2, "mx_concat_csr_batch_begin: bad arguments");
-    *res_out = nullptr;
-    int64_t nrows = 0, nnz = 0;
-    for (int k = 0; k < n_inputs; k++) {
-        MX_REQUIRE(objs[k].kind >= 0 && objs[k].kind <= 6, "Invalid vector type in argument %d.", k);   // rbind.cpp:131-135
-        nrows += objs[k].kind <= 2 ? objs[k].nrows : 1;
-        nnz += objs[k].nnz;
-    }
-    MX_REQUIRE(nrows <= INT_MAX - 1 && nnz <= INT_MAX, "rbind result exceeds R's int32 index range");
-    const size_t vb = out_kind == 0 ? 8 : out_kind == 1 ? 4 : 0;
-    mx_result *res = new (std::nothrow) mx_result();
-    MX_REQUIRE(res, "out of host memory");
-    res->info.values_dtype = out_kind == 0 ? MX_F64 : out_kind == 1 ? MX_LGL : MX_NONE;
-    res->info.alias_structure = 0;
-    res->info.indptr_len = nrows + 1;
-    res->info.nnz = nnz;
-    res->info.values_len = vb ? nnz : 0;
-    int rc = 0;
-    do {
-        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
-        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz))) break;
-        if (vb && (rc = res->values.alloc(vb * (size_t)nnz))) break;
-        if (hipMemset(res->indptr.p, 0, sizeof(int32_t)) != hipSuccess) { rc = set_error("hipMemset failed"); break; }
-        int row = 0;
-        int64_t pos = 0;
-        for (int k = 0; k < n_inputs && !rc; k++) {
-            const mx_rbind_input &o = objs[k];
-            const bool vec = o.kind >= 3;
-            const size_t ivb = (o.kind == 0 || o.kind == 3) ? 8 : (o.kind == 2 || o.kind == 6) ? 0 : 4;
-            DevBuf p, j, x;
-            if (!vec && (rc = p.upload(o.indptr, sizeof(int32_t) * ((size_t)o.nrows + 1)))) break;
-            if ((rc = j.upload(o.indices, sizeof(int32_t) * (size_t)o.nnz))) break;
-            if (ivb && (rc = x.upload(o.values, ivb * (size_t)o.nnz))) break;
-            if ((rc = mxd_csr_rbind_append(o.kind, p.as<int32_t>(), j.as<int32_t>(), ivb ? x.p : nullptr, vec ? 1 : o.nrows,
-                                           o.nnz, out_kind, row, pos, res->indptr.as<int32_t>(), res->indices.as<int32_t>(),
-                                           res->values.p, nullptr))) break;
-            if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-            row += vec ? 1 : o.nrows;
-            pos += o.nnz;
-        }
-    } while (0);
-    if (rc) { delete res; return rc; }
-    *info = res->info;
-    *res_out = res;
-    return 0;
-}
-
-int mx_remove_zero_valued_csr_begin(const int32_t *indptr, const int32_t *indices, const void *values, int value_dtype,
-                                    int nrows, int remove_NAs, mx_result **res_out, mx_result_info *info)
-{
-    MX_REQUIRE(res_out && info, "mx_remove_zero_valued_csr_begin: null output pointer");
-    MX_REQUIRE(nrows >= 0 && indptr, "mx_remove_zero_valued_csr_begin: bad arguments");
-    MX_REQUIRE(value_dtype == MX_F64 || value_dtype == MX_LGL, "mx_remove_zero_valued_csr_begin: values must be f64 or R logical");
-    *res_out = nullptr;
-    mx_result *res = new (std::nothrow) mx_result();
-    MX_REQUIRE(res, "out of host memory");
-    res->info.values_dtype = value_dtype;
-    const size_t vb = dtype_bytes(value_dtype);
-    int rc = 0;
-    do {
-        Csr A;
-        if ((rc = A.upload(indptr, indices, values, nrows, vb))) break;
-        DevBuf ws;
-        if ((rc = ws.alloc(mxd_csr_drop_workspace_bytes(nrows)))) break;
-        if ((rc = res->indptr.alloc(sizeof(int32_t) * ((size_t)nrows + 1)))) break;
-        int64_t nnz_out = 0;
-        int dirty = 0;
-        if ((rc = mxd_csr_drop_count(nrows, A.nnz, A.p.as<int32_t>(), A.x.p, value_dtype, remove_NAs, res->indptr.as<int32_t>(),
-                                     ws.p, &nnz_out, &dirty, nullptr)))
-            break;
-        res->info.indptr_len = (int64_t)nrows + 1;
-        if (!dirty) {                                                // misc.cpp:586-590: the input vectors themselves
-            res->info.alias_structure = 2;
-            res->info.nnz = A.nnz;
-            res->info.values_len = A.nnz;
-            break;
-        }
-        res->info.nnz = nnz_out;
-        res->info.values_len = nnz_out;
-        if ((rc = res->indices.alloc(sizeof(int32_t) * (size_t)nnz_out))) break;
-        if ((rc = res->values.alloc(vb * (size_t)nnz_out))) break;
-        if ((rc = mxd_csr_drop_fill(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), A.x.p, value_dtype, remove_NAs,
-                                    res->indptr.as<int32_t>(), res->indices.as<int32_t>(), res->values.p, nullptr)))
-            break;
-        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = set_error("stream sync failed"); break; }
-    } while (0);
-    if (rc) { delete res; return rc; }
-    *info = res->info;
-    *res_out = res;
-    return 0;
-}
-
-int mx_check_valid_csr_matrix(const int32_t *indptr, const int32_t *indices, int64_t n_indices, int nrows, int ncols,
-                              int *code, const char **message)
-{
-    MX_REQUIRE(code && indptr && nrows >= 0 && n_indices >= 0, "mx_check_valid_csr_matrix: bad arguments");
-    // (not through the CSR cache: an invalid index pointer is exactly what this routine is asked about)
-    DevBuf p, j, flags;
-    if (p.upload(indptr, sizeof(int32_t) * ((size_t)nrows + 1))) return 1;
-    if (j.upload(indices, sizeof(int32_t) * (size_t)n_indices)) return 1;
-    if (flags.alloc(16)) return 1;
-    if (mxd_csr_check_valid(nrows, ncols, n_indices, p.as<int32_t>(), j.as<int32_t>(), flags.as<int>(), code, nullptr)) return 1;
-    if (message) {
-        switch (*code) {
-            case 1: *message = "Matrix has negative indices."; break;
-            case 2: *message = "Matrix has invalid column indices."; break;
-            case 4: *message = "Matrix has missing values in the index pointer."; break;
-            case 5: *message = "Matrix index pointer is not monotonicaly increasing."; break;
-            default: *message = ""; break;
-        }
-    }
-    return 0;
-}
-
-int mx_result_finish(mx_result *res, int32_t *out_indptr, int32_t *out_indices, void *out_values)
-{
-    MX_REQUIRE(res, "mx_result_finish: null handle");
-    int rc = 0;
-    if (res->on_host) {                                           // a small call: plain copies out of the handle
-        const mx_result_info &inf = res->info;
-        const size_t vbh = dtype_bytes(inf.values_dtype);
-        if (inf.indptr_len > 0 && out_indptr) memcpy(out_indptr, res->host.data(), sizeof(int32_t) * (size_t)inf.indptr_len);
-        if (inf.nnz > 0 && out_indices) memcpy(out_indices, res->host.data() + res->host_indices, sizeof(int32_t) * (size_t)inf.nnz);
-        if (vbh && inf.values_len > 0 && out_values) memcpy(out_values, res->host.data() + res->host_values, vbh * (size_t)inf.values_len);
-        delete res;
-        return 0;
-    }
-    do {
-        const mx_result_info &inf = res->info;
-        if (!inf.alias_structure) {
-            if (inf.indptr_len > 0 && out_indptr &&
-                mx::xfer_d2h(out_indptr, res->indptr.p, sizeof(int32_t) * (size_t)inf.indptr_len) != 0) {
-                rc = set_error("D2H copy of indptr failed"); break;
-            }
-            if (inf.nnz > 0 && out_indices &&
-                mx::xfer_d2h(out_indices, res->indices.p, sizeof(int32_t) * (size_t)inf.nnz) != 0) {
-                rc = set_error("D2H copy of indices failed"); break;
-            }
-        }
-        const size_t vb = dtype_bytes(inf.values_dtype);
-        if (vb && inf.values_len > 0 && out_values && res->values.p &&
-            mx::xfer_d2h(out_values, res->values.p, vb * (size_t)inf.values_len) != 0) {
-            rc = set_error("D2H copy of values failed"); break;
-        }
-    } while (0);
-    delete res;
-    return rc;
-}
-
-int mx_result_discard(mx_result *res) { delete res; return 0; }
-
-// ---- index-vector classification -------------------------------------------------------------------
-static int check_seq_host(const int32_t *indices, int64_t n, int reversed, int *result)
-{
-    MX_REQUIRE(result, "check_is_seq: null result pointer");
-    if (n < 2) { *result = 1; return 0; }
-    // slice.cpp:28,40: end-point test first — avoids the transfer for the common negative
-    const int64_t span = reversed ? (int64_t)indices[0] - indices[n - 1] : (int64_t)indices[n - 1] - indices[0];
-    if (span != n - 1) { *result = 0; return 0; }
-    DevBuf d, flag;
-    if (d.upload(indices, sizeof(int32_t) * (size_t)n)) return 1;
-    if (flag.alloc(16)) return 1;
-    return mxd_check_is_seq(d.as<int32_t>(), n, reversed, flag.as<int32_t>(), result, nullptr);
-}
-int mx_check_is_seq(const int32_t *indices, int64_t n, int *result) { return check_seq_host(indices, n, 0, result); }
-int mx_check_is_rev_seq(const int32_t *indices, int64_t n, int *result) { return check_seq_host(indices, n, 1, result); }
-
-// ---- sort precondition (§8f rank 1) ------------------------------------------------------------------
-int mx_check_indices_are_sorted(const int32_t *indptr, const int32_t *indices, int nrows, int *result)
-{
-    MX_REQUIRE(result, "mx_check_indices_are_sorted: null result pointer");
-    if (nrows <= 0) { *result = 1; return 0; }
-    Csr A;
-    if (A.upload(indptr, indices, nullptr, nrows, 0)) return 1;
-    DevBuf flag;
-    if (flag.alloc(16)) return 1;
-    return mxd_csr_rows_sorted(nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), flag.as<int32_t>(), result, nullptr);
-}
-
-int mx_sort_sparse_indices(const int32_t *indptr, int32_t *indices, void *values, int value_dtype, int nrows)
-{
-    if (nrows <= 0) return 0;
-    const size_t vb = values ? dtype_bytes(value_dtype) : 0;
-    Csr A;
-    if (A.upload_private(indptr, indices, values, nrows, vb)) return 1;
-    if (A.nnz < 2) return 0;
-    DevBuf flag, tj, tx;
-    if (flag.alloc(16)) return 1;
-    int sorted = 0;
-    if (mxd_csr_rows_sorted(nrows, A.p.as<int32_t>(), A.j.as<int32_t>(), flag.as<int32_t>(), &sorted, nullptr)) return 1;
-    if (sorted) return 0;                      // nothing to do, inputs untouched
-    CsrCache::get().invalidate(indices);       // the host arrays are about to change under any cached copy
-    if (vb) CsrCache::get().invalidate(values);
-    if (tj.alloc(sizeof(int32_t) * (size_t)A.nnz)) return 1;
-    if (vb && tx.alloc(vb * (size_t)A.nnz)) return 1;
-    if (mxd_csr_sort_rows(nrows, A.nnz, A.p.as<int32_t>(), A.j.as<int32_t>(), vb ? A.x.p : nullptr,
-                          vb ? value_dtype : MX_NONE, tj.as<int32_t>(), tx.p, nullptr)) return 1;
-    if (mx::xfer_d2h(indices, A.j.p, sizeof(int32_t) * (size_t)A.nnz)) return 1;
-    if (vb && mx::xfer_d2h(values, A.x.p, vb * (size_t)A.nnz)) return 1;
-    return 0;
-}
-
-}  // extern "C"
-
-// diagnostic: the kernel family AUTO chose for the calling thread's last pipelined / sharded export product and the geometry
-// every block of it ran with (segments: -1 = the row-group form, 0 = not the row-split family; long_piece 0 = long-rows path off)
-extern "C" int mx_debug_last_export_family(int *family, int *segments, int *panels, int *long_piece)
-{
-    MX_REQUIRE(family && segments && panels && long_piece, "mx_debug_last_export_family: null argument");
-    *family = g_last_export_family.family; *segments = g_last_export_family.segments; *panels = g_last_export_family.panels;
-    *long_piece = g_last_export_family.lh.piece;
-    return 0;
-}
+// One translation unit, five files along its layers (everything below `namespace mx` shares file-local state —
+// the CSR cache, the per-thread lanes, the small-call stages — so the parts are included, not linked):
+#include "api_core.inc"           // helpers, device buffers, CSR cache, lanes, registration, row partition
+#include "api_small.inc"          // the small-call path
+#include "api_spmm_export.inc"    // pipelined + sharded CSR x dense exports
+#include "api_spmv_export.inc"    // options, the SpMV export; closes namespace mx
+#include "api_exports.inc"        // extern "C": the export level, the offload gate

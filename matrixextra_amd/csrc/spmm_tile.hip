@@ -507,34 +507,58 @@ void tile_cuts_kernel(int m, int R, const int32_t *__restrict__ indptr, long lon
 // matrix (sigma 1.5) paid E[max of 4] / mean ~ 2x in every visit and its busiest SIMD half as much again (1e4 x 1e4, 500 per row,
 // n = 100: 0.31 ms where equal rows take 0.108).  Here the rows of a block are RANKED by length (R <= 300: every thread counts
 // the rows ahead of its own) and dealt: ranks 4q .. 4q + 3 share visit q — four rows of nearly the same length —, and the
-// visits, longest first, go to the wavefronts in snake order (wavefront w sits on SIMD w % 4: every SIMD gets the same mix).
+// visits, longest first, go to the SIMD with the least work so far (wavefront w sits on SIMD w % 4).
 // A row is still summed by one group in storage order: the same bits.  perm[rb * R + slot] = row, m = no row.
 __global__ __launch_bounds__(256)
 void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const int32_t *__restrict__ indptr, const int32_t *__restrict__ cuts,
                            int32_t *__restrict__ perm)
 {
-    __shared__ int len[TL_MAX_WAVES * TL_NG * 5 + 4];
-    __shared__ short visit_of[TL_MAX_WAVES * 5 + 1];
+    constexpr int MAXR = TL_MAX_WAVES * TL_NG * 5;
+    __shared__ int len[MAXR + 4], sorted_len[MAXR + 4];
+    __shared__ short row_of_rank[MAXR + 4], visit_of[TL_MAX_WAVES * 5 + 1];
     const int rb = blockIdx.x, row0 = cuts[rb], nrows = cuts[rb + 1] - row0;
     if (nrows <= 0) return;
     for (int r = threadIdx.x; r < R; r += blockDim.x) len[r] = r < nrows ? indptr[row0 + r + 1] - indptr[row0 + r] : -1;
-    if (threadIdx.x == 0) {
-        int base[TL_MAX_WAVES + 1], rg[TL_MAX_WAVES], maxrg = 0;
-        base[0] = 0;
-        for (int w = 0; w < nw; w++) { rg[w] = (int)((rgw >> (4 * w)) & 15); base[w + 1] = base[w] + rg[w]; maxrg = max(maxrg, rg[w]); }
-        int q = 0;
-        for (int i = 0; i < maxrg; i++)
-            for (int k = 0; k < nw; k++) {
-                const int w = (i & 1) ? nw - 1 - k : k;
-                if (rg[w] > i) visit_of[q++] = (short)(base[w] + i);
-            }
-    }
     __syncthreads();
     for (int r = threadIdx.x; r < R; r += blockDim.x) {
         const int mine = len[r];
         int rank = 0;
         for (int o = 0; o < R; o++) rank += (len[o] > mine || (len[o] == mine && o < r)) ? 1 : 0;
-        perm[(size_t)rb * R + visit_of[rank / TL_NG] * TL_NG + rank % TL_NG] = mine >= 0 ? row0 + r : m;
+        sorted_len[rank] = mine;
+        row_of_rank[rank] = (short)r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // visits (ranks 4q .. 4q + 3, cost = the longest of them = rank 4q), longest first, each to the SIMD with the least work
+        // so far that still has a free visit slot, there to the wavefront with the most free slots.  (The first version dealt
+        // them in snake order over the wavefronts: fine for a smooth length distribution, but one row of 20 mean rows then
+        // shares its SIMD with as many other visits as every other SIMD has.)
+        int base[TL_MAX_WAVES + 1], free_[TL_MAX_WAVES];
+        long long load[4] = {0, 0, 0, 0};
+        base[0] = 0;
+        for (int w = 0; w < nw; w++) { free_[w] = (int)((rgw >> (4 * w)) & 15); base[w + 1] = base[w] + free_[w]; }
+        const int nq = R / TL_NG;
+        for (int q = 0; q < nq; q++) {
+            int best_c = -1;
+            for (int c = 0; c < 4; c++) {
+                bool has = false;
+                for (int w = c; w < nw; w += 4) has = has || free_[w] > 0;
+                if (has && (best_c < 0 || load[c] < load[best_c])) best_c = c;
+            }
+            int best_w = -1;
+            for (int w = best_c; w < nw; w += 4)
+                if (free_[w] > 0 && (best_w < 0 || free_[w] > free_[best_w])) best_w = w;
+            const int rg_w = (int)((rgw >> (4 * best_w)) & 15);
+            visit_of[q] = (short)(base[best_w] + (rg_w - free_[best_w]));
+            free_[best_w]--;
+            // (a visit costs its window bookkeeping whatever its rows hold: ~40 entries' worth)
+            load[best_c] += 40 + (long long)max(sorted_len[q * TL_NG], 0);
+        }
+    }
+    __syncthreads();
+    for (int rank = threadIdx.x; rank < R; rank += blockDim.x) {
+        const int r = row_of_rank[rank];
+        perm[(size_t)rb * R + visit_of[rank / TL_NG] * TL_NG + rank % TL_NG] = sorted_len[rank] >= 0 ? row0 + r : m;
     }
 }
 

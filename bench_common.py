@@ -204,7 +204,7 @@ def _extra_ms_frac(e):
     return [ms, fr] if ms is not None else None
 
 
-SUMMARY_ORDER = ("cfg5_shard", "cfg2_rowmajor", "spmv_cfg3", "gather_cfg3", "csr_add_csr_cfg4", "csr_mul_csr_cfg4",
+SUMMARY_ORDER = ("cfg5_shard", "cfg2_rowmajor", "spmv_cfg3", "spmv_cfg4_shape", "gather_cfg3", "csr_add_csr_cfg4", "csr_mul_csr_cfg4",
                  "vignette_dense_csc", "spmm_cfg2_skewed", "spmm_cfg2_zipf", "cfg5_shard_skewed", "cfg5_strong",
                  "rows_sorted_check_cfg4", "export_call_end_to_end", "spmm_short_rows_narrow_B", "csr_sub_csr_cfg4")
 

@@ -171,6 +171,29 @@ def extras(args, torch, D, synth, _lib, host, want_cpu):
                                                "(the reference is single-threaded here), best of 2"}
             res[f"csr_{name}_csr_cfg4"] = e
             del R, o
+        # X %*% v at this shape (v = 16 MB, more than an XCD's L2): the one-shot flat kernel and the kept plan, whose super-panels of
+        # 2^18 columns keep the slice of v that all workgroups of a launch read inside L2 (round 6; matmul.cpp:381-419)
+        try:
+            v4 = torch.randn(K4, dtype=torch.float64, device="cuda")
+            y_flat = D.spmv(A1, v4, algo=3)
+            y_plan = D.spmv_planned(A1, v4)
+            errw = float((y_flat - y_plan).abs().max() / y_flat.abs().max())
+            assert errw <= 1e-12, f"planned SpMV (wide) differs from the flat kernel: {errw}"
+            hv = v4.cpu().numpy()
+            ref_rows = np.array([np.dot(hx1[hp1[r]:hp1[r + 1]], hv[hj1[hp1[r]:hp1[r + 1]]]) for r in range(0, rs, 997)])
+            erro = float(np.max(np.abs(y_plan[:rs:997].cpu().numpy() - ref_rows)) / np.max(np.abs(ref_rows)))
+            assert erro <= 1e-12, f"planned SpMV (wide) differs from the host dot products: {erro}"
+            t_flat, t_plan = timeit(lambda: D.spmv(A1, v4, algo=3), reps=10), timeit(lambda: D.spmv_planned(A1, v4), reps=10)
+            byts_v = 4 * (m4 + 1) + 12 * A1.nnz + 8 * K4 + 8 * m4
+            res["spmv_cfg4_shape"] = {"ms": round(t_plan * 1e3, 4), "one_shot_flat_ms": round(t_flat * 1e3, 4),
+                                      "roofline": roofline(byts_v, t_plan, scope="kept plan: one launch per super-panel of 2^18 columns"),
+                                      "one_shot_flat_frac": round(byts_v / t_flat / 1e9 / 8000.0, 4),
+                                      "parity": "1e-12 against the flat kernel (all rows) and against host dot products (sampled rows)",
+                                      "shape": "2M x 2M, 50 per row, v f64 (16 MB)"}
+            A1.drop_spmv_plan()
+            del v4, y_flat, y_plan
+        except Exception as exc:                              # noqa: BLE001 - the merges' legs below must still report
+            res.setdefault("errors", {})["spmv_cfg4_shape"] = repr(exc)[:300]
         # the sortedness check the R callers run before every merge (R/operators.R:58,64,748,754)
         A1._sorted = None
         t = timeit(lambda: (setattr(A1, "_sorted", None), A1.rows_sorted()), reps=10)

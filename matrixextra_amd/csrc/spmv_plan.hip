@@ -21,7 +21,7 @@
 //     Up to 1,024 super-panels (2^28 columns).
 //   * rows of UNEVEN length.  A row block used to be 4,096 rows whatever they held: with the rows sorted by length the first
 //     blocks carried ten times the entries of the last and their workgroups were the tail (0.95 ms against 0.077).  A block
-//     of 4,096 rows that holds more than E entries (1.25 mean blocks) is now cut into sub-blocks of equal entry counts
+//     of 4,096 rows that holds more than E entries (1.06 mean blocks) is now cut into sub-blocks of equal entry counts
 //     (spmv_plan_cuts_kernel, on the device): rows of equal length keep exactly the blocks they had.
 // Measured (cfg3, MI355X): DESIGN.md §4.3.  Summation order: per row, panels in ascending order; inside a panel the
 // entries of a row are added with LDS atomics in whatever order their wavefronts arrive: equal to the reference to
@@ -192,6 +192,42 @@ void spmv_plan_kernel(int m, int K, int npanels, const int32_t *__restrict__ rb_
     if constexpr (KIND == MX_I32 || KIND == MX_LGL)
         for (int i = tid; i < (SP_RB + 8 + 31) / 32; i += SP_THREADS) na_rows[i] = 0u;
     const int32_t *__restrict__ so = seg_off + (size_t)rb * npanels;
+    // A LIGHT block (the tail of a matrix whose rows are sorted by length: 4,096 rows of one or two entries) would spend its
+    // time staging all of v — K x 8 bytes through 2 x 48 KB of LDS, a barrier per panel — for a few thousand products: it reads
+    // v[j] from global memory instead, panel after panel without a barrier (rows sorted by length, cfg3's shape: 0.163 -> see
+    // docs/experiments/round-6.md §10.5).  Uniform per workgroup.
+    const bool direct = !WIDE && (long long)(so[npanels] - so[0]) * 8 < (long long)K;      // (a gathered element moves a 64-byte sector: entries x 64 < K x 8)
+    if (direct) {
+        __syncthreads();
+        for (int p = 0; p < npanels; p++) {
+            const int s = so[p], e = so[p + 1], cb = p * SP_PANEL;
+            for (int k0 = s + tid * 4; k0 < e; k0 += SP_THREADS * 4) {
+                const i4 c0 = *reinterpret_cast<const i4 *>(ent + k0);
+                const d2 a0 = *reinterpret_cast<const d2 *>(val + k0), a1 = *reinterpret_cast<const d2 *>(val + k0 + 2);
+                const double av[4] = {a0[0], a0[1], a1[0], a1[1]};
+                double f[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) f[q] = sp_factor<KIND>(v_, min(cb + (c0[q] & ((1 << CB) - 1)), K - 1));
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int r = (int)((unsigned)c0[q] >> CB);
+                    double t = av[q] * f[q];
+                    if constexpr (KIND == MX_I32 || KIND == MX_LGL) {
+                        if (__double_as_longlong(f[q]) == (long long)MX_NA_REAL_BITS) { t = 0.0; if (r < SP_RB) atomicOr(&na_rows[r >> 5], 1u << (r & 31)); }
+                    }
+                    __hip_atomic_fetch_add(&acc[r], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nr; i += SP_THREADS) {
+            const double sum = acc[i];
+            if constexpr (KIND == MX_F32) ((float *)y_)[r0 + i] = (float)sum;
+            else if constexpr (KIND == MX_I32 || KIND == MX_LGL) ((double *)y_)[r0 + i] = (na_rows[i >> 5] >> (i & 31)) & 1u ? na_real() : sum;
+            else ((double *)y_)[r0 + i] = sum;
+        }
+        return;
+    }
     double stage[PER];
     if constexpr (!WIDE) {                                            // panel 0 -> buffer 0
 #pragma unroll
@@ -413,10 +449,10 @@ extern "C" int mxd_spmv_plan_create(int m, int K, const int32_t *indptr, const i
         int32_t ends[2] = {0, 0};
         if (read_back_small(&ends[0], indptr, sizeof(int32_t), st) || read_back_small(&ends[1], indptr + m, sizeof(int32_t), st)) break;
         pl->nnz = (long long)ends[1] - ends[0];
-        // row blocks: 4,096 rows, cut further where they hold more than E entries (1.25 mean blocks, at least 32k: a block must
+        // row blocks: 4,096 rows, cut further where they hold more than E entries (1.06 mean blocks, at least 32k: a block must
         // be worth a workgroup) — spmv_plan_cuts_kernel
         const long long mean_block = (long long)((double)pl->nnz / (double)m * SP_RB);
-        const long long E = std::max<long long>(32768, mean_block + mean_block / 4);
+        const long long E = std::max<long long>(32768, mean_block + mean_block / 16);
         const int nA = (int)ceil_div(m, SP_RB);
         const int max_cuts = (int)std::min<long long>((long long)nA + pl->nnz / E + 1, (long long)m);
         long long *nrb_dev = nullptr;

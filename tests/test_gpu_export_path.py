@@ -223,8 +223,10 @@ def test_sharded_export_bits_do_not_depend_on_the_device_list(gpu):
     with a few giant ones: the same bits for the GPU listed 2, 3 and 5 times."""
     lib = _lib.load()
     rng = np.random.default_rng(3)
-    m, K, n = 72_000, 120_000, 256
-    lens = np.minimum(np.maximum(rng.lognormal(mean=np.log(40) - 0.72, sigma=1.2, size=m), 1), 4000).astype(np.int64)
+    # (fewer than 32,768 rows: AUTO weighs the row-split kernel against the tile kernel only, and at density 7e-4 the tile
+    # kernel has nothing to re-use; n = 528 f32 makes the result 64.4 MiB: the exports shard from 64 MiB on)
+    m, K, n = 32_000, 120_000, 528
+    lens = np.minimum(np.maximum(rng.lognormal(mean=np.log(80) - 0.72, sigma=1.2, size=m), 1), 4000).astype(np.int64)
     lens[rng.choice(m, size=6, replace=False)] = 30_000
     row = np.repeat(np.arange(m, dtype=np.int64), lens)
     key = np.unique(row * K + rng.integers(0, K, size=row.size))    # sorted, distinct ids per row (a few draws collapse)

@@ -7,13 +7,22 @@ sys.path.insert(0, ROOT)
 from matrixextra_amd import _lib, device as D, synth
 lib = _lib.load()
 m, K, npr, n = (int(a) for a in sys.argv[1:5]) if len(sys.argv) > 4 else (10_000, 10_000, 500, 100)
-p, j, x = synth.device_csr_fixed(m, K, npr, seed=7)
-A = D.DeviceCSR(p, j, x, m, K, int(j.numel())); A.rows_sorted()
+kind = sys.argv[5] if len(sys.argv) > 5 else "equal"          # a row-length distribution of tools/cliff_hunt.py (lognormal_1.5, giant, blocks ...)
+if kind == "equal":
+    p, j, x = synth.device_csr_fixed(m, K, npr, seed=7)
+    A = D.DeviceCSR(p, j, x, m, K, int(j.numel()))
+else:
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from cliff_hunt import build, lens_of
+    A = build(m, K, lens_of(kind, m, npr, np.random.default_rng(7)), 7)
+A.rows_sorted()
+print(kind, "nnz", A.nnz, "cv", round(float(A.profile()[32]), 3), "MXGPU_TILE_DEAL", os.environ.get("MXGPU_TILE_DEAL"))
 B = torch.randn((K, n), dtype=torch.float64, device="cuda")
 out = torch.empty((m, n), dtype=torch.float64, device="cuda")
 for _ in range(200):
     D.spmm(A, B, out=out, algo=5)
-st = torch.zeros(2 * 16 * 4096, dtype=torch.int64, device="cuda")
+st = torch.zeros(2 * 16 * 16384, dtype=torch.int64, device="cuda")
 lib.mxd_debug_spmm_tile_stamps(C.c_void_p(st.data_ptr()))
 D.spmm(A, B, out=out, algo=5)
 torch.cuda.synchronize()
@@ -26,3 +35,8 @@ print(f"wavefronts {used.sum()}: sweep cycles mean {total.mean():.0f} (min {tota
 wg_tot = s[:, :, 1].max(axis=1)
 wg_tot = wg_tot[wg_tot > 0]
 print(f"workgroups {wg_tot.size}: slowest / mean sweep {wg_tot.max() / wg_tot.mean():.3f}")
+
+import numpy as np
+t = s[:, :, 1].max(axis=1)
+t = t[t > 0]
+print("workgroup sweep cycles: percentiles 10/50/90/99/max", [int(np.percentile(t, q)) for q in (10, 50, 90, 99, 100)])

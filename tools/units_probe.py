@@ -59,7 +59,7 @@ def avail():
 
 def run_pass(tag, i, counters, argv):
     d = os.path.join(OUT, f"{tag}_pmc_{i}")
-    if not glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    if not glob.glob(d + "/**/*counter_collection.csv", recursive=True) and not os.environ.get("UNITS_NO_RUN"):
         with open(d + ".log", "w") as log:
             try:
                 subprocess.run(["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", *argv],

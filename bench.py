@@ -113,7 +113,7 @@ def relaunch_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 from bench_common import (HBM_PEAK_GBS, STREAM, committed_kernels_traffic, committed_traffic, cpu_baseline_spmm,  # noqa: E402,F401
-                          headline_line, roofline, stream_copy_probe)
+                          bound_unit_of, headline_line, roofline, stream_copy_probe)
 
 
 STRONG_CHUNKS = 64
@@ -351,6 +351,7 @@ def spmm_leg(args, torch, dist, D, synth, lib, _lib, cfg, world, rank, steps, wa
         "roofline": roofline(alg_bytes, kern_avg_s, traffic=traffic[0], traffic_source=traffic[1],
                              **({"traffic_refused": traffic[2]} if traffic[2] else {}), kernel=kernel_name,
                              kernel_avg_ms=round(kern_avg_s * 1e3, 4), kernel_min_ms=round(float(kern_ms.min()), 4),
+                             **({"bound_unit": bound_unit_of(kernel_name)} if bound_unit_of(kernel_name) else {}),
                              # secondary, non-scoring: what actually bounds the kernel.  Every nonzero gathers one B
                              # row: nnz * n * s bytes move from L2 into the CUs' L1 whatever the schedule
                              l2_to_l1_gather={"bytes_per_launch": int(gb),

@@ -111,6 +111,28 @@ def committed_kernels_traffic(kernels, call_ms):
     return {"traffic_refused": "; ".join(whys) if whys else "no multi-kernel summary of the newest round"}
 
 
+def bound_unit_of(kernel_name):
+    """Which unit saturates in the dominant kernel, from the committed counter series (tools/units_probe.py ->
+    profiles/rNN_cfg2_units.json: TA / TCP / SQ passes of the sweep and of the bare gather).  A statement about the kernel, not
+    about this run: quoted with its file."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import prof_common as PC
+    if "spmm_plan_kernel" not in kernel_name:
+        return None
+    for f in PC.newest_round("*cfg2_units.json"):
+        try:
+            d = json.load(open(f))["kernels"]
+            me, bare = d["spmm_plan_kernel_cfg2"]["derived"], d["bare_gather_B_4MB_16waves_x8"]["counters"]
+            ta = next(v for k, v in me.items() if k.startswith("TA_busy_share_of_kernel_cycles"))
+            per = next(v for k, v in me.items() if k.startswith("TA_cycles_per_vector_memory_instruction"))
+            bare_per = bare["TA_TA_BUSY_sum"]["mean"] / 32.0e6
+            return (f"texture addressers {100 * ta:.0f} % busy, {per:.0f} TA cycles per 1-KiB gather instruction (bare gather: "
+                    f"{bare_per:.0f}) - {os.path.relpath(f, ROOT)}")
+        except Exception:
+            continue
+    return None
+
+
 STREAM = {"GBps": None}          # measured once per run (stream_copy_probe): the box's own float4-copy rate
 
 

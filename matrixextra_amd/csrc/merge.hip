@@ -176,30 +176,37 @@ void merge_count_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__
     // branch-free selects on n1 / n2 here 207 -> 224)
 #pragma unroll
     for (int u = 0; u < COUNT_U; u++) left[u] = false;
+    // (Round 6 tried the straight-line searches for ALL pairs first and the sliding windows only for those that do not fit — so that
+    // a wavefront with one big pair does not search its other pairs one after the other: log-normal rows, cfg4's shape, count
+    // 495 -> 590 us, fill 1303 -> 1343: the wasted searches of the big pairs cost more than the interleaving saves.  Not kept.)
     // One test for all COUNT_U pairs: when every row fits its lane group (the normal case) the searches are straight-line
     // code, and the compiler interleaves their dependent chains of cross-lane reads (~100 cycles a probe).
     bool big = false;
 #pragma unroll
     for (int u = 0; u < COUNT_U; u++) big = big || n1[u] > G || n2[u] > G;
     int c[COUNT_U];
-    // The pairs that fit their lane group: straight-line code for all COUNT_U of them, so that the compiler interleaves their
-    // dependent chains of cross-lane reads (~100 cycles a probe).  (A pair that does not fit holds INT_MAX in every lane here:
-    // its count is replaced below.  Round 5 sent a wavefront with ONE such pair through a branch that searched its other pairs
-    // one after the other — with log-normal rows, sigma 1, that is 88 % of the wavefronts.)
-#pragma unroll
-    for (int u = 0; u < COUNT_U; u++) {
-        bool hit;
-        group_lower_bound<G>(b[u], a[u], hit);
-        const int hits = __popcll(group_ballot<G>(hit && lg < n1[u]));
-        c[u] = INTERSECT ? hits : n1[u] + n2[u] - hits;
-    }
-    if (__ballot(big) != 0ULL) {
+    if (__ballot(big) == 0ULL) {
 #pragma unroll
         for (int u = 0; u < COUNT_U; u++) {
-            if (n1[u] <= G && n2[u] <= G) continue;                  // (uniform inside the group)
-            left[u] = ml.T != 0 && (n1[u] > ml.T || n2[u] > ml.T);
-            if (left[u]) c[u] = 0;                                   // listed at the end of the kernel
-            else c[u] = count_row_slow<G, INTERSECT>(lg, j1 + s1[u], n1[u], j2 + s2[u], n2[u]);
+            bool hit;
+            group_lower_bound<G>(b[u], a[u], hit);
+            const int hits = __popcll(group_ballot<G>(hit && lg < n1[u]));
+            c[u] = INTERSECT ? hits : n1[u] + n2[u] - hits;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < COUNT_U; u++) {
+            left[u] = ml.T != 0 && (n1[u] > ml.T || n2[u] > ml.T);   // (uniform inside the group)
+            if (left[u]) {
+                c[u] = 0;                                            // listed at the end of the kernel
+            } else if (__ballot(n1[u] > G || n2[u] > G) == 0ULL) {
+                bool hit;
+                group_lower_bound<G>(b[u], a[u], hit);
+                const int hits = __popcll(group_ballot<G>(hit && lg < n1[u]));
+                c[u] = INTERSECT ? hits : n1[u] + n2[u] - hits;
+            } else {
+                c[u] = count_row_slow<G, INTERSECT>(lg, j1 + s1[u], n1[u], j2 + s2[u], n2[u]);
+            }
         }
     }
 #pragma unroll
@@ -330,14 +337,18 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
     bool left[FILL_U];                                               // very long pairs: merge_long_fill_kernel's (see merge_count_kernel)
 #pragma unroll
     for (int u = 0; u < FILL_U; u++) left[u] = false;
-    // register-resident rows: one entry of A and one of B per lane, searches by cross-lane probes — straight-line code for all
-    // FILL_U pairs (the compiler interleaves their chains of cross-lane reads); a pair that does not fit its lane group holds
-    // INT_MAX in every lane, stores nothing here and takes the sliding windows below
 #pragma unroll
     for (int u = 0; u < FILL_U; u++) {
         const long long row = grp * FILL_U + u;
-        const bool fit = row < m && n1[u] <= G && n2[u] <= G;        // (uniform inside the group)
-        const bool va = fit && lg < n1[u], vb = fit && lg < n2[u];
+        const bool fits = __ballot(n1[u] > G || n2[u] > G) == 0ULL;
+        if (row >= m) continue;
+        if (!fits) {
+            left[u] = ml.T != 0 && (n1[u] > ml.T || n2[u] > ml.T);
+            if (!left[u]) fill_row_slow<G, OP, VT>(lg, j1 + s1[u], x1 + s1[u], n1[u], j2 + s2[u], x2 + s2[u], n2[u], o[u], jo, xo);
+            continue;
+        }
+        // register-resident rows: one entry of A and one of B per lane, searches by cross-lane probes
+        const bool va = lg < n1[u], vb = lg < n2[u];
         bool hit_a, hit_b;
         const int lb_a = group_lower_bound<G>(b[u], a[u], hit_a);     // entries of B below a
         hit_a = hit_a && va;
@@ -364,13 +375,6 @@ void merge_fill_kernel(int m, const int32_t *__restrict__ p1, const int32_t *__r
                 if constexpr (OP == MX_OP_SUB) xo[pos] = -xb[u]; else xo[pos] = xb[u];
             }
         }
-    }
-#pragma unroll
-    for (int u = 0; u < FILL_U; u++) {
-        const long long row = grp * FILL_U + u;
-        if (row >= m || (n1[u] <= G && n2[u] <= G)) continue;        // (uniform inside the group)
-        left[u] = ml.T != 0 && (n1[u] > ml.T || n2[u] > ml.T);
-        if (!left[u]) fill_row_slow<G, OP, VT>(lg, j1 + s1[u], x1 + s1[u], n1[u], j2 + s2[u], x2 + s2[u], n2[u], o[u], jo, xo);
     }
     if (ml.T != 0) {
 #pragma unroll

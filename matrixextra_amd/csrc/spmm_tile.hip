@@ -507,7 +507,7 @@ void tile_cuts_kernel(int m, int R, const int32_t *__restrict__ indptr, long lon
 // matrix (sigma 1.5) paid E[max of 4] / mean ~ 2x in every visit and its busiest SIMD half as much again (1e4 x 1e4, 500 per row,
 // n = 100: 0.31 ms where equal rows take 0.108).  Here the rows of a block are RANKED by length (R <= 300: every thread counts
 // the rows ahead of its own) and dealt: ranks 4q .. 4q + 3 share visit q — four rows of nearly the same length —, and the
-// visits, longest first, go to the SIMD with the least work so far (wavefront w sits on SIMD w % 4).
+// visits, longest first, go to the wavefront with the least work so far.
 // A row is still summed by one group in storage order: the same bits.  perm[rb * R + slot] = row, m = no row.
 __global__ __launch_bounds__(256)
 void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const int32_t *__restrict__ indptr, const int32_t *__restrict__ cuts,
@@ -529,30 +529,28 @@ void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const i
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // visits (ranks 4q .. 4q + 3, cost = the longest of them = rank 4q), longest first, each to the SIMD with the least work
-        // so far that still has a free visit slot, there to the wavefront with the most free slots.  (The first version dealt
-        // them in snake order over the wavefronts: fine for a smooth length distribution, but one row of 20 mean rows then
-        // shares its SIMD with as many other visits as every other SIMD has.)
+        // visits (ranks 4q .. 4q + 3, cost = the longest of them = rank 4q), longest first, each to the WAVEFRONT with the least
+        // work so far that still has a free visit slot (ties: the one on the least-loaded SIMD).  Per wavefront, not per SIMD: a
+        // row with several windows per tile makes its wavefront go round ALL its rows once per window, so what it shares the
+        // wavefront with costs again and again — a block with spare slots (the sub-blocks of tile_cuts_kernel) leaves such a row
+        // alone in its wavefront (tools/tile_stamps.py, log-normal sigma 1.5: waves 60 % of their cycles at the tile barrier).
         int base[TL_MAX_WAVES + 1], free_[TL_MAX_WAVES];
-        long long load[4] = {0, 0, 0, 0};
+        long long load[TL_MAX_WAVES], simd[4] = {0, 0, 0, 0};
         base[0] = 0;
-        for (int w = 0; w < nw; w++) { free_[w] = (int)((rgw >> (4 * w)) & 15); base[w + 1] = base[w] + free_[w]; }
+        for (int w = 0; w < nw; w++) { free_[w] = (int)((rgw >> (4 * w)) & 15); base[w + 1] = base[w] + free_[w]; load[w] = 0; }
         const int nq = R / TL_NG;
         for (int q = 0; q < nq; q++) {
-            int best_c = -1;
-            for (int c = 0; c < 4; c++) {
-                bool has = false;
-                for (int w = c; w < nw; w += 4) has = has || free_[w] > 0;
-                if (has && (best_c < 0 || load[c] < load[best_c])) best_c = c;
-            }
             int best_w = -1;
-            for (int w = best_c; w < nw; w += 4)
-                if (free_[w] > 0 && (best_w < 0 || free_[w] > free_[best_w])) best_w = w;
+            for (int w = 0; w < nw; w++) {
+                if (free_[w] <= 0) continue;
+                if (best_w < 0 || load[w] < load[best_w] || (load[w] == load[best_w] && simd[w & 3] < simd[best_w & 3])) best_w = w;
+            }
             const int rg_w = (int)((rgw >> (4 * best_w)) & 15);
             visit_of[q] = (short)(base[best_w] + (rg_w - free_[best_w]));
             free_[best_w]--;
-            // (a visit costs its window bookkeeping whatever its rows hold: ~40 entries' worth)
-            load[best_c] += 40 + (long long)max(sorted_len[q * TL_NG], 0);
+            // (a visit costs its window bookkeeping whatever its rows hold: ~40 entries' worth; a slot without rows nothing)
+            const long long cost = sorted_len[q * TL_NG] >= 0 ? 40 + (long long)sorted_len[q * TL_NG] : 0;
+            load[best_w] += cost; simd[best_w & 3] += cost;
         }
     }
     __syncthreads();

@@ -52,7 +52,7 @@ static_assert(13 + SP_WIDE_BITS <= 31, "row-in-block (0 .. 4096) and column-in-p
 // in rounds of 1,024), then every sub-block boundary.  cuts[0 .. nrb], nrb = the total — read back by the host (the build
 // synchronises anyway).  Rows of equal length: s = 1 everywhere, exactly the blocks of rounds 2-5.
 __global__ __launch_bounds__(1024)
-void spmv_plan_cuts_kernel(int m, const int32_t *__restrict__ indptr, long long E, int32_t *__restrict__ cuts, int max_cuts,
+void spmv_plan_cuts_kernel(int m, const int32_t *__restrict__ indptr, long long E, long long E_piece, int32_t *__restrict__ cuts, int max_cuts,
                            long long *__restrict__ nrb_out)
 {
     __shared__ int scan[1024];
@@ -67,8 +67,8 @@ void spmv_plan_cuts_kernel(int m, const int32_t *__restrict__ indptr, long long 
         if (k < nA) {
             r0 = k * SP_RB; r1 = min(r0 + SP_RB, m);
             e0 = indptr[r0]; nn = (long long)indptr[r1] - e0;
-            s = (int)max(1LL, (nn + E - 1) / E);
-            s = min(s, r1 - r0);                                       // (never more sub-blocks than rows)
+            s = nn > E ? (int)((nn + E_piece - 1) / E_piece) : 1;
+            s = max(1, min(s, r1 - r0));                               // (never more sub-blocks than rows)
         }
         scan[tid] = s;
         __syncthreads();
@@ -452,13 +452,15 @@ extern "C" int mxd_spmv_plan_create(int m, int K, const int32_t *indptr, const i
         // row blocks: 4,096 rows, cut further where they hold more than E entries (1.06 mean blocks, at least 32k: a block must
         // be worth a workgroup) — spmv_plan_cuts_kernel
         const long long mean_block = (long long)((double)pl->nnz / (double)m * SP_RB);
-        const long long E = std::max<long long>(32768, mean_block + mean_block / 16);
+        // (pieces of half a mean block: with heavy-first dispatch the launch then ends within half a block of the ideal — rows
+        // sorted by length, cfg3's shape: pieces of one mean block 0.142 ms, equal rows 0.079)
+        const long long E = std::max<long long>(32768, mean_block + mean_block / 16), E_piece = std::max<long long>(16384, mean_block / 2);
         const int nA = (int)ceil_div(m, SP_RB);
-        const int max_cuts = (int)std::min<long long>((long long)nA + pl->nnz / E + 1, (long long)m);
+        const int max_cuts = (int)std::min<long long>((long long)nA + pl->nnz / E_piece + 1, (long long)m);
         long long *nrb_dev = nullptr;
         if (hipMalloc((void **)&pl->rb_row, ((size_t)max_cuts + 2) * 4) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
         if (hipMalloc((void **)&nrb_dev, 16) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
-        hipLaunchKernelGGL(spmv_plan_cuts_kernel, dim3(1), dim3(1024), 0, st, m, indptr, E, pl->rb_row, max_cuts, nrb_dev);
+        hipLaunchKernelGGL(spmv_plan_cuts_kernel, dim3(1), dim3(1024), 0, st, m, indptr, E, E_piece, pl->rb_row, max_cuts, nrb_dev);
         long long nrb_ll = 0;
         const int rb_rc = read_back_small(&nrb_ll, nrb_dev, sizeof(nrb_ll), st);
         (void)hipFree(nrb_dev);

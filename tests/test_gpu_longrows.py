@@ -246,7 +246,7 @@ def test_scratch_is_sized_from_the_profile_and_a_wrong_profile_costs_speed_not_a
     canonical piece), not from nnz / piece; a kernel checks on the device that the launch's long rows fit.  A profile that
     understates them (another matrix's) leaves the rows to the product kernels: bit for bit the storage-order chain."""
     rng = np.random.default_rng(9)
-    m, K, n = 900, 4000, 64
+    m, K, n = 900, 4000, 128                                     # (128 f64 columns: one wavefront per row of B, one row per wavefront)
     long_rows = {r: int(rng.integers(1100, 3900)) for r in rng.choice(m, size=40, replace=False)}
     p, j, lens = _matrix(m, K, rng, 20, long_rows)
     x = rng.uniform(-1, 1, size=j.size)

@@ -377,19 +377,28 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
                 }
                 return maxc;
             };
-            // a group that filled its window may have more entries in this tile: the wavefront then goes round its rows
-            // again (the others find nothing) — every round loads every row's window exactly once, in the same order, so
-            // that a row's window is always awaited RG - 1 visits after it was asked for (counted vmcnt)
-            bool again;
-            do {
-                // (spelled out: a `#pragma unroll` over bodies this large is declined, and a rolled loop indexes the sums in scratch)
-                // (a wavefront skips the visits of the rows it does not have — my_rg is wave-uniform)
-                again = visit(0) == WIN * TL_G;
-                if constexpr (RG > 1) { if (my_rg > 1) again |= visit(1) == WIN * TL_G; }
-                if constexpr (RG > 2) { if (my_rg > 2) again |= visit(2) == WIN * TL_G; }
-                if constexpr (RG > 3) { if (my_rg > 3) again |= visit(3) == WIN * TL_G; }
-                if constexpr (RG > 4) { if (my_rg > 4) again |= visit(4) == WIN * TL_G; }
-            } while (again);
+            // One round over the wavefront's rows: every row's window is loaded exactly once per round, in the same order, so that a
+            // row's window is awaited RG - 1 visits after it was asked for (counted vmcnt).  A group that FILLED its window may have
+            // more entries in this tile: those rows — and only those — are visited again until none is left (round 5 went round
+            // ALL the wavefront's rows again: a row of 10,000 entries in K = 10,000 has 256 per tile, eight windows, and made its
+            // wavefront pay seven extra visits of every other row it holds, per tile — tools/tile_stamps.py, `giant`: the
+            // workgroups with such a row took 2.2x the others).  The extra visits are a separate, rarely taken path: the
+            // compiler's waits there are conservative, which is fine.
+            // (spelled out: a `#pragma unroll` over bodies this large is declined, and a rolled loop indexes the sums in scratch;
+            // a wavefront skips the visits of the rows it does not have — my_rg is wave-uniform)
+            constexpr int FULL = WIN * TL_G;
+            unsigned more = visit(0) == FULL ? 1u : 0u;
+            if constexpr (RG > 1) { if (my_rg > 1 && visit(1) == FULL) more |= 2u; }
+            if constexpr (RG > 2) { if (my_rg > 2 && visit(2) == FULL) more |= 4u; }
+            if constexpr (RG > 3) { if (my_rg > 3 && visit(3) == FULL) more |= 8u; }
+            if constexpr (RG > 4) { if (my_rg > 4 && visit(4) == FULL) more |= 16u; }
+            while (more) {                           // (wave-uniform)
+                if (more & 1u) { if (visit(0) != FULL) more &= ~1u; }
+                if constexpr (RG > 1) { if (more & 2u) { if (visit(1) != FULL) more &= ~2u; } }
+                if constexpr (RG > 2) { if (more & 4u) { if (visit(2) != FULL) more &= ~4u; } }
+                if constexpr (RG > 3) { if (more & 8u) { if (visit(3) != FULL) more &= ~8u; } }
+                if constexpr (RG > 4) { if (more & 16u) { if (visit(4) != FULL) more &= ~16u; } }
+            }
         }
         if (stamps && lane == 0) {                   // diagnostic build only (mxd_debug_spmm_tile_stamps): cycles at the barriers / in all
             stamps[((size_t)blockIdx.x * 16 + wave) * 2] = st_wait;
@@ -460,7 +469,7 @@ void tile_unsorted_rows_kernel(int m, const int32_t *__restrict__ indptr, const 
 // their prefix sums in rounds of 1,024, the boundaries by binary search); cuts[0 .. max_blocks]: everything past the last real
 // block is m (empty blocks: the launch is sized by the bound max_blocks, nothing is read back — the product stays capturable).
 __global__ __launch_bounds__(1024)
-void tile_cuts_kernel(int m, int R, const int32_t *__restrict__ indptr, long long E, int32_t *__restrict__ cuts, int max_blocks)
+void tile_cuts_kernel(int m, int R, const int32_t *__restrict__ indptr, long long E, long long E_piece, int32_t *__restrict__ cuts, int max_blocks)
 {
     __shared__ int scan[1024];
     __shared__ int carry;
@@ -474,7 +483,7 @@ void tile_cuts_kernel(int m, int R, const int32_t *__restrict__ indptr, long lon
         if (k < nA) {
             r0 = k * R; r1 = min(r0 + R, m);
             e0 = indptr[r0]; nn = (long long)indptr[r1] - e0;
-            s = (int)min((long long)(r1 - r0), max(1LL, (nn + E - 1) / E));
+            s = nn > E ? (int)min((long long)(r1 - r0), max(1LL, (nn + E_piece - 1) / E_piece)) : 1;
         }
         scan[tid] = s;
         __syncthreads();
@@ -507,7 +516,7 @@ void tile_cuts_kernel(int m, int R, const int32_t *__restrict__ indptr, long lon
 // matrix (sigma 1.5) paid E[max of 4] / mean ~ 2x in every visit and its busiest SIMD half as much again (1e4 x 1e4, 500 per row,
 // n = 100: 0.31 ms where equal rows take 0.108).  Here the rows of a block are RANKED by length (R <= 300: every thread counts
 // the rows ahead of its own) and dealt: ranks 4q .. 4q + 3 share visit q — four rows of nearly the same length —, and the
-// visits, longest first, go to the wavefront with the least work so far.
+// visits, longest first, go to the SIMD with the least work so far (wavefront w sits on SIMD w % 4).
 // A row is still summed by one group in storage order: the same bits.  perm[rb * R + slot] = row, m = no row.
 __global__ __launch_bounds__(256)
 void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const int32_t *__restrict__ indptr, const int32_t *__restrict__ cuts,
@@ -529,28 +538,32 @@ void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const i
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // visits (ranks 4q .. 4q + 3, cost = the longest of them = rank 4q), longest first, each to the WAVEFRONT with the least
-        // work so far that still has a free visit slot (ties: the one on the least-loaded SIMD).  Per wavefront, not per SIMD: a
-        // row with several windows per tile makes its wavefront go round ALL its rows once per window, so what it shares the
-        // wavefront with costs again and again — a block with spare slots (the sub-blocks of tile_cuts_kernel) leaves such a row
-        // alone in its wavefront (tools/tile_stamps.py, log-normal sigma 1.5: waves 60 % of their cycles at the tile barrier).
+        // visits (ranks 4q .. 4q + 3, cost = the longest of them = rank 4q), longest first, each to the SIMD with the least work
+        // (per SIMD, not per wavefront: dealing to the least-loaded WAVEFRONT was measured too — log-normal sigma 1 / 1.5, 1e4 x 1e4:
+        // 0.263 / 0.397 ms against 0.218 / 0.339; the wavefronts of a SIMD share its issue slots, so what counts is their sum)
+        // so far that still has a free visit slot, there to the wavefront with the most free slots.  (The first version dealt
+        // them in snake order over the wavefronts: fine for a smooth length distribution, but one row of 20 mean rows then
+        // shares its SIMD with as many other visits as every other SIMD has.)
         int base[TL_MAX_WAVES + 1], free_[TL_MAX_WAVES];
-        long long load[TL_MAX_WAVES], simd[4] = {0, 0, 0, 0};
+        long long load[4] = {0, 0, 0, 0};
         base[0] = 0;
-        for (int w = 0; w < nw; w++) { free_[w] = (int)((rgw >> (4 * w)) & 15); base[w + 1] = base[w] + free_[w]; load[w] = 0; }
+        for (int w = 0; w < nw; w++) { free_[w] = (int)((rgw >> (4 * w)) & 15); base[w + 1] = base[w] + free_[w]; }
         const int nq = R / TL_NG;
         for (int q = 0; q < nq; q++) {
-            int best_w = -1;
-            for (int w = 0; w < nw; w++) {
-                if (free_[w] <= 0) continue;
-                if (best_w < 0 || load[w] < load[best_w] || (load[w] == load[best_w] && simd[w & 3] < simd[best_w & 3])) best_w = w;
+            int best_c = -1;
+            for (int c = 0; c < 4; c++) {
+                bool has = false;
+                for (int w = c; w < nw; w += 4) has = has || free_[w] > 0;
+                if (has && (best_c < 0 || load[c] < load[best_c])) best_c = c;
             }
+            int best_w = -1;
+            for (int w = best_c; w < nw; w += 4)
+                if (free_[w] > 0 && (best_w < 0 || free_[w] > free_[best_w])) best_w = w;
             const int rg_w = (int)((rgw >> (4 * best_w)) & 15);
             visit_of[q] = (short)(base[best_w] + (rg_w - free_[best_w]));
             free_[best_w]--;
-            // (a visit costs its window bookkeeping whatever its rows hold: ~40 entries' worth; a slot without rows nothing)
-            const long long cost = sorted_len[q * TL_NG] >= 0 ? 40 + (long long)sorted_len[q * TL_NG] : 0;
-            load[best_w] += cost; simd[best_w & 3] += cost;
+            // (a visit costs its window bookkeeping whatever its rows hold: ~40 entries' worth)
+            load[best_c] += 40 + (long long)max(sorted_len[q * TL_NG], 0);
         }
     }
     __syncthreads();
@@ -773,9 +786,15 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
         const int deal_env = de ? atoi(de) : -1;
         const bool deal = deal_env >= 0 ? deal_env != 0 : profile_cv() > 0.15;
         if (deal && nnz > 0 && gm.R <= TL_MAX_WAVES * TL_NG * 5) {
+            // a block above E entries is cut into pieces of E_piece.  A product whose row blocks fill the machine in ONE round of
+            // workgroups pays a whole second round for the first extra block (1e4 x 1e4, log-normal sigma 1.5: 60 -> 68 blocks x 4
+            // slabs = 272 workgroups, 0.235 -> 0.338 ms): there only a block of twice the mean is cut (rows sorted by length:
+            // 0.378 -> 0.230); otherwise from 1.25 mean blocks on.
             const long long mean_block = (long long)((double)nnz / (double)m * gm.R);
-            const long long E = std::max<long long>(1024, mean_block + mean_block / 4);
-            const long long bound = (long long)ceil_div(m, gm.R) + nnz / E + 1;
+            const bool one_round = (long long)ceil_div(m, gm.R) * gm.nslabs <= 256;
+            const long long E = std::max<long long>(1024, one_round ? 2 * mean_block : mean_block + mean_block / 4);
+            const long long E_piece = std::max<long long>(1024, mean_block + mean_block / 4);
+            const long long bound = (long long)ceil_div(m, gm.R) + nnz / E_piece + 1;
             if (bound * gm.nslabs < (1LL << 30)) {
                 const int max_blocks = (int)std::min<long long>(bound, m);
                 const size_t cuts_b = (((size_t)max_blocks + 2) * sizeof(int32_t) + 255) & ~(size_t)255;
@@ -792,7 +811,7 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
                     cuts = (int32_t *)buf; perm = (int32_t *)(buf + cuts_b);
                     gm.nrb = max_blocks;
                     if (build_map) {
-                        hipLaunchKernelGGL(tile_cuts_kernel, dim3(1), dim3(1024), 0, stream, m, gm.R, indptr, E, cuts, max_blocks);
+                        hipLaunchKernelGGL(tile_cuts_kernel, dim3(1), dim3(1024), 0, stream, m, gm.R, indptr, E, E_piece, cuts, max_blocks);
                         hipLaunchKernelGGL(tile_deal_rows_kernel, dim3((unsigned)max_blocks), dim3(256), 0, stream, m, gm.R, gm.nw, gm.rgw, indptr, cuts, perm);
                     }
                 } else (void)hipGetLastError();                          // (no memory for the map: consecutive rows)

@@ -788,13 +788,14 @@ double rowsplit_est_us(int m, int n, int K, int dense_bytes, double avg_len, int
         // 64 / G rows per wavefront, as long as the longest of them (real row lengths are skewed: tools/zipf_map.py — m = 1e6,
         // 9 per row, log-normal sigma .5, n = 16: 0.131 ms where equal rows take 0.061)
         lockstep = lockstep_factor(profile_cv(), 64 / G);
-    } else if (profile_cv() > 0.15) {
-        // one wavefront per row (segment): the long rows are the launch's tail even with the long-rows pieces — measured on
-        // log-normal rows (tools/cliff_hunt.py, round 5; sigma 1 / 1.5 = cv 1.1 / 1.8): 1.5-1.7x the equal-rows rate at m >= 1e5,
-        // 2.9-3.2x at m = 1e4 with 500 per row, where the rows alone do not fill the machine.  (Without this term AUTO kept the
-        // dense-ish skewed products on this kernel — 0.31 ms — when the tile kernel with dealt rows takes 0.22.)
+    } else if (profile_cv() > 0.15 && m < 50000) {
+        // one wavefront per row (segment) and too few rows to fill the machine: the long rows are the launch's tail even with the
+        // long-rows pieces — measured on log-normal rows (tools/cliff_hunt.py, round 5; sigma 1 / 1.5 = cv 1.1 / 1.8): 2.9-3.2x the
+        // equal-rows rate at m = 1e4 with 500 per row.  (Without this term AUTO kept the dense-ish skewed products on this kernel —
+        // 0.31 ms — when the tile kernel with dealt rows takes 0.175.  From 5e4 rows on the slowdown is 1.5x and the model was
+        // fitted on skewed data there — real-sim's shape, tests/test_gpu_zipf.py — so nothing is added.)
         const double cv = profile_cv() < 1.5 ? profile_cv() : 1.5;
-        lockstep = 1.0 + cv * (m < 50000 ? 0.6 : 0.33);
+        lockstep = 1.0 + cv * 0.6;
     }
     // the hit rate: the mass of the entries whose row of B an XCD's L2 (4 MiB) holds — the hottest 4 MiB / (n s) rows of the
     // panel —, which for uniform columns is the share of the panel's bytes (round 4's term); hot columns sit anywhere, so P

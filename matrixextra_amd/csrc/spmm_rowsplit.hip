@@ -232,7 +232,15 @@ void longrows_fit_kernel(int m, const int32_t *__restrict__ indptr, int piece, u
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { rows += __shfl_xor(rows, o, 64); pieces += __shfl_xor(pieces, o, 64); }
-    if (lane_id() == 0 && rows) { atomicAdd(&head[4], rows); atomicAdd(&head[5], pieces); }
+    // one pair of atomics per WORKGROUP (<= 32 of them): same-address atomics are served one after the other at the memory side —
+    // the first version's two per wavefront of 256 workgroups cost ~20 us (cliff hunt: 0.131 -> 0.157 ms on a product with long rows)
+    __shared__ unsigned s_rows[4], s_pieces[4];
+    if (lane_id() == 0) { s_rows[threadIdx.x >> 6] = rows; s_pieces[threadIdx.x >> 6] = pieces; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned r4 = s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3], p4 = s_pieces[0] + s_pieces[1] + s_pieces[2] + s_pieces[3];
+        if (r4) { atomicAdd(&head[4], r4); atomicAdd(&head[5], p4); }
+    }
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(&head[3], 1u) == gridDim.x - 1) {
@@ -681,7 +689,7 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
         lr.piece = long_piece;
         E = (real_t *)(buf + head + 2 * rows_b + po_b);
         MX_HIP(hipMemsetAsync(buf, 0, 32, stream));
-        hipLaunchKernelGGL(longrows_fit_kernel, dim3((unsigned)std::min<long long>(256, ceil_div(m, 256))), dim3(256), 0, stream,
+        hipLaunchKernelGGL(longrows_fit_kernel, dim3((unsigned)std::min<long long>(32, ceil_div(m, 256))), dim3(256), 0, stream,
                            m, indptr, long_piece, (unsigned)slots, (unsigned)pieces, (unsigned *)buf);
         g_longrows_last = lr.counter;
     }

@@ -449,12 +449,17 @@ extern "C" int mxd_spmv_plan_create(int m, int K, const int32_t *indptr, const i
         int32_t ends[2] = {0, 0};
         if (read_back_small(&ends[0], indptr, sizeof(int32_t), st) || read_back_small(&ends[1], indptr + m, sizeof(int32_t), st)) break;
         pl->nnz = (long long)ends[1] - ends[0];
-        // row blocks: 4,096 rows, cut further where they hold more than E entries (1.06 mean blocks, at least 32k: a block must
+        // row blocks: 4,096 rows, cut further where they hold more than E entries (1.06 mean blocks — 2 in a one-round launch —, at least 32k: a block must
         // be worth a workgroup) — spmv_plan_cuts_kernel
         const long long mean_block = (long long)((double)pl->nnz / (double)m * SP_RB);
         // (pieces of half a mean block: with heavy-first dispatch the launch then ends within half a block of the ideal — rows
-        // sorted by length, cfg3's shape: pieces of one mean block 0.142 ms, equal rows 0.079)
-        const long long E = std::max<long long>(32768, mean_block + mean_block / 16), E_piece = std::max<long long>(16384, mean_block / 2);
+        // sorted by length, cfg3's shape: pieces of one mean block 0.142 ms, half a block 0.117, equal rows 0.079.  When the 4,096-row
+        // blocks fill the machine in ONE round of workgroups — cfg3: 245 on 256 CUs — the first extra block costs a whole second
+        // round: log-normal rows, sigma 1.5, a dozen blocks a few percent above the mean, 0.114 -> 0.170 ms; there only a block of
+        // twice the mean is cut)
+        const bool one_round = ceil_div(m, SP_RB) <= 256;
+        const long long E = std::max<long long>(32768, one_round ? 2 * mean_block : mean_block + mean_block / 16);
+        const long long E_piece = std::max<long long>(16384, mean_block / 2);
         const int nA = (int)ceil_div(m, SP_RB);
         const int max_cuts = (int)std::min<long long>((long long)nA + pl->nnz / E_piece + 1, (long long)m);
         long long *nrb_dev = nullptr;

@@ -221,7 +221,8 @@ __device__ __forceinline__ int long_piece_of(const LongRows &lr) { return lr.pie
 // every kernel of the launch alike — whether they fit the scratch (`cap_rows` list slots, `cap_pieces` partial-sum rows).
 // The scratch is sized from what the matrix profile knows (LongHint), capped; a caller whose hint was for another matrix, or a
 // matrix with more long rows than the cap holds, gets the plain kernels: slower, never wrong, nothing written out of bounds.
-// head: [0] the registration counter (u64), [2] fit, [3] workgroups done, [4..5] needed rows / pieces (for the debug entry)
+// head: [0] the registration counter (u64), [2] fit, [3] workgroups done, [4..5] needed rows / pieces (for the debug entry),
+// [16 ..] one (rows, pieces) partial per workgroup
 __global__ __launch_bounds__(256)
 void longrows_fit_kernel(int m, const int32_t *__restrict__ indptr, int piece, unsigned cap_rows, unsigned cap_pieces, unsigned *head)
 {
@@ -232,21 +233,35 @@ void longrows_fit_kernel(int m, const int32_t *__restrict__ indptr, int piece, u
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { rows += __shfl_xor(rows, o, 64); pieces += __shfl_xor(pieces, o, 64); }
-    // one pair of atomics per WORKGROUP (<= 32 of them): same-address atomics are served one after the other at the memory side —
-    // the first version's two per wavefront of 256 workgroups cost ~20 us (cliff hunt: 0.131 -> 0.157 ms on a product with long rows)
+    // One partial per WORKGROUP into its own two words (head[16 + 2 b], up to 256 workgroups), added up by the last one to finish:
+    // same-address atomics are served one after the other at the memory side — the first version's two per wavefront of 256
+    // workgroups cost ~20 us (cliff hunt: 0.131 -> 0.157 ms on a product with long rows), 32 workgroups with one pair each were
+    // too few threads for a million row pointers (0.137 -> 0.18 ms).  What remains is one counter increment per workgroup.
     __shared__ unsigned s_rows[4], s_pieces[4];
+    __shared__ bool last;
     if (lane_id() == 0) { s_rows[threadIdx.x >> 6] = rows; s_pieces[threadIdx.x >> 6] = pieces; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned r4 = s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3], p4 = s_pieces[0] + s_pieces[1] + s_pieces[2] + s_pieces[3];
-        if (r4) { atomicAdd(&head[4], r4); atomicAdd(&head[5], p4); }
-    }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(&head[3], 1u) == gridDim.x - 1) {
+        head[16 + 2 * blockIdx.x] = s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3];
+        head[17 + 2 * blockIdx.x] = s_pieces[0] + s_pieces[1] + s_pieces[2] + s_pieces[3];
         __threadfence();
-        const unsigned nr = __hip_atomic_load(&head[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned np = __hip_atomic_load(&head[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = atomicAdd(&head[3], 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    unsigned nr = 0, np = 0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+        nr += __hip_atomic_load(&head[16 + 2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        np += __hip_atomic_load(&head[17 + 2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { nr += __shfl_xor(nr, o, 64); np += __shfl_xor(np, o, 64); }
+    if (lane_id() == 0) { s_rows[threadIdx.x >> 6] = nr; s_pieces[threadIdx.x >> 6] = np; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        nr = s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3]; np = s_pieces[0] + s_pieces[1] + s_pieces[2] + s_pieces[3];
+        head[4] = nr; head[5] = np;
         head[2] = nr <= cap_rows && np <= cap_pieces ? 1u : 0u;
     }
 }
@@ -659,7 +674,7 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
     real_t *E = nullptr;
     g_longrows_last = nullptr;
     char *buf = nullptr;
-    size_t head = 256, rows_b = 0, po_b = 0, slots = 0, pieces = 0;
+    size_t head = 2560, rows_b = 0, po_b = 0, slots = 0, pieces = 0;       // (256 bytes of counters + 256 x 2 partials of the fit kernel)
     if (long_piece > 0 && nnz > long_piece) {
         slots = (size_t)(nnz / long_piece) + 1;
         pieces = 2 * slots;
@@ -689,7 +704,7 @@ static int launch_rowsplit(int m, int n, int K, int S, int P, const int32_t *ind
         lr.piece = long_piece;
         E = (real_t *)(buf + head + 2 * rows_b + po_b);
         MX_HIP(hipMemsetAsync(buf, 0, 32, stream));
-        hipLaunchKernelGGL(longrows_fit_kernel, dim3((unsigned)std::min<long long>(32, ceil_div(m, 256))), dim3(256), 0, stream,
+        hipLaunchKernelGGL(longrows_fit_kernel, dim3((unsigned)std::min<long long>(256, ceil_div(m, 1024))), dim3(256), 0, stream,
                            m, indptr, long_piece, (unsigned)slots, (unsigned)pieces, (unsigned *)buf);
         g_longrows_last = lr.counter;
     }

@@ -399,10 +399,14 @@ int mxd_spmv_csr_dvec_ex2(int m, int K, int64_t nnz,
  * (block of 4096 rows, panel of 6144 columns) so that the kernel can keep the panel of v it needs in LDS instead of
  * gathering v[j] from L2 — the gather, not the (j, a) stream, bounds the one-shot kernels.  Build once per matrix
  * (about the cost of six one-shot products — ~1 ms at cfg3 —; one internal stream sync), run against any number of vectors of any of
- * the four kinds.  K <= 64 * 6144 columns.  Sums: panels in ascending order, entries of a row inside a panel added with
+ * the four kinds.  Row blocks hold at most 4096 rows and — rows of uneven length — about half a mean block's entries where a
+ * block would be heavy (cut on the device).  Up to 64 * 6144 columns the panels of v sit in LDS; WIDER matrices (up to 2^28
+ * columns; round 6) are regrouped by super-panels of 2^18 columns and run ONE LAUNCH PER SUPER-PANEL, v read from global memory
+ * (every workgroup of a launch from the same 2 MB, which the L2s then hold), y added to from launch to launch — mxd_spmv_plan_run
+ * then queues ceil(K / 2^18) launches.  Sums: panels in ascending order, entries of a row inside a panel added with
  * LDS atomics — equal to the reference to 1e-12 (f64) / 1e-5 (float32 kind), not bitwise and not bit-reproducible from
- * run to run; the float32 kind keeps f64 sums and rounds ONCE at the end, where the reference accumulates in float and
- * rounds per term (src/matmul.cpp:403).  Integer / logical vectors: a row that meets an NA element yields NA_real_, a NaN
+ * run to run; the float32 kind keeps f64 sums and rounds ONCE at the end (once per super-panel for wide matrices), where the
+ * reference accumulates in float and rounds per term (src/matmul.cpp:403).  Integer / logical vectors: a row that meets an NA element yields NA_real_, a NaN
  * that comes out of the arithmetic stays an ordinary NaN (as the reference).  The one-shot MX_SPMV_FLAT kernel is the
  * bit-exact path. */
 typedef struct mx_spmv_plan mx_spmv_plan;

@@ -303,8 +303,9 @@ int mxd_spmm_plan_destroy(mx_spmm_plan *plan);
 int mxd_spmm_plan_info(const mx_spmm_plan *plan, int *npanels, int64_t *padded_entries);
 int mxd_spmm_plan_octet_cv(const mx_spmm_plan *plan, double *cv);
 /* longest work item (one octet x one 128-byte slab of B) over its share of the machine, for a B of n columns: above 2.5
- * AUTO runs the row-split kernel instead of this plan (rows sorted by length, a few giant rows against a narrow B) */
+ * (f32) / 4.5 (f64) AUTO runs the row-split kernel instead of this plan (rows sorted by length, a few giant rows against a narrow B) */
 int mxd_spmm_plan_imbalance(const mx_spmm_plan *plan, int n, int dense_dtype, double *imbalance);
+double mxd_spmm_plan_imbalance_limit(int dense_dtype);    /* the limit AUTO applies: 4.5 for f64 products, 2.5 for f32 (round 6) */
 int mxd_spmm_plan_run(const mx_spmm_plan *plan, int n, const void *B, size_t ldb, void *C, size_t ldc,
                       int dense_dtype, int colmajor_out, int wg_per_cu, int sync_mode, void *stream);
 /* rows [row0, row0 + nrows) of the planned matrix only (row0 a multiple of 64); C points at the block's first row, ldc is the

@@ -56,6 +56,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     lib.mx_last_error.restype = C.c_char_p
     lib.mxd_spmm_last_kernel.restype = C.c_char_p
+    lib.mxd_spmm_plan_imbalance_limit.restype = C.c_double
     lib.mxd_merge_workspace_bytes.restype = C.c_size_t
     lib.mxd_gather_workspace_bytes.restype = C.c_size_t
     lib.mxd_scan_workspace_bytes.restype = C.c_size_t

@@ -254,7 +254,7 @@ static int kept_spmm(Shard &s, int K, int n, int dt, const void *B, size_t ldb, 
         if (use) {
             double imb = 0.0;
             if (mxd_spmm_plan_imbalance(s.plan, n, dt, &imb)) return 1;
-            use = imb <= 2.5;
+            use = imb <= mxd_spmm_plan_imbalance_limit(dt);
         }
         if (use) {
             snprintf(s.kernel, sizeof(s.kernel), "spmm_plan_kernel");

@@ -280,7 +280,7 @@ int spmm_block(const SpmmFamily &fam, bool from_auto, int m, int n, int K, int64
         if (ok && K < (1 << 25)) {
             bool ready = false;
             if (plan_auto_build(m, K, indptr, indices, values, npanels, st, 1.55, &ready)) return 1;
-            if (ready && nnz >= 0 && plan_auto_imbalance(n, dense_dtype == MX_F64 ? 8 : 4) > MX_PLAN_MAX_IMBALANCE) ready = false;
+            if (ready && nnz >= 0 && plan_auto_imbalance(n, dense_dtype == MX_F64 ? 8 : 4) > plan_max_imbalance(dense_dtype == MX_F64 ? 8 : 4)) ready = false;
             if (ready) return plan_auto_run(n, B, ldb, C, ldc, dense_dtype, colmajor, st);
         }
         family = nnz >= 0 ? MX_SPMM_ROWSPLIT : MX_SPMM_ROWWAVE;       // (very uneven rows: the plan would pad too much)
@@ -421,7 +421,7 @@ extern "C" int mxd_spmm_csr_dense_ex2(int m, int n, int K, int64_t nnz,
         bool ready = false;          // the plan's buffers are re-used from call to call (grow-only, per thread)
         if (mx::plan_auto_build(m, K, indptr, indices, values, npanels, st, auto_pick_planned ? 1.55 : 0.0, &ready)) return 1;
         // (one octet that outlasts the rest of the sweep: the row-split kernel and its long-rows path instead)
-        if (ready && auto_pick_planned && nnz >= 0 && mx::plan_auto_imbalance(n, dense_dtype == MX_F64 ? 8 : 4) > mx::MX_PLAN_MAX_IMBALANCE)
+        if (ready && auto_pick_planned && nnz >= 0 && mx::plan_auto_imbalance(n, dense_dtype == MX_F64 ? 8 : 4) > mx::plan_max_imbalance(dense_dtype == MX_F64 ? 8 : 4))
             ready = false;
         if (ready) return mx::plan_auto_run(n, B, ldb, C, ldc, dense_dtype, colmajor_out, stream);
         if (nnz >= 0)                                                // (very uneven rows: the plan would pad too much)
@@ -461,3 +461,6 @@ extern "C" int mxd_spmm_csr_dense(int m, int n,
                                        colmajor_out, st);
     return mx::set_error("mxd_spmm_csr_dense: unsupported dense dtype %d", dense_dtype);
 }
+
+// the imbalance (mxd_spmm_plan_imbalance) above which AUTO leaves a kept plan for the row-split kernel, by element type
+extern "C" double mxd_spmm_plan_imbalance_limit(int dense_dtype) { return mx::plan_max_imbalance(dense_dtype == MX_F64 ? 8 : 4); }

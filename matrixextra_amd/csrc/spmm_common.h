@@ -155,7 +155,11 @@ int plan_auto_build(int m, int K, const int32_t *indptr, const int32_t *indices,
                     hipStream_t st, double max_pad_ratio, bool *ready);
 int plan_auto_run(int n, const void *B, size_t ldb, void *C, size_t ldc, int dense_dtype, int colmajor, void *stream);
 double plan_auto_imbalance(int n, int dense_bytes);       // of the plan plan_auto_build just built (spmm_plan.hip plan_imbalance)
-constexpr double MX_PLAN_MAX_IMBALANCE = 2.5;
+// above this AUTO leaves a plan for the row-split kernel.  By element size (round 6, tools/plan_imbalance_probe.py): the tail of an
+// unbalanced sweep is step-bound — as long in f32 as in f64 — while the row-split kernel moves half the bytes in f32: f32 products
+// are better off there from 2.5 on (2.5-2.8: 0.107-0.13 ms against 0.125-0.19), f64 products only from ~4.5 (2e5 x 5e4, n = 32, imbalance
+// 3.1 / 3.9: planned 0.43 / 0.40 ms, row-split 0.57 / 0.59; 3e5 x 1e5 at 5.5: planned 1.21, row-split 0.97)
+inline double plan_max_imbalance(int dense_bytes) { return dense_bytes == 8 ? 4.5 : 2.5; }
 void plan_auto_release();
 
 // ---- scan.hip

@@ -198,7 +198,7 @@ def spmm(A: DeviceCSR, B: torch.Tensor, out: torch.Tensor | None = None, colmajo
             if plan is not None:
                 imb = C.c_double(0.0)
                 check(lib.mxd_spmm_plan_imbalance(plan, C.c_int(n), C.c_int(dt), C.byref(imb)))
-                if imb.value > 2.5:                                  # one octet outlasts the sweep (spmm_plan.hip plan_imbalance)
+                if imb.value > lib.mxd_spmm_plan_imbalance_limit(C.c_int(dt)):   # one octet outlasts the sweep (spmm_plan.hip plan_imbalance)
                     plan = None
             if plan is not None:
                 check(lib.mxd_spmm_plan_run(plan, C.c_int(n), _dp(B), C.c_size_t(B.stride(0)), _dp(out), C.c_size_t(ldc),

@@ -439,6 +439,10 @@ int mx_debug_last_export_family(int *family, int *segments, int *panels, int *lo
  * *nnz_out_host (pinned or pageable host int64) is written after an internal
  * stream sync — the one host round trip of the operation.  nnz1 / nnz2 only
  * steer the lanes-per-row choice (pass -1 when unknown). */
+/* hint for the device-level merges of the calling thread (sticky): the operands' rows are of uneven length (coefficient of variation
+ * above ~0.3) — the lane groups then take one width up (round 6: 14-15 % on log-normal rows; 10 % slower on rows of equal length,
+ * hence not the default).  The export level reads the host row pointers and needs no hint. */
+int mxd_csr_merge_rows_uneven(int on);
 size_t mxd_merge_workspace_bytes(int m);
 int mxd_csr_merge_count(int op, int m,
                         const int32_t *indptr1, const int32_t *indices1, int64_t nnz1,

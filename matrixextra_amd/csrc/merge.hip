@@ -690,6 +690,10 @@ int merge_group(int m, int64_t nnz1, int64_t nnz2)
     // showed as +15 % on a 0.29-ms merge of 1e5 entries (bench.py export_small_calls)
     if (nnz1 + nnz2 >= (1LL << 21)) g_merge_long_T = 8.0 * avg > (double)MERGE_LONG_T ? (avg < 1e8 ? (int)(8.0 * avg) : INT_MAX) : MERGE_LONG_T;
     const int G = pick_group(avg, 8);
+    if (const char *e = getenv("MXGPU_MERGE_G")) {                    // (tools/merge_skew_probe.py: the lane-group width under skew)
+        const int g = atoi(e);
+        if (g == 8 || g == 16 || g == 32 || g == 64) return g;
+    }
     return g_merge_widen && G < 64 ? 2 * G : G;
 }
 
@@ -914,5 +918,16 @@ extern "C" int mxd_csr_merge_fused(int op, int m, const int32_t *indptr1, const 
         MX_REQUIRE(*nnz_out_host <= (int64_t)INT_MAX, "result has %lld entries: exceeds R's int32 index range",
                    (long long)*nnz_out_host);
     }
+    return 0;
+}
+
+// Rows of uneven length at the DEVICE level (round 6): the lane-group width follows the mean row length; with skewed rows the pairs
+// that do not fit take the sliding windows, and one width up is faster (1e6 x 1e5, 32 per row, log-normal sigma 1: `+` 0.866 -> 0.746 ms,
+// `*` 0.618 -> 0.524; rows of equal length: 0.45 -> 0.51, hence a hint and not the default).  The export level decides this from the
+// host row pointers by itself; a device-level caller that knows its operands (matrixextra_amd/device.py: the cached matrix profile's
+// cv) says so here — for the merges this thread launches from now on, until told otherwise.
+extern "C" int mxd_csr_merge_rows_uneven(int on)
+{
+    mx::merge_group_widen(on != 0);
     return 0;
 }

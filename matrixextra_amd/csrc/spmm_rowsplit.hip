@@ -166,9 +166,18 @@ __device__ __forceinline__ PanelWhere panel_where(int nbx, int passes)
     w.pass = (int)(t - (unsigned)w.p * (unsigned)passes);
     return w;
 }
+// (The predecessor — the same row block of the previous panel — has a lower workgroup id and is dispatched first; the hardware
+// dispatches in order, which no specification promises.  Should that ever fail with every CU held by waiting workgroups the wait
+// would never end: it is BOUNDED — 2^24 polls of ~130 cycles, about a second, three orders of magnitude beyond the longest
+// workgroup — and then traps: the launch fails loudly (the next synchronisation reports it) instead of hanging the device.
+// MXGPU_ROWSPLIT_LAUNCHES=1 runs one launch per panel, without any wait.)
 __device__ __forceinline__ void panel_wait(const unsigned *word, int p)
 {
-    while ((int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p) __builtin_amdgcn_s_sleep(2);
+    unsigned polls = 0;
+    while ((int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++polls > (1u << 24)) __builtin_trap();
+    }
     asm volatile("" ::: "memory");            // the reads of C stay behind the last poll
 }
 // every thread's stores of C have left, then one thread counts the workgroup in

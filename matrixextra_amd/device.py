@@ -294,6 +294,9 @@ def csr_elemwise(op, A: DeviceCSR, B: DeviceCSR, two_pass: bool = True):
                                       _dp(out_p), _dp(out_j), _dp(out_x), _dp(ws), C.byref(nnz_out), _stream()))
         n = int(nnz_out.value)
         return DeviceCSR(out_p, out_j[:n], out_x[:n], A.m, A.K, n)
+    # rows of uneven length (the cached matrix profiles' cv): one lane-group width up (mxd_csr_merge_rows_uneven)
+    uneven = A.nnz + B.nnz >= (1 << 21) and max(A.profile()[32], B.profile()[32]) > 0.3
+    lib.mxd_csr_merge_rows_uneven(C.c_int(int(uneven)))
     ws = torch.empty(lib.mxd_merge_workspace_bytes(A.m), dtype=torch.uint8, device=dev)
     out_p = torch.empty(A.m + 1, dtype=torch.int32, device=dev)
     nnz_out = C.c_int64(0)
@@ -305,6 +308,7 @@ def csr_elemwise(op, A: DeviceCSR, B: DeviceCSR, two_pass: bool = True):
     check(lib.mxd_csr_merge_fill(C.c_int(op), C.c_int(A.m), _dp(A.indptr), _dp(A.indices), _dp(A.values),
                                  C.c_int64(A.nnz), _dp(B.indptr), _dp(B.indices), _dp(B.values), C.c_int64(B.nnz),
                                  _dp(out_p), _dp(out_j), _dp(out_x), _stream()))
+    lib.mxd_csr_merge_rows_uneven(C.c_int(0))
     return DeviceCSR(out_p, out_j, out_x, A.m, A.K, int(nnz_out.value))
 
 

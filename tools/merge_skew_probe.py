@@ -18,7 +18,12 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "lognormal_1.0"
 m, K, mean = (int(os.environ.get("PROBE_M", 2_000_000)), int(os.environ.get("PROBE_K", 2_000_000)), int(os.environ.get("PROBE_MEAN", 50)))
 A = build(m, K, lens_of(kind, m, mean, np.random.default_rng(7)), 7)
 A2 = build(m, K, lens_of(kind, m, mean, np.random.default_rng(8)), 8)
-for name, op in (("add", _lib.MX_OP_ADD), ("mul", _lib.MX_OP_MUL)):
-    f = lambda: D.csr_elemwise(op, A, A2)
-    f(); f()
-    print(kind, name, "ms", round(timeit(f, reps=6), 4), "nnz", A.nnz, A2.nnz, flush=True)
+for g in ([None] if not os.environ.get("PROBE_G_SWEEP") else [None, "16", "32", "64"]):
+    if g is None:
+        os.environ.pop("MXGPU_MERGE_G", None)
+    else:
+        os.environ["MXGPU_MERGE_G"] = g
+    for name, op in (("add", _lib.MX_OP_ADD), ("mul", _lib.MX_OP_MUL)):
+        f = lambda: D.csr_elemwise(op, A, A2)
+        f(); f()
+        print(kind, "G", g, name, "ms", round(timeit(f, reps=6), 4), "nnz", A.nnz, A2.nnz, flush=True)

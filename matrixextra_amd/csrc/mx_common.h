@@ -82,6 +82,7 @@ enum { MX_SCRATCH_SPMV_SLICES = 0, MX_SCRATCH_PARTIALS = 1, MX_SCRATCH_EXPORT_B 
        MX_SCRATCH_TILE_PERM = 11,     // slot -> row map of the tile kernel for rows of uneven length (spmm_tile.hip)
        MX_SCRATCH_SLOTS = 12 };
 void *scratch_buffer(int slot, size_t bytes);
+unsigned scratch_generation(int slot);           // changes whenever the slot's buffer is (re)allocated — also after scratch_release
 void *scratch_buffer_zeroed(int slot, size_t bytes, hipStream_t st, bool *fresh);   // zero-filled when (re)allocated
 void scratch_release();
 void scratch_acquire(int slot, hipStream_t st);     // before queueing work that uses the slot: waits for the previous user when the stream changed

@@ -151,6 +151,7 @@ struct Scratch {
     hipEvent_t done = nullptr;               // recorded behind the last user (scratch_done); an event outlives its stream
     hipStream_t last = nullptr;
     bool used = false;
+    unsigned gen = 0;                        // counts the (re)allocations: what a user keeps IN the buffer between calls is gone when it changes
 };
 thread_local Scratch g_scratch[16][MX_SCRATCH_SLOTS];
 Scratch &scratch_slot(int slot)
@@ -190,9 +191,11 @@ void *scratch_buffer(int slot, size_t bytes)
         const size_t want = bytes + std::min<size_t>(bytes / 2, (size_t)256 << 20) + 4096;   // (fresh VRAM is cleared by the copy engines: 12 GB for an 8 GB result delayed that call's uploads by ~100 ms)
         if (hipMalloc(&w.p, want) != hipSuccess) { w.p = nullptr; return nullptr; }
         w.cap = want;
+        w.gen++;
     }
     return w.p;
 }
+unsigned scratch_generation(int slot) { return scratch_slot(slot).gen; }
 // the same buffer, zero-filled whenever it is (re)allocated (state that kernels reset themselves afterwards)
 void *scratch_buffer_zeroed(int slot, size_t bytes, hipStream_t st, bool *fresh)
 {

@@ -800,11 +800,11 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
                 const size_t cuts_b = (((size_t)max_blocks + 2) * sizeof(int32_t) + 255) & ~(size_t)255;
                 char *buf = (char *)scratch_buffer(MX_SCRATCH_TILE_PERM, cuts_b + (size_t)max_blocks * gm.R * sizeof(int32_t));
                 if (buf) {
-                    struct Key { const void *indptr, *buf; long long nnz; unsigned long long rgw; int m, R, nw, nl, max_blocks, pad; };   // (no padding bytes: compared with memcmp)
+                    struct Key { const void *indptr, *buf; long long nnz; unsigned long long rgw; int m, R, nw, nl, max_blocks; unsigned gen; };   // (no padding bytes: compared with memcmp; gen: the buffer's allocation — a freed and re-allocated buffer may come back at the same address)
                     static thread_local Key kept[16] = {};
                     int dev = 0;
                     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-                    const Key now = {indptr, buf, (long long)nnz, gm.rgw, m, gm.R, gm.nw, gm.nl, max_blocks, 0};
+                    const Key now = {indptr, buf, (long long)nnz, gm.rgw, m, gm.R, gm.nw, gm.nl, max_blocks, scratch_generation(MX_SCRATCH_TILE_PERM)};
                     build_map = memcmp(&kept[dev], &now, sizeof(Key)) != 0;
                     kept[dev] = now;
                     scratch_acquire(MX_SCRATCH_TILE_PERM, stream);

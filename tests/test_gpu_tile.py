@@ -213,5 +213,11 @@ def test_tile_rows_dealt_by_length_keep_every_bit(gpu, monkeypatch, colmajor, dt
         from matrixextra_amd import device as D
         A = D.DeviceCSR.from_host(p, j, x, K)
         assert A.profile()[32] > 0.15
-        got = D.spmm(A, torch.from_numpy(B).cuda(), colmajor=colmajor, algo=TILE).cpu().numpy()
+        Bd = torch.from_numpy(B).cuda()
+        got = D.spmm(A, Bd, colmajor=colmajor, algo=TILE).cpu().numpy()
         _same(got, ref)
+        # the cuts and the slot -> row map are kept for the next product with the same row pointers; they must not survive the
+        # release of the thread's workspaces (a freed buffer may come back at the same address)
+        _same(D.spmm(A, Bd, colmajor=colmajor, algo=TILE).cpu().numpy(), ref)
+        _lib.check(_lib.load().mxd_release_workspaces())
+        _same(D.spmm(A, Bd, colmajor=colmajor, algo=TILE).cpu().numpy(), ref)

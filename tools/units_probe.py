@@ -44,6 +44,9 @@ PROGRAMS = {
     # (the sweep alone — tools/sweep_time.py, cfg2 drawn on the device, 3 + 6 products: a counter pass of the whole bench.py
     # command took 7 minutes, most of it the profiler around the thousands of small launches of its input generation and checks)
     "spmm_plan_kernel_cfg2": (["python3", os.path.join(ROOT, "tools", "sweep_time.py"), "cfg2"], "spmm_plan_kernel", "all"),
+    # (UNITS_CFG5=1: the same series on configs[4]'s per-GPU shard — f32, n = 256, 64 per row — instead of the bare gather)
+    **({"spmm_plan_kernel_cfg5_shard": (["python3", os.path.join(ROOT, "tools", "sweep_time.py"), "cfg5"], "spmm_plan_kernel", "all")}
+       if os.environ.get("UNITS_CFG5") else {}),
     "bare_gather_B_4MB_16waves_x8": ([os.path.join(ROOT, "tools/microbench/build/spmm_gather_ceiling")], "gather<8, 1024>", "second_half"),
     "bare_gather_B_102MB_16waves_x8": ([os.path.join(ROOT, "tools/microbench/build/spmm_gather_ceiling")], "gather<8, 1024>", "first_half"),
 }
@@ -80,6 +83,8 @@ def main():
     for tag, (argv, filt, keep) in PROGRAMS.items():
         if tag.startswith("bare_gather_B_102MB"):
             continue                                            # same passes as the 4 MB run: split below
+        if os.environ.get("UNITS_CFG5") and not tag.endswith("cfg5_shard"):
+            continue
         acc = collections.defaultdict(lambda: collections.defaultdict(dict))        # counter -> dispatch -> value
         for i, p in enumerate(PASSES):
             cs = [c for c in p.split() if re.search(r'\b%s\b' % c, av)]
@@ -89,12 +94,14 @@ def main():
             # killed — twice, 39 and 10 minutes: they are taken on the torch-free microbenchmark only)
             if "STALLED_BY" in p and argv[0].startswith("python"):
                 continue
-            for r in run_pass(tag.split("_B_")[0], i, cs, argv):
+            for r in run_pass(tag.split("_B_")[0] if "_B_" in tag else tag, i, cs, argv):
                 if filt in r["Kernel_Name"]:
                     acc[r["Counter_Name"]][int(r["Dispatch_Id"])] = float(r["Counter_Value"])
         done[tag] = acc
     res = {"what": __doc__.split("\n\n")[0], "passes": PASSES, "kernels": {}}
     for tag, (argv, filt, keep) in PROGRAMS.items():
+        if tag not in done and "bare_gather_B_4MB_16waves_x8" not in done:
+            continue
         acc = done[tag if tag in done else "bare_gather_B_4MB_16waves_x8"]
         k = {}
         for c, by in sorted(acc.items()):
@@ -107,7 +114,7 @@ def main():
             if v:
                 k[c] = {"launches": len(v), "mean": sum(v) / len(v)}
         res["kernels"][tag] = {"filter": filt, "counters": k, "derived": derive(k)}
-    json.dump(res, open(os.path.join(OUT, "r06_cfg2_units.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(OUT, "r06_cfg5_units.json" if os.environ.get("UNITS_CFG5") else "r06_cfg2_units.json"), "w"), indent=1)
     for tag, k in res["kernels"].items():
         print(tag)
         for n, v in k["derived"].items():

@@ -52,12 +52,12 @@ static_assert(13 + SP_WIDE_BITS <= 31, "row-in-block (0 .. 4096) and column-in-p
 // in rounds of 1,024), then every sub-block boundary.  cuts[0 .. nrb], nrb = the total — read back by the host (the build
 // synchronises anyway).  Rows of equal length: s = 1 everywhere, exactly the blocks of rounds 2-5.
 __global__ __launch_bounds__(1024)
-void spmv_plan_cuts_kernel(int m, const int32_t *__restrict__ indptr, long long E, long long E_piece, int32_t *__restrict__ cuts, int max_cuts,
+void spmv_plan_cuts_kernel(int m, int RB, const int32_t *__restrict__ indptr, long long E, long long E_piece, int32_t *__restrict__ cuts, int max_cuts,
                            long long *__restrict__ nrb_out)
 {
     __shared__ int scan[1024];
     __shared__ int carry;
-    const int nA = (int)((m + SP_RB - 1) / SP_RB), tid = threadIdx.x;
+    const int nA = (int)((m + RB - 1) / RB), tid = threadIdx.x;
     if (tid == 0) carry = 0;
     __syncthreads();
     for (int k0 = 0; k0 < nA; k0 += 1024) {
@@ -65,7 +65,7 @@ void spmv_plan_cuts_kernel(int m, const int32_t *__restrict__ indptr, long long 
         int s = 0, r0 = 0, r1 = 0;
         long long e0 = 0, nn = 0;
         if (k < nA) {
-            r0 = k * SP_RB; r1 = min(r0 + SP_RB, m);
+            r0 = k * RB; r1 = min(r0 + RB, m);
             e0 = indptr[r0]; nn = (long long)indptr[r1] - e0;
             s = nn > E ? (int)((nn + E_piece - 1) / E_piece) : 1;
             s = max(1, min(s, r1 - r0));                               // (never more sub-blocks than rows)
@@ -451,21 +451,25 @@ extern "C" int mxd_spmv_plan_create(int m, int K, const int32_t *indptr, const i
         pl->nnz = (long long)ends[1] - ends[0];
         // row blocks: 4,096 rows, cut further where they hold more than E entries (1.06 mean blocks — 2 in a one-round launch —, at least 32k: a block must
         // be worth a workgroup) — spmv_plan_cuts_kernel
-        const long long mean_block = (long long)((double)pl->nnz / (double)m * SP_RB);
+        // rows per block: 4,096 (what the LDS sums hold) for a matrix whose blocks then fill the machine; fewer for fewer rows — ~256
+        // blocks, at least 256 rows each: 1e5 rows were 25 workgroups on 256 CUs (1e5 x 1e4, 64 per row: 0.17 ms against the flat
+        // kernel's 0.038)
+        const int RB = (int)std::min<long long>(SP_RB, std::max<long long>(256, (ceil_div(m, 256) + 63) / 64 * 64));
+        const long long mean_block = (long long)((double)pl->nnz / (double)m * RB);
         // (pieces of half a mean block: with heavy-first dispatch the launch then ends within half a block of the ideal — rows
-        // sorted by length, cfg3's shape: pieces of one mean block 0.142 ms, half a block 0.117, equal rows 0.079.  When the 4,096-row
+        // sorted by length, cfg3's shape: pieces of one mean block 0.142 ms, half a block 0.117, equal rows 0.079.  When the
         // blocks fill the machine in ONE round of workgroups — cfg3: 245 on 256 CUs — the first extra block costs a whole second
         // round: log-normal rows, sigma 1.5, a dozen blocks a few percent above the mean, 0.114 -> 0.170 ms; there only a block of
         // twice the mean is cut)
-        const bool one_round = ceil_div(m, SP_RB) <= 256;
-        const long long E = std::max<long long>(32768, one_round ? 2 * mean_block : mean_block + mean_block / 16);
-        const long long E_piece = std::max<long long>(16384, mean_block / 2);
-        const int nA = (int)ceil_div(m, SP_RB);
+        const bool one_round = ceil_div(m, RB) <= 256;
+        const long long E = std::max<long long>(8192, one_round ? 2 * mean_block : mean_block + mean_block / 16);
+        const long long E_piece = std::max<long long>(4096, mean_block / 2);
+        const int nA = (int)ceil_div(m, RB);
         const int max_cuts = (int)std::min<long long>((long long)nA + pl->nnz / E_piece + 1, (long long)m);
         long long *nrb_dev = nullptr;
         if (hipMalloc((void **)&pl->rb_row, ((size_t)max_cuts + 2) * 4) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
         if (hipMalloc((void **)&nrb_dev, 16) != hipSuccess) { set_error("spmv plan: allocation failed"); break; }
-        hipLaunchKernelGGL(spmv_plan_cuts_kernel, dim3(1), dim3(1024), 0, st, m, indptr, E, E_piece, pl->rb_row, max_cuts, nrb_dev);
+        hipLaunchKernelGGL(spmv_plan_cuts_kernel, dim3(1), dim3(1024), 0, st, m, RB, indptr, E, E_piece, pl->rb_row, max_cuts, nrb_dev);
         long long nrb_ll = 0;
         const int rb_rc = read_back_small(&nrb_ll, nrb_dev, sizeof(nrb_ll), st);
         (void)hipFree(nrb_dev);

@@ -452,9 +452,9 @@ extern "C" int mxd_spmv_plan_create(int m, int K, const int32_t *indptr, const i
         // row blocks: 4,096 rows, cut further where they hold more than E entries (1.06 mean blocks — 2 in a one-round launch —, at least 32k: a block must
         // be worth a workgroup) — spmv_plan_cuts_kernel
         // rows per block: 4,096 (what the LDS sums hold) for a matrix whose blocks then fill the machine; fewer for fewer rows — ~256
-        // blocks, at least 256 rows each: 1e5 rows were 25 workgroups on 256 CUs (1e5 x 1e4, 64 per row: 0.17 ms against the flat
-        // kernel's 0.038)
-        const int RB = (int)std::min<long long>(SP_RB, std::max<long long>(256, (ceil_div(m, 256) + 63) / 64 * 64));
+        // blocks, at least 64 rows each: 1e5 rows were 25 workgroups on 256 CUs (1e5 x 1e4, 64 per row: 0.170 -> 0.025 ms, the flat
+        // kernel 0.038; 1e4 x 1e4, 500 per row: 2.35 -> 0.154 with blocks of 256 rows)
+        const int RB = (int)std::min<long long>(SP_RB, std::max<long long>(64, (ceil_div(m, 256) + 63) / 64 * 64));
         const long long mean_block = (long long)((double)pl->nnz / (double)m * RB);
         // (pieces of half a mean block: with heavy-first dispatch the launch then ends within half a block of the ideal — rows
         // sorted by length, cfg3's shape: pieces of one mean block 0.142 ms, half a block 0.117, equal rows 0.079.  When the

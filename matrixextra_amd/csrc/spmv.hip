@@ -176,14 +176,11 @@ int spmv_launch(int m, int K, int64_t nnz, const int32_t *indptr, const int32_t 
     // With the matrix profile in scope (mxd_spmv_csr_dvec_ex2): a row of 16k entries or more is a tail for the lane-group
     // kernel — one group walks it — and nothing special for the flat kernel's equal slices (tools/spmv_skew_probe.py, 3e4 x
     // 1e5, 200 per row: four rows of 50,000 entries 0.237 ms against 0.087, log-normal sigma 1.5 0.152 against 0.065)
-    // ... and so are rows of very uneven length in a matrix of few rows (below the 32,768 rows from which the flat kernel runs
-    // anyway): one group per row runs as long as its longest rows — 1e4 x 1e4, 500 per row, log-normal sigma 1 / 1.5: 0.047 ms
-    // against 0.017 for rows of equal length (tools/cliff_hunt_ops.py) — where the flat kernel's equal slices do not care
     // (Round 6 tried the flat kernel for rows of very uneven length — cv > 0.5 — below 32,768 rows as well: 1e4 x 1e4, 500 per row,
     // log-normal 0.047 -> 0.054 ms, half of the rows empty 0.016 -> 0.044: the flat kernel's two launches cost ~0.045 ms whatever it
     // is given.  Not kept.)
     const bool long_rows = algo == MX_SPMV_AUTO && flat_ok && nnz >= ((int64_t)1 << 20) && m > 0 &&
-                           (profile_longest_over_mean() * ((double)nnz / m) >= 16384.0 || profile_cv() > 0.5);
+                           profile_longest_over_mean() * ((double)nnz / m) >= 16384.0;
     if (algo == MX_SPMV_FLAT || long_rows || (algo == MX_SPMV_AUTO && flat_ok && nnz >= ((int64_t)1 << 22) && m >= 32768))
         return spmv_flat_launch(m, nnz, indptr, indices, values, v, v_dtype, y, st);
     const int G = nnz < 0 ? 32 : pick_group((double)nnz / (double)(m > 0 ? m : 1));

@@ -482,6 +482,8 @@ extern "C" int mx_spmm_sharded_run_dev(mx_spmm_sharded *h, int n, int dense_dtyp
     MX_REQUIRE(h && B_dev, "mx_spmm_sharded_run_dev: null argument");
     MX_REQUIRE(n >= 1 && ldb >= (size_t)n, "mx_spmm_sharded_run_dev: bad n / ldb");
     MX_REQUIRE(dense_dtype == MX_F64 || dense_dtype == MX_F32, "mx_spmm_sharded_run_dev: unsupported dense dtype %d", dense_dtype);
+    for (size_t k = 0; k < h->sh.size(); k++)
+        MX_REQUIRE(B_dev[k] || h->K == 0, "mx_spmm_sharded_run_dev: no operand for shard %zu (B_dev[%zu] is NULL)", k, k);
     std::lock_guard<std::mutex> lk(h->mu);
     int cur = 0;
     MX_HIP(hipGetDevice(&cur));

@@ -80,7 +80,8 @@ enum { MX_SCRATCH_SPMV_SLICES = 0, MX_SCRATCH_PARTIALS = 1, MX_SCRATCH_EXPORT_B 
        MX_SCRATCH_LONGROWS = 9,       // list + pieces' partial sums of the row-split kernel's long rows (spmm_rowsplit.hip)
        MX_SCRATCH_MERGE_LONG = 10,    // list of the very long row pairs of a CSR (+) CSR launch (merge.hip)
        MX_SCRATCH_TILE_PERM = 11,     // slot -> row map of the tile kernel for rows of uneven length (spmm_tile.hip)
-       MX_SCRATCH_SLOTS = 12 };
+       MX_SCRATCH_TILE_X = 12,        // partial sums of the parts of cut rows (spmm_tile.hip)
+       MX_SCRATCH_SLOTS = 13 };
 void *scratch_buffer(int slot, size_t bytes);
 unsigned scratch_generation(int slot);           // changes whenever the slot's buffer is (re)allocated — also after scratch_release
 void *scratch_buffer_zeroed(int slot, size_t bytes, hipStream_t st, bool *fresh);   // zero-filled when (re)allocated

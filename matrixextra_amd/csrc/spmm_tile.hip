@@ -150,11 +150,13 @@ __device__ __forceinline__ void tl_window(const char *smem, int left, unsigned o
 }
 
 // TILE: bytes of one K-tile of the slab in LDS (two of them + one row of zeros); WIN: 16-entry windows per row (1 or 2)
-template <typename real_t, int CPL, int RG, int WIN, int TILE, bool COLMAJOR>
+// SPLIT: slots may hold PARTS of long rows (tile_deal_rows_kernel) — a stride and a row of Cx per slot
+template <typename real_t, int CPL, int RG, int WIN, int TILE, bool COLMAJOR, bool SPLIT>
 __global__ __launch_bounds__((TL_MAX_WAVES + 1) * MX_WAVE)
 void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
                       const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ values,
                       const unsigned char *__restrict__ unsorted, const int32_t *__restrict__ perm, const int32_t *__restrict__ cuts,
+                      const int32_t *__restrict__ split, real_t *__restrict__ Cx,
                       const real_t *__restrict__ B, size_t ldb, real_t *__restrict__ C, size_t ldc, int c_vec, int nl, unsigned long long rgw, unsigned long long *__restrict__ stamps)
 {
     constexpr int VEC = 16 / (int)sizeof(real_t);
@@ -236,7 +238,17 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
 
     const int g = lane / TL_G, lg = lane % TL_G;
     real_t acc[RG][CPL][VEC];
+    // SPLIT costs no register: log2 of a part's stride (0: a whole row) rides in bits 29 / 30 of rows[] (m < 2^29, the host
+    // checks), and the part's row of Cx (-1: the sum goes to C) is read again from split[] by the epilogue
     int rows[RG];
+    auto ROW = [&](int i) -> int { if constexpr (SPLIT) return rows[i] & 0x1FFFFFFF; else return rows[i]; };
+    auto SH = [&](int i) -> int { if constexpr (SPLIT) return (int)((unsigned)rows[i] >> 29); else return 0; };
+    auto XR = [&](int i) -> int {
+        if constexpr (SPLIT) {
+            const int sp = split[(size_t)rb * R + (my_base + i) * TL_NG + lane / TL_G];
+            return sp >= 0 ? (sp >> 12) - 1 : -1;
+        } else return -1;
+    };
     if (wave < nw) {
         const unsigned lane16 = (unsigned)lg * 16;
         int pos[RG], end[RG];
@@ -253,6 +265,25 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
             rows[i] = row;
             pos[i] = end[i] = 0;
             if (row < m) { pos[i] = indptr[row]; end[i] = indptr[row + 1]; }
+            // a LONG row cut into P = 2 / 4 / 8 interleaved parts (tile_deal_rows_kernel): this slot sums entries q, q + P, q + 2P ...
+            // of the row — its column ids still ascend — into a row of the scratch matrix Cx (part 0: into C), added up afterwards
+            if constexpr (SPLIT) if (split && row < m) {
+                const int sp = split[(size_t)rb * R + slot];
+                if (sp >= 0) {                                        // q | log2(P) << 8 | (row of Cx + 1) << 12 (0: part 0)
+                    const int q = sp & 255, len = end[i] - pos[i];
+                    // (a kept map may have cut a row that is NOT sorted by column in today's matrix: part 0 then sums all of it —
+                    // whole, from global memory, below — and the other parts nothing: their rows of Cx become zeros)
+                    const bool whole = unsorted && unsorted[row] != 0;
+                    if (whole) {
+                        if (q > 0) end[i] = pos[i];
+                    } else {
+                        const int lg2 = (sp >> 8) & 3;
+                        rows[i] |= lg2 << 29;
+                        pos[i] += q;
+                        end[i] = pos[i] + (len > q ? (len - q + (1 << lg2) - 1) >> lg2 : 0);  // (pos + the part's entry COUNT)
+                    }
+                }
+            }
 #pragma unroll
             for (int c = 0; c < CPL; c++)
 #pragma unroll
@@ -262,7 +293,7 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
         if (unsorted) {
 #pragma unroll
             for (int i = 0; i < RG; i++) {
-                const bool slow = rows[i] < m && unsorted[rows[i]] != 0;
+                const bool slow = ROW(i) < m && unsorted[ROW(i)] != 0;
                 if (__ballot(slow) == 0) continue;
                 const int gbase = g * TL_G;
                 int longest = slow ? end[i] - pos[i] : 0;
@@ -304,13 +335,13 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(values + first), 0, bytes_x, 0x00020000);
         int posl[RG], rem[RG];                       // pos - first + lane-in-group; entries the row has left
 #pragma unroll
-        for (int i = 0; i < RG; i++) { posl[i] = pos[i] - first + lg; rem[i] = end[i] - pos[i]; }
+        for (int i = 0; i < RG; i++) { posl[i] = pos[i] - first + (lg << SH(i)); rem[i] = end[i] - pos[i]; }
         auto load_window = [&](int i) {
             const int o4 = posl[i] << 2, o8 = posl[i] << 3;
 #pragma unroll
             for (int w = 0; w < WIN; w++) {
-                jv[i][w] = __builtin_amdgcn_raw_buffer_load_b32(rs_j, o4 + w * TL_G * 4, 0, 0);     // (used as loaded: nothing waits here)
-                av[i][w] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_x, o8 + w * TL_G * 8, 0, 0));
+                jv[i][w] = __builtin_amdgcn_raw_buffer_load_b32(rs_j, o4 + ((w * TL_G * 4) << SH(i)), 0, 0);     // (used as loaded: nothing waits here)
+                av[i][w] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_x, o8 + ((w * TL_G * 8) << SH(i)), 0, 0));
             }
         };
 #pragma unroll
@@ -366,7 +397,7 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
                 // read of a VGPR needs two wait states after the VALU write.)
                 if constexpr (WIN == 1) asm volatile("s_nop 1" : "+v"(off[0]), "+v"(aa[0]) : : "memory");
                 else asm volatile("s_nop 1" : "+v"(off[0]), "+v"(aa[0]), "+v"(off[WIN - 1]), "+v"(aa[WIN - 1]) : : "memory");
-                posl[i] += cnt;
+                posl[i] += cnt << SH(i);
                 rem[i] -= cnt;
                 load_window(i);
                 if (maxc > 0) {                      // (wave-uniform)
@@ -407,13 +438,14 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
         if constexpr (!COLMAJOR) {
 #pragma unroll
             for (int i = 0; i < RG; i++) {
-                if (rows[i] >= m) continue;
+                if (ROW(i) >= m) continue;
+                const int xr = XR(i);
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
                     const int col = c0 + c * (TL_G * VEC) + lg * VEC;
                     if (col >= n) continue;
-                    real_t *dst = C + (size_t)rows[i] * ldc + col;
-                    if (c_vec) vstore<real_t, VEC>(dst, acc[i][c]);
+                    real_t *dst = xr < 0 ? C + (size_t)ROW(i) * ldc + col : Cx + (size_t)xr * n + col;     // (Cx: row-major, ld = n)
+                    if (c_vec || xr >= 0) vstore<real_t, VEC>(dst, acc[i][c]);
                     else {
 #pragma unroll
                         for (int v = 0; v < VEC; v++) dst[v] = acc[i][c][v];
@@ -431,8 +463,17 @@ void spmm_tile_kernel(int m, int n, int K, int nslabs, int nrb,
         if (wave < nw) {
 #pragma unroll
             for (int i = 0; i < RG; i++) {
-                if (i >= my_rg || rows[i] >= m) continue;
-                const int r = rows[i] - row0;                        // (the block's rows, whatever slots they were dealt to)
+                if (i >= my_rg || ROW(i) >= m) continue;
+                const int xr = XR(i);
+                if (xr >= 0) {                                       // a part of a long row: straight into its row of Cx
+#pragma unroll
+                    for (int c = 0; c < CPL; c++) {
+                        const int col = c0 + c * (TL_G * VEC) + lg * VEC;
+                        if (col < n) vstore<real_t, VEC>(Cx + (size_t)xr * n + col, acc[i][c]);
+                    }
+                    continue;
+                }
+                const int r = ROW(i) - row0;                         // (the block's rows, whatever slots they were dealt to)
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
 #pragma unroll
@@ -518,13 +559,26 @@ void tile_cuts_kernel(int m, int R, const int32_t *__restrict__ indptr, long lon
 // the rows ahead of its own) and dealt: ranks 4q .. 4q + 3 share visit q — four rows of nearly the same length —, and the
 // visits, longest first, go to the SIMD with the least work so far (wavefront w sits on SIMD w % 4).
 // A row is still summed by one group in storage order: the same bits.  perm[rb * R + slot] = row, m = no row.
+// split / xstate: nullptr = no row is cut.  Otherwise a row longer than 1.5 * part_len entries (and sorted by column) is cut into
+// P = 2 / 4 / 8 interleaved parts (round 6, tools/tile_split_emulation.py: the storage-order chain of a 10,000-entry row is 0.16 ms
+// whatever else happens — cut into parts of <= 1,280 entries the product takes 0.13 ms in f64 and 0.09 in f32 where whole rows
+// take 0.18): each part is a slot of its own — the block has spare slots for that, Rslots > the rows of a base block —, part 0
+// sums into C, the others into rows of the scratch matrix Cx handed out from xstate[0] (capacity xcap); the parent rows are listed
+// (xstate[1], parents[]: row, first row of Cx, P) for tile_combine_kernel, which adds the parts in order: the same bits on
+// every run, but no longer the storage-order chain for THOSE rows.
+struct TileParent { int row, x0, parts; };
 __global__ __launch_bounds__(256)
 void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const int32_t *__restrict__ indptr, const int32_t *__restrict__ cuts,
-                           int32_t *__restrict__ perm)
+                           int32_t *__restrict__ perm, int32_t *__restrict__ split, int part_len, const unsigned char *__restrict__ unsorted,
+                           unsigned *__restrict__ xstate, unsigned xcap, TileParent *__restrict__ parents, unsigned pcap)
 {
     constexpr int MAXR = TL_MAX_WAVES * TL_NG * 5;
     __shared__ int len[MAXR + 4], sorted_len[MAXR + 4];
     __shared__ short row_of_rank[MAXR + 4], visit_of[TL_MAX_WAVES * 5 + 1];
+    // units: what a slot holds — a whole row or one part of a cut row — in dealing order
+    __shared__ short unit_rank[MAXR + 4];
+    __shared__ int unit_code[MAXR + 4], unit_len[MAXR + 4];
+    __shared__ int n_units;
     const int rb = blockIdx.x, row0 = cuts[rb], nrows = cuts[rb + 1] - row0;
     if (nrows <= 0) return;
     for (int r = threadIdx.x; r < R; r += blockDim.x) len[r] = r < nrows ? indptr[row0 + r + 1] - indptr[row0 + r] : -1;
@@ -538,18 +592,44 @@ void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const i
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // visits (ranks 4q .. 4q + 3, cost = the longest of them = rank 4q), longest first, each to the SIMD with the least work
+        // which rows are cut: longest first, while the block has spare slots (a block never holds more rows than slots)
+        int spare = R - nrows, nu = 0;
+        for (int rank = 0; rank < nrows; rank++) {
+            const int L = sorted_len[rank], row = row0 + row_of_rank[rank];
+            int lg2 = 0;
+            if (split && spare > 0 && 2 * L > 3 * part_len && !(unsorted && unsorted[row])) {
+                while (lg2 < 3 && (L >> lg2) > part_len) lg2++;
+                while (lg2 > 0 && (1 << lg2) - 1 > spare) lg2--;
+            }
+            int x0 = 0;
+            if (lg2 > 0) {
+                const unsigned at = atomicAdd(&xstate[0], (unsigned)((1 << lg2) - 1));
+                const unsigned pa = atomicAdd(&xstate[1], 1u);
+                if (at + (1u << lg2) - 1u <= xcap && pa < pcap) {
+                    x0 = (int)at;
+                    parents[pa].row = row; parents[pa].x0 = x0; parents[pa].parts = 1 << lg2;
+                    spare -= (1 << lg2) - 1;
+                } else lg2 = 0;                                       // (no room in Cx or in the list: the row stays whole; the counters only ever overshoot)
+            }
+            const int P = 1 << lg2;
+            for (int q = 0; q < P; q++) {
+                unit_rank[nu] = (short)rank;
+                unit_code[nu] = q | (lg2 << 8) | ((q > 0 ? x0 + q : 0) << 12);       // (row of Cx + 1: part q > 0 sums into row x0 + q - 1)
+                unit_len[nu] = (L - q + P - 1) >> lg2;
+                nu++;
+            }
+        }
+        n_units = nu;
+        // visits (units 4v .. 4v + 3, cost = the longest of them), longest first, each to the SIMD with the least work so far that
+        // still has a free visit slot, there to the wavefront with the most free slots
         // (per SIMD, not per wavefront: dealing to the least-loaded WAVEFRONT was measured too — log-normal sigma 1 / 1.5, 1e4 x 1e4:
         // 0.263 / 0.397 ms against 0.218 / 0.339; the wavefronts of a SIMD share its issue slots, so what counts is their sum)
-        // so far that still has a free visit slot, there to the wavefront with the most free slots.  (The first version dealt
-        // them in snake order over the wavefronts: fine for a smooth length distribution, but one row of 20 mean rows then
-        // shares its SIMD with as many other visits as every other SIMD has.)
         int base[TL_MAX_WAVES + 1], free_[TL_MAX_WAVES];
         long long load[4] = {0, 0, 0, 0};
         base[0] = 0;
         for (int w = 0; w < nw; w++) { free_[w] = (int)((rgw >> (4 * w)) & 15); base[w + 1] = base[w] + free_[w]; }
         const int nq = R / TL_NG;
-        for (int q = 0; q < nq; q++) {
+        for (int v = 0; v < nq; v++) {
             int best_c = -1;
             for (int c = 0; c < 4; c++) {
                 bool has = false;
@@ -560,16 +640,39 @@ void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const i
             for (int w = best_c; w < nw; w += 4)
                 if (free_[w] > 0 && (best_w < 0 || free_[w] > free_[best_w])) best_w = w;
             const int rg_w = (int)((rgw >> (4 * best_w)) & 15);
-            visit_of[q] = (short)(base[best_w] + (rg_w - free_[best_w]));
+            visit_of[v] = (short)(base[best_w] + (rg_w - free_[best_w]));
             free_[best_w]--;
-            // (a visit costs its window bookkeeping whatever its rows hold: ~40 entries' worth)
-            load[best_c] += 40 + (long long)max(sorted_len[q * TL_NG], 0);
+            // (a visit costs its window bookkeeping whatever its rows hold: ~40 entries' worth; a visit without rows nothing)
+            int longest = 0;
+            for (int u = v * TL_NG; u < min(v * TL_NG + TL_NG, nu); u++) longest = max(longest, unit_len[u]);
+            load[best_c] += v * TL_NG < nu ? 40 + longest : 0;
         }
     }
     __syncthreads();
-    for (int rank = threadIdx.x; rank < R; rank += blockDim.x) {
-        const int r = row_of_rank[rank];
-        perm[(size_t)rb * R + visit_of[rank / TL_NG] * TL_NG + rank % TL_NG] = sorted_len[rank] >= 0 ? row0 + r : m;
+    const int nu = n_units;
+    for (int u = threadIdx.x; u < R; u += blockDim.x) {
+        const size_t slot = (size_t)rb * R + visit_of[u / TL_NG] * TL_NG + u % TL_NG;
+        perm[slot] = u < nu ? row0 + row_of_rank[unit_rank[u]] : m;
+        if (split) split[slot] = u < nu ? unit_code[u] : 0;
+    }
+}
+
+// adds the parts of the cut rows: C[row, :] += Cx[x0, :] + Cx[x0 + 1, :] + ... in order (one wavefront per cut row)
+template <typename real_t>
+__global__ __launch_bounds__(256)
+void tile_combine_kernel(int n, const unsigned *__restrict__ xstate, unsigned pcap, const TileParent *__restrict__ parents,
+                         const real_t *__restrict__ Cx, real_t *__restrict__ C, size_t ldc, int colmajor)
+{
+    const unsigned np = min(xstate[1], pcap);
+    const int lane = lane_id();
+    for (unsigned i = blockIdx.x * 4 + uniform(threadIdx.x / MX_WAVE); i < np; i += gridDim.x * 4) {
+        const int row = uniform(parents[i].row), x0 = uniform(parents[i].x0), P = uniform(parents[i].parts);
+        for (int c = lane; c < n; c += MX_WAVE) {
+            real_t *dst = colmajor ? C + (size_t)c * ldc + row : C + (size_t)row * ldc + c;
+            real_t sum = *dst;
+            for (int q = 1; q < P; q++) sum += Cx[(size_t)(x0 + q - 1) * n + c];
+            *dst = sum;
+        }
     }
 }
 
@@ -701,26 +804,38 @@ double tile_est_us(int m, int n, int K, int dense_bytes, double avg_len, int col
 
 template <typename real_t, int CPL, int RG, int WIN, int TILE>
 static void launch_tile(const TileGeom &gm, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
-                        const unsigned char *unsorted, const int32_t *perm, const int32_t *cuts, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
-                        hipStream_t st)
+                        const unsigned char *unsorted, const int32_t *perm, const int32_t *cuts, const int32_t *split, real_t *Cx, const real_t *B, size_t ldb, real_t *C, size_t ldc,
+                        int colmajor, int c_vec, hipStream_t st)
 {
     const int per = 8 % gm.nslabs == 0 ? 8 / gm.nslabs : 0;
     const unsigned grid = per ? (unsigned)(8 * ceil_div(gm.nrb, per)) : (unsigned)(gm.nrb * gm.nslabs);
     const dim3 block((unsigned)(gm.nw + gm.nl) * MX_WAVE);
+    constexpr bool CAN_SPLIT = true;
+    if constexpr (CAN_SPLIT) {
+        if (split) {
+            if (colmajor)
+                hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, true, true>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
+                                   gm.nrb, indptr, indices, values, unsorted, perm, cuts, split, Cx, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
+            else
+                hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, false, true>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
+                                   gm.nrb, indptr, indices, values, unsorted, perm, cuts, split, Cx, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
+            return;
+        }
+    }
     if (colmajor)
-        hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, true>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
-                           gm.nrb, indptr, indices, values, unsorted, perm, cuts, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
+        hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, true, false>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
+                           gm.nrb, indptr, indices, values, unsorted, perm, cuts, nullptr, nullptr, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
     else
-        hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, false>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
-                           gm.nrb, indptr, indices, values, unsorted, perm, cuts, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
+        hipLaunchKernelGGL((spmm_tile_kernel<real_t, CPL, RG, WIN, TILE, false, false>), dim3(grid), block, 0, st, m, n, K, gm.nslabs,
+                           gm.nrb, indptr, indices, values, unsorted, perm, cuts, nullptr, nullptr, B, ldb, C, ldc, c_vec, gm.nl, gm.rgw, g_tile_stamps);
 }
 
 template <typename real_t, int CPL, int WIN, int TILE>
 static void launch_tile_rg(const TileGeom &gm, int m, int n, int K, const int32_t *indptr, const int32_t *indices, const double *values,
-                           const unsigned char *unsorted, const int32_t *perm, const int32_t *cuts, const real_t *B, size_t ldb, real_t *C, size_t ldc, int colmajor, int c_vec,
-                           hipStream_t st)
+                           const unsigned char *unsorted, const int32_t *perm, const int32_t *cuts, const int32_t *split, real_t *Cx, const real_t *B, size_t ldb, real_t *C, size_t ldc,
+                           int colmajor, int c_vec, hipStream_t st)
 {
-#define MX_TL_RG(RG) launch_tile<real_t, CPL, RG, WIN, TILE>(gm, m, n, K, indptr, indices, values, unsorted, perm, cuts, B, ldb, C, ldc, colmajor, c_vec, st)
+#define MX_TL_RG(RG) launch_tile<real_t, CPL, RG, WIN, TILE>(gm, m, n, K, indptr, indices, values, unsorted, perm, cuts, split, Cx, B, ldb, C, ldc, colmajor, c_vec, st)
     switch (gm.rg) {
     case 1: MX_TL_RG(1); break;
     case 2: MX_TL_RG(2); break;
@@ -779,42 +894,94 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
     // consecutive rows).  Kept per thread and device for the next product with the same row pointers and geometry: whatever the
     // matrix holds by then, the cuts and the map stay a partition of its rows into blocks of <= R — stale ones can cost
     // balance, never a row.
-    int32_t *perm = nullptr, *cuts = nullptr;
+    // LONG rows (round 6; with the map, when the profile's longest row is at least 2.5 parts long; MXGPU_TILE_SPLIT=0 / 1 forces):
+    // a row of more than 1.5 parts is cut into 2 / 4 / 8 interleaved parts of ~part_len entries (1.25 windows per tile) that
+    // take slots of their own — the geometry is given a third more slots than a base block has rows — and are added up by
+    // tile_combine_kernel.  Those rows' sums are regrouped (1e-12), all others stay the storage-order chain bit for bit.
+    int32_t *perm = nullptr, *cuts = nullptr, *split = nullptr;
+    real_t *Cx = nullptr;
+    unsigned *xstate = nullptr;
+    TileParent *parents = nullptr;
+    unsigned xcap = 0, pcap = 0;
     bool build_map = false;
     {
         const char *de = getenv("MXGPU_TILE_DEAL");                      // (read per call: the tests and the A/B runs switch it)
         const int deal_env = de ? atoi(de) : -1;
         const bool deal = deal_env >= 0 ? deal_env != 0 : profile_cv() > 0.15;
         if (deal && nnz > 0 && gm.R <= TL_MAX_WAVES * TL_NG * 5) {
+            const int Rrows = gm.R;                                      // rows of a base block (the slots may be more, below)
+            const int tile_rows = (small_tile ? 32768 : 65536) / (256 * gm.cpl), ntiles = (int)ceil_div(K, tile_rows);
+            const int part_len = 40 * ntiles;
+            const char *se = getenv("MXGPU_TILE_SPLIT");
+            bool want_split = se ? atoi(se) != 0 : profile_longest_over_mean() * ((double)nnz / (double)m) >= 2.5 * part_len;
+            if (m >= (1 << 29)) want_split = false;                     // (the kernel keeps a part's stride in the row number's top bits)
+            if (want_split) {
+                // a third more slots than rows: one more row per lane group where the registers allow it
+                const int gr2 = Rrows / TL_NG + (Rrows / TL_NG + 2) / 3, rgmax = gm.cpl == 1 ? 5 : 4;
+                const int lds = 2 * (small_tile ? 32768 : 65536) + 256 * gm.cpl;
+                bool found = false;
+                TileGeom best = gm;
+                for (int w = 14; w >= 4; w--) {
+                    TileGeom t = gm;
+                    if (!tile_deal(gr2, w, 2, rgmax, t)) continue;
+                    if (colmajor && (t.R | 1) * 256 * gm.cpl > lds) continue;
+                    if (!found || t.serial < best.serial) { best = t; found = true; }
+                }
+                if (found) { const int nrb0 = gm.nrb; gm = best; gm.nrb = nrb0; } else want_split = false;
+            }
             // a block above E entries is cut into pieces of E_piece.  A product whose row blocks fill the machine in ONE round of
             // workgroups pays a whole second round for the first extra block (1e4 x 1e4, log-normal sigma 1.5: 60 -> 68 blocks x 4
             // slabs = 272 workgroups, 0.235 -> 0.338 ms): there only a block of twice the mean is cut (rows sorted by length:
             // 0.378 -> 0.230); otherwise from 1.25 mean blocks on.
-            const long long mean_block = (long long)((double)nnz / (double)m * gm.R);
-            const bool one_round = (long long)ceil_div(m, gm.R) * gm.nslabs <= 256;
+            const long long mean_block = (long long)((double)nnz / (double)m * Rrows);
+            const bool one_round = (long long)ceil_div(m, Rrows) * gm.nslabs <= 256;
             const long long E = std::max<long long>(1024, one_round ? 2 * mean_block : mean_block + mean_block / 4);
             const long long E_piece = std::max<long long>(1024, mean_block + mean_block / 4);
-            const long long bound = (long long)ceil_div(m, gm.R) + nnz / E_piece + 1;
+            const long long bound = (long long)ceil_div(m, Rrows) + nnz / E_piece + 1;
             if (bound * gm.nslabs < (1LL << 30)) {
                 const int max_blocks = (int)std::min<long long>(bound, m);
                 const size_t cuts_b = (((size_t)max_blocks + 2) * sizeof(int32_t) + 255) & ~(size_t)255;
-                char *buf = (char *)scratch_buffer(MX_SCRATCH_TILE_PERM, cuts_b + (size_t)max_blocks * gm.R * sizeof(int32_t));
+                const size_t perm_b = ((size_t)max_blocks * gm.R * sizeof(int32_t) + 255) & ~(size_t)255;
+                pcap = want_split ? (unsigned)std::min<long long>((long long)max_blocks * gm.R, 1 << 18) : 0;
+                xcap = want_split ? (unsigned)std::min<long long>(std::min<long long>((long long)max_blocks * gm.R, (1 << 19) - 2),
+                                                                  ((long long)64 << 20) / ((long long)n * (long long)sizeof(real_t))) : 0;
+                const size_t split_b = want_split ? perm_b + 256 + (((size_t)pcap * sizeof(TileParent) + 255) & ~(size_t)255) : 0;
+                char *buf = (char *)scratch_buffer(MX_SCRATCH_TILE_PERM, cuts_b + perm_b + split_b);
+                if (buf && want_split) {
+                    Cx = (real_t *)scratch_buffer(MX_SCRATCH_TILE_X, (size_t)xcap * n * sizeof(real_t) + 256);
+                    if (!Cx) { (void)hipGetLastError(); buf = nullptr; }   // (no memory for the parts' rows: consecutive rows, whole)
+                }
                 if (buf) {
-                    struct Key { const void *indptr, *buf; long long nnz; unsigned long long rgw; int m, R, nw, nl, max_blocks; unsigned gen; };   // (no padding bytes: compared with memcmp; gen: the buffer's allocation — a freed and re-allocated buffer may come back at the same address)
+                    struct Key { const void *indptr, *buf, *cx; long long nnz; unsigned long long rgw; int m, R, Rrows, nw, nl, max_blocks, n, part_len; unsigned gen, genx; };   // (no padding bytes: compared with memcmp; gen: the buffers' allocations — a freed and re-allocated buffer may come back at the same address)
                     static thread_local Key kept[16] = {};
                     int dev = 0;
                     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-                    const Key now = {indptr, buf, (long long)nnz, gm.rgw, m, gm.R, gm.nw, gm.nl, max_blocks, scratch_generation(MX_SCRATCH_TILE_PERM)};
+                    Key now;
+                    memset(&now, 0, sizeof(now));
+                    now.indptr = indptr; now.buf = buf; now.cx = Cx; now.nnz = (long long)nnz; now.rgw = gm.rgw; now.m = m; now.R = gm.R; now.Rrows = Rrows;
+                    now.nw = gm.nw; now.nl = gm.nl; now.max_blocks = max_blocks; now.n = want_split ? n : 0; now.part_len = want_split ? part_len : 0;
+                    now.gen = scratch_generation(MX_SCRATCH_TILE_PERM); now.genx = want_split ? scratch_generation(MX_SCRATCH_TILE_X) : 0;
                     build_map = memcmp(&kept[dev], &now, sizeof(Key)) != 0;
                     kept[dev] = now;
                     scratch_acquire(MX_SCRATCH_TILE_PERM, stream);
+                    if (want_split) scratch_acquire(MX_SCRATCH_TILE_X, stream);
                     cuts = (int32_t *)buf; perm = (int32_t *)(buf + cuts_b);
+                    if (want_split) {
+                        split = (int32_t *)(buf + cuts_b + perm_b);
+                        xstate = (unsigned *)(buf + cuts_b + 2 * perm_b);
+                        parents = (TileParent *)(buf + cuts_b + 2 * perm_b + 256);
+                    }
                     gm.nrb = max_blocks;
                     if (build_map) {
-                        hipLaunchKernelGGL(tile_cuts_kernel, dim3(1), dim3(1024), 0, stream, m, gm.R, indptr, E, E_piece, cuts, max_blocks);
-                        hipLaunchKernelGGL(tile_deal_rows_kernel, dim3((unsigned)max_blocks), dim3(256), 0, stream, m, gm.R, gm.nw, gm.rgw, indptr, cuts, perm);
+                        // (the cut decisions need this call's sortedness flags: a row that is not sorted by column stays whole)
+                        if (flags && want_split)
+                            hipLaunchKernelGGL(tile_unsorted_rows_kernel, dim3((unsigned)ceil_div(m, 8)), dim3(512), 0, stream, m, indptr, indices, flags);
+                        if (want_split) MX_HIP(hipMemsetAsync(xstate, 0, 16, stream));
+                        hipLaunchKernelGGL(tile_cuts_kernel, dim3(1), dim3(1024), 0, stream, m, Rrows, indptr, E, E_piece, cuts, max_blocks);
+                        hipLaunchKernelGGL(tile_deal_rows_kernel, dim3((unsigned)max_blocks), dim3(256), 0, stream, m, gm.R, gm.nw, gm.rgw, indptr, cuts, perm,
+                                           split, part_len, (const unsigned char *)flags, xstate, xcap, parents, pcap);
                     }
-                } else (void)hipGetLastError();                          // (no memory for the map: consecutive rows)
+                } else { (void)hipGetLastError(); Cx = nullptr; }        // (no memory for the map: consecutive rows)
             }
         }
     }
@@ -822,12 +989,16 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
     if (flags)
         hipLaunchKernelGGL(tile_unsorted_rows_kernel, dim3((unsigned)ceil_div(m, 8)), dim3(512), 0, stream, m, indptr, indices, flags);
 #define MX_TL_GO(CPL, WIN, TILE)                                                                                                  \
-    launch_tile_rg<real_t, CPL, WIN, TILE>(gm, m, n, K, indptr, indices, values, flags, perm, cuts, B, ldb, C, ldc, colmajor, c_vec, stream)
+    launch_tile_rg<real_t, CPL, WIN, TILE>(gm, m, n, K, indptr, indices, values, flags, perm, cuts, split, Cx, B, ldb, C, ldc, colmajor, c_vec, stream)
     if (gm.cpl == 2) { if (small_tile) MX_TL_GO(2, 1, 32768); else MX_TL_GO(2, 2, 65536); }
     else { if (small_tile) MX_TL_GO(1, 1, 32768); else MX_TL_GO(1, 2, 65536); }
 #undef MX_TL_GO
+    if (split)
+        hipLaunchKernelGGL((tile_combine_kernel<real_t>), dim3(256), dim3(256), 0, stream, n, (const unsigned *)xstate, pcap, (const TileParent *)parents,
+                           (const real_t *)Cx, C, ldc, colmajor);
     if (flags) scratch_done(MX_SCRATCH_TILE_FLAGS, stream);
     if (perm) scratch_done(MX_SCRATCH_TILE_PERM, stream);
+    if (split) scratch_done(MX_SCRATCH_TILE_X, stream);
     kt_end(stream);
     MX_LAUNCH_CHECK();
     return 0;

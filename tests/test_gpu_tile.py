@@ -6,7 +6,10 @@ sortedness pass), repeated column ids, empty rows, rows denser than a window per
 n not a multiple of the slab, NaN / Inf / signed zeros.
 
 Every sum is the reference's storage-order FMA chain BIT FOR BIT, in both layouts: a row is summed by one lane group in
-CSR order, and the padding steps of a group that has fewer entries in a tile than its neighbours add -0.0 * 0.0."""
+CSR order, and the padding steps of a group that has fewer entries in a tile than its neighbours add -0.0 * 0.0.
+The one exception (round 6): a matrix whose profile shows rows several tile-windows long has THOSE rows cut into 2 / 4 / 8
+interleaved parts, summed side by side and added in order — the same bits on every run, regrouped against the chain
+(1e-13 in f64; north_star's tolerance is 1e-6); every other row keeps the chain."""
 import numpy as np
 import pytest
 
@@ -200,6 +203,7 @@ def test_tile_rows_dealt_by_length_keep_every_bit(gpu, monkeypatch, colmajor, dt
         B = rng.normal(size=(K, n)).astype(dtype)
         ref = _oracle(p, j, x, B)
         outs = []
+        monkeypatch.setenv("MXGPU_TILE_SPLIT", "0")                  # (long rows cut into parts: the next test)
         for deal in ("1", "0"):
             monkeypatch.setenv("MXGPU_TILE_DEAL", deal)
             for var, nw in ((0, 0), (variant(1, 3), 5), (variant(2, 2), 14)):
@@ -221,3 +225,55 @@ def test_tile_rows_dealt_by_length_keep_every_bit(gpu, monkeypatch, colmajor, dt
         _same(D.spmm(A, Bd, colmajor=colmajor, algo=TILE).cpu().numpy(), ref)
         _lib.check(_lib.load().mxd_release_workspaces())
         _same(D.spmm(A, Bd, colmajor=colmajor, algo=TILE).cpu().numpy(), ref)
+        monkeypatch.delenv("MXGPU_TILE_SPLIT")
+
+
+@pytest.mark.parametrize("colmajor", [False, True])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tile_long_rows_cut_into_parts(gpu, monkeypatch, colmajor, dtype):
+    """Long rows (round 6): with the rows dealt by length, a row several windows per tile long is cut into 2 / 4 / 8 interleaved
+    parts that take slots of their own and are added up in order by tile_combine_kernel — forced (MXGPU_TILE_SPLIT=1) and chosen
+    from the matrix profile.  Those rows are the chain regrouped (1e-13 f64 / 1e-5 f32 of the row's largest term sum); rows of
+    at most 40 entries are never cut (a part is 40 entries per tile at least) and keep every bit; a long row that is not sorted
+    by column stays whole — every bit again; the same bits on every run, with a kept map and after the workspaces' release."""
+    import torch
+    from matrixextra_amd import device as D
+    rng = np.random.default_rng(33)
+    tol = 1e-13 if dtype == np.float64 else 2e-5
+    for m, K, n in ((1000, 2000, 100), (333, 900, 64), (64, 6000, 132), (5, 400, 32)):
+        lens = np.minimum(rng.lognormal(mean=3.0, sigma=1.4, size=m).astype(np.int64), K)
+        lens[rng.integers(0, m, size=max(1, m // 50))] = 0
+        lens[m // 3] = K; lens[m // 2] = K // 2; lens[1] = K - 1     # long rows; row 1 will not be sorted by column
+        p = np.zeros(m + 1, dtype=np.int32); p[1:] = np.cumsum(lens)
+        j = np.concatenate([np.sort(rng.choice(K, size=int(L), replace=False)) for L in lens]).astype(np.int32)
+        j[p[1]:p[2]] = j[p[1]:p[2]][::-1]
+        x = rng.uniform(-1, 1, size=j.size)
+        B = rng.normal(size=(K, n)).astype(dtype)
+        ref = _oracle(p, j, x, B)
+        scale = np.abs(_oracle(p, j, np.abs(x), np.abs(B)))          # sum of |terms| per element
+        short = lens <= 40
+        short[1] = True                                              # (not sorted by column: whole)
+
+        def check(got):
+            assert np.all(np.abs(got.astype(np.float64) - ref) <= tol * np.maximum(scale, 1e-300))
+            _same(got[short], ref[short])
+
+        monkeypatch.setenv("MXGPU_TILE_DEAL", "1")
+        monkeypatch.setenv("MXGPU_TILE_SPLIT", "1")
+        first = None
+        for var, nw in ((0, 0), (variant(1, 3), 5), (variant(2, 2), 14), (variant(1, 2, True), 9)):
+            got = _run(p, j, x, B, colmajor, var, nw, rows_sorted=False)
+            check(got)
+            if var == 0:
+                first = got
+        monkeypatch.delenv("MXGPU_TILE_DEAL"); monkeypatch.delenv("MXGPU_TILE_SPLIT")
+        A = D.DeviceCSR.from_host(p, j, x, K)
+        Bd = torch.from_numpy(B).cuda()
+        a = D.spmm(A, Bd, colmajor=colmajor, algo=TILE).cpu().numpy()
+        check(a)
+        b = D.spmm(A, Bd, colmajor=colmajor, algo=TILE).cpu().numpy()             # the kept map
+        assert np.array_equal(a, b)
+        _lib.check(_lib.load().mxd_release_workspaces())
+        assert np.array_equal(D.spmm(A, Bd, colmajor=colmajor, algo=TILE).cpu().numpy(), a)
+        if m >= 64:
+            assert not np.array_equal(a, ref), "no row was cut: the test did not reach the parts"

@@ -567,6 +567,83 @@ void tile_cuts_kernel(int m, int R, const int32_t *__restrict__ indptr, long lon
 // (xstate[1], parents[]: row, first row of Cx, P) for tile_combine_kernel, which adds the parts in order: the same bits on
 // every run, but no longer the storage-order chain for THOSE rows.
 struct TileParent { int row, x0, parts; };
+// log2 of the number of parts a row of L entries is cut into when the block has the slots (part_len = 0: never)
+__device__ __forceinline__ int tile_parts_lg2(int L, int part_len)
+{
+    int lg2 = 0;
+    if (part_len > 0 && 2LL * L > 3LL * part_len)
+        while (lg2 < 3 && (L >> lg2) > part_len) lg2++;
+    return lg2;
+}
+
+// Row blocks in ONE pass over the rows, for matrices of <= 32,768 rows (round 6): a block takes rows while its UNITS — rows, and the
+// parts the long ones will be cut into — fit the workgroup's slots and its WEIGHT stays below E: a row weighs its entries + w_row,
+// what its slot costs whatever it holds (8 entries' worth per tile, measured: tools/tile_split_probe.py with MXGPU_TILE_WROW =
+// 0 / 8 / 16 / 40 — rows sorted by length, 1e4 x 1e4: 0.214 / 0.182 / 0.199 / 0.237 ms; 4,000 x 50,000: 0.59 / 0.43 / 0.50 / 0.48).  tile_cuts_kernel cuts every R
+// rows whatever they hold: a matrix with its rows sorted by length then needs ceil(m / R) blocks for its rows and again as many
+// pieces for its entries — 1e4 x 1e4, 500 per row: 155 blocks x 2 slabs, a second round of workgroups for the last 54 —, and the
+// spare slots of a block of short rows stay empty.  Here: every row's farthest block end (two monotone conditions: a binary
+// search in the prefix sums of the units, U[], and in indptr), kept as a 16-bit distance in LDS, then one thread walks from row
+// 0 (<= max_blocks hops through LDS).  When the launch could be ONE round of workgroups (target_blocks > 0) and E1 gives more
+// blocks than that, E2 is tried, and E1 again if that is still too many.  max_blocks bounds what the walk can produce (two
+// consecutive blocks always overflow one of the two limits); a walk that would pass it traps: loud, never a lost row.
+__global__ __launch_bounds__(1024)
+void tile_cuts_greedy_kernel(int m, int Rslots, const int32_t *__restrict__ indptr, const unsigned char *__restrict__ unsorted, int part_len,
+                             int w_row, long long E1, long long E2, int target_blocks, int32_t *__restrict__ U, int32_t *__restrict__ cuts, int max_blocks)
+{
+    __shared__ unsigned short delta[32768];
+    __shared__ int scan[1024];
+    __shared__ int carry, nblocks;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < m; k0 += 1024) {
+        const int r = k0 + tid;
+        int u = 0;
+        if (r < m) u = 1 << ((unsorted && unsorted[r]) ? 0 : tile_parts_lg2(indptr[r + 1] - indptr[r], part_len));
+        scan[tid] = u;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int v = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        if (r < m) U[r] = carry + scan[tid] - u;
+        __syncthreads();
+        if (tid == 1023) carry += scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) U[m] = carry;
+    __syncthreads();
+    for (int attempt = 0; attempt < 3; attempt++) {
+        const long long E = attempt == 1 ? E2 : E1;
+        for (int r = tid; r < m; r += 1024) {
+            const int u0 = U[r];
+            const long long e0 = indptr[r];
+            int lo = r + 1, hi = min(m, r + Rslots);                 // the block [r, j): the largest j that keeps both limits; one row at least
+            while (lo < hi) {
+                const int mid = lo + (hi - lo + 1) / 2;
+                if (U[mid] - u0 <= Rslots && (long long)indptr[mid] - e0 + (long long)(mid - r) * w_row <= E) lo = mid; else hi = mid - 1;
+            }
+            delta[r] = (unsigned short)(lo - r);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int i = 0, b = 0;
+            while (i < m) {
+                if (b >= max_blocks) __builtin_trap();
+                cuts[b++] = i;
+                i += delta[i];
+            }
+            nblocks = b;
+        }
+        __syncthreads();
+        if (target_blocks <= 0 || nblocks <= target_blocks || attempt == 2) break;
+        __syncthreads();
+    }
+    for (int i = nblocks + tid; i <= max_blocks; i += 1024) cuts[i] = m;
+}
 __global__ __launch_bounds__(256)
 void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const int32_t *__restrict__ indptr, const int32_t *__restrict__ cuts,
                            int32_t *__restrict__ perm, int32_t *__restrict__ split, int part_len, const unsigned char *__restrict__ unsorted,
@@ -597,8 +674,8 @@ void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const i
         for (int rank = 0; rank < nrows; rank++) {
             const int L = sorted_len[rank], row = row0 + row_of_rank[rank];
             int lg2 = 0;
-            if (split && spare > 0 && 2 * L > 3 * part_len && !(unsorted && unsorted[row])) {
-                while (lg2 < 3 && (L >> lg2) > part_len) lg2++;
+            if (split && spare > 0 && !(unsorted && unsorted[row])) {
+                lg2 = tile_parts_lg2(L, part_len);
                 while (lg2 > 0 && (1 << lg2) - 1 > spare) lg2--;
             }
             int x0 = 0;
@@ -911,7 +988,8 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
         if (deal && nnz > 0 && gm.R <= TL_MAX_WAVES * TL_NG * 5) {
             const int Rrows = gm.R;                                      // rows of a base block (the slots may be more, below)
             const int tile_rows = (small_tile ? 32768 : 65536) / (256 * gm.cpl), ntiles = (int)ceil_div(K, tile_rows);
-            const int part_len = 40 * ntiles;
+            const char *pe = getenv("MXGPU_TILE_PART");                    // (entries per tile and part; experiments)
+            const int part_len = (pe && atoi(pe) > 0 ? atoi(pe) : 40) * ntiles;
             const char *se = getenv("MXGPU_TILE_SPLIT");
             bool want_split = se ? atoi(se) != 0 : profile_longest_over_mean() * ((double)nnz / (double)m) >= 2.5 * part_len;
             if (m >= (1 << 29)) want_split = false;                     // (the kernel keeps a part's stride in the row number's top bits)
@@ -937,7 +1015,12 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
             const bool one_round = (long long)ceil_div(m, Rrows) * gm.nslabs <= 256;
             const long long E = std::max<long long>(1024, one_round ? 2 * mean_block : mean_block + mean_block / 4);
             const long long E_piece = std::max<long long>(1024, mean_block + mean_block / 4);
-            const long long bound = (long long)ceil_div(m, Rrows) + nnz / E_piece + 1;
+            // with spare slots (the cut rows' geometry) and <= 32,768 rows: blocks by units and entries in one pass (tile_cuts_greedy_kernel)
+            const char *ge = getenv("MXGPU_TILE_GREEDY");
+            const bool greedy = want_split && m <= 32768 && (ge ? atoi(ge) != 0 : true);
+            long long bound = (long long)ceil_div(m, Rrows) + nnz / E_piece + 1;
+            // (two consecutive blocks of the walk overflow the slots or the weight limit, which is >= 1.1 mean weights of Rrows rows)
+            if (greedy) bound = 2 * ((long long)ceil_div((long long)m + 2 * (long long)nnz / part_len, gm.R) + std::max<long long>(ceil_div(m, Rrows), one_round ? 256 / gm.nslabs : 0)) + 2;
             if (bound * gm.nslabs < (1LL << 30)) {
                 const int max_blocks = (int)std::min<long long>(bound, m);
                 const size_t cuts_b = (((size_t)max_blocks + 2) * sizeof(int32_t) + 255) & ~(size_t)255;
@@ -945,7 +1028,9 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
                 pcap = want_split ? (unsigned)std::min<long long>((long long)max_blocks * gm.R, 1 << 18) : 0;
                 xcap = want_split ? (unsigned)std::min<long long>(std::min<long long>((long long)max_blocks * gm.R, (1 << 19) - 2),
                                                                   ((long long)64 << 20) / ((long long)n * (long long)sizeof(real_t))) : 0;
-                const size_t split_b = want_split ? perm_b + 256 + (((size_t)pcap * sizeof(TileParent) + 255) & ~(size_t)255) : 0;
+                const size_t par_b = ((size_t)pcap * sizeof(TileParent) + 255) & ~(size_t)255;
+                const size_t u_b = greedy ? (((size_t)m + 1) * sizeof(int32_t) + 255) & ~(size_t)255 : 0;
+                const size_t split_b = want_split ? perm_b + 256 + par_b + u_b : 0;
                 char *buf = (char *)scratch_buffer(MX_SCRATCH_TILE_PERM, cuts_b + perm_b + split_b);
                 if (buf && want_split) {
                     Cx = (real_t *)scratch_buffer(MX_SCRATCH_TILE_X, (size_t)xcap * n * sizeof(real_t) + 256);
@@ -977,7 +1062,20 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
                         if (flags && want_split)
                             hipLaunchKernelGGL(tile_unsorted_rows_kernel, dim3((unsigned)ceil_div(m, 8)), dim3(512), 0, stream, m, indptr, indices, flags);
                         if (want_split) MX_HIP(hipMemsetAsync(xstate, 0, 16, stream));
-                        hipLaunchKernelGGL(tile_cuts_kernel, dim3(1), dim3(1024), 0, stream, m, Rrows, indptr, E, E_piece, cuts, max_blocks);
+                        if (greedy) {
+                            // weights: entries + w_row per row; one round of workgroups when the rows allow it (1.1, then 1.3 mean weights)
+                            const char *we = getenv("MXGPU_TILE_WROW"), *e2 = getenv("MXGPU_TILE_E2");   // (experiments)
+                            const int w_row = (we ? atoi(we) : 8) * ntiles;
+                            const double f2 = e2 ? atoi(e2) / 100.0 : 1.3;
+                            const double w_total = (double)nnz + (double)m * w_row;
+                            const int nb1 = 256 / gm.nslabs;
+                            const double w_block = one_round ? w_total / nb1 : ((double)mean_block + (double)Rrows * w_row) * 1.14;
+                            hipLaunchKernelGGL(tile_cuts_greedy_kernel, dim3(1), dim3(1024), 0, stream, m, gm.R, indptr, (const unsigned char *)flags, part_len,
+                                               w_row, (long long)(1.1 * w_block) + 1024, (long long)(f2 * w_block) + 1024, one_round ? nb1 : 0,
+                                               (int32_t *)(buf + cuts_b + 2 * perm_b + 256 + par_b), cuts, max_blocks);
+                        }
+                        else
+                            hipLaunchKernelGGL(tile_cuts_kernel, dim3(1), dim3(1024), 0, stream, m, Rrows, indptr, E, E_piece, cuts, max_blocks);
                         hipLaunchKernelGGL(tile_deal_rows_kernel, dim3((unsigned)max_blocks), dim3(256), 0, stream, m, gm.R, gm.nw, gm.rgw, indptr, cuts, perm,
                                            split, part_len, (const unsigned char *)flags, xstate, xcap, parents, pcap);
                     }

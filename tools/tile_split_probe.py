@@ -17,9 +17,13 @@ from cliff_hunt import build, lens_of
 lib = _lib.load()
 out = []
 shapes = [(10_000, 10_000, 500, 100), (30_000, 5_000, 300, 64), (4_000, 50_000, 2_000, 128)]
+if os.environ.get("PROBE_PICK"):
+    shapes = [shapes[int(i)] for i in os.environ["PROBE_PICK"].split(",")]
+if os.environ.get("PROBE_SHAPES"):
+    shapes = shapes[:int(os.environ["PROBE_SHAPES"])]
 os.environ["MXGPU_TILE_DEAL"] = "1"
 for (m, K, mean, n) in shapes:
-    for kind in ("equal", "lognormal_1.0", "lognormal_1.5", "giant", "blocks"):
+    for kind in os.environ.get("PROBE_KINDS", "equal,lognormal_1.0,lognormal_1.5,giant,blocks").split(","):
         A = build(m, K, lens_of(kind, m, mean, np.random.default_rng(7)), 7)
         for dt in (torch.float64, torch.float32):
             B = torch.randn((K, n), dtype=dt, device="cuda")

@@ -559,13 +559,13 @@ void tile_cuts_kernel(int m, int R, const int32_t *__restrict__ indptr, long lon
 // the rows ahead of its own) and dealt: ranks 4q .. 4q + 3 share visit q — four rows of nearly the same length —, and the
 // visits, longest first, go to the SIMD with the least work so far (wavefront w sits on SIMD w % 4).
 // A row is still summed by one group in storage order: the same bits.  perm[rb * R + slot] = row, m = no row.
-// split / xstate: nullptr = no row is cut.  Otherwise a row longer than 1.5 * part_len entries (and sorted by column) is cut into
+// split: nullptr = no row is cut.  Otherwise a row longer than 1.5 * part_len entries (and sorted by column) is cut into
 // P = 2 / 4 / 8 interleaved parts (round 6, tools/tile_split_emulation.py: the storage-order chain of a 10,000-entry row is 0.16 ms
 // whatever else happens — cut into parts of <= 1,280 entries the product takes 0.13 ms in f64 and 0.09 in f32 where whole rows
 // take 0.18): each part is a slot of its own — the block has spare slots for that, Rslots > the rows of a base block —, part 0
-// sums into C, the others into rows of the scratch matrix Cx handed out from xstate[0] (capacity xcap); the parent rows are listed
-// (xstate[1], parents[]: row, first row of Cx, P) for tile_combine_kernel, which adds the parts in order: the same bits on
-// every run, but no longer the storage-order chain for THOSE rows.
+// sums into C, the others into rows of the scratch matrix Cx (capacity xcap), handed out in block order (pass 0 / 1, blk[]:
+// below); the parent rows are listed (parents[]: row, first row of Cx, P) for tile_combine_kernel, which adds the parts in
+// order: the same bits on every run, but no longer the storage-order chain for THOSE rows.
 struct TileParent { int row, x0, parts; };
 // log2 of the number of parts a row of L entries is cut into when the block has the slots (part_len = 0: never)
 __device__ __forceinline__ int tile_parts_lg2(int L, int part_len)
@@ -647,7 +647,7 @@ void tile_cuts_greedy_kernel(int m, int Rslots, const int32_t *__restrict__ indp
 __global__ __launch_bounds__(256)
 void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const int32_t *__restrict__ indptr, const int32_t *__restrict__ cuts,
                            int32_t *__restrict__ perm, int32_t *__restrict__ split, int part_len, const unsigned char *__restrict__ unsorted,
-                           unsigned *__restrict__ xstate, unsigned xcap, TileParent *__restrict__ parents, unsigned pcap)
+                           int pass, int32_t *__restrict__ blk, int nblk, unsigned xcap, TileParent *__restrict__ parents, unsigned pcap)
 {
     constexpr int MAXR = TL_MAX_WAVES * TL_NG * 5;
     __shared__ int len[MAXR + 4], sorted_len[MAXR + 4];
@@ -669,8 +669,13 @@ void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const i
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // which rows are cut: longest first, while the block has spare slots (a block never holds more rows than slots)
-        int spare = R - nrows, nu = 0;
+        // which rows are cut: longest first, while the block has spare slots (a block never holds more rows than slots).
+        // The parts' rows of Cx and the places in the parents' list are handed out in BLOCK order: pass 0 only counts what this
+        // block wants (blk[rb] parts, blk[nblk + rb] parents), tile_part_scan_kernel turns the counts into offsets, pass 1 cuts — a
+        // row whose range does not fit the scratch stays whole (its range and its spare slots stay spent, so that every later
+        // decision is the one pass 0 counted): which rows those are does not depend on the order the blocks ran in.
+        int spare = R - nrows, nu = 0, my_parts = 0, my_parents = 0;
+        const unsigned x_base = split && pass ? (unsigned)blk[rb] : 0u, p_base = split && pass ? (unsigned)blk[nblk + rb] : 0u;
         for (int rank = 0; rank < nrows; rank++) {
             const int L = sorted_len[rank], row = row0 + row_of_rank[rank];
             int lg2 = 0;
@@ -680,14 +685,19 @@ void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const i
             }
             int x0 = 0;
             if (lg2 > 0) {
-                const unsigned at = atomicAdd(&xstate[0], (unsigned)((1 << lg2) - 1));
-                const unsigned pa = atomicAdd(&xstate[1], 1u);
-                if (at + (1u << lg2) - 1u <= xcap && pa < pcap) {
+                const unsigned at = x_base + (unsigned)my_parts, pa = p_base + (unsigned)my_parents;
+                my_parts += (1 << lg2) - 1; my_parents++;
+                spare -= (1 << lg2) - 1;
+                if (!pass) lg2 = 0;
+                else if (at + (1u << lg2) - 1u <= xcap && pa < pcap) {
                     x0 = (int)at;
                     parents[pa].row = row; parents[pa].x0 = x0; parents[pa].parts = 1 << lg2;
-                    spare -= (1 << lg2) - 1;
-                } else lg2 = 0;                                       // (no room in Cx or in the list: the row stays whole; the counters only ever overshoot)
+                } else {
+                    if (pa < pcap) parents[pa].parts = 0;             // (tile_combine_kernel skips it)
+                    lg2 = 0;
+                }
             }
+            if (!pass) continue;
             const int P = 1 << lg2;
             for (int q = 0; q < P; q++) {
                 unit_rank[nu] = (short)rank;
@@ -696,6 +706,7 @@ void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const i
                 nu++;
             }
         }
+        if (!pass) { blk[rb] = my_parts; blk[nblk + rb] = my_parents; }
         n_units = nu;
         // visits (units 4v .. 4v + 3, cost = the longest of them), longest first, each to the SIMD with the least work so far that
         // still has a free visit slot, there to the wavefront with the most free slots
@@ -726,11 +737,43 @@ void tile_deal_rows_kernel(int m, int R, int nw, unsigned long long rgw, const i
         }
     }
     __syncthreads();
+    if (!pass) return;
     const int nu = n_units;
     for (int u = threadIdx.x; u < R; u += blockDim.x) {
         const size_t slot = (size_t)rb * R + visit_of[u / TL_NG] * TL_NG + u % TL_NG;
         perm[slot] = u < nu ? row0 + row_of_rank[unit_rank[u]] : m;
         if (split) split[slot] = u < nu ? unit_code[u] : 0;
+    }
+}
+
+// the blocks' part / parent counts (tile_deal_rows_kernel, pass 0) -> their offsets; the totals into xstate[0 .. 1]
+__global__ __launch_bounds__(1024)
+void tile_part_scan_kernel(int nblk, int32_t *__restrict__ blk, unsigned *__restrict__ xstate)
+{
+    __shared__ int scan[1024];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    for (int which = 0; which < 2; which++) {
+        int32_t *a = blk + (size_t)which * nblk;
+        if (tid == 0) carry = 0;
+        __syncthreads();
+        for (int k0 = 0; k0 < nblk; k0 += 1024) {
+            const int k = k0 + tid, v = k < nblk ? a[k] : 0;
+            scan[tid] = v;
+            __syncthreads();
+            for (int o = 1; o < 1024; o <<= 1) {
+                const int t = tid >= o ? scan[tid - o] : 0;
+                __syncthreads();
+                scan[tid] += t;
+                __syncthreads();
+            }
+            if (k < nblk) a[k] = carry + scan[tid] - v;
+            __syncthreads();
+            if (tid == 1023) carry += scan[1023];
+            __syncthreads();
+        }
+        if (tid == 0) xstate[which] = (unsigned)carry;
+        __syncthreads();
     }
 }
 
@@ -744,6 +787,7 @@ void tile_combine_kernel(int n, const unsigned *__restrict__ xstate, unsigned pc
     const int lane = lane_id();
     for (unsigned i = blockIdx.x * 4 + uniform(threadIdx.x / MX_WAVE); i < np; i += gridDim.x * 4) {
         const int row = uniform(parents[i].row), x0 = uniform(parents[i].x0), P = uniform(parents[i].parts);
+        if (P < 2) continue;
         for (int c = lane; c < n; c += MX_WAVE) {
             real_t *dst = colmajor ? C + (size_t)c * ldc + row : C + (size_t)row * ldc + c;
             real_t sum = *dst;
@@ -1005,7 +1049,9 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
                     if (colmajor && (t.R | 1) * 256 * gm.cpl > lds) continue;
                     if (!found || t.serial < best.serial) { best = t; found = true; }
                 }
-                if (found) { const int nrb0 = gm.nrb; gm = best; gm.nrb = nrb0; } else want_split = false;
+                // (no larger geometry — the block already has all the rows a lane group can hold: with <= 32,768 rows the one-pass
+                // blocks below still make room, a block takes fewer rows where parts want slots; otherwise every row stays whole)
+                if (found) { const int nrb0 = gm.nrb; gm = best; gm.nrb = nrb0; } else if (m > 32768) want_split = false;
             }
             // a block above E entries is cut into pieces of E_piece.  A product whose row blocks fill the machine in ONE round of
             // workgroups pays a whole second round for the first extra block (1e4 x 1e4, log-normal sigma 1.5: 60 -> 68 blocks x 4
@@ -1030,7 +1076,8 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
                                                                   ((long long)64 << 20) / ((long long)n * (long long)sizeof(real_t))) : 0;
                 const size_t par_b = ((size_t)pcap * sizeof(TileParent) + 255) & ~(size_t)255;
                 const size_t u_b = greedy ? (((size_t)m + 1) * sizeof(int32_t) + 255) & ~(size_t)255 : 0;
-                const size_t split_b = want_split ? perm_b + 256 + par_b + u_b : 0;
+                const size_t blk_b = want_split ? ((size_t)2 * max_blocks * sizeof(int32_t) + 255) & ~(size_t)255 : 0;
+                const size_t split_b = want_split ? perm_b + 256 + par_b + u_b + blk_b : 0;
                 char *buf = (char *)scratch_buffer(MX_SCRATCH_TILE_PERM, cuts_b + perm_b + split_b);
                 if (buf && want_split) {
                     Cx = (real_t *)scratch_buffer(MX_SCRATCH_TILE_X, (size_t)xcap * n * sizeof(real_t) + 256);
@@ -1061,7 +1108,6 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
                         // (the cut decisions need this call's sortedness flags: a row that is not sorted by column stays whole)
                         if (flags && want_split)
                             hipLaunchKernelGGL(tile_unsorted_rows_kernel, dim3((unsigned)ceil_div(m, 8)), dim3(512), 0, stream, m, indptr, indices, flags);
-                        if (want_split) MX_HIP(hipMemsetAsync(xstate, 0, 16, stream));
                         if (greedy) {
                             // weights: entries + w_row per row; one round of workgroups when the rows allow it (1.1, then 1.3 mean weights)
                             const char *we = getenv("MXGPU_TILE_WROW"), *e2 = getenv("MXGPU_TILE_E2");   // (experiments)
@@ -1076,8 +1122,15 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
                         }
                         else
                             hipLaunchKernelGGL(tile_cuts_kernel, dim3(1), dim3(1024), 0, stream, m, Rrows, indptr, E, E_piece, cuts, max_blocks);
+                        int32_t *blk = want_split ? (int32_t *)(buf + cuts_b + 2 * perm_b + 256 + par_b + u_b) : nullptr;
+                        if (want_split) {                                // the parts' places in block order: count, scan, then cut
+                            MX_HIP(hipMemsetAsync(blk, 0, (size_t)2 * max_blocks * sizeof(int32_t), stream));
+                            hipLaunchKernelGGL(tile_deal_rows_kernel, dim3((unsigned)max_blocks), dim3(256), 0, stream, m, gm.R, gm.nw, gm.rgw, indptr, cuts, perm,
+                                               split, part_len, (const unsigned char *)flags, 0, blk, max_blocks, xcap, parents, pcap);
+                            hipLaunchKernelGGL(tile_part_scan_kernel, dim3(1), dim3(1024), 0, stream, max_blocks, blk, xstate);
+                        }
                         hipLaunchKernelGGL(tile_deal_rows_kernel, dim3((unsigned)max_blocks), dim3(256), 0, stream, m, gm.R, gm.nw, gm.rgw, indptr, cuts, perm,
-                                           split, part_len, (const unsigned char *)flags, xstate, xcap, parents, pcap);
+                                           split, part_len, (const unsigned char *)flags, 1, blk, max_blocks, xcap, parents, pcap);
                     }
                 } else { (void)hipGetLastError(); Cx = nullptr; }        // (no memory for the map: consecutive rows)
             }

@@ -277,3 +277,24 @@ def test_tile_long_rows_cut_into_parts(gpu, monkeypatch, colmajor, dtype):
         assert np.array_equal(D.spmm(A, Bd, colmajor=colmajor, algo=TILE).cpu().numpy(), a)
         if m >= 64:
             assert not np.array_equal(a, ref), "no row was cut: the test did not reach the parts"
+
+
+def test_tile_parts_beyond_the_scratch_stay_whole(gpu, monkeypatch):
+    """The parts' partial sums live in a scratch matrix of at most 64 MiB: a matrix that wants more parts than it has rows keeps
+    the rest of its long rows whole (tile_deal_rows_kernel hands the rows out with one atomic: a refused row has spent a slot of
+    the parents' list, which tile_combine_kernel must skip — round 6's fuzz run with tiny parts found it reading that slot).
+    20,000 rows of 100 entries, parts of 8 entries (MXGPU_TILE_PART=1): 140,000 parts wanted, 65,536 rows of scratch at n = 128."""
+    rng = np.random.default_rng(5)
+    m, K, n = 20000, 2000, 128
+    lens = np.full(m, 100, dtype=np.int64)
+    p = np.zeros(m + 1, dtype=np.int32); p[1:] = np.cumsum(lens)
+    j = np.sort(rng.integers(0, K, size=(m, 100)), axis=1).astype(np.int32).ravel()
+    x = rng.uniform(-1, 1, size=j.size)
+    B = rng.normal(size=(K, n))
+    ref = _oracle(p, j, x, B)
+    monkeypatch.setenv("MXGPU_TILE_DEAL", "1"); monkeypatch.setenv("MXGPU_TILE_SPLIT", "1"); monkeypatch.setenv("MXGPU_TILE_PART", "1")
+    for colmajor in (False, True):
+        got = _run(p, j, x, B, colmajor, rows_sorted=True)
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+        assert not np.array_equal(got, ref)                          # (parts were cut)
+        assert np.array_equal(got, _run(p, j, x, B, colmajor, rows_sorted=True))

@@ -16,7 +16,7 @@ from cliff_hunt import build, lens_of
 
 lib = _lib.load()
 out = []
-shapes = [(10_000, 10_000, 500, 100), (30_000, 5_000, 300, 64), (4_000, 50_000, 2_000, 128)]
+shapes = [(10_000, 10_000, 500, 100), (30_000, 5_000, 300, 64), (4_000, 50_000, 2_000, 128), (20_000, 20_000, 300, 128), (30_000, 30_000, 200, 64)]
 if os.environ.get("PROBE_PICK"):
     shapes = [shapes[int(i)] for i in os.environ["PROBE_PICK"].split(",")]
 if os.environ.get("PROBE_SHAPES"):

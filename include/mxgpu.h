@@ -425,6 +425,9 @@ int mxd_debug_spmv_tile_stamps(void *stamps_dev);
 int mxd_debug_rowsplit_long_rows(long long *rows, long long *pieces);   /* last row-split product of this thread: rows / pieces
                                                                            handed to the long-rows path (0 / 0 = off); syncs */
 int mxd_debug_spmm_tile_stamps(void *stamps_dev);
+/* how the process's last LDS-tile product laid out its rows: 0 = consecutive rows, 1 = dealt to the lane groups by length,
+ * | 2 = long rows cut into parts (those rows' sums regrouped), | 4 = row blocks made in one pass (csrc/spmm_tile.hip) */
+int mxd_debug_spmm_tile_mode(void);
 /* what the fit check found before that product: the rows longer than the piece, their pieces, and whether they fitted the
  * scratch sized from the profile's hint (fit 0: the product kernels summed them in line — slower, same answers); syncs */
 int mxd_debug_rowsplit_long_fit(long long *rows_needed, long long *pieces_needed, int *fit);

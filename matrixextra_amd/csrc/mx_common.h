@@ -61,7 +61,8 @@ int host_signal_wait(const HostSignal &s, unsigned *value, hipStream_t st);
 // pipeline or the device list cut the product.  The counts only size the scratch: a kernel checks on the device that the
 // launch's long rows fit (longrows_fit_kernel) and leaves them to the product kernels when they do not.
 struct LongHint { int piece = 0; long long rows = -1, pieces = -1; };
-struct SpmmFamily { int family = 0, segments = 0, panels = 0; LongHint lh = {-1, -1, -1}; };
+// tile_cv: the row-length cv of the WHOLE product's matrix (0: unknown) — the tile kernel deals a block's rows by length from it
+struct SpmmFamily { int family = 0, segments = 0, panels = 0; LongHint lh = {-1, -1, -1}; float tile_cv = 0.0f; };
 inline int canonical_long_piece(double mean_row)         // ~6 mean rows per piece, a power of two in [128, 1024]
 {
     int piece = 128;

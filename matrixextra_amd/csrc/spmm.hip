@@ -219,6 +219,7 @@ SpmmFamily spmm_auto_family(int m, int n, int K, int64_t nnz, int dense_dtype, c
     // (the caller's profile is in scope here, not in the blocks — and a PLANNED family whose plan is left for its imbalance
     // falls back to the row-split kernel in spmm_block: exactly the products with very long rows)
     f.lh = nnz > 0 && m > 0 ? rowsplit_long_hint(m, nnz) : LongHint();
+    f.tile_cv = (float)profile_cv();
     if (f.family == MX_SPMM_ROWSPLIT && nnz >= 0 && m > 0) {
         const int sz = dense_dtype == MX_F64 ? 8 : 4;
         const double avg = (double)nnz / m;
@@ -272,8 +273,10 @@ int spmm_block(const SpmmFamily &fam, bool from_auto, int m, int n, int K, int64
     if (family == MX_SPMM_ROWSPLIT)
         return run_rowsplit(m, n, K, nnz, from_auto ? fam.segments : 0, from_auto ? fam.panels : npanels, 0, indptr, indices, values,
                             B, ldb, C, ldc, dense_dtype, colmajor, st, from_auto ? fam.lh : LongHint{-1, -1, -1});
-    if (family == MX_SPMM_TILE && from_auto)
+    if (family == MX_SPMM_TILE && from_auto) {
+        TileDealScope deal(fam.tile_cv);
         return mxd_spmm_csr_dense_ex2(m, n, K, nnz, indptr, indices, values, B, ldb, C, ldc, dense_dtype, colmajor, family, 0, 0, 0, st);
+    }
     if (family == MX_SPMM_PLANNED && from_auto) {
         const bool ok = dense_dtype == MX_F64 ? slab_ok<double>(n, (const double *)B, ldb, (const double *)C, ldc, colmajor)
                                               : slab_ok<float>(n, (const float *)B, ldb, (const float *)C, ldc, colmajor);

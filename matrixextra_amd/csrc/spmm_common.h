@@ -100,6 +100,10 @@ double profile_cv();
 double profile_longest_over_mean();                       // 0 without a profile in scope
 bool profile_long_rows(double *entries, double *rows);    // [35], [36]: entries / number of the rows longer than canonical_long_piece(mean)
 bool profile_in_scope();
+// The tile kernel's row dealing for a block of a product whose family was chosen for the whole product (the export pipelines, whose
+// workers have no profile in scope): cv by value.  Under such a hint long rows are never cut into parts — a block's geometry,
+// and with it the part length, depends on the block: the exports keep the storage-order bits whatever the device list.
+struct TileDealScope { float saved; explicit TileDealScope(float cv); ~TileDealScope(); };
 const float *uniform_profile();
 inline double lockstep_factor(double cv, int rows_together)
 {

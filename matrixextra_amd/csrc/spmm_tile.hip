@@ -797,6 +797,8 @@ void tile_combine_kernel(int n, const unsigned *__restrict__ xstate, unsigned pc
     }
 }
 
+static thread_local float g_tile_deal_hint = -1.0f;    // TileDealScope: >= 0 = the cv to deal by, no parts
+static int g_tile_last_mode = 0;                       // diagnostic (mxd_debug_spmm_tile_mode; the last product of ANY thread): 1 dealt | 2 parts | 4 one-pass blocks
 static unsigned long long *g_tile_stamps = nullptr;   // diagnostic (tools/tile_stamps.py): per wavefront, cycles at the tile barriers / in all
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1028,7 +1030,9 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
     {
         const char *de = getenv("MXGPU_TILE_DEAL");                      // (read per call: the tests and the A/B runs switch it)
         const int deal_env = de ? atoi(de) : -1;
-        const bool deal = deal_env >= 0 ? deal_env != 0 : profile_cv() > 0.15;
+        const bool hinted = g_tile_deal_hint >= 0.0f;
+        const bool deal = deal_env >= 0 ? deal_env != 0 : (hinted ? g_tile_deal_hint : profile_cv()) > 0.15;
+        g_tile_last_mode = 0;
         if (deal && nnz > 0 && gm.R <= TL_MAX_WAVES * TL_NG * 5) {
             const int Rrows = gm.R;                                      // rows of a base block (the slots may be more, below)
             const int tile_rows = (small_tile ? 32768 : 65536) / (256 * gm.cpl), ntiles = (int)ceil_div(K, tile_rows);
@@ -1036,7 +1040,7 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
             const int part_len = (pe && atoi(pe) > 0 ? atoi(pe) : 40) * ntiles;
             const char *se = getenv("MXGPU_TILE_SPLIT");
             bool want_split = se ? atoi(se) != 0 : profile_longest_over_mean() * ((double)nnz / (double)m) >= 2.5 * part_len;
-            if (m >= (1 << 29)) want_split = false;                     // (the kernel keeps a part's stride in the row number's top bits)
+            if (m >= (1 << 29) || (hinted && !se)) want_split = false;                     // (the kernel keeps a part's stride in the row number's top bits)
             if (want_split) {
                 // a third more slots than rows: one more row per lane group where the registers allow it
                 const int gr2 = Rrows / TL_NG + (Rrows / TL_NG + 2) / 3, rgmax = gm.cpl == 1 ? 5 : 4;
@@ -1104,6 +1108,7 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
                         parents = (TileParent *)(buf + cuts_b + 2 * perm_b + 256);
                     }
                     gm.nrb = max_blocks;
+                    g_tile_last_mode = 1 | (want_split ? 2 : 0) | (greedy ? 4 : 0);
                     if (build_map) {
                         // (the cut decisions need this call's sortedness flags: a row that is not sorted by column stays whole)
                         if (flags && want_split)
@@ -1159,7 +1164,14 @@ template int tile_spmm<double>(int, int, int, int64_t, int, int, int, const int3
 template int tile_spmm<float>(int, int, int, int64_t, int, int, int, const int32_t *, const int32_t *, const double *, const float *, size_t,
                               float *, size_t, int, hipStream_t);
 
+TileDealScope::TileDealScope(float cv) : saved(g_tile_deal_hint) { g_tile_deal_hint = cv; }
+TileDealScope::~TileDealScope() { g_tile_deal_hint = saved; }
+
 }  // namespace mx
+
+// diagnostic: how the process's last tile product laid out its rows — 0 consecutive rows, 1 dealt by length, | 2 long rows cut
+// into parts, | 4 row blocks made in one pass
+extern "C" int mxd_debug_spmm_tile_mode(void) { return mx::g_tile_last_mode; }
 
 // diagnostic: a device buffer of 2 x 16 x (workgroups) uint64 makes the tile kernel record, per compute wavefront, the shader
 // clock cycles it spent at the tile barriers and in its sweep; NULL switches back

@@ -257,6 +257,32 @@ def test_sharded_export_bits_do_not_depend_on_the_device_list(gpu):
         np.testing.assert_allclose(outs[3][r], want, rtol=2e-5, atol=2e-5 * np.abs(want).max())
 
 
+def test_export_of_a_dense_ish_matrix_with_uneven_rows_deals_its_rows(gpu):
+    """Round 6: the tile kernel's rows dealt by length reach the exports — a result below 64 MiB is ONE device-level product with
+    AUTO inside and no matrix profile: the cv comes from the caller's row pointers (csrc/api_core.inc host_row_cv); the
+    pipelined / sharded exports carry the cv of the whole product's matrix in the family chosen for it —, and the exports never
+    cut a long row into parts: bit for bit the reference's storage-order chain (src/matmul.cpp:150-185), as before."""
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    m, K, n = 10_000, 10_000, 100
+    lens = np.minimum(np.floor(rng.lognormal(np.log(500) - 0.72, 1.2, size=m)), K).astype(np.int64)
+    lens[17] = K                                                     # one full row: several windows per tile
+    row = np.repeat(np.arange(m, dtype=np.int64), lens)
+    key = np.unique(row * K + rng.integers(0, K, size=row.size))
+    row = key // K
+    j = (key - row * K).astype(np.int32)
+    p = np.zeros(m + 1, dtype=np.int64); np.cumsum(np.bincount(row, minlength=m), out=p[1:])
+    p = p.astype(np.int32)
+    x = rng.uniform(-1, 1, size=j.size)
+    B = synth.dense_normal(K, n, dtype=np.float64)
+    Y = np.asfortranarray(B.T)
+    got = G.tcrossprod_csr_dense_numeric(p, j, x, Y, 1)
+    assert lib.mxd_spmm_last_kernel().decode() == "spmm_tile_kernel"
+    assert lib.mxd_debug_spmm_tile_mode() == 1                       # dealt by length, no row cut into parts
+    ref = O.tcrossprod_csr_dense(p, j, x, Y, 1, True)
+    assert np.array_equal(got, ref)
+
+
 def _option(lib, name):
     v = C.c_int64(0)
     _lib.check(lib.mx_get_option(name.encode(), C.byref(v)))

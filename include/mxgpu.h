@@ -263,7 +263,11 @@ int mxd_spmm_csr_dense(int m, int n,
  *                          brought into LDS by loader wavefronts with LDS-DMA (global_load_lds_dwordx4) while the compute
  *                          wavefronts sum their rows from the previous tile — B leaves L2 once per row block, not once per
  *                          entry.  A row is summed by one 16-lane group in storage order: bit for bit the reference's FMA chain
- *                          in BOTH layouts of C.  Needs 16-byte aligned rows of B (n a multiple of 2 / 4) and rows sorted by
+ *                          in BOTH layouts of C — with ONE exception (round 6): under a matrix profile (_ex3) that shows
+ *                          rows several 32-entry windows per tile long, THOSE rows are cut into 2 / 4 / 8 interleaved parts,
+ *                          summed side by side and added in order: the same bits on every run, the chain regrouped (1e-14
+ *                          in f64); every other row keeps its bits; MXGPU_TILE_SPLIT=0 switches it off, the exports never
+ *                          do it.  Rows of uneven length are dealt to the lane groups by length (same bits).  Needs 16-byte aligned rows of B (n a multiple of 2 / 4) and rows sorted by
  *                          column for the LDS sweep: rows_sorted = 1 = the caller vouches for it; otherwise a sortedness pass
  *                          flags every row (one read of the indices) and a row that is not sorted is summed whole from global
  *                          memory — always correct.  wg_per_cu = cpl + 4 * rg + 32 * small (cpl: 1 = 256-byte slabs, 2 = 512;

@@ -34,6 +34,7 @@
 // tile barrier — the steps executed are 1.5x the useful ones (four groups in lockstep, batches of four, the 4-column last
 // slab of n = 100).  `lds_read` in bench.py: nnz x slabs x 256 B per launch.
 #include "spmm_common.h"
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -798,7 +799,7 @@ void tile_combine_kernel(int n, const unsigned *__restrict__ xstate, unsigned pc
 }
 
 static thread_local float g_tile_deal_hint = -1.0f;    // TileDealScope: >= 0 = the cv to deal by, no parts
-static int g_tile_last_mode = 0;                       // diagnostic (mxd_debug_spmm_tile_mode; the last product of ANY thread): 1 dealt | 2 parts | 4 one-pass blocks
+static std::atomic<int> g_tile_last_mode{0};                     // diagnostic (mxd_debug_spmm_tile_mode; the last product of ANY thread): 1 dealt | 2 parts | 4 one-pass blocks
 static unsigned long long *g_tile_stamps = nullptr;   // diagnostic (tools/tile_stamps.py): per wavefront, cycles at the tile barriers / in all
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1066,11 +1067,17 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
             const long long E = std::max<long long>(1024, one_round ? 2 * mean_block : mean_block + mean_block / 4);
             const long long E_piece = std::max<long long>(1024, mean_block + mean_block / 4);
             // with spare slots (the cut rows' geometry) and <= 32,768 rows: blocks by units and entries in one pass (tile_cuts_greedy_kernel)
+            // — also without cut rows when the launch is several rounds of workgroups anyway (rows sorted by length, 30,000 x 30,000,
+            // 200 per row, n = 64: 0.72 -> 0.41 ms f64, 0.37 -> 0.25 f32; 20,000 x 20,000: 0.57 -> 0.49); a launch of ONE round keeps
+            // tile_cuts_kernel's blocks there (1e4 x 1e4: 0.195 -> 0.226 with the one-pass blocks, 30,000 x 5,000: 0.156 -> 0.215: a
+            // block cannot hold more rows than the geometry has slots, so the light blocks cannot grow and the heavy ones only add
+            // workgroups).  MXGPU_TILE_GREEDY: 0 never, 1 only with cut rows, 2 whenever the rows are dealt.
             const char *ge = getenv("MXGPU_TILE_GREEDY");
-            const bool greedy = want_split && m <= 32768 && (ge ? atoi(ge) != 0 : true);
+            const int gmode = ge ? atoi(ge) : -1;
+            const bool greedy = m <= 32768 && (gmode < 0 ? (want_split || !one_round) : (gmode >= 2 || (gmode == 1 && want_split)));
             long long bound = (long long)ceil_div(m, Rrows) + nnz / E_piece + 1;
             // (two consecutive blocks of the walk overflow the slots or the weight limit, which is >= 1.1 mean weights of Rrows rows)
-            if (greedy) bound = 2 * ((long long)ceil_div((long long)m + 2 * (long long)nnz / part_len, gm.R) + std::max<long long>(ceil_div(m, Rrows), one_round ? 256 / gm.nslabs : 0)) + 2;
+            if (greedy) bound = 2 * ((long long)ceil_div((long long)m + (want_split ? 2 * (long long)nnz / part_len : 0), gm.R) + std::max<long long>(ceil_div(m, Rrows), one_round ? 256 / gm.nslabs : 0)) + 2;
             if (bound * gm.nslabs < (1LL << 30)) {
                 const int max_blocks = (int)std::min<long long>(bound, m);
                 const size_t cuts_b = (((size_t)max_blocks + 2) * sizeof(int32_t) + 255) & ~(size_t)255;
@@ -1081,8 +1088,8 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
                 const size_t par_b = ((size_t)pcap * sizeof(TileParent) + 255) & ~(size_t)255;
                 const size_t u_b = greedy ? (((size_t)m + 1) * sizeof(int32_t) + 255) & ~(size_t)255 : 0;
                 const size_t blk_b = want_split ? ((size_t)2 * max_blocks * sizeof(int32_t) + 255) & ~(size_t)255 : 0;
-                const size_t split_b = want_split ? perm_b + 256 + par_b + u_b + blk_b : 0;
-                char *buf = (char *)scratch_buffer(MX_SCRATCH_TILE_PERM, cuts_b + perm_b + split_b);
+                const size_t split_b = want_split ? perm_b + 256 + par_b + blk_b : 0;      // split | xstate | parents | blk, then U
+                char *buf = (char *)scratch_buffer(MX_SCRATCH_TILE_PERM, cuts_b + perm_b + split_b + u_b);
                 if (buf && want_split) {
                     Cx = (real_t *)scratch_buffer(MX_SCRATCH_TILE_X, (size_t)xcap * n * sizeof(real_t) + 256);
                     if (!Cx) { (void)hipGetLastError(); buf = nullptr; }   // (no memory for the parts' rows: consecutive rows, whole)
@@ -1095,7 +1102,7 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
                     Key now;
                     memset(&now, 0, sizeof(now));
                     now.indptr = indptr; now.buf = buf; now.cx = Cx; now.nnz = (long long)nnz; now.rgw = gm.rgw; now.m = m; now.R = gm.R; now.Rrows = Rrows;
-                    now.nw = gm.nw; now.nl = gm.nl; now.max_blocks = max_blocks; now.n = want_split ? n : 0; now.part_len = want_split ? part_len : 0;
+                    now.nw = gm.nw; now.nl = gm.nl | (greedy ? 256 : 0); now.max_blocks = max_blocks; now.n = want_split ? n : 0; now.part_len = want_split ? part_len : 0;
                     now.gen = scratch_generation(MX_SCRATCH_TILE_PERM); now.genx = want_split ? scratch_generation(MX_SCRATCH_TILE_X) : 0;
                     build_map = memcmp(&kept[dev], &now, sizeof(Key)) != 0;
                     kept[dev] = now;
@@ -1121,13 +1128,14 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
                             const double w_total = (double)nnz + (double)m * w_row;
                             const int nb1 = 256 / gm.nslabs;
                             const double w_block = one_round ? w_total / nb1 : ((double)mean_block + (double)Rrows * w_row) * 1.14;
-                            hipLaunchKernelGGL(tile_cuts_greedy_kernel, dim3(1), dim3(1024), 0, stream, m, gm.R, indptr, (const unsigned char *)flags, part_len,
+                            hipLaunchKernelGGL(tile_cuts_greedy_kernel, dim3(1), dim3(1024), 0, stream, m, gm.R, indptr, (const unsigned char *)(want_split ? flags : nullptr),
+                                               want_split ? part_len : 0,
                                                w_row, (long long)(1.1 * w_block) + 1024, (long long)(f2 * w_block) + 1024, one_round ? nb1 : 0,
-                                               (int32_t *)(buf + cuts_b + 2 * perm_b + 256 + par_b), cuts, max_blocks);
+                                               (int32_t *)(buf + cuts_b + perm_b + split_b), cuts, max_blocks);
                         }
                         else
                             hipLaunchKernelGGL(tile_cuts_kernel, dim3(1), dim3(1024), 0, stream, m, Rrows, indptr, E, E_piece, cuts, max_blocks);
-                        int32_t *blk = want_split ? (int32_t *)(buf + cuts_b + 2 * perm_b + 256 + par_b + u_b) : nullptr;
+                        int32_t *blk = want_split ? (int32_t *)(buf + cuts_b + 2 * perm_b + 256 + par_b) : nullptr;
                         if (want_split) {                                // the parts' places in block order: count, scan, then cut
                             MX_HIP(hipMemsetAsync(blk, 0, (size_t)2 * max_blocks * sizeof(int32_t), stream));
                             hipLaunchKernelGGL(tile_deal_rows_kernel, dim3((unsigned)max_blocks), dim3(256), 0, stream, m, gm.R, gm.nw, gm.rgw, indptr, cuts, perm,
@@ -1171,7 +1179,7 @@ TileDealScope::~TileDealScope() { g_tile_deal_hint = saved; }
 
 // diagnostic: how the process's last tile product laid out its rows — 0 consecutive rows, 1 dealt by length, | 2 long rows cut
 // into parts, | 4 row blocks made in one pass
-extern "C" int mxd_debug_spmm_tile_mode(void) { return mx::g_tile_last_mode; }
+extern "C" int mxd_debug_spmm_tile_mode(void) { return mx::g_tile_last_mode.load(std::memory_order_relaxed); }
 
 // diagnostic: a device buffer of 2 x 16 x (workgroups) uint64 makes the tile kernel record, per compute wavefront, the shader
 // clock cycles it spent at the tile barriers and in its sweep; NULL switches back

@@ -206,10 +206,13 @@ def test_tile_rows_dealt_by_length_keep_every_bit(gpu, monkeypatch, colmajor, dt
         monkeypatch.setenv("MXGPU_TILE_SPLIT", "0")                  # (long rows cut into parts: the next test)
         for deal in ("1", "0"):
             monkeypatch.setenv("MXGPU_TILE_DEAL", deal)
-            for var, nw in ((0, 0), (variant(1, 3), 5), (variant(2, 2), 14)):
-                got = _run(p, j, x, B, colmajor, var, nw, rows_sorted=False)
-                _same(got, ref)
+            for greedy in (("2", "0") if deal == "1" else ("0",)):    # row blocks in one pass (by units and weight) / cut every R rows
+                monkeypatch.setenv("MXGPU_TILE_GREEDY", greedy)
+                for var, nw in ((0, 0), (variant(1, 3), 5), (variant(2, 2), 14)):
+                    got = _run(p, j, x, B, colmajor, var, nw, rows_sorted=False)
+                    _same(got, ref)
             outs.append(got)
+        monkeypatch.delenv("MXGPU_TILE_GREEDY")
         assert np.array_equal(outs[0], outs[1])
         monkeypatch.delenv("MXGPU_TILE_DEAL")
         # through the device layer with the matrix profile in scope (cv ~ 2: dealt) — the same bits again

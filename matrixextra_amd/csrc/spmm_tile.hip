@@ -1040,7 +1040,13 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
             const char *pe = getenv("MXGPU_TILE_PART");                    // (entries per tile and part; experiments)
             const int part_len = (pe && atoi(pe) > 0 ? atoi(pe) : 40) * ntiles;
             const char *se = getenv("MXGPU_TILE_SPLIT");
-            bool want_split = se ? atoi(se) != 0 : profile_longest_over_mean() * ((double)nnz / (double)m) >= 2.5 * part_len;
+            // (the longest row at least 2.5 parts long; 2 parts for row-major C when a row has few entries per tile — tools/tile_split_probe.py,
+            // 20,000 x 20,000, 300 per row, f64, longest row 2 parts: row-major 0.50 -> 0.41 / 0.50 -> 0.34, column-major, whose cut-row
+            // instances are the ones short of registers, 0.50 -> 0.54 / 0.51 -> 0.50; with 7 entries per tile — 30,000 x 5,000, rows
+            // sorted by length — cutting at 2 parts cost 0.157 -> 0.195)
+            const double per_tile = (double)nnz / (double)m / (double)ntiles;
+            bool want_split = se ? atoi(se) != 0
+                                 : profile_longest_over_mean() * ((double)nnz / (double)m) >= (!colmajor && per_tile < 3.0 ? 2.0 : 2.5) * part_len;
             if (m >= (1 << 29) || (hinted && !se)) want_split = false;                     // (the kernel keeps a part's stride in the row number's top bits)
             if (want_split) {
                 // a third more slots than rows: one more row per lane group where the registers allow it
@@ -1067,14 +1073,15 @@ int tile_spmm(int m, int n, int K, int64_t nnz, int variant, int nw, int rows_so
             const long long E = std::max<long long>(1024, one_round ? 2 * mean_block : mean_block + mean_block / 4);
             const long long E_piece = std::max<long long>(1024, mean_block + mean_block / 4);
             // with spare slots (the cut rows' geometry) and <= 32,768 rows: blocks by units and entries in one pass (tile_cuts_greedy_kernel)
-            // — also without cut rows when the launch is several rounds of workgroups anyway (rows sorted by length, 30,000 x 30,000,
-            // 200 per row, n = 64: 0.72 -> 0.41 ms f64, 0.37 -> 0.25 f32; 20,000 x 20,000: 0.57 -> 0.49); a launch of ONE round keeps
-            // tile_cuts_kernel's blocks there (1e4 x 1e4: 0.195 -> 0.226 with the one-pass blocks, 30,000 x 5,000: 0.156 -> 0.215: a
-            // block cannot hold more rows than the geometry has slots, so the light blocks cannot grow and the heavy ones only add
-            // workgroups).  MXGPU_TILE_GREEDY: 0 never, 1 only with cut rows, 2 whenever the rows are dealt.
+            // — also without cut rows when a row has few entries per tile (< 3 on average): a slot then costs its visit more than its
+            // entries, and tile_cuts_kernel's blocks of equal ENTRIES are the wrong balance (rows sorted by length, 30,000 x 30,000,
+            // 200 per row, n = 64: 0.72 -> 0.41 ms f64, 0.37 -> 0.25 f32; 20,000 x 20,000, 300 per row, f64: 0.57 -> 0.49).  With more
+            // entries per tile the entry-balanced blocks stay (1e4 x 1e4, 500 per row — 6 per tile: 0.195 -> 0.226 with the one-pass
+            // blocks; 30,000 x 5,000, 300 per row: 0.156 -> 0.215).  MXGPU_TILE_GREEDY: 0 never, 1 only with cut rows, 2 whenever the
+            // rows are dealt.
             const char *ge = getenv("MXGPU_TILE_GREEDY");
             const int gmode = ge ? atoi(ge) : -1;
-            const bool greedy = m <= 32768 && (gmode < 0 ? (want_split || !one_round) : (gmode >= 2 || (gmode == 1 && want_split)));
+            const bool greedy = m <= 32768 && (gmode < 0 ? (want_split || per_tile < 3.0) : (gmode >= 2 || (gmode == 1 && want_split)));
             long long bound = (long long)ceil_div(m, Rrows) + nnz / E_piece + 1;
             // (two consecutive blocks of the walk overflow the slots or the weight limit, which is >= 1.1 mean weights of Rrows rows)
             if (greedy) bound = 2 * ((long long)ceil_div((long long)m + (want_split ? 2 * (long long)nnz / part_len : 0), gm.R) + std::max<long long>(ceil_div(m, Rrows), one_round ? 256 / gm.nslabs : 0)) + 2;

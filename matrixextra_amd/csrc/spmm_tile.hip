@@ -33,6 +33,16 @@
 // profiles/r05_vignette_extras_pmc.json): LDS 40 % busy (no bank conflicts), VALU 54 %, waves a quarter of their cycles at the
 // tile barrier — the steps executed are 1.5x the useful ones (four groups in lockstep, batches of four, the 4-column last
 // slab of n = 100).  `lds_read` in bench.py: nnz x slabs x 256 B per launch.
+//
+// Rows of uneven length (round 6; the kernels behind tile_spmm's map, built once per matrix and geometry and kept):
+//   tile_cuts_kernel / tile_cuts_greedy_kernel  row blocks of about equal entries (every R rows, heavy ones cut further) / of
+//                                               about equal weight in one pass over the rows (units = rows + parts <= the slots);
+//   tile_deal_rows_kernel                       a block's rows ranked by length and dealt to the lane groups (four rows of nearly
+//                                               one length per visit, visits to the least-loaded SIMD); with a matrix profile
+//                                               that shows rows several windows per tile long: those rows cut into 2 / 4 / 8
+//                                               interleaved parts on slots of their own (count pass, tile_part_scan_kernel, cut pass);
+//   tile_combine_kernel                         adds a cut row's parts in order.
+// Dealt rows keep every bit; a cut row is the chain regrouped (device-level callers with a profile only, never the exports).
 #include "spmm_common.h"
 #include <atomic>
 #include <algorithm>
